@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz by EXECUTING the unmodified reference
+modules (read from /root/reference, build container only) on torch-CPU.
+
+The reference's third-party imports (SI_Toolkit, watchdog, Control_Toolkit_ASF) are not vendored
+with it; `tests/golden/standins/` supplies build-authored, test-only stand-ins (see its README).
+What the fixtures therefore pin is the logic that IS in the reference:
+  others/Interpolator.py, Cost_Functions/__init__.py (aggregation), Optimizers/optimizer_mppi.py,
+  Optimizers/optimizer_rpgd.py (ADAM torch branch + RPGD step), others/globals_and_utils.py
+  (create_rng / torch_gen_like_TF), Controllers/controller_mpc.py + Controllers/__init__.py
+  (construction order and step plumbing).
+What they do NOT pin (build-defined, "parity unpinned"): the predictor, the concrete cost terms,
+CEM and random-action (their modules import tensorflow at module level).
+
+Usage (build container only):  python tests/golden/make_golden.py
+Neither this script nor the stand-ins run on the GPU box; only the .npz outputs travel.
+"""
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = "/root/reference"
+sys.path.insert(0, REPO)
+
+from oracle import ctk_oracle as O  # noqa: E402  (only for EnvParams/derived constants + plant step)
+
+
+class RecordingRng:
+    """Observer around the reference's generator (globals_and_utils.py:61-83): calls it exactly as
+    the optimizer does and additionally recovers the raw N(0,1) / U[0,1) draws from a snapshot of
+    the generator state, asserting that the reference's scaling of them gives its output."""
+
+    def __init__(self, gen):
+        self.gen = gen
+        self.raw = []
+
+    def _snapshot(self):
+        g = torch.Generator()
+        g.set_state(self.gen.rng.get_state())
+        return g
+
+    def normal(self, shape, dtype, mean=0.0, stddev=1.0):
+        g = self._snapshot()
+        out = self.gen.normal(shape, dtype=dtype, mean=mean, stddev=stddev)
+        raw = torch.normal(mean=0.0, std=1.0, size=shape, generator=g, dtype=dtype)
+        assert torch.equal(raw * stddev + mean, out) or torch.allclose(raw * stddev + mean, out, rtol=0, atol=0)
+        self.raw.append(raw.numpy().copy())
+        return out
+
+    def uniform(self, shape, dtype, minval=0.0, maxval=1.0):
+        g = self._snapshot()
+        out = self.gen.uniform(shape, dtype=dtype, minval=minval, maxval=maxval)
+        raw = torch.rand(*shape, generator=g, dtype=dtype)
+        assert torch.equal(raw * (maxval - minval) + minval, out)
+        self.raw.append(raw.numpy().copy())
+        return out
+
+
+def setup_workdir():
+    work = tempfile.mkdtemp(prefix="ctk_golden_")
+    shutil.copytree(os.path.join(HERE, "standins", "asf_template", "Control_Toolkit_ASF"),
+                    os.path.join(work, "Control_Toolkit_ASF"))
+    os.symlink(REFERENCE, os.path.join(work, "Control_Toolkit"))
+    os.chdir(work)
+    sys.path.insert(0, work)
+    sys.path.insert(0, os.path.join(HERE, "standins"))
+    sys.dont_write_bytecode = True
+    return work
+
+
+def inject_constants(env: O.EnvParams, dt: float, mlp_weights):
+    import SI_Toolkit.Predictors.predictor_wrapper as pw
+    import Control_Toolkit_ASF.Cost_Functions.CartPole.default as cf
+    k = {kk: float(v) for kk, v in O.derived_constants(env, dt, 1).items()}
+    # fp32 scalars as python floats: torch multiplies them in fp32 with fp32 tensors
+    pw.CONSTANTS.clear(); pw.CONSTANTS.update(k)
+    pw.MLP_WEIGHTS = tuple(torch.tensor(a) for a in O.mlp_unpack(mlp_weights))
+    cf.CONSTANTS.clear(); cf.CONSTANTS.update(k)
+    for name in ("target_position", "dd_weight", "ekp_weight", "ccrc_weight", "terminal_weight"):
+        cf.CONSTANTS[name] = float(np.float32(getattr(env, name)))
+
+
+def plant_step(pred: O.Predictor, s, u):
+    return pred.step(np.asarray(s, np.float32).reshape(1, 4), np.asarray(u, np.float32).reshape(1))[0]
+
+
+def initial_state(seed):
+    rng = np.random.default_rng(seed)   # SURVEY 8d common synthetic inputs
+    return np.array([rng.uniform(-0.2, 0.2), rng.uniform(-0.5, 0.5), rng.uniform(-np.pi, np.pi),
+                     rng.uniform(-2, 2)], dtype=np.float32)
+
+
+def main():
+    out_dir = HERE
+    setup_workdir()
+    env = O.EnvParams(terminal_weight=0.5)
+    dt = 0.02
+    mlp_w = O.mlp_default_weights(0)
+    inject_constants(env, dt, mlp_w)
+
+    from SI_Toolkit.computation_library import PyTorchLibrary
+    from Control_Toolkit.others.Interpolator import Interpolator
+    from Control_Toolkit.others.globals_and_utils import create_rng
+    import Control_Toolkit.Controllers.controller_mpc as cm
+    from Control_Toolkit.Optimizers.optimizer_rpgd import ADAM
+    from Control_Toolkit_ASF.Cost_Functions.CartPole.default import default as CostClass
+
+    lib = PyTorchLibrary()
+    env_arr = env.as_array()
+    common = dict(env_params=env_arr, env_param_names=np.array(O.PARAM_NAMES), dt=np.float32(dt),
+                  mlp_weights=mlp_w)
+
+    # ---- Interpolator (others/Interpolator.py) ------------------------------------------------
+    interp = {}
+    g = np.random.default_rng(11)
+    for (H, p) in [(10, 1), (50, 10), (50, 1), (30, 10), (100, 10), (43, 10), (41, 10), (5, 10), (12, 3)]:
+        for C in (1, 2):
+            I = Interpolator(H, p, C, lib)
+            P = I.number_of_interpolation_inducing_points
+            y = g.standard_normal((7, P, C)).astype(np.float32)
+            out = I.interpolate(torch.tensor(y)).numpy()
+            interp[f"H{H}_p{p}_C{C}_y"] = y
+            interp[f"H{H}_p{p}_C{C}_out"] = out
+            interp[f"H{H}_p{p}_C{C}_mat"] = I.interp_mat.numpy()   # [P,H,C]
+    np.savez_compressed(os.path.join(out_dir, "interpolator.npz"), **interp)
+
+    # ---- cost aggregation (Cost_Functions/__init__.py:38-93) ----------------------------------
+    class _Agg(CostClass.__mro__[1]):   # reference cost_function_base with canned stage/terminal costs
+        def __init__(self, stage, term):
+            self.lib, self._s, self._t = lib, stage, term
+        def _get_stage_cost(self, states, inputs, previous_input):
+            return self._s
+        def get_terminal_cost(self, terminal_states):
+            return self._t
+    stage = g.standard_normal((9, 13)).astype(np.float32) * 100
+    term = g.standard_normal((9,)).astype(np.float32) * 100
+    agg = _Agg(torch.tensor(stage), torch.tensor(term))
+    J = agg.get_trajectory_cost(torch.zeros(9, 14, 4), torch.zeros(9, 13, 1), torch.zeros(1)).numpy()
+    Jsum = agg.get_summed_stage_cost(torch.zeros(9, 14, 4), torch.zeros(9, 13, 1), torch.zeros(1)).numpy()
+    # full concrete cost through the reference base class
+    from types import SimpleNamespace
+    cc = CostClass(SimpleNamespace(), lib)
+    traj = g.standard_normal((6, 8, 4)).astype(np.float32)
+    inp = g.uniform(-1, 1, (6, 7, 1)).astype(np.float32)
+    Jfull = cc.get_trajectory_cost(torch.tensor(traj), torch.tensor(inp), np.float32(0.25)).numpy()
+    np.savez_compressed(os.path.join(out_dir, "cost_aggregation.npz"), stage=stage, terminal=term, J=J, J_summed=Jsum,
+                        traj=traj, inputs=inp, u_prev=np.float32(0.25), J_full=Jfull, **common)
+
+    # ---- controller_mpc helper ----------------------------------------------------------------
+    low, high = np.array([-1.0], np.float32), np.array([1.0], np.float32)
+
+    def make_controller(opt_name, opt_cfg, predictor_spec):
+        cm.config_optimizers[opt_name] = dict(opt_cfg)
+        ctrl = cm.controller_mpc("CartPole", (low, high), {})
+        ctrl.configure(optimizer_name=opt_name, predictor_specification=predictor_spec)
+        return ctrl
+
+    # ---- MPPI (Optimizers/optimizer_mppi.py via Controllers/controller_mpc.py) -----------------
+    mppi_cases = {
+        "tiny_ode":   dict(N=8, H=10, p=1, pred="ODE", steps=3, seed=0, keep_traj=True),
+        "interp_ode": dict(N=64, H=50, p=10, pred="ODE", steps=3, seed=1, keep_traj=True),
+        "cfg2_ode":   dict(N=1024, H=50, p=1, pred="ODE", steps=3, seed=2, keep_traj=False),
+        "quirk_ode":  dict(N=32, H=41, p=10, pred="ODE", steps=2, seed=3, keep_traj=True),
+        "mlp":        dict(N=64, H=30, p=7, pred="MLP", steps=3, seed=4, keep_traj=True),
+    }
+    for name, c in mppi_cases.items():
+        cfg = dict(seed=1, mpc_horizon=c["H"], num_rollouts=c["N"], cc_weight=1.0, R=1.0, LBD=100.0, NU=1000.0,
+                   SQRTRHOINV=0.03, period_interpolation_inducing_points=c["p"], mpc_timestep=dt)
+        ctrl = make_controller("mppi", cfg, c["pred"])
+        opt = ctrl.optimizer
+        rec = RecordingRng(opt.rng); opt.rng = rec
+        plant = O.Predictor(kind="ODE", dt=dt, env=env)
+        s = initial_state(c["seed"])
+        d = dict(common, low=low, high=high, predictor=np.array(c["pred"]),
+                 **{k: np.float32(v) if isinstance(v, float) else np.array(v) for k, v in cfg.items()})
+        d["u_nom_init"] = opt.u_nom.numpy().copy()
+        for t in range(c["steps"]):
+            u_prev = np.float32(np.asarray(opt.u).reshape(-1)[0])
+            u = ctrl.step(s.copy())
+            d[f"s_{t}"] = s.copy(); d[f"u_prev_{t}"] = u_prev
+            d[f"noise_{t}"] = rec.raw[-1]
+            d[f"u_{t}"] = np.asarray(u, np.float32).reshape(-1)
+            d[f"u_nom_{t}"] = opt.u_nom.numpy().copy()
+            # J and u_run are returned by predict_and_cost but not stored unless logging: recompute
+            # them through the reference's own methods on the recorded tensors
+            d[f"opt_ctrl_seq_{t}"] = opt.optimal_control_sequence.copy()
+            s = plant_step(plant, s, u)
+        # second pass with logging on to capture J / u_run / trajectories (same seed => same draws)
+        ctrl2 = make_controller("mppi", cfg, c["pred"])
+        ctrl2.controller_logging = True
+        ctrl2.optimizer.optimizer_logging = True
+        for t in range(c["steps"]):
+            u2 = ctrl2.step(d[f"s_{t}"].copy())
+            assert np.array_equal(np.asarray(u2, np.float32).reshape(-1), d[f"u_{t}"])
+            lv = ctrl2.optimizer.logging_values
+            d[f"J_{t}"] = lv["J_logged"].copy()
+            d[f"u_run_{t}"] = lv["Q_logged"].copy()
+            if c["keep_traj"]:
+                d[f"traj_{t}"] = lv["rollout_trajectories_logged"].copy()
+        outs = ctrl2.get_outputs()
+        assert outs["J_logged"].shape == (c["steps"], c["N"])
+        d["steps"] = np.int32(c["steps"])
+        np.savez_compressed(os.path.join(out_dir, f"mppi_{name}.npz"), **d)
+
+    # ---- ADAM torch branch (optimizer_rpgd.py:56-82) ------------------------------------------
+    adam = ADAM(lib, learning_rate=0.05, beta_1=0.9, beta_2=0.999, epsilon=1e-8)
+    adam.build_optimizer(4, 6, (low, high))
+    var = torch.tensor(g.uniform(-1, 1, (4, 6, 1)).astype(np.float32))
+    ad = dict(var0=var.numpy().copy())
+    for t in range(3):
+        grad = torch.tensor(g.standard_normal((4, 6, 1)).astype(np.float32))
+        var = adam.apply_gradients([(grad, var)])
+        ad[f"grad_{t}"] = grad.numpy().copy(); ad[f"var_{t}"] = var.numpy().copy()
+    step_count, m_arr, v_arr = adam.get_weights()
+    ad.update(step=np.int32(step_count), m=m_arr, v=v_arr)
+    np.savez_compressed(os.path.join(out_dir, "adam.npz"), **ad)
+
+    # ---- RPGD (Optimizers/optimizer_rpgd.py via controller_mpc) --------------------------------
+    rpgd_cases = {
+        "ode_small":  dict(N=16, H=12, p=5, pred="ODE", its=2, steps=4, resamp=2, dist="uniform", seed=5, shift=1),
+        "ode_its20":  dict(N=32, H=50, p=10, pred="ODE", its=20, steps=2, resamp=10, dist="uniform", seed=6, shift=1),
+        "mlp_cfg4":   dict(N=64, H=50, p=10, pred="MLP", its=20, steps=2, resamp=10, dist="uniform", seed=7, shift=1),
+        "ode_normal": dict(N=16, H=10, p=1, pred="ODE", its=3, steps=3, resamp=1, dist="normal", seed=8, shift=2),
+    }
+    for name, c in rpgd_cases.items():
+        cfg = dict(seed=1, mpc_horizon=c["H"], num_rollouts=c["N"], outer_its=c["its"], sample_stdev=0.5,
+                   sample_mean=0.0, sample_whole_control_space=True, uniform_dist_min=-1.0, uniform_dist_max=1.0,
+                   resamp_per=c["resamp"], period_interpolation_inducing_points=c["p"],
+                   SAMPLING_DISTRIBUTION=c["dist"], shift_previous=c["shift"], warmup=False, warmup_iterations=250,
+                   learning_rate=0.05, opt_keep_k_ratio=0.25, gradmax_clip=5.0, rtol=1e-3, adam_beta_1=0.9,
+                   adam_beta_2=0.999, adam_epsilon=1e-8, mpc_timestep=dt)
+        # the rng is created in the ctor and first used by optimizer_reset() inside configure():
+        # patch create_rng's product at class level for the duration of construction
+        import Control_Toolkit.Optimizers as tmpl
+        orig_create = tmpl.create_rng
+        holder = {}
+        def recording_create(id, seed, computation_library=None):
+            holder["rec"] = RecordingRng(orig_create(id, seed, computation_library=computation_library))
+            return holder["rec"]
+        tmpl.create_rng = recording_create
+        try:
+            ctrl = make_controller("rpgd", cfg, c["pred"])
+        finally:
+            tmpl.create_rng = orig_create
+        opt, rec = ctrl.optimizer, holder["rec"]
+        d = dict(common, low=low, high=high, predictor=np.array(c["pred"]),
+                 **{k: (np.float32(v) if isinstance(v, float) else np.array(v)) for k, v in cfg.items()})
+        d["reset_draws"] = rec.raw[0]
+        d["Q_init"] = opt.Q_tf.detach().numpy().copy()
+        plant = O.Predictor(kind="ODE", dt=dt, env=env)
+        s = initial_state(c["seed"])
+        for t in range(c["steps"]):
+            ndraw = len(rec.raw)
+            u_prev = np.float32(np.asarray(opt.u).reshape(-1)[0])
+            u = ctrl.step(s.copy())
+            d[f"s_{t}"] = s.copy(); d[f"u_prev_{t}"] = u_prev
+            d[f"u_{t}"] = np.asarray(u, np.float32).reshape(-1)
+            if len(rec.raw) > ndraw:
+                d[f"resample_draws_{t}"] = rec.raw[-1]
+            d[f"Q_{t}"] = opt.Q_tf.detach().numpy().copy()            # warm-started population after the step
+            d[f"u_nom_{t}"] = opt.u_nom.detach().numpy().copy()
+            stp, m_arr, v_arr = opt.opt.get_weights()
+            d[f"adam_step_{t}"] = np.int32(stp); d[f"m_{t}"] = m_arr.copy(); d[f"v_{t}"] = v_arr.copy()
+            d[f"ages_{t}"] = opt.trajectory_ages.numpy().copy()
+            s = plant_step(plant, s, u)
+        d["steps"] = np.int32(c["steps"])
+        np.savez_compressed(os.path.join(out_dir, f"rpgd_{name}.npz"), **d)
+
+    print("golden fixtures written to", out_dir)
+    for f in sorted(os.listdir(out_dir)):
+        if f.endswith(".npz"):
+            print(f"  {f:28s} {os.path.getsize(os.path.join(out_dir, f)) / 1024:8.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()

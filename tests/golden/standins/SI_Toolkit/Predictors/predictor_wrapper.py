@@ -1,0 +1,54 @@
+"""Stand-in PredictorWrapper: the build's own cart-pole ODE / 5-32-32-4 tanh MLP in torch fp32
+(differentiable, so the reference's RPGD can backpropagate through it).  Same formulas as
+oracle/ctk_oracle.py:Predictor; constants are injected by tests/golden/make_golden.py."""
+import torch
+
+# injected by make_golden.py ------------------------------------------------------------------
+CONSTANTS = {}      # derived fp32 constants (oracle.derived_constants)
+MLP_WEIGHTS = None  # tuple of torch tensors (W1,b1,W2,b2,W3,b3)
+
+
+class PredictorWrapper:
+    def __init__(self):
+        self.num_states = 4
+        self.num_control_inputs = 1
+        self.kind = None
+        self.batch_size = None
+
+    def configure(self, batch_size, dt=None, computation_library=None, variable_parameters=None,
+                  predictor_specification=None, horizon=None, **kwargs):
+        self.batch_size = batch_size
+        self.kind = predictor_specification
+        self.dt = dt
+
+    def copy(self):
+        return PredictorWrapper()
+
+    def update(self, s=None, Q0=None):
+        pass   # no recurrent state
+
+    def _step(self, s, q):
+        if self.kind == "ODE":
+            k = CONSTANTS
+            x, v, th, om = s.unbind(1)
+            sn, cs = torch.sin(th), torch.cos(th)
+            A = k["u_max"] * q + k["k_ml"] * om * om * sn - k["M_fric"] * v
+            tmp = A * k["inv_mt"]
+            D = k["k43l"] - k["k_mpl_mt"] * cs * cs
+            Nn = k["g"] * sn - cs * tmp - k["k_jf"] * om
+            thdd = Nn / D
+            xdd = tmp - k["k_mpl_mt"] * thdd * cs
+            return torch.stack([x + k["dt"] * v, v + k["dt"] * xdd, th + k["dt"] * om, om + k["dt"] * thdd], 1)
+        W1, b1, W2, b2, W3, b3 = MLP_WEIGHTS
+        xin = torch.cat([s, q[:, None]], 1)
+        h1 = torch.tanh(xin @ W1.T + b1)
+        h2 = torch.tanh(h1 @ W2.T + b2)
+        return h2 @ W3.T + b3
+
+    def predict_core(self, s, Q):
+        states = [s]
+        cur = s
+        for h in range(Q.shape[1]):
+            cur = self._step(cur, Q[:, h, 0])
+            states.append(cur)
+        return torch.stack(states, 1)

@@ -1,0 +1,61 @@
+"""Shared helpers for the parity tests (oracle construction from a golden fixture)."""
+import os
+
+import numpy as np
+
+from oracle import ctk_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def env_from(d) -> O.EnvParams:
+    names = [str(x) for x in d["env_param_names"]]
+    return O.EnvParams(**{n: float(v) for n, v in zip(names, d["env_params"])})
+
+
+def predictor_from(d) -> O.Predictor:
+    return O.Predictor(kind=str(d["predictor"]), dt=float(d["dt"]), env=env_from(d), weights=d["mlp_weights"])
+
+
+def mppi_oracle_from(d) -> O.MPPI:
+    pred = predictor_from(d)
+    return O.MPPI(pred, O.Cost(pred.env, pred.dt), float(d["low"][0]), float(d["high"][0]),
+                  num_rollouts=int(d["num_rollouts"]), mpc_horizon=int(d["mpc_horizon"]),
+                  cc_weight=float(d["cc_weight"]), R=float(d["R"]), LBD=float(d["LBD"]), NU=float(d["NU"]),
+                  SQRTRHOINV=float(d["SQRTRHOINV"]),
+                  period_interpolation_inducing_points=int(d["period_interpolation_inducing_points"]))
+
+
+RPGD_KEYS = ("outer_its", "sample_stdev", "sample_mean", "sample_whole_control_space", "uniform_dist_min",
+             "uniform_dist_max", "resamp_per", "period_interpolation_inducing_points", "SAMPLING_DISTRIBUTION",
+             "shift_previous", "warmup", "warmup_iterations", "learning_rate", "opt_keep_k_ratio", "gradmax_clip",
+             "adam_beta_1", "adam_beta_2", "adam_epsilon")
+
+
+def rpgd_kwargs_from(d) -> dict:
+    kw = {}
+    for k in RPGD_KEYS:
+        v = d[k]
+        if v.dtype.kind in "US":
+            kw[k] = str(v)
+        elif v.dtype.kind == "b":
+            kw[k] = bool(v)
+        elif v.dtype.kind in "iu":
+            kw[k] = int(v)
+        else:
+            kw[k] = float(v)
+    return kw
+
+
+def rpgd_oracle_from(d) -> O.RPGD:
+    pred = predictor_from(d)
+    return O.RPGD(pred, O.Cost(pred.env, pred.dt), float(d["low"][0]), float(d["high"][0]),
+                  num_rollouts=int(d["num_rollouts"]), mpc_horizon=int(d["mpc_horizon"]), **rpgd_kwargs_from(d))
+
+
+MPPI_CASES = ["tiny_ode", "interp_ode", "cfg2_ode", "quirk_ode", "mlp"]
+RPGD_CASES = ["ode_small", "ode_its20", "mlp_cfg4", "ode_normal"]
