@@ -1,0 +1,135 @@
+"""template_optimizer — mirror of reference Optimizers/__init__.py:10-79 for the HIP engine."""
+from typing import Tuple
+
+import numpy as np
+
+from ..computation_library import ComputationLibrary, HipLibrary
+from ..others.globals_and_utils import create_rng
+from .._capi import CtkEngine, PARAMS
+
+
+class template_optimizer:
+    supported_computation_libraries = (HipLibrary,)
+    engine_name = None   # "mppi" | "cem" | "rpgd" | "random_action"
+
+    def __init__(self, predictor, cost_function, control_limits: "Tuple[np.ndarray, np.ndarray]",
+                 optimizer_logging: bool, seed, num_rollouts: int, mpc_horizon: int,
+                 computation_library: "ComputationLibrary", rng_mode: str = "device", device: int = 0,
+                 calculate_optimal_trajectory: bool = False, **kwargs) -> None:
+        # reference :27-28
+        if not isinstance(computation_library, self.supported_computation_libraries):
+            raise ValueError(f"The optimizer {self.__class__.__name__} does not support "
+                             f"{getattr(computation_library, 'lib', computation_library)}")
+        self.lib = computation_library
+        self.num_rollouts = num_rollouts
+        self.mpc_horizon = mpc_horizon
+        self.cost_function = cost_function
+        self.u = 0.0
+        self.predictor = predictor
+        self.num_states = None
+        self.num_control_inputs = None
+        self.action_low, self.action_high = control_limits
+        self.action_low = self.lib.to_tensor(self.action_low, self.lib.float32)
+        self.action_high = self.lib.to_tensor(self.action_high, self.lib.float32)
+        self.rng = create_rng(self.__class__.__name__, seed, computation_library=computation_library, mode=rng_mode)
+        self.seed = getattr(self.rng, "seed", 0 if seed is None else seed)
+        self.logging_values = {}
+        self.optimizer_logging = optimizer_logging
+        self.calculate_optimal_trajectory = bool(calculate_optimal_trajectory)
+        self.device = device
+        self.engine: CtkEngine = None
+        self._param_cache = {}
+        self._cost_version = None
+        self.optimal_trajectory = None
+        self.optimal_control_sequence = None
+        self.rollout_trajectories = None
+
+    # reference :52-63
+    def configure(self, num_states: int, num_control_inputs: int, default_configure: bool = True, **kwargs) -> None:
+        self.num_states = num_states
+        self.num_control_inputs = num_control_inputs
+        if default_configure:
+            self.optimizer_reset()
+
+    def step(self, s: np.ndarray, time=None):
+        raise NotImplementedError("Implement this function in a subclass.")
+
+    def optimizer_reset(self):
+        raise NotImplementedError("Implement this function in a subclass.")
+
+    @property
+    def optimizer_name(self):
+        name = self.__class__.__name__
+        if name != "template_optimizer":
+            return name.replace("optimizer_", "").replace("_", "-").lower()
+        raise AttributeError()
+
+    # ---- engine plumbing shared by the *_hip optimizers --------------------------------------
+    def _limits(self):
+        lo = np.asarray(self.action_low, np.float32).reshape(-1)
+        hi = np.asarray(self.action_high, np.float32).reshape(-1)
+        if lo.size != 1 or hi.size != 1:
+            raise NotImplementedError("only num_control_inputs == 1 is built")
+        return float(lo[0]), float(hi[0])
+
+    def _build_engine(self, dt, predictor_specification, **engine_kwargs):
+        if self.num_states != 4 or self.num_control_inputs != 1:
+            raise NotImplementedError("the HIP engine is built for num_states == 4, num_control_inputs == 1")
+        if getattr(self.predictor, "kind", None) is None:
+            self.predictor.configure(batch_size=self.num_rollouts, dt=dt, computation_library=self.lib,
+                                     predictor_specification=predictor_specification)
+        lo, hi = self._limits()
+        self.engine = CtkEngine(
+            self.engine_name, self.predictor.kind, num_rollouts=self.num_rollouts, mpc_horizon=self.mpc_horizon,
+            dt=dt, action_low=lo, action_high=hi, seed=self.seed, device=self.device,
+            intermediate_steps=getattr(self.predictor, "intermediate_steps", 1),
+            materialize_trajectories=bool(self.optimizer_logging), **engine_kwargs)
+        if self.predictor.kind == "MLP":
+            self.engine.set_predictor_weights(self.predictor.weights)
+        self._param_cache = {}
+        self._cost_version = None
+        self._sync_parameters(force=True)
+
+    def _sync_parameters(self, force=False):
+        """Upload changed dynamics / cost / per-step attributes (reference: variable_parameters
+        updated by template_controller.update_attributes, Controllers/__init__.py:106-107; cost
+        YAML hot reload, cost_function_wrapper.py:71-74).  Only between steps."""
+        vals = {}
+        vals.update(getattr(self.predictor, "parameters", {}))
+        cf = self.cost_function
+        vals.update(getattr(cf, "parameters", {}))
+        vp = getattr(cf, "variable_parameters", None) or getattr(self.predictor, "variable_parameters", None)
+        for name in ("target_position", "target_equilibrium"):
+            if vp is not None and hasattr(vp, name):
+                vals[name] = float(np.asarray(getattr(vp, name)).reshape(-1)[0])
+        for name, v in vals.items():
+            if name in PARAMS and (force or self._param_cache.get(name) != float(v)):
+                self.engine.set_param(name, float(v))
+                self._param_cache[name] = float(v)
+
+    def _draws(self, kind: str, shape):
+        """None => on-device Philox; otherwise RAW host draws of `shape`."""
+        if getattr(self.rng, "on_device", False):
+            return None
+        return (self.rng.normal if kind == "normal" else self.rng.uniform)(list(shape), dtype=self.lib.float32)
+
+    def _prepare_state(self, s):
+        s = np.asarray(s, dtype=np.float32)
+        if s.ndim == 2 and s.shape[0] == 1:
+            s = s[0]
+        if s.shape != (4,):
+            raise ValueError(f"state must have shape (4,), got {s.shape}")
+        return s
+
+    def _fill_logging(self, s_in, u):
+        # reference optimizer_mppi.py:214-218 / optimizer_cem_tf.py:104-108
+        self.rollout_trajectories = self.engine.read("TRAJ")
+        self.logging_values["Q_logged"] = self.engine.read("Q")
+        self.logging_values["J_logged"] = self.engine.read("J")
+        self.logging_values["rollout_trajectories_logged"] = self.rollout_trajectories
+        self.logging_values["u_logged"] = u
+
+    def _predict_optimal_trajectory(self, s, u_nom, u_prev):
+        # reference optimizer_mppi.py:199-202: single-trajectory rollout of the nominal plan
+        traj, _ = self.engine.rollout(s, np.asarray(u_nom, np.float32).reshape(1, self.mpc_horizon, 1), u_prev=u_prev)
+        return traj

@@ -1,0 +1,49 @@
+"""PredictorWrapper — host-side stand for SI_Toolkit.Predictors.predictor_wrapper.PredictorWrapper
+(external to the reference; call sites optimizer_mppi.py:188, controller_mpc.py:43,67-73).  On
+MI355X the rollout is fused into the optimizer kernels, so this object only carries the
+predictor *specification* (kind, dt, physical parameters, MLP weights) to the engine."""
+import numpy as np
+
+DEFAULT_DYNAMICS = dict(g=9.81, m_cart=0.230, m_pole=0.087, L=0.1975, u_max=2.62, M_fric=4.77, J_fric=2.5e-4)
+MLP_NUM_WEIGHTS = 1380   # W1[32,5] b1[32] W2[32,32] b2[32] W3[4,32] b3[4]
+
+
+class PredictorWrapper:
+    def __init__(self, parameters=None, weights=None, intermediate_steps: int = 1):
+        self.num_states = 4
+        self.num_control_inputs = 1
+        self.parameters = dict(DEFAULT_DYNAMICS)
+        if parameters:
+            unknown = set(parameters) - set(DEFAULT_DYNAMICS)
+            if unknown:
+                raise ValueError(f"unknown dynamics parameters {sorted(unknown)}")
+            self.parameters.update(parameters)
+        self.weights = None if weights is None else np.ascontiguousarray(weights, dtype=np.float32).ravel()
+        self.intermediate_steps = int(intermediate_steps)
+        self.predictor_specification = None
+        self.batch_size = None
+        self.dt = None
+
+    def configure(self, batch_size, dt=None, computation_library=None, variable_parameters=None,
+                  predictor_specification=None, horizon=None, **kwargs):
+        spec = "ODE" if predictor_specification in (None, "") else str(predictor_specification)
+        kind = "ODE" if spec.upper().startswith("ODE") else ("MLP" if spec.upper().startswith("MLP") or "dense" in spec.lower() else None)
+        if kind is None:
+            raise NotImplementedError(f"predictor_specification {spec!r}: only 'ODE' and 'MLP' are built")
+        if kind == "MLP":
+            if self.weights is None:
+                raise ValueError("MLP predictor needs weights (PredictorWrapper(weights=...))")
+            if self.weights.size != MLP_NUM_WEIGHTS:
+                raise ValueError(f"MLP predictor expects {MLP_NUM_WEIGHTS} weights (5-32-32-4), got {self.weights.size}")
+        self.kind = kind
+        self.predictor_specification = spec
+        self.batch_size = batch_size
+        self.dt = dt
+        self.variable_parameters = variable_parameters
+
+    def copy(self):
+        return PredictorWrapper(self.parameters, self.weights, self.intermediate_steps)
+
+    def update(self, s=None, Q0=None):
+        """RNN hidden-state advance in the reference (optimizer_mppi.py:195-197); stateless here."""
+        return None

@@ -1,0 +1,294 @@
+"""ctypes binding of include/ctk_hip.h (the stub a reference maintainer would add; the reference's
+own precedent for a ctypes boundary is Controllers/controller_C.py:261-274).
+
+Fails loudly: if libctk_hip.so is missing or cannot be loaded, importing the engine raises; if
+no gfx950 device is usable, `CtkEngine(...)` raises.  Nothing here computes on the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libctk_hip.so"
+_lib = None
+
+OPTIMIZERS = {"mppi": 0, "cem": 1, "rpgd": 2, "random_action": 3}
+PREDICTORS = {"ODE": 0, "MLP": 1}
+PARAMS = ("g", "m_cart", "m_pole", "L", "u_max", "M_fric", "J_fric", "target_position", "target_equilibrium",
+          "dd_weight", "ep_weight", "ekp_weight", "cc_weight", "ccrc_weight", "R", "x_scale", "terminal_weight")
+BUFFERS = {"Q": 0, "J": 1, "TRAJ": 2, "U_NOM": 3, "STD": 4, "ADAM_M": 5, "ADAM_V": 6, "AGES": 7, "BEST_IDX": 8, "PLAN": 9}
+LOC_NONE, LOC_HOST, LOC_DEVICE = 0, 1, 2
+MLP_NUM_WEIGHTS = 1380
+
+
+class CtkError(RuntimeError):
+    pass
+
+
+class CtkConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("optimizer", C.c_int32), ("predictor", C.c_int32), ("device", C.c_int32),
+        ("num_rollouts", C.c_int32), ("mpc_horizon", C.c_int32), ("num_states", C.c_int32),
+        ("num_control_inputs", C.c_int32), ("period_interpolation_inducing_points", C.c_int32),
+        ("intermediate_steps", C.c_int32), ("materialize_trajectories", C.c_int32),
+        ("global_rollout_offset", C.c_int32), ("seed", C.c_uint64), ("dt", C.c_float),
+        ("action_low", C.c_float), ("action_high", C.c_float),
+        ("cc_weight", C.c_float), ("R", C.c_float), ("LBD", C.c_float), ("NU", C.c_float), ("SQRTRHOINV", C.c_float),
+        ("cem_outer_it", C.c_int32), ("cem_best_k", C.c_int32), ("warmup", C.c_int32), ("warmup_iterations", C.c_int32),
+        ("cem_initial_action_stdev", C.c_float), ("cem_stdev_min", C.c_float),
+        ("outer_its", C.c_int32), ("resamp_per", C.c_int32), ("shift_previous", C.c_int32), ("opt_keep_k", C.c_int32),
+        ("sampling_distribution", C.c_int32),
+        ("sample_stdev", C.c_float), ("sample_mean", C.c_float), ("sample_min", C.c_float), ("sample_max", C.c_float),
+        ("learning_rate", C.c_float), ("gradmax_clip", C.c_float), ("adam_beta_1", C.c_float),
+        ("adam_beta_2", C.c_float), ("adam_epsilon", C.c_float),
+    ]
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+# every symbol include/ctk_hip.h declares: name -> (restype, argtypes)
+_FP = C.POINTER(C.c_float)
+_H = C.c_void_p
+SYMBOLS = {
+    "ctk_abi_version": (C.c_int, []),
+    "ctk_create": (C.c_int, [C.POINTER(CtkConfig), C.POINTER(_H)]),
+    "ctk_destroy": (None, [_H]),
+    "ctk_reset": (C.c_int, [_H, C.c_void_p, C.c_int]),
+    "ctk_last_error": (C.c_char_p, [_H]),
+    "ctk_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "ctk_set_param": (C.c_int, [_H, C.c_int, C.c_float]),
+    "ctk_get_param": (C.c_int, [_H, C.c_int, _FP]),
+    "ctk_set_predictor_weights": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
+    "ctk_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ctk_samples_needed": (C.c_size_t, [_H]),
+    "ctk_rollout": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ctk_mppi_partial_size": (C.c_size_t, [_H]),
+    "ctk_mppi_step_begin": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ctk_mppi_step_end": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p]),
+    "ctk_read": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ctk_state_size": (C.c_size_t, [_H]),
+    "ctk_get_state": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
+    "ctk_set_state": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
+    "ctk_profile_enable": (C.c_int, [_H, C.c_int]),
+    "ctk_profile_read": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ctk_dominant_kernel": (C.c_char_p, [_H]),
+}
+
+
+def load_library():
+    """Load libctk_hip.so (built in-tree by control_toolkit_amd/csrc/Makefile).  Raises CtkError
+    if it is missing — there is deliberately no other implementation to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one
+    # process leave the second one without devices ("No HIP GPUs are available").  Import torch
+    # first so that libctk_hip.so binds to the runtime already loaded (torch is only plumbing
+    # here: device memory for collectives, streams, torch.distributed).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    path = library_path()
+    if not os.path.exists(path):
+        raise CtkError(f"{path} not found: build it with `make -C control_toolkit_amd/csrc` "
+                       f"(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise CtkError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.ctk_abi_version() != 1:
+        raise CtkError("libctk_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a, shape=None) -> np.ndarray:
+    out = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    if shape is not None and tuple(out.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(out.shape)}")
+    return out
+
+
+class CtkEngine:
+    """Owns one ctk_handle (one optimizer instance on one GPU)."""
+
+    def __init__(self, optimizer: str, predictor: str, *, num_rollouts: int, mpc_horizon: int, dt: float,
+                 action_low: float = -1.0, action_high: float = 1.0, period_interpolation_inducing_points: int = 1,
+                 seed: int = 0, device: int = 0, intermediate_steps: int = 1, materialize_trajectories: bool = False,
+                 global_rollout_offset: int = 0, num_states: int = 4, num_control_inputs: int = 1, **kw):
+        lib = load_library()
+        if optimizer not in OPTIMIZERS:
+            raise ValueError(f"unknown optimizer {optimizer!r}")
+        if predictor not in PREDICTORS:
+            raise NotImplementedError(f"predictor_specification {predictor!r} is not built (have: {list(PREDICTORS)})")
+        cfg = CtkConfig()
+        cfg.struct_size = C.sizeof(CtkConfig)
+        cfg.optimizer, cfg.predictor, cfg.device = OPTIMIZERS[optimizer], PREDICTORS[predictor], device
+        cfg.num_rollouts, cfg.mpc_horizon = int(num_rollouts), int(mpc_horizon)
+        cfg.num_states, cfg.num_control_inputs = int(num_states), int(num_control_inputs)
+        cfg.period_interpolation_inducing_points = int(period_interpolation_inducing_points)
+        cfg.intermediate_steps = int(intermediate_steps)
+        cfg.materialize_trajectories = int(bool(materialize_trajectories))
+        cfg.global_rollout_offset = int(global_rollout_offset)
+        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cfg.dt, cfg.action_low, cfg.action_high = float(dt), float(action_low), float(action_high)
+        # defaults keep unrelated optimizers' fields valid
+        defaults = dict(cc_weight=1.0, R=1.0, LBD=100.0, NU=1000.0, SQRTRHOINV=0.03, cem_outer_it=1, cem_best_k=1,
+                        warmup=0, warmup_iterations=0, cem_initial_action_stdev=0.5, cem_stdev_min=0.01,
+                        outer_its=1, resamp_per=1, shift_previous=1, opt_keep_k=1, sampling_distribution=0,
+                        sample_stdev=0.5, sample_mean=0.0, sample_min=-1.0, sample_max=1.0, learning_rate=0.05,
+                        gradmax_clip=5.0, adam_beta_1=0.9, adam_beta_2=0.999, adam_epsilon=1e-8)
+        unknown = set(kw) - set(defaults)
+        if unknown:
+            raise TypeError(f"unknown engine arguments: {sorted(unknown)}")
+        defaults.update(kw)
+        for k, v in defaults.items():
+            setattr(cfg, k, type(getattr(cfg, k))(v))
+        self._lib, self.cfg = lib, cfg
+        self.optimizer, self.predictor = optimizer, predictor
+        self.N, self.H = int(num_rollouts), int(mpc_horizon)
+        self._h = _H()
+        rc = lib.ctk_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            msg = lib.ctk_last_error(None).decode()
+            self._h = _H()
+            raise (ValueError if rc == 1 else NotImplementedError if rc == 2 else CtkError)(msg)
+        self._u = np.zeros(1, np.float32)
+
+    # ---- plumbing ------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self._lib.ctk_last_error(self._h).decode()
+            raise (ValueError if rc == 1 else NotImplementedError if rc == 2 else CtkError)(f"[ctk {rc}] {msg}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.ctk_destroy(self._h)
+            self._h = _H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- API -----------------------------------------------------------------------------------
+    def reset(self, draws=None, loc: int = LOC_NONE):
+        if draws is not None and loc == LOC_NONE:
+            loc = LOC_HOST
+        d = _f32(draws) if (draws is not None and loc == LOC_HOST) else None
+        self._check(self._lib.ctk_reset(self._h, _ptr(d) if d is not None else (draws if loc == LOC_DEVICE else None), loc))
+
+    def set_stream(self, stream_ptr: int):
+        self._check(self._lib.ctk_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_param(self, name: str, value: float):
+        self._check(self._lib.ctk_set_param(self._h, PARAMS.index(name), float(value)))
+
+    def get_param(self, name: str) -> float:
+        v = C.c_float()
+        self._check(self._lib.ctk_get_param(self._h, PARAMS.index(name), C.byref(v)))
+        return v.value
+
+    def set_predictor_weights(self, w):
+        w = _f32(w).ravel()
+        self._check(self._lib.ctk_set_predictor_weights(self._h, _ptr(w), w.size))
+
+    def samples_needed(self) -> int:
+        return int(self._lib.ctk_samples_needed(self._h))
+
+    def step(self, s, samples=None, loc: int = None, u_prev=None) -> np.ndarray:
+        """samples: None (device Philox), a host ndarray (parity mode) or an int device pointer."""
+        s = _f32(s).reshape(-1)
+        if s.size != 4:
+            raise ValueError("state must have 4 entries")
+        up = None if u_prev is None else _f32(u_prev).reshape(-1)[:1].copy()
+        if samples is None:
+            sp, loc = None, LOC_NONE
+        elif isinstance(samples, int):
+            sp, loc = C.c_void_p(samples), LOC_DEVICE
+        else:
+            arr = _f32(samples)
+            need = self.samples_needed()
+            if arr.size != need:
+                raise ValueError(f"step consumes {need} draws, got {arr.size}")
+            sp, loc = _ptr(arr), LOC_HOST
+        self._check(self._lib.ctk_step(self._h, _ptr(s), _ptr(up), sp, loc, _ptr(self._u)))
+        return self._u.copy()
+
+    def rollout(self, s, Q, u_prev=0.0, want_traj=True):
+        Q = _f32(Q)
+        n = Q.shape[0]
+        Q = Q.reshape(n, self.H, 1)
+        s = _f32(s).reshape(-1)
+        up = _f32([u_prev]).reshape(1)
+        traj = np.empty((n, self.H + 1, 4), np.float32) if want_traj else None
+        J = np.empty((n,), np.float32)
+        self._check(self._lib.ctk_rollout(self._h, _ptr(s), _ptr(up), _ptr(Q), n, _ptr(traj), _ptr(J)))
+        return traj, J
+
+    def mppi_partial_size(self) -> int:
+        return int(self._lib.ctk_mppi_partial_size(self._h))
+
+    def mppi_step_begin(self, s, partial_dev_ptr: int, samples=None, u_prev=None):
+        s = _f32(s).reshape(-1)
+        up = None if u_prev is None else _f32(u_prev).reshape(-1)[:1].copy()
+        if samples is None:
+            sp, loc = None, LOC_NONE
+        elif isinstance(samples, int):
+            sp, loc = C.c_void_p(samples), LOC_DEVICE
+        else:
+            arr = _f32(samples); sp, loc = _ptr(arr), LOC_HOST
+        self._check(self._lib.ctk_mppi_step_begin(self._h, _ptr(s), _ptr(up), sp, loc, C.c_void_p(partial_dev_ptr)))
+
+    def mppi_step_end(self, parts_dev_ptr: int, n_parts: int) -> np.ndarray:
+        self._check(self._lib.ctk_mppi_step_end(self._h, C.c_void_p(parts_dev_ptr), int(n_parts), _ptr(self._u)))
+        return self._u.copy()
+
+    def read(self, name: str) -> np.ndarray:
+        N, H = self.N, self.H
+        cap = max(N * (H + 1) * 4, N * H, 1)
+        buf = np.empty(cap, np.float32)
+        n = C.c_size_t()
+        self._check(self._lib.ctk_read(self._h, BUFFERS[name], _ptr(buf), cap, C.byref(n)))
+        out = buf[: n.value].copy()
+        shapes = {"Q": (N, H, 1), "J": (N,), "TRAJ": (N, H + 1, 4), "U_NOM": (1, H, 1), "STD": (1, H, 1),
+                  "ADAM_M": (N, H, 1), "ADAM_V": (N, H, 1), "AGES": (N,), "PLAN": (N, H, 1)}
+        if name == "BEST_IDX":
+            return out.astype(np.int64)
+        return out.reshape(shapes[name])
+
+    def get_state(self) -> np.ndarray:
+        n = int(self._lib.ctk_state_size(self._h))
+        buf = np.empty(n, np.float32)
+        self._check(self._lib.ctk_get_state(self._h, _ptr(buf), n))
+        return buf
+
+    def set_state(self, state):
+        st = _f32(state).ravel()
+        self._check(self._lib.ctk_set_state(self._h, _ptr(st), st.size))
+
+    def profile_enable(self, on: bool = True):
+        self._check(self._lib.ctk_profile_enable(self._h, int(on)))
+
+    def profile_read(self) -> np.ndarray:
+        buf = np.empty(4096, np.float32)
+        n = C.c_size_t()
+        self._check(self._lib.ctk_profile_read(self._h, _ptr(buf), buf.size, C.byref(n)))
+        return buf[: n.value].copy()
+
+    def dominant_kernel(self) -> str:
+        return self._lib.ctk_dominant_kernel(self._h).decode()

@@ -1,0 +1,644 @@
+// ctk_api.hip — the C ABI of libctk_hip.so (include/ctk_hip.h): handle, device state, step
+// sequencing.  All compute is in the HIP kernels; there is no CPU fallback.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ctk_launch.h"
+#include "ctk_device.h"   // tile_stride
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct ctk_handle {
+    ctk_config cfg{};
+    int N = 0, H = 0, P = 0;
+    float params[CTK_P_COUNT]{};
+    EnvK k{};
+    MppiK mk{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // device state
+    InterpEntry* d_interp = nullptr;
+    float* d_samples = nullptr;  size_t samples_cap = 0;   // staging for host-supplied draws
+    float* d_J = nullptr;
+    float* d_Q = nullptr;
+    float* d_traj = nullptr;
+    float* d_parts = nullptr;   size_t parts_cap = 0;
+    float* d_parts2 = nullptr;
+    float* d_unom[2] = {nullptr, nullptr};   // MPPI u_nom ping-pong / CEM mu in [0]
+    int cur = 0;
+    float* d_std = nullptr;     // CEM
+    float* d_base = nullptr;    // affine rollout base/scale scratch [H] each
+    float* d_scale = nullptr;
+    int* d_idx = nullptr;       // best indices [N]
+    float* d_u = nullptr;       // optimizer's last output (device)
+    float* h_u = nullptr;       // pinned, device-visible host copy of u
+    float* h_u_dev = nullptr;   // device pointer aliasing h_u
+    float* d_weights = nullptr; // MLP
+    int count = 0;              // CEM / RPGD step counter
+    uint32_t call = 0;          // Philox call counter
+    bool mppi_pending = false;  // between step_begin and step_end
+    // profiling
+    bool prof = false;
+    std::vector<EventPair> events;
+    size_t ev_used = 0;
+    std::string err;
+    std::string dominant;
+};
+
+namespace {
+
+int fail(ctk_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                      \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail((h), CTK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// others/Interpolator.py:79-84
+int num_inducing_points(int H, int p) { return (int)std::ceil((double)(H - 1) / (double)p) + 1; }
+
+// Column t of the reference matrix (others/Interpolator.py:53-77), built the same way: fp32
+// (step-j)/step and j/step; closing row set to 1 BEFORE the division (quirk kept, see oracle).
+std::vector<InterpEntry> build_interp_table(int H, int p, int P) {
+    const int rows = (P - 1) * p + 1;
+    std::vector<float> M((size_t)rows * P, 0.0f);
+    for (int i = 0; i < P - 1; ++i)
+        for (int j = 0; j < p; ++j) {
+            M[(size_t)(i * p + j) * P + i] = (float)(p - j);
+            M[(size_t)(i * p + j) * P + i + 1] = (float)j;
+        }
+    M[(size_t)(rows - 1) * P + (P - 1)] = 1.0f;
+    std::vector<InterpEntry> tab(H);
+    for (int t = 0; t < H; ++t) {
+        int first = -1;
+        for (int c = 0; c < P; ++c)
+            if (M[(size_t)t * P + c] != 0.0f) { first = c; break; }
+        InterpEntry e{0, 0.0f, 0.0f};
+        if (P == 1) {
+            e.i0 = 0; e.w0 = M[(size_t)t * P] / (float)p;
+        } else {
+            e.i0 = first < 0 ? 0 : (first > P - 2 ? P - 2 : first);
+            e.w0 = M[(size_t)t * P + e.i0] / (float)p;
+            e.w1 = M[(size_t)t * P + e.i0 + 1] / (float)p;
+        }
+        tab[t] = e;
+    }
+    return tab;
+}
+
+void refresh_constants(ctk_handle* h) {
+    h->k = derive_constants(h->params, h->cfg.dt, h->cfg.intermediate_steps);
+    const ctk_config& c = h->cfg;
+    MppiK m;
+    m.stdev = (float)((double)c.SQRTRHOINV * (1.0 / std::sqrt((double)c.dt)));   // optimizer_mppi.py:130
+    const float one_m = 1.0f - 1.0f / c.NU;
+    m.k_dd = (0.5f * one_m) * c.R;
+    m.R = c.R;
+    m.k_uu = 0.5f * c.R;
+    m.cc = c.cc_weight;
+    m.neg_inv_lbd = (float)(-1.0 / (double)c.LBD);
+    h->mk = m;
+}
+
+void default_params(float* p) {
+    // oracle/ctk_oracle.py:EnvParams defaults
+    p[CTK_P_G] = 9.81f; p[CTK_P_M_CART] = 0.230f; p[CTK_P_M_POLE] = 0.087f; p[CTK_P_L] = 0.1975f;
+    p[CTK_P_U_MAX] = 2.62f; p[CTK_P_M_FRIC] = 4.77f; p[CTK_P_J_FRIC] = 2.5e-4f;
+    p[CTK_P_TARGET_POSITION] = 0.0f; p[CTK_P_TARGET_EQUILIBRIUM] = 1.0f;
+    p[CTK_P_DD_WEIGHT] = 600.0f; p[CTK_P_EP_WEIGHT] = 20000.0f; p[CTK_P_EKP_WEIGHT] = 80.0f;
+    p[CTK_P_CC_WEIGHT] = 1.0f; p[CTK_P_CCRC_WEIGHT] = 1.0f; p[CTK_P_R] = 1.0f; p[CTK_P_X_SCALE] = 0.198f;
+    p[CTK_P_TERMINAL_WEIGHT] = 0.0f;
+}
+
+template <class T>
+int dev_alloc(ctk_handle* h, T** p, size_t n) {
+    HIP_TRY(h, hipMalloc((void**)p, (n ? n : 1) * sizeof(T)));
+    HIP_TRY(h, hipMemsetAsync(*p, 0, (n ? n : 1) * sizeof(T), h->stream));
+    return CTK_OK;
+}
+
+int cem_iterations(const ctk_handle* h) {   // optimizer_cem_tf.py:92
+    return (h->cfg.warmup && h->count == 0) ? h->cfg.warmup_iterations : h->cfg.cem_outer_it;
+}
+
+size_t samples_needed(const ctk_handle* h) {
+    const size_t N = h->N, H = h->H, P = h->P;
+    switch (h->cfg.optimizer) {
+        case CTK_OPT_MPPI: return N * P;
+        case CTK_OPT_CEM: return (size_t)cem_iterations(h) * N * H;
+        case CTK_OPT_RANDOM_ACTION: return N * H;
+        case CTK_OPT_RPGD:
+            return (h->count % h->cfg.resamp_per == 0) ? (N - (size_t)h->cfg.opt_keep_k) * P : 0;
+    }
+    return 0;
+}
+
+// resolve a caller sample buffer to a device pointer (nullptr => on-device Philox)
+int resolve_samples(ctk_handle* h, const float* samples, int loc, size_t n, const float** out) {
+    *out = nullptr;
+    if (loc == CTK_LOC_NONE || n == 0) return CTK_OK;
+    if (samples == nullptr) return fail(h, CTK_ERR_INVALID_ARGUMENT, "samples pointer is NULL but samples_loc != CTK_LOC_NONE");
+    if (loc == CTK_LOC_DEVICE) { *out = samples; return CTK_OK; }
+    if (loc != CTK_LOC_HOST) return fail(h, CTK_ERR_INVALID_ARGUMENT, "bad samples_loc");
+    if (n > h->samples_cap) {
+        if (h->d_samples) HIP_TRY(h, hipFree(h->d_samples));
+        h->d_samples = nullptr; h->samples_cap = 0;
+        HIP_TRY(h, hipMalloc((void**)&h->d_samples, n * sizeof(float)));
+        h->samples_cap = n;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_samples, samples, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    *out = h->d_samples;
+    return CTK_OK;
+}
+
+RolloutArgs make_args(ctk_handle* h, const float* s, const float* u_prev, int N, int P) {
+    RolloutArgs a{};
+    for (int i = 0; i < CTK_S; ++i) a.s0[i] = s[i];
+    a.u_prev = u_prev ? u_prev[0] : 0.0f;
+    a.u_prev_dev = u_prev ? nullptr : h->d_u;
+    a.lo = h->cfg.action_low; a.hi = h->cfg.action_high;
+    a.N = N; a.H = h->H; a.P = P;
+    a.inv_Hp1 = 1.0f / (float)(h->H + 1);
+    a.interp = h->d_interp;
+    a.J = h->d_J;
+    a.Q_out = h->d_Q;
+    a.traj_out = h->cfg.materialize_trajectories ? h->d_traj : nullptr;
+    a.seed_lo = (uint32_t)(h->cfg.seed & 0xFFFFFFFFull);
+    a.seed_hi = (uint32_t)(h->cfg.seed >> 32);
+    a.call = h->call;
+    a.stream_id = 0;
+    a.global_row0 = h->cfg.global_rollout_offset;
+    return a;
+}
+
+struct ProfScope {   // HIP events around the dominant kernel, on the handle's stream
+    ctk_handle* h; bool on;
+    explicit ProfScope(ctk_handle* hh) : h(hh), on(hh->prof && hh->ev_used < hh->events.size()) {
+        if (on) hipEventRecord(h->events[h->ev_used].a, h->stream);
+    }
+    ~ProfScope() {
+        if (on) { hipEventRecord(h->events[h->ev_used].b, h->stream); ++h->ev_used; }
+    }
+};
+
+int finish_step(ctk_handle* h, float* u_out) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (u_out) u_out[0] = *h->h_u;
+    ++h->call;
+    return CTK_OK;
+}
+
+// ---- MPPI ------------------------------------------------------------------------------------
+int mppi_rollout(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc) {
+    const float* d_s = nullptr;
+    if (int rc = resolve_samples(h, samples, loc, (size_t)h->N * h->P, &d_s)) return rc;
+    RolloutArgs a = make_args(h, s, u_prev, h->N, h->P);
+    const bool log = h->cfg.materialize_trajectories != 0;
+    if (h->cfg.predictor != CTK_PRED_ODE) return fail(h, CTK_ERR_UNSUPPORTED, "MPPI: predictor not built yet");
+    {
+        ProfScope ps(h);
+        HIP_TRY(h, ctk_launch_mppi_rollout_ode(h->stream, a, h->k, h->mk, d_s, h->d_unom[h->cur], h->d_parts, log));
+    }
+    return CTK_OK;
+}
+
+int mppi_block_parts(const ctk_handle* h) { return ctk_mppi_num_blocks_ode(h->N); }
+
+// reduce the block records to <= 2048 records (hierarchical when the grid was huge)
+int mppi_reduce_blocks(ctk_handle* h, const float** parts, int* n_parts) {
+    int n = mppi_block_parts(h);
+    const float* src = h->d_parts;
+    if (n > 2048) {
+        HIP_TRY(h, ctk_launch_mppi_merge_partial(h->stream, src, n, 64, h->P, h->mk.neg_inv_lbd, h->d_parts2));
+        n = (n + 63) / 64;
+        src = h->d_parts2;
+    }
+    *parts = src; *n_parts = n;
+    return CTK_OK;
+}
+
+int mppi_update(ctk_handle* h, const float* parts, int n_parts, float* u_out) {
+    const int nxt = h->cur ^ 1;
+    HIP_TRY(h, ctk_launch_mppi_update(h->stream, parts, n_parts, h->P, h->mk.neg_inv_lbd, h->H, h->d_interp, h->d_unom[h->cur],
+                                      h->d_unom[nxt], h->cfg.action_low, h->cfg.action_high, h->d_u, h->h_u_dev));
+    h->cur = nxt;
+    return finish_step(h, u_out);
+}
+
+// ---- CEM --------------------------------------------------------------------------------------
+int cem_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc, float* u_out) {
+    if (h->cfg.predictor != CTK_PRED_ODE) return fail(h, CTK_ERR_UNSUPPORTED, "CEM: predictor not built yet");
+    const int its = cem_iterations(h);
+    const size_t per_it = (size_t)h->N * h->H;
+    const float* d_s = nullptr;
+    if (int rc = resolve_samples(h, samples, loc, per_it * its, &d_s)) return rc;
+    const bool log = h->cfg.materialize_trajectories != 0;
+    float* mu = h->d_unom[0];
+    for (int it = 0; it < its; ++it) {
+        RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);
+        a.stream_id = (uint32_t)it;
+        {
+            ProfScope ps(h);
+            HIP_TRY(h, ctk_launch_affine_rollout_ode(h->stream, a, h->k, d_s ? d_s + per_it * it : nullptr, 0, mu, h->d_std, log));
+        }
+        HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, h->cfg.cem_best_k, h->d_idx, nullptr));
+        HIP_TRY(h, ctk_launch_cem_refit(h->stream, h->d_Q, h->d_idx, h->cfg.cem_best_k, h->H, mu, h->d_std));
+    }
+    const float mid = (h->cfg.action_low + h->cfg.action_high) * 0.5f;
+    HIP_TRY(h, ctk_launch_cem_finish(h->stream, h->d_Q, h->d_idx, h->H, mu, h->d_std, h->cfg.cem_stdev_min,
+                                     h->cfg.cem_initial_action_stdev, mid, h->d_u, h->h_u_dev));
+    ++h->count;
+    return finish_step(h, u_out);
+}
+
+// ---- random action ----------------------------------------------------------------------------
+int random_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc, float* u_out) {
+    if (h->cfg.predictor != CTK_PRED_ODE) return fail(h, CTK_ERR_UNSUPPORTED, "random-action: predictor not built yet");
+    const float* d_s = nullptr;
+    if (int rc = resolve_samples(h, samples, loc, (size_t)h->N * h->H, &d_s)) return rc;
+    RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);
+    {
+        ProfScope ps(h);
+        HIP_TRY(h, ctk_launch_affine_rollout_ode(h->stream, a, h->k, d_s, 1, h->d_base, h->d_scale,
+                                                 h->cfg.materialize_trajectories != 0));
+    }
+    HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, 1, h->d_idx, nullptr));
+    HIP_TRY(h, ctk_launch_pick_best_first(h->stream, h->d_Q, h->d_idx, h->H, h->d_u, h->h_u_dev));
+    return finish_step(h, u_out);
+}
+
+int fill_const(ctk_handle* h, float* d, float v, int n) {
+    std::vector<float> tmp((size_t)n, v);
+    HIP_TRY(h, hipMemcpyAsync(d, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CTK_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int ctk_abi_version(void) { return CTK_ABI_VERSION; }
+
+const char* ctk_last_error(const ctk_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int ctk_create(const ctk_config* cfg, ctk_handle** out) {
+    if (out) *out = nullptr;
+    if (!cfg || !out) return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: NULL argument");
+    if (cfg->struct_size != sizeof(ctk_config))
+        return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: ctk_config size mismatch (ABI)");
+    if (cfg->num_states != CTK_S || cfg->num_control_inputs != CTK_C)
+        return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: only num_states == 4, num_control_inputs == 1 are built");
+    if (cfg->num_rollouts < 1 || cfg->mpc_horizon < 1 || cfg->mpc_horizon > 1024)
+        return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: need num_rollouts >= 1 and 1 <= mpc_horizon <= 1024");
+    if (cfg->period_interpolation_inducing_points < 1 || cfg->intermediate_steps < 1)
+        return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: period_interpolation_inducing_points and intermediate_steps must be >= 1");
+    if (!(cfg->dt > 0.0f)) return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: dt must be > 0");
+    if (cfg->optimizer < CTK_OPT_MPPI || cfg->optimizer > CTK_OPT_RANDOM_ACTION)
+        return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: unknown optimizer");
+    if (cfg->predictor != CTK_PRED_ODE && cfg->predictor != CTK_PRED_MLP)
+        return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: unknown predictor");
+    if (cfg->optimizer == CTK_OPT_CEM && (cfg->cem_best_k < 1 || cfg->cem_best_k > cfg->num_rollouts || cfg->cem_outer_it < 1))
+        return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: need 1 <= cem_best_k <= num_rollouts and cem_outer_it >= 1");
+    if (cfg->optimizer == CTK_OPT_MPPI && !(cfg->LBD > 0.0f && cfg->NU != 0.0f))
+        return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: MPPI needs LBD > 0 and NU != 0");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, CTK_ERR_NO_DEVICE, "ctk_create: no HIP device visible (libctk_hip has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: bad device ordinal");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+        return fail(nullptr, CTK_ERR_NO_DEVICE, "ctk_create: hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, CTK_ERR_NO_DEVICE, std::string("ctk_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+
+    ctk_handle* h = new ctk_handle();
+    h->cfg = *cfg;
+    h->N = cfg->num_rollouts; h->H = cfg->mpc_horizon;
+    const bool interp = (cfg->optimizer == CTK_OPT_MPPI || cfg->optimizer == CTK_OPT_RPGD);
+    h->P = interp ? num_inducing_points(h->H, cfg->period_interpolation_inducing_points) : h->H;
+    default_params(h->params);
+    refresh_constants(h);
+
+    auto bail = [&](int rc) { g_create_error = h->err; ctk_destroy(h); return rc; };
+#define TRY_CREATE(expr) do { int _rc = (expr); if (_rc) return bail(_rc); } while (0)
+#define HIP_CREATE(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { h->err = std::string(#expr) + ": " + hipGetErrorString(_e); return bail(CTK_ERR_HIP); } } while (0)
+
+    HIP_CREATE(hipSetDevice(cfg->device));
+    HIP_CREATE(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+
+    const size_t N = h->N, H = h->H, P = h->P;
+    // LDS budget of the rollout tiles (one wave per block): 64 * stride * 4 B <= 160 KiB
+    if ((size_t)(64 * tile_stride((int)P) + 64) * sizeof(float) > 160 * 1024) { h->err = "horizon too long for the LDS sample tile"; return bail(CTK_ERR_UNSUPPORTED); }
+
+    std::vector<InterpEntry> tab = build_interp_table((int)H, interp ? cfg->period_interpolation_inducing_points : 1, (int)P);
+    TRY_CREATE(dev_alloc(h, &h->d_interp, H));
+    HIP_CREATE(hipMemcpyAsync(h->d_interp, tab.data(), H * sizeof(InterpEntry), hipMemcpyHostToDevice, h->stream));
+    HIP_CREATE(hipStreamSynchronize(h->stream));   // tab goes out of scope below
+
+    TRY_CREATE(dev_alloc(h, &h->d_J, N));
+    TRY_CREATE(dev_alloc(h, &h->d_Q, N * H));
+    if (cfg->materialize_trajectories) TRY_CREATE(dev_alloc(h, &h->d_traj, N * (H + 1) * CTK_S));
+    const size_t nblk = (N + 63) / 64;
+    h->parts_cap = nblk * (2 + P);
+    TRY_CREATE(dev_alloc(h, &h->d_parts, h->parts_cap));
+    TRY_CREATE(dev_alloc(h, &h->d_parts2, ((nblk + 63) / 64) * (2 + P)));
+    TRY_CREATE(dev_alloc(h, &h->d_unom[0], H));
+    TRY_CREATE(dev_alloc(h, &h->d_unom[1], H));
+    TRY_CREATE(dev_alloc(h, &h->d_std, H));
+    TRY_CREATE(dev_alloc(h, &h->d_base, H));
+    TRY_CREATE(dev_alloc(h, &h->d_scale, H));
+    TRY_CREATE(dev_alloc(h, &h->d_idx, N));
+    TRY_CREATE(dev_alloc(h, &h->d_u, 1));
+    TRY_CREATE(dev_alloc(h, &h->d_weights, CTK_MLP_NW));
+    HIP_CREATE(hipHostMalloc((void**)&h->h_u, 64, hipHostMallocMapped));
+    *h->h_u = 0.0f;
+    HIP_CREATE(hipHostGetDevicePointer((void**)&h->h_u_dev, h->h_u, 0));
+
+    switch (cfg->optimizer) {
+        case CTK_OPT_MPPI: h->dominant = ctk_mppi_rollout_ode_name(cfg->materialize_trajectories != 0); break;
+        default: h->dominant = ctk_affine_rollout_ode_name(cfg->materialize_trajectories != 0); break;
+    }
+    if (cfg->optimizer != CTK_OPT_RPGD) TRY_CREATE(ctk_reset(h, nullptr, CTK_LOC_NONE));
+    HIP_CREATE(hipStreamSynchronize(h->stream));
+    *out = h;
+    return CTK_OK;
+#undef TRY_CREATE
+#undef HIP_CREATE
+}
+
+void ctk_destroy(ctk_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (auto& e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    void* bufs[] = {h->d_interp, h->d_samples, h->d_J, h->d_Q, h->d_traj, h->d_parts, h->d_parts2, h->d_unom[0], h->d_unom[1],
+                    h->d_std, h->d_base, h->d_scale, h->d_idx, h->d_u, h->d_weights};
+    for (void* b : bufs) if (b) hipFree(b);
+    if (h->h_u) hipHostFree(h->h_u);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int ctk_set_stream(ctk_handle* h, void* hip_stream) {
+    if (!h) return CTK_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->own_stream && h->stream) HIP_TRY(h, hipStreamDestroy(h->stream));
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    return CTK_OK;
+}
+
+int ctk_reset(ctk_handle* h, const float* draws, int draws_loc) {
+    if (!h) return CTK_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const float mid = 0.5f * (h->cfg.action_low + h->cfg.action_high);
+    h->count = 0;
+    h->mppi_pending = false;
+    switch (h->cfg.optimizer) {
+        case CTK_OPT_MPPI:   // optimizer_mppi.py:227-231 (self.u is NOT reset there)
+            h->cur = 0;
+            return fill_const(h, h->d_unom[0], mid, h->H);
+        case CTK_OPT_CEM: {  // optimizer_cem_tf.py:113-117 (self.u = 0.0)
+            if (int rc = fill_const(h, h->d_unom[0], (h->cfg.action_low + h->cfg.action_high) * 0.5f, h->H)) return rc;
+            if (int rc = fill_const(h, h->d_std, h->cfg.cem_initial_action_stdev, h->H)) return rc;
+            *h->h_u = 0.0f;
+            return fill_const(h, h->d_u, 0.0f, 1);
+        }
+        case CTK_OPT_RANDOM_ACTION:   // :78-86 draws and discards a sample
+            if (int rc = fill_const(h, h->d_base, h->cfg.action_low, h->H)) return rc;
+            return fill_const(h, h->d_scale, h->cfg.action_high - h->cfg.action_low, h->H);
+        case CTK_OPT_RPGD:
+            (void)draws; (void)draws_loc;
+            return fail(h, CTK_ERR_UNSUPPORTED, "RPGD is not built yet");
+    }
+    return CTK_OK;
+}
+
+int ctk_set_param(ctk_handle* h, int id, float value) {
+    if (!h) return CTK_ERR_INVALID_ARGUMENT;
+    if (id < 0 || id >= CTK_P_COUNT) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_set_param: unknown parameter id");
+    if (h->mppi_pending) return fail(h, CTK_ERR_STATE, "ctk_set_param: illegal between step_begin and step_end");
+    h->params[id] = value;
+    refresh_constants(h);
+    return CTK_OK;
+}
+
+int ctk_get_param(const ctk_handle* h, int id, float* value) {
+    if (!h || !value || id < 0 || id >= CTK_P_COUNT) return CTK_ERR_INVALID_ARGUMENT;
+    *value = h->params[id];
+    return CTK_OK;
+}
+
+int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n) {
+    if (!h || !w) return CTK_ERR_INVALID_ARGUMENT;
+    if (n != (size_t)CTK_MLP_NW) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_set_predictor_weights: expected 1380 floats");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemcpyAsync(h->d_weights, w, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CTK_OK;
+}
+
+size_t ctk_samples_needed(const ctk_handle* h) { return h ? samples_needed(h) : 0; }
+
+int ctk_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int samples_loc, float* u_out) {
+    if (!h || !s) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_step: NULL state") : CTK_ERR_INVALID_ARGUMENT;
+    if (h->mppi_pending) return fail(h, CTK_ERR_STATE, "ctk_step: a sharded step is pending (call ctk_mppi_step_end)");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    switch (h->cfg.optimizer) {
+        case CTK_OPT_MPPI: {
+            if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc)) return rc;
+            const float* parts; int n_parts;
+            if (int rc = mppi_reduce_blocks(h, &parts, &n_parts)) return rc;
+            return mppi_update(h, parts, n_parts, u_out);
+        }
+        case CTK_OPT_CEM: return cem_step(h, s, u_prev, samples, samples_loc, u_out);
+        case CTK_OPT_RANDOM_ACTION: return random_step(h, s, u_prev, samples, samples_loc, u_out);
+        case CTK_OPT_RPGD: return fail(h, CTK_ERR_UNSUPPORTED, "RPGD is not built yet");
+    }
+    return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_step: unknown optimizer");
+}
+
+size_t ctk_mppi_partial_size(const ctk_handle* h) { return h ? (size_t)(2 + h->P) : 0; }
+
+int ctk_mppi_step_begin(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int samples_loc,
+                        float* partial_dev) {
+    if (!h || !s || !partial_dev) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_mppi_step_begin: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
+    if (h->cfg.optimizer != CTK_OPT_MPPI) return fail(h, CTK_ERR_STATE, "ctk_mppi_step_begin: handle is not MPPI");
+    if (h->mppi_pending) return fail(h, CTK_ERR_STATE, "ctk_mppi_step_begin: previous sharded step not ended");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc)) return rc;
+    const float* parts; int n_parts;
+    if (int rc = mppi_reduce_blocks(h, &parts, &n_parts)) return rc;
+    HIP_TRY(h, ctk_launch_mppi_merge_partial(h->stream, parts, n_parts, n_parts, h->P, h->mk.neg_inv_lbd, partial_dev));
+    h->mppi_pending = true;
+    return CTK_OK;
+}
+
+int ctk_mppi_step_end(ctk_handle* h, const float* parts_dev, int n_parts, float* u_out) {
+    if (!h || !parts_dev || n_parts < 1) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_mppi_step_end: bad argument") : CTK_ERR_INVALID_ARGUMENT;
+    if (!h->mppi_pending) return fail(h, CTK_ERR_STATE, "ctk_mppi_step_end: no sharded step pending");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    h->mppi_pending = false;
+    return mppi_update(h, parts_dev, n_parts, u_out);
+}
+
+int ctk_rollout(ctk_handle* h, const float* s, const float* u_prev, const float* Q, int n, float* traj_out, float* J_out) {
+    if (!h || !s || !Q) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_rollout: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
+    if (n < 1 || n > h->N) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_rollout: need 1 <= n <= num_rollouts");
+    if (h->cfg.predictor != CTK_PRED_ODE) return fail(h, CTK_ERR_UNSUPPORTED, "ctk_rollout: predictor not built yet");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t H = h->H;
+    const float* d_s = nullptr;
+    if (int rc = resolve_samples(h, Q, CTK_LOC_HOST, (size_t)n * H, &d_s)) return rc;
+    float* d_traj = h->d_traj;
+    float* tmp_traj = nullptr;
+    if (traj_out && !d_traj) { HIP_TRY(h, hipMalloc((void**)&tmp_traj, (size_t)n * (H + 1) * CTK_S * sizeof(float))); d_traj = tmp_traj; }
+    // base 0, scale 1, no clipping: the plans are taken as given
+    float *d_zero = nullptr, *d_one = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&d_zero, 2 * H * sizeof(float)));
+    d_one = d_zero + H;
+    std::vector<float> zo(2 * H, 0.0f);
+    for (size_t i = 0; i < H; ++i) zo[H + i] = 1.0f;
+    HIP_TRY(h, hipMemcpyAsync(d_zero, zo.data(), 2 * H * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    RolloutArgs a = make_args(h, s, u_prev, n, (int)H);
+    a.lo = -INFINITY; a.hi = INFINITY;
+    a.traj_out = traj_out ? d_traj : nullptr;
+    hipError_t e = ctk_launch_affine_rollout_ode(h->stream, a, h->k, d_s, 0, d_zero, d_one, traj_out != nullptr);
+    if (e == hipSuccess && traj_out)
+        e = hipMemcpyAsync(traj_out, d_traj, (size_t)n * (H + 1) * CTK_S * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && J_out) e = hipMemcpyAsync(J_out, h->d_J, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    hipFree(d_zero);
+    if (tmp_traj) hipFree(tmp_traj);
+    HIP_TRY(h, e);
+    HIP_TRY(h, e2);
+    return CTK_OK;
+}
+
+int ctk_read(ctk_handle* h, int which, float* dst, size_t cap, size_t* n_out) {
+    if (!h || !dst) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: NULL destination") : CTK_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t N = h->N, H = h->H;
+    const float* src = nullptr; size_t n = 0; bool is_int = false;
+    switch (which) {
+        case CTK_BUF_Q: src = h->d_Q; n = N * H; break;
+        case CTK_BUF_J: src = h->d_J; n = N; break;
+        case CTK_BUF_TRAJ:
+            if (!h->d_traj) return fail(h, CTK_ERR_STATE, "ctk_read: trajectories not materialised (cfg.materialize_trajectories == 0)");
+            src = h->d_traj; n = N * (H + 1) * CTK_S; break;
+        case CTK_BUF_U_NOM: src = h->d_unom[h->cfg.optimizer == CTK_OPT_MPPI ? h->cur : 0]; n = H; break;
+        case CTK_BUF_STD: src = h->d_std; n = H; break;
+        case CTK_BUF_BEST_IDX:
+            src = (const float*)h->d_idx; is_int = true;
+            n = h->cfg.optimizer == CTK_OPT_CEM ? (size_t)h->cfg.cem_best_k : (h->cfg.optimizer == CTK_OPT_RPGD ? (size_t)h->cfg.opt_keep_k : 1);
+            break;
+        default: return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: buffer not available for this optimizer");
+    }
+    if (cap < n) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: destination too small");
+    HIP_TRY(h, hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (is_int) for (size_t i = 0; i < n; ++i) { int v; std::memcpy(&v, &dst[i], 4); dst[i] = (float)v; }
+    if (n_out) *n_out = n;
+    return CTK_OK;
+}
+
+size_t ctk_state_size(const ctk_handle* h) {
+    if (!h) return 0;
+    const size_t H = h->H;
+    switch (h->cfg.optimizer) {
+        case CTK_OPT_MPPI: return H + 1;
+        case CTK_OPT_CEM: return 2 * H + 2;
+        case CTK_OPT_RANDOM_ACTION: return 1;
+        case CTK_OPT_RPGD: return 0;
+    }
+    return 0;
+}
+
+int ctk_get_state(ctk_handle* h, float* dst, size_t cap) {
+    if (!h || !dst) return CTK_ERR_INVALID_ARGUMENT;
+    const size_t n = ctk_state_size(h), H = h->H;
+    if (cap < n) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_get_state: destination too small");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    size_t o = 0;
+    auto pull = [&](const float* src, size_t cnt) -> hipError_t {
+        hipError_t e = hipMemcpyAsync(dst + o, src, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+        o += cnt; return e;
+    };
+    switch (h->cfg.optimizer) {
+        case CTK_OPT_MPPI: HIP_TRY(h, pull(h->d_unom[h->cur], H)); HIP_TRY(h, pull(h->d_u, 1)); break;
+        case CTK_OPT_CEM: HIP_TRY(h, pull(h->d_unom[0], H)); HIP_TRY(h, pull(h->d_std, H)); HIP_TRY(h, pull(h->d_u, 1));
+            HIP_TRY(h, hipStreamSynchronize(h->stream)); dst[o++] = (float)h->count; break;
+        case CTK_OPT_RANDOM_ACTION: HIP_TRY(h, pull(h->d_u, 1)); break;
+        default: return fail(h, CTK_ERR_UNSUPPORTED, "ctk_get_state: not built for this optimizer");
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CTK_OK;
+}
+
+int ctk_set_state(ctk_handle* h, const float* src, size_t n) {
+    if (!h || !src) return CTK_ERR_INVALID_ARGUMENT;
+    if (n != ctk_state_size(h)) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_set_state: wrong state size");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t H = h->H;
+    size_t o = 0;
+    auto push = [&](float* dstp, size_t cnt) -> hipError_t {
+        hipError_t e = hipMemcpyAsync(dstp, src + o, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream);
+        o += cnt; return e;
+    };
+    switch (h->cfg.optimizer) {
+        case CTK_OPT_MPPI: HIP_TRY(h, push(h->d_unom[h->cur], H)); HIP_TRY(h, push(h->d_u, 1)); break;
+        case CTK_OPT_CEM: HIP_TRY(h, push(h->d_unom[0], H)); HIP_TRY(h, push(h->d_std, H)); HIP_TRY(h, push(h->d_u, 1));
+            h->count = (int)src[o++]; break;
+        case CTK_OPT_RANDOM_ACTION: HIP_TRY(h, push(h->d_u, 1)); break;
+        default: return fail(h, CTK_ERR_UNSUPPORTED, "ctk_set_state: not built for this optimizer");
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CTK_OK;
+}
+
+int ctk_profile_enable(ctk_handle* h, int on) {
+    if (!h) return CTK_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (on && h->events.empty()) {
+        h->events.resize(4096);
+        for (auto& e : h->events) { HIP_TRY(h, hipEventCreate(&e.a)); HIP_TRY(h, hipEventCreate(&e.b)); }
+    }
+    h->prof = on != 0;
+    h->ev_used = 0;
+    return CTK_OK;
+}
+
+int ctk_profile_read(ctk_handle* h, float* ms_out, size_t cap, size_t* n_out) {
+    if (!h || !ms_out) return CTK_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    size_t n = h->ev_used < cap ? h->ev_used : cap;
+    for (size_t i = 0; i < n; ++i) HIP_TRY(h, hipEventElapsedTime(&ms_out[i], h->events[i].a, h->events[i].b));
+    if (n_out) *n_out = n;
+    h->ev_used = 0;
+    return CTK_OK;
+}
+
+const char* ctk_dominant_kernel(const ctk_handle* h) { return h ? h->dominant.c_str() : ""; }
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+// ctk_sampled.hip — rollouts whose inputs are an affine map of per-step samples, and the
+// selection / refit kernels around them:
+//   CEM            Q = clip(mu[h] + eps[n,h]*std[h])          optimizer_cem_tf.py:64-66
+//   random-action  Q = lo + u01[n,h]*(hi-lo)                  optimizer_random_action_tf.py:56-61
+//   plain rollout  Q given (base 0, scale 1, no clip)         predictor.predict_core(s, Q)
+// plus smallest-K selection under the total order (J, index) (tf.argsort at
+// optimizer_cem_tf.py:73 / optimizer_rpgd.py:345 with ties fixed by index), the CEM elite
+// refit (:77-78) and the post-loop shift (:99-102).
+#include "ctk_rollout.h"
+#include "ctk_launch.h"
+
+constexpr int SAMP_BLOCK = 64;
+
+template <bool TRAJ>
+__global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout_ode(RolloutArgs a, EnvK k,
+                                                                     const float* __restrict__ samples, int rng_kind,
+                                                                     const float* __restrict__ base,
+                                                                     const float* __restrict__ scale) {
+    extern __shared__ float lds[];
+    const int stride = tile_stride(a.P);   // P == H here: one sample per step
+    float* tile = lds;
+    const int lane = threadIdx.x;
+    const int row0 = blockIdx.x * SAMP_BLOCK;
+    const int n = row0 + lane;
+    const bool valid = n < a.N;
+    load_tile<SAMP_BLOCK>(tile, samples, a, row0, 1.0f, rng_kind);
+    __syncthreads();
+    const float* my = tile + lane * stride;
+    const float J = rollout_ode<true, TRAJ>(a, k, n, valid, [&](int h) {
+        return fminf(fmaxf(base[h] + my[h] * scale[h], a.lo), a.hi);
+    });
+    if (valid) a.J[n] = J;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rank-by-counting selection: rank(i) = #{ j : (J_j, j) < (J_i, i) }.  One block = 64 rows x 16
+// waves; wave w scans the j-slice [w*L, (w+1)*L) with wave-uniform (scalar) loads of J_j, the
+// 16 partial counts meet in LDS.  Ranks are a permutation, so idx_out[rank] = i for rank < K
+// is a race-free scatter and idx_out comes out sorted ascending by (J, index).
+// ---------------------------------------------------------------------------------------------
+constexpr int SEL_WAVES = 16;
+
+__global__ __launch_bounds__(64 * SEL_WAVES) void ctk_select_topk(const float* __restrict__ J, int N, int K,
+                                                                  int* __restrict__ idx_out) {
+    __shared__ int cnt_s[SEL_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    const float Ji = (i < N) ? J[i] : INFINITY;
+    const int L = (N + SEL_WAVES - 1) / SEL_WAVES;
+    const int j0 = wave * L, j1 = min(N, j0 + L);
+    int cnt = 0;
+    for (int j = j0; j < j1; ++j) {
+        const float Jj = J[j];   // wave-uniform address
+        cnt += (Jj < Ji) | ((Jj == Ji) & (j < i));
+    }
+    cnt_s[wave][lane] = cnt;
+    __syncthreads();
+    if (wave == 0 && i < N) {
+        int r = 0;
+#pragma unroll
+        for (int w = 0; w < SEL_WAVES; ++w) r += cnt_s[w][lane];
+        if (r < K) idx_out[r] = i;
+    }
+}
+
+// elite refit: one block per horizon step h; mu = mean_k Q[idx[k],h]; sd = population std.
+__global__ __launch_bounds__(256) void ctk_cem_refit(const float* __restrict__ Q, const int* __restrict__ idx, int K, int H,
+                                                     float* __restrict__ mu, float* __restrict__ sd) {
+    __shared__ float red[4];
+    const int h = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    float s = 0.0f;
+    for (int kk = t; kk < K; kk += 256) s += Q[(size_t)idx[kk] * H + h];
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)K;
+    __syncthreads();
+    float v = 0.0f;
+    for (int kk = t; kk < K; kk += 256) {
+        const float d = Q[(size_t)idx[kk] * H + h] - mean;
+        v += d * d;
+    }
+    v = wave_sum(v);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (t == 0) {
+        mu[h] = mean;
+        sd[h] = sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K);   // tf.math.reduce_std: ddof = 0
+    }
+}
+
+// optimizer_cem_tf.py:99-102: clip std, shift both by one step, refill the tail; u = elite[0,0]
+__global__ __launch_bounds__(256) void ctk_cem_finish(const float* __restrict__ Q, const int* __restrict__ idx, int H,
+                                                      float* __restrict__ mu, float* __restrict__ sd, float std_min,
+                                                      float init_std, float mid, float* __restrict__ u_dev,
+                                                      float* __restrict__ u_host) {
+    extern __shared__ float lds[];
+    float* m_s = lds;
+    float* s_s = lds + H;
+    const int t = threadIdx.x;
+    for (int h = t; h < H; h += 256) {
+        m_s[h] = mu[h];
+        s_s[h] = fminf(fmaxf(sd[h], std_min), 1.0e8f);
+    }
+    __syncthreads();
+    for (int h = t; h < H; h += 256) {
+        mu[h] = (h + 1 < H) ? m_s[h + 1] : mid;
+        sd[h] = (h + 1 < H) ? s_s[h + 1] : init_std;
+    }
+    if (t == 0) {
+        const float u = Q[(size_t)idx[0] * H];
+        *u_dev = u;
+        *u_host = u;
+    }
+}
+
+__global__ void ctk_pick_best_first(const float* __restrict__ Q, const int* __restrict__ idx, int H,
+                                    float* __restrict__ u_dev, float* __restrict__ u_host) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float u = Q[(size_t)idx[0] * H];
+        *u_dev = u;
+        *u_host = u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+const char* ctk_affine_rollout_ode_name(bool log) {
+    return log ? "ctk_affine_rollout_ode<true>" : "ctk_affine_rollout_ode<false>";
+}
+
+hipError_t ctk_launch_affine_rollout_ode(hipStream_t st, const RolloutArgs& a, const EnvK& k, const float* samples,
+                                         int rng_kind, const float* base, const float* scale, bool log) {
+    const int blocks = (a.N + SAMP_BLOCK - 1) / SAMP_BLOCK;
+    const size_t lds = (size_t)SAMP_BLOCK * tile_stride(a.P) * sizeof(float);
+    if (log)
+        hipLaunchKernelGGL(ctk_affine_rollout_ode<true>, dim3(blocks), dim3(SAMP_BLOCK), lds, st, a, k, samples, rng_kind, base, scale);
+    else
+        hipLaunchKernelGGL(ctk_affine_rollout_ode<false>, dim3(blocks), dim3(SAMP_BLOCK), lds, st, a, k, samples, rng_kind, base, scale);
+    return hipGetLastError();
+}
+
+hipError_t ctk_launch_select_topk(hipStream_t st, const float* J, int N, int K, int* idx_out, unsigned*) {
+    hipLaunchKernelGGL(ctk_select_topk, dim3((N + 63) / 64), dim3(64 * SEL_WAVES), 0, st, J, N, K, idx_out);
+    return hipGetLastError();
+}
+
+hipError_t ctk_launch_cem_refit(hipStream_t st, const float* Q, const int* idx, int K, int H, float* mu, float* sd) {
+    hipLaunchKernelGGL(ctk_cem_refit, dim3(H), dim3(256), 0, st, Q, idx, K, H, mu, sd);
+    return hipGetLastError();
+}
+
+hipError_t ctk_launch_cem_finish(hipStream_t st, const float* Q, const int* idx, int H, float* mu, float* sd, float std_min,
+                                 float init_std, float mid, float* u_dev, float* u_host) {
+    hipLaunchKernelGGL(ctk_cem_finish, dim3(1), dim3(256), 2 * H * sizeof(float), st, Q, idx, H, mu, sd, std_min, init_std, mid,
+                       u_dev, u_host);
+    return hipGetLastError();
+}
+
+hipError_t ctk_launch_pick_best_first(hipStream_t st, const float* Q, const int* idx, int H, float* u_dev, float* u_host) {
+    hipLaunchKernelGGL(ctk_pick_best_first, dim3(1), dim3(64), 0, st, Q, idx, H, u_dev, u_host);
+    return hipGetLastError();
+}

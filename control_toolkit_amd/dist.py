@@ -1,0 +1,34 @@
+"""Sharded MPPI over the GPUs of one node: one process per GPU, rollouts
+[rank*N_local, (rank+1)*N_local) per rank, ONE all-gather of the (2+P)-float soft-min record per
+step over RCCL (torch.distributed backend "nccl" is RCCL on ROCm), then every rank merges the
+records with the same kernel and arrives at the identical u_nom without a second collective.
+The payload is 408 B per rank at cfg5, so the collective is latency-bound, not xGMI-bandwidth-bound.
+
+The engine is injected so that the collective plumbing can be exercised on CPU with the gloo
+backend (tests/test_dist_gloo.py); on the GPU box the engine is a CtkEngine."""
+from __future__ import annotations
+
+import numpy as np
+
+
+class ShardedMPPI:
+    def __init__(self, engine, rank: int, world_size: int, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.engine, self.rank, self.world_size, self.group = engine, rank, world_size, group
+        self.rec = int(engine.mppi_partial_size())
+        self.device = device if device is not None else torch.device("cpu")
+        self.mine = torch.zeros(self.rec, dtype=torch.float32, device=self.device)
+        self.all = torch.zeros(self.rec * world_size, dtype=torch.float32, device=self.device)
+
+    def step(self, s, samples=None, u_prev=None) -> np.ndarray:
+        """samples: this rank's slice of the draws (host array / device pointer) or None (device
+        Philox addressed by GLOBAL rollout index, so the result does not depend on world_size)."""
+        self.engine.mppi_step_begin(s, self.mine.data_ptr(), samples, u_prev=u_prev)
+        if self.world_size > 1:
+            self.dist.all_gather_into_tensor(self.all, self.mine, group=self.group)
+            parts = self.all
+        else:
+            parts = self.mine
+        return self.engine.mppi_step_end(parts.data_ptr(), self.world_size)

@@ -1,0 +1,212 @@
+/* ctk_hip.h — C ABI of libctk_hip.so, the MI355X (gfx950) batched-rollout engine behind the
+ * sampling-based MPC optimizers of SensorsINI/Control_Toolkit.
+ *
+ * The reference is 100 % Python and has no FFI for this path; the boundary it defines is the
+ * `template_optimizer` contract (reference Optimizers/__init__.py:10-79) that
+ * `controller_mpc` drives (reference Controllers/controller_mpc.py:57-65, :84-89, :104).  Each
+ * entry point below names the reference call it replaces.  The reference's own precedent for a
+ * C-ABI + ctypes boundary is Controllers/controller_C.py:261-274 (float* in/out, no torch
+ * types).  The ctypes binding a reference maintainer would add is shown in INTEGRATION.md and
+ * implemented in control_toolkit_amd/_capi.py.
+ *
+ * Conventions: all tensors fp32, row-major, batch first ([N,H,C], [N,H+1,S]); S = 4, C = 1.
+ * Every function that returns int returns 0 on success and a ctk_status otherwise;
+ * ctk_last_error() gives the message.  A handle is NOT thread-safe (the reference caller is a
+ * single-threaded loop, controller_server/controller_server.py:55-86); all work of a handle
+ * is issued on one HIP stream.  The library never falls back to a CPU path: without a usable
+ * gfx950 device ctk_create() fails.
+ */
+#ifndef CTK_HIP_H
+#define CTK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTK_ABI_VERSION 1
+
+typedef struct ctk_handle ctk_handle;
+
+typedef enum ctk_status {
+    CTK_OK = 0,
+    CTK_ERR_INVALID_ARGUMENT = 1, /* ValueError in the Python wrapper           */
+    CTK_ERR_UNSUPPORTED = 2,      /* NotImplementedError                        */
+    CTK_ERR_HIP = 3,              /* a HIP runtime call failed (RuntimeError)   */
+    CTK_ERR_NO_DEVICE = 4,        /* no gfx950 device / extension unusable      */
+    CTK_ERR_STATE = 5             /* call illegal in the current state          */
+} ctk_status;
+
+/* reference: which Optimizers/optimizer_<name>.py the handle replaces */
+typedef enum ctk_optimizer {
+    CTK_OPT_MPPI = 0,          /* Optimizers/optimizer_mppi.py              */
+    CTK_OPT_CEM = 1,           /* Optimizers/optimizer_cem_tf.py            */
+    CTK_OPT_RPGD = 2,          /* Optimizers/optimizer_rpgd.py              */
+    CTK_OPT_RANDOM_ACTION = 3  /* Optimizers/optimizer_random_action_tf.py  */
+} ctk_optimizer;
+
+/* reference: predictor_specification passed to PredictorWrapper.configure
+ * (Controllers/controller_mpc.py:67-73): "ODE" or a network name                              */
+typedef enum ctk_predictor {
+    CTK_PRED_ODE = 0, /* analytic cart-pole, explicit Euler, VALU, one thread per trajectory   */
+    CTK_PRED_MLP = 1  /* 5-32-32-4 tanh MLP, fp32 MFMA (v_mfma_f32_16x16x4_f32), 16 traj./wave */
+} ctk_predictor;
+
+/* Environment / cost parameters.  Replaces template_controller.update_attributes
+ * (Controllers/__init__.py:106-107, per-step targets) and the cost-YAML hot reload
+ * (Cost_Functions/cost_function_wrapper.py:71-74).  Legal only between steps.              */
+typedef enum ctk_param {
+    CTK_P_G = 0, CTK_P_M_CART, CTK_P_M_POLE, CTK_P_L, CTK_P_U_MAX, CTK_P_M_FRIC, CTK_P_J_FRIC,
+    CTK_P_TARGET_POSITION, CTK_P_TARGET_EQUILIBRIUM,
+    CTK_P_DD_WEIGHT, CTK_P_EP_WEIGHT, CTK_P_EKP_WEIGHT, CTK_P_CC_WEIGHT, CTK_P_CCRC_WEIGHT,
+    CTK_P_R, CTK_P_X_SCALE, CTK_P_TERMINAL_WEIGHT,
+    CTK_P_COUNT
+} ctk_param;
+
+/* Device-resident tensors readable with ctk_read(); replaces the to_numpy() calls that fill
+ * `logging_values` (optimizer_mppi.py:214-220, optimizer_cem_tf.py:96,104-108,
+ * optimizer_rpgd.py:428-435).                                                                */
+typedef enum ctk_buffer {
+    CTK_BUF_Q = 0,      /* [N,H,C]   inputs rolled out in the last step (u_run / Q)            */
+    CTK_BUF_J = 1,      /* [N]       trajectory costs of the last rollout                       */
+    CTK_BUF_TRAJ = 2,   /* [N,H+1,S] rollout trajectories (only if cfg.materialize_trajectories)*/
+    CTK_BUF_U_NOM = 3,  /* [H,C]     MPPI nominal plan / RPGD best plan / CEM mean              */
+    CTK_BUF_STD = 4,    /* [H,C]     CEM stdev                                                  */
+    CTK_BUF_ADAM_M = 5, /* [N,H,C]   RPGD Adam first moment                                     */
+    CTK_BUF_ADAM_V = 6, /* [N,H,C]   RPGD Adam second moment                                    */
+    CTK_BUF_AGES = 7,   /* [N]       RPGD trajectory ages                                       */
+    CTK_BUF_BEST_IDX = 8,/* [K] as fp32: indices of the best K rollouts, ascending cost         */
+    CTK_BUF_PLAN = 9,   /* [N,H,C]   RPGD population after warm start (next step's Q_tf)        */
+    CTK_BUF_COUNT
+} ctk_buffer;
+
+/* where a `const float*` sample buffer lives */
+typedef enum ctk_loc {
+    CTK_LOC_NONE = 0,   /* no buffer: draw with the on-device Philox4x32-10 generator          */
+    CTK_LOC_HOST = 1,   /* host memory (parity mode: caller's generator, copied H2D)           */
+    CTK_LOC_DEVICE = 2  /* already resident in HBM (device pointer)                            */
+} ctk_loc;
+
+/* Constructor arguments.  Field names are the reference's YAML keys / ctor argument names:
+ * common  Optimizers/__init__.py:13-24 ; MPPI optimizer_mppi.py:16-34 ; CEM
+ * optimizer_cem_tf.py:16-34 ; RPGD optimizer_rpgd.py:148-179 ; random
+ * optimizer_random_action_tf.py:15-27 ; dt = config "mpc_timestep" (controller_mpc.py:69). */
+typedef struct ctk_config {
+    uint32_t struct_size; /* = sizeof(ctk_config), ABI guard                                   */
+    int32_t optimizer;    /* ctk_optimizer                                                     */
+    int32_t predictor;    /* ctk_predictor                                                     */
+    int32_t device;       /* HIP device ordinal                                                */
+    int32_t num_rollouts; /* N — rollouts owned by THIS handle (the local shard)               */
+    int32_t mpc_horizon;  /* H                                                                 */
+    int32_t num_states;   /* S, must be 4                                                      */
+    int32_t num_control_inputs; /* C, must be 1                                                */
+    int32_t period_interpolation_inducing_points;
+    int32_t intermediate_steps; /* Euler sub-steps per dt (ODE predictor), >= 1               */
+    int32_t materialize_trajectories; /* optimizer_logging / calculate_optimal_trajectory      */
+    int32_t global_rollout_offset;    /* first global rollout index of this shard (Philox)     */
+    uint64_t seed;
+    float dt;
+    float action_low, action_high;
+    /* MPPI */
+    float cc_weight, R, LBD, NU, SQRTRHOINV;
+    /* CEM */
+    int32_t cem_outer_it, cem_best_k, warmup, warmup_iterations;
+    float cem_initial_action_stdev, cem_stdev_min;
+    /* RPGD */
+    int32_t outer_its, resamp_per, shift_previous, opt_keep_k;
+    int32_t sampling_distribution; /* 0 = uniform, 1 = normal                                 */
+    float sample_stdev, sample_mean, sample_min, sample_max;
+    float learning_rate, gradmax_clip, adam_beta_1, adam_beta_2, adam_epsilon;
+} ctk_config;
+
+/* -------------------------------------------------------------------------------------------
+ * lifetime
+ * ----------------------------------------------------------------------------------------- */
+int ctk_abi_version(void);
+
+/* Optimizer.__init__ + configure (controller_mpc.py:57-65,84-89; Optimizers/__init__.py:13-63).
+ * Allocates all device state, then performs optimizer_reset() except for RPGD, whose reset
+ * needs draws (call ctk_reset).  On failure *out is NULL and ctk_last_error(NULL) explains.  */
+int ctk_create(const ctk_config* cfg, ctk_handle** out);
+void ctk_destroy(ctk_handle* h);
+
+/* optimizer_reset() (optimizer_mppi.py:227-231, optimizer_cem_tf.py:113-117,
+ * optimizer_rpgd.py:527-548).  `draws`: RPGD only — [N,P,C] raw draws (U[0,1) or N(0,1)) for
+ * sample_actions (:275-296); loc NONE draws them on device.                                  */
+int ctk_reset(ctk_handle* h, const float* draws, int draws_loc);
+
+const char* ctk_last_error(const ctk_handle* h); /* h may be NULL: last create() error       */
+
+/* Use an existing HIP stream (e.g. torch's current stream) for all work of this handle.     */
+int ctk_set_stream(ctk_handle* h, void* hip_stream);
+
+/* -------------------------------------------------------------------------------------------
+ * parameters
+ * ----------------------------------------------------------------------------------------- */
+int ctk_set_param(ctk_handle* h, int id, float value);
+int ctk_get_param(const ctk_handle* h, int id, float* value);
+/* MLP weights, flat fp32: W1[32,5] b1[32] W2[32,32] b2[32] W3[4,32] b3[4] (1380 floats)      */
+int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n);
+
+/* -------------------------------------------------------------------------------------------
+ * the hot path: optimizer.step(s, time) -> u   (Optimizers/__init__.py:67)
+ *   MPPI   optimizer_mppi.py:205-225 (+ :181-193)   samples: N(0,1)   [N,P,C]
+ *   CEM    optimizer_cem_tf.py:83-111               samples: N(0,1)   [iters,N,H,C]
+ *   RPGD   optimizer_rpgd.py:388-524                samples: raw draws [N-k,P,C], used only on
+ *                                                   resampling steps (count % resamp_per == 0)
+ *   random optimizer_random_action_tf.py:49-76      samples: U[0,1)   [N,H,C]
+ * s: host [S].  u_prev: host [C] previous applied input (cost `previous_input`); NULL = the
+ * optimizer's own last output, as the reference passes self.u.  u_out: host [C].
+ * Synchronous: returns when u_out is valid.
+ * ----------------------------------------------------------------------------------------- */
+int ctk_step(ctk_handle* h, const float* s, const float* u_prev,
+             const float* samples, int samples_loc, float* u_out);
+
+/* Number of raw draws (floats) the NEXT ctk_step consumes from `samples` (0 if none).        */
+size_t ctk_samples_needed(const ctk_handle* h);
+
+/* predictor.predict_core(s, Q) + cost_function.get_trajectory_cost(traj, Q, u_prev)
+ * (call sites optimizer_mppi.py:188,199-202; Cost_Functions/__init__.py:74-93) for n <= N
+ * caller-supplied plans Q [n,H,C] (host).  traj_out [n,H+1,S] and J_out [n] may be NULL.     */
+int ctk_rollout(ctk_handle* h, const float* s, const float* u_prev, const float* Q, int n,
+                float* traj_out, float* J_out);
+
+/* -------------------------------------------------------------------------------------------
+ * sharded MPPI (one handle per GPU).  ctk_step == begin + end with one part.
+ *   begin: sample, roll out and reduce this shard to one partial record
+ *          [rho_r, a_r, b_r[P*C]] written to `partial_dev` (device pointer, 2+P*C floats);
+ *   (caller all-gathers the records over RCCL)
+ *   end:   merge `n_parts` records (device pointer, contiguous) and update u_nom; u_out host.
+ * ----------------------------------------------------------------------------------------- */
+size_t ctk_mppi_partial_size(const ctk_handle* h); /* floats per record                      */
+int ctk_mppi_step_begin(ctk_handle* h, const float* s, const float* u_prev,
+                        const float* samples, int samples_loc, float* partial_dev);
+int ctk_mppi_step_end(ctk_handle* h, const float* parts_dev, int n_parts, float* u_out);
+
+/* -------------------------------------------------------------------------------------------
+ * state access
+ * ----------------------------------------------------------------------------------------- */
+/* Copies buffer `which` to host `dst` (capacity `cap` floats); *n_out = floats written.      */
+int ctk_read(ctk_handle* h, int which, float* dst, size_t cap, size_t* n_out);
+
+/* Warm-start state (SURVEY.md 5 'checkpoint/resume'): MPPI u_nom,u ; CEM mu,std,count,u ;
+ * RPGD Q,m,v,ages,adam_step,count,u.  ctk_state_size() floats.                               */
+size_t ctk_state_size(const ctk_handle* h);
+int ctk_get_state(ctk_handle* h, float* dst, size_t cap);
+int ctk_set_state(ctk_handle* h, const float* src, size_t n);
+
+/* -------------------------------------------------------------------------------------------
+ * measurement: HIP-event timing of the dominant (rollout) kernel on the handle's stream.
+ * enable, run steps, then read per-step durations in milliseconds.
+ * ----------------------------------------------------------------------------------------- */
+int ctk_profile_enable(ctk_handle* h, int on);
+int ctk_profile_read(ctk_handle* h, float* ms_out, size_t cap, size_t* n_out);
+/* name of the dominant kernel (as it appears in rocprofv3 --kernel-trace) */
+const char* ctk_dominant_kernel(const ctk_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTK_HIP_H */
