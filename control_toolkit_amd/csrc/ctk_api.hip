@@ -174,6 +174,8 @@ RolloutArgs make_args(ctk_handle* h, const float* s, const float* u_prev, int N,
     a.u_prev_dev = u_prev ? nullptr : h->d_u;
     a.lo = h->cfg.action_low; a.hi = h->cfg.action_high;
     a.N = N; a.H = h->H; a.P = P;
+    a.p_magic = P >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)P - 1) / (uint64_t)P) : 0u;
+    a.identity_interp = (h->cfg.period_interpolation_inducing_points == 1 && P == h->H) ? 1 : 0;
     a.inv_Hp1 = 1.0f / (float)(h->H + 1);
     a.interp = h->d_interp;
     a.J = h->d_J;
@@ -348,7 +350,11 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
 
     const size_t N = h->N, H = h->H, P = h->P;
     // LDS budget of the rollout tiles (one wave per block): 64 * stride * 4 B <= 160 KiB
-    if ((size_t)(64 * tile_stride((int)P) + 64) * sizeof(float) > 160 * 1024) { h->err = "horizon too long for the LDS sample tile"; return bail(CTK_ERR_UNSUPPORTED); }
+    {
+        const size_t lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_ode_lds((int)P, (int)H)
+                                                          : (size_t)(64 * tile_stride((int)P)) * sizeof(float);
+        if (lds > 160 * 1024) { h->err = "horizon too long for the LDS sample tiles (160 KiB per CU)"; return bail(CTK_ERR_UNSUPPORTED); }
+    }
 
     std::vector<InterpEntry> tab = build_interp_table((int)H, interp ? cfg->period_interpolation_inducing_points : 1, (int)P);
     TRY_CREATE(dev_alloc(h, &h->d_interp, H));

@@ -72,6 +72,8 @@ struct RolloutArgs {
     const float* u_prev_dev; // optimizer's own last output, device resident
     float lo, hi;
     int N, H, P;
+    uint32_t p_magic;        // ceil(2^32 / P): flat / P == umulhi(flat, p_magic) for flat*P < 2^32 (P >= 2)
+    int identity_interp;     // period == 1: u[t] = y[t] (column t of the matrix is e_t)
     float inv_Hp1;           // 1/(H+1): mean over [H stage costs | terminal], Cost_Functions/__init__.py:92
     const InterpEntry* interp;  // [H]
     float* J;                // [N]
@@ -80,4 +82,5 @@ struct RolloutArgs {
     // counter-based RNG (samples == nullptr)
     uint32_t seed_lo, seed_hi, call, stream_id;
     int global_row0;
+    unsigned long long* stamps;   // diagnostic builds only (-DCTK_STAMPS): 8 s_memtime stamps per block
 };

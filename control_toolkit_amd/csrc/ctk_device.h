@@ -6,23 +6,78 @@
 #define CTK_DEV __device__ __forceinline__
 
 // ---------------------------------------------------------------------------------------------
-// wave64 reductions (ds_swizzle/DPP via __shfl_xor; all 64 lanes must be active)
+// wave64 reductions (all 64 lanes must be active)
 // ---------------------------------------------------------------------------------------------
-CTK_DEV float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+// DPP within each row of 16 lanes (VALU speed, no LDS crossbar), then 4 v_readlane across rows.
+template <int CTRL>
+CTK_DEV float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-CTK_DEV float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+
+template <class Op>
+CTK_DEV float wave_reduce(float v, Op op) {
+    v = op(v, dpp_mov<DPP_QUAD_XOR1>(v));
+    v = op(v, dpp_mov<DPP_QUAD_XOR2>(v));
+    v = op(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+    v = op(v, dpp_mov<DPP_ROW_MIRROR>(v));          // every lane of a row now holds the row's result
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return op(op(r0, r1), op(r2, r3));
 }
+CTK_DEV float wave_min(float v) { return wave_reduce(v, [](float a, float b) { return fminf(a, b); }); }
+CTK_DEV float wave_sum(float v) { return wave_reduce(v, [](float a, float b) { return a + b; }); }
 
 // ---------------------------------------------------------------------------------------------
 // Cart-pole (build-defined predictor, oracle/ctk_oracle.py:Predictor._ode_step).  One explicit
 // Euler sub-step; sn/cs = sin/cos of the CURRENT angle (shared with the stage cost).
 // ---------------------------------------------------------------------------------------------
+// Nn / D for a denominator that is positive and far from the fp32 range limits (D in
+// [k43l - k_mpl_mt, k43l], a fraction of the pole length): v_rcp_f32 + one Newton step on the
+// reciprocal + one residual correction on the quotient; no v_div_scale/v_div_fixup range
+// handling.  <= 1 ulp from the correctly rounded quotient.
+CTK_DEV float fdiv_pos(float num, float den) {
+    float r = __builtin_amdgcn_rcpf(den);
+    r = fmaf(fmaf(-den, r, 1.0f), r, r);
+    float q = num * r;
+    return fmaf(fmaf(-den, q, num), r, q);
+}
+
+// sin and cos of one argument with a shared 3-term Cody-Waite reduction by pi/2 and the same
+// minimax polynomials the ROCm device library uses on its small-argument path (|error| <~ 1 ulp
+// for |x| <= 2^15); larger arguments (never seen in a rollout: dozens of revolutions) take the
+// library's Payne-Hanek path.  25 VALU instructions instead of ~42: the recurrence is issue-bound.
+CTK_DEV void ctk_sincosf(float x, float* sn, float* cs) {
+    const float ax = fabsf(x);
+    if (__builtin_expect(!(ax <= 32768.0f), 0)) {
+        sincosf(x, sn, cs);
+        return;
+    }
+    const float fn = rintf(ax * 0.636619772f);                       // 2/pi
+    float r = fmaf(fn, -1.57079637e+00f, ax);                        // pi/2 split in three
+    r = fmaf(fn, 4.37113883e-08f, r);
+    r = fmaf(fn, 1.71512489e-15f, r);                                // hi+mid+lo = pi/2 to ~2^-76
+    const int n = (int)fn;
+    const float r2 = r * r;
+    float ps = fmaf(r2, -1.95152959e-04f, 8.33216087e-03f);
+    ps = fmaf(r2, ps, -1.66666546e-01f);
+    const float s = fmaf(r, r2 * ps, r);
+    float pc = fmaf(r2, 2.44331571e-05f, -1.38873163e-03f);
+    pc = fmaf(r2, pc, 4.16666456e-02f);
+    pc = fmaf(r2, pc, -0.5f);
+    const float c = fmaf(r2, pc, 1.0f);
+    const bool odd = n & 1;
+    const unsigned sbits = __builtin_bit_cast(unsigned, odd ? c : s);
+    const unsigned cbits = __builtin_bit_cast(unsigned, odd ? s : c);
+    const unsigned sgn_s = ((unsigned)(n & 2) << 30) ^ (__builtin_bit_cast(unsigned, x) & 0x80000000u);
+    const unsigned sgn_c = ((unsigned)((n + 1) & 2) << 30);
+    *sn = __builtin_bit_cast(float, sbits ^ sgn_s);
+    *cs = __builtin_bit_cast(float, cbits ^ sgn_c);
+}
+
 struct State4 {
     float x, v, th, om;
 };
@@ -32,7 +87,7 @@ CTK_DEV void ode_substep(const EnvK& k, State4& s, float F, float sn, float cs) 
     float tmp = A * k.inv_mt;
     float D = k.k43l - k.k_mpl_mt * cs * cs;
     float Nn = k.g * sn - cs * tmp - k.k_jf * s.om;
-    float thdd = Nn / D;
+    float thdd = fdiv_pos(Nn, D);
     float xdd = tmp - k.k_mpl_mt * thdd * cs;
     float nx = s.x + k.dt * s.v;
     float nv = s.v + k.dt * xdd;
@@ -47,7 +102,7 @@ CTK_DEV void ode_step(const EnvK& k, State4& s, float q, float sn, float cs) {
     ode_substep(k, s, F, sn, cs);
     for (int i = 1; i < k.intermediate_steps; ++i) {
         float sn2, cs2;
-        sincosf(s.th, &sn2, &cs2);
+        ctk_sincosf(s.th, &sn2, &cs2);
         ode_substep(k, s, F, sn2, cs2);
     }
 }

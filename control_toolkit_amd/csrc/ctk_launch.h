@@ -5,6 +5,7 @@
 // ---- ctk_mppi.hip ---------------------------------------------------------------------------
 const char* ctk_mppi_rollout_ode_name(bool log);
 int ctk_mppi_num_blocks_ode(int N);
+size_t ctk_mppi_rollout_ode_lds(int P, int H);
 hipError_t ctk_launch_mppi_rollout_ode(hipStream_t st, const RolloutArgs& a, const EnvK& k, const MppiK& m,
                                        const float* samples, const float* u_nom, float* parts, bool log);
 hipError_t ctk_launch_mppi_merge_partial(hipStream_t st, const float* parts, int n_parts, int per_block, int P,

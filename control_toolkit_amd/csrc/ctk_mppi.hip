@@ -1,65 +1,191 @@
 // ctk_mppi.hip — MPPI on gfx950 (replaces reference Optimizers/optimizer_mppi.py:181-193).
 //
-//   ctk_mppi_rollout_ode   one thread per trajectory, 64-thread (one-wave) blocks:
-//        LDS tile of the block's [64,P] perturbations (coalesced HBM read, scaled by stdev)
-//        -> H fused steps {interpolate, add nominal, clip, stage cost, MPPI correction, Euler step}
-//        -> J[n]; block-local soft-min partial (rho_b, a_b, b_b[P]) by wave shuffles + LDS
-//           column sums (sum_n e_n * delta_u_n is linear in the inducing points, so the
-//           reduction runs over P values per trajectory instead of H).
+//   ctk_mppi_rollout_ode   64 trajectories per 256-thread block.  All four waves do the parts
+//        that do not depend on the state (coalesced HBM read of the block's [64,P] perturbation
+//        tile into LDS, interpolation + nominal + clip + MPPI correction for all H steps into an
+//        LDS input buffer); then ONE wave runs the H-step recurrence, one trajectory per lane,
+//        state in registers, inputs prefetched from LDS {stage cost, Euler step}; then all four
+//        waves form the block-local soft-min partial (rho_b, a_b, b_b[P]) by wave shuffles + LDS
+//        column sums (sum_n e_n * delta_u_n is linear in the inducing points, so the reduction
+//        runs over P values per trajectory instead of H).
 //   ctk_mppi_merge         merges partial records {rho, a, b[P]} (blocks of one GPU, or the
 //        all-gathered records of several GPUs — SURVEY.md 8e) and either emits one record or
 //        applies the update u_nom <- clip(shift(u_nom) + interp(b)/a)   (:163-168,:184,:190).
 #include "ctk_rollout.h"
 #include "ctk_launch.h"
 
-constexpr int MPPI_BLOCK = 64;
+#ifdef CTK_STAMPS   // diagnostic build (tools/diag_mppi_stamps.hip); never compiled into libctk_hip.so
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        unsigned long long _t;                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                 \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (threadIdx.x == 0 && a.stamps) a.stamps[blockIdx.x * 8 + (i)] = _t;                     \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
+constexpr int MPPI_TRAJ = 64;     // trajectories per block: one wave runs the recurrence
+constexpr int MPPI_WAVES = 4;     // waves per block: the prologue / epilogue are spread over all four
+constexpr int MPPI_BLOCK = MPPI_TRAJ * MPPI_WAVES;
+
+// LDS carve (floats): tile[64][ts] | ubuf[64][us] | corr[4][64] | e[64] | colsum[4][P] | w0,w1,un,i0 [H] each
+__host__ __device__ inline int ubuf_stride(int H) { return (H + 1) | 1; }
 
 template <bool LOG>
 __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout_ode(RolloutArgs a, EnvK k, MppiK m,
                                                                    const float* __restrict__ samples,
                                                                    const float* __restrict__ u_nom,
+                                                                   const InterpEntry* __restrict__ interp,
                                                                    float* __restrict__ parts) {
     extern __shared__ float lds[];
-    const int P = a.P, stride = tile_stride(P);
-    float* tile = lds;                        // [64][stride]
-    float* e_s = lds + MPPI_BLOCK * stride;   // [64]
-    const int lane = threadIdx.x;
-    const int row0 = blockIdx.x * MPPI_BLOCK;
+    const int P = a.P, H = a.H, ts = tile_stride(P), us = ubuf_stride(H);
+    float* tile = lds;                         // [64][ts]  stdev * noise at the inducing points
+    float* ubuf = tile + MPPI_TRAJ * ts;       // [64][us]  clipped inputs u_run
+    float* corr_s = ubuf + MPPI_TRAJ * us;     // [4][64]   per-wave partial MPPI correction costs
+    float* e_s = corr_s + MPPI_WAVES * MPPI_TRAJ;   // [64]
+    float* col_s = e_s + MPPI_TRAJ;            // [4][P]    per-wave partial column sums
+    float* w0_s = col_s + MPPI_WAVES * P;      // [H] [H] [H] [H]  per-step tables
+    float* w1_s = w0_s + H;
+    float* un_s = w1_s + H;
+    int* i0_s = reinterpret_cast<int*>(un_s + H);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int row0 = blockIdx.x * MPPI_TRAJ;
     const int n = row0 + lane;
     const bool valid = n < a.N;
 
-    load_tile<MPPI_BLOCK>(tile, samples, a, row0, m.stdev, /*normal*/ 0);
+    STAMP(0);
+    // ---- prologue 1 (256 threads): coalesced load (or Philox draw) of the sample tile, plus the
+    //      per-step tables (interpolation entry, shifted nominal input) into LDS ---------------------
+    {
+        const int rows = min(MPPI_TRAJ, a.N - row0);
+        if (rows < MPPI_TRAJ) {
+            for (int i = t; i < MPPI_TRAJ * ts; i += MPPI_BLOCK) tile[i] = 0.0f;   // rows beyond N read as zeros
+            __syncthreads();
+        } else if (t < MPPI_TRAJ) {
+            for (int c = P; c < ts; ++c) tile[t * ts + c] = 0.0f;                  // zero pad columns
+        }
+        for (int h = t; h < H; h += MPPI_BLOCK) {
+            const InterpEntry e = interp[h];
+            i0_s[h] = e.i0; w0_s[h] = e.w0; w1_s[h] = e.w1;
+            un_s[h] = u_nom[min(h + 1, H - 1)];                                    // optimizer_mppi.py:184 (shift)
+        }
+        if (samples != nullptr) {
+            const float* src = samples + (size_t)row0 * P;
+            const int total = rows * P;
+            if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+                // 16 B per lane, all loads of a batch in flight before the first LDS store
+                const float4* src4 = reinterpret_cast<const float4*>(src);
+                const int n4 = total >> 2;
+                for (int b0 = 0; b0 < n4; b0 += 4 * MPPI_BLOCK) {
+                    float4 v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i4 = b0 + j * MPPI_BLOCK + t;
+                        if (i4 < n4) v[j] = src4[i4];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i4 = b0 + j * MPPI_BLOCK + t;
+                        if (i4 < n4) {
+                            const int flat = i4 << 2;
+                            int r = P >= 2 ? (int)__umulhi((uint32_t)flat, a.p_magic) : flat, c = flat - r * P;
+                            const float e4[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                tile[r * ts + c] = e4[q] * m.stdev;
+                                if (++c == P) { c = 0; ++r; }
+                            }
+                        }
+                    }
+                }
+                for (int i = (n4 << 2) + t; i < total; i += MPPI_BLOCK) {
+                    const int r = i / P;
+                    tile[r * ts + (i - r * P)] = src[i] * m.stdev;
+                }
+            } else {
+                for (int i = t; i < total; i += MPPI_BLOCK) {
+                    const int r = i / P;
+                    tile[r * ts + (i - r * P)] = src[i] * m.stdev;
+                }
+            }
+        } else {
+            // on-device Philox: thread (wave, lane) draws column blocks cb = wave, wave+4, .. of row `lane`
+            const uint32_t grow = (uint32_t)(a.global_row0 + n);
+            for (int cb = wave; cb * 4 < P; cb += MPPI_WAVES) {
+                float d[4];
+                draw4(a, grow, (uint32_t)cb, 0, d);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (cb * 4 + j < P && valid) tile[lane * ts + cb * 4 + j] = d[j] * m.stdev;
+            }
+        }
+    }
     __syncthreads();
+    STAMP(1);
 
-    const float* my = tile + lane * stride;
-    const int H = a.H;
-    float corr = 0.0f;
-    float J = rollout_ode<LOG, LOG>(a, k, n, valid, [&](int h) {
-        const InterpEntry e = a.interp[h];                       // wave-uniform -> scalar loads
-        const float du = my[e.i0] * e.w0 + my[e.i0 + 1] * e.w1;  // Interpolator.py:97-106
-        const float un = u_nom[min(h + 1, H - 1)];               // optimizer_mppi.py:184 (shift)
-        const float u = fminf(fmaxf(un + du, a.lo), a.hi);       // :186-187
-        corr += m.cc * (m.k_dd * (du * du) + m.R * u * du + m.k_uu * (u * u));  // :154-155
-        return u;
-    });
-    J += corr;
-    if (valid) a.J[n] = J;
+    // ---- prologue 2 (256 threads): inputs of all H steps.  No dependence on the state, so this is
+    //      off the recurrence's critical path: interpolate, add the shifted nominal, clip, and
+    //      accumulate the MPPI control-cost correction.  Wave w takes steps h = w, w+4, ...
+    {
+        const float* my = tile + lane * ts;
+        float corr = 0.0f;
+        const bool ident = a.identity_interp != 0;
+#pragma unroll 4
+        for (int h = wave; h < H; h += MPPI_WAVES) {
+            float du;
+            if (ident) {
+                du = my[h];                                           // period 1: the matrix is the identity
+            } else {
+                const int i0 = i0_s[h];                               // LDS broadcast reads
+                du = my[i0] * w0_s[h] + my[i0 + 1] * w1_s[h];         // Interpolator.py:97-106
+            }
+            const float u = fminf(fmaxf(un_s[h] + du, a.lo), a.hi);   // optimizer_mppi.py:186-187
+            corr += m.cc * (m.k_dd * (du * du) + m.R * u * du + m.k_uu * (u * u));   // :154-155
+            ubuf[lane * us + h] = u;
+            if constexpr (LOG) {
+                if (valid) a.Q_out[(size_t)n * H + h] = u;
+            }
+        }
+        corr_s[wave * MPPI_TRAJ + lane] = corr;
+    }
+    __syncthreads();
+    STAMP(2);
 
-    // block-local soft-min partial (optimizer_mppi.py:163-168 restricted to this block)
-    const float Jv = valid ? J : INFINITY;
-    const float rho = wave_min(Jv);
-    const float e = valid ? expf(m.neg_inv_lbd * (J - rho)) : 0.0f;
-    const float asum = wave_sum(e);
-    e_s[lane] = e;
+    // ---- the recurrence: wave 0 only, one trajectory per lane ------------------------------------
+    float e = 0.0f;
+    if (wave == 0) {
+        const float* myu = ubuf + lane * us;
+        float J = rollout_ode<false, LOG>(a, k, n, valid, [&](int h) { return myu[h]; });
+        J += (corr_s[lane] + corr_s[MPPI_TRAJ + lane]) + (corr_s[2 * MPPI_TRAJ + lane] + corr_s[3 * MPPI_TRAJ + lane]);
+        STAMP(3);
+        if (valid) a.J[n] = J;
+        // block-local soft-min partial (optimizer_mppi.py:163-168 restricted to this block)
+        const float rho = wave_min(valid ? J : INFINITY);
+        e = valid ? expf(m.neg_inv_lbd * (J - rho)) : 0.0f;
+        const float asum = wave_sum(e);
+        e_s[lane] = e;
+        if (lane == 0) {
+            float* rec = parts + (size_t)blockIdx.x * (2 + P);
+            rec[0] = rho; rec[1] = asum;
+        }
+    }
+    __syncthreads();
+    STAMP(4);
+
+    // ---- epilogue (256 threads): b_b[p] = sum_r e_r * tile[r][p]; wave w sums rows 16w..16w+15 -----
+    for (int p = lane; p < P; p += 64) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc += e_s[wave * 16 + r] * tile[(wave * 16 + r) * ts + p];
+        col_s[wave * P + p] = acc;
+    }
     __syncthreads();
     float* rec = parts + (size_t)blockIdx.x * (2 + P);
-    if (lane == 0) { rec[0] = rho; rec[1] = asum; }
-    for (int p = lane; p < P; p += MPPI_BLOCK) {
-        float acc = 0.0f;
-#pragma unroll 8
-        for (int r = 0; r < MPPI_BLOCK; ++r) acc += e_s[r] * tile[r * stride + p];
-        rec[2 + p] = acc;
-    }
+    for (int p = t; p < P; p += MPPI_BLOCK) rec[2 + p] = (col_s[p] + col_s[P + p]) + (col_s[2 * P + p] + col_s[3 * P + p]);
+    STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -158,18 +284,20 @@ const char* ctk_mppi_rollout_ode_name(bool log) {
     return log ? "ctk_mppi_rollout_ode<true>" : "ctk_mppi_rollout_ode<false>";
 }
 
-int ctk_mppi_num_blocks_ode(int N) { return (N + MPPI_BLOCK - 1) / MPPI_BLOCK; }
+int ctk_mppi_num_blocks_ode(int N) { return (N + MPPI_TRAJ - 1) / MPPI_TRAJ; }
 
-size_t ctk_mppi_rollout_ode_lds(int P) { return (size_t)(MPPI_BLOCK * tile_stride(P) + MPPI_BLOCK) * sizeof(float); }
+size_t ctk_mppi_rollout_ode_lds(int P, int H) {
+    return (size_t)(MPPI_TRAJ * tile_stride(P) + MPPI_TRAJ * ubuf_stride(H) + MPPI_WAVES * MPPI_TRAJ + MPPI_TRAJ + MPPI_WAVES * P + 4 * H) * sizeof(float);
+}
 
 hipError_t ctk_launch_mppi_rollout_ode(hipStream_t st, const RolloutArgs& a, const EnvK& k, const MppiK& m,
                                        const float* samples, const float* u_nom, float* parts, bool log) {
     const int blocks = ctk_mppi_num_blocks_ode(a.N);
-    const size_t lds = ctk_mppi_rollout_ode_lds(a.P);
+    const size_t lds = ctk_mppi_rollout_ode_lds(a.P, a.H);
     if (log)
-        hipLaunchKernelGGL(ctk_mppi_rollout_ode<true>, dim3(blocks), dim3(MPPI_BLOCK), lds, st, a, k, m, samples, u_nom, parts);
+        hipLaunchKernelGGL(ctk_mppi_rollout_ode<true>, dim3(blocks), dim3(MPPI_BLOCK), lds, st, a, k, m, samples, u_nom, a.interp, parts);
     else
-        hipLaunchKernelGGL(ctk_mppi_rollout_ode<false>, dim3(blocks), dim3(MPPI_BLOCK), lds, st, a, k, m, samples, u_nom, parts);
+        hipLaunchKernelGGL(ctk_mppi_rollout_ode<false>, dim3(blocks), dim3(MPPI_BLOCK), lds, st, a, k, m, samples, u_nom, a.interp, parts);
     return hipGetLastError();
 }
 

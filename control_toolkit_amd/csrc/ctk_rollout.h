@@ -56,10 +56,12 @@ CTK_DEV float rollout_ode(const RolloutArgs& a, const EnvK& k, int n, bool valid
     if constexpr (WRITE_TRAJ) {
         if (a.traj_out) traj = reinterpret_cast<float4*>(a.traj_out) + (size_t)n * (H + 1);
     }
+    float u_next = ufn(0);
     for (int h = 0; h < H; ++h) {
-        const float u = ufn(h);
+        const float u = u_next;
+        if (h + 1 < H) u_next = ufn(h + 1);   // issued a whole step ahead of its use: LDS latency hidden
         float sn, cs;
-        sincosf(s.th, &sn, &cs);
+        ctk_sincosf(s.th, &sn, &cs);
         csum += stage_cost(k, s, cs, u, uprev);
         if constexpr (WRITE_TRAJ) {
             if (valid && traj) traj[h] = make_float4(s.x, s.v, s.th, s.om);

@@ -1,0 +1,138 @@
+"""-m gpu: CEM and random-action through the C ABI against the oracle (their reference modules
+import tensorflow at module level and cannot be executed here: the oracle follows the source
+text of optimizer_cem_tf.py / optimizer_random_action_tf.py — parity unpinned by a reference run)."""
+import numpy as np
+import pytest
+
+from oracle import ctk_oracle as O
+from control_toolkit_amd import CtkEngine
+from gpu_helpers import apply_env
+
+pytestmark = pytest.mark.gpu
+
+
+def make_cem(N, H, K, its, env, **kw):
+    pred = O.Predictor("ODE", dt=0.02, env=env)
+    o = O.CEM(pred, O.Cost(env), num_rollouts=N, mpc_horizon=H, cem_outer_it=its, cem_best_k=K, **kw)
+    e = CtkEngine("cem", "ODE", num_rollouts=N, mpc_horizon=H, dt=0.02, cem_outer_it=its, cem_best_k=K,
+                  cem_initial_action_stdev=kw.get("cem_initial_action_stdev", 0.5), cem_stdev_min=kw.get("cem_stdev_min", 0.01),
+                  warmup=int(kw.get("warmup", False)), warmup_iterations=kw.get("warmup_iterations", 250),
+                  materialize_trajectories=True)
+    apply_env(e, env)
+    return pred, o, e
+
+
+@pytest.mark.parametrize("N,H,K,its", [(4096, 30, 409, 3), (200, 40, 40, 3), (64, 8, 64, 1), (100, 5, 1, 2)])
+def test_cem_matches_oracle(N, H, K, its):
+    env = O.EnvParams(terminal_weight=0.2)
+    pred, o, e = make_cem(N, H, K, its, env)
+    rng = np.random.default_rng(N)
+    s = np.array([0.02, 0.1, 2.9, -0.5], np.float32)
+    for t in range(3):
+        noise = rng.standard_normal((its, N, H, 1)).astype(np.float32)
+        uo = o.step(s, noise)
+        ug = e.step(s, noise)
+        Jg = e.read("J")
+        np.testing.assert_allclose(Jg, o.J, rtol=3e-5)
+        np.testing.assert_allclose(e.read("Q"), o.Q, rtol=1e-5, atol=2e-6)
+        # elite set: identical unless two costs are closer than the fp32 cost tolerance at the cut
+        bg = e.read("BEST_IDX")
+        srt = np.sort(o.J)
+        gap_ok = (srt[K] - srt[K - 1]) > 1e-4 * abs(srt[K - 1]) if K < N else True
+        if gap_ok:
+            assert set(bg.tolist()) == set(o.best_idx.tolist())
+        assert np.all(np.diff(Jg[bg]) >= 0)                      # sorted ascending (tf.argsort)
+        assert bg[0] == np.argmin(Jg)
+        np.testing.assert_allclose(e.read("U_NOM"), o.dist_mue, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(e.read("STD"), o.stdev, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(ug[0], uo, rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(e.read("TRAJ"), o.rollout_trajectories, rtol=1e-4, atol=4e-5)
+        s = pred.step(s.reshape(1, 4), np.array([uo], np.float32))[0]
+    e.close()
+
+
+def test_cem_warmup_and_reset():
+    env = O.EnvParams()
+    pred, o, e = make_cem(128, 10, 16, 2, env, warmup=True, warmup_iterations=5)
+    rng = np.random.default_rng(1)
+    s = np.array([0.0, 0.0, 3.0, 0.0], np.float32)
+    assert e.samples_needed() == 5 * 128 * 10            # first step runs warmup_iterations (optimizer_cem_tf.py:92)
+    n0 = rng.standard_normal((5, 128, 10, 1)).astype(np.float32)
+    np.testing.assert_allclose(e.step(s, n0)[0], o.step(s, n0), rtol=1e-5, atol=2e-6)
+    assert e.samples_needed() == 2 * 128 * 10
+    n1 = rng.standard_normal((2, 128, 10, 1)).astype(np.float32)
+    np.testing.assert_allclose(e.step(s, n1)[0], o.step(s, n1), rtol=1e-5, atol=2e-6)
+    e.reset(); o.optimizer_reset()
+    np.testing.assert_array_equal(e.read("U_NOM"), o.dist_mue)
+    np.testing.assert_array_equal(e.read("STD"), o.stdev)
+    assert e.samples_needed() == 5 * 128 * 10
+    e.close()
+
+
+def test_cem_best_k_equals_n_gives_population_mean():
+    env = O.EnvParams()
+    N, H = 256, 12
+    _, o, e = make_cem(N, H, N, 1, env)
+    noise = np.random.default_rng(2).standard_normal((1, N, H, 1)).astype(np.float32)
+    s = np.array([0.1, 0.0, 0.5, 0.0], np.float32)
+    e.step(s, noise)
+    Q = e.read("Q")
+    # mu (before the shift) == mean(Q)  (SURVEY 4); after the shift mu[h] == mean(Q)[h+1]
+    np.testing.assert_allclose(e.read("U_NOM")[0, :-1, 0], Q.mean(0)[1:, 0], rtol=1e-5, atol=1e-6)
+    assert e.read("U_NOM")[0, -1, 0] == 0.0 and e.read("STD")[0, -1, 0] == np.float32(0.5)
+    e.close()
+
+
+@pytest.mark.parametrize("N,H", [(32, 10), (320, 35), (1000, 20)])
+def test_random_action_matches_oracle(N, H):
+    # (32, 10) is BASELINE config 1
+    env = O.EnvParams(terminal_weight=0.1)
+    pred = O.Predictor("ODE", dt=0.02, env=env)
+    o = O.RandomAction(pred, O.Cost(env), num_rollouts=N, mpc_horizon=H)
+    e = CtkEngine("random_action", "ODE", num_rollouts=N, mpc_horizon=H, dt=0.02, materialize_trajectories=True)
+    apply_env(e, env)
+    rng = np.random.default_rng(N)
+    s = np.array([0.0, 0.1, 0.5, -0.2], np.float32)
+    for t in range(3):
+        u01 = rng.random((N, H, 1), dtype=np.float32)
+        uo = o.step(s, u01)
+        ug = e.step(s, u01)
+        np.testing.assert_allclose(e.read("Q"), o.Q, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(e.read("J"), o.J, rtol=3e-5)
+        assert int(e.read("BEST_IDX")[0]) == int(o.best_idx)
+        np.testing.assert_array_equal(ug[0], uo)
+        s = pred.step(s.reshape(1, 4), np.array([uo], np.float32))[0]
+    e.close()
+
+
+def test_device_rng_cem_and_random_run():
+    e = CtkEngine("cem", "ODE", num_rollouts=512, mpc_horizon=20, dt=0.02, cem_outer_it=2, cem_best_k=50, seed=3)
+    s = np.array([0.0, 0.0, 3.0, 0.0], np.float32)
+    u = e.step(s)
+    Q = e.read("Q")
+    assert np.isfinite(u).all() and abs(Q.mean()) < 0.1 and 0.2 < Q.std() < 0.7
+    noise_like = O.device_noise(seed=3, stream=1, call=0, first_row=0, rows=512, cols=20, kind="normal")
+    assert noise_like.shape == (512, 20)
+    e.close()
+    r = CtkEngine("random_action", "ODE", num_rollouts=256, mpc_horizon=10, dt=0.02, seed=4)
+    u = r.step(s)
+    Q = r.read("Q")
+    exp = O.device_noise(seed=4, stream=0, call=0, first_row=0, rows=256, cols=10, kind="uniform") * 2 - 1
+    np.testing.assert_allclose(Q[:, :, 0], exp, rtol=0, atol=1e-6)
+    assert u[0] == Q[np.argmin(r.read("J")), 0, 0]
+    r.close()
+
+
+def test_plain_rollout_matches_oracle():
+    env = O.EnvParams(terminal_weight=0.4)
+    pred = O.Predictor("ODE", dt=0.02, env=env)
+    cost = O.Cost(env)
+    e = CtkEngine("mppi", "ODE", num_rollouts=64, mpc_horizon=25, dt=0.02)
+    apply_env(e, env)
+    Q = np.random.default_rng(0).uniform(-1.5, 1.5, (10, 25, 1)).astype(np.float32)   # beyond the limits: taken as given
+    s = np.array([0.1, 0.2, 1.0, -1.0], np.float32)
+    traj, J = e.rollout(s, Q, u_prev=0.3)
+    to = pred.predict_core(np.tile(s, (10, 1)), Q)
+    np.testing.assert_allclose(traj, to, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(J, cost.get_trajectory_cost(to, Q, np.array([0.3], np.float32)), rtol=3e-5)
+    e.close()

@@ -65,7 +65,10 @@ def test_mppi_matches_oracle_seeded(N, H, p):
         uo = o.step(s, noise)
         ug = e.step(s, noise)
         np.testing.assert_allclose(e.read("J"), o.J, rtol=3e-5)
-        np.testing.assert_allclose(e.read("TRAJ"), o.rollout_trajectories, rtol=1e-4, atol=2e-5)
+        # states: rtol 1e-4 after H = 50 steps.  The upright pendulum is an unstable
+        # equilibrium (e-folding time sqrt(l/g) ~ 0.14 s = 7 steps), so 1-ulp differences (FMA
+        # contraction, reciprocal-based division) grow along the horizon: atol scales with H.
+        np.testing.assert_allclose(e.read("TRAJ"), o.rollout_trajectories, rtol=1e-4, atol=2e-5 * max(1, H // 25))
         np.testing.assert_allclose(e.read("U_NOM"), o.u_nom, **U_TOL)
         np.testing.assert_allclose(ug[0], uo, **U_TOL)
         s = pred.step(s.reshape(1, 4), np.array([uo], np.float32))[0]
