@@ -8,6 +8,7 @@
 
 #include "ctk_launch.h"
 #include "ctk_device.h"   // tile_stride
+#include "ctk_mlp.h"      // mlp_hid, per-lane weight layout
 
 namespace {
 
@@ -44,10 +45,12 @@ struct ctk_handle {
     float* d_u = nullptr;       // optimizer's last output (device)
     float* h_u = nullptr;       // pinned, device-visible host copy of u
     float* h_u_dev = nullptr;   // device pointer aliasing h_u
-    float* d_weights = nullptr; // MLP
+    float* d_weights = nullptr; // MLP: raw [1380]
+    float* d_wperm = nullptr;   // MLP: per-lane permuted, forward [64][48] then backward [64][28]
     int count = 0;              // CEM / RPGD step counter
     uint32_t call = 0;          // Philox call counter
     bool mppi_pending = false;  // between step_begin and step_end
+    bool have_weights = false;  // MLP weights uploaded
     // profiling
     bool prof = false;
     std::vector<EventPair> events;
@@ -114,6 +117,41 @@ void refresh_constants(ctk_handle* h) {
     m.cc = c.cc_weight;
     m.neg_inv_lbd = (float)(-1.0 / (double)c.LBD);
     h->mk = m;
+}
+
+// Per-lane MFMA operand layout of the MLP weights (ctk_mlp.h header comment).
+// raw: W1[32,5] b1[32] W2[32,32] b2[32] W3[4,32] b3[4].  out: fwd [64][48] | bwd [64][28].
+std::vector<float> permute_mlp_weights(const float* raw) {
+    const float* W1 = raw;                 const float* b1 = W1 + 32 * 5;
+    const float* W2 = b1 + 32;             const float* b2 = W2 + 32 * 32;
+    const float* W3 = b2 + 32;             const float* b3 = W3 + 4 * 32;
+    std::vector<float> out((size_t)64 * (MLP_FWD_PER_LANE + MLP_BWD_PER_LANE), 0.0f);
+    for (int l = 0; l < 64; ++l) {
+        const int i = l & 15, g = l >> 4;
+        float* f = out.data() + (size_t)l * MLP_FWD_PER_LANE;
+        for (int m = 0; m < 2; ++m)
+            for (int ks = 0; ks < 2; ++ks) {
+                const int kk = 4 * ks + g;
+                f[m * 2 + ks] = kk < 5 ? W1[(16 * m + i) * 5 + kk] : 0.0f;
+            }
+        for (int mo = 0; mo < 2; ++mo)
+            for (int j = 0; j < 8; ++j) f[4 + mo * 8 + j] = W2[(16 * mo + i) * 32 + mlp_hid(j, g)];
+        for (int j = 0; j < 8; ++j) f[20 + j] = (i % 4 == 0) ? W3[(i / 4) * 32 + mlp_hid(j, g)] : 0.0f;
+        for (int m = 0; m < 2; ++m)
+            for (int r = 0; r < 4; ++r) {
+                f[28 + m * 4 + r] = b1[16 * m + 4 * g + r];
+                f[36 + m * 4 + r] = b2[16 * m + 4 * g + r];
+            }
+        for (int r = 0; r < 4; ++r) f[44 + r] = (r == 0) ? b3[g] : 0.0f;
+        // backward (vector-Jacobian products, used by RPGD): A operands of W3^T, W2^T, W1^T
+        float* b = out.data() + (size_t)64 * MLP_FWD_PER_LANE + (size_t)l * MLP_BWD_PER_LANE;
+        for (int m = 0; m < 2; ++m) b[m] = W3[g * 32 + 16 * m + i];                       // rows: hidden, k: output comp g
+        for (int mi = 0; mi < 2; ++mi)
+            for (int j = 0; j < 8; ++j) b[2 + mi * 8 + j] = W2[mlp_hid(j, g) * 32 + 16 * mi + i];   // rows: hidden_in, k: hidden_out
+        const int inp = (i % 4 == 0) ? i / 4 : (i == 1 ? 4 : -1);                          // rows 0,4,8,12 -> state 0..3; row 1 -> input
+        for (int j = 0; j < 8; ++j) b[18 + j] = inp >= 0 ? W1[mlp_hid(j, g) * 5 + inp] : 0.0f;
+    }
+    return out;
 }
 
 void default_params(float* p) {
@@ -189,13 +227,11 @@ RolloutArgs make_args(ctk_handle* h, const float* s, const float* u_prev, int N,
     return a;
 }
 
-struct ProfScope {   // HIP events around the dominant kernel, on the handle's stream
-    ctk_handle* h; bool on;
-    explicit ProfScope(ctk_handle* hh) : h(hh), on(hh->prof && hh->ev_used < hh->events.size()) {
-        if (on) hipEventRecord(h->events[h->ev_used].a, h->stream);
-    }
-    ~ProfScope() {
-        if (on) { hipEventRecord(h->events[h->ev_used].b, h->stream); ++h->ev_used; }
+// Event pair for the next dominant-kernel launch (nullptrs when profiling is off / ring is full).
+struct ProfSlot {
+    hipEvent_t a = nullptr, b = nullptr;
+    explicit ProfSlot(ctk_handle* h) {
+        if (h->prof && h->ev_used < h->events.size()) { a = h->events[h->ev_used].a; b = h->events[h->ev_used].b; ++h->ev_used; }
     }
 };
 
@@ -206,21 +242,26 @@ int finish_step(ctk_handle* h, float* u_out) {
     return CTK_OK;
 }
 
+int check_predictor(ctk_handle* h) {
+    if (h->cfg.predictor == CTK_PRED_MLP && !h->have_weights)
+        return fail(h, CTK_ERR_STATE, "MLP predictor: call ctk_set_predictor_weights before stepping");
+    return CTK_OK;
+}
+
 // ---- MPPI ------------------------------------------------------------------------------------
 int mppi_rollout(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc) {
     const float* d_s = nullptr;
     if (int rc = resolve_samples(h, samples, loc, (size_t)h->N * h->P, &d_s)) return rc;
     RolloutArgs a = make_args(h, s, u_prev, h->N, h->P);
     const bool log = h->cfg.materialize_trajectories != 0;
-    if (h->cfg.predictor != CTK_PRED_ODE) return fail(h, CTK_ERR_UNSUPPORTED, "MPPI: predictor not built yet");
-    {
-        ProfScope ps(h);
-        HIP_TRY(h, ctk_launch_mppi_rollout_ode(h->stream, a, h->k, h->mk, d_s, h->d_unom[h->cur], h->d_parts, log));
-    }
+    if (int rc = check_predictor(h)) return rc;
+    ProfSlot ps(h);
+    HIP_TRY(h, ctk_launch_mppi_rollout(h->stream, h->cfg.predictor, a, h->k, h->mk, d_s, h->d_unom[h->cur], h->d_wperm,
+                                       h->d_parts, log, ps.a, ps.b));
     return CTK_OK;
 }
 
-int mppi_block_parts(const ctk_handle* h) { return ctk_mppi_num_blocks_ode(h->N); }
+int mppi_block_parts(const ctk_handle* h) { return ctk_mppi_num_blocks(h->N); }
 
 // reduce the block records to <= 2048 records (hierarchical when the grid was huge)
 int mppi_reduce_blocks(ctk_handle* h, const float** parts, int* n_parts) {
@@ -245,7 +286,7 @@ int mppi_update(ctk_handle* h, const float* parts, int n_parts, float* u_out) {
 
 // ---- CEM --------------------------------------------------------------------------------------
 int cem_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc, float* u_out) {
-    if (h->cfg.predictor != CTK_PRED_ODE) return fail(h, CTK_ERR_UNSUPPORTED, "CEM: predictor not built yet");
+    if (int rc = check_predictor(h)) return rc;
     const int its = cem_iterations(h);
     const size_t per_it = (size_t)h->N * h->H;
     const float* d_s = nullptr;
@@ -255,10 +296,9 @@ int cem_step(ctk_handle* h, const float* s, const float* u_prev, const float* sa
     for (int it = 0; it < its; ++it) {
         RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);
         a.stream_id = (uint32_t)it;
-        {
-            ProfScope ps(h);
-            HIP_TRY(h, ctk_launch_affine_rollout_ode(h->stream, a, h->k, d_s ? d_s + per_it * it : nullptr, 0, mu, h->d_std, log));
-        }
+        ProfSlot ps(h);
+        HIP_TRY(h, ctk_launch_affine_rollout(h->stream, h->cfg.predictor, a, h->k, d_s ? d_s + per_it * it : nullptr, 0, mu,
+                                             h->d_std, h->d_wperm, log, ps.a, ps.b));
         HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, h->cfg.cem_best_k, h->d_idx, nullptr));
         HIP_TRY(h, ctk_launch_cem_refit(h->stream, h->d_Q, h->d_idx, h->cfg.cem_best_k, h->H, mu, h->d_std));
     }
@@ -271,15 +311,13 @@ int cem_step(ctk_handle* h, const float* s, const float* u_prev, const float* sa
 
 // ---- random action ----------------------------------------------------------------------------
 int random_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc, float* u_out) {
-    if (h->cfg.predictor != CTK_PRED_ODE) return fail(h, CTK_ERR_UNSUPPORTED, "random-action: predictor not built yet");
+    if (int rc = check_predictor(h)) return rc;
     const float* d_s = nullptr;
     if (int rc = resolve_samples(h, samples, loc, (size_t)h->N * h->H, &d_s)) return rc;
     RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);
-    {
-        ProfScope ps(h);
-        HIP_TRY(h, ctk_launch_affine_rollout_ode(h->stream, a, h->k, d_s, 1, h->d_base, h->d_scale,
-                                                 h->cfg.materialize_trajectories != 0));
-    }
+    ProfSlot ps(h);
+    HIP_TRY(h, ctk_launch_affine_rollout(h->stream, h->cfg.predictor, a, h->k, d_s, 1, h->d_base, h->d_scale, h->d_wperm,
+                                         h->cfg.materialize_trajectories != 0, ps.a, ps.b));
     HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, 1, h->d_idx, nullptr));
     HIP_TRY(h, ctk_launch_pick_best_first(h->stream, h->d_Q, h->d_idx, h->H, h->d_u, h->h_u_dev));
     return finish_step(h, u_out);
@@ -351,7 +389,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     const size_t N = h->N, H = h->H, P = h->P;
     // LDS budget of the rollout tiles (one wave per block): 64 * stride * 4 B <= 160 KiB
     {
-        const size_t lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_ode_lds((int)P, (int)H)
+        const size_t lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_lds((int)P, (int)H)
                                                           : (size_t)(64 * tile_stride((int)P)) * sizeof(float);
         if (lds > 160 * 1024) { h->err = "horizon too long for the LDS sample tiles (160 KiB per CU)"; return bail(CTK_ERR_UNSUPPORTED); }
     }
@@ -376,13 +414,14 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     TRY_CREATE(dev_alloc(h, &h->d_idx, N));
     TRY_CREATE(dev_alloc(h, &h->d_u, 1));
     TRY_CREATE(dev_alloc(h, &h->d_weights, CTK_MLP_NW));
+    TRY_CREATE(dev_alloc(h, &h->d_wperm, (size_t)64 * (MLP_FWD_PER_LANE + MLP_BWD_PER_LANE)));
     HIP_CREATE(hipHostMalloc((void**)&h->h_u, 64, hipHostMallocMapped));
     *h->h_u = 0.0f;
     HIP_CREATE(hipHostGetDevicePointer((void**)&h->h_u_dev, h->h_u, 0));
 
     switch (cfg->optimizer) {
-        case CTK_OPT_MPPI: h->dominant = ctk_mppi_rollout_ode_name(cfg->materialize_trajectories != 0); break;
-        default: h->dominant = ctk_affine_rollout_ode_name(cfg->materialize_trajectories != 0); break;
+        case CTK_OPT_MPPI: h->dominant = ctk_mppi_rollout_name(cfg->predictor, cfg->materialize_trajectories != 0); break;
+        default: h->dominant = ctk_affine_rollout_name(cfg->predictor, cfg->materialize_trajectories != 0); break;
     }
     if (cfg->optimizer != CTK_OPT_RPGD) TRY_CREATE(ctk_reset(h, nullptr, CTK_LOC_NONE));
     HIP_CREATE(hipStreamSynchronize(h->stream));
@@ -398,7 +437,7 @@ void ctk_destroy(ctk_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (auto& e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     void* bufs[] = {h->d_interp, h->d_samples, h->d_J, h->d_Q, h->d_traj, h->d_parts, h->d_parts2, h->d_unom[0], h->d_unom[1],
-                    h->d_std, h->d_base, h->d_scale, h->d_idx, h->d_u, h->d_weights};
+                    h->d_std, h->d_base, h->d_scale, h->d_idx, h->d_u, h->d_weights, h->d_wperm};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_u) hipHostFree(h->h_u);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -460,7 +499,10 @@ int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n) {
     if (n != (size_t)CTK_MLP_NW) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_set_predictor_weights: expected 1380 floats");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipMemcpyAsync(h->d_weights, w, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    const std::vector<float> perm = permute_mlp_weights(w);
+    HIP_TRY(h, hipMemcpyAsync(h->d_wperm, perm.data(), perm.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->have_weights = true;
     return CTK_OK;
 }
 
@@ -511,7 +553,7 @@ int ctk_mppi_step_end(ctk_handle* h, const float* parts_dev, int n_parts, float*
 int ctk_rollout(ctk_handle* h, const float* s, const float* u_prev, const float* Q, int n, float* traj_out, float* J_out) {
     if (!h || !s || !Q) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_rollout: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
     if (n < 1 || n > h->N) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_rollout: need 1 <= n <= num_rollouts");
-    if (h->cfg.predictor != CTK_PRED_ODE) return fail(h, CTK_ERR_UNSUPPORTED, "ctk_rollout: predictor not built yet");
+    if (int rc = check_predictor(h)) return rc;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const size_t H = h->H;
     const float* d_s = nullptr;
@@ -529,7 +571,7 @@ int ctk_rollout(ctk_handle* h, const float* s, const float* u_prev, const float*
     RolloutArgs a = make_args(h, s, u_prev, n, (int)H);
     a.lo = -INFINITY; a.hi = INFINITY;
     a.traj_out = traj_out ? d_traj : nullptr;
-    hipError_t e = ctk_launch_affine_rollout_ode(h->stream, a, h->k, d_s, 0, d_zero, d_one, traj_out != nullptr);
+    hipError_t e = ctk_launch_affine_rollout(h->stream, h->cfg.predictor, a, h->k, d_s, 0, d_zero, d_one, h->d_wperm, traj_out != nullptr);
     if (e == hipSuccess && traj_out)
         e = hipMemcpyAsync(traj_out, d_traj, (size_t)n * (H + 1) * CTK_S * sizeof(float), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess && J_out) e = hipMemcpyAsync(J_out, h->d_J, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream);

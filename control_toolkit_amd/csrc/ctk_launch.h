@@ -1,13 +1,24 @@
 // ctk_launch.h — host-callable launchers implemented in the kernel translation units.
 #pragma once
+#include <hip/hip_ext.h>
 #include "ctk_common.h"
 
+// Launch with the dispatch's own begin/end timestamps attached to (ev_start, ev_stop) when given
+// (hipExtLaunchKernelGGL): the measured interval is the kernel, not the queue around it.
+#define CTK_LAUNCH(kernel, grid, block, lds, st, e0, e1, ...)                                         \
+    do {                                                                                              \
+        if (e0) hipExtLaunchKernelGGL(kernel, grid, block, lds, st, e0, e1, 0, __VA_ARGS__);          \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                           \
+    } while (0)
+
 // ---- ctk_mppi.hip ---------------------------------------------------------------------------
-const char* ctk_mppi_rollout_ode_name(bool log);
-int ctk_mppi_num_blocks_ode(int N);
-size_t ctk_mppi_rollout_ode_lds(int P, int H);
-hipError_t ctk_launch_mppi_rollout_ode(hipStream_t st, const RolloutArgs& a, const EnvK& k, const MppiK& m,
-                                       const float* samples, const float* u_nom, float* parts, bool log);
+const char* ctk_mppi_rollout_name(int pred, bool log);
+int ctk_mppi_num_blocks(int N);
+size_t ctk_mppi_rollout_lds(int P, int H);
+// wperm: per-lane permuted MLP weights (ctk_api.hip: permute_mlp_weights), nullptr for the ODE predictor
+hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const MppiK& m,
+                                   const float* samples, const float* u_nom, const float* wperm, float* parts, bool log,
+                                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t ctk_launch_mppi_merge_partial(hipStream_t st, const float* parts, int n_parts, int per_block, int P,
                                          float neg_inv_lbd, float* out_rec);
 hipError_t ctk_launch_mppi_update(hipStream_t st, const float* parts, int n_parts, int P, float neg_inv_lbd, int H,
@@ -15,10 +26,11 @@ hipError_t ctk_launch_mppi_update(hipStream_t st, const float* parts, int n_part
                                   float* u_dev, float* u_host);
 
 // ---- ctk_sampled.hip : u[n,h] = clip(base[h] + sample[n,h] * scale[h]) rollouts, selection ----
-const char* ctk_affine_rollout_ode_name(bool log);
+const char* ctk_affine_rollout_name(int pred, bool log);
 // samples [N,H] (device) or nullptr (Philox, rng_kind 0 normal / 1 uniform); base/scale [H] device.
-hipError_t ctk_launch_affine_rollout_ode(hipStream_t st, const RolloutArgs& a, const EnvK& k, const float* samples,
-                                         int rng_kind, const float* base, const float* scale, bool log);
+hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const float* samples,
+                                     int rng_kind, const float* base, const float* scale, const float* wperm, bool log,
+                                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // Smallest-K selection under the total order (J, index) and CEM refit
 // (optimizer_cem_tf.py:73-78): idx_out[K] ascending, mu/std [H] from Q[idx].
 hipError_t ctk_launch_select_topk(hipStream_t st, const float* J, int N, int K, int* idx_out, unsigned* scratch);

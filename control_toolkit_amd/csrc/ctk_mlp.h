@@ -1,0 +1,161 @@
+// ctk_mlp.h — the 5-32-32-4 tanh MLP predictor on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate — bit-for-bit a k-ordered fmaf
+// chain, so parity with the fp32 oracle is a summation-order matter only).
+//
+// One wave owns 16 trajectories for all H steps; nothing leaves registers between layers.
+// The products are formed TRANSPOSED, Z[out, traj] = W[out, k] * X[k, traj], so that the
+// accumulator layout of one layer IS the B-operand layout of the next:
+//   lane l: c = l & 15 (trajectory), g = l >> 4
+//   A operand: lane holds A[row = l&15][k = g]          (weights, pre-permuted per lane on the host)
+//   B operand: lane holds B[k = g][col = c]             (activations of trajectory c)
+//   C/D      : lane, reg r holds D[row = 4g + r][col = c]
+// A D tile (rows = 16 neurons) therefore supplies, in its register r, the B operand of the k-step
+// whose k-slot g is neuron 4g + r: the k order is permuted (hid(j, g) = 16(j>>2) + 4g + (j&3)),
+// and the weights are stored in that same order.  The state lives as "lane (c, g) holds component
+// g of trajectory c": it is the B operand of layer 1 as it stands, and layer 3's weight rows are
+// placed at rows {0,4,8,12} so that its output register 0 is again component g.
+#pragma once
+#include "ctk_device.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MLP_FWD_PER_LANE = 48;   // floats per lane, forward  (12 x float4)
+constexpr int MLP_BWD_PER_LANE = 28;   // floats per lane, backward ( 7 x float4; 26 used)
+
+__host__ __device__ inline int mlp_hid(int j, int g) { return 16 * (j >> 2) + 4 * g + (j & 3); }
+
+struct MlpFwdW {
+    float w1[2][2];   // [out tile m][k-step]
+    float w2[2][8];   // [out tile][k-step]
+    float w3[8];      // [k-step]
+    f32x4 b1[2], b2[2], b3;
+};
+
+CTK_DEV MlpFwdW mlp_load_fwd(const float* __restrict__ wperm) {
+    const float4* p = reinterpret_cast<const float4*>(wperm) + (threadIdx.x & 63) * (MLP_FWD_PER_LANE / 4);
+    float4 v[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v[i] = p[i];
+    MlpFwdW w;
+    w.w1[0][0] = v[0].x; w.w1[0][1] = v[0].y; w.w1[1][0] = v[0].z; w.w1[1][1] = v[0].w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int mo = i >> 1, j0 = (i & 1) * 4;
+        w.w2[mo][j0] = v[1 + i].x; w.w2[mo][j0 + 1] = v[1 + i].y; w.w2[mo][j0 + 2] = v[1 + i].z; w.w2[mo][j0 + 3] = v[1 + i].w;
+    }
+    w.w3[0] = v[5].x; w.w3[1] = v[5].y; w.w3[2] = v[5].z; w.w3[3] = v[5].w;
+    w.w3[4] = v[6].x; w.w3[5] = v[6].y; w.w3[6] = v[6].z; w.w3[7] = v[6].w;
+    w.b1[0] = f32x4{v[7].x, v[7].y, v[7].z, v[7].w};
+    w.b1[1] = f32x4{v[8].x, v[8].y, v[8].z, v[8].w};
+    w.b2[0] = f32x4{v[9].x, v[9].y, v[9].z, v[9].w};
+    w.b2[1] = f32x4{v[10].x, v[10].y, v[10].z, v[10].w};
+    w.b3 = f32x4{v[11].x, v[11].y, v[11].z, v[11].w};
+    return w;
+}
+
+// tanh(x) = 1 - 2 / (exp(2x) + 1): v_exp_f32 + v_rcp_f32 (1 ulp each); exact limits +-1 for
+// |x| large (exp -> inf / 0).  Absolute error <~ 2e-7 (cancellation near 0 costs relative, not
+// absolute, accuracy; the activations feed fp32 sums of 32 terms).
+CTK_DEV float ctk_tanhf(float x) {
+    const float t = __builtin_amdgcn_exp2f(x * 2.885390081777927f);   // exp(2x) = 2^(2x*log2 e)
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
+}
+
+#define CTK_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+struct MlpAct {
+    f32x4 h1[2], h2[2];
+};
+
+// One predictor step for the wave's 16 trajectories.  sv: state component g of trajectory c;
+// u: input of trajectory c (any lane group).  Returns the next state component.
+CTK_DEV float mlp_step(const MlpFwdW& w, float sv, float u, int g, MlpAct* keep = nullptr) {
+    const float x1 = (g == 0) ? u : 0.0f;   // k-step 1 of layer 1: k = 4 is the input, k = 5..7 padding
+    f32x4 a0 = w.b1[0], a1 = w.b1[1];
+    a0 = CTK_MFMA(w.w1[0][0], sv, a0);
+    a1 = CTK_MFMA(w.w1[1][0], sv, a1);
+    a0 = CTK_MFMA(w.w1[0][1], x1, a0);
+    a1 = CTK_MFMA(w.w1[1][1], x1, a1);
+    f32x4 h1[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { h1[0][r] = ctk_tanhf(a0[r]); h1[1][r] = ctk_tanhf(a1[r]); }
+    f32x4 c0 = w.b2[0], c1 = w.b2[1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float b = h1[j >> 2][j & 3];
+        c0 = CTK_MFMA(w.w2[0][j], b, c0);
+        c1 = CTK_MFMA(w.w2[1][j], b, c1);
+    }
+    f32x4 h2[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { h2[0][r] = ctk_tanhf(c0[r]); h2[1][r] = ctk_tanhf(c1[r]); }
+    // layer 3: two interleaved accumulation chains (dependent MFMA latency 40 > issue 32 cycles)
+    f32x4 o0 = w.b3, o1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        o0 = CTK_MFMA(w.w3[j], h2[j >> 2][j & 3], o0);
+        o1 = CTK_MFMA(w.w3[j + 1], h2[(j + 1) >> 2][(j + 1) & 3], o1);
+    }
+    if (keep) { keep->h1[0] = h1[0]; keep->h1[1] = h1[1]; keep->h2[0] = h2[0]; keep->h2[1] = h2[1]; }
+    return o0[0] + o1[0];
+}
+
+// stage-cost share of lane group g (oracle Cost._get_stage_cost split by state component):
+//   g = 0: dd(x)   g = 1: cc(u) + ccrc(u - u_prev)   g = 2: ep(angle)   g = 3: ekp(angleD)
+CTK_DEV float mlp_stage_cost_share(const EnvK& k, int g, float sv, float u, float uprev) {
+    const float dxn = (sv - k.target_position) * k.inv_xs;
+    const float omc = 1.0f - cosf(sv);
+    const float du = u - uprev;
+    const float t0 = k.dd_weight * dxn * dxn;
+    const float t1 = k.ccR * u * u + k.ccrc_weight * du * du;
+    const float t2 = k.ep_c * omc * omc;
+    const float t3 = k.ekp_weight * sv * sv;
+    return g == 0 ? t0 : (g == 1 ? t1 : (g == 2 ? t2 : t3));
+}
+
+CTK_DEV float mlp_terminal_cost_share(const EnvK& k, int g, float sv) {
+    const float dxn = (sv - k.target_position) * k.inv_xs;
+    const float omc = 1.0f - cosf(sv);
+    const float t0 = k.dd_weight * dxn * dxn;
+    const float t2 = k.ep_c * omc * omc;
+    return k.terminal_weight * (g == 0 ? t0 : (g == 2 ? t2 : 0.0f));
+}
+
+// sum over the 4 lane groups (lanes c, c+16, c+32, c+48): every lane ends with the trajectory total
+CTK_DEV float sum_over_groups(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// Rolls the wave's 16 trajectories (first one = traj0).  ufn(h) yields the input of trajectory c.
+// Returns J of trajectory c in every lane.
+template <bool WRITE_Q, bool WRITE_TRAJ, class UFn>
+CTK_DEV float rollout_mlp(const RolloutArgs& a, const EnvK& k, const MlpFwdW& w, int traj0, UFn&& ufn) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int n = traj0 + c;
+    const bool valid = n < a.N;
+    float sv = a.s0[g];
+    float uprev = a.u_prev_dev ? *a.u_prev_dev : a.u_prev;
+    float csum = 0.0f;
+    const int H = a.H;
+    float u_next = ufn(0);
+    for (int h = 0; h < H; ++h) {
+        const float u = u_next;
+        if (h + 1 < H) u_next = ufn(h + 1);
+        csum += mlp_stage_cost_share(k, g, sv, u, uprev);
+        if constexpr (WRITE_TRAJ) {
+            if (valid && a.traj_out) a.traj_out[((size_t)n * (H + 1) + h) * CTK_S + g] = sv;
+        }
+        if constexpr (WRITE_Q) {
+            if (valid && g == 0) a.Q_out[(size_t)n * H + h] = u;
+        }
+        sv = mlp_step(w, sv, u, g);
+        uprev = u;
+    }
+    if constexpr (WRITE_TRAJ) {
+        if (valid && a.traj_out) a.traj_out[((size_t)n * (H + 1) + H) * CTK_S + g] = sv;
+    }
+    csum += mlp_terminal_cost_share(k, g, sv);
+    return sum_over_groups(csum) * a.inv_Hp1;
+}

@@ -12,6 +12,7 @@
 //        all-gathered records of several GPUs — SURVEY.md 8e) and either emits one record or
 //        applies the update u_nom <- clip(shift(u_nom) + interp(b)/a)   (:163-168,:184,:190).
 #include "ctk_rollout.h"
+#include "ctk_mlp.h"
 #include "ctk_launch.h"
 
 #ifdef CTK_STAMPS   // diagnostic build (tools/diag_mppi_stamps.hip); never compiled into libctk_hip.so
@@ -34,12 +35,13 @@ constexpr int MPPI_BLOCK = MPPI_TRAJ * MPPI_WAVES;
 // LDS carve (floats): tile[64][ts] | ubuf[64][us] | corr[4][64] | e[64] | colsum[4][P] | w0,w1,un,i0 [H] each
 __host__ __device__ inline int ubuf_stride(int H) { return (H + 1) | 1; }
 
-template <bool LOG>
-__global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout_ode(RolloutArgs a, EnvK k, MppiK m,
-                                                                   const float* __restrict__ samples,
-                                                                   const float* __restrict__ u_nom,
-                                                                   const InterpEntry* __restrict__ interp,
-                                                                   float* __restrict__ parts) {
+template <int PRED, bool LOG>
+__global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, EnvK k, MppiK m,
+                                                               const float* __restrict__ samples,
+                                                               const float* __restrict__ u_nom,
+                                                               const InterpEntry* __restrict__ interp,
+                                                               const float* __restrict__ wperm,
+                                                               float* __restrict__ parts) {
     extern __shared__ float lds[];
     const int P = a.P, H = a.H, ts = tile_stride(P), us = ubuf_stride(H);
     float* tile = lds;                         // [64][ts]  stdev * noise at the inducing points
@@ -57,72 +59,14 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout_ode(RolloutArgs a
     const bool valid = n < a.N;
 
     STAMP(0);
-    // ---- prologue 1 (256 threads): coalesced load (or Philox draw) of the sample tile, plus the
-    //      per-step tables (interpolation entry, shifted nominal input) into LDS ---------------------
-    {
-        const int rows = min(MPPI_TRAJ, a.N - row0);
-        if (rows < MPPI_TRAJ) {
-            for (int i = t; i < MPPI_TRAJ * ts; i += MPPI_BLOCK) tile[i] = 0.0f;   // rows beyond N read as zeros
-            __syncthreads();
-        } else if (t < MPPI_TRAJ) {
-            for (int c = P; c < ts; ++c) tile[t * ts + c] = 0.0f;                  // zero pad columns
-        }
-        for (int h = t; h < H; h += MPPI_BLOCK) {
-            const InterpEntry e = interp[h];
-            i0_s[h] = e.i0; w0_s[h] = e.w0; w1_s[h] = e.w1;
-            un_s[h] = u_nom[min(h + 1, H - 1)];                                    // optimizer_mppi.py:184 (shift)
-        }
-        if (samples != nullptr) {
-            const float* src = samples + (size_t)row0 * P;
-            const int total = rows * P;
-            if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-                // 16 B per lane, all loads of a batch in flight before the first LDS store
-                const float4* src4 = reinterpret_cast<const float4*>(src);
-                const int n4 = total >> 2;
-                for (int b0 = 0; b0 < n4; b0 += 4 * MPPI_BLOCK) {
-                    float4 v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int i4 = b0 + j * MPPI_BLOCK + t;
-                        if (i4 < n4) v[j] = src4[i4];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int i4 = b0 + j * MPPI_BLOCK + t;
-                        if (i4 < n4) {
-                            const int flat = i4 << 2;
-                            int r = P >= 2 ? (int)__umulhi((uint32_t)flat, a.p_magic) : flat, c = flat - r * P;
-                            const float e4[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                tile[r * ts + c] = e4[q] * m.stdev;
-                                if (++c == P) { c = 0; ++r; }
-                            }
-                        }
-                    }
-                }
-                for (int i = (n4 << 2) + t; i < total; i += MPPI_BLOCK) {
-                    const int r = i / P;
-                    tile[r * ts + (i - r * P)] = src[i] * m.stdev;
-                }
-            } else {
-                for (int i = t; i < total; i += MPPI_BLOCK) {
-                    const int r = i / P;
-                    tile[r * ts + (i - r * P)] = src[i] * m.stdev;
-                }
-            }
-        } else {
-            // on-device Philox: thread (wave, lane) draws column blocks cb = wave, wave+4, .. of row `lane`
-            const uint32_t grow = (uint32_t)(a.global_row0 + n);
-            for (int cb = wave; cb * 4 < P; cb += MPPI_WAVES) {
-                float d[4];
-                draw4(a, grow, (uint32_t)cb, 0, d);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (cb * 4 + j < P && valid) tile[lane * ts + cb * 4 + j] = d[j] * m.stdev;
-            }
-        }
+    // ---- prologue 1 (256 threads): per-step tables (interpolation entry, shifted nominal input) and
+    //      the sample tile (coalesced HBM read or Philox draw) into LDS ------------------------------
+    for (int h = t; h < H; h += MPPI_BLOCK) {
+        const InterpEntry e = interp[h];
+        i0_s[h] = e.i0; w0_s[h] = e.w0; w1_s[h] = e.w1;
+        un_s[h] = u_nom[min(h + 1, H - 1)];                                        // optimizer_mppi.py:184 (shift)
     }
+    load_tile<MPPI_TRAJ, MPPI_BLOCK>(tile, samples, a, row0, m.stdev, /*normal*/ 0);
     __syncthreads();
     STAMP(1);
 
@@ -154,17 +98,32 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout_ode(RolloutArgs a
     __syncthreads();
     STAMP(2);
 
-    // ---- the recurrence: wave 0 only, one trajectory per lane ------------------------------------
-    float e = 0.0f;
+    // ---- the recurrence --------------------------------------------------------------------------
+    float J = 0.0f;
+    if constexpr (PRED == CTK_PRED_ODE) {
+        // wave 0 only: one trajectory per lane, state in registers
+        if (wave == 0) {
+            const float* myu = ubuf + lane * us;
+            J = rollout_ode<false, LOG>(a, k, n, valid, [&](int h) { return myu[h]; });
+        }
+    } else {
+        // all four waves: 16 trajectories each on the fp32 matrix cores (ctk_mlp.h)
+        const MlpFwdW w = mlp_load_fwd(wperm);
+        const int tr = wave * CTK_MLP_TRAJ_PER_WAVE + (lane & 15);
+        const float* myu = ubuf + tr * us;
+        const float Jw = rollout_mlp<false, LOG>(a, k, w, row0 + wave * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return myu[h]; });
+        if (lane < 16) e_s[tr] = Jw;          // hand the 64 costs to wave 0 (e_s doubles as J scratch)
+        __syncthreads();
+        if (wave == 0) J = e_s[lane];
+        __syncthreads();
+    }
     if (wave == 0) {
-        const float* myu = ubuf + lane * us;
-        float J = rollout_ode<false, LOG>(a, k, n, valid, [&](int h) { return myu[h]; });
         J += (corr_s[lane] + corr_s[MPPI_TRAJ + lane]) + (corr_s[2 * MPPI_TRAJ + lane] + corr_s[3 * MPPI_TRAJ + lane]);
         STAMP(3);
         if (valid) a.J[n] = J;
         // block-local soft-min partial (optimizer_mppi.py:163-168 restricted to this block)
         const float rho = wave_min(valid ? J : INFINITY);
-        e = valid ? expf(m.neg_inv_lbd * (J - rho)) : 0.0f;
+        const float e = valid ? expf(m.neg_inv_lbd * (J - rho)) : 0.0f;
         const float asum = wave_sum(e);
         e_s[lane] = e;
         if (lane == 0) {
@@ -280,24 +239,29 @@ __global__ __launch_bounds__(MERGE_BLOCK) void ctk_mppi_merge(const float* __res
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-const char* ctk_mppi_rollout_ode_name(bool log) {
-    return log ? "ctk_mppi_rollout_ode<true>" : "ctk_mppi_rollout_ode<false>";
+const char* ctk_mppi_rollout_name(int pred, bool log) {
+    if (pred == CTK_PRED_ODE) return log ? "ctk_mppi_rollout<0, true>" : "ctk_mppi_rollout<0, false>";
+    return log ? "ctk_mppi_rollout<1, true>" : "ctk_mppi_rollout<1, false>";
 }
 
-int ctk_mppi_num_blocks_ode(int N) { return (N + MPPI_TRAJ - 1) / MPPI_TRAJ; }
+int ctk_mppi_num_blocks(int N) { return (N + MPPI_TRAJ - 1) / MPPI_TRAJ; }
 
-size_t ctk_mppi_rollout_ode_lds(int P, int H) {
+size_t ctk_mppi_rollout_lds(int P, int H) {
     return (size_t)(MPPI_TRAJ * tile_stride(P) + MPPI_TRAJ * ubuf_stride(H) + MPPI_WAVES * MPPI_TRAJ + MPPI_TRAJ + MPPI_WAVES * P + 4 * H) * sizeof(float);
 }
 
-hipError_t ctk_launch_mppi_rollout_ode(hipStream_t st, const RolloutArgs& a, const EnvK& k, const MppiK& m,
-                                       const float* samples, const float* u_nom, float* parts, bool log) {
-    const int blocks = ctk_mppi_num_blocks_ode(a.N);
-    const size_t lds = ctk_mppi_rollout_ode_lds(a.P, a.H);
-    if (log)
-        hipLaunchKernelGGL(ctk_mppi_rollout_ode<true>, dim3(blocks), dim3(MPPI_BLOCK), lds, st, a, k, m, samples, u_nom, a.interp, parts);
-    else
-        hipLaunchKernelGGL(ctk_mppi_rollout_ode<false>, dim3(blocks), dim3(MPPI_BLOCK), lds, st, a, k, m, samples, u_nom, a.interp, parts);
+hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const MppiK& m,
+                                   const float* samples, const float* u_nom, const float* wperm, float* parts, bool log,
+                                   hipEvent_t e0, hipEvent_t e1) {
+    const dim3 grid(ctk_mppi_num_blocks(a.N)), block(MPPI_BLOCK);
+    const size_t lds = ctk_mppi_rollout_lds(a.P, a.H);
+    if (pred == CTK_PRED_ODE) {
+        if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts);
+        else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts);
+    } else {
+        if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_MLP, true>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts);
+        else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_MLP, false>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts);
+    }
     return hipGetLastError();
 }
 

@@ -4,42 +4,71 @@
 #pragma once
 #include "ctk_device.h"
 
-// Loads (or draws) the per-block sample tile into LDS.
-//   tile[r * stride + c] = scale * sample[(row0 + r) * P + c]   r < rows_in_block, c < P
-// Global reads are fully coalesced (the block's rows are one contiguous span of the
-// [N,P,C] buffer); column P.. of every row is a zero pad.
-template <int BLOCK>
+// Loads (or draws) the per-block sample tile into LDS, cooperatively with THREADS threads:
+//   tile[r * stride + c] = scale * sample[(row0 + r) * P + c]   r < ROWS, c < P
+// Global reads are fully coalesced 16-B-per-lane loads (the block's rows are one contiguous span
+// of the [N,P,C] buffer), a batch of four per thread in flight before the first LDS store.
+// Rows beyond N and the pad columns P.. of every row read as zeros.  Ends WITHOUT a barrier.
+template <int ROWS, int THREADS>
 CTK_DEV void load_tile(float* tile, const float* __restrict__ samples, const RolloutArgs& a, int row0, float scale,
                        int rng_kind) {
-    const int P = a.P, stride = tile_stride(P);
-    const int rows = min(BLOCK, a.N - row0);
+    const int P = a.P, ts = tile_stride(P);
+    const int rows = min(ROWS, a.N - row0);
     const int t = threadIdx.x;
-    if (rows < BLOCK) {   // last, partial block: rows beyond N read as zeros
-        for (int i = t; i < BLOCK * stride; i += BLOCK) tile[i] = 0.0f;
+    if (rows < ROWS) {
+        for (int i = t; i < ROWS * ts; i += THREADS) tile[i] = 0.0f;
         __syncthreads();
     } else {
-        for (int c = P; c < stride; ++c) tile[t * stride + c] = 0.0f;
+        for (int r = t; r < ROWS; r += THREADS)
+            for (int c = P; c < ts; ++c) tile[r * ts + c] = 0.0f;
     }
     if (samples != nullptr) {
         const float* src = samples + (size_t)row0 * P;
         const int total = rows * P;
-        const int q = BLOCK / P, rem = BLOCK - q * P;   // advance of (r,c) per BLOCK elements
-        int r = t / P, c = t - r * P;
-        for (int i = t; i < total; i += BLOCK) {
-            tile[r * stride + c] = src[i] * scale;
-            r += q; c += rem;
-            if (c >= P) { c -= P; ++r; }
+        int done = 0;
+        if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            const float4* src4 = reinterpret_cast<const float4*>(src);
+            const int n4 = total >> 2;
+            for (int b0 = 0; b0 < n4; b0 += 4 * THREADS) {
+                float4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i4 = b0 + j * THREADS + t;
+                    if (i4 < n4) v[j] = src4[i4];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i4 = b0 + j * THREADS + t;
+                    if (i4 < n4) {
+                        const int flat = i4 << 2;
+                        int r = P >= 2 ? (int)__umulhi((uint32_t)flat, a.p_magic) : flat, c = flat - r * P;
+                        const float e4[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            tile[r * ts + c] = e4[q] * scale;
+                            if (++c == P) { c = 0; ++r; }
+                        }
+                    }
+                }
+            }
+            done = n4 << 2;
+        }
+        for (int i = done + t; i < total; i += THREADS) {
+            const int r = P >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i;
+            tile[r * ts + (i - r * P)] = src[i] * scale;
         }
     } else {
-        // on-device Philox: every thread draws its own row (global row index => shard invariant)
-        const bool valid = (row0 + t) < a.N;
-        const uint32_t grow = (uint32_t)(a.global_row0 + row0 + t);
-        for (int cb = 0; cb * 4 < P; ++cb) {
+        // on-device Philox, addressed by (global row, column block): shard- and launch-shape invariant
+        constexpr int TPR = THREADS / ROWS;           // threads per row
+        const int r = t % ROWS, cb0 = t / ROWS;
+        const bool valid = (row0 + r) < a.N;
+        const uint32_t grow = (uint32_t)(a.global_row0 + row0 + r);
+        for (int cb = cb0; cb * 4 < P; cb += TPR) {
             float d[4];
             draw4(a, grow, (uint32_t)cb, rng_kind, d);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (cb * 4 + j < P) tile[t * stride + cb * 4 + j] = valid ? d[j] * scale : 0.0f;
+                if (cb * 4 + j < P && valid) tile[r * ts + cb * 4 + j] = d[j] * scale;
         }
     }
 }

@@ -7,29 +7,41 @@
 // optimizer_cem_tf.py:73 / optimizer_rpgd.py:345 with ties fixed by index), the CEM elite
 // refit (:77-78) and the post-loop shift (:99-102).
 #include "ctk_rollout.h"
+#include "ctk_mlp.h"
 #include "ctk_launch.h"
 
-constexpr int SAMP_BLOCK = 64;
+constexpr int SAMP_BLOCK = 64;   // one wave per block: 64 trajectories (ODE) or 16 (MLP, MFMA columns)
 
-template <bool TRAJ>
-__global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout_ode(RolloutArgs a, EnvK k,
-                                                                     const float* __restrict__ samples, int rng_kind,
-                                                                     const float* __restrict__ base,
-                                                                     const float* __restrict__ scale) {
+template <int PRED, bool TRAJ>
+__global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(RolloutArgs a, EnvK k, const float* __restrict__ samples,
+                                                                 int rng_kind, const float* __restrict__ base,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ wperm) {
     extern __shared__ float lds[];
+    constexpr int ROWS = PRED == CTK_PRED_ODE ? SAMP_BLOCK : CTK_MLP_TRAJ_PER_WAVE;
     const int stride = tile_stride(a.P);   // P == H here: one sample per step
     float* tile = lds;
     const int lane = threadIdx.x;
-    const int row0 = blockIdx.x * SAMP_BLOCK;
-    const int n = row0 + lane;
-    const bool valid = n < a.N;
-    load_tile<SAMP_BLOCK>(tile, samples, a, row0, 1.0f, rng_kind);
+    const int row0 = blockIdx.x * ROWS;
+    load_tile<ROWS, SAMP_BLOCK>(tile, samples, a, row0, 1.0f, rng_kind);
     __syncthreads();
-    const float* my = tile + lane * stride;
-    const float J = rollout_ode<true, TRAJ>(a, k, n, valid, [&](int h) {
-        return fminf(fmaxf(base[h] + my[h] * scale[h], a.lo), a.hi);
-    });
-    if (valid) a.J[n] = J;
+    if constexpr (PRED == CTK_PRED_ODE) {
+        const int n = row0 + lane;
+        const bool valid = n < a.N;
+        const float* my = tile + lane * stride;
+        const float J = rollout_ode<true, TRAJ>(a, k, n, valid, [&](int h) {
+            return fminf(fmaxf(base[h] + my[h] * scale[h], a.lo), a.hi);
+        });
+        if (valid) a.J[n] = J;
+    } else {
+        const MlpFwdW w = mlp_load_fwd(wperm);
+        const int c = lane & 15, n = row0 + c;
+        const float* my = tile + c * stride;
+        const float J = rollout_mlp<true, TRAJ>(a, k, w, row0, [&](int h) {
+            return fminf(fmaxf(base[h] + my[h] * scale[h], a.lo), a.hi);
+        });
+        if (lane < 16 && n < a.N) a.J[n] = J;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -124,18 +136,24 @@ __global__ void ctk_pick_best_first(const float* __restrict__ Q, const int* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-const char* ctk_affine_rollout_ode_name(bool log) {
-    return log ? "ctk_affine_rollout_ode<true>" : "ctk_affine_rollout_ode<false>";
+const char* ctk_affine_rollout_name(int pred, bool log) {
+    if (pred == CTK_PRED_ODE) return log ? "ctk_affine_rollout<0, true>" : "ctk_affine_rollout<0, false>";
+    return log ? "ctk_affine_rollout<1, true>" : "ctk_affine_rollout<1, false>";
 }
 
-hipError_t ctk_launch_affine_rollout_ode(hipStream_t st, const RolloutArgs& a, const EnvK& k, const float* samples,
-                                         int rng_kind, const float* base, const float* scale, bool log) {
-    const int blocks = (a.N + SAMP_BLOCK - 1) / SAMP_BLOCK;
-    const size_t lds = (size_t)SAMP_BLOCK * tile_stride(a.P) * sizeof(float);
-    if (log)
-        hipLaunchKernelGGL(ctk_affine_rollout_ode<true>, dim3(blocks), dim3(SAMP_BLOCK), lds, st, a, k, samples, rng_kind, base, scale);
-    else
-        hipLaunchKernelGGL(ctk_affine_rollout_ode<false>, dim3(blocks), dim3(SAMP_BLOCK), lds, st, a, k, samples, rng_kind, base, scale);
+hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const float* samples,
+                                     int rng_kind, const float* base, const float* scale, const float* wperm, bool log,
+                                     hipEvent_t e0, hipEvent_t e1) {
+    const int rows = pred == CTK_PRED_ODE ? SAMP_BLOCK : CTK_MLP_TRAJ_PER_WAVE;
+    const dim3 grid((a.N + rows - 1) / rows), block(SAMP_BLOCK);
+    const size_t lds = (size_t)rows * tile_stride(a.P) * sizeof(float);
+    if (pred == CTK_PRED_ODE) {
+        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
+        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
+    } else {
+        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_MLP, true>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
+        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_MLP, false>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
+    }
     return hipGetLastError();
 }
 

@@ -18,7 +18,7 @@ int main(int argc, char** argv) {
     std::vector<float> noise((size_t)N * P);
     unsigned s = 1; for (auto& v : noise) { s = s * 1664525u + 1013904223u; v = ((s >> 8) * (1.f / 16777216.f) - 0.5f) * 3.f; }
     float *d_noise, *d_unom, *d_J, *d_parts; InterpEntry* d_tab; unsigned long long* d_st;
-    const int nb = ctk_mppi_num_blocks_ode(N);
+    const int nb = ctk_mppi_num_blocks(N);
     CK(hipMalloc(&d_noise, noise.size() * 4)); CK(hipMalloc(&d_unom, H * 4)); CK(hipMalloc(&d_J, N * 4));
     CK(hipMalloc(&d_parts, (size_t)nb * (2 + P) * 4)); CK(hipMalloc(&d_tab, H * sizeof(InterpEntry))); CK(hipMalloc(&d_st, nb * 8 * 8));
     CK(hipMemcpy(d_noise, noise.data(), noise.size() * 4, hipMemcpyHostToDevice));
@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     float ms = 0;
     for (int it = 0; it < 20; ++it) {
         CK(hipEventRecord(e0, 0));
-        CK(ctk_launch_mppi_rollout_ode(0, a, k, m, d_noise, d_unom, d_parts, false));
+        CK(ctk_launch_mppi_rollout(0, CTK_PRED_ODE, a, k, m, d_noise, d_unom, nullptr, d_parts, false));
         CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize()); CK(hipEventElapsedTime(&ms, e0, e1));
     }
     std::vector<unsigned long long> st(nb * 8);
