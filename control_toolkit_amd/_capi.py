@@ -210,6 +210,10 @@ class CtkEngine:
     def samples_needed(self) -> int:
         return int(self._lib.ctk_samples_needed(self._h))
 
+    def samples_needed_reset(self) -> int:
+        """RPGD: raw draws optimizer_reset consumes (N * P)."""
+        return self.N * int(self._lib.ctk_mppi_partial_size(self._h) - 2)
+
     def step(self, s, samples=None, loc: int = None, u_prev=None) -> np.ndarray:
         """samples: None (device Philox), a host ndarray (parity mode) or an int device pointer."""
         s = _f32(s).reshape(-1)

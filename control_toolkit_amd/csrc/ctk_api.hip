@@ -47,6 +47,16 @@ struct ctk_handle {
     float* h_u_dev = nullptr;   // device pointer aliasing h_u
     float* d_weights = nullptr; // MLP: raw [1380]
     float* d_wperm = nullptr;   // MLP: per-lane permuted, forward [64][48] then backward [64][28]
+    // RPGD: population, Adam moments, ages (ping-pong), bias-correction table, adjoint scratch
+    float* d_pop[2] = {nullptr, nullptr};
+    float* d_m[2] = {nullptr, nullptr};
+    float* d_v[2] = {nullptr, nullptr};
+    float* d_ages[2] = {nullptr, nullptr};
+    float* d_bc = nullptr;  int bc_len = 0;
+    float* d_scratch = nullptr;
+    int rcur = 0;
+    int adam_step = 0;
+    bool rpgd_ready = false;
     int count = 0;              // CEM / RPGD step counter
     uint32_t call = 0;          // Philox call counter
     bool mppi_pending = false;  // between step_begin and step_end
@@ -323,6 +333,60 @@ int random_step(ctk_handle* h, const float* s, const float* u_prev, const float*
     return finish_step(h, u_out);
 }
 
+// ---- RPGD --------------------------------------------------------------------------------------
+int rpgd_iterations(const ctk_handle* h) {   // optimizer_rpgd.py:219-221,397-400
+    const int first = h->cfg.warmup ? h->cfg.warmup_iterations : h->cfg.outer_its;
+    return h->count == 0 ? first : h->cfg.outer_its;
+}
+
+int rpgd_warm(ctk_handle* h, const RolloutArgs& a, int n_new, int gather, int reset, const float* d_draws, int from, int to) {
+    const ctk_config& c = h->cfg;
+    HIP_TRY(h, ctk_launch_rpgd_warmstart(h->stream, a, h->N, h->H, h->P, n_new, gather, c.shift_previous, c.sampling_distribution,
+                                         reset, c.action_low, c.action_high, c.sample_stdev, c.sample_mean, c.sample_min,
+                                         c.sample_max, d_draws, h->d_idx, h->d_pop[from], h->d_m[from], h->d_v[from],
+                                         h->d_ages[from], h->d_pop[to], h->d_m[to], h->d_v[to], h->d_ages[to], h->d_interp,
+                                         h->d_unom[0], h->d_u, h->h_u_dev));
+    return CTK_OK;
+}
+
+int rpgd_reset(ctk_handle* h, const float* draws, int loc) {
+    const float* d_draws = nullptr;
+    if (int rc = resolve_samples(h, draws, loc, (size_t)h->N * h->P, &d_draws)) return rc;
+    float zero_s[CTK_S] = {0, 0, 0, 0};
+    RolloutArgs a = make_args(h, zero_s, nullptr, h->N, h->P);
+    if (int rc = rpgd_warm(h, a, h->N, 0, 1, d_draws, h->rcur, h->rcur)) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->count = 0; h->adam_step = 0; h->rpgd_ready = true;
+    ++h->call;
+    return CTK_OK;
+}
+
+int rpgd_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc, float* u_out) {
+    if (!h->rpgd_ready) return fail(h, CTK_ERR_STATE, "RPGD: call ctk_reset (optimizer_reset) before the first step");
+    if (int rc = check_predictor(h)) return rc;
+    const ctk_config& c = h->cfg;
+    const int iters = rpgd_iterations(h);
+    const int cur = h->rcur, nxt = cur ^ 1;
+    const bool resample = (h->count % c.resamp_per) == 0;                      // :449
+    const float* d_draws = nullptr;
+    if (resample)
+        if (int rc = resolve_samples(h, samples, loc, (size_t)(h->N - c.opt_keep_k) * h->P, &d_draws)) return rc;
+    RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);   // p_magic divides by H in the descent kernel
+    {
+        ProfSlot ps(h);
+        HIP_TRY(h, ctk_launch_rpgd_descent(h->stream, c.predictor, a, h->k, c.learning_rate, c.adam_beta_1, c.adam_beta_2,
+                                           c.adam_epsilon, c.gradmax_clip, h->d_pop[cur], h->d_m[cur], h->d_v[cur], h->d_bc,
+                                           h->bc_len, h->adam_step, iters, h->d_wperm, h->d_scratch, ps.a, ps.b));
+    }
+    h->adam_step += iters;
+    HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, c.opt_keep_k, h->d_idx, nullptr));   // :345-346
+    RolloutArgs aw = make_args(h, s, u_prev, h->N, h->P);
+    if (int rc = rpgd_warm(h, aw, resample ? h->N - c.opt_keep_k : 0, resample ? 1 : 0, 0, d_draws, cur, nxt)) return rc;
+    h->rcur = nxt;
+    ++h->count;
+    return finish_step(h, u_out);
+}
+
 int fill_const(ctk_handle* h, float* d, float v, int n) {
     std::vector<float> tmp((size_t)n, v);
     HIP_TRY(h, hipMemcpyAsync(d, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -357,6 +421,13 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: unknown predictor");
     if (cfg->optimizer == CTK_OPT_CEM && (cfg->cem_best_k < 1 || cfg->cem_best_k > cfg->num_rollouts || cfg->cem_outer_it < 1))
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: need 1 <= cem_best_k <= num_rollouts and cem_outer_it >= 1");
+    if (cfg->optimizer == CTK_OPT_RPGD) {
+        if (cfg->opt_keep_k < 1 || cfg->opt_keep_k > cfg->num_rollouts || cfg->outer_its < 0 || cfg->resamp_per < 1 ||
+            cfg->shift_previous < 0 || (cfg->sampling_distribution != 0 && cfg->sampling_distribution != 1))
+            return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: RPGD needs 1 <= opt_keep_k <= num_rollouts, outer_its >= 0, resamp_per >= 1, shift_previous >= 0, sampling_distribution in {0,1}");
+        if (cfg->intermediate_steps != 1)
+            return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: the RPGD adjoint is built for intermediate_steps == 1");
+    }
     if (cfg->optimizer == CTK_OPT_MPPI && !(cfg->LBD > 0.0f && cfg->NU != 0.0f))
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: MPPI needs LBD > 0 and NU != 0");
 
@@ -390,6 +461,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     // LDS budget of the rollout tiles (one wave per block): 64 * stride * 4 B <= 160 KiB
     {
         const size_t lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_lds((int)P, (int)H)
+                         : cfg->optimizer == CTK_OPT_RPGD ? ctk_rpgd_descent_lds(cfg->predictor, (int)H, nullptr)
                                                           : (size_t)(64 * tile_stride((int)P)) * sizeof(float);
         if (lds > 160 * 1024) { h->err = "horizon too long for the LDS sample tiles (160 KiB per CU)"; return bail(CTK_ERR_UNSUPPORTED); }
     }
@@ -419,7 +491,28 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     *h->h_u = 0.0f;
     HIP_CREATE(hipHostGetDevicePointer((void**)&h->h_u_dev, h->h_u, 0));
 
+    if (cfg->optimizer == CTK_OPT_RPGD) {
+        for (int b = 0; b < 2; ++b) {
+            TRY_CREATE(dev_alloc(h, &h->d_pop[b], N * H));
+            TRY_CREATE(dev_alloc(h, &h->d_m[b], N * H));
+            TRY_CREATE(dev_alloc(h, &h->d_v[b], N * H));
+            TRY_CREATE(dev_alloc(h, &h->d_ages[b], N));
+        }
+        // bias corrections 1 - beta^t in double, rounded to fp32 (optimizer_rpgd.py:73-74); beyond the
+        // table both are exactly 1.0f in fp32
+        h->bc_len = 32768;
+        std::vector<float> bc((size_t)2 * h->bc_len);
+        for (int tt = 1; tt <= h->bc_len; ++tt) {
+            bc[2 * (tt - 1)] = (float)(1.0 - std::pow((double)cfg->adam_beta_1, (double)tt));
+            bc[2 * (tt - 1) + 1] = (float)(1.0 - std::pow((double)cfg->adam_beta_2, (double)tt));
+        }
+        TRY_CREATE(dev_alloc(h, &h->d_bc, bc.size()));
+        HIP_CREATE(hipMemcpyAsync(h->d_bc, bc.data(), bc.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIP_CREATE(hipStreamSynchronize(h->stream));
+        TRY_CREATE(dev_alloc(h, &h->d_scratch, ctk_rpgd_scratch_floats(cfg->predictor, (int)N, (int)H)));
+    }
     switch (cfg->optimizer) {
+        case CTK_OPT_RPGD: h->dominant = ctk_rpgd_descent_name(cfg->predictor); break;
         case CTK_OPT_MPPI: h->dominant = ctk_mppi_rollout_name(cfg->predictor, cfg->materialize_trajectories != 0); break;
         default: h->dominant = ctk_affine_rollout_name(cfg->predictor, cfg->materialize_trajectories != 0); break;
     }
@@ -437,7 +530,8 @@ void ctk_destroy(ctk_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (auto& e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     void* bufs[] = {h->d_interp, h->d_samples, h->d_J, h->d_Q, h->d_traj, h->d_parts, h->d_parts2, h->d_unom[0], h->d_unom[1],
-                    h->d_std, h->d_base, h->d_scale, h->d_idx, h->d_u, h->d_weights, h->d_wperm};
+                    h->d_std, h->d_base, h->d_scale, h->d_idx, h->d_u, h->d_weights, h->d_wperm,
+                    h->d_pop[0], h->d_pop[1], h->d_m[0], h->d_m[1], h->d_v[0], h->d_v[1], h->d_ages[0], h->d_ages[1], h->d_bc, h->d_scratch};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_u) hipHostFree(h->h_u);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -473,8 +567,7 @@ int ctk_reset(ctk_handle* h, const float* draws, int draws_loc) {
             if (int rc = fill_const(h, h->d_base, h->cfg.action_low, h->H)) return rc;
             return fill_const(h, h->d_scale, h->cfg.action_high - h->cfg.action_low, h->H);
         case CTK_OPT_RPGD:
-            (void)draws; (void)draws_loc;
-            return fail(h, CTK_ERR_UNSUPPORTED, "RPGD is not built yet");
+            return rpgd_reset(h, draws, draws_loc);
     }
     return CTK_OK;
 }
@@ -521,7 +614,7 @@ int ctk_step(ctk_handle* h, const float* s, const float* u_prev, const float* sa
         }
         case CTK_OPT_CEM: return cem_step(h, s, u_prev, samples, samples_loc, u_out);
         case CTK_OPT_RANDOM_ACTION: return random_step(h, s, u_prev, samples, samples_loc, u_out);
-        case CTK_OPT_RPGD: return fail(h, CTK_ERR_UNSUPPORTED, "RPGD is not built yet");
+        case CTK_OPT_RPGD: return rpgd_step(h, s, u_prev, samples, samples_loc, u_out);
     }
     return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_step: unknown optimizer");
 }
@@ -589,7 +682,15 @@ int ctk_read(ctk_handle* h, int which, float* dst, size_t cap, size_t* n_out) {
     const size_t N = h->N, H = h->H;
     const float* src = nullptr; size_t n = 0; bool is_int = false;
     switch (which) {
-        case CTK_BUF_Q: src = h->d_Q; n = N * H; break;
+        case CTK_BUF_Q: src = h->cfg.optimizer == CTK_OPT_RPGD ? h->d_pop[h->rcur ^ 1] : h->d_Q; n = N * H; break;
+        case CTK_BUF_PLAN: if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: PLAN is an RPGD buffer");
+            src = h->d_pop[h->rcur]; n = N * H; break;
+        case CTK_BUF_ADAM_M: if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: ADAM_M is an RPGD buffer");
+            src = h->d_m[h->rcur]; n = N * H; break;
+        case CTK_BUF_ADAM_V: if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: ADAM_V is an RPGD buffer");
+            src = h->d_v[h->rcur]; n = N * H; break;
+        case CTK_BUF_AGES: if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: AGES is an RPGD buffer");
+            src = h->d_ages[h->rcur]; n = N; break;
         case CTK_BUF_J: src = h->d_J; n = N; break;
         case CTK_BUF_TRAJ:
             if (!h->d_traj) return fail(h, CTK_ERR_STATE, "ctk_read: trajectories not materialised (cfg.materialize_trajectories == 0)");
@@ -617,7 +718,7 @@ size_t ctk_state_size(const ctk_handle* h) {
         case CTK_OPT_MPPI: return H + 1;
         case CTK_OPT_CEM: return 2 * H + 2;
         case CTK_OPT_RANDOM_ACTION: return 1;
-        case CTK_OPT_RPGD: return 0;
+        case CTK_OPT_RPGD: return 3 * (size_t)h->N * H + (size_t)h->N + 3;
     }
     return 0;
 }
@@ -637,6 +738,14 @@ int ctk_get_state(ctk_handle* h, float* dst, size_t cap) {
         case CTK_OPT_CEM: HIP_TRY(h, pull(h->d_unom[0], H)); HIP_TRY(h, pull(h->d_std, H)); HIP_TRY(h, pull(h->d_u, 1));
             HIP_TRY(h, hipStreamSynchronize(h->stream)); dst[o++] = (float)h->count; break;
         case CTK_OPT_RANDOM_ACTION: HIP_TRY(h, pull(h->d_u, 1)); break;
+        case CTK_OPT_RPGD: {
+            const size_t NH = (size_t)h->N * H;
+            HIP_TRY(h, pull(h->d_pop[h->rcur], NH)); HIP_TRY(h, pull(h->d_m[h->rcur], NH)); HIP_TRY(h, pull(h->d_v[h->rcur], NH));
+            HIP_TRY(h, pull(h->d_ages[h->rcur], h->N)); HIP_TRY(h, pull(h->d_u, 1));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            dst[o++] = (float)h->adam_step; dst[o++] = (float)h->count;
+            break;
+        }
         default: return fail(h, CTK_ERR_UNSUPPORTED, "ctk_get_state: not built for this optimizer");
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -658,6 +767,14 @@ int ctk_set_state(ctk_handle* h, const float* src, size_t n) {
         case CTK_OPT_CEM: HIP_TRY(h, push(h->d_unom[0], H)); HIP_TRY(h, push(h->d_std, H)); HIP_TRY(h, push(h->d_u, 1));
             h->count = (int)src[o++]; break;
         case CTK_OPT_RANDOM_ACTION: HIP_TRY(h, push(h->d_u, 1)); break;
+        case CTK_OPT_RPGD: {
+            const size_t NH = (size_t)h->N * H;
+            HIP_TRY(h, push(h->d_pop[h->rcur], NH)); HIP_TRY(h, push(h->d_m[h->rcur], NH)); HIP_TRY(h, push(h->d_v[h->rcur], NH));
+            HIP_TRY(h, push(h->d_ages[h->rcur], h->N)); HIP_TRY(h, push(h->d_u, 1));
+            h->adam_step = (int)src[o++]; h->count = (int)src[o++];
+            h->rpgd_ready = true;
+            break;
+        }
         default: return fail(h, CTK_ERR_UNSUPPORTED, "ctk_set_state: not built for this optimizer");
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));

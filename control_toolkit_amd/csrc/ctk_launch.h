@@ -40,3 +40,19 @@ hipError_t ctk_launch_cem_finish(hipStream_t st, const float* Q, const int* idx,
                                  float std_min, float init_std, float mid, float* u_dev, float* u_host);
 // random-action: u = Q[argmin J, 0]  (optimizer_random_action_tf.py:65-68)
 hipError_t ctk_launch_pick_best_first(hipStream_t st, const float* Q, const int* idx, int H, float* u_dev, float* u_host);
+
+// ---- ctk_rpgd.hip ---------------------------------------------------------------------------
+const char* ctk_rpgd_descent_name(int pred);
+size_t ctk_rpgd_descent_lds(int pred, int H, bool* tape_in_lds);
+size_t ctk_rpgd_scratch_floats(int pred, int N, int H);
+// All `iters` clipped-gradient Adam iterations + the final cost pass; bc_table[2*(t-1)] = 1-b1^t, [..+1] = 1-b2^t
+hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, float lr, float b1, float b2,
+                                   float eps, float clip, float* Q, float* m, float* v, const float* bc_table, int bc_len,
+                                   int t0, int iters, const float* wperm, float* scratch, hipEvent_t ev_start = nullptr,
+                                   hipEvent_t ev_stop = nullptr);
+hipError_t ctk_launch_rpgd_warmstart(hipStream_t st, const RolloutArgs& a, int N, int H, int P, int n_new, int gather, int shift_previous,
+                                     int sampling_distribution, int reset, float lo, float hi, float sample_stdev,
+                                     float sample_mean, float sample_min, float sample_max, const float* draws, const int* idx,
+                                     const float* Q_old, const float* m_old, const float* v_old, const float* ages_old,
+                                     float* Q_new, float* m_new, float* v_new, float* ages_new, const InterpEntry* interp,
+                                     float* u_nom, float* u_dev, float* u_host);

@@ -1,0 +1,291 @@
+// ctk_rpgd.hip — RPGD on gfx950 (replaces reference Optimizers/optimizer_rpgd.py:298-338, :340-380,
+// :449-516 and the in-repo torch ADAM :56-82).
+//
+//   ctk_rpgd_descent<PRED>   ALL `iters` Adam iterations of one MPC step in ONE launch: the N plans
+//        are independent during the descent (loss = sum_n J_n, :325), so a block keeps its 64 plans
+//        in LDS across iterations.  Per iteration: forward rollout storing what the adjoint needs,
+//        hand-written reverse sweep (the autograd tape of :310-314 / :329-333) giving dJ/dQ,
+//        per-plan clip_by_norm (:315,:334), Adam (:56-82) with coalesced m/v traffic, clip to the
+//        limits (:319,:336).  After the last iteration one more forward pass yields the costs that
+//        get_action sorts (:342).  ODE: one thread per plan (wave 0 of the block), adjoint state in
+//        LDS.  MLP: 16 plans per wave on the fp32 matrix cores both ways, activations in an
+//        L2-resident global scratch.
+//   ctk_rpgd_warmstart       keep the best k (sorted), shift plans by shift_previous and moments by
+//        one, resample the rest at the inducing points, age bookkeeping, u = best plan's first
+//        input (:426,:449-516,:523).
+#include "ctk_rollout.h"
+#include "ctk_mlp.h"
+#include "ctk_launch.h"
+
+constexpr int RP_TRAJ = 64;
+constexpr int RP_WAVES = 4;
+constexpr int RP_BLOCK = RP_TRAJ * RP_WAVES;
+constexpr int RP_LD = RP_TRAJ + 1;   // LDS row stride of the [h][plan] tiles (odd: conflict-free both ways)
+constexpr int RP_NS = 6;             // floats stored per (plan, step) for the ODE adjoint
+
+// ---------------------------------------------------------------------------------------------
+// ODE: forward with tape, reverse sweep
+// ---------------------------------------------------------------------------------------------
+// tape[(h * RP_NS + i) * 64 + lane], i: 0 x, 1 omega, 2 sin, 3 cos, 4 tmp, 5 thdd
+CTK_DEV void rpgd_forward_ode_tape(const RolloutArgs& a, const EnvK& k, const float* q_s, float* tape, int lane, State4& s) {
+    s = State4{a.s0[0], a.s0[1], a.s0[2], a.s0[3]};
+    const int H = a.H;
+    float u_next = q_s[lane];
+    for (int h = 0; h < H; ++h) {
+        const float u = u_next;
+        if (h + 1 < H) u_next = q_s[(h + 1) * RP_LD + lane];
+        float sn, cs;
+        ctk_sincosf(s.th, &sn, &cs);
+        const float F = k.u_max * u;
+        const float A = F + k.k_ml * s.om * s.om * sn - k.M_fric * s.v;
+        const float tmp = A * k.inv_mt;
+        const float D = k.k43l - k.k_mpl_mt * cs * cs;
+        const float Nn = k.g * sn - cs * tmp - k.k_jf * s.om;
+        const float thdd = fdiv_pos(Nn, D);
+        const float xdd = tmp - k.k_mpl_mt * thdd * cs;
+        float* tp = tape + (size_t)h * RP_NS * 64 + lane;
+        tp[0] = s.x; tp[64] = s.om; tp[128] = sn; tp[192] = cs; tp[256] = tmp; tp[320] = thdd;
+        const float nx = s.x + k.dt * s.v, nv = s.v + k.dt * xdd, nth = s.th + k.dt * s.om, nom = s.om + k.dt * thdd;
+        s.x = nx; s.v = nv; s.th = nth; s.om = nom;
+    }
+}
+
+// Reverse sweep: g_s[h][lane] = dJ/dQ[n,h]; returns sum_h g^2.  (oracle: rollout_cost_and_grad)
+CTK_DEV float rpgd_backward_ode(const RolloutArgs& a, const EnvK& k, const float* q_s, const float* tape, float* g_s, int lane,
+                                const State4& sH, float uprev0) {
+    const int H = a.H;
+    const float inv = a.inv_Hp1;
+    const float two_dd = 2.0f * k.dd_weight * k.inv_xs * k.inv_xs;
+    // terminal: terminal_weight * (dd + ep) at s_H
+    float snH, csH;
+    ctk_sincosf(sH.th, &snH, &csH);
+    float lx = k.terminal_weight * two_dd * (sH.x - k.target_position) * inv;
+    float lv = 0.0f;
+    float lth = k.terminal_weight * 2.0f * k.ep_c * (1.0f - csH) * snH * inv;
+    float lom = 0.0f;
+    float nrm2 = 0.0f;
+    float u_hp1 = 0.0f;                       // u_{h+1}
+    float u_h = q_s[(H - 1) * RP_LD + lane];
+    for (int h = H - 1; h >= 0; --h) {
+        const float u_hm1 = h > 0 ? q_s[(h - 1) * RP_LD + lane] : uprev0;
+        const float* tp = tape + (size_t)h * RP_NS * 64 + lane;
+        const float x = tp[0], om = tp[64], sn = tp[128], cs = tp[192], tmp = tp[256], thdd = tp[320];
+        const float D = k.k43l - k.k_mpl_mt * cs * cs;
+        const float dt = k.dt;
+        // adjoint of the Euler step (oracle Predictor._ode_vjp)
+        const float a_xdd = dt * lv;
+        const float a_thdd = dt * lom - k.k_mpl_mt * cs * a_xdd;
+        float a_tmp = a_xdd;
+        float a_cs = -k.k_mpl_mt * thdd * a_xdd;
+        const float a_Nn = fdiv_pos(a_thdd, D);
+        const float a_D = -a_Nn * thdd;
+        float a_sn = k.g * a_Nn;
+        a_cs = a_cs - tmp * a_Nn - 2.0f * k.k_mpl_mt * cs * a_D;
+        a_tmp = a_tmp - cs * a_Nn;
+        const float a_A = a_tmp * k.inv_mt;
+        a_sn = a_sn + k.k_ml * om * om * a_A;
+        const float o_x = lx;
+        const float o_v = lv + dt * lx - k.M_fric * a_A;
+        const float o_th = lth + cs * a_sn - sn * a_cs;
+        const float o_om = lom + dt * lth - k.k_jf * a_Nn + 2.0f * k.k_ml * om * sn * a_A;
+        const float g_q = k.u_max * a_A;
+        // direct input-cost gradient: cc + ccrc towards both neighbours
+        float gu = 2.0f * k.ccR * u_h + 2.0f * k.ccrc_weight * (u_h - u_hm1);
+        if (h + 1 < H) gu -= 2.0f * k.ccrc_weight * (u_hp1 - u_h);
+        const float g = gu * inv + g_q;
+        g_s[h * RP_LD + lane] = g;
+        nrm2 += g * g;
+        // stage-cost state gradient at s_h
+        lx = two_dd * (x - k.target_position) * inv + o_x;
+        lv = o_v;
+        lth = 2.0f * k.ep_c * (1.0f - cs) * sn * inv + o_th;
+        lom = 2.0f * k.ekp_weight * om * inv + o_om;
+        u_hp1 = u_h; u_h = u_hm1;
+    }
+    return nrm2;
+}
+
+struct AdamK {
+    float lr, b1, b2, one_m_b1, one_m_b2, eps, clip;
+};
+
+// Adam for one element (optimizer_rpgd.py:68-79 in fp32, scalars rounded to fp32 as torch does)
+CTK_DEV float adam_update(const AdamK& ad, float q, float g, float& m, float& v, float bc1, float bc2, float lo, float hi) {
+    m = m * ad.b1 + ad.one_m_b1 * g;
+    v = v * ad.b2 + ad.one_m_b2 * (g * g);
+    const float m_hat = m / bc1, v_hat = v / bc2;
+    const float qn = q - ad.lr * m_hat / (sqrtf(v_hat) + ad.eps);
+    return fminf(fmaxf(qn, lo), hi);
+}
+
+template <int PRED>
+__global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_descent(RolloutArgs a, EnvK k, AdamK ad, float* __restrict__ Q,
+                                                             float* __restrict__ m, float* __restrict__ v,
+                                                             const float* __restrict__ bc_table, int bc_len, int t0, int iters,
+                                                             const float* __restrict__ wperm, float* __restrict__ scratch,
+                                                             int tape_in_lds) {
+    extern __shared__ float lds[];
+    const int H = a.H;
+    float* q_s = lds;                       // [H][65]
+    float* g_s = q_s + H * RP_LD;           // [H][65]
+    float* sc_s = g_s + H * RP_LD;          // [64] clip scale per plan
+    float* tape_l = sc_s + RP_TRAJ;         // [H][6][64] (ODE, when it fits)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int row0 = blockIdx.x * RP_TRAJ;
+    const int rows = min(RP_TRAJ, a.N - row0);
+    const int total = rows * H;
+    const size_t gbase = (size_t)row0 * H;
+    const float uprev0 = a.u_prev_dev ? *a.u_prev_dev : a.u_prev;
+
+    // plans of this block -> LDS, transposed to [h][plan] (coalesced global read)
+    for (int i = t; i < RP_TRAJ * H; i += RP_BLOCK) {
+        const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;   // p_magic = ceil(2^32 / H) here
+        q_s[h * RP_LD + r] = i < total ? Q[gbase + i] : 0.0f;
+    }
+    __syncthreads();
+
+    if constexpr (PRED == CTK_PRED_ODE) {
+        float* tape = tape_in_lds ? tape_l : scratch + (size_t)blockIdx.x * H * RP_NS * 64;
+        for (int it = 0; it < iters; ++it) {
+            if (wave == 0) {
+                State4 sH;
+                rpgd_forward_ode_tape(a, k, q_s, tape, lane, sH);
+                const float nrm2 = rpgd_backward_ode(a, k, q_s, tape, g_s, lane, sH, uprev0);
+                // lib.clip_by_norm(g, clip, [1,2]) = g * clip / max(||g||, clip)   (:315,:334)
+                sc_s[lane] = ad.clip / fmaxf(sqrtf(nrm2), ad.clip);
+            }
+            __syncthreads();
+            const int ti = t0 + it + 1;                                   // state['step'] += 1 (:59)
+            const float bc1 = ti <= bc_len ? bc_table[2 * (ti - 1)] : 1.0f;
+            const float bc2 = ti <= bc_len ? bc_table[2 * (ti - 1) + 1] : 1.0f;
+            for (int i = t; i < total; i += RP_BLOCK) {
+                const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;
+                float mm = m[gbase + i], vv = v[gbase + i];
+                const float g = g_s[h * RP_LD + r] * sc_s[r];
+                q_s[h * RP_LD + r] = adam_update(ad, q_s[h * RP_LD + r], g, mm, vv, bc1, bc2, a.lo, a.hi);
+                m[gbase + i] = mm; v[gbase + i] = vv;
+            }
+            __syncthreads();
+        }
+        // get_action's forward pass (:342): costs of the refined plans
+        if (wave == 0) {
+            const int n = row0 + lane;
+            const bool valid = n < a.N;
+            const float J = rollout_ode<false, false>(a, k, n, valid, [&](int h) { return q_s[h * RP_LD + lane]; });
+            if (valid) a.J[n] = J;
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < total; i += RP_BLOCK) {
+        const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;
+        Q[gbase + i] = q_s[h * RP_LD + r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// warm start / resampling / reset.  One thread per (row, h) of the NEW population.
+//   new row i <  n_new : fresh sample (sample_actions :275-296), moments 0, age 0
+//   new row i >= n_new : keeper idx[i - n_new] (or row i itself when gather == 0): plan shifted
+//                        by shift_previous repeating the last input (:377-379), moments shifted by
+//                        ONE and zero-filled (:465,:501), age kept; then every age += 1 (:514)
+// ---------------------------------------------------------------------------------------------
+struct WarmArgs {
+    int N, H, P, n_new, gather, shift_previous, sampling_distribution, reset;
+    float lo, hi, sample_stdev, sample_mean, sample_min, sample_max;
+};
+
+__global__ __launch_bounds__(256) void ctk_rpgd_warmstart(WarmArgs w, RolloutArgs a, const float* __restrict__ draws,
+                                                          const int* __restrict__ idx, const float* __restrict__ Q_old,
+                                                          const float* __restrict__ m_old, const float* __restrict__ v_old,
+                                                          const float* __restrict__ ages_old, float* __restrict__ Q_new,
+                                                          float* __restrict__ m_new, float* __restrict__ v_new,
+                                                          float* __restrict__ ages_new, const InterpEntry* __restrict__ interp,
+                                                          float* __restrict__ u_nom, float* __restrict__ u_dev,
+                                                          float* __restrict__ u_host) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int H = w.H;
+    if (gid < w.N * H) {
+        const int i = gid / H, h = gid - i * H;
+        float q, mm = 0.0f, vv = 0.0f;
+        if (i < w.n_new) {
+            const InterpEntry e = interp[h];
+            float y[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = min(e.i0 + j, w.P - 1);
+                float d;
+                if (draws != nullptr) {
+                    d = draws[(size_t)i * w.P + col];
+                } else {
+                    float d4[4];
+                    draw4(a, (uint32_t)(a.global_row0 + i), (uint32_t)(col >> 2), w.sampling_distribution == 0 ? 1 : 0, d4);
+                    d = d4[col & 3];
+                }
+                const float raw = w.sampling_distribution == 0 ? d * (w.sample_max - w.sample_min) + w.sample_min   // uniform
+                                                                : d * w.sample_stdev + w.sample_mean;                // normal
+                y[j] = fminf(fmaxf(raw, w.lo), w.hi);                                                                // :292
+            }
+            q = y[0] * e.w0 + (e.i0 + 1 < w.P ? y[1] * e.w1 : 0.0f);                                                 // :294
+        } else {
+            const int src = w.gather ? idx[i - w.n_new] : i;
+            const int hs = min(h + w.shift_previous, H - 1);
+            q = Q_old[(size_t)src * H + hs];
+            if (h + 1 < H) { mm = m_old[(size_t)src * H + h + 1]; vv = v_old[(size_t)src * H + h + 1]; }
+        }
+        Q_new[gid] = q; m_new[gid] = mm; v_new[gid] = vv;
+        if (h == 0) {
+            const float age = (i < w.n_new) ? 0.0f : ages_old[w.gather ? idx[i - w.n_new] : i];
+            ages_new[i] = w.reset ? 0.0f : age + 1.0f;
+        }
+    }
+    if (!w.reset && gid < H) {
+        const int best = idx[0];                       // u_nom = Q_tf[best_idx[0]] BEFORE the warm start (:426)
+        const float q = Q_old[(size_t)best * H + gid];
+        u_nom[gid] = q;
+        if (gid == 0) { *u_dev = q; *u_host = q; }     // :523
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+const char* ctk_rpgd_descent_name(int pred) { return pred == CTK_PRED_ODE ? "ctk_rpgd_descent<0>" : "ctk_rpgd_descent<1>"; }
+
+size_t ctk_rpgd_descent_lds(int pred, int H, bool* tape_in_lds) {
+    const size_t base = (size_t)(2 * H * RP_LD + RP_TRAJ) * sizeof(float);
+    const size_t tape = pred == CTK_PRED_ODE ? (size_t)H * RP_NS * 64 * sizeof(float) : 0;
+    const bool fits = base + tape <= 160 * 1024;
+    if (tape_in_lds) *tape_in_lds = fits && tape > 0;
+    return fits ? base + tape : base;
+}
+
+size_t ctk_rpgd_scratch_floats(int pred, int N, int H) {
+    const size_t blocks = (N + RP_TRAJ - 1) / RP_TRAJ;
+    return pred == CTK_PRED_ODE ? blocks * H * RP_NS * 64 : blocks * 4 * (size_t)H * 64 * 20;
+}
+
+hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, float lr, float b1, float b2,
+                                   float eps, float clip, float* Q, float* m, float* v, const float* bc_table, int bc_len,
+                                   int t0, int iters, const float* wperm, float* scratch, hipEvent_t e0, hipEvent_t e1) {
+    AdamK ad{lr, b1, b2, (float)(1.0 - (double)b1), (float)(1.0 - (double)b2), eps, clip};
+    bool tape_in_lds = false;
+    const size_t lds = ctk_rpgd_descent_lds(pred, a.H, &tape_in_lds);
+    const dim3 grid((a.N + RP_TRAJ - 1) / RP_TRAJ), block(RP_BLOCK);
+    if (pred == CTK_PRED_ODE)
+        CTK_LAUNCH((ctk_rpgd_descent<CTK_PRED_ODE>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm,
+                   scratch, tape_in_lds ? 1 : 0);
+    else
+        return hipErrorNotSupported;
+    return hipGetLastError();
+}
+
+hipError_t ctk_launch_rpgd_warmstart(hipStream_t st, const RolloutArgs& a, int N, int H, int P, int n_new, int gather, int shift_previous,
+                                     int sampling_distribution, int reset, float lo, float hi, float sample_stdev,
+                                     float sample_mean, float sample_min, float sample_max, const float* draws, const int* idx,
+                                     const float* Q_old, const float* m_old, const float* v_old, const float* ages_old,
+                                     float* Q_new, float* m_new, float* v_new, float* ages_new, const InterpEntry* interp,
+                                     float* u_nom, float* u_dev, float* u_host) {
+    WarmArgs w{N, H, P, n_new, gather, shift_previous, sampling_distribution, reset, lo, hi, sample_stdev, sample_mean, sample_min, sample_max};
+    const int total = N * H;
+    hipLaunchKernelGGL(ctk_rpgd_warmstart, dim3((total + 255) / 256), dim3(256), 0, st, w, a, draws, idx, Q_old, m_old, v_old, ages_old,
+                       Q_new, m_new, v_new, ages_new, interp, u_nom, u_dev, u_host);
+    return hipGetLastError();
+}
