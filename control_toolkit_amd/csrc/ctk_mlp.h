@@ -159,3 +159,62 @@ CTK_DEV float rollout_mlp(const RolloutArgs& a, const EnvK& k, const MlpFwdW& w,
     csum += mlp_terminal_cost_share(k, g, sv);
     return sum_over_groups(csum) * a.inv_Hp1;
 }
+
+// ---------------------------------------------------------------------------------------------
+// reverse mode (RPGD): vector-Jacobian product of one step, same operand-layout trick.
+// ---------------------------------------------------------------------------------------------
+struct MlpBwdW {
+    float w3t[2];      // [hidden tile]            A = W3^T (rows hidden, k = output component)
+    float w2t[2][8];   // [hidden_in tile][k-step] A = W2^T (rows hidden_in, k = hidden_out permuted)
+    float w1t[8];      // [k-step]                 A = W1^T (rows {0,4,8,12} -> state 0..3, row 1 -> input)
+};
+
+CTK_DEV MlpBwdW mlp_load_bwd(const float* __restrict__ wperm) {
+    const float4* p = reinterpret_cast<const float4*>(wperm + 64 * MLP_FWD_PER_LANE) + (threadIdx.x & 63) * (MLP_BWD_PER_LANE / 4);
+    float4 v[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) v[i] = p[i];
+    const float f[28] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w,
+                         v[3].x, v[3].y, v[3].z, v[3].w, v[4].x, v[4].y, v[4].z, v[4].w, v[5].x, v[5].y, v[5].z, v[5].w,
+                         v[6].x, v[6].y, v[6].z, v[6].w};
+    MlpBwdW w;
+    w.w3t[0] = f[0]; w.w3t[1] = f[1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { w.w2t[0][j] = f[2 + j]; w.w2t[1][j] = f[10 + j]; w.w1t[j] = f[18 + j]; }
+    return w;
+}
+
+// lam: adjoint of the NEXT state component g of trajectory c.  act: the activations of this step.
+// Returns the adjoint w.r.t. this step's state component g; *du (valid on lane group 0) is the
+// adjoint w.r.t. the step's input.
+CTK_DEV float mlp_step_vjp(const MlpBwdW& w, const MlpAct& act, float lam, float* du) {
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 t0 = CTK_MFMA(w.w3t[0], lam, z), t1 = CTK_MFMA(w.w3t[1], lam, z);
+    f32x4 d2[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        d2[0][r] = t0[r] * (1.0f - act.h2[0][r] * act.h2[0][r]);
+        d2[1][r] = t1[r] * (1.0f - act.h2[1][r] * act.h2[1][r]);
+    }
+    f32x4 s0 = z, s1 = z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float b = d2[j >> 2][j & 3];
+        s0 = CTK_MFMA(w.w2t[0][j], b, s0);
+        s1 = CTK_MFMA(w.w2t[1][j], b, s1);
+    }
+    f32x4 d1[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        d1[0][r] = s0[r] * (1.0f - act.h1[0][r] * act.h1[0][r]);
+        d1[1][r] = s1[r] * (1.0f - act.h1[1][r] * act.h1[1][r]);
+    }
+    f32x4 o0 = z, o1 = z;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        o0 = CTK_MFMA(w.w1t[j], d1[j >> 2][j & 3], o0);
+        o1 = CTK_MFMA(w.w1t[j + 1], d1[(j + 1) >> 2][(j + 1) & 3], o1);
+    }
+    *du = o0[1] + o1[1];
+    return o0[0] + o1[0];
+}

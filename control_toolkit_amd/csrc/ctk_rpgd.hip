@@ -105,6 +105,73 @@ CTK_DEV float rpgd_backward_ode(const RolloutArgs& a, const EnvK& k, const float
     return nrm2;
 }
 
+// ---------------------------------------------------------------------------------------------
+// MLP: forward with the activations taped to an L2-resident global scratch, reverse sweep on MFMA.
+// tape layout per wave: [h][lane][20] floats = {state component, h1[8], h2[8], pad[3]} (5 x float4
+// per lane, lane-contiguous: every store/load instruction moves 1 KiB coalesced).
+// ---------------------------------------------------------------------------------------------
+constexpr int RP_MLP_TAPE = 20;
+
+CTK_DEV float rpgd_forward_mlp_tape(const RolloutArgs& a, const MlpFwdW& w, const float* q_s, float* tape, int col, int g) {
+    const int lane = threadIdx.x & 63;
+    float sv = a.s0[g];
+    const int H = a.H;
+    for (int h = 0; h < H; ++h) {
+        const float u = q_s[h * RP_LD + col];
+        MlpAct act;
+        const float nsv = mlp_step(w, sv, u, g, &act);
+        float4* tp = reinterpret_cast<float4*>(tape + ((size_t)h * 64 + lane) * RP_MLP_TAPE);
+        tp[0] = make_float4(sv, 0.f, 0.f, 0.f);
+        tp[1] = make_float4(act.h1[0][0], act.h1[0][1], act.h1[0][2], act.h1[0][3]);
+        tp[2] = make_float4(act.h1[1][0], act.h1[1][1], act.h1[1][2], act.h1[1][3]);
+        tp[3] = make_float4(act.h2[0][0], act.h2[0][1], act.h2[0][2], act.h2[0][3]);
+        tp[4] = make_float4(act.h2[1][0], act.h2[1][1], act.h2[1][2], act.h2[1][3]);
+        sv = nsv;
+    }
+    return sv;
+}
+
+// reverse sweep for the wave's 16 plans; lanes of group 0 write g_s[h][col] and return sum_h g^2
+CTK_DEV float rpgd_backward_mlp(const RolloutArgs& a, const EnvK& k, const MlpBwdW& w, const float* q_s, const float* tape,
+                                float* g_s, int col, int g, float svH, float uprev0) {
+    const int lane = threadIdx.x & 63;
+    const int H = a.H;
+    const float inv = a.inv_Hp1;
+    const float two_dd = 2.0f * k.dd_weight * k.inv_xs * k.inv_xs;
+    // terminal adjoint share of lane group g
+    float snT, csT;
+    ctk_sincosf(svH, &snT, &csT);
+    float lam = k.terminal_weight * inv * (g == 0 ? two_dd * (svH - k.target_position) : (g == 2 ? 2.0f * k.ep_c * (1.0f - csT) * snT : 0.0f));
+    float nrm2 = 0.0f;
+    float u_hp1 = 0.0f, u_h = q_s[(H - 1) * RP_LD + col];
+    const float4* tp = reinterpret_cast<const float4*>(tape + ((size_t)(H - 1) * 64 + lane) * RP_MLP_TAPE);
+    float4 r0 = tp[0], r1 = tp[1], r2 = tp[2], r3 = tp[3], r4 = tp[4];
+    for (int h = H - 1; h >= 0; --h) {
+        MlpAct act;
+        act.h1[0] = f32x4{r1.x, r1.y, r1.z, r1.w}; act.h1[1] = f32x4{r2.x, r2.y, r2.z, r2.w};
+        act.h2[0] = f32x4{r3.x, r3.y, r3.z, r3.w}; act.h2[1] = f32x4{r4.x, r4.y, r4.z, r4.w};
+        const float sv = r0.x;
+        if (h > 0) {   // prefetch the previous step's tape while this step's MFMAs run
+            const float4* tq = reinterpret_cast<const float4*>(tape + ((size_t)(h - 1) * 64 + lane) * RP_MLP_TAPE);
+            r0 = tq[0]; r1 = tq[1]; r2 = tq[2]; r3 = tq[3]; r4 = tq[4];
+        }
+        const float u_hm1 = h > 0 ? q_s[(h - 1) * RP_LD + col] : uprev0;
+        float du;
+        const float ds = mlp_step_vjp(w, act, lam, &du);
+        float gu = 2.0f * k.ccR * u_h + 2.0f * k.ccrc_weight * (u_h - u_hm1);
+        if (h + 1 < H) gu -= 2.0f * k.ccrc_weight * (u_hp1 - u_h);
+        const float gq = gu * inv + du;
+        if (g == 0) { g_s[h * RP_LD + col] = gq; nrm2 += gq * gq; }
+        float sn, cs;
+        ctk_sincosf(sv, &sn, &cs);
+        const float share = g == 0 ? two_dd * (sv - k.target_position)
+                          : (g == 2 ? 2.0f * k.ep_c * (1.0f - cs) * sn : (g == 3 ? 2.0f * k.ekp_weight * sv : 0.0f));
+        lam = share * inv + ds;
+        u_hp1 = u_h; u_h = u_hm1;
+    }
+    return nrm2;
+}
+
 struct AdamK {
     float lr, b1, b2, one_m_b1, one_m_b2, eps, clip;
 };
@@ -174,6 +241,31 @@ __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_descent(RolloutArgs a, EnvK
             const float J = rollout_ode<false, false>(a, k, n, valid, [&](int h) { return q_s[h * RP_LD + lane]; });
             if (valid) a.J[n] = J;
         }
+    }
+    else {
+        const MlpFwdW wf = mlp_load_fwd(wperm);
+        const MlpBwdW wb = mlp_load_bwd(wperm);
+        const int g = lane >> 4, col = wave * CTK_MLP_TRAJ_PER_WAVE + (lane & 15);
+        float* tape = scratch + (size_t)(blockIdx.x * RP_WAVES + wave) * H * 64 * RP_MLP_TAPE;
+        for (int it = 0; it < iters; ++it) {
+            const float svH = rpgd_forward_mlp_tape(a, wf, q_s, tape, col, g);
+            const float nrm2 = rpgd_backward_mlp(a, k, wb, q_s, tape, g_s, col, g, svH, uprev0);
+            if (g == 0) sc_s[col] = ad.clip / fmaxf(sqrtf(nrm2), ad.clip);
+            __syncthreads();
+            const int ti = t0 + it + 1;
+            const float bc1 = ti <= bc_len ? bc_table[2 * (ti - 1)] : 1.0f;
+            const float bc2 = ti <= bc_len ? bc_table[2 * (ti - 1) + 1] : 1.0f;
+            for (int i = t; i < total; i += RP_BLOCK) {
+                const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;
+                float mm = m[gbase + i], vv = v[gbase + i];
+                const float gg = g_s[h * RP_LD + r] * sc_s[r];
+                q_s[h * RP_LD + r] = adam_update(ad, q_s[h * RP_LD + r], gg, mm, vv, bc1, bc2, a.lo, a.hi);
+                m[gbase + i] = mm; v[gbase + i] = vv;
+            }
+            __syncthreads();
+        }
+        const float J = rollout_mlp<false, false>(a, k, wf, row0 + wave * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return q_s[h * RP_LD + col]; });
+        if (lane < 16 && row0 + col < a.N) a.J[row0 + col] = J;
     }
     __syncthreads();
     for (int i = t; i < total; i += RP_BLOCK) {
@@ -259,7 +351,7 @@ size_t ctk_rpgd_descent_lds(int pred, int H, bool* tape_in_lds) {
 
 size_t ctk_rpgd_scratch_floats(int pred, int N, int H) {
     const size_t blocks = (N + RP_TRAJ - 1) / RP_TRAJ;
-    return pred == CTK_PRED_ODE ? blocks * H * RP_NS * 64 : blocks * 4 * (size_t)H * 64 * 20;
+    return pred == CTK_PRED_ODE ? blocks * H * RP_NS * 64 : blocks * RP_WAVES * (size_t)H * 64 * RP_MLP_TAPE;
 }
 
 hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, float lr, float b1, float b2,
@@ -273,7 +365,8 @@ hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& 
         CTK_LAUNCH((ctk_rpgd_descent<CTK_PRED_ODE>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm,
                    scratch, tape_in_lds ? 1 : 0);
     else
-        return hipErrorNotSupported;
+        CTK_LAUNCH((ctk_rpgd_descent<CTK_PRED_MLP>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm,
+                   scratch, 0);
     return hipGetLastError();
 }
 
