@@ -1,0 +1,130 @@
+"""CPU tests (-m "not gpu"): the C-ABI library loads and exports every symbol include/ctk_hip.h
+declares, the ctypes struct matches the C struct, and the host-side mirror of the reference's
+plugin interface behaves like the reference (names, argument meaning, error behaviour).  No
+compute call is made: without a GPU the engine must fail loudly, never fall back."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ctk_hip.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ctk_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from control_toolkit_amd._capi import load_library, SYMBOLS, library_path
+    lib = load_library()
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"libctk_hip.so does not export {n}"
+    assert set(names) == set(SYMBOLS), "ctypes binding and header disagree"
+    assert lib.ctk_abi_version() == 1
+    assert os.path.dirname(library_path()).endswith("control_toolkit_amd")   # in-tree, not site-packages
+
+
+def test_ctypes_config_matches_c_struct(tmp_path):
+    """sizeof/offsetof of ctk_config as the C compiler sees it == the ctypes mirror."""
+    from control_toolkit_amd._capi import CtkConfig
+    fields = [f[0] for f in CtkConfig._fields_]
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "ctk_hip.h"\nint main(){printf("%zu", sizeof(ctk_config));'
+    for f in fields:
+        prog += f'printf(" %zu", offsetof(ctk_config, {f}));'
+    prog += "return 0;}"
+    c = tmp_path / "s.c"; c.write_text(prog)
+    exe = tmp_path / "s"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) == ctypes.sizeof(CtkConfig)
+    for name, off in zip(fields, out[1:]):
+        assert getattr(CtkConfig, name).offset == int(off), name
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from control_toolkit_amd import CtkEngine, CtkError
+    with pytest.raises(CtkError, match="no HIP device|No HIP|no CPU fallback"):
+        CtkEngine("mppi", "ODE", num_rollouts=32, mpc_horizon=10, dt=0.02)
+    with pytest.raises(ValueError):
+        CtkEngine("nope", "ODE", num_rollouts=32, mpc_horizon=10, dt=0.02)
+    with pytest.raises(NotImplementedError):
+        CtkEngine("mppi", "GRU-6IN-32H1-32H2-5OUT-0", num_rollouts=32, mpc_horizon=10, dt=0.02)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under control_toolkit_amd/ may import or load it."""
+    pkg = os.path.join(ROOT, "control_toolkit_amd")
+    pat = re.compile(r"^\s*(from|import)\s+\S*oracle|importlib.*oracle|CDLL\(.*oracle", re.I)
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                for line in open(os.path.join(dp, f)):
+                    assert not pat.search(line), f"{f}: {line.strip()}"
+    for f in ("bench.py",):
+        body = open(os.path.join(ROOT, f)).read()
+        assert body.count("from oracle import") == 1 and "def cpu_baseline" in body   # only the cpu_baseline leg
+
+
+def test_hip_library_gate_and_optimizer_discovery():
+    from control_toolkit_amd.computation_library import HipLibrary
+    from control_toolkit_amd.others.globals_and_utils import import_optimizer_by_name, find_optimizer_if_it_exists, create_rng
+    from control_toolkit_amd.Predictors import PredictorWrapper
+    from control_toolkit_amd.Cost_Functions import CostFunctionWrapper
+    lib = HipLibrary()
+    assert lib.lib == "HIP" and lib.to_tensor([1, 2], lib.float32).dtype == np.float32
+    lib.set_device("gpu:0")(lambda: None)
+    with pytest.raises(ValueError):
+        lib.set_device("/device:CPU:0")
+    # discovery by file name, class name == file stem (reference globals_and_utils.py:103-133)
+    for name in ("mppi-hip", "cem-hip", "rpgd-hip", "random-action-hip"):
+        cls = import_optimizer_by_name(name)
+        assert cls.__name__ == "optimizer_" + name.replace("-", "_")
+        assert find_optimizer_if_it_exists(name)[0] == cls.__name__
+    with pytest.raises(ValueError):
+        import_optimizer_by_name("does-not-exist")
+    Mppi = import_optimizer_by_name("mppi-hip")
+    lim = (np.array([-1.0], np.float32), np.array([1.0], np.float32))
+    kw = dict(predictor=PredictorWrapper(), cost_function=CostFunctionWrapper(), control_limits=lim, seed=1,
+              cc_weight=1.0, R=1.0, LBD=100.0, mpc_horizon=10, num_rollouts=32, NU=1000.0, SQRTRHOINV=0.03,
+              period_interpolation_inducing_points=1, optimizer_logging=False, calculate_optimal_trajectory=False,
+              mpc_timestep=0.02)   # extra YAML keys are swallowed by **kwargs like the reference's
+    with pytest.raises(ValueError, match="does not support"):   # reference Optimizers/__init__.py:27-28
+        Mppi(computation_library=object(), **kw)
+    o = Mppi(computation_library=lib, **kw)
+    assert o.optimizer_name == "mppi-hip" and o.num_rollouts == 32 and o.mpc_horizon == 10 and o.logging_values == {}
+    assert create_rng("x", None, lib).seed > 0                       # None -> datetime seed (:87-91)
+    r = create_rng("x", 3, lib, mode="host")
+    assert r.normal([4, 2, 1]).shape == (4, 2, 1) and 0 <= r.uniform([3]).min() < 1
+    with pytest.raises(NotImplementedError):
+        PredictorWrapper().configure(batch_size=1, dt=0.02, predictor_specification="GRU-6IN-32H1-32H2-5OUT-0")
+    with pytest.raises(ValueError):
+        PredictorWrapper().configure(batch_size=1, dt=0.02, predictor_specification="MLP")   # no weights
+
+
+def test_controller_config_errors_match_reference():
+    from control_toolkit_amd.Controllers.controller_mpc import controller_mpc
+    lim = (np.array([-1.0], np.float32), np.array([1.0], np.float32))
+    with pytest.raises(ValueError, match="could not be interpreted"):   # reference Controllers/__init__.py:57-58
+        controller_mpc("CartPole", lim, {}, config_controllers={"mpc": {"computation_library": "tensorflow", "controller_logging": False}})
+    c = controller_mpc("CartPole", lim, {"target_position": 0.1},
+                       config_controllers={"mpc": {"optimizer": "mppi-hip", "computation_library": "hip", "controller_logging": True,
+                                                   "device": "gpu:0"}},
+                       config_optimizers={})
+    assert c.controller_name == "mpc" and c.has_optimizer and c.lib.lib == "HIP"
+    assert float(c.variable_parameters.target_position) == np.float32(0.1)
+    c.update_logs({"Q_logged": np.zeros((2, 3, 1), np.float32), "J_logged": np.zeros(2, np.float32)})
+    c.update_logs({"Q_logged": np.ones((2, 3, 1), np.float32), "J_logged": np.ones(2, np.float32)})
+    out = c.get_outputs()                                               # stacked along axis 0 (:159-168)
+    assert out["Q_logged"].shape == (2, 2, 3, 1) and out["s_logged"] is None
