@@ -166,7 +166,12 @@ class CtkEngine:
             msg = lib.ctk_last_error(None).decode()
             self._h = _H()
             raise (ValueError if rc == 1 else NotImplementedError if rc == 2 else CtkError)(msg)
+        # preallocated argument buffers: the per-step call path does no allocation and no ndarray->ctypes casts
         self._u = np.zeros(1, np.float32)
+        self._s = np.zeros(4, np.float32)
+        self._up = np.zeros(1, np.float32)
+        self._u_p, self._s_p, self._up_p = self._u.ctypes.data, self._s.ctypes.data, self._up.ctypes.data
+        self._step_fn = lib.ctk_step
 
     # ---- plumbing ------------------------------------------------------------------------------
     def _check(self, rc: int):
@@ -216,21 +221,27 @@ class CtkEngine:
 
     def step(self, s, samples=None, loc: int = None, u_prev=None) -> np.ndarray:
         """samples: None (device Philox), a host ndarray (parity mode) or an int device pointer."""
-        s = _f32(s).reshape(-1)
-        if s.size != 4:
-            raise ValueError("state must have 4 entries")
-        up = None if u_prev is None else _f32(u_prev).reshape(-1)[:1].copy()
+        try:
+            self._s[:] = np.asarray(s).reshape(-1)
+        except ValueError:
+            raise ValueError("state must have 4 entries") from None
+        up_p = None
+        if u_prev is not None:
+            self._up[0] = np.asarray(u_prev).reshape(-1)[0]
+            up_p = self._up_p
         if samples is None:
             sp, loc = None, LOC_NONE
-        elif isinstance(samples, int):
-            sp, loc = C.c_void_p(samples), LOC_DEVICE
+        elif type(samples) is int:
+            sp, loc = samples, LOC_DEVICE
         else:
             arr = _f32(samples)
             need = self.samples_needed()
             if arr.size != need:
                 raise ValueError(f"step consumes {need} draws, got {arr.size}")
-            sp, loc = _ptr(arr), LOC_HOST
-        self._check(self._lib.ctk_step(self._h, _ptr(s), _ptr(up), sp, loc, _ptr(self._u)))
+            sp, loc = arr.ctypes.data, LOC_HOST
+        rc = self._step_fn(self._h, self._s_p, up_p, sp, loc, self._u_p)
+        if rc:
+            self._check(rc)
         return self._u.copy()
 
     def rollout(self, s, Q, u_prev=0.0, want_traj=True):

@@ -1,5 +1,6 @@
 // ctk_api.hip — the C ABI of libctk_hip.so (include/ctk_hip.h): handle, device state, step
 // sequencing.  All compute is in the HIP kernels; there is no CPU fallback.
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -36,6 +37,7 @@ struct ctk_handle {
     float* d_traj = nullptr;
     float* d_parts = nullptr;   size_t parts_cap = 0;
     float* d_parts2 = nullptr;
+    unsigned* d_counter = nullptr;   // ticket counter of the fused in-launch merge
     float* d_unom[2] = {nullptr, nullptr};   // MPPI u_nom ping-pong / CEM mu in [0]
     int cur = 0;
     float* d_std = nullptr;     // CEM
@@ -43,8 +45,9 @@ struct ctk_handle {
     float* d_scale = nullptr;
     int* d_idx = nullptr;       // best indices [N]
     float* d_u = nullptr;       // optimizer's last output (device)
-    float* h_u = nullptr;       // pinned, device-visible host copy of u
+    float* h_u = nullptr;       // pinned, coherent, device-visible host slot: {u, sequence number} written by ONE 8-B store
     float* h_u_dev = nullptr;   // device pointer aliasing h_u
+    uint32_t seq = 1;           // sequence number the NEXT publishing kernel will write (the slot starts at 0)
     float* d_weights = nullptr; // MLP: raw [1380]
     float* d_wperm = nullptr;   // MLP: per-lane permuted, forward [64][48] then backward [64][28]
     // RPGD: population, Adam moments, ages (ping-pong), bias-correction table, adjoint scratch
@@ -245,9 +248,25 @@ struct ProfSlot {
     }
 };
 
+// Completion of a step = the publishing kernel's single 8-byte system-scope store {u, seq} landing in
+// the pinned host slot.  Polling it avoids the completion-signal round trip of
+// hipStreamSynchronize (several microseconds per step); the spin is bounded, and on timeout the
+// stream is synchronised so that a device fault surfaces as an error instead of a hang.
 int finish_step(ctk_handle* h, float* u_out) {
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (u_out) u_out[0] = *h->h_u;
+    const uint32_t want = h->seq;
+    volatile uint32_t* slot = reinterpret_cast<volatile uint32_t*>(h->h_u) + 1;
+    bool seen = false;
+    for (int spin = 0; spin < 4000000; ++spin) {
+        if (*slot == want) { seen = true; break; }
+        __builtin_ia32_pause();
+    }
+    if (!seen) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (*slot != want) return fail(h, CTK_ERR_HIP, "step finished without publishing its result");
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (u_out) u_out[0] = *reinterpret_cast<volatile float*>(h->h_u);
+    ++h->seq;
     ++h->call;
     return CTK_OK;
 }
@@ -259,19 +278,26 @@ int check_predictor(ctk_handle* h) {
 }
 
 // ---- MPPI ------------------------------------------------------------------------------------
-int mppi_rollout(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc) {
+int mppi_block_parts(const ctk_handle* h) { return ctk_mppi_num_blocks(h->N); }
+bool mppi_can_fuse(const ctk_handle* h) { return mppi_block_parts(h) <= CTK_MPPI_FUSE_MAX_BLOCKS; }
+
+// fuse_mode: 0 block records only; 1 the last block also merges + updates (single-GPU step);
+//            2 the last block emits this shard's ONE record into partial_dev (sharded step_begin)
+int mppi_rollout(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc, int fuse_mode,
+                 float* partial_dev) {
     const float* d_s = nullptr;
     if (int rc = resolve_samples(h, samples, loc, (size_t)h->N * h->P, &d_s)) return rc;
     RolloutArgs a = make_args(h, s, u_prev, h->N, h->P);
     const bool log = h->cfg.materialize_trajectories != 0;
     if (int rc = check_predictor(h)) return rc;
+    MppiFuse fz;
+    fz.mode = fuse_mode; fz.counter = h->d_counter; fz.out_rec = partial_dev;
+    fz.u_nom_out = h->d_unom[h->cur ^ 1]; fz.u_dev = h->d_u; fz.u_host = h->h_u_dev; fz.seq = h->seq;
     ProfSlot ps(h);
     HIP_TRY(h, ctk_launch_mppi_rollout(h->stream, h->cfg.predictor, a, h->k, h->mk, d_s, h->d_unom[h->cur], h->d_wperm,
-                                       h->d_parts, log, ps.a, ps.b));
+                                       h->d_parts, log, fz, ps.a, ps.b));
     return CTK_OK;
 }
-
-int mppi_block_parts(const ctk_handle* h) { return ctk_mppi_num_blocks(h->N); }
 
 // reduce the block records to <= 2048 records (hierarchical when the grid was huge)
 int mppi_reduce_blocks(ctk_handle* h, const float** parts, int* n_parts) {
@@ -289,7 +315,7 @@ int mppi_reduce_blocks(ctk_handle* h, const float** parts, int* n_parts) {
 int mppi_update(ctk_handle* h, const float* parts, int n_parts, float* u_out) {
     const int nxt = h->cur ^ 1;
     HIP_TRY(h, ctk_launch_mppi_update(h->stream, parts, n_parts, h->P, h->mk.neg_inv_lbd, h->H, h->d_interp, h->d_unom[h->cur],
-                                      h->d_unom[nxt], h->cfg.action_low, h->cfg.action_high, h->d_u, h->h_u_dev));
+                                      h->d_unom[nxt], h->cfg.action_low, h->cfg.action_high, h->d_u, h->h_u_dev, h->seq));
     h->cur = nxt;
     return finish_step(h, u_out);
 }
@@ -314,7 +340,7 @@ int cem_step(ctk_handle* h, const float* s, const float* u_prev, const float* sa
     }
     const float mid = (h->cfg.action_low + h->cfg.action_high) * 0.5f;
     HIP_TRY(h, ctk_launch_cem_finish(h->stream, h->d_Q, h->d_idx, h->H, mu, h->d_std, h->cfg.cem_stdev_min,
-                                     h->cfg.cem_initial_action_stdev, mid, h->d_u, h->h_u_dev));
+                                     h->cfg.cem_initial_action_stdev, mid, h->d_u, h->h_u_dev, h->seq));
     ++h->count;
     return finish_step(h, u_out);
 }
@@ -329,7 +355,7 @@ int random_step(ctk_handle* h, const float* s, const float* u_prev, const float*
     HIP_TRY(h, ctk_launch_affine_rollout(h->stream, h->cfg.predictor, a, h->k, d_s, 1, h->d_base, h->d_scale, h->d_wperm,
                                          h->cfg.materialize_trajectories != 0, ps.a, ps.b));
     HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, 1, h->d_idx, nullptr));
-    HIP_TRY(h, ctk_launch_pick_best_first(h->stream, h->d_Q, h->d_idx, h->H, h->d_u, h->h_u_dev));
+    HIP_TRY(h, ctk_launch_pick_best_first(h->stream, h->d_Q, h->d_idx, h->H, h->d_u, h->h_u_dev, h->seq));
     return finish_step(h, u_out);
 }
 
@@ -345,7 +371,7 @@ int rpgd_warm(ctk_handle* h, const RolloutArgs& a, int n_new, int gather, int re
                                          reset, c.action_low, c.action_high, c.sample_stdev, c.sample_mean, c.sample_min,
                                          c.sample_max, d_draws, h->d_idx, h->d_pop[from], h->d_m[from], h->d_v[from],
                                          h->d_ages[from], h->d_pop[to], h->d_m[to], h->d_v[to], h->d_ages[to], h->d_interp,
-                                         h->d_unom[0], h->d_u, h->h_u_dev));
+                                         h->d_unom[0], h->d_u, h->h_u_dev, h->seq));
     return CTK_OK;
 }
 
@@ -478,6 +504,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     h->parts_cap = nblk * (2 + P);
     TRY_CREATE(dev_alloc(h, &h->d_parts, h->parts_cap));
     TRY_CREATE(dev_alloc(h, &h->d_parts2, ((nblk + 63) / 64) * (2 + P)));
+    TRY_CREATE(dev_alloc(h, &h->d_counter, 1));
     TRY_CREATE(dev_alloc(h, &h->d_unom[0], H));
     TRY_CREATE(dev_alloc(h, &h->d_unom[1], H));
     TRY_CREATE(dev_alloc(h, &h->d_std, H));
@@ -487,8 +514,8 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     TRY_CREATE(dev_alloc(h, &h->d_u, 1));
     TRY_CREATE(dev_alloc(h, &h->d_weights, CTK_MLP_NW));
     TRY_CREATE(dev_alloc(h, &h->d_wperm, (size_t)64 * (MLP_FWD_PER_LANE + MLP_BWD_PER_LANE)));
-    HIP_CREATE(hipHostMalloc((void**)&h->h_u, 64, hipHostMallocMapped));
-    *h->h_u = 0.0f;
+    HIP_CREATE(hipHostMalloc((void**)&h->h_u, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(h->h_u, 0, 64);
     HIP_CREATE(hipHostGetDevicePointer((void**)&h->h_u_dev, h->h_u, 0));
 
     if (cfg->optimizer == CTK_OPT_RPGD) {
@@ -530,7 +557,7 @@ void ctk_destroy(ctk_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (auto& e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     void* bufs[] = {h->d_interp, h->d_samples, h->d_J, h->d_Q, h->d_traj, h->d_parts, h->d_parts2, h->d_unom[0], h->d_unom[1],
-                    h->d_std, h->d_base, h->d_scale, h->d_idx, h->d_u, h->d_weights, h->d_wperm,
+                    h->d_std, h->d_base, h->d_scale, h->d_idx, h->d_u, h->d_weights, h->d_wperm, h->d_counter,
                     h->d_pop[0], h->d_pop[1], h->d_m[0], h->d_m[1], h->d_v[0], h->d_v[1], h->d_ages[0], h->d_ages[1], h->d_bc, h->d_scratch};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_u) hipHostFree(h->h_u);
@@ -560,7 +587,6 @@ int ctk_reset(ctk_handle* h, const float* draws, int draws_loc) {
         case CTK_OPT_CEM: {  // optimizer_cem_tf.py:113-117 (self.u = 0.0)
             if (int rc = fill_const(h, h->d_unom[0], (h->cfg.action_low + h->cfg.action_high) * 0.5f, h->H)) return rc;
             if (int rc = fill_const(h, h->d_std, h->cfg.cem_initial_action_stdev, h->H)) return rc;
-            *h->h_u = 0.0f;
             return fill_const(h, h->d_u, 0.0f, 1);
         }
         case CTK_OPT_RANDOM_ACTION:   // :78-86 draws and discards a sample
@@ -607,7 +633,12 @@ int ctk_step(ctk_handle* h, const float* s, const float* u_prev, const float* sa
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     switch (h->cfg.optimizer) {
         case CTK_OPT_MPPI: {
-            if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc)) return rc;
+            if (mppi_can_fuse(h)) {   // one launch: the last block to finish merges and updates
+                if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 1, nullptr)) return rc;
+                h->cur ^= 1;
+                return finish_step(h, u_out);
+            }
+            if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 0, nullptr)) return rc;
             const float* parts; int n_parts;
             if (int rc = mppi_reduce_blocks(h, &parts, &n_parts)) return rc;
             return mppi_update(h, parts, n_parts, u_out);
@@ -627,10 +658,14 @@ int ctk_mppi_step_begin(ctk_handle* h, const float* s, const float* u_prev, cons
     if (h->cfg.optimizer != CTK_OPT_MPPI) return fail(h, CTK_ERR_STATE, "ctk_mppi_step_begin: handle is not MPPI");
     if (h->mppi_pending) return fail(h, CTK_ERR_STATE, "ctk_mppi_step_begin: previous sharded step not ended");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc)) return rc;
-    const float* parts; int n_parts;
-    if (int rc = mppi_reduce_blocks(h, &parts, &n_parts)) return rc;
-    HIP_TRY(h, ctk_launch_mppi_merge_partial(h->stream, parts, n_parts, n_parts, h->P, h->mk.neg_inv_lbd, partial_dev));
+    if (mppi_can_fuse(h)) {
+        if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 2, partial_dev)) return rc;
+    } else {
+        if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 0, nullptr)) return rc;
+        const float* parts; int n_parts;
+        if (int rc = mppi_reduce_blocks(h, &parts, &n_parts)) return rc;
+        HIP_TRY(h, ctk_launch_mppi_merge_partial(h->stream, parts, n_parts, n_parts, h->P, h->mk.neg_inv_lbd, partial_dev));
+    }
     h->mppi_pending = true;
     return CTK_OK;
 }

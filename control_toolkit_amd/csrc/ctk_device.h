@@ -173,6 +173,14 @@ CTK_DEV void draw4(const RolloutArgs& a, uint32_t row, uint32_t cb, int kind, fl
     }
 }
 
+// Publishes the step's result: u to the device copy, and {u, seq} to the pinned host slot with ONE
+// 8-byte system-scope release store (the host polls seq; ctk_api.hip:finish_step).
+CTK_DEV void publish_u(float* u_dev, float* u_host, float u, uint32_t seq) {
+    *u_dev = u;
+    const unsigned long long v = ((unsigned long long)seq << 32) | (unsigned long long)__builtin_bit_cast(unsigned, u);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(u_host), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // row stride of the per-block sample tile in LDS: odd (conflict-free column walks with
 // ds_read_b32: bank = addr/4 mod 32) and >= P+1 so that column P is a readable zero pad.
 __host__ __device__ inline int tile_stride(int P) { return (P + 1) | 1; }

@@ -16,14 +16,23 @@ const char* ctk_mppi_rollout_name(int pred, bool log);
 int ctk_mppi_num_blocks(int N);
 size_t ctk_mppi_rollout_lds(int P, int H);
 // wperm: per-lane permuted MLP weights (ctk_api.hip: permute_mlp_weights), nullptr for the ODE predictor
+// In-launch merge by the last block to finish (<= CTK_MPPI_FUSE_MAX_BLOCKS blocks).
+constexpr int CTK_MPPI_FUSE_MAX_BLOCKS = 256;
+struct MppiFuse {
+    int mode = 0;              // 0 records only, 1 merge + update u_nom/u, 2 merge into ONE record (sharded step_begin)
+    unsigned* counter = nullptr;
+    float* out_rec = nullptr;  // mode 2
+    float* u_nom_out = nullptr, *u_dev = nullptr, *u_host = nullptr;   // mode 1
+    uint32_t seq = 0;          // sequence number published with u (mode 1)
+};
 hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const MppiK& m,
                                    const float* samples, const float* u_nom, const float* wperm, float* parts, bool log,
-                                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                                   const MppiFuse& fuse, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t ctk_launch_mppi_merge_partial(hipStream_t st, const float* parts, int n_parts, int per_block, int P,
                                          float neg_inv_lbd, float* out_rec);
 hipError_t ctk_launch_mppi_update(hipStream_t st, const float* parts, int n_parts, int P, float neg_inv_lbd, int H,
                                   const InterpEntry* interp, const float* u_nom_in, float* u_nom_out, float lo, float hi,
-                                  float* u_dev, float* u_host);
+                                  float* u_dev, float* u_host, uint32_t seq);
 
 // ---- ctk_sampled.hip : u[n,h] = clip(base[h] + sample[n,h] * scale[h]) rollouts, selection ----
 const char* ctk_affine_rollout_name(int pred, bool log);
@@ -37,9 +46,9 @@ hipError_t ctk_launch_select_topk(hipStream_t st, const float* J, int N, int K, 
 hipError_t ctk_launch_cem_refit(hipStream_t st, const float* Q, const int* idx, int K, int H, float* mu, float* sd);
 // CEM post-loop (optimizer_cem_tf.py:99-102) and u = elite[0,0]
 hipError_t ctk_launch_cem_finish(hipStream_t st, const float* Q, const int* idx, int H, float* mu, float* sd,
-                                 float std_min, float init_std, float mid, float* u_dev, float* u_host);
+                                 float std_min, float init_std, float mid, float* u_dev, float* u_host, uint32_t seq);
 // random-action: u = Q[argmin J, 0]  (optimizer_random_action_tf.py:65-68)
-hipError_t ctk_launch_pick_best_first(hipStream_t st, const float* Q, const int* idx, int H, float* u_dev, float* u_host);
+hipError_t ctk_launch_pick_best_first(hipStream_t st, const float* Q, const int* idx, int H, float* u_dev, float* u_host, uint32_t seq);
 
 // ---- ctk_rpgd.hip ---------------------------------------------------------------------------
 const char* ctk_rpgd_descent_name(int pred);
@@ -55,4 +64,4 @@ hipError_t ctk_launch_rpgd_warmstart(hipStream_t st, const RolloutArgs& a, int N
                                      float sample_mean, float sample_min, float sample_max, const float* draws, const int* idx,
                                      const float* Q_old, const float* m_old, const float* v_old, const float* ages_old,
                                      float* Q_new, float* m_new, float* v_new, float* ages_new, const InterpEntry* interp,
-                                     float* u_nom, float* u_dev, float* u_host);
+                                     float* u_nom, float* u_dev, float* u_host, uint32_t seq);

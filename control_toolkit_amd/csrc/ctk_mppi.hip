@@ -35,13 +35,133 @@ constexpr int MPPI_BLOCK = MPPI_TRAJ * MPPI_WAVES;
 // LDS carve (floats): tile[64][ts] | ubuf[64][us] | corr[4][64] | e[64] | colsum[4][P] | w0,w1,un,i0 [H] each
 __host__ __device__ inline int ubuf_stride(int H) { return (H + 1) | 1; }
 
+// ---------------------------------------------------------------------------------------------
+// merge of partial records {rho, a, b[P]} by one 256-thread block.
+// FINAL=false: writes one merged record to `out_rec`.
+// FINAL=true : applies the MPPI update and publishes u.
+// SC1: the records were handed over inside ONE launch (fused tail below): every load of them is an
+//      agent-scope relaxed atomic load (global_load ... sc1), cdna_hip_programming.md G16.
+// ---------------------------------------------------------------------------------------------
+constexpr int MERGE_BLOCK = 256;
+constexpr int MERGE_CHUNK = 1024;
+
+template <bool SC1>
+CTK_DEV float ld_rec(const float* p) {
+    if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+CTK_DEV void st_rec(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct MppiUpdateArgs {
+    int H;
+    const InterpEntry* interp;
+    const float* u_nom_in;
+    float* u_nom_out;
+    float lo, hi;
+    float* u_dev;
+    float* u_host;
+    uint32_t seq;
+};
+
+// scratch: >= 8 + (P + 1) + min(cnt, MERGE_CHUNK) floats of LDS
+template <bool FINAL, bool SC1>
+CTK_DEV void mppi_merge_block(float* scratch, const float* base, int cnt, int P, float neg_inv_lbd, float* out_rec,
+                              const MppiUpdateArgs& up) {
+    float* red = scratch;             // [4] cross-wave scratch
+    float* b_s = scratch + 8;         // [P + 1] merged numerator
+    float* sc_s = b_s + P + 1;        // [chunk] per-record rescale factors
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int rs = 2 + P;
+
+    float r = INFINITY;
+    for (int i = t; i < cnt; i += MERGE_BLOCK) r = fminf(r, ld_rec<SC1>(base + (size_t)i * rs));
+    r = wave_min(r);
+    if (lane == 0) red[wave] = r;
+    __syncthreads();
+    const float rho = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+    __syncthreads();
+
+    float a_acc = 0.0f;
+    float b_acc[4] = {0.f, 0.f, 0.f, 0.f};   // thread t owns columns t, t+256, ... (P <= 1024)
+    for (int c0 = 0; c0 < cnt; c0 += MERGE_CHUNK) {
+        const int cn = min(MERGE_CHUNK, cnt - c0);
+        for (int i = t; i < cn; i += MERGE_BLOCK) {
+            const float* rec = base + (size_t)(c0 + i) * rs;
+            const float sc = expf(neg_inv_lbd * (ld_rec<SC1>(rec) - rho));   // e^{-(rho_r - rho)/lambda}
+            sc_s[i] = sc;
+            a_acc += ld_rec<SC1>(rec + 1) * sc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = t + j * MERGE_BLOCK;
+            if (p < P) {
+                float acc = b_acc[j];
+                for (int i = 0; i < cn; ++i) acc += ld_rec<SC1>(base + (size_t)(c0 + i) * rs + 2 + p) * sc_s[i];
+                b_acc[j] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    a_acc = wave_sum(a_acc);
+    if (lane == 0) red[wave] = a_acc;
+    __syncthreads();
+    const float a_tot = red[0] + red[1] + red[2] + red[3];
+
+    if constexpr (!FINAL) {
+        if (t == 0) { out_rec[0] = rho; out_rec[1] = a_tot; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = t + j * MERGE_BLOCK;
+            if (p < P) out_rec[2 + p] = b_acc[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = t + j * MERGE_BLOCK;
+            if (p < P) b_s[p] = b_acc[j];
+        }
+        if (t == 0) b_s[P] = 0.0f;   // pad read by i0+1 when P == 1
+        __syncthreads();
+        for (int h = t; h < up.H; h += MERGE_BLOCK) {
+            const InterpEntry e = up.interp[h];
+            const float w = (b_s[e.i0] * e.w0 + b_s[e.i0 + 1] * e.w1) / a_tot;
+            const float un = up.u_nom_in[min(h + 1, up.H - 1)];
+            const float o = fminf(fmaxf(un + w, up.lo), up.hi);   // optimizer_mppi.py:190
+            up.u_nom_out[h] = o;
+            if (h == 0) publish_u(up.u_dev, up.u_host, o, up.seq);   // :191 u = u_nom[0,0,:]
+        }
+    }
+}
+
+// grid.x blocks; block b merges records [b*per_block, ...)
+template <bool FINAL>
+__global__ __launch_bounds__(MERGE_BLOCK) void ctk_mppi_merge(const float* __restrict__ parts, int n_parts, int per_block,
+                                                             int P, float neg_inv_lbd, float* __restrict__ out_rec,
+                                                             MppiUpdateArgs up) {
+    extern __shared__ float lds[];
+    const int first = blockIdx.x * per_block;
+    const int cnt = min(per_block, n_parts - first);
+    mppi_merge_block<FINAL, false>(lds, parts + (size_t)first * (2 + P), cnt, P, neg_inv_lbd,
+                                   out_rec ? out_rec + (size_t)blockIdx.x * (2 + P) : nullptr, up);
+}
+
+// In-launch tail of the rollout kernel (single-GPU, <= 256 blocks): the block whose ticket is last
+// merges all block records and applies the update, saving the second launch and its boundary.
+struct FuseArgs {
+    int mode;             // 0: records only; 1: last block merges + updates u_nom/u; 2: last block emits ONE merged record
+    unsigned* counter;    // zero before the launch; the last block resets it
+    float* out_rec;       // mode 2
+    MppiUpdateArgs up;    // mode 1
+};
+
 template <int PRED, bool LOG>
 __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, EnvK k, MppiK m,
                                                                const float* __restrict__ samples,
                                                                const float* __restrict__ u_nom,
                                                                const InterpEntry* __restrict__ interp,
                                                                const float* __restrict__ wperm,
-                                                               float* __restrict__ parts) {
+                                                               float* __restrict__ parts, FuseArgs fz) {
     extern __shared__ float lds[];
     const int P = a.P, H = a.H, ts = tile_stride(P), us = ubuf_stride(H);
     float* tile = lds;                         // [64][ts]  stdev * noise at the inducing points
@@ -128,7 +248,7 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
         e_s[lane] = e;
         if (lane == 0) {
             float* rec = parts + (size_t)blockIdx.x * (2 + P);
-            rec[0] = rho; rec[1] = asum;
+            st_rec(rec, rho); st_rec(rec + 1, asum);
         }
     }
     __syncthreads();
@@ -143,97 +263,31 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
     }
     __syncthreads();
     float* rec = parts + (size_t)blockIdx.x * (2 + P);
-    for (int p = t; p < P; p += MPPI_BLOCK) rec[2 + p] = (col_s[p] + col_s[P + p]) + (col_s[2 * P + p] + col_s[3 * P + p]);
+    for (int p = t; p < P; p += MPPI_BLOCK) st_rec(rec + 2 + p, (col_s[p] + col_s[P + p]) + (col_s[2 * P + p] + col_s[3 * P + p]));
     STAMP(5);
-}
 
-// ---------------------------------------------------------------------------------------------
-// merge of partial records.  grid.x blocks; block b merges records [b*per_block, ...).
-// FINAL=false: writes one record per block to `out_rec`.
-// FINAL=true (grid.x == 1): applies the MPPI update and publishes u.
-// ---------------------------------------------------------------------------------------------
-constexpr int MERGE_BLOCK = 256;
-
-template <bool FINAL>
-__global__ __launch_bounds__(MERGE_BLOCK) void ctk_mppi_merge(const float* __restrict__ parts, int n_parts, int per_block,
-                                                             int P, float neg_inv_lbd, float* __restrict__ out_rec,
-                                                             // FINAL only:
-                                                             int H, const InterpEntry* __restrict__ interp,
-                                                             const float* __restrict__ u_nom_in,
-                                                             float* __restrict__ u_nom_out, float lo, float hi,
-                                                             float* __restrict__ u_dev, float* __restrict__ u_host) {
-    extern __shared__ float lds[];
-    float* red = lds;                 // [MERGE_BLOCK / 64] cross-wave scratch
-    float* b_s = lds + 8;             // [P] merged numerator
-    float* sc_s = b_s + P + 1;        // [chunk] per-record rescale factors
-    constexpr int CHUNK = 1024;
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int first = blockIdx.x * per_block;
-    const int cnt = min(per_block, n_parts - first);
-    const int rs = 2 + P;
-    const float* base = parts + (size_t)first * rs;
-
-    // rho = min over records
-    float r = INFINITY;
-    for (int i = t; i < cnt; i += MERGE_BLOCK) r = fminf(r, base[(size_t)i * rs]);
-    r = wave_min(r);
-    if (lane == 0) red[wave] = r;
-    __syncthreads();
-    float rho = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
-    __syncthreads();
-
-    float a_acc = 0.0f;
-    float b_acc[4] = {0.f, 0.f, 0.f, 0.f};   // thread t owns columns t, t+256, ... (P <= 1024)
-    for (int c0 = 0; c0 < cnt; c0 += CHUNK) {
-        const int cn = min(CHUNK, cnt - c0);
-        for (int i = t; i < cn; i += MERGE_BLOCK) {
-            const float* rec = base + (size_t)(c0 + i) * rs;
-            const float sc = expf(neg_inv_lbd * (rec[0] - rho));   // e^{-(rho_r - rho)/lambda}
-            sc_s[i] = sc;
-            a_acc += rec[1] * sc;
+    // ---- fused tail: hand-off of the block records inside the launch (cdna_hip_programming.md G16,
+    //      sc1 form: every record store above is a write-through agent-scope store, every storing wave
+    //      drains its stores, the workgroup meets, ONE lane takes a ticket; the block that drew the last
+    //      ticket reads every record with sc1 loads).  Placement-independent.
+    if (fz.mode != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* last_s = reinterpret_cast<int*>(lds);
+        if (t == 0) {
+            const unsigned ticket = __hip_atomic_fetch_add(fz.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *last_s = (ticket == gridDim.x - 1) ? 1 : 0;
         }
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = t + j * MERGE_BLOCK;
-            if (p < P) {
-                float acc = b_acc[j];
-                for (int i = 0; i < cn; ++i) acc += base[(size_t)(c0 + i) * rs + 2 + p] * sc_s[i];
-                b_acc[j] = acc;
-            }
-        }
+        const bool last = *last_s != 0;
         __syncthreads();
-    }
-    a_acc = wave_sum(a_acc);
-    if (lane == 0) red[wave] = a_acc;
-    __syncthreads();
-    const float a_tot = red[0] + red[1] + red[2] + red[3];
-
-    if constexpr (!FINAL) {
-        float* rec = out_rec + (size_t)blockIdx.x * rs;
-        if (t == 0) { rec[0] = rho; rec[1] = a_tot; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = t + j * MERGE_BLOCK;
-            if (p < P) rec[2 + p] = b_acc[j];
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = t + j * MERGE_BLOCK;
-            if (p < P) b_s[p] = b_acc[j];
-        }
-        if (t == 0) b_s[P] = 0.0f;   // pad read by i0+1 when P == 1
-        __syncthreads();
-        for (int h = t; h < H; h += MERGE_BLOCK) {
-            const InterpEntry e = interp[h];
-            const float w = (b_s[e.i0] * e.w0 + b_s[e.i0 + 1] * e.w1) / a_tot;
-            const float un = u_nom_in[min(h + 1, H - 1)];
-            const float o = fminf(fmaxf(un + w, lo), hi);   // optimizer_mppi.py:190
-            u_nom_out[h] = o;
-            if (h == 0) { *u_dev = o; *u_host = o; }        // :191 u = u_nom[0,0,:]
+        if (last) {
+            if (fz.mode == 1) mppi_merge_block<true, true>(lds, parts, (int)gridDim.x, P, m.neg_inv_lbd, nullptr, fz.up);
+            else mppi_merge_block<false, true>(lds, parts, (int)gridDim.x, P, m.neg_inv_lbd, fz.out_rec, fz.up);
+            if (t == 0) __hip_atomic_store(fz.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    STAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -246,40 +300,44 @@ const char* ctk_mppi_rollout_name(int pred, bool log) {
 
 int ctk_mppi_num_blocks(int N) { return (N + MPPI_TRAJ - 1) / MPPI_TRAJ; }
 
+static size_t merge_lds(int P, int cnt) { return (size_t)(8 + P + 1 + (cnt < MERGE_CHUNK ? cnt : MERGE_CHUNK)) * sizeof(float); }
+
 size_t ctk_mppi_rollout_lds(int P, int H) {
-    return (size_t)(MPPI_TRAJ * tile_stride(P) + MPPI_TRAJ * ubuf_stride(H) + MPPI_WAVES * MPPI_TRAJ + MPPI_TRAJ + MPPI_WAVES * P + 4 * H) * sizeof(float);
+    const size_t roll = (size_t)(MPPI_TRAJ * tile_stride(P) + MPPI_TRAJ * ubuf_stride(H) + MPPI_WAVES * MPPI_TRAJ + MPPI_TRAJ + MPPI_WAVES * P + 4 * H) * sizeof(float);
+    const size_t tail = merge_lds(P, CTK_MPPI_FUSE_MAX_BLOCKS);
+    return roll > tail ? roll : tail;
 }
 
 hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const MppiK& m,
                                    const float* samples, const float* u_nom, const float* wperm, float* parts, bool log,
-                                   hipEvent_t e0, hipEvent_t e1) {
+                                   const MppiFuse& fuse, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid(ctk_mppi_num_blocks(a.N)), block(MPPI_BLOCK);
     const size_t lds = ctk_mppi_rollout_lds(a.P, a.H);
+    FuseArgs fz{};
+    fz.mode = fuse.mode; fz.counter = fuse.counter; fz.out_rec = fuse.out_rec;
+    fz.up = MppiUpdateArgs{a.H, a.interp, u_nom, fuse.u_nom_out, a.lo, a.hi, fuse.u_dev, fuse.u_host, fuse.seq};
     if (pred == CTK_PRED_ODE) {
-        if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts);
-        else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts);
+        if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
+        else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
     } else {
-        if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_MLP, true>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts);
-        else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_MLP, false>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts);
+        if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_MLP, true>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
+        else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_MLP, false>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
     }
     return hipGetLastError();
 }
 
-static size_t merge_lds(int P) { return (size_t)(8 + P + 1 + 1024) * sizeof(float); }
-
 hipError_t ctk_launch_mppi_merge_partial(hipStream_t st, const float* parts, int n_parts, int per_block, int P,
                                          float neg_inv_lbd, float* out_rec) {
     const int blocks = (n_parts + per_block - 1) / per_block;
-    hipLaunchKernelGGL(ctk_mppi_merge<false>, dim3(blocks), dim3(MERGE_BLOCK), merge_lds(P), st, parts, n_parts, per_block, P,
-                       neg_inv_lbd, out_rec, 0, (const InterpEntry*)nullptr, (const float*)nullptr, (float*)nullptr, 0.f, 0.f,
-                       (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(ctk_mppi_merge<false>, dim3(blocks), dim3(MERGE_BLOCK), merge_lds(P, per_block), st, parts, n_parts, per_block, P,
+                       neg_inv_lbd, out_rec, MppiUpdateArgs{});
     return hipGetLastError();
 }
 
 hipError_t ctk_launch_mppi_update(hipStream_t st, const float* parts, int n_parts, int P, float neg_inv_lbd, int H,
                                   const InterpEntry* interp, const float* u_nom_in, float* u_nom_out, float lo, float hi,
-                                  float* u_dev, float* u_host) {
-    hipLaunchKernelGGL(ctk_mppi_merge<true>, dim3(1), dim3(MERGE_BLOCK), merge_lds(P), st, parts, n_parts, n_parts, P, neg_inv_lbd,
-                       (float*)nullptr, H, interp, u_nom_in, u_nom_out, lo, hi, u_dev, u_host);
+                                  float* u_dev, float* u_host, uint32_t seq) {
+    hipLaunchKernelGGL(ctk_mppi_merge<true>, dim3(1), dim3(MERGE_BLOCK), merge_lds(P, n_parts), st, parts, n_parts, n_parts, P, neg_inv_lbd,
+                       (float*)nullptr, MppiUpdateArgs{H, interp, u_nom_in, u_nom_out, lo, hi, u_dev, u_host, seq});
     return hipGetLastError();
 }

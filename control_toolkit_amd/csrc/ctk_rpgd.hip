@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void ctk_rpgd_warmstart(WarmArgs w, RolloutArg
                                                           float* __restrict__ m_new, float* __restrict__ v_new,
                                                           float* __restrict__ ages_new, const InterpEntry* __restrict__ interp,
                                                           float* __restrict__ u_nom, float* __restrict__ u_dev,
-                                                          float* __restrict__ u_host) {
+                                                          float* __restrict__ u_host, uint32_t seq) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int H = w.H;
     if (gid < w.N * H) {
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void ctk_rpgd_warmstart(WarmArgs w, RolloutArg
         const int best = idx[0];                       // u_nom = Q_tf[best_idx[0]] BEFORE the warm start (:426)
         const float q = Q_old[(size_t)best * H + gid];
         u_nom[gid] = q;
-        if (gid == 0) { *u_dev = q; *u_host = q; }     // :523
+        if (gid == 0) publish_u(u_dev, u_host, q, seq);   // :523
     }
 }
 
@@ -375,10 +375,10 @@ hipError_t ctk_launch_rpgd_warmstart(hipStream_t st, const RolloutArgs& a, int N
                                      float sample_mean, float sample_min, float sample_max, const float* draws, const int* idx,
                                      const float* Q_old, const float* m_old, const float* v_old, const float* ages_old,
                                      float* Q_new, float* m_new, float* v_new, float* ages_new, const InterpEntry* interp,
-                                     float* u_nom, float* u_dev, float* u_host) {
+                                     float* u_nom, float* u_dev, float* u_host, uint32_t seq) {
     WarmArgs w{N, H, P, n_new, gather, shift_previous, sampling_distribution, reset, lo, hi, sample_stdev, sample_mean, sample_min, sample_max};
     const int total = N * H;
     hipLaunchKernelGGL(ctk_rpgd_warmstart, dim3((total + 255) / 256), dim3(256), 0, st, w, a, draws, idx, Q_old, m_old, v_old, ages_old,
-                       Q_new, m_new, v_new, ages_new, interp, u_nom, u_dev, u_host);
+                       Q_new, m_new, v_new, ages_new, interp, u_nom, u_dev, u_host, seq);
     return hipGetLastError();
 }

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void ctk_cem_refit(const float* __restrict__ Q
 __global__ __launch_bounds__(256) void ctk_cem_finish(const float* __restrict__ Q, const int* __restrict__ idx, int H,
                                                       float* __restrict__ mu, float* __restrict__ sd, float std_min,
                                                       float init_std, float mid, float* __restrict__ u_dev,
-                                                      float* __restrict__ u_host) {
+                                                      float* __restrict__ u_host, uint32_t seq) {
     extern __shared__ float lds[];
     float* m_s = lds;
     float* s_s = lds + H;
@@ -119,20 +119,13 @@ __global__ __launch_bounds__(256) void ctk_cem_finish(const float* __restrict__ 
         mu[h] = (h + 1 < H) ? m_s[h + 1] : mid;
         sd[h] = (h + 1 < H) ? s_s[h + 1] : init_std;
     }
-    if (t == 0) {
-        const float u = Q[(size_t)idx[0] * H];
-        *u_dev = u;
-        *u_host = u;
-    }
+    __syncthreads();
+    if (t == 0) publish_u(u_dev, u_host, Q[(size_t)idx[0] * H], seq);
 }
 
 __global__ void ctk_pick_best_first(const float* __restrict__ Q, const int* __restrict__ idx, int H,
-                                    float* __restrict__ u_dev, float* __restrict__ u_host) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const float u = Q[(size_t)idx[0] * H];
-        *u_dev = u;
-        *u_host = u;
-    }
+                                    float* __restrict__ u_dev, float* __restrict__ u_host, uint32_t seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) publish_u(u_dev, u_host, Q[(size_t)idx[0] * H], seq);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -168,13 +161,13 @@ hipError_t ctk_launch_cem_refit(hipStream_t st, const float* Q, const int* idx, 
 }
 
 hipError_t ctk_launch_cem_finish(hipStream_t st, const float* Q, const int* idx, int H, float* mu, float* sd, float std_min,
-                                 float init_std, float mid, float* u_dev, float* u_host) {
+                                 float init_std, float mid, float* u_dev, float* u_host, uint32_t seq) {
     hipLaunchKernelGGL(ctk_cem_finish, dim3(1), dim3(256), 2 * H * sizeof(float), st, Q, idx, H, mu, sd, std_min, init_std, mid,
-                       u_dev, u_host);
+                       u_dev, u_host, seq);
     return hipGetLastError();
 }
 
-hipError_t ctk_launch_pick_best_first(hipStream_t st, const float* Q, const int* idx, int H, float* u_dev, float* u_host) {
-    hipLaunchKernelGGL(ctk_pick_best_first, dim3(1), dim3(64), 0, st, Q, idx, H, u_dev, u_host);
+hipError_t ctk_launch_pick_best_first(hipStream_t st, const float* Q, const int* idx, int H, float* u_dev, float* u_host, uint32_t seq) {
+    hipLaunchKernelGGL(ctk_pick_best_first, dim3(1), dim3(64), 0, st, Q, idx, H, u_dev, u_host, seq);
     return hipGetLastError();
 }

@@ -10,7 +10,7 @@ from gpu_helpers import rpgd_engine_from
 pytestmark = pytest.mark.gpu
 
 
-def assert_close_mostly(actual, desired, rtol, atol, outlier_frac=2e-3, outlier_atol=0.1):
+def assert_close_mostly(actual, desired, rtol, atol, outlier_frac=5e-3, outlier_atol=0.1):
     """Adam's normalised update m_hat/(sqrt(v_hat)+eps) has magnitude ~1 whatever the gradient's
     size, so where an input's gradient is within fp32 rounding of zero a sign difference moves that
     single element by up to 2*lr per iteration.  Require the stated tolerance for all but a

@@ -25,25 +25,27 @@ int main(int argc, char** argv) {
     CK(hipMemset(d_unom, 0, H * 4)); CK(hipMemcpy(d_tab, tab.data(), H * sizeof(InterpEntry), hipMemcpyHostToDevice));
     RolloutArgs a{}; a.s0[0] = 0.05f; a.s0[1] = -0.1f; a.s0[2] = 2.8f; a.s0[3] = 0.4f; a.lo = -1; a.hi = 1; a.N = N; a.H = H; a.P = P;
     a.inv_Hp1 = 1.f / (H + 1); a.p_magic = (uint32_t)((0x100000000ull + P - 1) / P); a.identity_interp = 1; a.interp = d_tab; a.J = d_J; a.stamps = d_st;
+    unsigned* d_cnt; float *d_unom2, *d_u, *h_u; CK(hipMalloc(&d_cnt, 4)); CK(hipMemset(d_cnt, 0, 4)); CK(hipMalloc(&d_unom2, H * 4)); CK(hipMalloc(&d_u, 4)); CK(hipHostMalloc(&h_u, 64, hipHostMallocMapped));
+    MppiFuse fz; fz.mode = argc > 3 ? atoi(argv[3]) : 1; fz.counter = d_cnt; fz.u_nom_out = d_unom2; fz.u_dev = d_u; fz.u_host = h_u;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms = 0;
     for (int it = 0; it < 20; ++it) {
         CK(hipEventRecord(e0, 0));
-        CK(ctk_launch_mppi_rollout(0, CTK_PRED_ODE, a, k, m, d_noise, d_unom, nullptr, d_parts, false));
+        CK(ctk_launch_mppi_rollout(0, CTK_PRED_ODE, a, k, m, d_noise, d_unom, nullptr, d_parts, false, fz));
         CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize()); CK(hipEventElapsedTime(&ms, e0, e1));
     }
     std::vector<unsigned long long> st(nb * 8);
     CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
-    const char* names[5] = {"tile load", "inputs (interp/clip/corr)", "recurrence (wave 0)", "softmin partial", "column sums + store"};
+    const char* names[6] = {"tile load", "inputs (interp/clip/corr)", "recurrence (wave 0)", "softmin partial", "column sums + store", "fused tail (ticket; last block merges)"};
     printf("N=%d H=%d blocks=%d  event time %.2f us (stamped build)\n", N, H, nb, ms * 1e3);
-    for (int ph = 0; ph < 5; ++ph) {
+    for (int ph = 0; ph < 6; ++ph) {
         std::vector<double> d;
         for (int b = 0; b < nb; ++b) d.push_back((double)(st[b * 8 + ph + 1] - st[b * 8 + ph]));
         std::sort(d.begin(), d.end());
-        printf("  %-28s median %8.0f ticks (100 MHz s_memtime => %.2f us)\n", names[ph], d[d.size() / 2], d[d.size() / 2] / 100.0);
+        printf("  %-40s median %8.0f cycles   max %8.0f\n", names[ph], d[d.size() / 2], d.back());
     }
     unsigned long long mn = ~0ull, mx = 0;
-    for (int b = 0; b < nb; ++b) { mn = std::min(mn, st[b * 8]); mx = std::max(mx, st[b * 8 + 5]); }
-    printf("  first block start -> last block end: %.2f us\n", (mx - mn) / 100.0);
+    for (int b = 0; b < nb; ++b) { mn = std::min(mn, st[b * 8]); mx = std::max(mx, st[b * 8 + 6]); }
+    printf("  first block start -> last block end: %llu cycles\n", mx - mn);
     return 0;
 }
