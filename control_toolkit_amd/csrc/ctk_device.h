@@ -78,6 +78,33 @@ CTK_DEV void ctk_sincosf(float x, float* sn, float* cs) {
     *cs = __builtin_bit_cast(float, cbits ^ sgn_c);
 }
 
+// The same without the range check: the caller tracks max|x| over the horizon and re-runs the rare
+// out-of-range wave through the checked version (keeps a divergent branch out of the recurrence).
+constexpr float CTK_SINCOS_FAST_LIMIT = 32768.0f;
+CTK_DEV void ctk_sincosf_fast(float x, float* sn, float* cs) {
+    const float ax = fabsf(x);
+    const float fn = rintf(ax * 0.636619772f);
+    float r = fmaf(fn, -1.57079637e+00f, ax);
+    r = fmaf(fn, 4.37113883e-08f, r);
+    r = fmaf(fn, 1.71512489e-15f, r);
+    const int n = (int)fn;
+    const float r2 = r * r;
+    float ps = fmaf(r2, -1.95152959e-04f, 8.33216087e-03f);
+    ps = fmaf(r2, ps, -1.66666546e-01f);
+    const float s = fmaf(r, r2 * ps, r);
+    float pc = fmaf(r2, 2.44331571e-05f, -1.38873163e-03f);
+    pc = fmaf(r2, pc, 4.16666456e-02f);
+    pc = fmaf(r2, pc, -0.5f);
+    const float c = fmaf(r2, pc, 1.0f);
+    const bool odd = n & 1;
+    const unsigned sbits = __builtin_bit_cast(unsigned, odd ? c : s);
+    const unsigned cbits = __builtin_bit_cast(unsigned, odd ? s : c);
+    const unsigned sgn_s = ((unsigned)(n & 2) << 30) ^ (__builtin_bit_cast(unsigned, x) & 0x80000000u);
+    const unsigned sgn_c = ((unsigned)((n + 1) & 2) << 30);
+    *sn = __builtin_bit_cast(float, sbits ^ sgn_s);
+    *cs = __builtin_bit_cast(float, cbits ^ sgn_c);
+}
+
 struct State4 {
     float x, v, th, om;
 };
@@ -118,6 +145,18 @@ CTK_DEV float stage_cost(const EnvK& k, const State4& s, float cs, float u, floa
     float du = u - uprev;
     float ccrc = k.ccrc_weight * du * du;
     return dd + ep + ekp + cc + ccrc;
+}
+
+// The state-dependent part of the stage cost (dd + ep + ekp); the input-only part (cc + ccrc) can be
+// summed off the recurrence.
+CTK_DEV float stage_cost_state(const EnvK& k, const State4& s, float cs) {
+    const float dxn = (s.x - k.target_position) * k.inv_xs;
+    const float omc = 1.0f - cs;
+    return k.dd_weight * dxn * dxn + k.ep_c * omc * omc + k.ekp_weight * s.om * s.om;
+}
+CTK_DEV float stage_cost_input(const EnvK& k, float u, float uprev) {
+    const float du = u - uprev;
+    return k.ccR * u * u + k.ccrc_weight * du * du;
 }
 
 CTK_DEV float terminal_cost(const EnvK& k, const State4& s) {

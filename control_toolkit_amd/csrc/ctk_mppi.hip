@@ -53,6 +53,8 @@ CTK_DEV float ld_rec(const float* p) {
 CTK_DEV void st_rec(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct MppiUpdateArgs {
+    // per-step tables already resident in this block's LDS (fused tail) — nullptr: read them from memory
+    const float* w0_l = nullptr; const float* w1_l = nullptr; const float* un_l = nullptr; const int* i0_l = nullptr;
     int H;
     const InterpEntry* interp;
     const float* u_nom_in;
@@ -63,18 +65,38 @@ struct MppiUpdateArgs {
     uint32_t seq;
 };
 
-// scratch: >= 8 + (P + 1) + min(cnt, MERGE_CHUNK) floats of LDS
+// scratch: >= 8 + (P + 1) + min(cnt, MERGE_CHUNK) floats of LDS, plus cnt*(2+P) more when `stage`
+// (all records fetched into LDS by ONE wide pass: one memory round trip instead of one per record).
 template <bool FINAL, bool SC1>
 CTK_DEV void mppi_merge_block(float* scratch, const float* base, int cnt, int P, float neg_inv_lbd, float* out_rec,
-                              const MppiUpdateArgs& up) {
+                              const MppiUpdateArgs& up, bool stage) {
     float* red = scratch;             // [4] cross-wave scratch
     float* b_s = scratch + 8;         // [P + 1] merged numerator
     float* sc_s = b_s + P + 1;        // [chunk] per-record rescale factors
+    float* st_s = sc_s + (cnt < MERGE_CHUNK ? cnt : MERGE_CHUNK);   // [cnt][2+P] staged records
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int rs = 2 + P;
+    if (stage) {
+        const int tot = cnt * rs;
+        for (int i0 = 0; i0 < tot; i0 += 4 * MERGE_BLOCK) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j * MERGE_BLOCK + t;
+                if (i < tot) v[j] = ld_rec<SC1>(base + i);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j * MERGE_BLOCK + t;
+                if (i < tot) st_s[i] = v[j];
+            }
+        }
+        __syncthreads();
+    }
+    auto rec_at = [&](int i, int f) -> float { return stage ? st_s[i * rs + f] : ld_rec<SC1>(base + (size_t)i * rs + f); };
 
     float r = INFINITY;
-    for (int i = t; i < cnt; i += MERGE_BLOCK) r = fminf(r, ld_rec<SC1>(base + (size_t)i * rs));
+    for (int i = t; i < cnt; i += MERGE_BLOCK) r = fminf(r, rec_at(i, 0));
     r = wave_min(r);
     if (lane == 0) red[wave] = r;
     __syncthreads();
@@ -86,10 +108,9 @@ CTK_DEV void mppi_merge_block(float* scratch, const float* base, int cnt, int P,
     for (int c0 = 0; c0 < cnt; c0 += MERGE_CHUNK) {
         const int cn = min(MERGE_CHUNK, cnt - c0);
         for (int i = t; i < cn; i += MERGE_BLOCK) {
-            const float* rec = base + (size_t)(c0 + i) * rs;
-            const float sc = expf(neg_inv_lbd * (ld_rec<SC1>(rec) - rho));   // e^{-(rho_r - rho)/lambda}
+            const float sc = expf(neg_inv_lbd * (rec_at(c0 + i, 0) - rho));   // e^{-(rho_r - rho)/lambda}
             sc_s[i] = sc;
-            a_acc += ld_rec<SC1>(rec + 1) * sc;
+            a_acc += rec_at(c0 + i, 1) * sc;
         }
         __syncthreads();
 #pragma unroll
@@ -97,7 +118,7 @@ CTK_DEV void mppi_merge_block(float* scratch, const float* base, int cnt, int P,
             const int p = t + j * MERGE_BLOCK;
             if (p < P) {
                 float acc = b_acc[j];
-                for (int i = 0; i < cn; ++i) acc += ld_rec<SC1>(base + (size_t)(c0 + i) * rs + 2 + p) * sc_s[i];
+                for (int i = 0; i < cn; ++i) acc += rec_at(c0 + i, 2 + p) * sc_s[i];
                 b_acc[j] = acc;
             }
         }
@@ -124,9 +145,10 @@ CTK_DEV void mppi_merge_block(float* scratch, const float* base, int cnt, int P,
         if (t == 0) b_s[P] = 0.0f;   // pad read by i0+1 when P == 1
         __syncthreads();
         for (int h = t; h < up.H; h += MERGE_BLOCK) {
-            const InterpEntry e = up.interp[h];
+            InterpEntry e; float un;
+            if (up.w0_l) { e = InterpEntry{up.i0_l[h], up.w0_l[h], up.w1_l[h]}; un = up.un_l[h]; }
+            else { e = up.interp[h]; un = up.u_nom_in[min(h + 1, up.H - 1)]; }
             const float w = (b_s[e.i0] * e.w0 + b_s[e.i0 + 1] * e.w1) / a_tot;
-            const float un = up.u_nom_in[min(h + 1, up.H - 1)];
             const float o = fminf(fmaxf(un + w, up.lo), up.hi);   // optimizer_mppi.py:190
             up.u_nom_out[h] = o;
             if (h == 0) publish_u(up.u_dev, up.u_host, o, up.seq);   // :191 u = u_nom[0,0,:]
@@ -138,18 +160,19 @@ CTK_DEV void mppi_merge_block(float* scratch, const float* base, int cnt, int P,
 template <bool FINAL>
 __global__ __launch_bounds__(MERGE_BLOCK) void ctk_mppi_merge(const float* __restrict__ parts, int n_parts, int per_block,
                                                              int P, float neg_inv_lbd, float* __restrict__ out_rec,
-                                                             MppiUpdateArgs up) {
+                                                             MppiUpdateArgs up, int stage_ok) {
     extern __shared__ float lds[];
     const int first = blockIdx.x * per_block;
     const int cnt = min(per_block, n_parts - first);
     mppi_merge_block<FINAL, false>(lds, parts + (size_t)first * (2 + P), cnt, P, neg_inv_lbd,
-                                   out_rec ? out_rec + (size_t)blockIdx.x * (2 + P) : nullptr, up);
+                                   out_rec ? out_rec + (size_t)blockIdx.x * (2 + P) : nullptr, up, stage_ok != 0);
 }
 
 // In-launch tail of the rollout kernel (single-GPU, <= 256 blocks): the block whose ticket is last
 // merges all block records and applies the update, saving the second launch and its boundary.
 struct FuseArgs {
     int mode;             // 0: records only; 1: last block merges + updates u_nom/u; 2: last block emits ONE merged record
+    int stage_ok;         // the launch's LDS holds all records staged (merge_lds with staging)
     unsigned* counter;    // zero before the launch; the last block resets it
     float* out_rec;       // mode 2
     MppiUpdateArgs up;    // mode 1
@@ -181,39 +204,51 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
     STAMP(0);
     // ---- prologue 1 (256 threads): per-step tables (interpolation entry, shifted nominal input) and
     //      the sample tile (coalesced HBM read or Philox draw) into LDS ------------------------------
-    for (int h = t; h < H; h += MPPI_BLOCK) {
-        const InterpEntry e = interp[h];
-        i0_s[h] = e.i0; w0_s[h] = e.w0; w1_s[h] = e.w1;
-        un_s[h] = u_nom[min(h + 1, H - 1)];                                        // optimizer_mppi.py:184 (shift)
-    }
-    load_tile<MPPI_TRAJ, MPPI_BLOCK>(tile, samples, a, row0, m.stdev, /*normal*/ 0);
+    load_tile_early<MPPI_TRAJ, MPPI_BLOCK>(tile, samples, a, row0, m.stdev, /*normal*/ 0, [&] {
+        for (int h = t; h < H; h += MPPI_BLOCK) {           // issued while the sample loads are in flight
+            const InterpEntry e = interp[h];
+            i0_s[h] = e.i0; w0_s[h] = e.w0; w1_s[h] = e.w1;
+            un_s[h] = u_nom[min(h + 1, H - 1)];                                    // optimizer_mppi.py:184 (shift)
+        }
+    });
     __syncthreads();
     STAMP(1);
 
-    // ---- prologue 2 (256 threads): inputs of all H steps.  No dependence on the state, so this is
-    //      off the recurrence's critical path: interpolate, add the shifted nominal, clip, and
-    //      accumulate the MPPI control-cost correction.  Wave w takes steps h = w, w+4, ...
+    // ---- prologue 2 (256 threads): everything that depends on the inputs only, for all H steps, off
+    //      the recurrence's critical path: interpolate, add the shifted nominal, clip (-> u_run), the
+    //      MPPI control-cost correction and the input-only stage-cost terms (cc + ccrc).  Wave w takes
+    //      the contiguous steps [w*Hc, (w+1)*Hc) so that u[h-1] is at hand (recomputed once per chunk).
+    //      ubuf receives u (MLP) or the force u_max*u (ODE).
     {
         const float* my = tile + lane * ts;
-        float corr = 0.0f;
         const bool ident = a.identity_interp != 0;
-#pragma unroll 4
-        for (int h = wave; h < H; h += MPPI_WAVES) {
-            float du;
+        auto input_at = [&](int h, float& du) {
             if (ident) {
                 du = my[h];                                           // period 1: the matrix is the identity
             } else {
                 const int i0 = i0_s[h];                               // LDS broadcast reads
                 du = my[i0] * w0_s[h] + my[i0 + 1] * w1_s[h];         // Interpolator.py:97-106
             }
-            const float u = fminf(fmaxf(un_s[h] + du, a.lo), a.hi);   // optimizer_mppi.py:186-187
+            return fminf(fmaxf(un_s[h] + du, a.lo), a.hi);            // optimizer_mppi.py:186-187
+        };
+        const int Hc = (H + MPPI_WAVES - 1) / MPPI_WAVES;
+        const int h0 = wave * Hc, h1 = min(H, h0 + Hc);
+        float corr = 0.0f, cin = 0.0f, dummy;
+        float uprev = (h0 == 0 || h0 >= H) ? (a.u_prev_dev ? *a.u_prev_dev : a.u_prev) : input_at(h0 - 1, dummy);
+#pragma unroll 2
+        for (int h = h0; h < h1; ++h) {
+            float du;
+            const float u = input_at(h, du);
             corr += m.cc * (m.k_dd * (du * du) + m.R * u * du + m.k_uu * (u * u));   // :154-155
-            ubuf[lane * us + h] = u;
+            cin += stage_cost_input(k, u, uprev);
+            uprev = u;
+            ubuf[lane * us + h] = (PRED == CTK_PRED_ODE) ? k.u_max * u : u;
             if constexpr (LOG) {
                 if (valid) a.Q_out[(size_t)n * H + h] = u;
             }
         }
-        corr_s[wave * MPPI_TRAJ + lane] = corr;
+        // mean over H+1 applies to the stage costs, not to the MPPI correction (optimizer_mppi.py:158-161)
+        corr_s[wave * MPPI_TRAJ + lane] = (PRED == CTK_PRED_ODE) ? corr + cin * a.inv_Hp1 : corr;
     }
     __syncthreads();
     STAMP(2);
@@ -223,8 +258,14 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
     if constexpr (PRED == CTK_PRED_ODE) {
         // wave 0 only: one trajectory per lane, state in registers
         if (wave == 0) {
-            const float* myu = ubuf + lane * us;
-            J = rollout_ode<false, LOG>(a, k, n, valid, [&](int h) { return myu[h]; });
+            const float* myF = ubuf + lane * us;
+            float amax = 0.0f;
+            auto F_at = [&](int h) { return myF[h]; };
+            if (k.intermediate_steps == 1) J = recur_ode_state_cost<LOG, false, true>(a, k, n, valid, F_at, &amax);
+            else J = recur_ode_state_cost<LOG, true, false>(a, k, n, valid, F_at, &amax);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0))   // wave-uniform, ~never
+                J = recur_ode_state_cost<LOG, true, false>(a, k, n, valid, F_at, &amax);
+            J *= a.inv_Hp1;
         }
     } else {
         // all four waves: 16 trajectories each on the fp32 matrix cores (ctk_mlp.h)
@@ -282,8 +323,12 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
         const bool last = *last_s != 0;
         __syncthreads();
         if (last) {
-            if (fz.mode == 1) mppi_merge_block<true, true>(lds, parts, (int)gridDim.x, P, m.neg_inv_lbd, nullptr, fz.up);
-            else mppi_merge_block<false, true>(lds, parts, (int)gridDim.x, P, m.neg_inv_lbd, fz.out_rec, fz.up);
+            // the merge scratch grows from lds[0]; the per-step tables at the end of the carve stay intact
+            // whenever the scratch ends below them
+            const size_t scratch_floats = 8 + P + 1 + min((int)gridDim.x, MERGE_CHUNK) + (fz.stage_ok ? (size_t)gridDim.x * (2 + P) : 0);
+            if (scratch_floats <= (size_t)(w0_s - lds)) { fz.up.w0_l = w0_s; fz.up.w1_l = w1_s; fz.up.un_l = un_s; fz.up.i0_l = i0_s; }
+            if (fz.mode == 1) mppi_merge_block<true, true>(lds, parts, (int)gridDim.x, P, m.neg_inv_lbd, nullptr, fz.up, fz.stage_ok != 0);
+            else mppi_merge_block<false, true>(lds, parts, (int)gridDim.x, P, m.neg_inv_lbd, fz.out_rec, fz.up, fz.stage_ok != 0);
             if (t == 0) __hip_atomic_store(fz.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -301,6 +346,9 @@ const char* ctk_mppi_rollout_name(int pred, bool log) {
 int ctk_mppi_num_blocks(int N) { return (N + MPPI_TRAJ - 1) / MPPI_TRAJ; }
 
 static size_t merge_lds(int P, int cnt) { return (size_t)(8 + P + 1 + (cnt < MERGE_CHUNK ? cnt : MERGE_CHUNK)) * sizeof(float); }
+// with all records staged in LDS (used when it stays <= 64 KiB)
+static size_t merge_lds_staged(int P, int cnt) { return merge_lds(P, cnt) + (size_t)cnt * (2 + P) * sizeof(float); }
+static bool merge_can_stage(int P, int cnt) { return merge_lds_staged(P, cnt) <= 64 * 1024; }
 
 size_t ctk_mppi_rollout_lds(int P, int H) {
     const size_t roll = (size_t)(MPPI_TRAJ * tile_stride(P) + MPPI_TRAJ * ubuf_stride(H) + MPPI_WAVES * MPPI_TRAJ + MPPI_TRAJ + MPPI_WAVES * P + 4 * H) * sizeof(float);
@@ -308,14 +356,26 @@ size_t ctk_mppi_rollout_lds(int P, int H) {
     return roll > tail ? roll : tail;
 }
 
+// LDS of one launch: the rollout carve, or the fused tail's (staged) merge scratch if larger
+static size_t rollout_launch_lds(int P, int H, int blocks, int* stage_ok) {
+    size_t lds = ctk_mppi_rollout_lds(P, H);
+    *stage_ok = 0;
+    if (blocks <= CTK_MPPI_FUSE_MAX_BLOCKS && merge_can_stage(P, blocks)) {
+        const size_t st = merge_lds_staged(P, blocks);
+        if (st > lds) lds = st;
+        *stage_ok = 1;
+    }
+    return lds;
+}
+
 hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const MppiK& m,
                                    const float* samples, const float* u_nom, const float* wperm, float* parts, bool log,
                                    const MppiFuse& fuse, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid(ctk_mppi_num_blocks(a.N)), block(MPPI_BLOCK);
-    const size_t lds = ctk_mppi_rollout_lds(a.P, a.H);
     FuseArgs fz{};
+    const size_t lds = rollout_launch_lds(a.P, a.H, (int)grid.x, &fz.stage_ok);
     fz.mode = fuse.mode; fz.counter = fuse.counter; fz.out_rec = fuse.out_rec;
-    fz.up = MppiUpdateArgs{a.H, a.interp, u_nom, fuse.u_nom_out, a.lo, a.hi, fuse.u_dev, fuse.u_host, fuse.seq};
+    fz.up = MppiUpdateArgs{nullptr, nullptr, nullptr, nullptr, a.H, a.interp, u_nom, fuse.u_nom_out, a.lo, a.hi, fuse.u_dev, fuse.u_host, fuse.seq};
     if (pred == CTK_PRED_ODE) {
         if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
         else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
@@ -329,15 +389,18 @@ hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& 
 hipError_t ctk_launch_mppi_merge_partial(hipStream_t st, const float* parts, int n_parts, int per_block, int P,
                                          float neg_inv_lbd, float* out_rec) {
     const int blocks = (n_parts + per_block - 1) / per_block;
-    hipLaunchKernelGGL(ctk_mppi_merge<false>, dim3(blocks), dim3(MERGE_BLOCK), merge_lds(P, per_block), st, parts, n_parts, per_block, P,
-                       neg_inv_lbd, out_rec, MppiUpdateArgs{});
+    const bool stage = merge_can_stage(P, per_block);
+    hipLaunchKernelGGL(ctk_mppi_merge<false>, dim3(blocks), dim3(MERGE_BLOCK), stage ? merge_lds_staged(P, per_block) : merge_lds(P, per_block),
+                       st, parts, n_parts, per_block, P, neg_inv_lbd, out_rec, MppiUpdateArgs{}, stage ? 1 : 0);
     return hipGetLastError();
 }
 
 hipError_t ctk_launch_mppi_update(hipStream_t st, const float* parts, int n_parts, int P, float neg_inv_lbd, int H,
                                   const InterpEntry* interp, const float* u_nom_in, float* u_nom_out, float lo, float hi,
                                   float* u_dev, float* u_host, uint32_t seq) {
-    hipLaunchKernelGGL(ctk_mppi_merge<true>, dim3(1), dim3(MERGE_BLOCK), merge_lds(P, n_parts), st, parts, n_parts, n_parts, P, neg_inv_lbd,
-                       (float*)nullptr, MppiUpdateArgs{H, interp, u_nom_in, u_nom_out, lo, hi, u_dev, u_host, seq});
+    const bool stage = merge_can_stage(P, n_parts);
+    hipLaunchKernelGGL(ctk_mppi_merge<true>, dim3(1), dim3(MERGE_BLOCK), stage ? merge_lds_staged(P, n_parts) : merge_lds(P, n_parts), st,
+                       parts, n_parts, n_parts, P, neg_inv_lbd, (float*)nullptr,
+                       MppiUpdateArgs{nullptr, nullptr, nullptr, nullptr, H, interp, u_nom_in, u_nom_out, lo, hi, u_dev, u_host, seq}, stage ? 1 : 0);
     return hipGetLastError();
 }

@@ -9,9 +9,11 @@
 // Global reads are fully coalesced 16-B-per-lane loads (the block's rows are one contiguous span
 // of the [N,P,C] buffer), a batch of four per thread in flight before the first LDS store.
 // Rows beyond N and the pad columns P.. of every row read as zeros.  Ends WITHOUT a barrier.
-template <int ROWS, int THREADS>
-CTK_DEV void load_tile(float* tile, const float* __restrict__ samples, const RolloutArgs& a, int row0, float scale,
-                       int rng_kind) {
+// `early` runs after the first batch of sample loads has been ISSUED and before anything waits on
+// them: other global loads placed there share the same memory round trip.
+template <int ROWS, int THREADS, class Early>
+CTK_DEV void load_tile_early(float* tile, const float* __restrict__ samples, const RolloutArgs& a, int row0, float scale,
+                       int rng_kind, Early&& early) {
     const int P = a.P, ts = tile_stride(P);
     const int rows = min(ROWS, a.N - row0);
     const int t = threadIdx.x;
@@ -26,6 +28,7 @@ CTK_DEV void load_tile(float* tile, const float* __restrict__ samples, const Rol
         const float* src = samples + (size_t)row0 * P;
         const int total = rows * P;
         int done = 0;
+        bool early_done = false;
         if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
             const float4* src4 = reinterpret_cast<const float4*>(src);
             const int n4 = total >> 2;
@@ -36,6 +39,7 @@ CTK_DEV void load_tile(float* tile, const float* __restrict__ samples, const Rol
                     const int i4 = b0 + j * THREADS + t;
                     if (i4 < n4) v[j] = src4[i4];
                 }
+                if (b0 == 0) { early(); early_done = true; }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int i4 = b0 + j * THREADS + t;
@@ -53,11 +57,13 @@ CTK_DEV void load_tile(float* tile, const float* __restrict__ samples, const Rol
             }
             done = n4 << 2;
         }
+        if (!early_done) early();
         for (int i = done + t; i < total; i += THREADS) {
             const int r = P >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i;
             tile[r * ts + (i - r * P)] = src[i] * scale;
         }
     } else {
+        early();
         // on-device Philox, addressed by (global row, column block): shard- and launch-shape invariant
         constexpr int TPR = THREADS / ROWS;           // threads per row
         const int r = t % ROWS, cb0 = t / ROWS;
@@ -71,6 +77,11 @@ CTK_DEV void load_tile(float* tile, const float* __restrict__ samples, const Rol
                 if (cb * 4 + j < P && valid) tile[r * ts + cb * 4 + j] = d[j] * scale;
         }
     }
+}
+
+template <int ROWS, int THREADS>
+CTK_DEV void load_tile(float* tile, const float* __restrict__ samples, const RolloutArgs& a, int row0, float scale, int rng_kind) {
+    load_tile_early<ROWS, THREADS>(tile, samples, a, row0, scale, rng_kind, [] {});
 }
 
 // Rolls one trajectory; ufn(h) yields the (already clipped) input of step h.
@@ -105,4 +116,45 @@ CTK_DEV float rollout_ode(const RolloutArgs& a, const EnvK& k, int n, bool valid
         if (valid && traj) traj[H] = make_float4(s.x, s.v, s.th, s.om);
     }
     return (csum + terminal_cost(k, s)) * a.inv_Hp1;
+}
+
+// Recurrence of the MPPI kernel: the inputs arrive as forces F[h] = u_max * u[h] (prepared off the
+// critical path together with the input-only cost terms), the per-step work is {sincos, state cost,
+// Euler step}.  Returns sum_h (dd + ep + ekp) + terminal; *amax = max |angle| seen (range check of the
+// fast sincos, done once after the loop by the caller).
+template <bool WRITE_TRAJ, bool CHECKED, bool SINGLE, class FFn>
+CTK_DEV float recur_ode_state_cost(const RolloutArgs& a, const EnvK& k, int n, bool valid, FFn&& ffn, float* amax) {
+    State4 s{a.s0[0], a.s0[1], a.s0[2], a.s0[3]};
+    float csum = 0.0f, am = 0.0f;
+    const int H = a.H;
+    float4* traj = nullptr;
+    if constexpr (WRITE_TRAJ) {
+        if (a.traj_out) traj = reinterpret_cast<float4*>(a.traj_out) + (size_t)n * (H + 1);
+    }
+    float F_next = ffn(0);
+#pragma unroll 2
+    for (int h = 0; h < H; ++h) {
+        const float F = F_next;
+        if (h + 1 < H) F_next = ffn(h + 1);
+        float sn, cs;
+        if constexpr (CHECKED) ctk_sincosf(s.th, &sn, &cs);
+        else { ctk_sincosf_fast(s.th, &sn, &cs); am = fmaxf(am, fabsf(s.th)); }
+        csum += stage_cost_state(k, s, cs);
+        if constexpr (WRITE_TRAJ) {
+            if (valid && traj) traj[h] = make_float4(s.x, s.v, s.th, s.om);
+        }
+        ode_substep(k, s, F, sn, cs);
+        if constexpr (!SINGLE) {
+            for (int i = 1; i < k.intermediate_steps; ++i) {
+                float sn2, cs2;
+                ctk_sincosf(s.th, &sn2, &cs2);
+                ode_substep(k, s, F, sn2, cs2);
+            }
+        }
+    }
+    if constexpr (WRITE_TRAJ) {
+        if (valid && traj) traj[H] = make_float4(s.x, s.v, s.th, s.om);
+    }
+    *amax = am;
+    return csum + terminal_cost(k, s);
 }
