@@ -1,17 +1,18 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the hot path on MI355X.
 
-Metric (BASELINE.json): trajectory-steps/sec = N*H / wall(controller.step), MPPI, N=1024, H=50,
-4-state analytic cart-pole (configs[1]); one "step" = one full MPPI iteration (sample buffer
-resident in HBM -> fused rollout+cost kernel -> soft-min merge/update -> u back on the host),
-timed at the optimizer.step boundary, closed loop against a host plant step.
+Metric (BASELINE.json): trajectory-steps/sec = N*H / wall(controller.step).  Default workload =
+BASELINE configs[1]: MPPI, N=1024, H=50, 4-state analytic cart-pole; one "step" = one full MPPI
+iteration (sample buffer resident in HBM -> fused rollout+cost -> soft-min merge/update -> u back on
+the host), timed at the optimizer.step boundary, closed loop against a host plant step.
 
   python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: weak scaling — every rank rolls out its own 1024 trajectories (global population 1024*N),
-one all-gather of the 52-float soft-min record per step over RCCL (control_toolkit_amd/dist.py).
+N > 1: weak scaling — every rank rolls out its own shard (global population = N_local * ranks), one
+all-gather of the (2+P)-float soft-min record per step over RCCL (control_toolkit_amd/dist.py).
+Other BASELINE configs are parity-test cases; `--workload` times them too (not the headline line).
 """
 import argparse
 import json
@@ -25,17 +26,25 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA = fp32 vector rate (spec)
+
 WORKLOADS = {
-    # name: (optimizer, predictor, N, H, period)
-    "mppi_cfg2": ("mppi", "ODE", 1024, 50, 1),
-    "mppi_cfg2_interp": ("mppi", "ODE", 1024, 50, 10),
+    # name: dict(optimizer, predictor, N, H, period, engine kwargs, rollouts per step fwd/bwd)
+    "mppi_cfg2": dict(opt="mppi", pred="ODE", N=1024, H=50, p=1, kw={}),
+    "mppi_cfg2_interp": dict(opt="mppi", pred="ODE", N=1024, H=50, p=10, kw={}),
+    "cem_cfg3": dict(opt="cem", pred="ODE", N=4096, H=30, p=1,
+                     kw=dict(cem_outer_it=3, cem_best_k=409, cem_initial_action_stdev=0.5, cem_stdev_min=0.01)),
+    "rpgd_cfg4": dict(opt="rpgd", pred="MLP", N=256, H=50, p=10,
+                      kw=dict(outer_its=20, resamp_per=10, shift_previous=1, opt_keep_k=64, sampling_distribution=0,
+                              sample_min=-1.0, sample_max=1.0, learning_rate=0.05, gradmax_clip=5.0)),
+    "mppi_cfg5_shard": dict(opt="mppi", pred="MLP", N=8192, H=100, p=10, kw={}),
 }
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def plant_step(s, u, dt=0.02):
-    """Host plant (double precision cart-pole Euler step with the default parameters) that closes
-    the loop so the state changes every call.  Not the oracle; bench plumbing only."""
+    """Host plant (double-precision cart-pole Euler step, default parameters) that closes the loop so
+    the state changes every call.  Bench plumbing only; not the oracle."""
     g, mc, mp, L, umax, Mf, Jf = 9.81, 0.230, 0.087, 0.1975, 2.62, 4.77, 2.5e-4
     x, v, th, om = (float(a) for a in s)
     sn, cs = math.sin(th), math.cos(th)
@@ -48,29 +57,69 @@ def plant_step(s, u, dt=0.02):
     return np.array([x + dt * v, v + dt * xdd, th + dt * om, om + dt * thdd], np.float32)
 
 
-def algorithmic_bytes(N, H, P, C=1, S=4):
-    # noise read + J write + u_nom in/out + state
-    return 4 * N * P * C + 4 * N + 8 * H * C + 4 * S
+def mlp_weights(seed=0):
+    """5-32-32-4 tanh MLP, N(0, 1/fan_in) weights; same recipe as the oracle's."""
+    rng = np.random.default_rng(seed)
+    parts = [rng.normal(0, 1 / math.sqrt(5), (32, 5)), rng.normal(0, 0.1, (32,)), rng.normal(0, 1 / math.sqrt(32), (32, 32)),
+             rng.normal(0, 0.1, (32,)), rng.normal(0, 1 / math.sqrt(32), (4, 32)), rng.normal(0, 0.1, (4,))]
+    return np.concatenate([a.ravel() for a in parts]).astype(np.float32)
 
 
-def cpu_baseline(N, H, p, budget_s=12.0):
-    """The oracle (NumPy fp32 restatement of the reference's batched-tensor path) timed on the
-    host cores of this box, on a bounded sample of the same workload."""
+def algorithmic(w, P, samples_in_hbm):
+    """compulsory bytes (and MLP flops) of the DOMINANT kernel's launch."""
+    N, H, C, S = w["N"], w["H"], 1, 4
+    flops = None
+    if w["opt"] == "mppi":
+        b = (4 * N * P * C if samples_in_hbm else 0) + 4 * N + 8 * H * C + 4 * S
+        if w["pred"] == "MLP":
+            flops = 2624 * N * H
+    elif w["opt"] == "cem":      # one outer iteration = one rollout launch
+        K = w["kw"]["cem_best_k"]
+        b = (4 * N * H * C if samples_in_hbm else 0) + 4 * N + 4 * K * H * C + 8 * H * C
+    elif w["opt"] == "rpgd":     # one descent launch = outer_its Adam iterations + the final cost pass
+        its = w["kw"]["outer_its"]
+        b = its * (24 * N * H * C + 4 * N) + 4 * N * H * C + 4 * N
+        if w["pred"] == "MLP":
+            flops = 2624 * N * H * (2 * its + 1)
+    else:
+        b = 4 * N * H * C + 4 * N
+    return b, flops
+
+
+def cpu_baseline(w, budget_s=12.0):
+    """The oracle (NumPy fp32 restatement of the reference's batched-tensor path) timed on the host
+    cores of this box, on a bounded sample of the same workload."""
     from oracle import ctk_oracle as O
-    pred = O.Predictor("ODE")
-    o = O.MPPI(pred, O.Cost(pred.env), num_rollouts=N, mpc_horizon=H, period_interpolation_inducing_points=p)
+    N, H, p = w["N"], w["H"], w["p"]
+    pred = O.Predictor(w["pred"])
+    cost = O.Cost(pred.env)
     rng = np.random.default_rng(0)
     s = np.array([0.05, -0.1, 2.8, 0.4], np.float32)
-    noise = rng.standard_normal((N, o.P, 1)).astype(np.float32)
-    o.step(s, noise)   # warm-up
+    if w["opt"] == "mppi":
+        o = O.MPPI(pred, cost, num_rollouts=N, mpc_horizon=H, period_interpolation_inducing_points=p)
+        noise = rng.standard_normal((N, o.P, 1)).astype(np.float32)
+        step = lambda s: o.step(s, noise)
+    elif w["opt"] == "cem":
+        kw = w["kw"]
+        o = O.CEM(pred, cost, num_rollouts=N, mpc_horizon=H, cem_outer_it=kw["cem_outer_it"], cem_best_k=kw["cem_best_k"])
+        noise = rng.standard_normal((kw["cem_outer_it"], N, H, 1)).astype(np.float32)
+        step = lambda s: o.step(s, noise)
+    else:
+        kw = w["kw"]
+        o = O.RPGD(pred, cost, num_rollouts=N, mpc_horizon=H, outer_its=kw["outer_its"], resamp_per=kw["resamp_per"],
+                   period_interpolation_inducing_points=p, opt_keep_k_ratio=kw["opt_keep_k"] / N)
+        o.optimizer_reset(rng.random((N, o.P, 1), dtype=np.float32))
+        dr = rng.random((N - o.k, o.P, 1), dtype=np.float32)
+        step = lambda s: o.step(s, dr)
+    step(s)   # warm-up
     t0 = time.perf_counter(); n = 0
     while True:
-        u = o.step(s, noise); s = plant_step(s, u); n += 1
+        u = step(s); s = plant_step(s, u); n += 1
         el = time.perf_counter() - t0
         if el > budget_s or n >= 200:
             break
     return {"value": N * H * n / el, "unit": "trajectory-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} MPPI steps of N={N}, H={H} (oracle/ctk_oracle.py, NumPy fp32, single thread), {el:.1f} s"}
+            "sample": f"{n} {w['opt'].upper()} steps of N={N}, H={H} (oracle/ctk_oracle.py, NumPy fp32, single thread), {el:.1f} s"}
 
 
 def main():
@@ -80,8 +129,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="mppi_cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--samples", default="buffer", choices=["buffer", "device-rng"],
-                    help="buffer: [N,P,C] N(0,1) sample buffers resident in HBM (north_star); device-rng: in-kernel Philox")
+                    help="MPPI: [N,P,C] N(0,1) sample buffers resident in HBM (north_star) or the in-kernel Philox sampler")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="use the begin / all-gather / end path even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -92,33 +142,42 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    opt, predk, N, H, p = WORKLOADS[args.workload]
-    eng = CtkEngine(opt, predk, num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p,
-                    seed=1, device=local_rank, global_rollout_offset=rank * N)
+    w = WORKLOADS[args.workload]
+    if world > 1 and w["opt"] != "mppi":
+        raise SystemExit("only the MPPI workloads are sharded (DESIGN.md 6)")
+    N, H, p = w["N"], w["H"], w["p"]
+    eng = CtkEngine(w["opt"], w["pred"], num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p,
+                    seed=1, device=local_rank, global_rollout_offset=rank * N, **w["kw"])
+    if w["pred"] == "MLP":
+        eng.set_predictor_weights(mlp_weights(0))
     P = eng.mppi_partial_size() - 2
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    sharded = ShardedMPPI(eng, rank, world, device=dev) if world > 1 else None
+    if w["opt"] == "rpgd":
+        eng.reset()
+    sharded = ShardedMPPI(eng, rank, world, device=dev) if (world > 1 or args.force_sharded) else None
 
-    # synthetic inputs, resident in HBM before the timed region: a pool of sample buffers
+    # synthetic inputs, resident in HBM before the timed region: a pool of sample buffers (MPPI)
     pool = None
-    if args.samples == "buffer":
+    samples_in_hbm = w["opt"] == "mppi" and args.samples == "buffer"
+    if samples_in_hbm:
         g = torch.Generator(device=dev); g.manual_seed(1 + rank)
         pool = [torch.randn((N, P, 1), generator=g, device=dev, dtype=torch.float32) for _ in range(16)]
+        ptrs = [t.data_ptr() for t in pool]
     rng0 = np.random.default_rng(0)
     s = np.array([rng0.uniform(-0.2, 0.2), rng0.uniform(-0.5, 0.5), rng0.uniform(-np.pi, np.pi), rng0.uniform(-2, 2)], np.float32)
 
+    step_fn = sharded.step if sharded is not None else eng.step
+
     def one_step(i, s):
-        samples = pool[i % len(pool)].data_ptr() if pool is not None else None
-        u = sharded.step(s, samples) if sharded is not None else eng.step(s, samples)
+        u = step_fn(s, ptrs[i & 15] if pool is not None else None)
         return u, plant_step(s, u[0])
 
     for i in range(args.warmup):
@@ -127,12 +186,12 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    per_step = []
+    per_step = np.empty(args.steps)
     t0 = time.perf_counter()
+    ta = t0
     for i in range(args.steps):
-        ta = time.perf_counter()
         _, s = one_step(i, s)
-        per_step.append(time.perf_counter() - ta)
+        tb = time.perf_counter(); per_step[i] = tb - ta; ta = tb
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -148,25 +207,39 @@ def main():
     if rank == 0:
         total_units = N * H * world * args.steps
         kms = float(np.mean(kern_ms)) if len(kern_ms) else float("nan")
-        alg = algorithmic_bytes(N, H, P) if args.samples == "buffer" else 4 * N + 8 * H + 16
-        achieved = alg / (kms * 1e-3) / 1e9 if kms == kms and kms > 0 else None
-        ps = np.array(per_step) * 1e3
+        alg_bytes, alg_flops = algorithmic(w, P, samples_in_hbm)
+        ok = kms == kms and kms > 0
+        if alg_flops is not None:
+            ach = alg_flops / (kms * 1e-3) / 1e12 if ok else None
+            roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": ach / MFMA_F32_PEAK_TF if ach else None, "traffic": None, "algorithmic_flops": alg_flops,
+                    "note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32) for exact-fp32 parity; 16 trajectories per wave"}
+        else:
+            ach = alg_bytes / (kms * 1e-3) / 1e9 if ok else None
+            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS if ach else None,
+                    "traffic": 224768 if args.workload == "mppi_cfg2" and samples_in_hbm else None,
+                    "note": "issue/latency-bound at this size, not HBM-bound: 0.2 MB per launch vs an H-step dependent "
+                            "recurrence (~65 VALU instructions per step on one wave per 64 trajectories); traffic = "
+                            "FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/), DESIGN.md 5"}
+        roof.update({"kernel": eng.dominant_kernel(), "kernel_us": kms * 1e3, "algorithmic_bytes": alg_bytes,
+                     "kernel_launches_per_step": len(kern_ms) / max(1, args.steps)})
+        ps = per_step * 1e3
         out = {
             "metric": "trajectory-steps/sec (N*H per controller.step)", "value": total_units / elapsed,
             "unit": "trajectory-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"MPPI N={N} per GPU, H={H}, period={p}, 4-state analytic cart-pole, C=1 ({args.workload})",
-                       "samples": args.samples, "global_rollouts": N * world,
-                       "parallelism": f"rollout-shards x{world}, 1 all-gather of {P + 2} floats/step" if world > 1 else "single GPU"},
+            "config": {"workload": f"{w['opt'].upper()} N={N} per GPU, H={H}, period={p}, predictor {w['pred']} "
+                                   f"(4 states, 1 input) [{args.workload}]",
+                       "samples": args.samples if w["opt"] == "mppi" else "device-rng", "global_rollouts": N * world,
+                       "parallelism": (f"rollout shards x{world}, 1 all-gather of {P + 2} floats per step" if world > 1
+                                       else "single GPU")},
             "step_ms_median": float(np.median(ps)), "step_ms_p95": float(np.percentile(ps, 95)),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
-                         "kernel": eng.dominant_kernel(), "kernel_us": kms * 1e3, "algorithmic_bytes": alg,
-                         "note": "latency-bound at this size: 0.2 MB/step vs a ~H*~10^2-cycle dependent chain per trajectory (DESIGN.md)"},
+            "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(N, H, p)
+            out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))
     eng.close()
     if world > 1:

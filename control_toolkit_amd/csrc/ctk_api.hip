@@ -488,7 +488,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     {
         const size_t lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_lds((int)P, (int)H)
                          : cfg->optimizer == CTK_OPT_RPGD ? ctk_rpgd_descent_lds(cfg->predictor, (int)H, nullptr)
-                                                          : (size_t)(64 * tile_stride((int)P)) * sizeof(float);
+                                                          : ctk_affine_rollout_lds((int)H);
         if (lds > 160 * 1024) { h->err = "horizon too long for the LDS sample tiles (160 KiB per CU)"; return bail(CTK_ERR_UNSUPPORTED); }
     }
 

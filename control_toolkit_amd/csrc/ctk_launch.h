@@ -36,6 +36,7 @@ hipError_t ctk_launch_mppi_update(hipStream_t st, const float* parts, int n_part
 
 // ---- ctk_sampled.hip : u[n,h] = clip(base[h] + sample[n,h] * scale[h]) rollouts, selection ----
 const char* ctk_affine_rollout_name(int pred, bool log);
+size_t ctk_affine_rollout_lds(int H);
 // samples [N,H] (device) or nullptr (Philox, rng_kind 0 normal / 1 uniform); base/scale [H] device.
 hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const float* samples,
                                      int rng_kind, const float* base, const float* scale, const float* wperm, bool log,

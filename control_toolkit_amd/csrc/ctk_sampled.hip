@@ -10,37 +10,82 @@
 #include "ctk_mlp.h"
 #include "ctk_launch.h"
 
-constexpr int SAMP_BLOCK = 64;   // one wave per block: 64 trajectories (ODE) or 16 (MLP, MFMA columns)
+constexpr int SAMP_TRAJ = 64;                 // trajectories per block
+constexpr int SAMP_WAVES = 4;
+constexpr int SAMP_BLOCK = SAMP_TRAJ * SAMP_WAVES;
 
+// Same anatomy as ctk_mppi_rollout (ctk_mppi.hip): 4-wave prologues (coalesced sample tile -> LDS; inputs
+// of all H steps, input-only cost terms, coalesced write of the plans Q), then the recurrence on one
+// wave (ODE, one trajectory per lane) or on all four (MLP, 16 trajectories per wave on MFMA).
+// LDS carve (floats): tile[64][ts] | ubuf[64][us] | cin[4][64] | base[H] | scale[H]
 template <int PRED, bool TRAJ>
 __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(RolloutArgs a, EnvK k, const float* __restrict__ samples,
                                                                  int rng_kind, const float* __restrict__ base,
                                                                  const float* __restrict__ scale,
                                                                  const float* __restrict__ wperm) {
     extern __shared__ float lds[];
-    constexpr int ROWS = PRED == CTK_PRED_ODE ? SAMP_BLOCK : CTK_MLP_TRAJ_PER_WAVE;
-    const int stride = tile_stride(a.P);   // P == H here: one sample per step
+    const int H = a.H, ts = tile_stride(a.P), us = (H + 1) | 1;   // P == H here: one sample per step
     float* tile = lds;
-    const int lane = threadIdx.x;
-    const int row0 = blockIdx.x * ROWS;
-    load_tile<ROWS, SAMP_BLOCK>(tile, samples, a, row0, 1.0f, rng_kind);
+    float* ubuf = tile + SAMP_TRAJ * ts;
+    float* cin_s = ubuf + SAMP_TRAJ * us;
+    float* base_s = cin_s + SAMP_WAVES * SAMP_TRAJ;
+    float* scale_s = base_s + H;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int row0 = blockIdx.x * SAMP_TRAJ;
+    const int n = row0 + lane;
+    const bool valid = n < a.N;
+
+    load_tile_early<SAMP_TRAJ, SAMP_BLOCK>(tile, samples, a, row0, 1.0f, rng_kind, [&] {
+        for (int h = t; h < H; h += SAMP_BLOCK) { base_s[h] = base[h]; scale_s[h] = scale[h]; }
+    });
     __syncthreads();
+
+    {   // inputs of all H steps + input-only stage-cost terms; wave w takes a contiguous chunk of steps
+        const float* my = tile + lane * ts;
+        auto input_at = [&](int h) { return fminf(fmaxf(base_s[h] + my[h] * scale_s[h], a.lo), a.hi); };
+        const int Hc = (H + SAMP_WAVES - 1) / SAMP_WAVES;
+        const int h0 = wave * Hc, h1 = min(H, h0 + Hc);
+        float cin = 0.0f;
+        float uprev = (h0 == 0 || h0 >= H) ? (a.u_prev_dev ? *a.u_prev_dev : a.u_prev) : input_at(h0 - 1);
+#pragma unroll 2
+        for (int h = h0; h < h1; ++h) {
+            const float u = input_at(h);
+            cin += stage_cost_input(k, u, uprev);
+            uprev = u;
+            ubuf[lane * us + h] = u;
+        }
+        cin_s[wave * SAMP_TRAJ + lane] = cin;
+    }
+    __syncthreads();
+
+    {   // the plans, coalesced: Q[row0*H + i] for the block's contiguous span (elite refit / logging read it)
+        const int total = min(SAMP_TRAJ, a.N - row0) * H;
+        float* dst = a.Q_out + (size_t)row0 * H;
+        for (int i = t; i < total; i += SAMP_BLOCK) {
+            const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i;
+            dst[i] = ubuf[r * us + (i - r * H)];
+        }
+    }
+
     if constexpr (PRED == CTK_PRED_ODE) {
-        const int n = row0 + lane;
-        const bool valid = n < a.N;
-        const float* my = tile + lane * stride;
-        const float J = rollout_ode<true, TRAJ>(a, k, n, valid, [&](int h) {
-            return fminf(fmaxf(base[h] + my[h] * scale[h], a.lo), a.hi);
-        });
-        if (valid) a.J[n] = J;
+        if (wave == 0) {
+            const float* myu = ubuf + lane * us;
+            float amax = 0.0f;
+            auto F_at = [&](int h) { return k.u_max * myu[h]; };
+            float J;
+            if (k.intermediate_steps == 1) J = recur_ode_state_cost<TRAJ, false, true>(a, k, n, valid, F_at, &amax);
+            else J = recur_ode_state_cost<TRAJ, true, false>(a, k, n, valid, F_at, &amax);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0))
+                J = recur_ode_state_cost<TRAJ, true, false>(a, k, n, valid, F_at, &amax);
+            J += (cin_s[lane] + cin_s[SAMP_TRAJ + lane]) + (cin_s[2 * SAMP_TRAJ + lane] + cin_s[3 * SAMP_TRAJ + lane]);
+            if (valid) a.J[n] = J * a.inv_Hp1;
+        }
     } else {
         const MlpFwdW w = mlp_load_fwd(wperm);
-        const int c = lane & 15, n = row0 + c;
-        const float* my = tile + c * stride;
-        const float J = rollout_mlp<true, TRAJ>(a, k, w, row0, [&](int h) {
-            return fminf(fmaxf(base[h] + my[h] * scale[h], a.lo), a.hi);
-        });
-        if (lane < 16 && n < a.N) a.J[n] = J;
+        const int tr = wave * CTK_MLP_TRAJ_PER_WAVE + (lane & 15);
+        const float* myu = ubuf + tr * us;
+        const float J = rollout_mlp<false, TRAJ>(a, k, w, row0 + wave * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return myu[h]; });
+        if (lane < 16 && row0 + tr < a.N) a.J[row0 + tr] = J;
     }
 }
 
@@ -52,18 +97,40 @@ __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(RolloutArgs a, 
 // ---------------------------------------------------------------------------------------------
 constexpr int SEL_WAVES = 16;
 
+// order-preserving map float -> uint32 (total order; -0.0 < +0.0, NaNs sort last)
+CTK_DEV uint32_t f32_sortable(float f) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
 __global__ __launch_bounds__(64 * SEL_WAVES) void ctk_select_topk(const float* __restrict__ J, int N, int K,
                                                                   int* __restrict__ idx_out) {
     __shared__ int cnt_s[SEL_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
-    const float Ji = (i < N) ? J[i] : INFINITY;
+    // 64-bit key (sortable cost, index): unique, so ranks are a permutation
+    const unsigned long long key_i = ((unsigned long long)f32_sortable((i < N) ? J[i] : INFINITY) << 32) | (unsigned)i;
     const int L = (N + SEL_WAVES - 1) / SEL_WAVES;
     const int j0 = wave * L, j1 = min(N, j0 + L);
     int cnt = 0;
-    for (int j = j0; j < j1; ++j) {
-        const float Jj = J[j];   // wave-uniform address
-        cnt += (Jj < Ji) | ((Jj == Ji) & (j < i));
+    for (int jb = j0; jb < j1; jb += 64) {
+        // one coalesced vector load of 64 costs, then 64 wave-uniform broadcasts (v_readlane) instead of
+        // 64 dependent scalar loads
+        const int jj = jb + lane;
+        const uint32_t mine = f32_sortable(jj < j1 ? J[jj] : INFINITY);
+        const int nq = min(64, j1 - jb);
+        if (nq == 64) {
+#pragma unroll
+            for (int q = 0; q < 64; ++q) {
+                const unsigned long long key_j = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine, q) << 32) | (unsigned)(jb + q);
+                cnt += key_j < key_i;
+            }
+        } else {
+            for (int q = 0; q < nq; ++q) {
+                const unsigned long long key_j = ((unsigned long long)(uint32_t)__shfl((int)mine, q, 64) << 32) | (unsigned)(jb + q);
+                cnt += key_j < key_i;
+            }
+        }
     }
     cnt_s[wave][lane] = cnt;
     __syncthreads();
@@ -137,9 +204,8 @@ const char* ctk_affine_rollout_name(int pred, bool log) {
 hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const float* samples,
                                      int rng_kind, const float* base, const float* scale, const float* wperm, bool log,
                                      hipEvent_t e0, hipEvent_t e1) {
-    const int rows = pred == CTK_PRED_ODE ? SAMP_BLOCK : CTK_MLP_TRAJ_PER_WAVE;
-    const dim3 grid((a.N + rows - 1) / rows), block(SAMP_BLOCK);
-    const size_t lds = (size_t)rows * tile_stride(a.P) * sizeof(float);
+    const dim3 grid((a.N + SAMP_TRAJ - 1) / SAMP_TRAJ), block(SAMP_BLOCK);
+    const size_t lds = ctk_affine_rollout_lds(a.H);
     if (pred == CTK_PRED_ODE) {
         if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
         else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
@@ -148,6 +214,10 @@ hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs
         else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_MLP, false>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
     }
     return hipGetLastError();
+}
+
+size_t ctk_affine_rollout_lds(int H) {
+    return (size_t)(SAMP_TRAJ * tile_stride(H) + SAMP_TRAJ * ((H + 1) | 1) + SAMP_WAVES * SAMP_TRAJ + 2 * H) * sizeof(float);
 }
 
 hipError_t ctk_launch_select_topk(hipStream_t st, const float* J, int N, int K, int* idx_out, unsigned*) {
