@@ -61,6 +61,22 @@ CTK_DEV float ctk_tanhf(float x) {
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
 }
 
+// two at a time: the multiplies/adds/fma pack into v_pk_*_f32 (the exp/rcp stay per value)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+CTK_DEV f32x2 ctk_tanhf2(f32x2 x) {
+    const f32x2 y = x * 2.885390081777927f;
+    f32x2 t;
+    t.x = __builtin_amdgcn_exp2f(y.x); t.y = __builtin_amdgcn_exp2f(y.y);
+    const f32x2 d = t + 1.0f;
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+    return r * -2.0f + 1.0f;
+}
+CTK_DEV f32x4 ctk_tanhf4(f32x4 x) {
+    const f32x2 lo = ctk_tanhf2(f32x2{x[0], x[1]}), hi = ctk_tanhf2(f32x2{x[2], x[3]});
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+
 #define CTK_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 struct MlpAct {
@@ -77,8 +93,7 @@ CTK_DEV float mlp_step(const MlpFwdW& w, float sv, float u, int g, MlpAct* keep 
     a0 = CTK_MFMA(w.w1[0][1], x1, a0);
     a1 = CTK_MFMA(w.w1[1][1], x1, a1);
     f32x4 h1[2];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { h1[0][r] = ctk_tanhf(a0[r]); h1[1][r] = ctk_tanhf(a1[r]); }
+    h1[0] = ctk_tanhf4(a0); h1[1] = ctk_tanhf4(a1);
     f32x4 c0 = w.b2[0], c1 = w.b2[1];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -87,8 +102,7 @@ CTK_DEV float mlp_step(const MlpFwdW& w, float sv, float u, int g, MlpAct* keep 
         c1 = CTK_MFMA(w.w2[1][j], b, c1);
     }
     f32x4 h2[2];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { h2[0][r] = ctk_tanhf(c0[r]); h2[1][r] = ctk_tanhf(c1[r]); }
+    h2[0] = ctk_tanhf4(c0); h2[1] = ctk_tanhf4(c1);
     // layer 3: two interleaved accumulation chains (dependent MFMA latency 40 > issue 32 cycles)
     f32x4 o0 = w.b3, o1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -100,25 +114,55 @@ CTK_DEV float mlp_step(const MlpFwdW& w, float sv, float u, int g, MlpAct* keep 
     return o0[0] + o1[0];
 }
 
-// stage-cost share of lane group g (oracle Cost._get_stage_cost split by state component):
+// Stage-cost share of lane group g (oracle Cost._get_stage_cost split by state component):
 //   g = 0: dd(x)   g = 1: cc(u) + ccrc(u - u_prev)   g = 2: ep(angle)   g = 3: ekp(angleD)
-CTK_DEV float mlp_stage_cost_share(const EnvK& k, int g, float sv, float u, float uprev) {
-    const float dxn = (sv - k.target_position) * k.inv_xs;
-    const float omc = 1.0f - cosf(sv);
-    const float du = u - uprev;
-    const float t0 = k.dd_weight * dxn * dxn;
-    const float t1 = k.ccR * u * u + k.ccrc_weight * du * du;
-    const float t2 = k.ep_c * omc * omc;
-    const float t3 = k.ekp_weight * sv * sv;
-    return g == 0 ? t0 : (g == 1 ? t1 : (g == 2 ? t2 : t3));
+// as per-lane coefficients, so every lane runs the same few instructions:
+//   share = A*(sv - B)^2 + E*(1 - cos sv)^2 + I*(ccR u^2 + ccrc (u - u_prev)^2)
+struct MlpCostK {
+    float A, B, E, I;
+};
+CTK_DEV MlpCostK mlp_cost_coeffs(const EnvK& k, int g, bool with_input_cost) {
+    MlpCostK c;
+    c.A = g == 0 ? k.dd_weight * k.inv_xs * k.inv_xs : (g == 3 ? k.ekp_weight : 0.0f);
+    c.B = g == 0 ? k.target_position : 0.0f;
+    c.E = g == 2 ? k.ep_c : 0.0f;
+    c.I = (g == 1 && with_input_cost) ? 1.0f : 0.0f;
+    return c;
 }
 
-CTK_DEV float mlp_terminal_cost_share(const EnvK& k, int g, float sv) {
-    const float dxn = (sv - k.target_position) * k.inv_xs;
+// cos only, unchecked (see ctk_sincosf_fast): same reduction and polynomials
+CTK_DEV float ctk_cosf_fast(float x) {
+    const float ax = fabsf(x);
+    const float fn = rintf(ax * 0.636619772f);
+    float r = fmaf(fn, -1.57079637e+00f, ax);
+    r = fmaf(fn, 4.37113883e-08f, r);
+    r = fmaf(fn, 1.71512489e-15f, r);
+    const int n = (int)fn;
+    const float r2 = r * r;
+    float ps = fmaf(r2, -1.95152959e-04f, 8.33216087e-03f);
+    ps = fmaf(r2, ps, -1.66666546e-01f);
+    const float s = fmaf(r, r2 * ps, r);
+    float pc = fmaf(r2, 2.44331571e-05f, -1.38873163e-03f);
+    pc = fmaf(r2, pc, 4.16666456e-02f);
+    pc = fmaf(r2, pc, -0.5f);
+    const float c = fmaf(r2, pc, 1.0f);
+    const unsigned cbits = __builtin_bit_cast(unsigned, (n & 1) ? s : c);
+    return __builtin_bit_cast(float, cbits ^ ((unsigned)((n + 1) & 2) << 30));
+}
+
+template <bool CHECKED>
+CTK_DEV float mlp_stage_cost_share(const EnvK& k, const MlpCostK& c, float sv, float u, float uprev) {
+    const float d = sv - c.B;
+    const float omc = 1.0f - (CHECKED ? cosf(sv) : ctk_cosf_fast(sv));
+    const float du = u - uprev;
+    return c.A * d * d + c.E * omc * omc + c.I * (k.ccR * u * u + k.ccrc_weight * du * du);
+}
+
+CTK_DEV float mlp_terminal_cost_share(const EnvK& k, const MlpCostK& c, int g, float sv) {
+    const float d = sv - c.B;
     const float omc = 1.0f - cosf(sv);
-    const float t0 = k.dd_weight * dxn * dxn;
-    const float t2 = k.ep_c * omc * omc;
-    return k.terminal_weight * (g == 0 ? t0 : (g == 2 ? t2 : 0.0f));
+    // terminal = terminal_weight * (dd + ep): the dd share lives on g == 0 (A there is the dd coefficient)
+    return k.terminal_weight * ((g == 0 ? c.A * d * d : 0.0f) + c.E * omc * omc);
 }
 
 // sum over the 4 lane groups (lanes c, c+16, c+32, c+48): every lane ends with the trajectory total
@@ -129,21 +173,24 @@ CTK_DEV float sum_over_groups(float v) {
 }
 
 // Rolls the wave's 16 trajectories (first one = traj0).  ufn(h) yields the input of trajectory c.
-// Returns J of trajectory c in every lane.
-template <bool WRITE_Q, bool WRITE_TRAJ, class UFn>
-CTK_DEV float rollout_mlp(const RolloutArgs& a, const EnvK& k, const MlpFwdW& w, int traj0, UFn&& ufn) {
+// Returns J of trajectory c in every lane.  INPUT_COST: include cc + ccrc (callers that sum the
+// input-only terms off the recurrence pass false and add them themselves).
+template <bool WRITE_Q, bool WRITE_TRAJ, bool INPUT_COST, bool CHECKED, class UFn>
+CTK_DEV float rollout_mlp_impl(const RolloutArgs& a, const EnvK& k, const MlpFwdW& w, int traj0, UFn&& ufn, float* amax) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const int n = traj0 + c;
     const bool valid = n < a.N;
+    const MlpCostK ck = mlp_cost_coeffs(k, g, INPUT_COST);
     float sv = a.s0[g];
     float uprev = a.u_prev_dev ? *a.u_prev_dev : a.u_prev;
-    float csum = 0.0f;
+    float csum = 0.0f, am = 0.0f;
     const int H = a.H;
     float u_next = ufn(0);
     for (int h = 0; h < H; ++h) {
         const float u = u_next;
         if (h + 1 < H) u_next = ufn(h + 1);
-        csum += mlp_stage_cost_share(k, g, sv, u, uprev);
+        csum += mlp_stage_cost_share<CHECKED>(k, ck, sv, u, uprev);
+        if constexpr (!CHECKED) am = fmaxf(am, fabsf(sv));
         if constexpr (WRITE_TRAJ) {
             if (valid && a.traj_out) a.traj_out[((size_t)n * (H + 1) + h) * CTK_S + g] = sv;
         }
@@ -156,8 +203,19 @@ CTK_DEV float rollout_mlp(const RolloutArgs& a, const EnvK& k, const MlpFwdW& w,
     if constexpr (WRITE_TRAJ) {
         if (valid && a.traj_out) a.traj_out[((size_t)n * (H + 1) + H) * CTK_S + g] = sv;
     }
-    csum += mlp_terminal_cost_share(k, g, sv);
+    csum += mlp_terminal_cost_share(k, ck, g, sv);
+    *amax = am;
     return sum_over_groups(csum) * a.inv_Hp1;
+}
+
+template <bool WRITE_Q, bool WRITE_TRAJ, bool INPUT_COST = true, class UFn>
+CTK_DEV float rollout_mlp(const RolloutArgs& a, const EnvK& k, const MlpFwdW& w, int traj0, UFn&& ufn) {
+    float amax;
+    float J = rollout_mlp_impl<WRITE_Q, WRITE_TRAJ, INPUT_COST, false>(a, k, w, traj0, ufn, &amax);
+    // angle beyond the unchecked cos's range somewhere in the wave (never in practice): redo, checked
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0))
+        J = rollout_mlp_impl<WRITE_Q, WRITE_TRAJ, INPUT_COST, true>(a, k, w, traj0, ufn, &amax);
+    return J;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
             }
         }
         // mean over H+1 applies to the stage costs, not to the MPPI correction (optimizer_mppi.py:158-161)
-        corr_s[wave * MPPI_TRAJ + lane] = (PRED == CTK_PRED_ODE) ? corr + cin * a.inv_Hp1 : corr;
+        corr_s[wave * MPPI_TRAJ + lane] = corr + cin * a.inv_Hp1;
     }
     __syncthreads();
     STAMP(2);
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
         const MlpFwdW w = mlp_load_fwd(wperm);
         const int tr = wave * CTK_MLP_TRAJ_PER_WAVE + (lane & 15);
         const float* myu = ubuf + tr * us;
-        const float Jw = rollout_mlp<false, LOG>(a, k, w, row0 + wave * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return myu[h]; });
+        const float Jw = rollout_mlp<false, LOG, false>(a, k, w, row0 + wave * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return myu[h]; });
         if (lane < 16) e_s[tr] = Jw;          // hand the 64 costs to wave 0 (e_s doubles as J scratch)
         __syncthreads();
         if (wave == 0) J = e_s[lane];
