@@ -159,10 +159,13 @@ def main():
     if w["pred"] == "MLP":
         eng.set_predictor_weights(mlp_weights(0))
     P = eng.mppi_partial_size() - 2
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    sharded = None
+    if world > 1 or args.force_sharded:
+        # the collective runs on torch's stream: issue the engine's kernels there too
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        sharded = ShardedMPPI(eng, rank, world, device=dev)
     if w["opt"] == "rpgd":
         eng.reset()
-    sharded = ShardedMPPI(eng, rank, world, device=dev) if (world > 1 or args.force_sharded) else None
 
     # synthetic inputs, resident in HBM before the timed region: a pool of sample buffers (MPPI)
     pool = None

@@ -220,6 +220,26 @@ CTK_DEV void publish_u(float* u_dev, float* u_host, float u, uint32_t seq) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(u_host), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Kernel-argument prefetch.  Arguments are read with scalar loads at their points of use; the scalar
+// cache is cold at every launch and each first touch of a 64-B line of the kernarg segment is a
+// full memory round trip (~1-2 k cycles), paid serially wherever the compiler sank the load
+// (measured with s_memtime stamps: 2.4 k cycles before the first sample load could even issue).
+// Touch every line once, back to back, at kernel entry: the misses overlap each other and the
+// sample loads, later uses hit the scalar cache.  The sum is consumed at the very end of the
+// kernel by a never-true store so that nothing waits on these loads early.
+template <int BYTES>
+CTK_DEV uint32_t kernarg_prefetch() {
+    const __attribute__((address_space(4))) uint32_t* ka =
+        (const __attribute__((address_space(4))) uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < (BYTES + 63) / 64; ++i) acc += ka[i * 16];
+    return acc;
+}
+CTK_DEV void kernarg_prefetch_sink(uint32_t acc, float* some_global) {
+    if (__builtin_expect(acc == 0x9E3779B9u && blockIdx.x == 0x7FFFFFFFu, 0)) *some_global = 0.0f;
+}
+
 // row stride of the per-block sample tile in LDS: odd (conflict-free column walks with
 // ds_read_b32: bank = addr/4 mod 32) and >= P+1 so that column P is a readable zero pad.
 __host__ __device__ inline int tile_stride(int P) { return (P + 1) | 1; }

@@ -11,10 +11,6 @@
 //   ctk_mppi_merge         merges partial records {rho, a, b[P]} (blocks of one GPU, or the
 //        all-gathered records of several GPUs — SURVEY.md 8e) and either emits one record or
 //        applies the update u_nom <- clip(shift(u_nom) + interp(b)/a)   (:163-168,:184,:190).
-#include "ctk_rollout.h"
-#include "ctk_mlp.h"
-#include "ctk_launch.h"
-
 #ifdef CTK_STAMPS   // diagnostic build (tools/diag_mppi_stamps.hip); never compiled into libctk_hip.so
 #define STAMP(i)                                                                                   \
     do {                                                                                           \
@@ -22,11 +18,15 @@
         unsigned long long _t;                                                                     \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                 \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (threadIdx.x == 0 && a.stamps) a.stamps[blockIdx.x * 8 + (i)] = _t;                     \
+        if (threadIdx.x == 0 && a.stamps) a.stamps[blockIdx.x * 16 + (i)] = _t;                     \
     } while (0)
 #else
 #define STAMP(i)
 #endif
+
+#include "ctk_rollout.h"
+#include "ctk_mlp.h"
+#include "ctk_launch.h"
 
 constexpr int MPPI_TRAJ = 64;     // trajectories per block: one wave runs the recurrence
 constexpr int MPPI_WAVES = 4;     // waves per block: the prologue / epilogue are spread over all four
@@ -201,6 +201,7 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
     const int n = row0 + lane;
     const bool valid = n < a.N;
 
+    const uint32_t ka_sink = kernarg_prefetch<sizeof(RolloutArgs) + sizeof(EnvK) + sizeof(MppiK) + 5 * sizeof(void*) + sizeof(FuseArgs)>();
     STAMP(0);
     // ---- prologue 1 (256 threads): per-step tables (interpolation entry, shifted nominal input) and
     //      the sample tile (coalesced HBM read or Philox draw) into LDS ------------------------------
@@ -261,10 +262,16 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
             const float* myF = ubuf + lane * us;
             float amax = 0.0f;
             auto F_at = [&](int h) { return myF[h]; };
+#ifndef CTK_DIAG_NO_COLD
             if (k.intermediate_steps == 1) J = recur_ode_state_cost<LOG, false, true>(a, k, n, valid, F_at, &amax);
             else J = recur_ode_state_cost<LOG, true, false>(a, k, n, valid, F_at, &amax);
+#else
+            J = recur_ode_state_cost<LOG, false, true>(a, k, n, valid, F_at, &amax);
+#endif
+#ifndef CTK_DIAG_NO_COLD
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0))   // wave-uniform, ~never
                 J = recur_ode_state_cost<LOG, true, false>(a, k, n, valid, F_at, &amax);
+#endif
             J *= a.inv_Hp1;
         }
     } else {
@@ -333,6 +340,7 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
         }
     }
     STAMP(6);
+    kernarg_prefetch_sink(ka_sink, parts);
 }
 
 // ---------------------------------------------------------------------------------------------

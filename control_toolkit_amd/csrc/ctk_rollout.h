@@ -3,6 +3,9 @@
 // optimizer_mppi.py:188 predict_core + :159 get_trajectory_cost, fused).
 #pragma once
 #include "ctk_device.h"
+#ifndef STAMP
+#define STAMP(i)
+#endif
 
 // Loads (or draws) the per-block sample tile into LDS, cooperatively with THREADS threads:
 //   tile[r * stride + c] = scale * sample[(row0 + r) * P + c]   r < ROWS, c < P
@@ -39,7 +42,7 @@ CTK_DEV void load_tile_early(float* tile, const float* __restrict__ samples, con
                     const int i4 = b0 + j * THREADS + t;
                     if (i4 < n4) v[j] = src4[i4];
                 }
-                if (b0 == 0) { early(); early_done = true; }
+                if (b0 == 0) { STAMP(8); early(); early_done = true; STAMP(9); }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int i4 = b0 + j * THREADS + t;
@@ -56,6 +59,7 @@ CTK_DEV void load_tile_early(float* tile, const float* __restrict__ samples, con
                 }
             }
             done = n4 << 2;
+            STAMP(10);
         }
         if (!early_done) early();
         for (int i = done + t; i < total; i += THREADS) {
@@ -64,6 +68,7 @@ CTK_DEV void load_tile_early(float* tile, const float* __restrict__ samples, con
         }
     } else {
         early();
+#ifndef CTK_DIAG_NO_COLD   // diagnostic builds only: measure the kernel without its cold code
         // on-device Philox, addressed by (global row, column block): shard- and launch-shape invariant
         constexpr int TPR = THREADS / ROWS;           // threads per row
         const int r = t % ROWS, cb0 = t / ROWS;
@@ -76,6 +81,7 @@ CTK_DEV void load_tile_early(float* tile, const float* __restrict__ samples, con
             for (int j = 0; j < 4; ++j)
                 if (cb * 4 + j < P && valid) tile[r * ts + cb * 4 + j] = d[j] * scale;
         }
+#endif
     }
 }
 

@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
     float *d_noise, *d_unom, *d_J, *d_parts; InterpEntry* d_tab; unsigned long long* d_st;
     const int nb = ctk_mppi_num_blocks(N);
     CK(hipMalloc(&d_noise, noise.size() * 4)); CK(hipMalloc(&d_unom, H * 4)); CK(hipMalloc(&d_J, N * 4));
-    CK(hipMalloc(&d_parts, (size_t)nb * (2 + P) * 4)); CK(hipMalloc(&d_tab, H * sizeof(InterpEntry))); CK(hipMalloc(&d_st, nb * 8 * 8));
+    CK(hipMalloc(&d_parts, (size_t)nb * (2 + P) * 4)); CK(hipMalloc(&d_tab, H * sizeof(InterpEntry))); CK(hipMalloc(&d_st, nb * 16 * 8)); CK(hipMemset(d_st, 0, nb * 16 * 8));
     CK(hipMemcpy(d_noise, noise.data(), noise.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemset(d_unom, 0, H * 4)); CK(hipMemcpy(d_tab, tab.data(), H * sizeof(InterpEntry), hipMemcpyHostToDevice));
     RolloutArgs a{}; a.s0[0] = 0.05f; a.s0[1] = -0.1f; a.s0[2] = 2.8f; a.s0[3] = 0.4f; a.lo = -1; a.hi = 1; a.N = N; a.H = H; a.P = P;
@@ -34,18 +34,28 @@ int main(int argc, char** argv) {
         CK(ctk_launch_mppi_rollout(0, CTK_PRED_ODE, a, k, m, d_noise, d_unom, nullptr, d_parts, false, fz));
         CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize()); CK(hipEventElapsedTime(&ms, e0, e1));
     }
-    std::vector<unsigned long long> st(nb * 8);
+    std::vector<unsigned long long> st(nb * 16);
     CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
     const char* names[6] = {"tile load", "inputs (interp/clip/corr)", "recurrence (wave 0)", "softmin partial", "column sums + store", "fused tail (ticket; last block merges)"};
     printf("N=%d H=%d blocks=%d  event time %.2f us (stamped build)\n", N, H, nb, ms * 1e3);
     for (int ph = 0; ph < 6; ++ph) {
         std::vector<double> d;
-        for (int b = 0; b < nb; ++b) d.push_back((double)(st[b * 8 + ph + 1] - st[b * 8 + ph]));
+        for (int b = 0; b < nb; ++b) d.push_back((double)(st[b * 16 + ph + 1] - st[b * 16 + ph]));
         std::sort(d.begin(), d.end());
         printf("  %-40s median %8.0f cycles   max %8.0f\n", names[ph], d[d.size() / 2], d.back());
     }
+    {   // inside the tile load: 0 -> 8 (pads zeroed, sample loads issued) -> 9 (table loads issued + stored) -> 10 (samples in LDS) -> 1 (barrier)
+        const int seq[5] = {0, 8, 9, 10, 1};
+        const char* nm[4] = {"  issue sample loads", "  table loads + LDS stores (early)", "  wait samples + LDS stores", "  barrier"};
+        for (int i = 0; i < 4; ++i) {
+            std::vector<double> d;
+            for (int b = 0; b < nb; ++b) d.push_back((double)(st[b * 16 + seq[i + 1]] - st[b * 16 + seq[i]]));
+            std::sort(d.begin(), d.end());
+            printf("    %-38s median %8.0f cycles\n", nm[i], d[d.size() / 2]);
+        }
+    }
     unsigned long long mn = ~0ull, mx = 0;
-    for (int b = 0; b < nb; ++b) { mn = std::min(mn, st[b * 8]); mx = std::max(mx, st[b * 8 + 6]); }
+    for (int b = 0; b < nb; ++b) { mn = std::min(mn, st[b * 16]); mx = std::max(mx, st[b * 16 + 6]); }
     printf("  first block start -> last block end: %llu cycles\n", mx - mn);
     return 0;
 }
