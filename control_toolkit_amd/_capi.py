@@ -70,6 +70,11 @@ SYMBOLS = {
     "ctk_mppi_partial_size": (C.c_size_t, [_H]),
     "ctk_mppi_step_begin": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ctk_mppi_step_end": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p]),
+    "ctk_shard_candidates_size": (C.c_size_t, [_H]),
+    "ctk_shard_iterations": (C.c_int, [_H]),
+    "ctk_shard_iter_begin": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ctk_shard_iter_end": (C.c_int, [_H, C.c_void_p, C.c_int]),
+    "ctk_shard_finish": (C.c_int, [_H, C.c_void_p]),
     "ctk_read": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ctk_state_size": (C.c_size_t, [_H]),
     "ctk_get_state": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
@@ -271,6 +276,37 @@ class CtkEngine:
 
     def mppi_step_end(self, parts_dev_ptr: int, n_parts: int) -> np.ndarray:
         self._check(self._lib.ctk_mppi_step_end(self._h, C.c_void_p(parts_dev_ptr), int(n_parts), _ptr(self._u)))
+        return self._u.copy()
+
+    # ---- sharded CEM / random-action ---------------------------------------------------------------
+    def shard_candidates_size(self) -> int:
+        return int(self._lib.ctk_shard_candidates_size(self._h))
+
+    def shard_iterations(self) -> int:
+        return int(self._lib.ctk_shard_iterations(self._h))
+
+    def shard_iter_begin(self, s, cand_dev_ptr: int, samples=None, u_prev=None):
+        self._s[:] = np.asarray(s).reshape(-1)
+        up_p = None
+        if u_prev is not None:
+            self._up[0] = np.asarray(u_prev).reshape(-1)[0]
+            up_p = self._up_p
+        if samples is None:
+            sp, loc = None, LOC_NONE
+        elif type(samples) is int:
+            sp, loc = samples, LOC_DEVICE
+        else:
+            arr = _f32(samples)
+            if arr.size != self.N * self.H:
+                raise ValueError(f"one iteration consumes {self.N * self.H} draws, got {arr.size}")
+            sp, loc = arr.ctypes.data, LOC_HOST
+        self._check(self._lib.ctk_shard_iter_begin(self._h, self._s_p, up_p, sp, loc, cand_dev_ptr))
+
+    def shard_iter_end(self, cands_all_ptr: int, n_ranks: int):
+        self._check(self._lib.ctk_shard_iter_end(self._h, cands_all_ptr, int(n_ranks)))
+
+    def shard_finish(self) -> np.ndarray:
+        self._check(self._lib.ctk_shard_finish(self._h, self._u_p))
         return self._u.copy()
 
     def read(self, name: str) -> np.ndarray:

@@ -63,6 +63,10 @@ struct ctk_handle {
     int count = 0;              // CEM / RPGD step counter
     uint32_t call = 0;          // Philox call counter
     bool mppi_pending = false;  // between step_begin and step_end
+    bool shard_pending = false; // sharded CEM / random-action: between iter_begin and iter_end
+    int shard_it = 0;           // iteration index within the current sharded step
+    int* d_shard_idx = nullptr; size_t shard_idx_cap = 0;
+    const float* shard_last_cands = nullptr;
     bool have_weights = false;  // MLP weights uploaded
     // profiling
     bool prof = false;
@@ -335,12 +339,12 @@ int cem_step(ctk_handle* h, const float* s, const float* u_prev, const float* sa
         ProfSlot ps(h);
         HIP_TRY(h, ctk_launch_affine_rollout(h->stream, h->cfg.predictor, a, h->k, d_s ? d_s + per_it * it : nullptr, 0, mu,
                                              h->d_std, h->d_wperm, log, ps.a, ps.b));
-        HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, h->cfg.cem_best_k, h->d_idx, nullptr));
-        HIP_TRY(h, ctk_launch_cem_refit(h->stream, h->d_Q, h->d_idx, h->cfg.cem_best_k, h->H, mu, h->d_std));
+        HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, h->cfg.cem_best_k, h->d_idx));
+        HIP_TRY(h, ctk_launch_cem_refit(h->stream, h->d_Q, h->d_idx, h->cfg.cem_best_k, h->H, mu, h->d_std, h->H));
     }
     const float mid = (h->cfg.action_low + h->cfg.action_high) * 0.5f;
     HIP_TRY(h, ctk_launch_cem_finish(h->stream, h->d_Q, h->d_idx, h->H, mu, h->d_std, h->cfg.cem_stdev_min,
-                                     h->cfg.cem_initial_action_stdev, mid, h->d_u, h->h_u_dev, h->seq));
+                                     h->cfg.cem_initial_action_stdev, mid, h->d_u, h->h_u_dev, h->seq, h->H));
     ++h->count;
     return finish_step(h, u_out);
 }
@@ -354,8 +358,8 @@ int random_step(ctk_handle* h, const float* s, const float* u_prev, const float*
     ProfSlot ps(h);
     HIP_TRY(h, ctk_launch_affine_rollout(h->stream, h->cfg.predictor, a, h->k, d_s, 1, h->d_base, h->d_scale, h->d_wperm,
                                          h->cfg.materialize_trajectories != 0, ps.a, ps.b));
-    HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, 1, h->d_idx, nullptr));
-    HIP_TRY(h, ctk_launch_pick_best_first(h->stream, h->d_Q, h->d_idx, h->H, h->d_u, h->h_u_dev, h->seq));
+    HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, 1, h->d_idx));
+    HIP_TRY(h, ctk_launch_pick_best_first(h->stream, h->d_Q, h->d_idx, h->H, h->d_u, h->h_u_dev, h->seq, h->H));
     return finish_step(h, u_out);
 }
 
@@ -405,7 +409,7 @@ int rpgd_step(ctk_handle* h, const float* s, const float* u_prev, const float* s
                                            h->bc_len, h->adam_step, iters, h->d_wperm, h->d_scratch, ps.a, ps.b));
     }
     h->adam_step += iters;
-    HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, c.opt_keep_k, h->d_idx, nullptr));   // :345-346
+    HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, c.opt_keep_k, h->d_idx));   // :345-346
     RolloutArgs aw = make_args(h, s, u_prev, h->N, h->P);
     if (int rc = rpgd_warm(h, aw, resample ? h->N - c.opt_keep_k : 0, resample ? 1 : 0, 0, d_draws, cur, nxt)) return rc;
     h->rcur = nxt;
@@ -560,6 +564,7 @@ void ctk_destroy(ctk_handle* h) {
                     h->d_std, h->d_base, h->d_scale, h->d_idx, h->d_u, h->d_weights, h->d_wperm, h->d_counter,
                     h->d_pop[0], h->d_pop[1], h->d_m[0], h->d_m[1], h->d_v[0], h->d_v[1], h->d_ages[0], h->d_ages[1], h->d_bc, h->d_scratch};
     for (void* b : bufs) if (b) hipFree(b);
+    if (h->d_shard_idx) hipFree(h->d_shard_idx);
     if (h->h_u) hipHostFree(h->h_u);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -580,6 +585,7 @@ int ctk_reset(ctk_handle* h, const float* draws, int draws_loc) {
     const float mid = 0.5f * (h->cfg.action_low + h->cfg.action_high);
     h->count = 0;
     h->mppi_pending = false;
+    h->shard_pending = false; h->shard_it = 0; h->shard_last_cands = nullptr;
     switch (h->cfg.optimizer) {
         case CTK_OPT_MPPI:   // optimizer_mppi.py:227-231 (self.u is NOT reset there)
             h->cur = 0;
@@ -676,6 +682,80 @@ int ctk_mppi_step_end(ctk_handle* h, const float* parts_dev, int n_parts, float*
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     h->mppi_pending = false;
     return mppi_update(h, parts_dev, n_parts, u_out);
+}
+
+// ---- sharded CEM / random-action ----------------------------------------------------------------
+static int shard_k(const ctk_handle* h) { return h->cfg.optimizer == CTK_OPT_CEM ? h->cfg.cem_best_k : 1; }
+
+size_t ctk_shard_candidates_size(const ctk_handle* h) {
+    if (!h || (h->cfg.optimizer != CTK_OPT_CEM && h->cfg.optimizer != CTK_OPT_RANDOM_ACTION)) return 0;
+    return (size_t)shard_k(h) * (2 + h->H);
+}
+
+int ctk_shard_iterations(const ctk_handle* h) {
+    if (!h) return 0;
+    return h->cfg.optimizer == CTK_OPT_CEM ? cem_iterations(h) : (h->cfg.optimizer == CTK_OPT_RANDOM_ACTION ? 1 : 0);
+}
+
+int ctk_shard_iter_begin(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int samples_loc, float* cand_dev) {
+    if (!h || !s || !cand_dev) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_shard_iter_begin: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
+    const bool cem = h->cfg.optimizer == CTK_OPT_CEM;
+    if (!cem && h->cfg.optimizer != CTK_OPT_RANDOM_ACTION) return fail(h, CTK_ERR_STATE, "ctk_shard_iter_begin: CEM / random-action handles only");
+    if (h->shard_pending) return fail(h, CTK_ERR_STATE, "ctk_shard_iter_begin: previous iteration not ended");
+    if (int rc = check_predictor(h)) return rc;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const float* d_s = nullptr;
+    if (int rc = resolve_samples(h, samples, samples_loc, (size_t)h->N * h->H, &d_s)) return rc;   // ONE iteration's draws [N,H,C]
+    RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);
+    a.stream_id = (uint32_t)h->shard_it;
+    ProfSlot ps(h);
+    HIP_TRY(h, ctk_launch_affine_rollout(h->stream, h->cfg.predictor, a, h->k, d_s, cem ? 0 : 1, cem ? h->d_unom[0] : h->d_base,
+                                         cem ? h->d_std : h->d_scale, h->d_wperm, h->cfg.materialize_trajectories != 0, ps.a, ps.b));
+    const int K = shard_k(h);
+    HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, K, h->d_idx));
+    HIP_TRY(h, ctk_launch_pack_candidates(h->stream, h->d_J, h->d_Q, h->d_idx, K, h->H, h->cfg.global_rollout_offset, cand_dev));
+    h->shard_pending = true;
+    return CTK_OK;
+}
+
+int ctk_shard_iter_end(ctk_handle* h, const float* cands_all_dev, int n_ranks) {
+    if (!h || !cands_all_dev || n_ranks < 1) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_shard_iter_end: bad argument") : CTK_ERR_INVALID_ARGUMENT;
+    if (!h->shard_pending) return fail(h, CTK_ERR_STATE, "ctk_shard_iter_end: no iteration pending");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const int K = shard_k(h), rs = 2 + h->H, M = n_ranks * K;
+    if ((size_t)M > h->shard_idx_cap) {
+        if (h->d_shard_idx) HIP_TRY(h, hipFree(h->d_shard_idx));
+        h->d_shard_idx = nullptr; h->shard_idx_cap = 0;
+        HIP_TRY(h, hipMalloc((void**)&h->d_shard_idx, (size_t)M * sizeof(int)));
+        h->shard_idx_cap = (size_t)M;
+    }
+    // global best K of the union of the per-shard best-K lists: positions are ordered like global indices
+    // among equal costs (rank-major, each list sorted), so the positional tie-break is the global one
+    HIP_TRY(h, ctk_launch_select_topk(h->stream, cands_all_dev, M, K, h->d_shard_idx, rs));
+    if (h->cfg.optimizer == CTK_OPT_CEM)
+        HIP_TRY(h, ctk_launch_cem_refit(h->stream, cands_all_dev + 2, h->d_shard_idx, K, h->H, h->d_unom[0], h->d_std, rs));
+    h->shard_last_cands = cands_all_dev;
+    h->shard_pending = false;
+    ++h->shard_it;
+    return CTK_OK;
+}
+
+int ctk_shard_finish(ctk_handle* h, float* u_out) {
+    if (!h) return CTK_ERR_INVALID_ARGUMENT;
+    if (h->shard_pending || h->shard_it == 0 || !h->shard_last_cands) return fail(h, CTK_ERR_STATE, "ctk_shard_finish: no completed iteration");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const int rs = 2 + h->H;
+    if (h->cfg.optimizer == CTK_OPT_CEM) {
+        const float mid = (h->cfg.action_low + h->cfg.action_high) * 0.5f;
+        HIP_TRY(h, ctk_launch_cem_finish(h->stream, h->shard_last_cands + 2, h->d_shard_idx, h->H, h->d_unom[0], h->d_std,
+                                         h->cfg.cem_stdev_min, h->cfg.cem_initial_action_stdev, mid, h->d_u, h->h_u_dev, h->seq, rs));
+        ++h->count;
+    } else {
+        HIP_TRY(h, ctk_launch_pick_best_first(h->stream, h->shard_last_cands + 2, h->d_shard_idx, h->H, h->d_u, h->h_u_dev, h->seq, rs));
+    }
+    h->shard_it = 0;
+    h->shard_last_cands = nullptr;
+    return finish_step(h, u_out);
 }
 
 int ctk_rollout(ctk_handle* h, const float* s, const float* u_prev, const float* Q, int n, float* traj_out, float* J_out) {

@@ -43,13 +43,17 @@ hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs
                                      hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // Smallest-K selection under the total order (J, index) and CEM refit
 // (optimizer_cem_tf.py:73-78): idx_out[K] ascending, mu/std [H] from Q[idx].
-hipError_t ctk_launch_select_topk(hipStream_t st, const float* J, int N, int K, int* idx_out, unsigned* scratch);
-hipError_t ctk_launch_cem_refit(hipStream_t st, const float* Q, const int* idx, int K, int H, float* mu, float* sd);
+hipError_t ctk_launch_select_topk(hipStream_t st, const float* J, int N, int K, int* idx_out, int ldj = 1);
+hipError_t ctk_launch_cem_refit(hipStream_t st, const float* Q, const int* idx, int K, int H, float* mu, float* sd, int ldq);
+// this shard's best-K records {J, global index, Q[H]} for the sharded selection
+hipError_t ctk_launch_pack_candidates(hipStream_t st, const float* J, const float* Q, const int* idx, int K, int H, int global_offset,
+                                      float* cand);
 // CEM post-loop (optimizer_cem_tf.py:99-102) and u = elite[0,0]
 hipError_t ctk_launch_cem_finish(hipStream_t st, const float* Q, const int* idx, int H, float* mu, float* sd,
-                                 float std_min, float init_std, float mid, float* u_dev, float* u_host, uint32_t seq);
+                                 float std_min, float init_std, float mid, float* u_dev, float* u_host, uint32_t seq, int ldq);
 // random-action: u = Q[argmin J, 0]  (optimizer_random_action_tf.py:65-68)
-hipError_t ctk_launch_pick_best_first(hipStream_t st, const float* Q, const int* idx, int H, float* u_dev, float* u_host, uint32_t seq);
+hipError_t ctk_launch_pick_best_first(hipStream_t st, const float* Q, const int* idx, int H, float* u_dev, float* u_host, uint32_t seq,
+                                      int ldq);
 
 // ---- ctk_rpgd.hip ---------------------------------------------------------------------------
 const char* ctk_rpgd_descent_name(int pred);

@@ -104,13 +104,14 @@ CTK_DEV uint32_t f32_sortable(float f) {
     return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
 
-__global__ __launch_bounds__(64 * SEL_WAVES) void ctk_select_topk(const float* __restrict__ J, int N, int K,
+// J_i = J[i * ldj] (ldj = 1 for a plain cost vector; candidate records of the sharded path are strided)
+__global__ __launch_bounds__(64 * SEL_WAVES) void ctk_select_topk(const float* __restrict__ J, int ldj, int N, int K,
                                                                   int* __restrict__ idx_out) {
     __shared__ int cnt_s[SEL_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     // 64-bit key (sortable cost, index): unique, so ranks are a permutation
-    const unsigned long long key_i = ((unsigned long long)f32_sortable((i < N) ? J[i] : INFINITY) << 32) | (unsigned)i;
+    const unsigned long long key_i = ((unsigned long long)f32_sortable((i < N) ? J[(size_t)i * ldj] : INFINITY) << 32) | (unsigned)i;
     const int L = (N + SEL_WAVES - 1) / SEL_WAVES;
     const int j0 = wave * L, j1 = min(N, j0 + L);
     int cnt = 0;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void ctk_select_topk(const float* _
         // one coalesced vector load of 64 costs, then 64 wave-uniform broadcasts (v_readlane) instead of
         // 64 dependent scalar loads
         const int jj = jb + lane;
-        const uint32_t mine = f32_sortable(jj < j1 ? J[jj] : INFINITY);
+        const uint32_t mine = f32_sortable(jj < j1 ? J[(size_t)jj * ldj] : INFINITY);
         const int nq = min(64, j1 - jb);
         if (nq == 64) {
 #pragma unroll
@@ -144,12 +145,13 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void ctk_select_topk(const float* _
 }
 
 // elite refit: one block per horizon step h; mu = mean_k Q[idx[k],h]; sd = population std.
-__global__ __launch_bounds__(256) void ctk_cem_refit(const float* __restrict__ Q, const int* __restrict__ idx, int K, int H,
+// Q row r = Q[r * ldq .. + H) (ldq = H for the plan matrix; 2+H with Q pointing at column 2 of candidate records)
+__global__ __launch_bounds__(256) void ctk_cem_refit(const float* __restrict__ Q, int ldq, const int* __restrict__ idx, int K, int H,
                                                      float* __restrict__ mu, float* __restrict__ sd) {
     __shared__ float red[4];
     const int h = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63;
     float s = 0.0f;
-    for (int kk = t; kk < K; kk += 256) s += Q[(size_t)idx[kk] * H + h];
+    for (int kk = t; kk < K; kk += 256) s += Q[(size_t)idx[kk] * ldq + h];
     s = wave_sum(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void ctk_cem_refit(const float* __restrict__ Q
     __syncthreads();
     float v = 0.0f;
     for (int kk = t; kk < K; kk += 256) {
-        const float d = Q[(size_t)idx[kk] * H + h] - mean;
+        const float d = Q[(size_t)idx[kk] * ldq + h] - mean;
         v += d * d;
     }
     v = wave_sum(v);
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void ctk_cem_refit(const float* __restrict__ Q
 }
 
 // optimizer_cem_tf.py:99-102: clip std, shift both by one step, refill the tail; u = elite[0,0]
-__global__ __launch_bounds__(256) void ctk_cem_finish(const float* __restrict__ Q, const int* __restrict__ idx, int H,
+__global__ __launch_bounds__(256) void ctk_cem_finish(const float* __restrict__ Q, int ldq, const int* __restrict__ idx, int H,
                                                       float* __restrict__ mu, float* __restrict__ sd, float std_min,
                                                       float init_std, float mid, float* __restrict__ u_dev,
                                                       float* __restrict__ u_host, uint32_t seq) {
@@ -188,12 +190,28 @@ __global__ __launch_bounds__(256) void ctk_cem_finish(const float* __restrict__ 
         sd[h] = (h + 1 < H) ? s_s[h + 1] : init_std;
     }
     __syncthreads();
-    if (t == 0) publish_u(u_dev, u_host, Q[(size_t)idx[0] * H], seq);
+    if (t == 0) publish_u(u_dev, u_host, Q[(size_t)idx[0] * ldq], seq);
 }
 
-__global__ void ctk_pick_best_first(const float* __restrict__ Q, const int* __restrict__ idx, int H,
+__global__ void ctk_pick_best_first(const float* __restrict__ Q, int ldq, const int* __restrict__ idx, int H,
                                     float* __restrict__ u_dev, float* __restrict__ u_host, uint32_t seq) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) publish_u(u_dev, u_host, Q[(size_t)idx[0] * H], seq);
+    if (threadIdx.x == 0 && blockIdx.x == 0) publish_u(u_dev, u_host, Q[(size_t)idx[0] * ldq], seq);
+}
+
+// sharded selection: this shard's best K plans as records {J, global index (int bits), Q[H]},
+// sorted ascending by (J, index) — what is all-gathered; the global top-K is the top-K of their union.
+__global__ __launch_bounds__(256) void ctk_pack_candidates(const float* __restrict__ J, const float* __restrict__ Q,
+                                                           const int* __restrict__ idx, int K, int H, int global_offset,
+                                                           float* __restrict__ cand) {
+    const int rs = 2 + H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K * rs; i += gridDim.x * blockDim.x) {
+        const int kk = i / rs, f = i - kk * rs, src = idx[kk];
+        float v;
+        if (f == 0) v = J[src];
+        else if (f == 1) v = __builtin_bit_cast(float, global_offset + src);
+        else v = Q[(size_t)src * H + (f - 2)];
+        cand[i] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -221,24 +239,33 @@ size_t ctk_affine_rollout_lds(int H) {
     return (size_t)(SAMP_TRAJ * tile_stride(H) + SAMP_TRAJ * ((H + 1) | 1) + SAMP_WAVES * SAMP_TRAJ + 2 * H) * sizeof(float);
 }
 
-hipError_t ctk_launch_select_topk(hipStream_t st, const float* J, int N, int K, int* idx_out, unsigned*) {
-    hipLaunchKernelGGL(ctk_select_topk, dim3((N + 63) / 64), dim3(64 * SEL_WAVES), 0, st, J, N, K, idx_out);
+hipError_t ctk_launch_select_topk(hipStream_t st, const float* J, int N, int K, int* idx_out, int ldj) {
+    hipLaunchKernelGGL(ctk_select_topk, dim3((N + 63) / 64), dim3(64 * SEL_WAVES), 0, st, J, ldj, N, K, idx_out);
     return hipGetLastError();
 }
 
-hipError_t ctk_launch_cem_refit(hipStream_t st, const float* Q, const int* idx, int K, int H, float* mu, float* sd) {
-    hipLaunchKernelGGL(ctk_cem_refit, dim3(H), dim3(256), 0, st, Q, idx, K, H, mu, sd);
+hipError_t ctk_launch_cem_refit(hipStream_t st, const float* Q, const int* idx, int K, int H, float* mu, float* sd, int ldq) {
+    hipLaunchKernelGGL(ctk_cem_refit, dim3(H), dim3(256), 0, st, Q, ldq, idx, K, H, mu, sd);
+    return hipGetLastError();
+}
+
+hipError_t ctk_launch_pack_candidates(hipStream_t st, const float* J, const float* Q, const int* idx, int K, int H, int global_offset,
+                                      float* cand) {
+    const int total = K * (2 + H);
+    hipLaunchKernelGGL(ctk_pack_candidates, dim3((total + 255) / 256 > 64 ? 64 : (total + 255) / 256), dim3(256), 0, st, J, Q, idx, K, H,
+                       global_offset, cand);
     return hipGetLastError();
 }
 
 hipError_t ctk_launch_cem_finish(hipStream_t st, const float* Q, const int* idx, int H, float* mu, float* sd, float std_min,
-                                 float init_std, float mid, float* u_dev, float* u_host, uint32_t seq) {
-    hipLaunchKernelGGL(ctk_cem_finish, dim3(1), dim3(256), 2 * H * sizeof(float), st, Q, idx, H, mu, sd, std_min, init_std, mid,
+                                 float init_std, float mid, float* u_dev, float* u_host, uint32_t seq, int ldq) {
+    hipLaunchKernelGGL(ctk_cem_finish, dim3(1), dim3(256), 2 * H * sizeof(float), st, Q, ldq, idx, H, mu, sd, std_min, init_std, mid,
                        u_dev, u_host, seq);
     return hipGetLastError();
 }
 
-hipError_t ctk_launch_pick_best_first(hipStream_t st, const float* Q, const int* idx, int H, float* u_dev, float* u_host, uint32_t seq) {
-    hipLaunchKernelGGL(ctk_pick_best_first, dim3(1), dim3(64), 0, st, Q, idx, H, u_dev, u_host, seq);
+hipError_t ctk_launch_pick_best_first(hipStream_t st, const float* Q, const int* idx, int H, float* u_dev, float* u_host, uint32_t seq,
+                                      int ldq) {
+    hipLaunchKernelGGL(ctk_pick_best_first, dim3(1), dim3(64), 0, st, Q, ldq, idx, H, u_dev, u_host, seq);
     return hipGetLastError();
 }

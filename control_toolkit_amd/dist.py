@@ -32,3 +32,34 @@ class ShardedMPPI:
         else:
             parts = self.mine
         return self.engine.mppi_step_end(parts.data_ptr(), self.world_size)
+
+
+class ShardedTopK:
+    """Sharded CEM / random-action: per outer iteration every rank rolls out its shard
+    and contributes its best K plans as records {J, global index, Q[H]}; ONE all-gather of those records
+    per iteration; every rank then selects the global best K from the union and (CEM) refits the same
+    mean / stdev — no second collective.  cfg3: K*(2+H) = 409*32 floats = 51 KiB per rank."""
+
+    def __init__(self, engine, rank: int, world_size: int, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.engine, self.rank, self.world_size, self.group = engine, rank, world_size, group
+        self.rec = int(engine.shard_candidates_size())
+        self.device = device if device is not None else torch.device("cpu")
+        self.mine = torch.zeros(self.rec, dtype=torch.float32, device=self.device)
+        self.all = torch.zeros(self.rec * world_size, dtype=torch.float32, device=self.device)
+
+    def step(self, s, samples=None, u_prev=None) -> np.ndarray:
+        """samples: None (device Philox by global rollout index) or this rank's draws [iterations, N_local, H, 1]."""
+        its = self.engine.shard_iterations()
+        for it in range(its):
+            smp = None if samples is None else samples[it]
+            self.engine.shard_iter_begin(s, self.mine.data_ptr(), smp, u_prev=u_prev)
+            if self.world_size > 1:
+                self.dist.all_gather_into_tensor(self.all, self.mine, group=self.group)
+                parts = self.all
+            else:
+                parts = self.mine
+            self.engine.shard_iter_end(parts.data_ptr(), self.world_size)
+        return self.engine.shard_finish()

@@ -186,6 +186,25 @@ int ctk_mppi_step_begin(ctk_handle* h, const float* s, const float* u_prev,
 int ctk_mppi_step_end(ctk_handle* h, const float* parts_dev, int n_parts, float* u_out);
 
 /* -------------------------------------------------------------------------------------------
+ * sharded CEM / random-action: the global best K is the best K of the union of the
+ * shards' best-K lists, so ONE all-gather of K records {J, global index, Q[H]} per outer iteration
+ * replaces tf.argsort over all N (optimizer_cem_tf.py:73-75, optimizer_random_action_tf.py:65-66).
+ *   for it in range(ctk_shard_iterations(h)):
+ *       ctk_shard_iter_begin(h, s, u_prev, samples_it, loc, cand_dev)   roll out + local best K -> cand_dev
+ *       (caller all-gathers the ctk_shard_candidates_size(h) floats of every rank)
+ *       ctk_shard_iter_end(h, cands_all_dev, n_ranks)                   global best K (+ CEM refit, :77-78)
+ *   ctk_shard_finish(h, u_out)                                          CEM :99-102 / random :68
+ * samples_it: this iteration's draws only ([N,H,C]); cand_dev / cands_all_dev are device pointers
+ * and cands_all_dev must stay valid until ctk_shard_finish.  K = cem_best_k (CEM) or 1.
+ * ----------------------------------------------------------------------------------------- */
+size_t ctk_shard_candidates_size(const ctk_handle* h);
+int ctk_shard_iterations(const ctk_handle* h);
+int ctk_shard_iter_begin(ctk_handle* h, const float* s, const float* u_prev,
+                         const float* samples, int samples_loc, float* cand_dev);
+int ctk_shard_iter_end(ctk_handle* h, const float* cands_all_dev, int n_ranks);
+int ctk_shard_finish(ctk_handle* h, float* u_out);
+
+/* -------------------------------------------------------------------------------------------
  * state access
  * ----------------------------------------------------------------------------------------- */
 /* Copies buffer `which` to host `dst` (capacity `cap` floats); *n_out = floats written.      */

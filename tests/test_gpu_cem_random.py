@@ -136,3 +136,37 @@ def test_plain_rollout_matches_oracle():
     np.testing.assert_allclose(traj, to, rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(J, cost.get_trajectory_cost(to, Q, np.array([0.3], np.float32)), rtol=3e-5)
     e.close()
+
+
+@pytest.mark.parametrize("opt", ["cem", "random_action"])
+def test_sharded_topk_two_shards_equal_one_handle(opt):
+    """two shards of N/2 + one exchange of best-K records per iteration == one handle of N."""
+    import torch
+    N, H, K, its = 2048, 30, 205, 3
+    kw = dict(cem_outer_it=its, cem_best_k=K) if opt == "cem" else {}
+    full = CtkEngine(opt, "ODE", num_rollouts=N, mpc_horizon=H, dt=0.02, **kw)
+    sh = [CtkEngine(opt, "ODE", num_rollouts=N // 2, mpc_horizon=H, dt=0.02, global_rollout_offset=i * N // 2, **kw) for i in range(2)]
+    rec = sh[0].shard_candidates_size()
+    assert rec == (K if opt == "cem" else 1) * (2 + H)
+    gathered = torch.zeros(2 * rec, dtype=torch.float32, device="cuda")
+    rng = np.random.default_rng(4)
+    s = np.array([0.02, 0.1, 2.9, -0.5], np.float32)
+    n_it = sh[0].shard_iterations()
+    assert n_it == (its if opt == "cem" else 1)
+    for t in range(3):
+        draws = (rng.standard_normal((n_it, N, H, 1)) if opt == "cem" else rng.random((n_it, N, H, 1))).astype(np.float32)
+        u_full = full.step(s, draws if opt == "cem" else draws[0])
+        for it in range(n_it):
+            for i, e in enumerate(sh):
+                e.shard_iter_begin(s, gathered.data_ptr() + 4 * i * rec, draws[it, i * N // 2:(i + 1) * N // 2])
+            torch.cuda.synchronize()
+            for e in sh:
+                e.shard_iter_end(gathered.data_ptr(), 2)
+        us = [e.shard_finish() for e in sh]
+        np.testing.assert_array_equal(us[0], us[1])
+        np.testing.assert_allclose(us[0], u_full, rtol=1e-6, atol=1e-7)
+        if opt == "cem":
+            np.testing.assert_allclose(sh[0].read("U_NOM"), full.read("U_NOM"), rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(sh[1].read("STD"), full.read("STD"), rtol=1e-4, atol=1e-6)
+    for e in sh + [full]:
+        e.close()
