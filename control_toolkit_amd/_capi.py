@@ -75,6 +75,10 @@ SYMBOLS = {
     "ctk_shard_iter_begin": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ctk_shard_iter_end": (C.c_int, [_H, C.c_void_p, C.c_int]),
     "ctk_shard_finish": (C.c_int, [_H, C.c_void_p]),
+    "ctk_rpgd_keepers_size": (C.c_size_t, [_H]),
+    "ctk_rpgd_fresh_rows": (C.c_size_t, [_H, C.c_int]),
+    "ctk_rpgd_step_begin": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ctk_rpgd_step_end": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "ctk_read": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ctk_state_size": (C.c_size_t, [_H]),
     "ctk_get_state": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
@@ -307,6 +311,31 @@ class CtkEngine:
 
     def shard_finish(self) -> np.ndarray:
         self._check(self._lib.ctk_shard_finish(self._h, self._u_p))
+        return self._u.copy()
+
+    # ---- sharded RPGD ---------------------------------------------------------------------------------
+    def rpgd_keepers_size(self) -> int:
+        return int(self._lib.ctk_rpgd_keepers_size(self._h))
+
+    def rpgd_fresh_rows(self, n_ranks: int) -> int:
+        return int(self._lib.ctk_rpgd_fresh_rows(self._h, int(n_ranks)))
+
+    def rpgd_step_begin(self, s, keep_dev_ptr: int, u_prev=None):
+        self._s[:] = np.asarray(s).reshape(-1)
+        up_p = None
+        if u_prev is not None:
+            self._up[0] = np.asarray(u_prev).reshape(-1)[0]
+            up_p = self._up_p
+        self._check(self._lib.ctk_rpgd_step_begin(self._h, self._s_p, up_p, keep_dev_ptr))
+
+    def rpgd_step_end(self, keep_all_ptr: int, n_ranks: int, draws=None) -> np.ndarray:
+        if draws is None:
+            dp, loc = None, LOC_NONE
+        elif type(draws) is int:
+            dp, loc = draws, LOC_DEVICE
+        else:
+            arr = _f32(draws); dp, loc = arr.ctypes.data, LOC_HOST
+        self._check(self._lib.ctk_rpgd_step_end(self._h, keep_all_ptr, int(n_ranks), dp, loc, self._u_p))
         return self._u.copy()
 
     def read(self, name: str) -> np.ndarray:

@@ -67,6 +67,7 @@ struct ctk_handle {
     int shard_it = 0;           // iteration index within the current sharded step
     int* d_shard_idx = nullptr; size_t shard_idx_cap = 0;
     const float* shard_last_cands = nullptr;
+    float shard_s[CTK_S] = {0, 0, 0, 0}; float shard_uprev = 0.0f; bool shard_has_uprev = false;
     bool have_weights = false;  // MLP weights uploaded
     // profiling
     bool prof = false;
@@ -199,7 +200,7 @@ size_t samples_needed(const ctk_handle* h) {
         case CTK_OPT_CEM: return (size_t)cem_iterations(h) * N * H;
         case CTK_OPT_RANDOM_ACTION: return N * H;
         case CTK_OPT_RPGD:
-            return (h->count % h->cfg.resamp_per == 0) ? (N - (size_t)h->cfg.opt_keep_k) * P : 0;
+            return (h->count % h->cfg.resamp_per == 0 && (size_t)h->cfg.opt_keep_k < N) ? (N - (size_t)h->cfg.opt_keep_k) * P : 0;
     }
     return 0;
 }
@@ -369,13 +370,26 @@ int rpgd_iterations(const ctk_handle* h) {   // optimizer_rpgd.py:219-221,397-40
     return h->count == 0 ? first : h->cfg.outer_its;
 }
 
-int rpgd_warm(ctk_handle* h, const RolloutArgs& a, int n_new, int gather, int reset, const float* d_draws, int from, int to) {
+int rpgd_warm(ctk_handle* h, const RolloutArgs& a, int n_new, int gather, int reset, const float* d_draws, int from, int to,
+              const int* idx = nullptr, const float* recs = nullptr, int keeper_base = 0) {
     const ctk_config& c = h->cfg;
     HIP_TRY(h, ctk_launch_rpgd_warmstart(h->stream, a, h->N, h->H, h->P, n_new, gather, c.shift_previous, c.sampling_distribution,
                                          reset, c.action_low, c.action_high, c.sample_stdev, c.sample_mean, c.sample_min,
-                                         c.sample_max, d_draws, h->d_idx, h->d_pop[from], h->d_m[from], h->d_v[from],
+                                         c.sample_max, d_draws, idx ? idx : h->d_idx, h->d_pop[from], h->d_m[from], h->d_v[from],
                                          h->d_ages[from], h->d_pop[to], h->d_m[to], h->d_v[to], h->d_ages[to], h->d_interp,
-                                         h->d_unom[0], h->d_u, h->h_u_dev, h->seq));
+                                         h->d_unom[0], h->d_u, h->h_u_dev, h->seq, recs, 3 + 3 * h->H, keeper_base));
+    return CTK_OK;
+}
+
+int rpgd_descent(ctk_handle* h, const float* s, const float* u_prev) {
+    const ctk_config& c = h->cfg;
+    const int iters = rpgd_iterations(h);
+    RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);   // p_magic divides by H in the descent kernel
+    ProfSlot ps(h);
+    HIP_TRY(h, ctk_launch_rpgd_descent(h->stream, c.predictor, a, h->k, c.learning_rate, c.adam_beta_1, c.adam_beta_2,
+                                       c.adam_epsilon, c.gradmax_clip, h->d_pop[h->rcur], h->d_m[h->rcur], h->d_v[h->rcur], h->d_bc,
+                                       h->bc_len, h->adam_step, iters, h->d_wperm, h->d_scratch, ps.a, ps.b));
+    h->adam_step += iters;
     return CTK_OK;
 }
 
@@ -395,20 +409,13 @@ int rpgd_step(ctk_handle* h, const float* s, const float* u_prev, const float* s
     if (!h->rpgd_ready) return fail(h, CTK_ERR_STATE, "RPGD: call ctk_reset (optimizer_reset) before the first step");
     if (int rc = check_predictor(h)) return rc;
     const ctk_config& c = h->cfg;
-    const int iters = rpgd_iterations(h);
+    if (c.opt_keep_k > h->N) return fail(h, CTK_ERR_INVALID_ARGUMENT, "RPGD: opt_keep_k exceeds this handle's rollouts (a shard? use ctk_rpgd_step_begin/end)");
     const int cur = h->rcur, nxt = cur ^ 1;
     const bool resample = (h->count % c.resamp_per) == 0;                      // :449
     const float* d_draws = nullptr;
     if (resample)
         if (int rc = resolve_samples(h, samples, loc, (size_t)(h->N - c.opt_keep_k) * h->P, &d_draws)) return rc;
-    RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);   // p_magic divides by H in the descent kernel
-    {
-        ProfSlot ps(h);
-        HIP_TRY(h, ctk_launch_rpgd_descent(h->stream, c.predictor, a, h->k, c.learning_rate, c.adam_beta_1, c.adam_beta_2,
-                                           c.adam_epsilon, c.gradmax_clip, h->d_pop[cur], h->d_m[cur], h->d_v[cur], h->d_bc,
-                                           h->bc_len, h->adam_step, iters, h->d_wperm, h->d_scratch, ps.a, ps.b));
-    }
-    h->adam_step += iters;
+    if (int rc = rpgd_descent(h, s, u_prev)) return rc;
     HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, c.opt_keep_k, h->d_idx));   // :345-346
     RolloutArgs aw = make_args(h, s, u_prev, h->N, h->P);
     if (int rc = rpgd_warm(h, aw, resample ? h->N - c.opt_keep_k : 0, resample ? 1 : 0, 0, d_draws, cur, nxt)) return rc;
@@ -452,9 +459,9 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     if (cfg->optimizer == CTK_OPT_CEM && (cfg->cem_best_k < 1 || cfg->cem_best_k > cfg->num_rollouts || cfg->cem_outer_it < 1))
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: need 1 <= cem_best_k <= num_rollouts and cem_outer_it >= 1");
     if (cfg->optimizer == CTK_OPT_RPGD) {
-        if (cfg->opt_keep_k < 1 || cfg->opt_keep_k > cfg->num_rollouts || cfg->outer_its < 0 || cfg->resamp_per < 1 ||
+        if (cfg->opt_keep_k < 1 || cfg->outer_its < 0 || cfg->resamp_per < 1 ||
             cfg->shift_previous < 0 || (cfg->sampling_distribution != 0 && cfg->sampling_distribution != 1))
-            return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: RPGD needs 1 <= opt_keep_k <= num_rollouts, outer_its >= 0, resamp_per >= 1, shift_previous >= 0, sampling_distribution in {0,1}");
+            return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: RPGD needs opt_keep_k >= 1 (<= the GLOBAL population), outer_its >= 0, resamp_per >= 1, shift_previous >= 0, sampling_distribution in {0,1}");
         if (cfg->intermediate_steps != 1)
             return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: the RPGD adjoint is built for intermediate_steps == 1");
     }
@@ -755,6 +762,76 @@ int ctk_shard_finish(ctk_handle* h, float* u_out) {
     }
     h->shard_it = 0;
     h->shard_last_cands = nullptr;
+    return finish_step(h, u_out);
+}
+
+// ---- sharded RPGD --------------------------------------------------------------------------------
+static int rpgd_local_keep(const ctk_handle* h) { return h->cfg.opt_keep_k < h->N ? h->cfg.opt_keep_k : h->N; }
+
+size_t ctk_rpgd_keepers_size(const ctk_handle* h) {
+    if (!h || h->cfg.optimizer != CTK_OPT_RPGD) return 0;
+    return (size_t)rpgd_local_keep(h) * (3 + 3 * h->H);
+}
+
+// fresh rows this shard must draw at the next step_end (0 on non-resampling steps), given the world size
+size_t ctk_rpgd_fresh_rows(const ctk_handle* h, int n_ranks) {
+    if (!h || h->cfg.optimizer != CTK_OPT_RPGD || n_ranks < 1) return 0;
+    if (h->count % h->cfg.resamp_per != 0) return 0;
+    const long Ng = (long)n_ranks * h->N, first_keeper = Ng - h->cfg.opt_keep_k, off = h->cfg.global_rollout_offset;
+    long n = first_keeper - off;
+    if (n < 0) n = 0;
+    if (n > h->N) n = h->N;
+    return (size_t)n;
+}
+
+int ctk_rpgd_step_begin(ctk_handle* h, const float* s, const float* u_prev, float* keep_dev) {
+    if (!h || !s || !keep_dev) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_rpgd_step_begin: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
+    if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_STATE, "ctk_rpgd_step_begin: handle is not RPGD");
+    if (!h->rpgd_ready) return fail(h, CTK_ERR_STATE, "RPGD: call ctk_reset (optimizer_reset) before the first step");
+    if (h->shard_pending) return fail(h, CTK_ERR_STATE, "ctk_rpgd_step_begin: previous sharded step not ended");
+    if (int rc = check_predictor(h)) return rc;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    for (int i = 0; i < CTK_S; ++i) h->shard_s[i] = s[i];
+    h->shard_has_uprev = u_prev != nullptr;
+    h->shard_uprev = u_prev ? u_prev[0] : 0.0f;
+    if (int rc = rpgd_descent(h, s, u_prev)) return rc;
+    const int kl = rpgd_local_keep(h), cur = h->rcur;
+    HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, kl, h->d_idx));
+    HIP_TRY(h, ctk_launch_rpgd_pack_keepers(h->stream, h->d_J, h->d_pop[cur], h->d_m[cur], h->d_v[cur], h->d_ages[cur], h->d_idx, kl,
+                                            h->H, h->cfg.global_rollout_offset, keep_dev));
+    h->shard_pending = true;
+    return CTK_OK;
+}
+
+int ctk_rpgd_step_end(ctk_handle* h, const float* keep_all_dev, int n_ranks, const float* draws, int draws_loc, float* u_out) {
+    if (!h || !keep_all_dev || n_ranks < 1) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_rpgd_step_end: bad argument") : CTK_ERR_INVALID_ARGUMENT;
+    if (h->cfg.optimizer != CTK_OPT_RPGD || !h->shard_pending) return fail(h, CTK_ERR_STATE, "ctk_rpgd_step_end: no sharded RPGD step pending");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const ctk_config& c = h->cfg;
+    const int kl = rpgd_local_keep(h), M = n_ranks * kl, rs = 3 + 3 * h->H;
+    if (c.opt_keep_k > M) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_rpgd_step_end: opt_keep_k exceeds the gathered candidates");
+    if ((size_t)M > h->shard_idx_cap) {
+        if (h->d_shard_idx) HIP_TRY(h, hipFree(h->d_shard_idx));
+        h->d_shard_idx = nullptr; h->shard_idx_cap = 0;
+        HIP_TRY(h, hipMalloc((void**)&h->d_shard_idx, (size_t)M * sizeof(int)));
+        h->shard_idx_cap = (size_t)M;
+    }
+    // global keep-k (sorted) out of the union of the shards' sorted best lists (positional tie-break == global index)
+    HIP_TRY(h, ctk_launch_select_topk(h->stream, keep_all_dev, M, c.opt_keep_k, h->d_shard_idx, rs));
+    const bool resample = (h->count % c.resamp_per) == 0;
+    const int n_fresh = (int)ctk_rpgd_fresh_rows(h, n_ranks);
+    const long first_keeper = (long)n_ranks * h->N - c.opt_keep_k;
+    const int keeper_base = (int)(c.global_rollout_offset > first_keeper ? c.global_rollout_offset - first_keeper : 0);
+    const float* d_draws = nullptr;
+    if (resample && n_fresh > 0)
+        if (int rc = resolve_samples(h, draws, draws_loc, (size_t)n_fresh * h->P, &d_draws)) return rc;
+    const float* up = h->shard_has_uprev ? &h->shard_uprev : nullptr;
+    RolloutArgs aw = make_args(h, h->shard_s, up, h->N, h->P);
+    const int cur = h->rcur, nxt = cur ^ 1;
+    if (int rc = rpgd_warm(h, aw, resample ? n_fresh : 0, resample ? 1 : 0, 0, d_draws, cur, nxt, h->d_shard_idx, keep_all_dev, keeper_base)) return rc;
+    h->rcur = nxt;
+    ++h->count;
+    h->shard_pending = false;
     return finish_step(h, u_out);
 }
 

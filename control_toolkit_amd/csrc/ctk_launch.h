@@ -69,4 +69,7 @@ hipError_t ctk_launch_rpgd_warmstart(hipStream_t st, const RolloutArgs& a, int N
                                      float sample_mean, float sample_min, float sample_max, const float* draws, const int* idx,
                                      const float* Q_old, const float* m_old, const float* v_old, const float* ages_old,
                                      float* Q_new, float* m_new, float* v_new, float* ages_new, const InterpEntry* interp,
-                                     float* u_nom, float* u_dev, float* u_host, uint32_t seq);
+                                     float* u_nom, float* u_dev, float* u_host, uint32_t seq, const float* recs = nullptr,
+                                     int rs = 0, int keeper_base = 0);
+hipError_t ctk_launch_rpgd_pack_keepers(hipStream_t st, const float* J, const float* Q, const float* m, const float* v,
+                                        const float* ages, const int* idx, int K, int H, int global_offset, float* out);

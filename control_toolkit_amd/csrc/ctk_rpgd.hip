@@ -284,6 +284,11 @@ __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_descent(RolloutArgs a, EnvK
 struct WarmArgs {
     int N, H, P, n_new, gather, shift_previous, sampling_distribution, reset;
     float lo, hi, sample_stdev, sample_mean, sample_min, sample_max;
+    // sharded step: keepers and the best plan come from the all-gathered keeper records
+    // {J, global index, age, Q[H], m[H], v[H]} instead of this handle's own rows
+    const float* recs;     // nullptr: single-handle step
+    int rs;                // record stride (3 + 3H)
+    int keeper_base;       // index (in the global sorted keeper list) of the first keeper this shard hosts
 };
 
 __global__ __launch_bounds__(256) void ctk_rpgd_warmstart(WarmArgs w, RolloutArgs a, const float* __restrict__ draws,
@@ -318,6 +323,11 @@ __global__ __launch_bounds__(256) void ctk_rpgd_warmstart(WarmArgs w, RolloutArg
                 y[j] = fminf(fmaxf(raw, w.lo), w.hi);                                                                // :292
             }
             q = y[0] * e.w0 + (e.i0 + 1 < w.P ? y[1] * e.w1 : 0.0f);                                                 // :294
+        } else if (w.gather && w.recs) {
+            const float* rec = w.recs + (size_t)idx[w.keeper_base + i - w.n_new] * w.rs;
+            const int hs = min(h + w.shift_previous, H - 1);
+            q = rec[3 + hs];
+            if (h + 1 < H) { mm = rec[3 + H + h + 1]; vv = rec[3 + 2 * H + h + 1]; }
         } else {
             const int src = w.gather ? idx[i - w.n_new] : i;
             const int hs = min(h + w.shift_previous, H - 1);
@@ -326,16 +336,47 @@ __global__ __launch_bounds__(256) void ctk_rpgd_warmstart(WarmArgs w, RolloutArg
         }
         Q_new[gid] = q; m_new[gid] = mm; v_new[gid] = vv;
         if (h == 0) {
-            const float age = (i < w.n_new) ? 0.0f : ages_old[w.gather ? idx[i - w.n_new] : i];
+            float age = 0.0f;
+            if (i >= w.n_new) {
+                if (w.gather && w.recs) age = w.recs[(size_t)idx[w.keeper_base + i - w.n_new] * w.rs + 2];
+                else age = ages_old[w.gather ? idx[i - w.n_new] : i];
+            }
             ages_new[i] = w.reset ? 0.0f : age + 1.0f;
         }
     }
     if (!w.reset && gid < H) {
-        const int best = idx[0];                       // u_nom = Q_tf[best_idx[0]] BEFORE the warm start (:426)
-        const float q = Q_old[(size_t)best * H + gid];
+        // u_nom = Q_tf[best_idx[0]] BEFORE the warm start (:426)
+        const float q = w.recs ? w.recs[(size_t)idx[0] * w.rs + 3 + gid] : Q_old[(size_t)idx[0] * H + gid];
         u_nom[gid] = q;
         if (gid == 0) publish_u(u_dev, u_host, q, seq);   // :523
     }
+}
+
+// this shard's best plans with their optimizer state, sorted: {J, global index, age, Q[H], m[H], v[H]}
+__global__ __launch_bounds__(256) void ctk_rpgd_pack_keepers(const float* __restrict__ J, const float* __restrict__ Q,
+                                                             const float* __restrict__ m, const float* __restrict__ v,
+                                                             const float* __restrict__ ages, const int* __restrict__ idx, int K,
+                                                             int H, int global_offset, float* __restrict__ out) {
+    const int rs = 3 + 3 * H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K * rs; i += gridDim.x * blockDim.x) {
+        const int kk = i / rs, f = i - kk * rs, src = idx[kk];
+        float val;
+        if (f == 0) val = J[src];
+        else if (f == 1) val = __builtin_bit_cast(float, global_offset + src);
+        else if (f == 2) val = ages[src];
+        else if (f < 3 + H) val = Q[(size_t)src * H + (f - 3)];
+        else if (f < 3 + 2 * H) val = m[(size_t)src * H + (f - 3 - H)];
+        else val = v[(size_t)src * H + (f - 3 - 2 * H)];
+        out[i] = val;
+    }
+}
+
+hipError_t ctk_launch_rpgd_pack_keepers(hipStream_t st, const float* J, const float* Q, const float* m, const float* v,
+                                        const float* ages, const int* idx, int K, int H, int global_offset, float* out) {
+    const int total = K * (3 + 3 * H);
+    hipLaunchKernelGGL(ctk_rpgd_pack_keepers, dim3((total + 255) / 256 > 128 ? 128 : (total + 255) / 256), dim3(256), 0, st, J, Q, m, v,
+                       ages, idx, K, H, global_offset, out);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -375,8 +416,10 @@ hipError_t ctk_launch_rpgd_warmstart(hipStream_t st, const RolloutArgs& a, int N
                                      float sample_mean, float sample_min, float sample_max, const float* draws, const int* idx,
                                      const float* Q_old, const float* m_old, const float* v_old, const float* ages_old,
                                      float* Q_new, float* m_new, float* v_new, float* ages_new, const InterpEntry* interp,
-                                     float* u_nom, float* u_dev, float* u_host, uint32_t seq) {
-    WarmArgs w{N, H, P, n_new, gather, shift_previous, sampling_distribution, reset, lo, hi, sample_stdev, sample_mean, sample_min, sample_max};
+                                     float* u_nom, float* u_dev, float* u_host, uint32_t seq, const float* recs, int rs,
+                                     int keeper_base) {
+    WarmArgs w{N, H, P, n_new, gather, shift_previous, sampling_distribution, reset, lo, hi, sample_stdev, sample_mean, sample_min, sample_max,
+               recs, rs, keeper_base};
     const int total = N * H;
     hipLaunchKernelGGL(ctk_rpgd_warmstart, dim3((total + 255) / 256), dim3(256), 0, st, w, a, draws, idx, Q_old, m_old, v_old, ages_old,
                        Q_new, m_new, v_new, ages_new, interp, u_nom, u_dev, u_host, seq);

@@ -63,3 +63,32 @@ class ShardedTopK:
                 parts = self.mine
             self.engine.shard_iter_end(parts.data_ptr(), self.world_size)
         return self.engine.shard_finish()
+
+
+class ShardedRPGD:
+    """Sharded RPGD: the Adam descent is local; one all-gather per step of the shards'
+    best plans WITH their optimizer state, after which every rank rebuilds its rows of the global
+    population [fresh | keepers sorted by cost] exactly as one big optimizer would."""
+
+    def __init__(self, engine, rank: int, world_size: int, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.engine, self.rank, self.world_size, self.group = engine, rank, world_size, group
+        self.rec = int(engine.rpgd_keepers_size())
+        self.device = device if device is not None else torch.device("cpu")
+        self.mine = torch.zeros(self.rec, dtype=torch.float32, device=self.device)
+        self.all = torch.zeros(self.rec * world_size, dtype=torch.float32, device=self.device)
+
+    def fresh_rows(self) -> int:
+        return self.engine.rpgd_fresh_rows(self.world_size)
+
+    def step(self, s, draws=None, u_prev=None) -> np.ndarray:
+        """draws: None (device Philox by global row) or raw draws [fresh_rows(), P, 1] for this shard."""
+        self.engine.rpgd_step_begin(s, self.mine.data_ptr(), u_prev=u_prev)
+        if self.world_size > 1:
+            self.dist.all_gather_into_tensor(self.all, self.mine, group=self.group)
+            parts = self.all
+        else:
+            parts = self.mine
+        return self.engine.rpgd_step_end(parts.data_ptr(), self.world_size, draws)

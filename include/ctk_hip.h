@@ -205,6 +205,25 @@ int ctk_shard_iter_end(ctk_handle* h, const float* cands_all_dev, int n_ranks);
 int ctk_shard_finish(ctk_handle* h, float* u_out);
 
 /* -------------------------------------------------------------------------------------------
+ * sharded RPGD.  The descent needs no exchange (loss = sum_n J_n, optimizer_rpgd.py:325);
+ * the keep-k / resample step (:345-346, :449-516) needs the global best k plans WITH their Adam
+ * moments and ages: one all-gather of ctk_rpgd_keepers_size(h) floats per rank — records
+ * {J, global index, age, Q[H], m[H], v[H]} of the shard's best min(k, N_local) plans, sorted.
+ *   ctk_rpgd_step_begin(h, s, u_prev, keep_dev)          descent + cost pass + local best list -> keep_dev
+ *   (all-gather)
+ *   ctk_rpgd_step_end(h, keep_all_dev, n_ranks, draws, loc, u_out)
+ * Every rank then rebuilds ITS rows of the global population [fresh | keepers sorted] (:454-455): global
+ * row g < N_global - k is resampled (Philox by global row, or `draws` = raw draws for this shard's
+ * ctk_rpgd_fresh_rows() fresh rows, [rows,P,C]); the others take keeper g - (N_global - k) from the
+ * records.  cfg.opt_keep_k is the GLOBAL k; equal shard sizes are assumed (N_global = n_ranks * N).
+ * ----------------------------------------------------------------------------------------- */
+size_t ctk_rpgd_keepers_size(const ctk_handle* h);
+size_t ctk_rpgd_fresh_rows(const ctk_handle* h, int n_ranks);
+int ctk_rpgd_step_begin(ctk_handle* h, const float* s, const float* u_prev, float* keep_dev);
+int ctk_rpgd_step_end(ctk_handle* h, const float* keep_all_dev, int n_ranks,
+                      const float* draws, int draws_loc, float* u_out);
+
+/* -------------------------------------------------------------------------------------------
  * state access
  * ----------------------------------------------------------------------------------------- */
 /* Copies buffer `which` to host `dst` (capacity `cap` floats); *n_out = floats written.      */

@@ -165,3 +165,50 @@ def test_rpgd_mlp_matches_oracle(N, H, p, its):
         e.set_state(state_vec(o.Q, o.opt.m, o.opt.v, o.trajectory_ages, float(o.u), o.opt.step_count, o.count))
         s = pred.step(s.reshape(1, 4), np.array([uo], np.float32))[0]
     e.close()
+
+
+@pytest.mark.parametrize("pred,host_draws", [("ODE", True), ("ODE", False), ("MLP", False)])
+def test_sharded_rpgd_two_shards_equal_one_handle(pred, host_draws):
+    """2 shards of N/2 with one exchange of keeper records per step == one handle of N
+    (same global population layout [fresh | keepers sorted], same Adam state, same u)."""
+    import torch
+    from control_toolkit_amd import CtkEngine
+    N, H, p, its, k = 128, 20, 5, 3, 32
+    kw = dict(mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p, outer_its=its, resamp_per=2, shift_previous=1,
+              opt_keep_k=k, sampling_distribution=0, sample_min=-1.0, sample_max=1.0, learning_rate=0.05, gradmax_clip=5.0, seed=21)
+    full = CtkEngine("rpgd", pred, num_rollouts=N, **kw)
+    sh = [CtkEngine("rpgd", pred, num_rollouts=N // 2, global_rollout_offset=i * N // 2, **kw) for i in range(2)]
+    if pred == "MLP":
+        w = O.mlp_default_weights(3)
+        for e in sh + [full]:
+            e.set_predictor_weights(w)
+    P = O.num_inducing_points(H, p)
+    rng = np.random.default_rng(5)
+    d0 = rng.random((N, P, 1), dtype=np.float32) if host_draws else None
+    full.reset(d0)
+    for i, e in enumerate(sh):
+        e.reset(None if d0 is None else d0[i * N // 2:(i + 1) * N // 2])
+    np.testing.assert_array_equal(np.concatenate([e.read("PLAN") for e in sh]), full.read("PLAN"))
+    rec = sh[0].rpgd_keepers_size()
+    assert rec == k * (3 + 3 * H)
+    gathered = torch.zeros(2 * rec, dtype=torch.float32, device="cuda")
+    s = np.array([0.05, 0.0, 2.9, 0.3], np.float32)
+    for t in range(4):
+        fresh = [e.rpgd_fresh_rows(2) for e in sh]
+        assert fresh == ([64, 32] if t % 2 == 0 else [0, 0])
+        dr = rng.random((N - k, P, 1), dtype=np.float32) if (host_draws and t % 2 == 0) else None
+        u_full = full.step(s, dr)
+        for i, e in enumerate(sh):
+            e.rpgd_step_begin(s, gathered.data_ptr() + 4 * i * rec)
+        torch.cuda.synchronize()
+        us = []
+        for i, e in enumerate(sh):
+            mine = None if dr is None else dr[i * 64: i * 64 + fresh[i]]
+            us.append(e.rpgd_step_end(gathered.data_ptr(), 2, mine))
+        np.testing.assert_array_equal(us[0], us[1])
+        np.testing.assert_allclose(us[0], u_full, rtol=1e-6, atol=1e-7)
+        for name in ("PLAN", "ADAM_M", "ADAM_V", "AGES"):
+            got = np.concatenate([e.read(name) for e in sh])
+            np.testing.assert_allclose(got, full.read(name), rtol=1e-6, atol=1e-7, err_msg=name)
+    for e in sh + [full]:
+        e.close()
