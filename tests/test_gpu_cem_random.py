@@ -170,3 +170,31 @@ def test_sharded_topk_two_shards_equal_one_handle(opt):
             np.testing.assert_allclose(sh[1].read("STD"), full.read("STD"), rtol=1e-4, atol=1e-6)
     for e in sh + [full]:
         e.close()
+
+
+@pytest.mark.parametrize("N,K", [(65536, 100), (5000, 5000), (1, 1), (63, 7)])
+def test_select_topk_against_numpy(N, K):
+    """the selection kernel alone, through random-action/CEM handles: sorted ascending, ties by index"""
+    H = 2
+    e = CtkEngine("cem", "ODE", num_rollouts=N, mpc_horizon=H, dt=0.02, cem_outer_it=1, cem_best_k=K)
+    rng = np.random.default_rng(N)
+    noise = rng.standard_normal((1, N, H, 1)).astype(np.float32)
+    noise[0, N // 2:, :, :] = noise[0, : N - N // 2, :, :][: N - N // 2]     # duplicate plans -> exact cost ties
+    e.step(np.array([0.0, 0.0, 1.0, 0.0], np.float32), noise)
+    J = e.read("J")
+    got = e.read("BEST_IDX")
+    np.testing.assert_array_equal(got, np.argsort(J, kind="stable")[:K])
+    e.close()
+
+
+@pytest.mark.parametrize("opt", ["mppi", "cem", "random_action", "rpgd"])
+def test_degenerate_sizes_n1_h1(opt):
+    kw = dict(cem=dict(cem_outer_it=2, cem_best_k=1), rpgd=dict(outer_its=2, opt_keep_k=1, resamp_per=1)).get(opt, {})
+    e = CtkEngine(opt, "ODE", num_rollouts=1, mpc_horizon=1, dt=0.02, seed=2, **kw)
+    if opt == "rpgd":
+        e.reset()
+    s = np.array([0.0, 0.0, 0.5, 0.0], np.float32)
+    for _ in range(3):
+        u = e.step(s)
+        assert np.isfinite(u).all() and -1.0 <= u[0] <= 1.0
+    e.close()

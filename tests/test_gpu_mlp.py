@@ -96,3 +96,42 @@ def test_cem_and_random_mlp_match_oracle():
     np.testing.assert_array_equal(g.step(s, u01)[0], r.step(s, u01))
     np.testing.assert_allclose(g.read("J"), r.J, rtol=5e-5, atol=1e-3)
     g.close()
+
+
+def test_mppi_cfg5_full_size_eight_shards_equal_one_handle():
+    """BASELINE config 5 at full size (MPPI, N = 65536, H = 100, MLP): size-independent properties —
+    8 shards of 8192 merged through the record exchange == one handle of 65536 (which takes the
+    multi-launch hierarchical merge, > 256 blocks), inputs within limits, deterministic."""
+    import torch
+    N, H, p, G = 65536, 100, 10, 8
+    w = O.mlp_default_weights(0)
+    kw = dict(mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p, seed=5)
+    full = CtkEngine("mppi", "MLP", num_rollouts=N, **kw)
+    full.set_predictor_weights(w)
+    sh = []
+    for i in range(G):
+        e = CtkEngine("mppi", "MLP", num_rollouts=N // G, global_rollout_offset=i * (N // G), **kw)
+        e.set_predictor_weights(w)
+        sh.append(e)
+    rec = full.mppi_partial_size()
+    parts = torch.zeros(G * rec, dtype=torch.float32, device="cuda")
+    s = np.array([0.05, 0.0, 2.0, 0.5], np.float32)
+    for t in range(2):
+        u_full = full.step(s, None)                       # device Philox, addressed by global rollout index
+        for i, e in enumerate(sh):
+            e.mppi_step_begin(s, parts.data_ptr() + 4 * i * rec, None)
+        torch.cuda.synchronize()
+        us = [e.mppi_step_end(parts.data_ptr(), G) for e in sh]
+        assert all(np.array_equal(us[0], u) for u in us[1:])
+        np.testing.assert_allclose(us[0], u_full, **U_TOL)
+        np.testing.assert_allclose(sh[3].read("U_NOM"), full.read("U_NOM"), **U_TOL)
+        assert np.all(np.abs(full.read("U_NOM")) <= 1.0)
+        J = full.read("J")
+        assert np.isfinite(J).all() and J.shape == (N,)
+        Js = np.concatenate([e.read("J") for e in sh])
+        if t == 0:
+            np.testing.assert_array_equal(Js, J)          # same draws, same nominal plan: identical costs
+        else:
+            np.testing.assert_allclose(Js, J, rtol=1e-5)  # u_nom now differs by the merge's summation order
+    for e in sh + [full]:
+        e.close()
