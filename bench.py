@@ -39,6 +39,14 @@ WORKLOADS = {
                       kw=dict(outer_its=20, resamp_per=10, shift_previous=1, opt_keep_k=64, sampling_distribution=0,
                               sample_min=-1.0, sample_max=1.0, learning_rate=0.05, gradmax_clip=5.0)),
     "mppi_cfg5_shard": dict(opt="mppi", pred="MLP", N=8192, H=100, p=10, kw={}),
+    # the reference's own default problem sizes (Control_Toolkit_ASF_Template/config_optimizers.yml)
+    "mppi_default": dict(opt="mppi", pred="ODE", N=3500, H=35, p=10, kw={}),
+    "cem_default": dict(opt="cem", pred="ODE", N=200, H=40, p=1,
+                        kw=dict(cem_outer_it=3, cem_best_k=40, cem_initial_action_stdev=0.5, cem_stdev_min=0.01)),
+    "rpgd_default": dict(opt="rpgd", pred="ODE", N=32, H=40, p=10,
+                         kw=dict(outer_its=2, resamp_per=10, shift_previous=1, opt_keep_k=8, sampling_distribution=0,
+                                 sample_min=-1.0, sample_max=1.0, learning_rate=0.05, gradmax_clip=5.0)),
+    "random_default": dict(opt="random_action", pred="ODE", N=320, H=35, p=1, kw={}),
 }
 
 
@@ -104,6 +112,10 @@ def cpu_baseline(w, budget_s=12.0):
         o = O.CEM(pred, cost, num_rollouts=N, mpc_horizon=H, cem_outer_it=kw["cem_outer_it"], cem_best_k=kw["cem_best_k"])
         noise = rng.standard_normal((kw["cem_outer_it"], N, H, 1)).astype(np.float32)
         step = lambda s: o.step(s, noise)
+    elif w["opt"] == "random_action":
+        o = O.RandomAction(pred, cost, num_rollouts=N, mpc_horizon=H)
+        u01 = rng.random((N, H, 1), dtype=np.float32)
+        step = lambda s: o.step(s, u01)
     else:
         kw = w["kw"]
         o = O.RPGD(pred, cost, num_rollouts=N, mpc_horizon=H, outer_its=kw["outer_its"], resamp_per=kw["resamp_per"],
@@ -144,11 +156,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # rehearsal hooks for a one-GPU box (never set by the driver): all ranks on device 0, gloo instead of RCCL
+    backend = os.environ.get("CTK_BENCH_BACKEND", "nccl")
+    if os.environ.get("CTK_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     w = WORKLOADS[args.workload]
     if world > 1 and w["opt"] != "mppi":

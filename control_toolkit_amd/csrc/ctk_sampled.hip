@@ -91,12 +91,17 @@ __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(RolloutArgs a, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// rank-by-counting selection: rank(i) = #{ j : (J_j, j) < (J_i, i) }.  One block = 64 rows x 16
-// waves; wave w scans the j-slice [w*L, (w+1)*L) with wave-uniform (scalar) loads of J_j, the
-// 16 partial counts meet in LDS.  Ranks are a permutation, so idx_out[rank] = i for rank < K
-// is a race-free scatter and idx_out comes out sorted ascending by (J, index).
+// rank-by-counting selection: rank(i) = #{ j : (J_j, j) < (J_i, i) }, a permutation under the total
+// order (cost, index), so idx_out[rank] = i for rank < K is a race-free scatter and idx_out comes
+// out sorted ascending — what tf.argsort gives, ties fixed by index.
+// Work N^2 comparisons, spread over N/16 blocks x 16 waves (256 blocks at N = 4096: the whole
+// chip): a block owns 16 rows; wave w scans the j-slice [w*L, (w+1)*L); lane (r = lane & 15,
+// q = lane >> 4) compares row r against the j = 4t + q of the slice, the slice staged in LDS as
+// sortable 32-bit keys (coalesced load; 4 distinct addresses per LDS read, broadcast within 16 lanes).
 // ---------------------------------------------------------------------------------------------
 constexpr int SEL_WAVES = 16;
+constexpr int SEL_ROWS = 16;
+constexpr int SEL_CHUNK = 1024;   // keys per wave and pass (LDS: 16 waves x 1024 x 4 B = 64 KiB)
 
 // order-preserving map float -> uint32 (total order; -0.0 < +0.0, NaNs sort last)
 CTK_DEV uint32_t f32_sortable(float f) {
@@ -107,40 +112,35 @@ CTK_DEV uint32_t f32_sortable(float f) {
 // J_i = J[i * ldj] (ldj = 1 for a plain cost vector; candidate records of the sharded path are strided)
 __global__ __launch_bounds__(64 * SEL_WAVES) void ctk_select_topk(const float* __restrict__ J, int ldj, int N, int K,
                                                                   int* __restrict__ idx_out) {
-    __shared__ int cnt_s[SEL_WAVES][64];
+    __shared__ uint32_t key_s[SEL_WAVES][SEL_CHUNK];
+    __shared__ int cnt_s[SEL_WAVES][SEL_ROWS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + lane;
-    // 64-bit key (sortable cost, index): unique, so ranks are a permutation
-    const unsigned long long key_i = ((unsigned long long)f32_sortable((i < N) ? J[(size_t)i * ldj] : INFINITY) << 32) | (unsigned)i;
+    const int r = lane & 15, q = lane >> 4;
+    const int i = blockIdx.x * SEL_ROWS + r;
+    const uint32_t ki = f32_sortable((i < N) ? J[(size_t)i * ldj] : INFINITY);
     const int L = (N + SEL_WAVES - 1) / SEL_WAVES;
     const int j0 = wave * L, j1 = min(N, j0 + L);
     int cnt = 0;
-    for (int jb = j0; jb < j1; jb += 64) {
-        // one coalesced vector load of 64 costs, then 64 wave-uniform broadcasts (v_readlane) instead of
-        // 64 dependent scalar loads
-        const int jj = jb + lane;
-        const uint32_t mine = f32_sortable(jj < j1 ? J[(size_t)jj * ldj] : INFINITY);
-        const int nq = min(64, j1 - jb);
-        if (nq == 64) {
-#pragma unroll
-            for (int q = 0; q < 64; ++q) {
-                const unsigned long long key_j = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine, q) << 32) | (unsigned)(jb + q);
-                cnt += key_j < key_i;
-            }
-        } else {
-            for (int q = 0; q < nq; ++q) {
-                const unsigned long long key_j = ((unsigned long long)(uint32_t)__shfl((int)mine, q, 64) << 32) | (unsigned)(jb + q);
-                cnt += key_j < key_i;
-            }
+    for (int jb = j0; jb < j1; jb += SEL_CHUNK) {
+        const int n = min(SEL_CHUNK, j1 - jb);
+        for (int t = lane; t < n; t += 64) key_s[wave][t] = f32_sortable(J[(size_t)(jb + t) * ldj]);
+        // wave-private slice: LDS ops of one wave complete in order, no barrier needed
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+        for (int t = q; t < n; t += 4) {
+            const uint32_t kj = key_s[wave][t];
+            const int j = jb + t;
+            cnt += (kj < ki) | ((kj == ki) & (j < i));
         }
     }
-    cnt_s[wave][lane] = cnt;
+    cnt += __shfl_xor(cnt, 16, 64);
+    cnt += __shfl_xor(cnt, 32, 64);
+    if (lane < SEL_ROWS) cnt_s[wave][lane] = cnt;
     __syncthreads();
-    if (wave == 0 && i < N) {
-        int r = 0;
+    if (wave == 0 && lane < SEL_ROWS && i < N) {
+        int rk = 0;
 #pragma unroll
-        for (int w = 0; w < SEL_WAVES; ++w) r += cnt_s[w][lane];
-        if (r < K) idx_out[r] = i;
+        for (int w = 0; w < SEL_WAVES; ++w) rk += cnt_s[w][lane];
+        if (rk < K) idx_out[rk] = i;
     }
 }
 
@@ -240,7 +240,7 @@ size_t ctk_affine_rollout_lds(int H) {
 }
 
 hipError_t ctk_launch_select_topk(hipStream_t st, const float* J, int N, int K, int* idx_out, int ldj) {
-    hipLaunchKernelGGL(ctk_select_topk, dim3((N + 63) / 64), dim3(64 * SEL_WAVES), 0, st, J, ldj, N, K, idx_out);
+    hipLaunchKernelGGL(ctk_select_topk, dim3((N + SEL_ROWS - 1) / SEL_ROWS), dim3(64 * SEL_WAVES), 0, st, J, ldj, N, K, idx_out);
     return hipGetLastError();
 }
 
