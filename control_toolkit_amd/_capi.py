@@ -361,8 +361,9 @@ class CtkEngine:
         st = _f32(state).ravel()
         self._check(self._lib.ctk_set_state(self._h, _ptr(st), st.size))
 
-    def profile_enable(self, on: bool = True):
-        self._check(self._lib.ctk_profile_enable(self._h, int(on)))
+    def profile_enable(self, on=True, every: int = 1):
+        """time every `every`-th launch of the dominant kernel (dispatch timestamps); on=False disables"""
+        self._check(self._lib.ctk_profile_enable(self._h, int(every) if on else 0))
 
     def profile_read(self) -> np.ndarray:
         buf = np.empty(4096, np.float32)

@@ -71,6 +71,8 @@ struct ctk_handle {
     bool have_weights = false;  // MLP weights uploaded
     // profiling
     bool prof = false;
+    int prof_every = 1;         // time every n-th dominant-kernel launch (timing a launch costs ~8 us of host time)
+    unsigned prof_tick = 0;
     std::vector<EventPair> events;
     size_t ev_used = 0;
     std::string err;
@@ -249,7 +251,9 @@ RolloutArgs make_args(ctk_handle* h, const float* s, const float* u_prev, int N,
 struct ProfSlot {
     hipEvent_t a = nullptr, b = nullptr;
     explicit ProfSlot(ctk_handle* h) {
-        if (h->prof && h->ev_used < h->events.size()) { a = h->events[h->ev_used].a; b = h->events[h->ev_used].b; ++h->ev_used; }
+        if (h->prof && h->ev_used < h->events.size() && (h->prof_tick++ % (unsigned)h->prof_every) == 0) {
+            a = h->events[h->ev_used].a; b = h->events[h->ev_used].b; ++h->ev_used;
+        }
     }
 };
 
@@ -981,6 +985,8 @@ int ctk_profile_enable(ctk_handle* h, int on) {
         for (auto& e : h->events) { HIP_TRY(h, hipEventCreate(&e.a)); HIP_TRY(h, hipEventCreate(&e.b)); }
     }
     h->prof = on != 0;
+    h->prof_every = on > 1 ? on : 1;
+    h->prof_tick = 0;
     h->ev_used = 0;
     return CTK_OK;
 }

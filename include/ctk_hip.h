@@ -237,7 +237,9 @@ int ctk_set_state(ctk_handle* h, const float* src, size_t n);
 
 /* -------------------------------------------------------------------------------------------
  * measurement: HIP-event timing of the dominant (rollout) kernel on the handle's stream.
- * enable, run steps, then read per-step durations in milliseconds.
+ * enable, run steps, then read the durations in milliseconds.  `on` = n > 0 times every n-th launch of
+ * the dominant kernel (timing a launch through its dispatch timestamps costs several microseconds of
+ * host time, so a sparse sample perturbs the timed region less); 0 disables.
  * ----------------------------------------------------------------------------------------- */
 int ctk_profile_enable(ctk_handle* h, int on);
 int ctk_profile_read(ctk_handle* h, float* ms_out, size_t cap, size_t* n_out);
