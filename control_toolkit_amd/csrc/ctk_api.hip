@@ -59,6 +59,7 @@ struct ctk_handle {
     float* d_scratch = nullptr;
     int rcur = 0;
     int adam_step = 0;
+    int variant = 0;            // the optimizer asked for; cfg.optimizer holds its engine family (GRADIENT -> RPGD, CEM_NAIVE_GRAD -> CEM)
     bool rpgd_ready = false;
     int count = 0;              // CEM / RPGD step counter
     uint32_t call = 0;          // Philox call counter
@@ -202,6 +203,7 @@ size_t samples_needed(const ctk_handle* h) {
         case CTK_OPT_CEM: return (size_t)cem_iterations(h) * N * H;
         case CTK_OPT_RANDOM_ACTION: return N * H;
         case CTK_OPT_RPGD:
+            if (h->variant == CTK_OPT_GRADIENT) return N;   // the shifted-in tail input of every plan
             return (h->count % h->cfg.resamp_per == 0 && (size_t)h->cfg.opt_keep_k < N) ? (N - (size_t)h->cfg.opt_keep_k) * P : 0;
     }
     return 0;
@@ -338,6 +340,26 @@ int cem_step(ctk_handle* h, const float* s, const float* u_prev, const float* sa
     if (int rc = resolve_samples(h, samples, loc, per_it * its, &d_s)) return rc;
     const bool log = h->cfg.materialize_trajectories != 0;
     float* mu = h->d_unom[0];
+    if (h->variant == CTK_OPT_CEM_NAIVE_GRAD) {
+        // optimizer_cem_naive_grad_tf.py:57-87 per outer iteration: sample, ONE clipped-gradient SGD step on every
+        // sample (:63-71), roll the moved samples out again (:73-74), elite refit (:77-83)
+        const ctk_config& c = h->cfg;
+        for (int it = 0; it < its; ++it) {
+            RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);
+            a.stream_id = (uint32_t)it;
+            HIP_TRY(h, ctk_launch_sample_plans(h->stream, a, d_s ? d_s + per_it * it : nullptr, mu, h->d_std, h->d_pop[0]));
+            ProfSlot ps(h);
+            HIP_TRY(h, ctk_launch_rpgd_descent(h->stream, c.predictor, a, h->k, c.learning_rate, 0.0f, 0.0f, 0.0f, c.gradmax_clip,
+                                               h->d_pop[0], nullptr, nullptr, nullptr, 0, 0, 1, h->d_wperm, h->d_scratch, ps.a, ps.b, 2));
+            HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, c.cem_best_k, h->d_idx));
+            HIP_TRY(h, ctk_launch_cem_refit(h->stream, h->d_pop[0], h->d_idx, c.cem_best_k, h->H, mu, h->d_std, h->H));
+        }
+        const float mid = (c.action_low + c.action_high) * 0.5f;
+        HIP_TRY(h, ctk_launch_cem_finish(h->stream, h->d_pop[0], h->d_idx, h->H, mu, h->d_std, c.cem_stdev_min,
+                                         c.cem_initial_action_stdev, mid, h->d_u, h->h_u_dev, h->seq, h->H, 10.0f, 1));   // :101-104
+        ++h->count;
+        return finish_step(h, u_out);
+    }
     for (int it = 0; it < its; ++it) {
         RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);
         a.stream_id = (uint32_t)it;
@@ -375,13 +397,13 @@ int rpgd_iterations(const ctk_handle* h) {   // optimizer_rpgd.py:219-221,397-40
 }
 
 int rpgd_warm(ctk_handle* h, const RolloutArgs& a, int n_new, int gather, int reset, const float* d_draws, int from, int to,
-              const int* idx = nullptr, const float* recs = nullptr, int keeper_base = 0) {
+              const int* idx = nullptr, const float* recs = nullptr, int keeper_base = 0, int fresh_tail = 0) {
     const ctk_config& c = h->cfg;
     HIP_TRY(h, ctk_launch_rpgd_warmstart(h->stream, a, h->N, h->H, h->P, n_new, gather, c.shift_previous, c.sampling_distribution,
                                          reset, c.action_low, c.action_high, c.sample_stdev, c.sample_mean, c.sample_min,
                                          c.sample_max, d_draws, idx ? idx : h->d_idx, h->d_pop[from], h->d_m[from], h->d_v[from],
                                          h->d_ages[from], h->d_pop[to], h->d_m[to], h->d_v[to], h->d_ages[to], h->d_interp,
-                                         h->d_unom[0], h->d_u, h->h_u_dev, h->seq, recs, 3 + 3 * h->H, keeper_base));
+                                         h->d_unom[0], h->d_u, h->h_u_dev, h->seq, recs, 3 + 3 * h->H, keeper_base, fresh_tail));
     return CTK_OK;
 }
 
@@ -392,7 +414,8 @@ int rpgd_descent(ctk_handle* h, const float* s, const float* u_prev) {
     ProfSlot ps(h);
     HIP_TRY(h, ctk_launch_rpgd_descent(h->stream, c.predictor, a, h->k, c.learning_rate, c.adam_beta_1, c.adam_beta_2,
                                        c.adam_epsilon, c.gradmax_clip, h->d_pop[h->rcur], h->d_m[h->rcur], h->d_v[h->rcur], h->d_bc,
-                                       h->bc_len, h->adam_step, iters, h->d_wperm, h->d_scratch, ps.a, ps.b));
+                                       h->bc_len, h->adam_step, iters, h->d_wperm, h->d_scratch, ps.a, ps.b,
+                                       h->variant == CTK_OPT_GRADIENT ? 1 : 0));
     h->adam_step += iters;
     return CTK_OK;
 }
@@ -415,6 +438,19 @@ int rpgd_step(ctk_handle* h, const float* s, const float* u_prev, const float* s
     const ctk_config& c = h->cfg;
     if (c.opt_keep_k > h->N) return fail(h, CTK_ERR_INVALID_ARGUMENT, "RPGD: opt_keep_k exceeds this handle's rollouts (a shard? use ctk_rpgd_step_begin/end)");
     const int cur = h->rcur, nxt = cur ^ 1;
+    if (h->variant == CTK_OPT_GRADIENT) {
+        // optimizer_gradient_tf.py:101-173: Keras-Adam descent on all N plans, u = best plan's first input,
+        // every plan shifted by one with a FRESH uniform tail input (:137-144), moments shifted by one (:147-166)
+        const float* d_tail = nullptr;
+        if (int rc = resolve_samples(h, samples, loc, (size_t)h->N, &d_tail)) return rc;
+        if (int rc = rpgd_descent(h, s, u_prev)) return rc;
+        HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, 1, h->d_idx));
+        RolloutArgs ag = make_args(h, s, u_prev, h->N, h->P);
+        if (int rc = rpgd_warm(h, ag, 0, 0, 0, d_tail, cur, nxt, nullptr, nullptr, 0, 1)) return rc;
+        h->rcur = nxt;
+        ++h->count;
+        return finish_step(h, u_out);
+    }
     const bool resample = (h->count % c.resamp_per) == 0;                      // :449
     const float* d_draws = nullptr;
     if (resample)
@@ -456,8 +492,24 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     if (cfg->period_interpolation_inducing_points < 1 || cfg->intermediate_steps < 1)
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: period_interpolation_inducing_points and intermediate_steps must be >= 1");
     if (!(cfg->dt > 0.0f)) return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: dt must be > 0");
-    if (cfg->optimizer < CTK_OPT_MPPI || cfg->optimizer > CTK_OPT_RANDOM_ACTION)
+    if (cfg->optimizer < CTK_OPT_MPPI || cfg->optimizer > CTK_OPT_CEM_NAIVE_GRAD)
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: unknown optimizer");
+    // variants run on an engine family: gradient = RPGD machinery without resampling (Keras Adam, fresh tail);
+    // cem-naive-grad = CEM machinery with one SGD step on the samples
+    ctk_config mapped = *cfg;
+    if (cfg->optimizer == CTK_OPT_GRADIENT) {
+        mapped.optimizer = CTK_OPT_RPGD;
+        mapped.period_interpolation_inducing_points = 1;   // plans are sampled per step, no inducing points (:176-181)
+        mapped.sampling_distribution = 0; mapped.sample_min = cfg->action_low; mapped.sample_max = cfg->action_high;
+        mapped.shift_previous = 1; mapped.opt_keep_k = 1; mapped.resamp_per = 0x7FFFFFFF;
+    } else if (cfg->optimizer == CTK_OPT_CEM_NAIVE_GRAD) {
+        mapped.optimizer = CTK_OPT_CEM;
+        mapped.warmup = 0;                                  // the reference has no warm-up for this optimizer (:96)
+        if (cfg->intermediate_steps != 1)
+            return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: the gradient kernels are built for intermediate_steps == 1");
+    }
+    const int variant = cfg->optimizer;
+    cfg = &mapped;
     if (cfg->predictor != CTK_PRED_ODE && cfg->predictor != CTK_PRED_MLP)
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: unknown predictor");
     if (cfg->optimizer == CTK_OPT_CEM && (cfg->cem_best_k < 1 || cfg->cem_best_k > cfg->num_rollouts || cfg->cem_outer_it < 1))
@@ -484,6 +536,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
 
     ctk_handle* h = new ctk_handle();
     h->cfg = *cfg;
+    h->variant = variant;
     h->N = cfg->num_rollouts; h->H = cfg->mpc_horizon;
     const bool interp = (cfg->optimizer == CTK_OPT_MPPI || cfg->optimizer == CTK_OPT_RPGD);
     h->P = interp ? num_inducing_points(h->H, cfg->period_interpolation_inducing_points) : h->H;
@@ -502,7 +555,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     // LDS budget of the rollout tiles (one wave per block): 64 * stride * 4 B <= 160 KiB
     {
         const size_t lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_lds((int)P, (int)H)
-                         : cfg->optimizer == CTK_OPT_RPGD ? ctk_rpgd_descent_lds(cfg->predictor, (int)H, nullptr)
+                         : (cfg->optimizer == CTK_OPT_RPGD || variant == CTK_OPT_CEM_NAIVE_GRAD) ? ctk_rpgd_descent_lds(cfg->predictor, (int)H, nullptr)
                                                           : ctk_affine_rollout_lds((int)H);
         if (lds > 160 * 1024) { h->err = "horizon too long for the LDS sample tiles (160 KiB per CU)"; return bail(CTK_ERR_UNSUPPORTED); }
     }
@@ -533,7 +586,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     std::memset(h->h_u, 0, 64);
     HIP_CREATE(hipHostGetDevicePointer((void**)&h->h_u_dev, h->h_u, 0));
 
-    if (cfg->optimizer == CTK_OPT_RPGD) {
+    if (cfg->optimizer == CTK_OPT_RPGD || variant == CTK_OPT_CEM_NAIVE_GRAD) {
         for (int b = 0; b < 2; ++b) {
             TRY_CREATE(dev_alloc(h, &h->d_pop[b], N * H));
             TRY_CREATE(dev_alloc(h, &h->d_m[b], N * H));
@@ -555,6 +608,8 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     }
     switch (cfg->optimizer) {
         case CTK_OPT_RPGD: h->dominant = ctk_rpgd_descent_name(cfg->predictor); break;
+        case CTK_OPT_CEM: if (variant == CTK_OPT_CEM_NAIVE_GRAD) { h->dominant = ctk_rpgd_descent_name(cfg->predictor); break; }
+            h->dominant = ctk_affine_rollout_name(cfg->predictor, cfg->materialize_trajectories != 0); break;
         case CTK_OPT_MPPI: h->dominant = ctk_mppi_rollout_name(cfg->predictor, cfg->materialize_trajectories != 0); break;
         default: h->dominant = ctk_affine_rollout_name(cfg->predictor, cfg->materialize_trajectories != 0); break;
     }
@@ -712,6 +767,7 @@ int ctk_shard_iter_begin(ctk_handle* h, const float* s, const float* u_prev, con
     if (!h || !s || !cand_dev) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_shard_iter_begin: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
     const bool cem = h->cfg.optimizer == CTK_OPT_CEM;
     if (!cem && h->cfg.optimizer != CTK_OPT_RANDOM_ACTION) return fail(h, CTK_ERR_STATE, "ctk_shard_iter_begin: CEM / random-action handles only");
+    if (h->variant != h->cfg.optimizer) return fail(h, CTK_ERR_UNSUPPORTED, "ctk_shard_iter_begin: not built for this optimizer variant");
     if (h->shard_pending) return fail(h, CTK_ERR_STATE, "ctk_shard_iter_begin: previous iteration not ended");
     if (int rc = check_predictor(h)) return rc;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -790,7 +846,7 @@ size_t ctk_rpgd_fresh_rows(const ctk_handle* h, int n_ranks) {
 
 int ctk_rpgd_step_begin(ctk_handle* h, const float* s, const float* u_prev, float* keep_dev) {
     if (!h || !s || !keep_dev) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_rpgd_step_begin: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
-    if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_STATE, "ctk_rpgd_step_begin: handle is not RPGD");
+    if (h->cfg.optimizer != CTK_OPT_RPGD || h->variant != CTK_OPT_RPGD) return fail(h, CTK_ERR_STATE, "ctk_rpgd_step_begin: handle is not RPGD");
     if (!h->rpgd_ready) return fail(h, CTK_ERR_STATE, "RPGD: call ctk_reset (optimizer_reset) before the first step");
     if (h->shard_pending) return fail(h, CTK_ERR_STATE, "ctk_rpgd_step_begin: previous sharded step not ended");
     if (int rc = check_predictor(h)) return rc;
@@ -878,7 +934,8 @@ int ctk_read(ctk_handle* h, int which, float* dst, size_t cap, size_t* n_out) {
     const size_t N = h->N, H = h->H;
     const float* src = nullptr; size_t n = 0; bool is_int = false;
     switch (which) {
-        case CTK_BUF_Q: src = h->cfg.optimizer == CTK_OPT_RPGD ? h->d_pop[h->rcur ^ 1] : h->d_Q; n = N * H; break;
+        case CTK_BUF_Q: src = h->cfg.optimizer == CTK_OPT_RPGD ? h->d_pop[h->rcur ^ 1] : (h->variant == CTK_OPT_CEM_NAIVE_GRAD ? h->d_pop[0] : h->d_Q);
+            n = N * H; break;
         case CTK_BUF_PLAN: if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: PLAN is an RPGD buffer");
             src = h->d_pop[h->rcur]; n = N * H; break;
         case CTK_BUF_ADAM_M: if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: ADAM_M is an RPGD buffer");

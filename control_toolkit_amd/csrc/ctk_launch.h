@@ -45,12 +45,15 @@ hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs
 // (optimizer_cem_tf.py:73-78): idx_out[K] ascending, mu/std [H] from Q[idx].
 hipError_t ctk_launch_select_topk(hipStream_t st, const float* J, int N, int K, int* idx_out, int ldj = 1);
 hipError_t ctk_launch_cem_refit(hipStream_t st, const float* Q, const int* idx, int K, int H, float* mu, float* sd, int ldq);
+// plans of one CEM-with-gradient iteration: Q[n,h] = clip(mu[h] + eps[n,h] * std[h]) (optimizer_cem_naive_grad_tf.py:60-62)
+hipError_t ctk_launch_sample_plans(hipStream_t st, const RolloutArgs& a, const float* samples, const float* mu, const float* sd, float* Q);
 // this shard's best-K records {J, global index, Q[H]} for the sharded selection
 hipError_t ctk_launch_pack_candidates(hipStream_t st, const float* J, const float* Q, const int* idx, int K, int H, int global_offset,
                                       float* cand);
 // CEM post-loop (optimizer_cem_tf.py:99-102) and u = elite[0,0]
 hipError_t ctk_launch_cem_finish(hipStream_t st, const float* Q, const int* idx, int H, float* mu, float* sd,
-                                 float std_min, float init_std, float mid, float* u_dev, float* u_host, uint32_t seq, int ldq);
+                                 float std_min, float init_std, float mid, float* u_dev, float* u_host, uint32_t seq, int ldq,
+                                 float std_max = 1.0e8f, int u_from_mu = 0);
 // random-action: u = Q[argmin J, 0]  (optimizer_random_action_tf.py:65-68)
 hipError_t ctk_launch_pick_best_first(hipStream_t st, const float* Q, const int* idx, int H, float* u_dev, float* u_host, uint32_t seq,
                                       int ldq);
@@ -63,13 +66,13 @@ size_t ctk_rpgd_scratch_floats(int pred, int N, int H);
 hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, float lr, float b1, float b2,
                                    float eps, float clip, float* Q, float* m, float* v, const float* bc_table, int bc_len,
                                    int t0, int iters, const float* wperm, float* scratch, hipEvent_t ev_start = nullptr,
-                                   hipEvent_t ev_stop = nullptr);
+                                   hipEvent_t ev_stop = nullptr, int rule = 0);
 hipError_t ctk_launch_rpgd_warmstart(hipStream_t st, const RolloutArgs& a, int N, int H, int P, int n_new, int gather, int shift_previous,
                                      int sampling_distribution, int reset, float lo, float hi, float sample_stdev,
                                      float sample_mean, float sample_min, float sample_max, const float* draws, const int* idx,
                                      const float* Q_old, const float* m_old, const float* v_old, const float* ages_old,
                                      float* Q_new, float* m_new, float* v_new, float* ages_new, const InterpEntry* interp,
                                      float* u_nom, float* u_dev, float* u_host, uint32_t seq, const float* recs = nullptr,
-                                     int rs = 0, int keeper_base = 0);
+                                     int rs = 0, int keeper_base = 0, int fresh_tail = 0);
 hipError_t ctk_launch_rpgd_pack_keepers(hipStream_t st, const float* J, const float* Q, const float* m, const float* v,
                                         const float* ages, const int* idx, int K, int H, int global_offset, float* out);

@@ -174,12 +174,20 @@ CTK_DEV float rpgd_backward_mlp(const RolloutArgs& a, const EnvK& k, const MlpBw
 
 struct AdamK {
     float lr, b1, b2, one_m_b1, one_m_b2, eps, clip;
+    int rule;   // 0: in-repo torch Adam (optimizer_rpgd.py:56-82); 1: Keras Adam (gradient_tf, bharadhwaj); 2: plain SGD (cem_naive_grad)
 };
 
 // Adam for one element (optimizer_rpgd.py:68-79 in fp32, scalars rounded to fp32 as torch does)
 CTK_DEV float adam_update(const AdamK& ad, float q, float g, float& m, float& v, float bc1, float bc2, float lo, float hi) {
+    if (ad.rule == 2) return fminf(fmaxf(q - ad.lr * g, lo), hi);   // optimizer_cem_naive_grad_tf.py:70-71
     m = m * ad.b1 + ad.one_m_b1 * g;
     v = v * ad.b2 + ad.one_m_b2 * (g * g);
+    if (ad.rule == 1) {
+        // tf.keras.optimizers.Adam (third party; published update rule): lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
+        // var -= lr_t * m / (sqrt(v) + eps)   — epsilon is NOT bias-corrected, unlike the torch branch
+        const float lr_t = ad.lr * sqrtf(bc2) / bc1;
+        return fminf(fmaxf(q - lr_t * m / (sqrtf(v) + ad.eps), lo), hi);
+    }
     const float m_hat = m / bc1, v_hat = v / bc2;
     const float qn = q - ad.lr * m_hat / (sqrtf(v_hat) + ad.eps);
     return fminf(fmaxf(qn, lo), hi);
@@ -227,10 +235,11 @@ __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_descent(RolloutArgs a, EnvK
             const float bc2 = ti <= bc_len ? bc_table[2 * (ti - 1) + 1] : 1.0f;
             for (int i = t; i < total; i += RP_BLOCK) {
                 const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;
-                float mm = m[gbase + i], vv = v[gbase + i];
+                float mm = 0.0f, vv = 0.0f;
+                if (ad.rule != 2) { mm = m[gbase + i]; vv = v[gbase + i]; }
                 const float g = g_s[h * RP_LD + r] * sc_s[r];
                 q_s[h * RP_LD + r] = adam_update(ad, q_s[h * RP_LD + r], g, mm, vv, bc1, bc2, a.lo, a.hi);
-                m[gbase + i] = mm; v[gbase + i] = vv;
+                if (ad.rule != 2) { m[gbase + i] = mm; v[gbase + i] = vv; }
             }
             __syncthreads();
         }
@@ -257,10 +266,11 @@ __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_descent(RolloutArgs a, EnvK
             const float bc2 = ti <= bc_len ? bc_table[2 * (ti - 1) + 1] : 1.0f;
             for (int i = t; i < total; i += RP_BLOCK) {
                 const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;
-                float mm = m[gbase + i], vv = v[gbase + i];
+                float mm = 0.0f, vv = 0.0f;
+                if (ad.rule != 2) { mm = m[gbase + i]; vv = v[gbase + i]; }
                 const float gg = g_s[h * RP_LD + r] * sc_s[r];
                 q_s[h * RP_LD + r] = adam_update(ad, q_s[h * RP_LD + r], gg, mm, vv, bc1, bc2, a.lo, a.hi);
-                m[gbase + i] = mm; v[gbase + i] = vv;
+                if (ad.rule != 2) { m[gbase + i] = mm; v[gbase + i] = vv; }
             }
             __syncthreads();
         }
@@ -289,6 +299,8 @@ struct WarmArgs {
     const float* recs;     // nullptr: single-handle step
     int rs;                // record stride (3 + 3H)
     int keeper_base;       // index (in the global sorted keeper list) of the first keeper this shard hosts
+    int fresh_tail;        // gradient_tf: the shifted-in tail input is a fresh U[lo,hi) draw per plan
+                           // (optimizer_gradient_tf.py:137-144) instead of a repeat of the last input
 };
 
 __global__ __launch_bounds__(256) void ctk_rpgd_warmstart(WarmArgs w, RolloutArgs a, const float* __restrict__ draws,
@@ -332,6 +344,17 @@ __global__ __launch_bounds__(256) void ctk_rpgd_warmstart(WarmArgs w, RolloutArg
             const int src = w.gather ? idx[i - w.n_new] : i;
             const int hs = min(h + w.shift_previous, H - 1);
             q = Q_old[(size_t)src * H + hs];
+            if (w.fresh_tail && h + w.shift_previous >= H) {
+                float d;
+                if (draws != nullptr) {
+                    d = draws[i];
+                } else {
+                    float d4[4];
+                    draw4(a, (uint32_t)(a.global_row0 + i), 0u, 1, d4);
+                    d = d4[0];
+                }
+                q = d * (w.hi - w.lo) + w.lo;
+            }
             if (h + 1 < H) { mm = m_old[(size_t)src * H + h + 1]; vv = v_old[(size_t)src * H + h + 1]; }
         }
         Q_new[gid] = q; m_new[gid] = mm; v_new[gid] = vv;
@@ -397,8 +420,8 @@ size_t ctk_rpgd_scratch_floats(int pred, int N, int H) {
 
 hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, float lr, float b1, float b2,
                                    float eps, float clip, float* Q, float* m, float* v, const float* bc_table, int bc_len,
-                                   int t0, int iters, const float* wperm, float* scratch, hipEvent_t e0, hipEvent_t e1) {
-    AdamK ad{lr, b1, b2, (float)(1.0 - (double)b1), (float)(1.0 - (double)b2), eps, clip};
+                                   int t0, int iters, const float* wperm, float* scratch, hipEvent_t e0, hipEvent_t e1, int rule) {
+    AdamK ad{lr, b1, b2, (float)(1.0 - (double)b1), (float)(1.0 - (double)b2), eps, clip, rule};
     bool tape_in_lds = false;
     const size_t lds = ctk_rpgd_descent_lds(pred, a.H, &tape_in_lds);
     const dim3 grid((a.N + RP_TRAJ - 1) / RP_TRAJ), block(RP_BLOCK);
@@ -417,9 +440,9 @@ hipError_t ctk_launch_rpgd_warmstart(hipStream_t st, const RolloutArgs& a, int N
                                      const float* Q_old, const float* m_old, const float* v_old, const float* ages_old,
                                      float* Q_new, float* m_new, float* v_new, float* ages_new, const InterpEntry* interp,
                                      float* u_nom, float* u_dev, float* u_host, uint32_t seq, const float* recs, int rs,
-                                     int keeper_base) {
+                                     int keeper_base, int fresh_tail) {
     WarmArgs w{N, H, P, n_new, gather, shift_previous, sampling_distribution, reset, lo, hi, sample_stdev, sample_mean, sample_min, sample_max,
-               recs, rs, keeper_base};
+               recs, rs, keeper_base, fresh_tail};
     const int total = N * H;
     hipLaunchKernelGGL(ctk_rpgd_warmstart, dim3((total + 255) / 256), dim3(256), 0, st, w, a, draws, idx, Q_old, m_old, v_old, ages_old,
                        Q_new, m_new, v_new, ages_new, interp, u_nom, u_dev, u_host, seq);

@@ -172,17 +172,19 @@ __global__ __launch_bounds__(256) void ctk_cem_refit(const float* __restrict__ Q
 }
 
 // optimizer_cem_tf.py:99-102: clip std, shift both by one step, refill the tail; u = elite[0,0]
+// std_max / u_from_mu: optimizer_cem_naive_grad_tf.py:101-104 clips the stdev to [min, 10] and applies the
+// MEAN's first input; optimizer_cem_tf.py:99-101 clips to [min, 1e8] and applies the best elite's
 __global__ __launch_bounds__(256) void ctk_cem_finish(const float* __restrict__ Q, int ldq, const int* __restrict__ idx, int H,
                                                       float* __restrict__ mu, float* __restrict__ sd, float std_min,
                                                       float init_std, float mid, float* __restrict__ u_dev,
-                                                      float* __restrict__ u_host, uint32_t seq) {
+                                                      float* __restrict__ u_host, uint32_t seq, float std_max, int u_from_mu) {
     extern __shared__ float lds[];
     float* m_s = lds;
     float* s_s = lds + H;
     const int t = threadIdx.x;
     for (int h = t; h < H; h += 256) {
         m_s[h] = mu[h];
-        s_s[h] = fminf(fmaxf(sd[h], std_min), 1.0e8f);
+        s_s[h] = fminf(fmaxf(sd[h], std_min), std_max);
     }
     __syncthreads();
     for (int h = t; h < H; h += 256) {
@@ -190,12 +192,37 @@ __global__ __launch_bounds__(256) void ctk_cem_finish(const float* __restrict__ 
         sd[h] = (h + 1 < H) ? s_s[h + 1] : init_std;
     }
     __syncthreads();
-    if (t == 0) publish_u(u_dev, u_host, Q[(size_t)idx[0] * ldq], seq);
+    if (t == 0) publish_u(u_dev, u_host, u_from_mu ? m_s[0] : Q[(size_t)idx[0] * ldq], seq);
 }
 
 __global__ void ctk_pick_best_first(const float* __restrict__ Q, int ldq, const int* __restrict__ idx, int H,
                                     float* __restrict__ u_dev, float* __restrict__ u_host, uint32_t seq) {
     if (threadIdx.x == 0 && blockIdx.x == 0) publish_u(u_dev, u_host, Q[(size_t)idx[0] * ldq], seq);
+}
+
+// plans of a CEM-with-gradient iteration, without rolling them out (the descent kernel does that)
+__global__ __launch_bounds__(256) void ctk_sample_plans(RolloutArgs a, const float* __restrict__ samples,
+                                                        const float* __restrict__ mu, const float* __restrict__ sd,
+                                                        float* __restrict__ Q) {
+    const int H = a.H;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= a.N * H) return;
+    const int n = H >= 2 ? (int)__umulhi((uint32_t)gid, a.p_magic) : gid, h = gid - n * H;
+    float e;
+    if (samples != nullptr) {
+        e = samples[gid];
+    } else {
+        float d4[4];
+        draw4(a, (uint32_t)(a.global_row0 + n), (uint32_t)(h >> 2), 0, d4);
+        e = d4[h & 3];
+    }
+    Q[gid] = fminf(fmaxf(mu[h] + e * sd[h], a.lo), a.hi);
+}
+
+hipError_t ctk_launch_sample_plans(hipStream_t st, const RolloutArgs& a, const float* samples, const float* mu, const float* sd, float* Q) {
+    const int total = a.N * a.H;
+    hipLaunchKernelGGL(ctk_sample_plans, dim3((total + 255) / 256), dim3(256), 0, st, a, samples, mu, sd, Q);
+    return hipGetLastError();
 }
 
 // sharded selection: this shard's best K plans as records {J, global index (int bits), Q[H]},
@@ -258,9 +285,10 @@ hipError_t ctk_launch_pack_candidates(hipStream_t st, const float* J, const floa
 }
 
 hipError_t ctk_launch_cem_finish(hipStream_t st, const float* Q, const int* idx, int H, float* mu, float* sd, float std_min,
-                                 float init_std, float mid, float* u_dev, float* u_host, uint32_t seq, int ldq) {
+                                 float init_std, float mid, float* u_dev, float* u_host, uint32_t seq, int ldq, float std_max,
+                                 int u_from_mu) {
     hipLaunchKernelGGL(ctk_cem_finish, dim3(1), dim3(256), 2 * H * sizeof(float), st, Q, ldq, idx, H, mu, sd, std_min, init_std, mid,
-                       u_dev, u_host, seq);
+                       u_dev, u_host, seq, std_max, u_from_mu);
     return hipGetLastError();
 }
 

@@ -44,7 +44,12 @@ typedef enum ctk_optimizer {
     CTK_OPT_MPPI = 0,          /* Optimizers/optimizer_mppi.py              */
     CTK_OPT_CEM = 1,           /* Optimizers/optimizer_cem_tf.py            */
     CTK_OPT_RPGD = 2,          /* Optimizers/optimizer_rpgd.py              */
-    CTK_OPT_RANDOM_ACTION = 3  /* Optimizers/optimizer_random_action_tf.py  */
+    CTK_OPT_RANDOM_ACTION = 3, /* Optimizers/optimizer_random_action_tf.py  */
+    /* thin variants over the same kernels */
+    CTK_OPT_GRADIENT = 4,      /* Optimizers/optimizer_gradient_tf.py: Keras-Adam descent on N plans, no resampling;
+                                  uses outer_its (= gradient_steps), learning_rate, adam_*, gradmax_clip, warmup*   */
+    CTK_OPT_CEM_NAIVE_GRAD = 5 /* Optimizers/optimizer_cem_naive_grad_tf.py: CEM whose samples take one clipped-gradient
+                                  SGD step before selection; uses cem_*, learning_rate, gradmax_clip               */
 } ctk_optimizer;
 
 /* reference: predictor_specification passed to PredictorWrapper.configure
@@ -157,6 +162,8 @@ int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n);
  *   RPGD   optimizer_rpgd.py:388-524                samples: raw draws [N-k,P,C], used only on
  *                                                   resampling steps (count % resamp_per == 0)
  *   random optimizer_random_action_tf.py:49-76      samples: U[0,1)   [N,H,C]
+ *   gradient optimizer_gradient_tf.py:101-173       samples: U[0,1)   [N,1,C] (the shifted-in tail input, :137-142)
+ *   cem-naive-grad optimizer_cem_naive_grad_tf.py:89-115  samples: N(0,1) [cem_outer_it,N,H,C]
  * s: host [S].  u_prev: host [C] previous applied input (cost `previous_input`); NULL = the
  * optimizer's own last output, as the reference passes self.u.  u_out: host [C].
  * Synchronous: returns when u_out is valid.

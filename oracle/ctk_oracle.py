@@ -729,3 +729,113 @@ def device_noise(seed: int, stream: int, call: int, first_row: int, rows: int, c
         ta, tb = f32(2.0 * math.pi) * u2a, f32(2.0 * math.pi) * u2b
         out = np.stack([ra * np.cos(ta), ra * np.sin(ta), rb * np.cos(tb), rb * np.sin(tb)], axis=-1).astype(np.float32)
     return out.reshape(rows, nblk * 4)[:, :cols].astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+# thin variants.  Restated from the source text (both modules import tensorflow at
+# module level and cannot be executed here): parity unpinned by any reference execution.
+# ----------------------------------------------------------------------------------------------
+class KerasAdam:
+    """tf.keras.optimizers.Adam (third party; published update rule, non-amsgrad):
+    lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; var -= lr_t*m/(sqrt(v)+eps)."""
+    def __init__(self, lr, b1, b2, eps):
+        self.lr, self.b1, self.b2, self.eps = lr, b1, b2, eps
+        self.reset()
+
+    def reset(self):
+        self.step_count, self.m, self.v = 0, None, None
+
+    def apply(self, g, var):
+        self.step_count += 1
+        if self.m is None:
+            self.m, self.v = np.zeros_like(g), np.zeros_like(g)
+        self.m = (self.m * f32(self.b1) + f32(1 - self.b1) * g).astype(np.float32)
+        self.v = (self.v * f32(self.b2) + f32(1 - self.b2) * (g * g)).astype(np.float32)
+        lr_t = f32(self.lr) * np.sqrt(f32(1 - self.b2 ** self.step_count)) / f32(1 - self.b1 ** self.step_count)
+        return (var - f32(lr_t) * self.m / (np.sqrt(self.v) + f32(self.eps))).astype(np.float32)
+
+
+class GradientTF:
+    """Optimizers/optimizer_gradient_tf.py: Adam descent on N plans, no resampling."""
+    def __init__(self, predictor, cost, low=-1.0, high=1.0, *, num_rollouts, mpc_horizon, gradient_steps=5,
+                 learning_rate=0.05, adam_beta_1=0.9, adam_beta_2=0.999, adam_epsilon=1e-7, gradmax_clip=5.0,
+                 warmup=False, warmup_iterations=250):
+        self.predictor, self.cost = predictor, cost
+        self.N, self.H = num_rollouts, mpc_horizon
+        self.low, self.high = f32(low), f32(high)
+        self.gradient_steps = gradient_steps
+        self.first_iter_count = warmup_iterations if warmup else gradient_steps     # :66-69
+        self.gradmax_clip = f32(gradmax_clip)
+        self.opt = KerasAdam(learning_rate, adam_beta_1, adam_beta_2, adam_epsilon)
+        self.u = f32(0.0)
+
+    def optimizer_reset(self, u01):
+        # :174-185: uniform plans over the whole horizon, Adam weights zeroed
+        self.Q = np.clip(np.asarray(u01, np.float32) * (self.high - self.low) + self.low, self.low, self.high).astype(np.float32)
+        assert self.Q.shape == (self.N, self.H, 1)
+        self.count = 0
+        self.opt.reset()
+
+    def step(self, s, tail_u01):
+        """tail_u01 [N,1,1]: the U[0,1) draws behind rng.uniform([N,1,C], low, high) at :137-142."""
+        s_t = np.tile(np.asarray(s, np.float32).reshape(1, 4), (self.N, 1))
+        iters = self.first_iter_count if self.count == 0 else self.gradient_steps          # :108-112
+        for _ in range(iters):                                                             # :116-118, :82-98
+            _, _, g = rollout_cost_and_grad(self.predictor, self.cost, s_t, self.Q, np.array([self.u], np.float32))
+            g = clip_by_norm(g, self.gradmax_clip)
+            self.Q = np.clip(self.opt.apply(g, self.Q), self.low, self.high).astype(np.float32)
+        traj = self.predictor.predict_core(s_t, self.Q)                                    # :127
+        J = self.cost.get_trajectory_cost(traj, self.Q, np.array([self.u], np.float32))
+        best = argsort_total_order(J)[0]                                                   # :130-131
+        self.u = f32(self.Q[best, 0, 0])                                                   # :133
+        self.J, self.Q_refined, self.best_idx = J, self.Q.copy(), best
+        self.count += 1
+        Q_s = (np.asarray(tail_u01, np.float32).reshape(self.N, 1, 1) * (self.high - self.low) + self.low).astype(np.float32)
+        self.Q = np.concatenate([self.Q[:, 1:, :], Q_s], axis=1)                            # :143-144
+        if self.opt.m is not None:                                                         # :146-166
+            z = np.zeros((self.N, 1, 1), np.float32)
+            self.opt.m = np.concatenate([self.opt.m[:, 1:, :], z], 1)
+            self.opt.v = np.concatenate([self.opt.v[:, 1:, :], z], 1)
+        return np.array(self.u, np.float32)
+
+
+class CEMNaiveGrad:
+    """Optimizers/optimizer_cem_naive_grad_tf.py: CEM whose samples take one clipped-gradient SGD step."""
+    def __init__(self, predictor, cost, low=-1.0, high=1.0, *, num_rollouts, mpc_horizon, cem_outer_it=1,
+                 cem_initial_action_stdev=0.5, cem_stdev_min=0.1, cem_best_k=40, learning_rate=0.1, gradmax_clip=10.0):
+        self.predictor, self.cost = predictor, cost
+        self.N, self.H = num_rollouts, mpc_horizon
+        self.low, self.high = f32(low), f32(high)
+        self.cem_outer_it, self.K = cem_outer_it, cem_best_k
+        self.init_std, self.std_min = f32(cem_initial_action_stdev), f32(cem_stdev_min)
+        self.lr, self.gradmax_clip = f32(learning_rate), f32(gradmax_clip)
+        self.u = f32(0.0)
+        self.optimizer_reset()
+
+    def optimizer_reset(self):
+        # :117-119
+        self.dist_mue = ((self.low + self.high) * f32(0.5) * np.ones((1, self.H, 1), np.float32)).astype(np.float32)
+        self.stdev = (self.init_std * np.ones((1, self.H, 1), np.float32)).astype(np.float32)
+
+    def step(self, s, noise):
+        """noise: standard normal [cem_outer_it, N, H, 1] (rng.normal at :60-61, one draw per outer iteration)."""
+        s_t = np.tile(np.asarray(s, np.float32).reshape(1, 4), (self.N, 1))
+        up = np.array([self.u], np.float32)
+        for it in range(self.cem_outer_it):                                                # :96-97
+            Q = np.clip(np.tile(self.dist_mue, (self.N, 1, 1)) + np.asarray(noise[it], np.float32) * self.stdev,
+                        self.low, self.high).astype(np.float32)                           # :60-62
+            _, _, g = rollout_cost_and_grad(self.predictor, self.cost, s_t, Q, up)         # :64-68
+            Qn = np.clip(Q - self.lr * clip_by_norm(g, self.gradmax_clip), self.low, self.high).astype(np.float32)   # :70-72
+            traj = self.predictor.predict_core(s_t, Qn)                                    # :74-75
+            J = self.cost.get_trajectory_cost(traj, Qn, up)
+            best = argsort_total_order(J)[: self.K]                                        # :78-80
+            elite = Qn[best]
+            self.dist_mue = np.mean(elite, axis=0, keepdims=True, dtype=np.float32)        # :82-83
+            self.stdev = np.sqrt(np.mean((elite - self.dist_mue) ** 2, axis=0, keepdims=True, dtype=np.float32)).astype(np.float32)
+        self.stdev = np.clip(self.stdev, self.std_min, f32(10.0))                          # :101
+        self.stdev = np.concatenate([self.stdev[:, 1:, :], self.init_std * np.ones((1, 1, 1), np.float32)], 1)   # :102
+        self.u = f32(self.dist_mue[0, 0, 0])                                               # :103 — the MEAN's first input
+        self.dist_mue = np.concatenate(
+            [self.dist_mue[:, 1:, :], (self.low + self.high) * f32(0.5) * np.ones((1, 1, 1), np.float32)], 1)   # :104
+        self.Q, self.J, self.best_idx = Qn, J, best
+        return np.array(self.u, np.float32)
