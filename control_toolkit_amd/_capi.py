@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libctk_hip.so"
 _lib = None
 
-OPTIMIZERS = {"mppi": 0, "cem": 1, "rpgd": 2, "random_action": 3, "gradient": 4, "cem_naive_grad": 5}
+OPTIMIZERS = {"mppi": 0, "cem": 1, "rpgd": 2, "random_action": 3, "gradient": 4, "cem_naive_grad": 5,
+              "cem_grad_bharadhwaj": 6}
 PREDICTORS = {"ODE": 0, "MLP": 1}
 PARAMS = ("g", "m_cart", "m_pole", "L", "u_max", "M_fric", "J_fric", "target_position", "target_equilibrium",
           "dd_weight", "ep_weight", "ekp_weight", "cc_weight", "ccrc_weight", "R", "x_scale", "terminal_weight")

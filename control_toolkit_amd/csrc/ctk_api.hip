@@ -200,7 +200,10 @@ size_t samples_needed(const ctk_handle* h) {
     const size_t N = h->N, H = h->H, P = h->P;
     switch (h->cfg.optimizer) {
         case CTK_OPT_MPPI: return N * P;
-        case CTK_OPT_CEM: return (size_t)cem_iterations(h) * N * H;
+        case CTK_OPT_CEM:
+            if (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ)   // initial elites + (N-K) fresh samples per iteration
+                return (size_t)h->cfg.cem_best_k * H + (size_t)cem_iterations(h) * (N - (size_t)h->cfg.cem_best_k) * H;
+            return (size_t)cem_iterations(h) * N * H;
         case CTK_OPT_RANDOM_ACTION: return N * H;
         case CTK_OPT_RPGD:
             if (h->variant == CTK_OPT_GRADIENT) return N;   // the shifted-in tail input of every plan
@@ -331,9 +334,47 @@ int mppi_update(ctk_handle* h, const float* parts, int n_parts, float* u_out) {
     return finish_step(h, u_out);
 }
 
+// ---- cem-grad-bharadhwaj (variant of the CEM family) ---------------------------------------------
+// optimizer_cem_grad_bharadhwaj_tf.py:151-178.  Per outer iteration (:93-120): population = [elites | fresh
+// samples], ONE Keras-Adam step on all of it (the optimizer's moments persist by POSITION across iterations
+// and MPC steps and are never shifted or reset, exactly like the tf.Variable / Keras pair of the reference),
+// cost pass, best K -> next iteration's elites, refit.
+int cem_bharadhwaj_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc, float* u_out) {
+    const ctk_config& c = h->cfg;
+    const int its = cem_iterations(h), K = c.cem_best_k;
+    const size_t H = h->H, n_el = (size_t)K * H, n_rest = (size_t)(h->N - K) * H;
+    const float* d_s = nullptr;
+    if (int rc = resolve_samples(h, samples, loc, n_el + its * n_rest, &d_s)) return rc;
+    float* mu = h->d_unom[0];
+    int cur = h->rcur;
+    for (int it = 0; it < its; ++it) {
+        RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);
+        a.stream_id = (uint32_t)it;
+        HIP_TRY(h, ctk_launch_cem_build_population(h->stream, a, K, it == 0 ? 1 : 0, h->d_pop[cur ^ 1], h->d_idx, d_s,
+                                                   d_s ? d_s + n_el + it * n_rest : nullptr, mu, h->d_std, h->d_pop[cur]));
+        {
+            ProfSlot ps(h);
+            HIP_TRY(h, ctk_launch_rpgd_descent(h->stream, c.predictor, a, h->k, c.learning_rate, c.adam_beta_1, c.adam_beta_2,
+                                               c.adam_epsilon, c.gradmax_clip, h->d_pop[cur], h->d_m[0], h->d_v[0], h->d_bc, h->bc_len,
+                                               h->adam_step, 1, h->d_wperm, h->d_scratch, ps.a, ps.b, 1));
+        }
+        ++h->adam_step;
+        HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, K, h->d_idx));
+        HIP_TRY(h, ctk_launch_cem_refit(h->stream, h->d_pop[cur], h->d_idx, K, h->H, mu, h->d_std, h->H));
+        if (it + 1 < its) cur ^= 1;   // the refined population becomes Q_prev of the next build
+    }
+    h->rcur = cur;
+    const float mid = (c.action_low + c.action_high) * 0.5f;
+    HIP_TRY(h, ctk_launch_cem_finish(h->stream, h->d_pop[cur], h->d_idx, h->H, mu, h->d_std, c.cem_stdev_min,
+                                     c.cem_initial_action_stdev, mid, h->d_u, h->h_u_dev, h->seq, h->H, 10.0f, 0));   // :167-168,:130-141
+    ++h->count;
+    return finish_step(h, u_out);
+}
+
 // ---- CEM --------------------------------------------------------------------------------------
 int cem_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc, float* u_out) {
     if (int rc = check_predictor(h)) return rc;
+    if (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) return cem_bharadhwaj_step(h, s, u_prev, samples, loc, u_out);
     const int its = cem_iterations(h);
     const size_t per_it = (size_t)h->N * h->H;
     const float* d_s = nullptr;
@@ -492,7 +533,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     if (cfg->period_interpolation_inducing_points < 1 || cfg->intermediate_steps < 1)
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: period_interpolation_inducing_points and intermediate_steps must be >= 1");
     if (!(cfg->dt > 0.0f)) return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: dt must be > 0");
-    if (cfg->optimizer < CTK_OPT_MPPI || cfg->optimizer > CTK_OPT_CEM_NAIVE_GRAD)
+    if (cfg->optimizer < CTK_OPT_MPPI || cfg->optimizer > CTK_OPT_CEM_GRAD_BHARADHWAJ)
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: unknown optimizer");
     // variants run on an engine family: gradient = RPGD machinery without resampling (Keras Adam, fresh tail);
     // cem-naive-grad = CEM machinery with one SGD step on the samples
@@ -502,9 +543,9 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
         mapped.period_interpolation_inducing_points = 1;   // plans are sampled per step, no inducing points (:176-181)
         mapped.sampling_distribution = 0; mapped.sample_min = cfg->action_low; mapped.sample_max = cfg->action_high;
         mapped.shift_previous = 1; mapped.opt_keep_k = 1; mapped.resamp_per = 0x7FFFFFFF;
-    } else if (cfg->optimizer == CTK_OPT_CEM_NAIVE_GRAD) {
+    } else if (cfg->optimizer == CTK_OPT_CEM_NAIVE_GRAD || cfg->optimizer == CTK_OPT_CEM_GRAD_BHARADHWAJ) {
         mapped.optimizer = CTK_OPT_CEM;
-        mapped.warmup = 0;                                  // the reference has no warm-up for this optimizer (:96)
+        if (cfg->optimizer == CTK_OPT_CEM_NAIVE_GRAD) mapped.warmup = 0;   // the reference has no warm-up for this optimizer (:96)
         if (cfg->intermediate_steps != 1)
             return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: the gradient kernels are built for intermediate_steps == 1");
     }
@@ -555,7 +596,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     // LDS budget of the rollout tiles (one wave per block): 64 * stride * 4 B <= 160 KiB
     {
         const size_t lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_lds((int)P, (int)H)
-                         : (cfg->optimizer == CTK_OPT_RPGD || variant == CTK_OPT_CEM_NAIVE_GRAD) ? ctk_rpgd_descent_lds(cfg->predictor, (int)H, nullptr)
+                         : (cfg->optimizer == CTK_OPT_RPGD || variant == CTK_OPT_CEM_NAIVE_GRAD || variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) ? ctk_rpgd_descent_lds(cfg->predictor, (int)H, nullptr)
                                                           : ctk_affine_rollout_lds((int)H);
         if (lds > 160 * 1024) { h->err = "horizon too long for the LDS sample tiles (160 KiB per CU)"; return bail(CTK_ERR_UNSUPPORTED); }
     }
@@ -586,7 +627,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     std::memset(h->h_u, 0, 64);
     HIP_CREATE(hipHostGetDevicePointer((void**)&h->h_u_dev, h->h_u, 0));
 
-    if (cfg->optimizer == CTK_OPT_RPGD || variant == CTK_OPT_CEM_NAIVE_GRAD) {
+    if (cfg->optimizer == CTK_OPT_RPGD || variant == CTK_OPT_CEM_NAIVE_GRAD || variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) {
         for (int b = 0; b < 2; ++b) {
             TRY_CREATE(dev_alloc(h, &h->d_pop[b], N * H));
             TRY_CREATE(dev_alloc(h, &h->d_m[b], N * H));
@@ -608,7 +649,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     }
     switch (cfg->optimizer) {
         case CTK_OPT_RPGD: h->dominant = ctk_rpgd_descent_name(cfg->predictor); break;
-        case CTK_OPT_CEM: if (variant == CTK_OPT_CEM_NAIVE_GRAD) { h->dominant = ctk_rpgd_descent_name(cfg->predictor); break; }
+        case CTK_OPT_CEM: if (variant == CTK_OPT_CEM_NAIVE_GRAD || variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) { h->dominant = ctk_rpgd_descent_name(cfg->predictor); break; }
             h->dominant = ctk_affine_rollout_name(cfg->predictor, cfg->materialize_trajectories != 0); break;
         case CTK_OPT_MPPI: h->dominant = ctk_mppi_rollout_name(cfg->predictor, cfg->materialize_trajectories != 0); break;
         default: h->dominant = ctk_affine_rollout_name(cfg->predictor, cfg->materialize_trajectories != 0); break;
@@ -934,13 +975,17 @@ int ctk_read(ctk_handle* h, int which, float* dst, size_t cap, size_t* n_out) {
     const size_t N = h->N, H = h->H;
     const float* src = nullptr; size_t n = 0; bool is_int = false;
     switch (which) {
-        case CTK_BUF_Q: src = h->cfg.optimizer == CTK_OPT_RPGD ? h->d_pop[h->rcur ^ 1] : (h->variant == CTK_OPT_CEM_NAIVE_GRAD ? h->d_pop[0] : h->d_Q);
+        case CTK_BUF_Q: src = h->cfg.optimizer == CTK_OPT_RPGD ? h->d_pop[h->rcur ^ 1] : (h->variant == CTK_OPT_CEM_NAIVE_GRAD ? h->d_pop[0] : (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ ? h->d_pop[h->rcur] : h->d_Q));
             n = N * H; break;
         case CTK_BUF_PLAN: if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: PLAN is an RPGD buffer");
             src = h->d_pop[h->rcur]; n = N * H; break;
-        case CTK_BUF_ADAM_M: if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: ADAM_M is an RPGD buffer");
+        case CTK_BUF_ADAM_M:
+            if (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) { src = h->d_m[0]; n = N * H; break; }
+            if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: ADAM_M is an RPGD buffer");
             src = h->d_m[h->rcur]; n = N * H; break;
-        case CTK_BUF_ADAM_V: if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: ADAM_V is an RPGD buffer");
+        case CTK_BUF_ADAM_V:
+            if (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) { src = h->d_v[0]; n = N * H; break; }
+            if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: ADAM_V is an RPGD buffer");
             src = h->d_v[h->rcur]; n = N * H; break;
         case CTK_BUF_AGES: if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: AGES is an RPGD buffer");
             src = h->d_ages[h->rcur]; n = N; break;
@@ -969,7 +1014,7 @@ size_t ctk_state_size(const ctk_handle* h) {
     const size_t H = h->H;
     switch (h->cfg.optimizer) {
         case CTK_OPT_MPPI: return H + 1;
-        case CTK_OPT_CEM: return 2 * H + 2;
+        case CTK_OPT_CEM: return 2 * H + 2 + (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ ? 2 * (size_t)h->N * H + 1 : 0);
         case CTK_OPT_RANDOM_ACTION: return 1;
         case CTK_OPT_RPGD: return 3 * (size_t)h->N * H + (size_t)h->N + 3;
     }
@@ -989,7 +1034,12 @@ int ctk_get_state(ctk_handle* h, float* dst, size_t cap) {
     switch (h->cfg.optimizer) {
         case CTK_OPT_MPPI: HIP_TRY(h, pull(h->d_unom[h->cur], H)); HIP_TRY(h, pull(h->d_u, 1)); break;
         case CTK_OPT_CEM: HIP_TRY(h, pull(h->d_unom[0], H)); HIP_TRY(h, pull(h->d_std, H)); HIP_TRY(h, pull(h->d_u, 1));
-            HIP_TRY(h, hipStreamSynchronize(h->stream)); dst[o++] = (float)h->count; break;
+            HIP_TRY(h, hipStreamSynchronize(h->stream)); dst[o++] = (float)h->count;
+            if (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) {   // the Keras optimizer's persistent moments and step count
+                HIP_TRY(h, pull(h->d_m[0], (size_t)h->N * H)); HIP_TRY(h, pull(h->d_v[0], (size_t)h->N * H));
+                HIP_TRY(h, hipStreamSynchronize(h->stream)); dst[o++] = (float)h->adam_step;
+            }
+            break;
         case CTK_OPT_RANDOM_ACTION: HIP_TRY(h, pull(h->d_u, 1)); break;
         case CTK_OPT_RPGD: {
             const size_t NH = (size_t)h->N * H;
@@ -1018,7 +1068,12 @@ int ctk_set_state(ctk_handle* h, const float* src, size_t n) {
     switch (h->cfg.optimizer) {
         case CTK_OPT_MPPI: HIP_TRY(h, push(h->d_unom[h->cur], H)); HIP_TRY(h, push(h->d_u, 1)); break;
         case CTK_OPT_CEM: HIP_TRY(h, push(h->d_unom[0], H)); HIP_TRY(h, push(h->d_std, H)); HIP_TRY(h, push(h->d_u, 1));
-            h->count = (int)src[o++]; break;
+            h->count = (int)src[o++];
+            if (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) {
+                HIP_TRY(h, push(h->d_m[0], (size_t)h->N * H)); HIP_TRY(h, push(h->d_v[0], (size_t)h->N * H));
+                h->adam_step = (int)src[o++];
+            }
+            break;
         case CTK_OPT_RANDOM_ACTION: HIP_TRY(h, push(h->d_u, 1)); break;
         case CTK_OPT_RPGD: {
             const size_t NH = (size_t)h->N * H;

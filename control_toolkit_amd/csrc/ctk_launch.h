@@ -47,6 +47,8 @@ hipError_t ctk_launch_select_topk(hipStream_t st, const float* J, int N, int K, 
 hipError_t ctk_launch_cem_refit(hipStream_t st, const float* Q, const int* idx, int K, int H, float* mu, float* sd, int ldq);
 // plans of one CEM-with-gradient iteration: Q[n,h] = clip(mu[h] + eps[n,h] * std[h]) (optimizer_cem_naive_grad_tf.py:60-62)
 hipError_t ctk_launch_sample_plans(hipStream_t st, const RolloutArgs& a, const float* samples, const float* mu, const float* sd, float* Q);
+hipError_t ctk_launch_cem_build_population(hipStream_t st, const RolloutArgs& a, int K, int first, const float* Q_prev, const int* idx,
+                                           const float* eps_elite, const float* eps_rest, const float* mu, const float* sd, float* Q);
 // this shard's best-K records {J, global index, Q[H]} for the sharded selection
 hipError_t ctk_launch_pack_candidates(hipStream_t st, const float* J, const float* Q, const int* idx, int K, int H, int global_offset,
                                       float* cand);

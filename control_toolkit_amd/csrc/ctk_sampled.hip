@@ -225,6 +225,43 @@ hipError_t ctk_launch_sample_plans(hipStream_t st, const RolloutArgs& a, const f
     return hipGetLastError();
 }
 
+// population of one cem-grad-bharadhwaj iteration (optimizer_cem_grad_bharadhwaj_tf.py:94-97):
+// rows [0,K) = the elites (first iteration: fresh samples, :158; afterwards the previous iteration's best K of
+// the refined population, :118-119), rows [K,N) = fresh samples mu + std*eps; everything clipped.
+__global__ __launch_bounds__(256) void ctk_cem_build_population(RolloutArgs a, int K, int first, const float* __restrict__ Q_prev,
+                                                                const int* __restrict__ idx, const float* __restrict__ eps_elite,
+                                                                const float* __restrict__ eps_rest, const float* __restrict__ mu,
+                                                                const float* __restrict__ sd, float* __restrict__ Q) {
+    const int H = a.H;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= a.N * H) return;
+    const int n = H >= 2 ? (int)__umulhi((uint32_t)gid, a.p_magic) : gid, h = gid - n * H;
+    float q;
+    if (n < K && !first) {
+        q = Q_prev[(size_t)idx[n] * H + h];
+    } else {
+        const float* src = n < K ? eps_elite : eps_rest;
+        float e;
+        if (src != nullptr) {
+            e = src[(size_t)(n < K ? n : n - K) * H + h];
+        } else {   // Philox: stream_id separates the iterations, elites of the first iteration use the same row space
+            float d4[4];
+            draw4(a, (uint32_t)(a.global_row0 + n), (uint32_t)(h >> 2), 0, d4);
+            e = d4[h & 3];
+        }
+        q = mu[h] + sd[h] * e;                                   // :122-128
+    }
+    Q[gid] = fminf(fmaxf(q, a.lo), a.hi);                        // :96
+}
+
+hipError_t ctk_launch_cem_build_population(hipStream_t st, const RolloutArgs& a, int K, int first, const float* Q_prev, const int* idx,
+                                           const float* eps_elite, const float* eps_rest, const float* mu, const float* sd, float* Q) {
+    const int total = a.N * a.H;
+    hipLaunchKernelGGL(ctk_cem_build_population, dim3((total + 255) / 256), dim3(256), 0, st, a, K, first, Q_prev, idx, eps_elite, eps_rest,
+                       mu, sd, Q);
+    return hipGetLastError();
+}
+
 // sharded selection: this shard's best K plans as records {J, global index (int bits), Q[H]},
 // sorted ascending by (J, index) — what is all-gathered; the global top-K is the top-K of their union.
 __global__ __launch_bounds__(256) void ctk_pack_candidates(const float* __restrict__ J, const float* __restrict__ Q,

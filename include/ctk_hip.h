@@ -48,8 +48,11 @@ typedef enum ctk_optimizer {
     /* thin variants over the same kernels */
     CTK_OPT_GRADIENT = 4,      /* Optimizers/optimizer_gradient_tf.py: Keras-Adam descent on N plans, no resampling;
                                   uses outer_its (= gradient_steps), learning_rate, adam_*, gradmax_clip, warmup*   */
-    CTK_OPT_CEM_NAIVE_GRAD = 5 /* Optimizers/optimizer_cem_naive_grad_tf.py: CEM whose samples take one clipped-gradient
+    CTK_OPT_CEM_NAIVE_GRAD = 5,/* Optimizers/optimizer_cem_naive_grad_tf.py: CEM whose samples take one clipped-gradient
                                   SGD step before selection; uses cem_*, learning_rate, gradmax_clip               */
+    CTK_OPT_CEM_GRAD_BHARADHWAJ = 6 /* Optimizers/optimizer_cem_grad_bharadhwaj_tf.py: population = [elites | fresh
+                                  samples], one Keras-Adam step per outer iteration; uses cem_*, learning_rate,
+                                  adam_*, gradmax_clip, warmup*                                                    */
 } ctk_optimizer;
 
 /* reference: predictor_specification passed to PredictorWrapper.configure
@@ -164,6 +167,8 @@ int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n);
  *   random optimizer_random_action_tf.py:49-76      samples: U[0,1)   [N,H,C]
  *   gradient optimizer_gradient_tf.py:101-173       samples: U[0,1)   [N,1,C] (the shifted-in tail input, :137-142)
  *   cem-naive-grad optimizer_cem_naive_grad_tf.py:89-115  samples: N(0,1) [cem_outer_it,N,H,C]
+ *   cem-grad-bharadhwaj optimizer_cem_grad_bharadhwaj_tf.py:151-178  samples: N(0,1) [K,H,C] (initial elites, :158)
+ *                                                   then [iters, N-K, H, C] (:94)
  * s: host [S].  u_prev: host [C] previous applied input (cost `previous_input`); NULL = the
  * optimizer's own last output, as the reference passes self.u.  u_out: host [C].
  * Synchronous: returns when u_out is valid.

@@ -839,3 +839,59 @@ class CEMNaiveGrad:
             [self.dist_mue[:, 1:, :], (self.low + self.high) * f32(0.5) * np.ones((1, 1, 1), np.float32)], 1)   # :104
         self.Q, self.J, self.best_idx = Qn, J, best
         return np.array(self.u, np.float32)
+
+
+class CEMGradBharadhwaj:
+    """Optimizers/optimizer_cem_grad_bharadhwaj_tf.py: CEM over [elites | fresh samples] with one Keras-Adam
+    step per outer iteration.  The Keras optimizer's moments live by POSITION in the population variable and
+    are never shifted or reset by the reference (optimizer_reset :180-184 resets only the distribution)."""
+    def __init__(self, predictor, cost, low=-1.0, high=1.0, *, num_rollouts, mpc_horizon, cem_outer_it=2,
+                 cem_initial_action_stdev=2.0, cem_stdev_min=1e-6, cem_best_k=8, learning_rate=0.05, adam_beta_1=0.9,
+                 adam_beta_2=0.999, adam_epsilon=1e-8, gradmax_clip=5.0, warmup=False, warmup_iterations=250):
+        self.predictor, self.cost = predictor, cost
+        self.N, self.H = num_rollouts, mpc_horizon
+        self.low, self.high = f32(low), f32(high)
+        self.cem_outer_it, self.K = cem_outer_it, cem_best_k
+        self.init_std, self.std_min = f32(cem_initial_action_stdev), f32(cem_stdev_min)
+        self.gradmax_clip = f32(gradmax_clip)
+        self.warmup, self.warmup_iterations = warmup, warmup_iterations
+        self.opt = KerasAdam(learning_rate, adam_beta_1, adam_beta_2, adam_epsilon)
+        self.u = f32(0.0)
+        self.optimizer_reset()
+
+    def optimizer_reset(self):
+        self.dist_mue = ((self.low + self.high) * f32(0.5) * np.ones((1, self.H, 1), np.float32)).astype(np.float32)
+        self.stdev = (self.init_std * np.ones((1, self.H, 1), np.float32)).astype(np.float32)
+        self.count = 0
+
+    def iterations(self):
+        return self.warmup_iterations if (self.warmup and self.count == 0) else self.cem_outer_it   # :161
+
+    def _sample(self, eps):
+        return (np.tile(self.dist_mue, (eps.shape[0], 1, 1)) + self.stdev * np.asarray(eps, np.float32)).astype(np.float32)   # :122-128
+
+    def step(self, s, eps_elite, eps_rest):
+        """eps_elite [K,H,1] (:158), eps_rest [iterations, N-K, H, 1] (:94): standard normal draws."""
+        s_t = np.tile(np.asarray(s, np.float32).reshape(1, 4), (self.N, 1))
+        up = np.array([self.u], np.float32)
+        elite_Q = self._sample(eps_elite)                                                   # :158
+        for it in range(self.iterations()):                                                 # :162-163
+            Q = np.clip(np.concatenate([elite_Q, self._sample(eps_rest[it])], 0), self.low, self.high).astype(np.float32)   # :94-96
+            _, _, g = rollout_cost_and_grad(self.predictor, self.cost, s_t, Q, up)          # :99-104
+            g = clip_by_norm(g, self.gradmax_clip)                                          # :106
+            Qn = np.clip(self.opt.apply(g, Q), self.low, self.high).astype(np.float32)      # :108-109
+            traj = self.predictor.predict_core(s_t, Qn)                                     # :111-112
+            J = self.cost.get_trajectory_cost(traj, Qn, up)
+            best = argsort_total_order(J)[: self.K]                                         # :115-117
+            elite_Q = Qn[best]
+            self.dist_mue = np.mean(elite_Q, axis=0, keepdims=True, dtype=np.float32)       # :119-120
+            self.stdev = np.sqrt(np.mean((elite_Q - self.dist_mue) ** 2, axis=0, keepdims=True, dtype=np.float32)).astype(np.float32)
+        self.u = f32(elite_Q[0, 0, 0])                                                      # :167
+        # apply_time_delta :130-141
+        self.dist_mue = np.concatenate(
+            [self.dist_mue[:, 1:, :], (self.low + self.high) * f32(0.5) * np.ones((1, 1, 1), np.float32)], 1)
+        self.stdev = np.clip(self.stdev, self.std_min, f32(10.0))
+        self.stdev = np.concatenate([self.stdev[:, 1:, :], self.init_std * np.ones((1, 1, 1), np.float32)], 1)
+        self.Q, self.J, self.best_idx = Qn, J, best
+        self.count += 1
+        return np.array(self.u, np.float32)

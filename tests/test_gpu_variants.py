@@ -104,3 +104,35 @@ def test_variant_optimizers_discoverable_and_run():
             u = opt.step(s)
             assert np.isfinite(u).all() and abs(float(u)) <= 1.0
         assert opt.logging_values["Q_logged"].shape == (cfg["num_rollouts"], 35, 1)
+
+
+@pytest.mark.parametrize("pred,N,H,K,its", [("ODE", 32, 50, 8, 2), ("MLP", 64, 16, 16, 3)])
+def test_cem_grad_bharadhwaj_matches_oracle(pred, N, H, K, its):
+    env = O.EnvParams(terminal_weight=0.2)
+    w = O.mlp_default_weights(4)
+    p = O.Predictor(pred, dt=0.02, env=env, weights=w)
+    kw = dict(cem_outer_it=its, cem_best_k=K, cem_initial_action_stdev=2.0, cem_stdev_min=1e-6, learning_rate=0.05,
+              adam_beta_1=0.9, adam_beta_2=0.999, adam_epsilon=1e-8, gradmax_clip=5.0)
+    o = O.CEMGradBharadhwaj(p, O.Cost(env), num_rollouts=N, mpc_horizon=H, **kw)
+    e = CtkEngine("cem_grad_bharadhwaj", pred, num_rollouts=N, mpc_horizon=H, dt=0.02, **kw)
+    apply_env(e, env)
+    if pred == "MLP":
+        e.set_predictor_weights(w)
+    rng = np.random.default_rng(N * H)
+    s = np.array([0.02, 0.1, 2.9, -0.5], np.float32)
+    for t in range(3):
+        el = rng.standard_normal((K, H, 1)).astype(np.float32)
+        rest = rng.standard_normal((its, N - K, H, 1)).astype(np.float32)
+        assert e.samples_needed() == el.size + rest.size
+        uo = o.step(s, el, rest)
+        ug = e.step(s, np.concatenate([el.ravel(), rest.ravel()]))
+        tol = dict(rtol=5e-4, atol=5e-4)
+        assert_close_mostly(e.read("Q"), o.Q, **tol)
+        assert_close_mostly(e.read("ADAM_M"), o.opt.m, **tol)
+        np.testing.assert_allclose(e.read("U_NOM"), o.dist_mue, rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(e.read("STD"), o.stdev, rtol=5e-3, atol=1e-3)
+        np.testing.assert_allclose(ug[0], uo, rtol=1e-3, atol=1e-3)
+        # re-pin to the oracle's state (mu, std, u, count, m, v, adam step)
+        e.set_state(np.concatenate([o.dist_mue.ravel(), o.stdev.ravel(), [float(o.u)], [o.count], o.opt.m.ravel(), o.opt.v.ravel(),
+                                    [o.opt.step_count]]).astype(np.float32))
+    e.close()
