@@ -533,6 +533,9 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     if (cfg->period_interpolation_inducing_points < 1 || cfg->intermediate_steps < 1)
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: period_interpolation_inducing_points and intermediate_steps must be >= 1");
     if (!(cfg->dt > 0.0f)) return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: dt must be > 0");
+    if ((long long)cfg->num_rollouts * (cfg->mpc_horizon + 1) * CTK_S > (1ll << 30))
+        return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: num_rollouts * (mpc_horizon + 1) * num_states must stay below 2^30 (32-bit element indices)");
+    if (!(cfg->action_low <= cfg->action_high)) return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: action_low must be <= action_high");
     if (cfg->optimizer < CTK_OPT_MPPI || cfg->optimizer > CTK_OPT_CEM_GRAD_BHARADHWAJ)
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: unknown optimizer");
     // variants run on an engine family: gradient = RPGD machinery without resampling (Keras Adam, fresh tail);
@@ -665,7 +668,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
 void ctk_destroy(ctk_handle* h) {
     if (!h) return;
     hipSetDevice(h->cfg.device);
-    if (h->stream) hipStreamSynchronize(h->stream);
+    hipStreamSynchronize(h->stream);   // also correct for the null (default) stream handed in by ctk_set_stream
     for (auto& e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     void* bufs[] = {h->d_interp, h->d_samples, h->d_J, h->d_Q, h->d_traj, h->d_parts, h->d_parts2, h->d_unom[0], h->d_unom[1],
                     h->d_std, h->d_base, h->d_scale, h->d_idx, h->d_u, h->d_weights, h->d_wperm, h->d_counter,
@@ -700,7 +703,8 @@ int ctk_reset(ctk_handle* h, const float* draws, int draws_loc) {
         case CTK_OPT_CEM: {  // optimizer_cem_tf.py:113-117 (self.u = 0.0)
             if (int rc = fill_const(h, h->d_unom[0], (h->cfg.action_low + h->cfg.action_high) * 0.5f, h->H)) return rc;
             if (int rc = fill_const(h, h->d_std, h->cfg.cem_initial_action_stdev, h->H)) return rc;
-            return fill_const(h, h->d_u, 0.0f, 1);
+            // only optimizer_cem_tf.py:117 resets self.u; the gradient variants' resets leave it (and Adam) alone
+            return h->variant == CTK_OPT_CEM ? fill_const(h, h->d_u, 0.0f, 1) : CTK_OK;
         }
         case CTK_OPT_RANDOM_ACTION:   // :78-86 draws and discards a sample
             if (int rc = fill_const(h, h->d_base, h->cfg.action_low, h->H)) return rc;

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void ctk_sample_plans(RolloutArgs a, const flo
     const int H = a.H;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= a.N * H) return;
-    const int n = H >= 2 ? (int)__umulhi((uint32_t)gid, a.p_magic) : gid, h = gid - n * H;
+    const int n = gid / H, h = gid - n * H;   // gid ranges over N*H: beyond the exactness range of the p_magic trick
     float e;
     if (samples != nullptr) {
         e = samples[gid];
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void ctk_cem_build_population(RolloutArgs a, i
     const int H = a.H;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= a.N * H) return;
-    const int n = H >= 2 ? (int)__umulhi((uint32_t)gid, a.p_magic) : gid, h = gid - n * H;
+    const int n = gid / H, h = gid - n * H;   // gid ranges over N*H: beyond the exactness range of the p_magic trick
     float q;
     if (n < K && !first) {
         q = Q_prev[(size_t)idx[n] * H + h];
