@@ -37,6 +37,7 @@ struct ctk_handle {
     float* d_traj = nullptr;
     float* d_parts = nullptr;   size_t parts_cap = 0;
     float* d_parts2 = nullptr;
+    float* d_parts3 = nullptr;
     unsigned* d_counter = nullptr;   // ticket counter of the fused in-launch merge
     float* d_unom[2] = {nullptr, nullptr};   // MPPI u_nom ping-pong / CEM mu in [0]
     int cur = 0;
@@ -293,7 +294,9 @@ int check_predictor(ctk_handle* h) {
 
 // ---- MPPI ------------------------------------------------------------------------------------
 int mppi_block_parts(const ctk_handle* h) { return ctk_mppi_num_blocks(h->N); }
-bool mppi_can_fuse(const ctk_handle* h) { return mppi_block_parts(h) <= CTK_MPPI_FUSE_MAX_BLOCKS; }
+bool mppi_can_fuse(const ctk_handle* h) {
+    return mppi_block_parts(h) <= CTK_MPPI_FUSE_MAX_BLOCKS && !ctk_mppi_uses_throughput_kernel(h->cfg.predictor, h->N);
+}
 
 // fuse_mode: 0 block records only; 1 the last block also merges + updates (single-GPU step);
 //            2 the last block emits this shard's ONE record into partial_dev (sharded step_begin)
@@ -315,12 +318,17 @@ int mppi_rollout(ctk_handle* h, const float* s, const float* u_prev, const float
 
 // reduce the block records to <= 2048 records (hierarchical when the grid was huge)
 int mppi_reduce_blocks(ctk_handle* h, const float** parts, int* n_parts) {
+    // tree of 32-way merges (each a grid of 256-thread blocks with the records staged in LDS) until one
+    // block can take the rest: N = 65536 -> 1024 -> 32 records; N = 4 M -> 65536 -> 2048 -> 64
     int n = mppi_block_parts(h);
     const float* src = h->d_parts;
-    if (n > 2048) {
-        HIP_TRY(h, ctk_launch_mppi_merge_partial(h->stream, src, n, 64, h->P, h->mk.neg_inv_lbd, h->d_parts2));
-        n = (n + 63) / 64;
-        src = h->d_parts2;
+    float* bufs[2] = {h->d_parts2, h->d_parts3};
+    int b = 0;
+    while (n > 64) {
+        HIP_TRY(h, ctk_launch_mppi_merge_partial(h->stream, src, n, 32, h->P, h->mk.neg_inv_lbd, bufs[b]));
+        n = (n + 31) / 32;
+        src = bufs[b];
+        b ^= 1;
     }
     *parts = src; *n_parts = n;
     return CTK_OK;
@@ -615,7 +623,8 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     const size_t nblk = (N + 63) / 64;
     h->parts_cap = nblk * (2 + P);
     TRY_CREATE(dev_alloc(h, &h->d_parts, h->parts_cap));
-    TRY_CREATE(dev_alloc(h, &h->d_parts2, ((nblk + 63) / 64) * (2 + P)));
+    TRY_CREATE(dev_alloc(h, &h->d_parts2, ((nblk + 31) / 32) * (2 + P)));
+    TRY_CREATE(dev_alloc(h, &h->d_parts3, ((nblk + 1023) / 1024) * (2 + P)));
     TRY_CREATE(dev_alloc(h, &h->d_counter, 1));
     TRY_CREATE(dev_alloc(h, &h->d_unom[0], H));
     TRY_CREATE(dev_alloc(h, &h->d_unom[1], H));
@@ -654,7 +663,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
         case CTK_OPT_RPGD: h->dominant = ctk_rpgd_descent_name(cfg->predictor); break;
         case CTK_OPT_CEM: if (variant == CTK_OPT_CEM_NAIVE_GRAD || variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) { h->dominant = ctk_rpgd_descent_name(cfg->predictor); break; }
             h->dominant = ctk_affine_rollout_name(cfg->predictor, cfg->materialize_trajectories != 0); break;
-        case CTK_OPT_MPPI: h->dominant = ctk_mppi_rollout_name(cfg->predictor, cfg->materialize_trajectories != 0); break;
+        case CTK_OPT_MPPI: h->dominant = ctk_mppi_rollout_name(cfg->predictor, cfg->materialize_trajectories != 0, cfg->num_rollouts); break;
         default: h->dominant = ctk_affine_rollout_name(cfg->predictor, cfg->materialize_trajectories != 0); break;
     }
     if (cfg->optimizer != CTK_OPT_RPGD) TRY_CREATE(ctk_reset(h, nullptr, CTK_LOC_NONE));
@@ -670,7 +679,7 @@ void ctk_destroy(ctk_handle* h) {
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);   // also correct for the null (default) stream handed in by ctk_set_stream
     for (auto& e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-    void* bufs[] = {h->d_interp, h->d_samples, h->d_J, h->d_Q, h->d_traj, h->d_parts, h->d_parts2, h->d_unom[0], h->d_unom[1],
+    void* bufs[] = {h->d_interp, h->d_samples, h->d_J, h->d_Q, h->d_traj, h->d_parts, h->d_parts2, h->d_parts3, h->d_unom[0], h->d_unom[1],
                     h->d_std, h->d_base, h->d_scale, h->d_idx, h->d_u, h->d_weights, h->d_wperm, h->d_counter,
                     h->d_pop[0], h->d_pop[1], h->d_m[0], h->d_m[1], h->d_v[0], h->d_v[1], h->d_ages[0], h->d_ages[1], h->d_bc, h->d_scratch};
     for (void* b : bufs) if (b) hipFree(b);

@@ -12,12 +12,16 @@
     } while (0)
 
 // ---- ctk_mppi.hip ---------------------------------------------------------------------------
-const char* ctk_mppi_rollout_name(int pred, bool log);
+const char* ctk_mppi_rollout_name(int pred, bool log, int N);
 int ctk_mppi_num_blocks(int N);
+bool ctk_mppi_uses_throughput_kernel(int pred, int N);
 size_t ctk_mppi_rollout_lds(int P, int H);
 // wperm: per-lane permuted MLP weights (ctk_api.hip: permute_mlp_weights), nullptr for the ODE predictor
 // In-launch merge by the last block to finish (<= CTK_MPPI_FUSE_MAX_BLOCKS blocks).
-constexpr int CTK_MPPI_FUSE_MAX_BLOCKS = 256;
+constexpr int CTK_MPPI_FUSE_MAX_BLOCKS = 64;     // beyond this the last block's serial record fetch costs more than a launch
+// From this many rollouts on (ODE predictor) the latency-oriented 4-wave block gives way to the
+// throughput-oriented single-wave block (half the LDS, 2x the resident recurrence waves per CU).
+constexpr int CTK_MPPI_THROUGHPUT_MIN_N = 32768;
 struct MppiFuse {
     int mode = 0;              // 0 records only, 1 merge + update u_nom/u, 2 merge into ONE record (sharded step_begin)
     unsigned* counter = nullptr;

@@ -344,9 +344,88 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
 }
 
 // ---------------------------------------------------------------------------------------------
+// Throughput variant (ODE, N >= CTK_MPPI_THROUGHPUT_MIN_N): one wave per block, 64 trajectories, the
+// inputs formed inline in the recurrence instead of through an LDS input buffer.  LDS per block is the
+// sample tile only (13.5 KiB at P = 50 instead of 27 KiB), so ~11 recurrence waves are resident per CU
+// instead of 5 and the VALU issue slots of every SIMD are covered by several waves.  Same arithmetic in
+// the same order as the 4-wave kernel's prologue 2 + recurrence; block records merged by separate launches.
+// ---------------------------------------------------------------------------------------------
+template <bool LOG>
+__global__ __launch_bounds__(64) void ctk_mppi_rollout_tp(RolloutArgs a, EnvK k, MppiK m, const float* __restrict__ samples,
+                                                          const float* __restrict__ u_nom,
+                                                          const InterpEntry* __restrict__ interp, float* __restrict__ parts) {
+    extern __shared__ float lds[];
+    const int P = a.P, H = a.H, ts = tile_stride(P);
+    float* tile = lds;                 // [64][ts]
+    float* e_s = tile + 64 * ts;       // [64]
+    float* w0_s = e_s + 64;            // per-step tables [H] x 4
+    float* w1_s = w0_s + H;
+    float* un_s = w1_s + H;
+    int* i0_s = reinterpret_cast<int*>(un_s + H);
+    const int lane = threadIdx.x;
+    const int row0 = blockIdx.x * 64;
+    const int n = row0 + lane;
+    const bool valid = n < a.N;
+
+    load_tile_early<64, 64>(tile, samples, a, row0, m.stdev, 0, [&] {
+        for (int h = lane; h < H; h += 64) {
+            const InterpEntry e = interp[h];
+            i0_s[h] = e.i0; w0_s[h] = e.w0; w1_s[h] = e.w1;
+            un_s[h] = u_nom[min(h + 1, H - 1)];
+        }
+    });
+    __syncthreads();
+
+    const float* my = tile + lane * ts;
+    const bool ident = a.identity_interp != 0;
+    float corr = 0.0f, cin = 0.0f;
+    float uprev = a.u_prev_dev ? *a.u_prev_dev : a.u_prev;
+    float amax = 0.0f;
+    auto F_at = [&](int h) {
+        float du;
+        if (ident) du = my[h];
+        else { const int i0 = i0_s[h]; du = my[i0] * w0_s[h] + my[i0 + 1] * w1_s[h]; }
+        const float u = fminf(fmaxf(un_s[h] + du, a.lo), a.hi);
+        corr += m.cc * (m.k_dd * (du * du) + m.R * u * du + m.k_uu * (u * u));
+        cin += stage_cost_input(k, u, uprev);
+        uprev = u;
+        if constexpr (LOG) {
+            if (valid) a.Q_out[(size_t)n * H + h] = u;
+        }
+        return k.u_max * u;
+    };
+    float J;
+    if (k.intermediate_steps == 1) J = recur_ode_state_cost<LOG, false, true>(a, k, n, valid, F_at, &amax);
+    else J = recur_ode_state_cost<LOG, true, false>(a, k, n, valid, F_at, &amax);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0)) {
+        corr = 0.0f; cin = 0.0f; uprev = a.u_prev_dev ? *a.u_prev_dev : a.u_prev;
+        J = recur_ode_state_cost<LOG, true, false>(a, k, n, valid, F_at, &amax);
+    }
+    J = (J + cin) * a.inv_Hp1 + corr;
+    if (valid) a.J[n] = J;
+
+    const float rho = wave_min(valid ? J : INFINITY);
+    const float e = valid ? expf(m.neg_inv_lbd * (J - rho)) : 0.0f;
+    const float asum = wave_sum(e);
+    e_s[lane] = e;
+    __syncthreads();
+    float* rec = parts + (size_t)blockIdx.x * (2 + P);
+    if (lane == 0) { rec[0] = rho; rec[1] = asum; }
+    for (int p = lane; p < P; p += 64) {
+        float acc = 0.0f;
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) acc += e_s[r] * tile[r * ts + p];
+        rec[2 + p] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-const char* ctk_mppi_rollout_name(int pred, bool log) {
+bool ctk_mppi_uses_throughput_kernel(int pred, int N) { return pred == CTK_PRED_ODE && N >= CTK_MPPI_THROUGHPUT_MIN_N; }
+
+const char* ctk_mppi_rollout_name(int pred, bool log, int N) {
+    if (ctk_mppi_uses_throughput_kernel(pred, N)) return log ? "ctk_mppi_rollout_tp<true>" : "ctk_mppi_rollout_tp<false>";
     if (pred == CTK_PRED_ODE) return log ? "ctk_mppi_rollout<0, true>" : "ctk_mppi_rollout<0, false>";
     return log ? "ctk_mppi_rollout<1, true>" : "ctk_mppi_rollout<1, false>";
 }
@@ -380,6 +459,12 @@ hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& 
                                    const float* samples, const float* u_nom, const float* wperm, float* parts, bool log,
                                    const MppiFuse& fuse, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid(ctk_mppi_num_blocks(a.N)), block(MPPI_BLOCK);
+    if (ctk_mppi_uses_throughput_kernel(pred, a.N)) {
+        const size_t lds_tp = (size_t)(64 * tile_stride(a.P) + 64 + 4 * a.H) * sizeof(float);
+        if (log) CTK_LAUNCH((ctk_mppi_rollout_tp<true>), grid, dim3(64), lds_tp, st, e0, e1, a, k, m, samples, u_nom, a.interp, parts);
+        else CTK_LAUNCH((ctk_mppi_rollout_tp<false>), grid, dim3(64), lds_tp, st, e0, e1, a, k, m, samples, u_nom, a.interp, parts);
+        return hipGetLastError();
+    }
     FuseArgs fz{};
     const size_t lds = rollout_launch_lds(a.P, a.H, (int)grid.x, &fz.stage_ok);
     fz.mode = fuse.mode; fz.counter = fuse.counter; fz.out_rec = fuse.out_rec;
