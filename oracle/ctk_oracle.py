@@ -126,9 +126,60 @@ def mlp_unpack(w: np.ndarray):
     return W1, b1, W2, b2, W3, b3
 
 
+# GRU predictor (build-defined; the reference only hints at it through the network-name convention
+# 'GRU-6IN-32H1-32H2-5OUT-0', Control_Toolkit_ASF_Template/config_controllers.yml:8, and through
+# predictor.update(s, Q0) — the hidden-state advance at optimizer_mppi.py:195-197).  Two GRU layers of
+# 32 units (PyTorch gate convention: r, z, n; reset applied after the recurrent matmul) + dense 32->4:
+#   r = sig(W_ir x + b_ir + W_hr h + b_hr);  z = sig(W_iz x + b_iz + W_hz h + b_hz)
+#   n = tanh(W_in x + b_in + r * (W_hn h + b_hn));  h' = (1 - z) * n + z * h
+# Flat layout: per layer W_i[96,I] W_h[96,32] b_i[96] b_h[96] (rows r|z|n), then W_o[4,32] b_o[4].
+GRU_H = 32
+GRU_NUM_WEIGHTS = (96 * 5 + 96 * 32 + 192) + (96 * 32 + 96 * 32 + 192) + (4 * 32 + 4)   # 10212
+
+
+def gru_default_weights(seed: int = 0) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    parts = []
+    for I in (MLP_IN, GRU_H):
+        parts += [rng.normal(0, 1 / math.sqrt(I), (96, I)), rng.normal(0, 1 / math.sqrt(GRU_H), (96, GRU_H)),
+                  rng.normal(0, 0.1, (96,)), rng.normal(0, 0.1, (96,))]
+    parts += [rng.normal(0, 1 / math.sqrt(GRU_H), (4, GRU_H)), rng.normal(0, 0.1, (4,))]
+    return np.concatenate([a.ravel() for a in parts]).astype(np.float32)
+
+
+def gru_unpack(w: np.ndarray):
+    w = np.asarray(w, dtype=np.float32)
+    assert w.size == GRU_NUM_WEIGHTS
+    o = 0
+    layers = []
+    for I in (MLP_IN, GRU_H):
+        Wi = w[o:o + 96 * I].reshape(96, I); o += 96 * I
+        Wh = w[o:o + 96 * GRU_H].reshape(96, GRU_H); o += 96 * GRU_H
+        bi = w[o:o + 96]; o += 96
+        bh = w[o:o + 96]; o += 96
+        layers.append((Wi, Wh, bi, bh))
+    Wo = w[o:o + 4 * GRU_H].reshape(4, GRU_H); o += 4 * GRU_H
+    bo = w[o:o + 4]
+    return layers, Wo, bo
+
+
+def _sigmoid(x):
+    return (f32(1.0) / (f32(1.0) + np.exp(-x))).astype(np.float32)
+
+
+def gru_cell(x, h, Wi, Wh, bi, bh):
+    gi = (x @ Wi.T + bi).astype(np.float32)
+    gh = (h @ Wh.T + bh).astype(np.float32)
+    r = _sigmoid(gi[:, :32] + gh[:, :32])
+    z = _sigmoid(gi[:, 32:64] + gh[:, 32:64])
+    n = np.tanh(gi[:, 64:] + r * gh[:, 64:]).astype(np.float32)
+    return ((f32(1.0) - z) * n + z * h).astype(np.float32)
+
+
 @dataclass
 class Predictor:
-    """kind = "ODE" (analytic cart-pole, explicit Euler) or "MLP" (direct next-state net)."""
+    """kind = "ODE" (analytic cart-pole, explicit Euler), "MLP" (direct next-state net) or "GRU"
+    (recurrent net; `hidden` [2,32] is the state every rollout starts from, advanced by update())."""
     kind: str = "ODE"
     dt: float = 0.02
     intermediate_steps: int = 1
@@ -138,6 +189,27 @@ class Predictor:
     def __post_init__(self):
         if self.kind == "MLP" and self.weights is None:
             self.weights = mlp_default_weights(0)
+        if self.kind == "GRU":
+            if self.weights is None:
+                self.weights = gru_default_weights(0)
+            self.hidden = np.zeros((2, GRU_H), np.float32)
+
+    # GRU -------------------------------------------------------------------------------------
+    def _gru_step(self, s, q, h1, h2):
+        layers, Wo, bo = gru_unpack(self.weights)
+        xin = np.concatenate([s, q[:, None]], axis=1).astype(np.float32)
+        h1n = gru_cell(xin, h1, *layers[0])
+        h2n = gru_cell(h1n, h2, *layers[1])
+        return (h2n @ Wo.T + bo).astype(np.float32), h1n, h2n
+
+    def update(self, s, q0):
+        """predictor.update(s, Q0) (optimizer_mppi.py:195-197): advance the carried hidden state by the
+        real state and the applied input."""
+        if self.kind != "GRU":
+            return
+        s = np.asarray(s, np.float32).reshape(1, 4)
+        _, h1, h2 = self._gru_step(s, np.asarray(q0, np.float32).reshape(1), self.hidden[0:1], self.hidden[1:2])
+        self.hidden = np.concatenate([h1, h2], 0)
 
     # one predictor step ---------------------------------------------------------------------
     def step(self, s: np.ndarray, q: np.ndarray) -> np.ndarray:
@@ -227,6 +299,12 @@ class Predictor:
         traj = np.empty((N, H + 1, 4), dtype=np.float32)
         traj[:, 0] = s
         cur = s
+        if self.kind == "GRU":
+            h1 = np.tile(self.hidden[0:1], (N, 1)); h2 = np.tile(self.hidden[1:2], (N, 1))
+            for h in range(H):
+                cur, h1, h2 = self._gru_step(cur, Q[:, h, 0], h1, h2)
+                traj[:, h + 1] = cur
+            return traj
         for h in range(H):
             cur = self.step(cur, Q[:, h, 0])
             traj[:, h + 1] = cur
@@ -416,6 +494,7 @@ class MPPI:
         u_nom = np.clip(u_nom + self.reward_weighted_average(J, delta_u), self.low, self.high)  # :190
         self.u_nom = u_nom.astype(np.float32)
         self.u = f32(u_nom[0, 0, 0])                                             # :191
+        self.predictor.update(s, self.u)                                         # :192,:195-197 (RNN hidden state)
         self.J, self.u_run, self.rollout_trajectories, self.delta_u = J, u_run, traj, delta_u
         return np.array(self.u, dtype=np.float32)
 
