@@ -39,6 +39,8 @@ WORKLOADS = {
                       kw=dict(outer_its=20, resamp_per=10, shift_previous=1, opt_keep_k=64, sampling_distribution=0,
                               sample_min=-1.0, sample_max=1.0, learning_rate=0.05, gradmax_clip=5.0)),
     "mppi_cfg5_shard": dict(opt="mppi", pred="MLP", N=8192, H=100, p=10, kw={}),
+    # recurrent predictor (2x32 GRU, weights in LDS) at the headline MPPI size
+    "mppi_gru": dict(opt="mppi", pred="GRU", N=1024, H=50, p=1, kw={}),
     # the reference's own default problem sizes (Control_Toolkit_ASF_Template/config_optimizers.yml)
     "mppi_default": dict(opt="mppi", pred="ODE", N=3500, H=35, p=10, kw={}),
     "cem_default": dict(opt="cem", pred="ODE", N=200, H=40, p=1,
@@ -75,6 +77,17 @@ def mlp_weights(seed=0):
     return np.concatenate([a.ravel() for a in parts]).astype(np.float32)
 
 
+def gru_weights(seed=0):
+    """2x32 GRU + dense 32->4 (10212 floats); same recipe as the oracle's gru_default_weights."""
+    rng = np.random.default_rng(seed)
+    parts = []
+    for fan_in in (5, 32):
+        parts += [rng.normal(0, 1 / math.sqrt(fan_in), (96, fan_in)), rng.normal(0, 1 / math.sqrt(32), (96, 32)),
+                  rng.normal(0, 0.1, (96,)), rng.normal(0, 0.1, (96,))]
+    parts += [rng.normal(0, 1 / math.sqrt(32), (4, 32)), rng.normal(0, 0.1, (4,))]
+    return np.concatenate([a.ravel() for a in parts]).astype(np.float32)
+
+
 def algorithmic(w, P, samples_in_hbm):
     """compulsory bytes (and MLP flops) of the DOMINANT kernel's launch."""
     N, H, C, S = w["N"], w["H"], 1, 4
@@ -83,6 +96,8 @@ def algorithmic(w, P, samples_in_hbm):
         b = (4 * N * P * C if samples_in_hbm else 0) + 4 * N + 8 * H * C + 4 * S
         if w["pred"] == "MLP":
             flops = 2624 * N * H
+        elif w["pred"] == "GRU":   # 2 * (96*5 + 96*32 + 2*96*32 + 4*32) multiply-adds per trajectory step
+            flops = 19648 * N * H
     elif w["opt"] == "cem":      # one outer iteration = one rollout launch
         K = w["kw"]["cem_best_k"]
         b = (4 * N * H * C if samples_in_hbm else 0) + 4 * N + 4 * K * H * C + 8 * H * C
@@ -179,6 +194,8 @@ def main():
                     seed=1, device=local_rank, global_rollout_offset=rank * N, **w["kw"])
     if w["pred"] == "MLP":
         eng.set_predictor_weights(mlp_weights(0))
+    elif w["pred"] == "GRU":
+        eng.set_predictor_weights(gru_weights(0))
     P = eng.mppi_partial_size() - 2
     sharded = None
     if world > 1 or args.force_sharded:

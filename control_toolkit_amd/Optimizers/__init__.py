@@ -84,7 +84,7 @@ class template_optimizer:
             dt=dt, action_low=lo, action_high=hi, seed=self.seed, device=self.device,
             intermediate_steps=getattr(self.predictor, "intermediate_steps", 1),
             materialize_trajectories=bool(self.optimizer_logging), **engine_kwargs)
-        if self.predictor.kind == "MLP":
+        if self.predictor.kind in ("MLP", "GRU"):
             self.engine.set_predictor_weights(self.predictor.weights)
         self._param_cache = {}
         self._cost_version = None

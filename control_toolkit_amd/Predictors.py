@@ -1,11 +1,12 @@
 """PredictorWrapper — host-side stand for SI_Toolkit.Predictors.predictor_wrapper.PredictorWrapper
 (external to the reference; call sites optimizer_mppi.py:188, controller_mpc.py:43,67-73).  On
 MI355X the rollout is fused into the optimizer kernels, so this object only carries the
-predictor *specification* (kind, dt, physical parameters, MLP weights) to the engine."""
+predictor *specification* (kind, dt, physical parameters, network weights) to the engine."""
 import numpy as np
 
 DEFAULT_DYNAMICS = dict(g=9.81, m_cart=0.230, m_pole=0.087, L=0.1975, u_max=2.62, M_fric=4.77, J_fric=2.5e-4)
 MLP_NUM_WEIGHTS = 1380   # W1[32,5] b1[32] W2[32,32] b2[32] W3[4,32] b3[4]
+GRU_NUM_WEIGHTS = 10212  # per layer W_i[96,I] W_h[96,32] b_i[96] b_h[96] (I = 5, 32), then W_o[4,32] b_o[4]
 
 
 class PredictorWrapper:
@@ -27,14 +28,17 @@ class PredictorWrapper:
     def configure(self, batch_size, dt=None, computation_library=None, variable_parameters=None,
                   predictor_specification=None, horizon=None, **kwargs):
         spec = "ODE" if predictor_specification in (None, "") else str(predictor_specification)
-        kind = "ODE" if spec.upper().startswith("ODE") else ("MLP" if spec.upper().startswith("MLP") or "dense" in spec.lower() else None)
+        up = spec.upper()
+        kind = ("ODE" if up.startswith("ODE") else "GRU" if up.startswith("GRU")      # 'GRU-6IN-32H1-32H2-5OUT-0' convention
+                else "MLP" if up.startswith("MLP") or up.startswith("DENSE") else None)
         if kind is None:
-            raise NotImplementedError(f"predictor_specification {spec!r}: only 'ODE' and 'MLP' are built")
-        if kind == "MLP":
+            raise NotImplementedError(f"predictor_specification {spec!r}: only 'ODE', 'MLP' and 'GRU' are built")
+        if kind in ("MLP", "GRU"):
+            want = MLP_NUM_WEIGHTS if kind == "MLP" else GRU_NUM_WEIGHTS
             if self.weights is None:
-                raise ValueError("MLP predictor needs weights (PredictorWrapper(weights=...))")
-            if self.weights.size != MLP_NUM_WEIGHTS:
-                raise ValueError(f"MLP predictor expects {MLP_NUM_WEIGHTS} weights (5-32-32-4), got {self.weights.size}")
+                raise ValueError(f"{kind} predictor needs weights (PredictorWrapper(weights=...))")
+            if self.weights.size != want:
+                raise ValueError(f"{kind} predictor expects {want} weights, got {self.weights.size}")
         self.kind = kind
         self.predictor_specification = spec
         self.batch_size = batch_size
@@ -45,5 +49,7 @@ class PredictorWrapper:
         return PredictorWrapper(self.parameters, self.weights, self.intermediate_steps)
 
     def update(self, s=None, Q0=None):
-        """RNN hidden-state advance in the reference (optimizer_mppi.py:195-197); stateless here."""
+        """RNN hidden-state advance in the reference (optimizer_mppi.py:195-197).  The carried state lives
+        on the device behind the optimizer's engine (ctk_predictor_update); the MPPI step advances it itself,
+        so this host object has nothing to do."""
         return None

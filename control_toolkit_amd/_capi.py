@@ -17,7 +17,7 @@ _lib = None
 
 OPTIMIZERS = {"mppi": 0, "cem": 1, "rpgd": 2, "random_action": 3, "gradient": 4, "cem_naive_grad": 5,
               "cem_grad_bharadhwaj": 6}
-PREDICTORS = {"ODE": 0, "MLP": 1}
+PREDICTORS = {"ODE": 0, "MLP": 1, "GRU": 2}
 PARAMS = ("g", "m_cart", "m_pole", "L", "u_max", "M_fric", "J_fric", "target_position", "target_equilibrium",
           "dd_weight", "ep_weight", "ekp_weight", "cc_weight", "ccrc_weight", "R", "x_scale", "terminal_weight")
 BUFFERS = {"Q": 0, "J": 1, "TRAJ": 2, "U_NOM": 3, "STD": 4, "ADAM_M": 5, "ADAM_V": 6, "AGES": 7, "BEST_IDX": 8, "PLAN": 9}
@@ -65,6 +65,10 @@ SYMBOLS = {
     "ctk_set_param": (C.c_int, [_H, C.c_int, C.c_float]),
     "ctk_get_param": (C.c_int, [_H, C.c_int, _FP]),
     "ctk_set_predictor_weights": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
+    "ctk_predictor_hidden_size": (C.c_size_t, [_H]),
+    "ctk_predictor_update": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    "ctk_predictor_get_hidden": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
+    "ctk_predictor_set_hidden": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
     "ctk_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ctk_samples_needed": (C.c_size_t, [_H]),
     "ctk_rollout": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -115,7 +119,7 @@ def load_library():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.ctk_abi_version() != 1:
+    if lib.ctk_abi_version() != 2:
         raise CtkError("libctk_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -221,6 +225,24 @@ class CtkEngine:
     def set_predictor_weights(self, w):
         w = _f32(w).ravel()
         self._check(self._lib.ctk_set_predictor_weights(self._h, _ptr(w), w.size))
+
+    # recurrent predictor state (GRU): predictor.update(s, Q0), optimizer_mppi.py:195-197
+    def predictor_hidden_size(self) -> int:
+        return int(self._lib.ctk_predictor_hidden_size(self._h))
+
+    def predictor_update(self, s, u=None):
+        s = _f32(s).ravel()
+        u = None if u is None else _f32(u).ravel()
+        self._check(self._lib.ctk_predictor_update(self._h, _ptr(s), _ptr(u)))
+
+    def predictor_get_hidden(self) -> np.ndarray:
+        out = np.empty(self.predictor_hidden_size(), np.float32)
+        self._check(self._lib.ctk_predictor_get_hidden(self._h, _ptr(out), out.size))
+        return out.reshape(2, -1)
+
+    def predictor_set_hidden(self, hidden=None):
+        hid = None if hidden is None else _f32(hidden).ravel()
+        self._check(self._lib.ctk_predictor_set_hidden(self._h, _ptr(hid), 0 if hid is None else hid.size))
 
     def samples_needed(self) -> int:
         return int(self._lib.ctk_samples_needed(self._h))

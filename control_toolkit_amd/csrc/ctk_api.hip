@@ -10,6 +10,7 @@
 #include "ctk_launch.h"
 #include "ctk_device.h"   // tile_stride
 #include "ctk_mlp.h"      // mlp_hid, per-lane weight layout
+#include "ctk_gru.h"      // GRU per-lane table layout
 
 namespace {
 
@@ -49,8 +50,10 @@ struct ctk_handle {
     float* h_u = nullptr;       // pinned, coherent, device-visible host slot: {u, sequence number} written by ONE 8-B store
     float* h_u_dev = nullptr;   // device pointer aliasing h_u
     uint32_t seq = 1;           // sequence number the NEXT publishing kernel will write (the slot starts at 0)
-    float* d_weights = nullptr; // MLP: raw [1380]
+    float* d_weights = nullptr; // raw network weights (MLP [1380] / GRU [10212])
     float* d_wperm = nullptr;   // MLP: per-lane permuted, forward [64][48] then backward [64][28]
+                                // GRU: per-lane table [232][64], then the carried hidden state [2][32]
+    float mppi_s[CTK_S] = {0, 0, 0, 0};   // state of the pending sharded MPPI step (GRU hidden-state advance at step_end)
     // RPGD: population, Adam moments, ages (ping-pong), bias-correction table, adjoint scratch
     float* d_pop[2] = {nullptr, nullptr};
     float* d_m[2] = {nullptr, nullptr};
@@ -176,6 +179,47 @@ std::vector<float> permute_mlp_weights(const float* raw) {
     return out;
 }
 
+// Per-lane MFMA operand table of the GRU weights (ctk_gru.h header comment): out[index][lane].
+// raw: per layer W_i[96,I] W_h[96,32] b_i[96] b_h[96] (rows r|z|n), then W_o[4,32] b_o[4].
+std::vector<float> permute_gru_weights(const float* raw) {
+    std::vector<float> out((size_t)GRU_LDS_FLOATS, 0.0f);
+    const float* p = raw;
+    for (int l = 0; l < 64; ++l) {
+        const int i = l & 15, g = l >> 4;
+        auto put = [&](int idx, float v) { out[(size_t)idx * 64 + l] = v; };
+        const float* q = raw;
+        for (int L = 0; L < 2; ++L) {
+            const int I = L == 0 ? CTK_MLP_IN : 32, KS = L == 0 ? 2 : 8;
+            const float* Wi = q;              const float* Wh = Wi + 96 * I;
+            const float* bi = Wh + 96 * 32;   const float* bh = bi + 96;
+            q = bh + 96;
+            const int ih_base = L == 0 ? GRU_W_L1_IH : GRU_W_L2_IH, hh_base = L == 0 ? GRU_W_L1_HH : GRU_W_L2_HH;
+            for (int gate = 0; gate < 3; ++gate)
+                for (int m = 0; m < 2; ++m) {
+                    const int row = 32 * gate + 16 * m + i;
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const int kk = L == 0 ? 4 * ks + g : mlp_hid(ks, g);
+                        put(ih_base + (gate * 2 + m) * KS + ks, (L == 0 && kk >= CTK_MLP_IN) ? 0.0f : Wi[row * I + kk]);
+                    }
+                    for (int j = 0; j < 8; ++j) put(hh_base + (gate * 2 + m) * 8 + j, Wh[row * 32 + mlp_hid(j, g)]);
+                }
+            for (int m = 0; m < 2; ++m)
+                for (int r = 0; r < 4; ++r) {
+                    const int unit = 16 * m + 4 * g + r, b0 = GRU_W_BIAS + L * 32 + m * 4 + r;
+                    put(b0 + 0, bi[unit] + bh[unit]);              // r gate: both biases feed one accumulator
+                    put(b0 + 8, bi[32 + unit] + bh[32 + unit]);    // z gate
+                    put(b0 + 16, bi[64 + unit]);                   // n gate, input part
+                    put(b0 + 24, bh[64 + unit]);                   // n gate, hidden part (scaled by r)
+                }
+        }
+        const float* Wo = q; const float* bo = Wo + 4 * 32;
+        for (int j = 0; j < 8; ++j) put(GRU_W_OUT + j, (i % 4 == 0) ? Wo[(i / 4) * 32 + mlp_hid(j, g)] : 0.0f);
+        for (int r = 0; r < 4; ++r) put(GRU_W_BIAS + 64 + r, r == 0 ? bo[g] : 0.0f);
+    }
+    (void)p;
+    return out;
+}
+
 void default_params(float* p) {
     // oracle/ctk_oracle.py:EnvParams defaults
     p[CTK_P_G] = 9.81f; p[CTK_P_M_CART] = 0.230f; p[CTK_P_M_POLE] = 0.087f; p[CTK_P_L] = 0.1975f;
@@ -287,8 +331,8 @@ int finish_step(ctk_handle* h, float* u_out) {
 }
 
 int check_predictor(ctk_handle* h) {
-    if (h->cfg.predictor == CTK_PRED_MLP && !h->have_weights)
-        return fail(h, CTK_ERR_STATE, "MLP predictor: call ctk_set_predictor_weights before stepping");
+    if (h->cfg.predictor != CTK_PRED_ODE && !h->have_weights)
+        return fail(h, CTK_ERR_STATE, "network predictor: call ctk_set_predictor_weights before stepping");
     return CTK_OK;
 }
 
@@ -334,11 +378,20 @@ int mppi_reduce_blocks(ctk_handle* h, const float** parts, int* n_parts) {
     return CTK_OK;
 }
 
+// optimizer_mppi.py:192,195-197: predictor.update(s, u_nom[:, :1]) — behind the update on the stream, off the
+// caller's latency path (the step's result is already published when this runs)
+int mppi_advance_hidden(ctk_handle* h) {
+    if (h->cfg.predictor != CTK_PRED_GRU) return CTK_OK;
+    HIP_TRY(h, ctk_launch_gru_advance(h->stream, h->mppi_s, h->d_u, 0.0f, h->d_wperm));
+    return CTK_OK;
+}
+
 int mppi_update(ctk_handle* h, const float* parts, int n_parts, float* u_out) {
     const int nxt = h->cur ^ 1;
     HIP_TRY(h, ctk_launch_mppi_update(h->stream, parts, n_parts, h->P, h->mk.neg_inv_lbd, h->H, h->d_interp, h->d_unom[h->cur],
                                       h->d_unom[nxt], h->cfg.action_low, h->cfg.action_high, h->d_u, h->h_u_dev, h->seq));
     h->cur = nxt;
+    if (int rc = mppi_advance_hidden(h)) return rc;
     return finish_step(h, u_out);
 }
 
@@ -562,8 +615,10 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     }
     const int variant = cfg->optimizer;
     cfg = &mapped;
-    if (cfg->predictor != CTK_PRED_ODE && cfg->predictor != CTK_PRED_MLP)
+    if (cfg->predictor != CTK_PRED_ODE && cfg->predictor != CTK_PRED_MLP && cfg->predictor != CTK_PRED_GRU)
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: unknown predictor");
+    if (cfg->predictor == CTK_PRED_GRU && (cfg->optimizer == CTK_OPT_RPGD || variant != cfg->optimizer))
+        return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: the GRU predictor is built forward-only (MPPI, CEM, random-action); no reverse mode for the gradient-based optimizers");
     if (cfg->optimizer == CTK_OPT_CEM && (cfg->cem_best_k < 1 || cfg->cem_best_k > cfg->num_rollouts || cfg->cem_outer_it < 1))
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: need 1 <= cem_best_k <= num_rollouts and cem_outer_it >= 1");
     if (cfg->optimizer == CTK_OPT_RPGD) {
@@ -606,9 +661,9 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     const size_t N = h->N, H = h->H, P = h->P;
     // LDS budget of the rollout tiles (one wave per block): 64 * stride * 4 B <= 160 KiB
     {
-        const size_t lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_lds((int)P, (int)H)
+        const size_t lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_lds((int)P, (int)H, cfg->predictor)
                          : (cfg->optimizer == CTK_OPT_RPGD || variant == CTK_OPT_CEM_NAIVE_GRAD || variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) ? ctk_rpgd_descent_lds(cfg->predictor, (int)H, nullptr)
-                                                          : ctk_affine_rollout_lds((int)H);
+                                                          : ctk_affine_rollout_lds((int)H, cfg->predictor);
         if (lds > 160 * 1024) { h->err = "horizon too long for the LDS sample tiles (160 KiB per CU)"; return bail(CTK_ERR_UNSUPPORTED); }
     }
 
@@ -633,8 +688,9 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     TRY_CREATE(dev_alloc(h, &h->d_scale, H));
     TRY_CREATE(dev_alloc(h, &h->d_idx, N));
     TRY_CREATE(dev_alloc(h, &h->d_u, 1));
-    TRY_CREATE(dev_alloc(h, &h->d_weights, CTK_MLP_NW));
-    TRY_CREATE(dev_alloc(h, &h->d_wperm, (size_t)64 * (MLP_FWD_PER_LANE + MLP_BWD_PER_LANE)));
+    TRY_CREATE(dev_alloc(h, &h->d_weights, cfg->predictor == CTK_PRED_GRU ? GRU_NW_RAW : CTK_MLP_NW));
+    TRY_CREATE(dev_alloc(h, &h->d_wperm, cfg->predictor == CTK_PRED_GRU ? (size_t)GRU_LDS_FLOATS + GRU_HIDDEN_FLOATS
+                                                                          : (size_t)64 * (MLP_FWD_PER_LANE + MLP_BWD_PER_LANE)));
     HIP_CREATE(hipHostMalloc((void**)&h->h_u, 64, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(h->h_u, 0, 64);
     HIP_CREATE(hipHostGetDevicePointer((void**)&h->h_u_dev, h->h_u, 0));
@@ -741,13 +797,49 @@ int ctk_get_param(const ctk_handle* h, int id, float* value) {
 
 int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n) {
     if (!h || !w) return CTK_ERR_INVALID_ARGUMENT;
-    if (n != (size_t)CTK_MLP_NW) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_set_predictor_weights: expected 1380 floats");
+    if (h->cfg.predictor == CTK_PRED_ODE) return fail(h, CTK_ERR_STATE, "ctk_set_predictor_weights: the ODE predictor has no weights");
+    const bool gru = h->cfg.predictor == CTK_PRED_GRU;
+    if (n != (size_t)(gru ? GRU_NW_RAW : CTK_MLP_NW))
+        return fail(h, CTK_ERR_INVALID_ARGUMENT, gru ? "ctk_set_predictor_weights: expected 10212 floats (GRU)" : "ctk_set_predictor_weights: expected 1380 floats (MLP)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipMemcpyAsync(h->d_weights, w, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    const std::vector<float> perm = permute_mlp_weights(w);
+    if (gru) HIP_TRY(h, hipMemsetAsync(h->d_wperm + GRU_LDS_FLOATS, 0, GRU_HIDDEN_FLOATS * sizeof(float), h->stream));
+    const std::vector<float> perm = gru ? permute_gru_weights(w) : permute_mlp_weights(w);
     HIP_TRY(h, hipMemcpyAsync(h->d_wperm, perm.data(), perm.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->have_weights = true;
+    return CTK_OK;
+}
+
+size_t ctk_predictor_hidden_size(const ctk_handle* h) { return (h && h->cfg.predictor == CTK_PRED_GRU) ? (size_t)GRU_HIDDEN_FLOATS : 0; }
+
+int ctk_predictor_update(ctk_handle* h, const float* s, const float* u) {
+    if (!h || !s) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_predictor_update: NULL state") : CTK_ERR_INVALID_ARGUMENT;
+    if (h->cfg.predictor != CTK_PRED_GRU) return CTK_OK;   // predictor.update is a no-op for stateless predictors
+    if (int rc = check_predictor(h)) return rc;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, ctk_launch_gru_advance(h->stream, s, u ? nullptr : h->d_u, u ? u[0] : 0.0f, h->d_wperm));
+    return CTK_OK;
+}
+
+int ctk_predictor_get_hidden(ctk_handle* h, float* dst, size_t cap) {
+    if (!h || !dst) return CTK_ERR_INVALID_ARGUMENT;
+    if (h->cfg.predictor != CTK_PRED_GRU) return fail(h, CTK_ERR_STATE, "ctk_predictor_get_hidden: predictor has no hidden state");
+    if (cap < (size_t)GRU_HIDDEN_FLOATS) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_predictor_get_hidden: need room for 64 floats");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemcpyAsync(dst, h->d_wperm + GRU_LDS_FLOATS, GRU_HIDDEN_FLOATS * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CTK_OK;
+}
+
+int ctk_predictor_set_hidden(ctk_handle* h, const float* src, size_t n) {
+    if (!h) return CTK_ERR_INVALID_ARGUMENT;
+    if (h->cfg.predictor != CTK_PRED_GRU) return fail(h, CTK_ERR_STATE, "ctk_predictor_set_hidden: predictor has no hidden state");
+    if (src && n != (size_t)GRU_HIDDEN_FLOATS) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_predictor_set_hidden: expected 64 floats");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (src) HIP_TRY(h, hipMemcpyAsync(h->d_wperm + GRU_LDS_FLOATS, src, GRU_HIDDEN_FLOATS * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    else HIP_TRY(h, hipMemsetAsync(h->d_wperm + GRU_LDS_FLOATS, 0, GRU_HIDDEN_FLOATS * sizeof(float), h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CTK_OK;
 }
 
@@ -759,9 +851,11 @@ int ctk_step(ctk_handle* h, const float* s, const float* u_prev, const float* sa
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     switch (h->cfg.optimizer) {
         case CTK_OPT_MPPI: {
+            for (int i = 0; i < CTK_S; ++i) h->mppi_s[i] = s[i];
             if (mppi_can_fuse(h)) {   // one launch: the last block to finish merges and updates
                 if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 1, nullptr)) return rc;
                 h->cur ^= 1;
+                if (int rc = mppi_advance_hidden(h)) return rc;
                 return finish_step(h, u_out);
             }
             if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 0, nullptr)) return rc;
@@ -784,6 +878,7 @@ int ctk_mppi_step_begin(ctk_handle* h, const float* s, const float* u_prev, cons
     if (h->cfg.optimizer != CTK_OPT_MPPI) return fail(h, CTK_ERR_STATE, "ctk_mppi_step_begin: handle is not MPPI");
     if (h->mppi_pending) return fail(h, CTK_ERR_STATE, "ctk_mppi_step_begin: previous sharded step not ended");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    for (int i = 0; i < CTK_S; ++i) h->mppi_s[i] = s[i];
     if (mppi_can_fuse(h)) {
         if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 2, partial_dev)) return rc;
     } else {

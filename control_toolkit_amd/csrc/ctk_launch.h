@@ -15,7 +15,7 @@
 const char* ctk_mppi_rollout_name(int pred, bool log, int N);
 int ctk_mppi_num_blocks(int N);
 bool ctk_mppi_uses_throughput_kernel(int pred, int N);
-size_t ctk_mppi_rollout_lds(int P, int H);
+size_t ctk_mppi_rollout_lds(int P, int H, int pred = 0);
 // wperm: per-lane permuted MLP weights (ctk_api.hip: permute_mlp_weights), nullptr for the ODE predictor
 // In-launch merge by the last block to finish (<= CTK_MPPI_FUSE_MAX_BLOCKS blocks).
 constexpr int CTK_MPPI_FUSE_MAX_BLOCKS = 64;     // beyond this the last block's serial record fetch costs more than a launch
@@ -40,7 +40,9 @@ hipError_t ctk_launch_mppi_update(hipStream_t st, const float* parts, int n_part
 
 // ---- ctk_sampled.hip : u[n,h] = clip(base[h] + sample[n,h] * scale[h]) rollouts, selection ----
 const char* ctk_affine_rollout_name(int pred, bool log);
-size_t ctk_affine_rollout_lds(int H);
+size_t ctk_affine_rollout_lds(int H, int pred = 0);
+// GRU: hidden <- cell(hidden, [s, u]) for the carried state behind the weight table (ctk_gru.h); u_dev NULL: u_val
+hipError_t ctk_launch_gru_advance(hipStream_t st, const float* s, const float* u_dev, float u_val, float* wperm);
 // samples [N,H] (device) or nullptr (Philox, rng_kind 0 normal / 1 uniform); base/scale [H] device.
 hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const float* samples,
                                      int rng_kind, const float* base, const float* scale, const float* wperm, bool log,

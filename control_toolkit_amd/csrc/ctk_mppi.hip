@@ -26,6 +26,7 @@
 
 #include "ctk_rollout.h"
 #include "ctk_mlp.h"
+#include "ctk_gru.h"
 #include "ctk_launch.h"
 
 constexpr int MPPI_TRAJ = 64;     // trajectories per block: one wave runs the recurrence
@@ -168,6 +169,13 @@ __global__ __launch_bounds__(MERGE_BLOCK) void ctk_mppi_merge(const float* __res
                                    out_rec ? out_rec + (size_t)blockIdx.x * (2 + P) : nullptr, up, stage_ok != 0);
 }
 
+// floats of the rollout carve (everything but the GRU weight table), rounded up so that the table that
+// follows it is 16-byte aligned
+__host__ __device__ inline int mppi_carve_floats(int P, int H) {
+    const int f = MPPI_TRAJ * tile_stride(P) + MPPI_TRAJ * ubuf_stride(H) + MPPI_WAVES * MPPI_TRAJ + MPPI_TRAJ + MPPI_WAVES * P + 4 * H;
+    return (f + 3) & ~3;
+}
+
 // In-launch tail of the rollout kernel (single-GPU, <= 256 blocks): the block whose ticket is last
 // merges all block records and applies the update, saving the second launch and its boundary.
 struct FuseArgs {
@@ -196,6 +204,7 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
     float* w1_s = w0_s + H;
     float* un_s = w1_s + H;
     int* i0_s = reinterpret_cast<int*>(un_s + H);
+    float* gru_s = lds + mppi_carve_floats(P, H);   // GRU only: [232][64] per-lane weight table (ctk_gru.h)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int row0 = blockIdx.x * MPPI_TRAJ;
     const int n = row0 + lane;
@@ -212,6 +221,7 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
             un_s[h] = u_nom[min(h + 1, H - 1)];                                    // optimizer_mppi.py:184 (shift)
         }
     });
+    if constexpr (PRED == CTK_PRED_GRU) gru_stage_weights<MPPI_BLOCK>(gru_s, wperm);
     __syncthreads();
     STAMP(1);
 
@@ -275,11 +285,17 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
             J *= a.inv_Hp1;
         }
     } else {
-        // all four waves: 16 trajectories each on the fp32 matrix cores (ctk_mlp.h)
-        const MlpFwdW w = mlp_load_fwd(wperm);
+        // all four waves: 16 trajectories each on the fp32 matrix cores (ctk_mlp.h / ctk_gru.h)
         const int tr = wave * CTK_MLP_TRAJ_PER_WAVE + (lane & 15);
         const float* myu = ubuf + tr * us;
-        const float Jw = rollout_mlp<false, LOG, false>(a, k, w, row0 + wave * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return myu[h]; });
+        float Jw;
+        if constexpr (PRED == CTK_PRED_MLP) {
+            const MlpFwdW w = mlp_load_fwd(wperm);
+            Jw = rollout_mlp<false, LOG, false>(a, k, w, row0 + wave * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return myu[h]; });
+        } else {
+            Jw = rollout_gru<false, LOG, false>(a, k, gru_s, wperm + GRU_LDS_FLOATS, row0 + wave * CTK_MLP_TRAJ_PER_WAVE,
+                                                [&](int h) { return myu[h]; });
+        }
         if (lane < 16) e_s[tr] = Jw;          // hand the 64 costs to wave 0 (e_s doubles as J scratch)
         __syncthreads();
         if (wave == 0) J = e_s[lane];
@@ -427,6 +443,7 @@ bool ctk_mppi_uses_throughput_kernel(int pred, int N) { return pred == CTK_PRED_
 const char* ctk_mppi_rollout_name(int pred, bool log, int N) {
     if (ctk_mppi_uses_throughput_kernel(pred, N)) return log ? "ctk_mppi_rollout_tp<true>" : "ctk_mppi_rollout_tp<false>";
     if (pred == CTK_PRED_ODE) return log ? "ctk_mppi_rollout<0, true>" : "ctk_mppi_rollout<0, false>";
+    if (pred == CTK_PRED_GRU) return log ? "ctk_mppi_rollout<2, true>" : "ctk_mppi_rollout<2, false>";
     return log ? "ctk_mppi_rollout<1, true>" : "ctk_mppi_rollout<1, false>";
 }
 
@@ -437,15 +454,15 @@ static size_t merge_lds(int P, int cnt) { return (size_t)(8 + P + 1 + (cnt < MER
 static size_t merge_lds_staged(int P, int cnt) { return merge_lds(P, cnt) + (size_t)cnt * (2 + P) * sizeof(float); }
 static bool merge_can_stage(int P, int cnt) { return merge_lds_staged(P, cnt) <= 64 * 1024; }
 
-size_t ctk_mppi_rollout_lds(int P, int H) {
-    const size_t roll = (size_t)(MPPI_TRAJ * tile_stride(P) + MPPI_TRAJ * ubuf_stride(H) + MPPI_WAVES * MPPI_TRAJ + MPPI_TRAJ + MPPI_WAVES * P + 4 * H) * sizeof(float);
+size_t ctk_mppi_rollout_lds(int P, int H, int pred) {
+    const size_t roll = (size_t)(mppi_carve_floats(P, H) + (pred == CTK_PRED_GRU ? GRU_LDS_FLOATS : 0)) * sizeof(float);
     const size_t tail = merge_lds(P, CTK_MPPI_FUSE_MAX_BLOCKS);
     return roll > tail ? roll : tail;
 }
 
 // LDS of one launch: the rollout carve, or the fused tail's (staged) merge scratch if larger
-static size_t rollout_launch_lds(int P, int H, int blocks, int* stage_ok) {
-    size_t lds = ctk_mppi_rollout_lds(P, H);
+static size_t rollout_launch_lds(int P, int H, int pred, int blocks, int* stage_ok) {
+    size_t lds = ctk_mppi_rollout_lds(P, H, pred);
     *stage_ok = 0;
     if (blocks <= CTK_MPPI_FUSE_MAX_BLOCKS && merge_can_stage(P, blocks)) {
         const size_t st = merge_lds_staged(P, blocks);
@@ -466,15 +483,18 @@ hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& 
         return hipGetLastError();
     }
     FuseArgs fz{};
-    const size_t lds = rollout_launch_lds(a.P, a.H, (int)grid.x, &fz.stage_ok);
+    const size_t lds = rollout_launch_lds(a.P, a.H, pred, (int)grid.x, &fz.stage_ok);
     fz.mode = fuse.mode; fz.counter = fuse.counter; fz.out_rec = fuse.out_rec;
     fz.up = MppiUpdateArgs{nullptr, nullptr, nullptr, nullptr, a.H, a.interp, u_nom, fuse.u_nom_out, a.lo, a.hi, fuse.u_dev, fuse.u_host, fuse.seq};
     if (pred == CTK_PRED_ODE) {
         if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
         else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
-    } else {
+    } else if (pred == CTK_PRED_MLP) {
         if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_MLP, true>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
         else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_MLP, false>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
+    } else {
+        if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_GRU, true>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
+        else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_GRU, false>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
     }
     return hipGetLastError();
 }

@@ -8,6 +8,7 @@
 // refit (:77-78) and the post-loop shift (:99-102).
 #include "ctk_rollout.h"
 #include "ctk_mlp.h"
+#include "ctk_gru.h"
 #include "ctk_launch.h"
 
 constexpr int SAMP_TRAJ = 64;                 // trajectories per block
@@ -17,7 +18,12 @@ constexpr int SAMP_BLOCK = SAMP_TRAJ * SAMP_WAVES;
 // Same anatomy as ctk_mppi_rollout (ctk_mppi.hip): 4-wave prologues (coalesced sample tile -> LDS; inputs
 // of all H steps, input-only cost terms, coalesced write of the plans Q), then the recurrence on one
 // wave (ODE, one trajectory per lane) or on all four (MLP, 16 trajectories per wave on MFMA).
-// LDS carve (floats): tile[64][ts] | ubuf[64][us] | cin[4][64] | base[H] | scale[H]
+// LDS carve (floats): tile[64][ts] | ubuf[64][us] | cin[4][64] | base[H] | scale[H] | (GRU) weight table
+__host__ __device__ inline int affine_carve_floats(int H) {
+    const int f = SAMP_TRAJ * tile_stride(H) + SAMP_TRAJ * ((H + 1) | 1) + SAMP_WAVES * SAMP_TRAJ + 2 * H;
+    return (f + 3) & ~3;
+}
+
 template <int PRED, bool TRAJ>
 __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(RolloutArgs a, EnvK k, const float* __restrict__ samples,
                                                                  int rng_kind, const float* __restrict__ base,
@@ -30,6 +36,7 @@ __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(RolloutArgs a, 
     float* cin_s = ubuf + SAMP_TRAJ * us;
     float* base_s = cin_s + SAMP_WAVES * SAMP_TRAJ;
     float* scale_s = base_s + H;
+    float* gru_s = lds + affine_carve_floats(H);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int row0 = blockIdx.x * SAMP_TRAJ;
     const int n = row0 + lane;
@@ -38,6 +45,7 @@ __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(RolloutArgs a, 
     load_tile_early<SAMP_TRAJ, SAMP_BLOCK>(tile, samples, a, row0, 1.0f, rng_kind, [&] {
         for (int h = t; h < H; h += SAMP_BLOCK) { base_s[h] = base[h]; scale_s[h] = scale[h]; }
     });
+    if constexpr (PRED == CTK_PRED_GRU) gru_stage_weights<SAMP_BLOCK>(gru_s, wperm);
     __syncthreads();
 
     {   // inputs of all H steps + input-only stage-cost terms; wave w takes a contiguous chunk of steps
@@ -81,13 +89,46 @@ __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(RolloutArgs a, 
             if (valid) a.J[n] = J * a.inv_Hp1;
         }
     } else {
-        const MlpFwdW w = mlp_load_fwd(wperm);
         const int tr = wave * CTK_MLP_TRAJ_PER_WAVE + (lane & 15);
         const float* myu = ubuf + tr * us;
-        float J = rollout_mlp<false, TRAJ, false>(a, k, w, row0 + wave * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return myu[h]; });
+        float J;
+        if constexpr (PRED == CTK_PRED_MLP) {
+            const MlpFwdW w = mlp_load_fwd(wperm);
+            J = rollout_mlp<false, TRAJ, false>(a, k, w, row0 + wave * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return myu[h]; });
+        } else {
+            J = rollout_gru<false, TRAJ, false>(a, k, gru_s, wperm + GRU_LDS_FLOATS, row0 + wave * CTK_MLP_TRAJ_PER_WAVE,
+                                                [&](int h) { return myu[h]; });
+        }
         J += ((cin_s[tr] + cin_s[SAMP_TRAJ + tr]) + (cin_s[2 * SAMP_TRAJ + tr] + cin_s[3 * SAMP_TRAJ + tr])) * a.inv_Hp1;
         if (lane < 16 && row0 + tr < a.N) a.J[row0 + tr] = J;
     }
+}
+
+// predictor.update(s, Q0) for the GRU (optimizer_mppi.py:195-197): one wave; all 16 MFMA columns carry
+// the same (s, u); the weights stream from memory (one step: no point staging them); the lanes of column 0
+// write the new hidden state back in place (table | hidden, see ctk_api.hip:permute_gru_weights).
+__global__ __launch_bounds__(64) void ctk_gru_advance(float s0, float s1, float s2, float s3, const float* __restrict__ u_dev,
+                                                      float u_val, float* __restrict__ wperm) {
+    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+    float* hidden = wperm + GRU_LDS_FLOATS;
+    GruState st = gru_load_state(hidden, g);
+    const float sv = g == 0 ? s0 : (g == 1 ? s1 : (g == 2 ? s2 : s3));
+    const float u = u_dev ? *u_dev : u_val;
+    (void)gru_step(wperm + lane, st, sv, u, g);
+    if (c == 0) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                hidden[16 * m + 4 * g + r] = st.h1[m][r];
+                hidden[32 + 16 * m + 4 * g + r] = st.h2[m][r];
+            }
+    }
+}
+
+hipError_t ctk_launch_gru_advance(hipStream_t st, const float* s, const float* u_dev, float u_val, float* wperm) {
+    hipLaunchKernelGGL(ctk_gru_advance, dim3(1), dim3(64), 0, st, s[0], s[1], s[2], s[3], u_dev, u_val, wperm);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -281,6 +322,7 @@ __global__ __launch_bounds__(256) void ctk_pack_candidates(const float* __restri
 // ---------------------------------------------------------------------------------------------
 const char* ctk_affine_rollout_name(int pred, bool log) {
     if (pred == CTK_PRED_ODE) return log ? "ctk_affine_rollout<0, true>" : "ctk_affine_rollout<0, false>";
+    if (pred == CTK_PRED_GRU) return log ? "ctk_affine_rollout<2, true>" : "ctk_affine_rollout<2, false>";
     return log ? "ctk_affine_rollout<1, true>" : "ctk_affine_rollout<1, false>";
 }
 
@@ -288,19 +330,22 @@ hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs
                                      int rng_kind, const float* base, const float* scale, const float* wperm, bool log,
                                      hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid((a.N + SAMP_TRAJ - 1) / SAMP_TRAJ), block(SAMP_BLOCK);
-    const size_t lds = ctk_affine_rollout_lds(a.H);
+    const size_t lds = ctk_affine_rollout_lds(a.H, pred);
     if (pred == CTK_PRED_ODE) {
         if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
         else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
-    } else {
+    } else if (pred == CTK_PRED_MLP) {
         if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_MLP, true>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
         else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_MLP, false>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
+    } else {
+        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_GRU, true>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
+        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_GRU, false>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
     }
     return hipGetLastError();
 }
 
-size_t ctk_affine_rollout_lds(int H) {
-    return (size_t)(SAMP_TRAJ * tile_stride(H) + SAMP_TRAJ * ((H + 1) | 1) + SAMP_WAVES * SAMP_TRAJ + 2 * H) * sizeof(float);
+size_t ctk_affine_rollout_lds(int H, int pred) {
+    return (size_t)(affine_carve_floats(H) + (pred == CTK_PRED_GRU ? GRU_LDS_FLOATS : 0)) * sizeof(float);
 }
 
 hipError_t ctk_launch_select_topk(hipStream_t st, const float* J, int N, int K, int* idx_out, int ldj) {

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CTK_ABI_VERSION 1
+#define CTK_ABI_VERSION 2
 
 typedef struct ctk_handle ctk_handle;
 
@@ -59,7 +59,12 @@ typedef enum ctk_optimizer {
  * (Controllers/controller_mpc.py:67-73): "ODE" or a network name                              */
 typedef enum ctk_predictor {
     CTK_PRED_ODE = 0, /* analytic cart-pole, explicit Euler, VALU, one thread per trajectory   */
-    CTK_PRED_MLP = 1  /* 5-32-32-4 tanh MLP, fp32 MFMA (v_mfma_f32_16x16x4_f32), 16 traj./wave */
+    CTK_PRED_MLP = 1, /* 5-32-32-4 tanh MLP, fp32 MFMA (v_mfma_f32_16x16x4_f32), 16 traj./wave */
+    CTK_PRED_GRU = 2  /* 2x32 GRU + dense 32->4 (network-name convention 'GRU-..-32H1-32H2-..',
+                         Control_Toolkit_ASF_Template/config_controllers.yml:8), fp32 MFMA, weights in LDS;
+                         carries a hidden state across MPC steps (ctk_predictor_update).  Forward path only:
+                         the sampling optimizers (MPPI, CEM, random-action) and ctk_rollout; the
+                         gradient-based optimizers reject it with CTK_ERR_UNSUPPORTED.                   */
 } ctk_predictor;
 
 /* Environment / cost parameters.  Replaces template_controller.update_attributes
@@ -155,8 +160,23 @@ int ctk_set_stream(ctk_handle* h, void* hip_stream);
  * ----------------------------------------------------------------------------------------- */
 int ctk_set_param(ctk_handle* h, int id, float value);
 int ctk_get_param(const ctk_handle* h, int id, float* value);
-/* MLP weights, flat fp32: W1[32,5] b1[32] W2[32,32] b2[32] W3[4,32] b3[4] (1380 floats)      */
+/* Network weights, flat fp32.
+ *   MLP: W1[32,5] b1[32] W2[32,32] b2[32] W3[4,32] b3[4]                       (1380 floats)
+ *   GRU: per layer W_i[96,I] W_h[96,32] b_i[96] b_h[96] (rows r|z|n, I = 5 then 32), then
+ *        W_o[4,32] b_o[4]                                                        (10212 floats)
+ * Uploading GRU weights also zeroes the carried hidden state.                                 */
 int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n);
+
+/* Recurrent predictor state (GRU): [2,32] fp32, the state every rollout starts from.
+ * ctk_predictor_update = predictor.update(s, Q0) (optimizer_mppi.py:195-197): advance it by the measured
+ * state s[4] and the applied input u[1] (NULL: the optimizer's last output, still on the device).
+ * ctk_step of an MPPI handle does this itself after the nominal-plan update (optimizer_mppi.py:192),
+ * CEM / random-action never do (optimizer_cem_tf.py, optimizer_random_action_tf.py have no such call).
+ * Non-recurrent predictors: size 0, update is a no-op, get/set reject.                          */
+size_t ctk_predictor_hidden_size(const ctk_handle* h);
+int ctk_predictor_update(ctk_handle* h, const float* s, const float* u);
+int ctk_predictor_get_hidden(ctk_handle* h, float* dst, size_t cap);
+int ctk_predictor_set_hidden(ctk_handle* h, const float* src, size_t n); /* src NULL: zeros */
 
 /* -------------------------------------------------------------------------------------------
  * the hot path: optimizer.step(s, time) -> u   (Optimizers/__init__.py:67)

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libctk_hip.so does not export {n}"
     assert set(names) == set(SYMBOLS), "ctypes binding and header disagree"
-    assert lib.ctk_abi_version() == 1
+    assert lib.ctk_abi_version() == 2
     assert os.path.dirname(library_path()).endswith("control_toolkit_amd")   # in-tree, not site-packages
 
 
@@ -60,7 +60,7 @@ def test_engine_fails_loudly_without_gpu():
     with pytest.raises(ValueError):
         CtkEngine("nope", "ODE", num_rollouts=32, mpc_horizon=10, dt=0.02)
     with pytest.raises(NotImplementedError):
-        CtkEngine("mppi", "GRU-6IN-32H1-32H2-5OUT-0", num_rollouts=32, mpc_horizon=10, dt=0.02)
+        CtkEngine("mppi", "LSTM-6IN-32H1-32H2-5OUT-0", num_rollouts=32, mpc_horizon=10, dt=0.02)
 
 
 def test_product_never_imports_the_oracle():
@@ -108,7 +108,12 @@ def test_hip_library_gate_and_optimizer_discovery():
     r = create_rng("x", 3, lib, mode="host")
     assert r.normal([4, 2, 1]).shape == (4, 2, 1) and 0 <= r.uniform([3]).min() < 1
     with pytest.raises(NotImplementedError):
-        PredictorWrapper().configure(batch_size=1, dt=0.02, predictor_specification="GRU-6IN-32H1-32H2-5OUT-0")
+        PredictorWrapper().configure(batch_size=1, dt=0.02, predictor_specification="LSTM-6IN-32H1-32H2-5OUT-0")
+    with pytest.raises(ValueError):
+        PredictorWrapper().configure(batch_size=1, dt=0.02, predictor_specification="GRU-6IN-32H1-32H2-5OUT-0")   # no weights
+    g = PredictorWrapper(weights=np.zeros(10212, np.float32))
+    g.configure(batch_size=1, dt=0.02, predictor_specification="GRU-6IN-32H1-32H2-5OUT-0")
+    assert g.kind == "GRU"
     with pytest.raises(ValueError):
         PredictorWrapper().configure(batch_size=1, dt=0.02, predictor_specification="MLP")   # no weights
 
