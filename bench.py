@@ -163,6 +163,12 @@ def main():
     ap.add_argument("--force-sharded", action="store_true", help="use the begin / all-gather / end path even with one rank")
     args = ap.parse_args()
 
+    # Contract: ONE JSON line on stdout.  Native libraries write banners to fd 1 (RCCL prints its version block
+    # there at communicator init), so everything but the result line goes to stderr.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from control_toolkit_amd import CtkEngine
@@ -179,7 +185,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # rehearsal hook: a ONE-rank RCCL group with the collective actually issued, to exercise the RCCL call path
+    # (init, all_gather_into_tensor / all_reduce / barrier on torch's stream) on a one-GPU box
+    force_pg = os.environ.get("CTK_BENCH_FORCE_PG") == "1"
+    if world > 1 or force_pg:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -198,10 +207,10 @@ def main():
         eng.set_predictor_weights(gru_weights(0))
     P = eng.mppi_partial_size() - 2
     sharded = None
-    if world > 1 or args.force_sharded:
+    if world > 1 or args.force_sharded or force_pg:
         # the collective runs on torch's stream: issue the engine's kernels there too
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
-        sharded = ShardedMPPI(eng, rank, world, device=dev)
+        sharded = ShardedMPPI(eng, rank, world, device=dev, always_collective=force_pg)
     if w["opt"] == "rpgd":
         eng.reset()
 
@@ -225,7 +234,7 @@ def main():
     # launch costs ~8 us of host time (measured), so timing all of them would distort the metric
     prof_every = 1 if args.steps < 40 else 8
     eng.profile_enable(True, every=prof_every)
-    if world > 1:
+    if world > 1 or force_pg:
         dist.barrier()
     torch.cuda.synchronize()
     per_step = np.empty(args.steps)
@@ -235,14 +244,14 @@ def main():
         plant_step(s, step_fn(s, ptrs[i & 15])[0])        # controller.step, then the plant: closed loop
         tb = time.perf_counter(); per_step[i] = tb - ta; ta = tb
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force_pg:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = eng.profile_read()
     eng.profile_enable(False)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if world > 1 or force_pg:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -255,7 +264,9 @@ def main():
             ach = alg_flops / (kms * 1e-3) / 1e12 if ok else None
             roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                     "frac": ach / MFMA_F32_PEAK_TF if ach else None, "traffic": None, "algorithmic_flops": alg_flops,
-                    "note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32) for exact-fp32 parity; 16 trajectories per wave"}
+                    "note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32) for exact-fp32 parity; "
+                            + ("16 trajectories per workgroup, the GRU step split over its 4 waves (ctk_gru.h); latency-bound: "
+                               "64 workgroups on 256 CUs at this size" if w["pred"] == "GRU" else "16 trajectories per wave")}
         else:
             ach = alg_bytes / (kms * 1e-3) / 1e9 if ok else None
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -282,9 +293,10 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w)
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    os.close(result_fd)
     eng.close()
-    if world > 1:
+    if world > 1 or force_pg:
         dist.destroy_process_group()
 
 

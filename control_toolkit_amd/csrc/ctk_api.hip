@@ -179,44 +179,39 @@ std::vector<float> permute_mlp_weights(const float* raw) {
     return out;
 }
 
-// Per-lane MFMA operand table of the GRU weights (ctk_gru.h header comment): out[index][lane].
+// Per-lane MFMA operands of the GRU weights for the four waves of a workgroup (ctk_gru.h header comment and
+// struct GruW): out[wave][lane][72].  Wave (m, q) = wave index 2m + q owns hidden-unit tile m; its A rows are the
+// r (q = 0) or z (q = 1) rows, its B rows the n rows (input products for q = 0, recurrent products for q = 1).
 // raw: per layer W_i[96,I] W_h[96,32] b_i[96] b_h[96] (rows r|z|n), then W_o[4,32] b_o[4].
 std::vector<float> permute_gru_weights(const float* raw) {
-    std::vector<float> out((size_t)GRU_LDS_FLOATS, 0.0f);
-    const float* p = raw;
-    for (int l = 0; l < 64; ++l) {
-        const int i = l & 15, g = l >> 4;
-        auto put = [&](int idx, float v) { out[(size_t)idx * 64 + l] = v; };
-        const float* q = raw;
-        for (int L = 0; L < 2; ++L) {
-            const int I = L == 0 ? CTK_MLP_IN : 32, KS = L == 0 ? 2 : 8;
-            const float* Wi = q;              const float* Wh = Wi + 96 * I;
-            const float* bi = Wh + 96 * 32;   const float* bh = bi + 96;
-            q = bh + 96;
-            const int ih_base = L == 0 ? GRU_W_L1_IH : GRU_W_L2_IH, hh_base = L == 0 ? GRU_W_L1_HH : GRU_W_L2_HH;
-            for (int gate = 0; gate < 3; ++gate)
-                for (int m = 0; m < 2; ++m) {
-                    const int row = 32 * gate + 16 * m + i;
-                    for (int ks = 0; ks < KS; ++ks) {
-                        const int kk = L == 0 ? 4 * ks + g : mlp_hid(ks, g);
-                        put(ih_base + (gate * 2 + m) * KS + ks, (L == 0 && kk >= CTK_MLP_IN) ? 0.0f : Wi[row * I + kk]);
-                    }
-                    for (int j = 0; j < 8; ++j) put(hh_base + (gate * 2 + m) * 8 + j, Wh[row * 32 + mlp_hid(j, g)]);
-                }
-            for (int m = 0; m < 2; ++m)
+    std::vector<float> out((size_t)GRU_TABLE_FLOATS, 0.0f);
+    for (int wv = 0; wv < 4; ++wv)
+        for (int l = 0; l < 64; ++l) {
+            const int m = wv >> 1, q = wv & 1, i = l & 15, g = l >> 4;
+            float* e = out.data() + (size_t)(wv * 64 + l) * GRU_W_PER_LANE;
+            const float* p = raw;
+            for (int L = 0; L < 2; ++L) {
+                const int I = L == 0 ? CTK_MLP_IN : 32, KS = L == 0 ? 2 : 8, base = L == 0 ? 0 : 18;
+                const float* Wi = p;              const float* Wh = Wi + 96 * I;
+                const float* bi = Wh + 96 * 32;   const float* bh = bi + 96;
+                p = bh + 96;
+                const int rowA = 32 * q + 16 * m + i, rowN = 64 + 16 * m + i;
+                auto kk = [&](int ks) { return L == 0 ? 4 * ks + g : mlp_hid(ks, g); };
+                auto wi = [&](int row, int ks) { return (L == 0 && kk(ks) >= CTK_MLP_IN) ? 0.0f : Wi[row * I + kk(ks)]; };
+                for (int ks = 0; ks < KS; ++ks) e[base + ks] = wi(rowA, ks);
+                for (int j = 0; j < 8; ++j) e[base + KS + j] = Wh[rowA * 32 + mlp_hid(j, g)];
+                if (q == 0) for (int ks = 0; ks < KS; ++ks) e[base + KS + 8 + ks] = wi(rowN, ks);
+                else for (int j = 0; j < 8; ++j) e[base + KS + 8 + j] = Wh[rowN * 32 + mlp_hid(j, g)];
                 for (int r = 0; r < 4; ++r) {
-                    const int unit = 16 * m + 4 * g + r, b0 = GRU_W_BIAS + L * 32 + m * 4 + r;
-                    put(b0 + 0, bi[unit] + bh[unit]);              // r gate: both biases feed one accumulator
-                    put(b0 + 8, bi[32 + unit] + bh[32 + unit]);    // z gate
-                    put(b0 + 16, bi[64 + unit]);                   // n gate, input part
-                    put(b0 + 24, bh[64 + unit]);                   // n gate, hidden part (scaled by r)
+                    const int unit = 16 * m + 4 * g + r;
+                    e[50 + 8 * L + r] = bi[32 * q + unit] + bh[32 * q + unit];   // r or z: both biases feed one accumulator
+                    e[54 + 8 * L + r] = q == 0 ? bi[64 + unit] : bh[64 + unit];  // n: input part / recurrent part (scaled by r)
                 }
+            }
+            const float* Wo = p; const float* bo = Wo + 4 * 32;
+            for (int j = 0; j < 8; ++j) e[42 + j] = (i % 4 == 0) ? Wo[(i / 4) * 32 + mlp_hid(j, g)] : 0.0f;
+            for (int r = 0; r < 4; ++r) e[66 + r] = r == 0 ? bo[g] : 0.0f;
         }
-        const float* Wo = q; const float* bo = Wo + 4 * 32;
-        for (int j = 0; j < 8; ++j) put(GRU_W_OUT + j, (i % 4 == 0) ? Wo[(i / 4) * 32 + mlp_hid(j, g)] : 0.0f);
-        for (int r = 0; r < 4; ++r) put(GRU_W_BIAS + 64 + r, r == 0 ? bo[g] : 0.0f);
-    }
-    (void)p;
     return out;
 }
 
@@ -337,7 +332,7 @@ int check_predictor(ctk_handle* h) {
 }
 
 // ---- MPPI ------------------------------------------------------------------------------------
-int mppi_block_parts(const ctk_handle* h) { return ctk_mppi_num_blocks(h->N); }
+int mppi_block_parts(const ctk_handle* h) { return ctk_mppi_num_blocks(h->N, h->cfg.predictor); }
 bool mppi_can_fuse(const ctk_handle* h) {
     return mppi_block_parts(h) <= CTK_MPPI_FUSE_MAX_BLOCKS && !ctk_mppi_uses_throughput_kernel(h->cfg.predictor, h->N);
 }
@@ -675,7 +670,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     TRY_CREATE(dev_alloc(h, &h->d_J, N));
     TRY_CREATE(dev_alloc(h, &h->d_Q, N * H));
     if (cfg->materialize_trajectories) TRY_CREATE(dev_alloc(h, &h->d_traj, N * (H + 1) * CTK_S));
-    const size_t nblk = (N + 63) / 64;
+    const size_t nblk = (size_t)ctk_mppi_num_blocks((int)N, cfg->predictor);
     h->parts_cap = nblk * (2 + P);
     TRY_CREATE(dev_alloc(h, &h->d_parts, h->parts_cap));
     TRY_CREATE(dev_alloc(h, &h->d_parts2, ((nblk + 31) / 32) * (2 + P)));
@@ -689,7 +684,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     TRY_CREATE(dev_alloc(h, &h->d_idx, N));
     TRY_CREATE(dev_alloc(h, &h->d_u, 1));
     TRY_CREATE(dev_alloc(h, &h->d_weights, cfg->predictor == CTK_PRED_GRU ? GRU_NW_RAW : CTK_MLP_NW));
-    TRY_CREATE(dev_alloc(h, &h->d_wperm, cfg->predictor == CTK_PRED_GRU ? (size_t)GRU_LDS_FLOATS + GRU_HIDDEN_FLOATS
+    TRY_CREATE(dev_alloc(h, &h->d_wperm, cfg->predictor == CTK_PRED_GRU ? (size_t)GRU_TABLE_FLOATS + GRU_HIDDEN_FLOATS
                                                                           : (size_t)64 * (MLP_FWD_PER_LANE + MLP_BWD_PER_LANE)));
     HIP_CREATE(hipHostMalloc((void**)&h->h_u, 64, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(h->h_u, 0, 64);
@@ -803,7 +798,7 @@ int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n) {
         return fail(h, CTK_ERR_INVALID_ARGUMENT, gru ? "ctk_set_predictor_weights: expected 10212 floats (GRU)" : "ctk_set_predictor_weights: expected 1380 floats (MLP)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipMemcpyAsync(h->d_weights, w, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    if (gru) HIP_TRY(h, hipMemsetAsync(h->d_wperm + GRU_LDS_FLOATS, 0, GRU_HIDDEN_FLOATS * sizeof(float), h->stream));
+    if (gru) HIP_TRY(h, hipMemsetAsync(h->d_wperm + GRU_TABLE_FLOATS, 0, GRU_HIDDEN_FLOATS * sizeof(float), h->stream));
     const std::vector<float> perm = gru ? permute_gru_weights(w) : permute_mlp_weights(w);
     HIP_TRY(h, hipMemcpyAsync(h->d_wperm, perm.data(), perm.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -827,7 +822,7 @@ int ctk_predictor_get_hidden(ctk_handle* h, float* dst, size_t cap) {
     if (h->cfg.predictor != CTK_PRED_GRU) return fail(h, CTK_ERR_STATE, "ctk_predictor_get_hidden: predictor has no hidden state");
     if (cap < (size_t)GRU_HIDDEN_FLOATS) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_predictor_get_hidden: need room for 64 floats");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    HIP_TRY(h, hipMemcpyAsync(dst, h->d_wperm + GRU_LDS_FLOATS, GRU_HIDDEN_FLOATS * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(dst, h->d_wperm + GRU_TABLE_FLOATS, GRU_HIDDEN_FLOATS * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CTK_OK;
 }
@@ -837,8 +832,8 @@ int ctk_predictor_set_hidden(ctk_handle* h, const float* src, size_t n) {
     if (h->cfg.predictor != CTK_PRED_GRU) return fail(h, CTK_ERR_STATE, "ctk_predictor_set_hidden: predictor has no hidden state");
     if (src && n != (size_t)GRU_HIDDEN_FLOATS) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_predictor_set_hidden: expected 64 floats");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    if (src) HIP_TRY(h, hipMemcpyAsync(h->d_wperm + GRU_LDS_FLOATS, src, GRU_HIDDEN_FLOATS * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    else HIP_TRY(h, hipMemsetAsync(h->d_wperm + GRU_LDS_FLOATS, 0, GRU_HIDDEN_FLOATS * sizeof(float), h->stream));
+    if (src) HIP_TRY(h, hipMemcpyAsync(h->d_wperm + GRU_TABLE_FLOATS, src, GRU_HIDDEN_FLOATS * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    else HIP_TRY(h, hipMemsetAsync(h->d_wperm + GRU_TABLE_FLOATS, 0, GRU_HIDDEN_FLOATS * sizeof(float), h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CTK_OK;
 }

@@ -13,7 +13,7 @@
 
 // ---- ctk_mppi.hip ---------------------------------------------------------------------------
 const char* ctk_mppi_rollout_name(int pred, bool log, int N);
-int ctk_mppi_num_blocks(int N);
+int ctk_mppi_num_blocks(int N, int pred);   // workgroups = block records of one rollout launch (64 trajectories each; GRU: 16)
 bool ctk_mppi_uses_throughput_kernel(int pred, int N);
 size_t ctk_mppi_rollout_lds(int P, int H, int pred = 0);
 // wperm: per-lane permuted MLP weights (ctk_api.hip: permute_mlp_weights), nullptr for the ODE predictor

@@ -169,12 +169,15 @@ __global__ __launch_bounds__(MERGE_BLOCK) void ctk_mppi_merge(const float* __res
                                    out_rec ? out_rec + (size_t)blockIdx.x * (2 + P) : nullptr, up, stage_ok != 0);
 }
 
-// floats of the rollout carve (everything but the GRU weight table), rounded up so that the table that
-// follows it is 16-byte aligned
-__host__ __device__ inline int mppi_carve_floats(int P, int H) {
-    const int f = MPPI_TRAJ * tile_stride(P) + MPPI_TRAJ * ubuf_stride(H) + MPPI_WAVES * MPPI_TRAJ + MPPI_TRAJ + MPPI_WAVES * P + 4 * H;
+// floats of the rollout carve (everything but the GRU exchange slots), rounded up so that what follows is
+// 16-byte aligned.
+// traj = trajectories per workgroup: 64 (ODE: one wave runs them, one per lane; MLP: 16 per wave) or
+// GRU_TRAJ = 16 (GRU: the four waves share one 16-trajectory MFMA column block, ctk_gru.h)
+__host__ __device__ inline int mppi_carve_floats(int P, int H, int traj) {
+    const int f = traj * tile_stride(P) + traj * ubuf_stride(H) + MPPI_BLOCK + traj + MPPI_WAVES * P + 4 * H;
     return (f + 3) & ~3;
 }
+__host__ __device__ inline int mppi_traj(int pred) { return pred == CTK_PRED_GRU ? GRU_TRAJ : MPPI_TRAJ; }
 
 // In-launch tail of the rollout kernel (single-GPU, <= 256 blocks): the block whose ticket is last
 // merges all block records and applies the update, saving the second launch and its boundary.
@@ -194,44 +197,50 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
                                                                const float* __restrict__ wperm,
                                                                float* __restrict__ parts, FuseArgs fz) {
     extern __shared__ float lds[];
+    constexpr int TRAJ = (PRED == CTK_PRED_GRU) ? GRU_TRAJ : MPPI_TRAJ;   // trajectories of this workgroup
+    constexpr int CHUNKS = MPPI_BLOCK / TRAJ;                             // horizon chunks of prologue 2 (4 / 16)
+    constexpr int RPW = TRAJ / MPPI_WAVES;                                // tile rows per wave in the epilogue
     const int P = a.P, H = a.H, ts = tile_stride(P), us = ubuf_stride(H);
-    float* tile = lds;                         // [64][ts]  stdev * noise at the inducing points
-    float* ubuf = tile + MPPI_TRAJ * ts;       // [64][us]  clipped inputs u_run
-    float* corr_s = ubuf + MPPI_TRAJ * us;     // [4][64]   per-wave partial MPPI correction costs
-    float* e_s = corr_s + MPPI_WAVES * MPPI_TRAJ;   // [64]
-    float* col_s = e_s + MPPI_TRAJ;            // [4][P]    per-wave partial column sums
+    float* tile = lds;                         // [TRAJ][ts]  stdev * noise at the inducing points
+    float* ubuf = tile + TRAJ * ts;            // [TRAJ][us]  clipped inputs u_run
+    float* corr_s = ubuf + TRAJ * us;          // [CHUNKS][TRAJ] per-chunk partial MPPI correction costs
+    float* e_s = corr_s + MPPI_BLOCK;          // [TRAJ]
+    float* col_s = e_s + TRAJ;                 // [4][P]    per-wave partial column sums
     float* w0_s = col_s + MPPI_WAVES * P;      // [H] [H] [H] [H]  per-step tables
     float* w1_s = w0_s + H;
     float* un_s = w1_s + H;
     int* i0_s = reinterpret_cast<int*>(un_s + H);
-    float* gru_s = lds + mppi_carve_floats(P, H);   // GRU only: [232][64] per-lane weight table (ctk_gru.h)
+    float* gru_ex = lds + mppi_carve_floats(P, H, TRAJ);   // GRU only: exchange slots of the four waves (ctk_gru.h)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int row0 = blockIdx.x * MPPI_TRAJ;
-    const int n = row0 + lane;
-    const bool valid = n < a.N;
+    const int row0 = blockIdx.x * TRAJ;
+    const int n = row0 + lane;                 // wave 0's view: lane = trajectory of the workgroup
+    const bool valid = lane < TRAJ && n < a.N;
 
     const uint32_t ka_sink = kernarg_prefetch<sizeof(RolloutArgs) + sizeof(EnvK) + sizeof(MppiK) + 5 * sizeof(void*) + sizeof(FuseArgs)>();
     STAMP(0);
     // ---- prologue 1 (256 threads): per-step tables (interpolation entry, shifted nominal input) and
     //      the sample tile (coalesced HBM read or Philox draw) into LDS ------------------------------
-    load_tile_early<MPPI_TRAJ, MPPI_BLOCK>(tile, samples, a, row0, m.stdev, /*normal*/ 0, [&] {
+    load_tile_early<TRAJ, MPPI_BLOCK>(tile, samples, a, row0, m.stdev, /*normal*/ 0, [&] {
         for (int h = t; h < H; h += MPPI_BLOCK) {           // issued while the sample loads are in flight
             const InterpEntry e = interp[h];
             i0_s[h] = e.i0; w0_s[h] = e.w0; w1_s[h] = e.w1;
             un_s[h] = u_nom[min(h + 1, H - 1)];                                    // optimizer_mppi.py:184 (shift)
         }
     });
-    if constexpr (PRED == CTK_PRED_GRU) gru_stage_weights<MPPI_BLOCK>(gru_s, wperm);
     __syncthreads();
     STAMP(1);
 
     // ---- prologue 2 (256 threads): everything that depends on the inputs only, for all H steps, off
     //      the recurrence's critical path: interpolate, add the shifted nominal, clip (-> u_run), the
-    //      MPPI control-cost correction and the input-only stage-cost terms (cc + ccrc).  Wave w takes
-    //      the contiguous steps [w*Hc, (w+1)*Hc) so that u[h-1] is at hand (recomputed once per chunk).
-    //      ubuf receives u (MLP) or the force u_max*u (ODE).
+    //      MPPI control-cost correction and the input-only stage-cost terms (cc + ccrc).  Thread (trajectory
+    //      t % TRAJ, chunk t / TRAJ — lane and wave when TRAJ = 64) takes the contiguous steps [chunk*Hc,
+    //      (chunk+1)*Hc) so that u[h-1] is at hand (recomputed once per chunk).
+    //      ubuf receives u (MLP, GRU) or the force u_max*u (ODE).
     {
-        const float* my = tile + lane * ts;
+        const int ptraj = t % TRAJ, chunk = t / TRAJ;
+        const int pn = row0 + ptraj;
+        const bool pvalid = pn < a.N;
+        const float* my = tile + ptraj * ts;
         const bool ident = a.identity_interp != 0;
         auto input_at = [&](int h, float& du) {
             if (ident) {
@@ -242,8 +251,8 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
             }
             return fminf(fmaxf(un_s[h] + du, a.lo), a.hi);            // optimizer_mppi.py:186-187
         };
-        const int Hc = (H + MPPI_WAVES - 1) / MPPI_WAVES;
-        const int h0 = wave * Hc, h1 = min(H, h0 + Hc);
+        const int Hc = (H + CHUNKS - 1) / CHUNKS;
+        const int h0 = chunk * Hc, h1 = min(H, h0 + Hc);
         float corr = 0.0f, cin = 0.0f, dummy;
         float uprev = (h0 == 0 || h0 >= H) ? (a.u_prev_dev ? *a.u_prev_dev : a.u_prev) : input_at(h0 - 1, dummy);
 #pragma unroll 2
@@ -253,13 +262,13 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
             corr += m.cc * (m.k_dd * (du * du) + m.R * u * du + m.k_uu * (u * u));   // :154-155
             cin += stage_cost_input(k, u, uprev);
             uprev = u;
-            ubuf[lane * us + h] = (PRED == CTK_PRED_ODE) ? k.u_max * u : u;
+            ubuf[ptraj * us + h] = (PRED == CTK_PRED_ODE) ? k.u_max * u : u;
             if constexpr (LOG) {
-                if (valid) a.Q_out[(size_t)n * H + h] = u;
+                if (pvalid) a.Q_out[(size_t)pn * H + h] = u;
             }
         }
         // mean over H+1 applies to the stage costs, not to the MPPI correction (optimizer_mppi.py:158-161)
-        corr_s[wave * MPPI_TRAJ + lane] = corr + cin * a.inv_Hp1;
+        corr_s[chunk * TRAJ + ptraj] = corr + cin * a.inv_Hp1;
     }
     __syncthreads();
     STAMP(2);
@@ -284,32 +293,38 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
 #endif
             J *= a.inv_Hp1;
         }
-    } else {
-        // all four waves: 16 trajectories each on the fp32 matrix cores (ctk_mlp.h / ctk_gru.h)
+    } else if constexpr (PRED == CTK_PRED_MLP) {
+        // all four waves: 16 trajectories each on the fp32 matrix cores (ctk_mlp.h)
         const int tr = wave * CTK_MLP_TRAJ_PER_WAVE + (lane & 15);
         const float* myu = ubuf + tr * us;
-        float Jw;
-        if constexpr (PRED == CTK_PRED_MLP) {
-            const MlpFwdW w = mlp_load_fwd(wperm);
-            Jw = rollout_mlp<false, LOG, false>(a, k, w, row0 + wave * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return myu[h]; });
-        } else {
-            Jw = rollout_gru<false, LOG, false>(a, k, gru_s, wperm + GRU_LDS_FLOATS, row0 + wave * CTK_MLP_TRAJ_PER_WAVE,
-                                                [&](int h) { return myu[h]; });
-        }
+        const MlpFwdW w = mlp_load_fwd(wperm);
+        const float Jw = rollout_mlp<false, LOG, false>(a, k, w, row0 + wave * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return myu[h]; });
         if (lane < 16) e_s[tr] = Jw;          // hand the 64 costs to wave 0 (e_s doubles as J scratch)
         __syncthreads();
         if (wave == 0) J = e_s[lane];
         __syncthreads();
+    } else {
+        // the four waves share the workgroup's 16 trajectories (ctk_gru.h); wave 0 ends with J of trajectory
+        // lane & 15 in every lane, i.e. lane = trajectory for lanes 0..15
+        const float* myu = ubuf + (lane & 15) * us;
+        J = rollout_gru<LOG, false>(a, k, wperm, wperm + GRU_TABLE_FLOATS, gru_ex, row0, [&](int h) { return myu[h]; });
     }
     if (wave == 0) {
-        J += (corr_s[lane] + corr_s[MPPI_TRAJ + lane]) + (corr_s[2 * MPPI_TRAJ + lane] + corr_s[3 * MPPI_TRAJ + lane]);
+        if constexpr (TRAJ == MPPI_TRAJ) {
+            J += (corr_s[lane] + corr_s[TRAJ + lane]) + (corr_s[2 * TRAJ + lane] + corr_s[3 * TRAJ + lane]);
+        } else {
+            float cs = 0.0f;
+#pragma unroll
+            for (int cnk = 0; cnk < CHUNKS; ++cnk) cs += corr_s[cnk * TRAJ + (lane & (TRAJ - 1))];
+            J += cs;
+        }
         STAMP(3);
         if (valid) a.J[n] = J;
         // block-local soft-min partial (optimizer_mppi.py:163-168 restricted to this block)
         const float rho = wave_min(valid ? J : INFINITY);
         const float e = valid ? expf(m.neg_inv_lbd * (J - rho)) : 0.0f;
         const float asum = wave_sum(e);
-        e_s[lane] = e;
+        if (lane < TRAJ) e_s[lane] = e;
         if (lane == 0) {
             float* rec = parts + (size_t)blockIdx.x * (2 + P);
             st_rec(rec, rho); st_rec(rec + 1, asum);
@@ -318,11 +333,11 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
     __syncthreads();
     STAMP(4);
 
-    // ---- epilogue (256 threads): b_b[p] = sum_r e_r * tile[r][p]; wave w sums rows 16w..16w+15 -----
+    // ---- epilogue (256 threads): b_b[p] = sum_r e_r * tile[r][p]; wave w sums rows RPW*w..RPW*w+RPW-1 ----
     for (int p = lane; p < P; p += 64) {
         float acc = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc += e_s[wave * 16 + r] * tile[(wave * 16 + r) * ts + p];
+        for (int r = 0; r < RPW; ++r) acc += e_s[wave * RPW + r] * tile[(wave * RPW + r) * ts + p];
         col_s[wave * P + p] = acc;
     }
     __syncthreads();
@@ -447,7 +462,7 @@ const char* ctk_mppi_rollout_name(int pred, bool log, int N) {
     return log ? "ctk_mppi_rollout<1, true>" : "ctk_mppi_rollout<1, false>";
 }
 
-int ctk_mppi_num_blocks(int N) { return (N + MPPI_TRAJ - 1) / MPPI_TRAJ; }
+int ctk_mppi_num_blocks(int N, int pred) { const int tr = mppi_traj(pred); return (N + tr - 1) / tr; }
 
 static size_t merge_lds(int P, int cnt) { return (size_t)(8 + P + 1 + (cnt < MERGE_CHUNK ? cnt : MERGE_CHUNK)) * sizeof(float); }
 // with all records staged in LDS (used when it stays <= 64 KiB)
@@ -455,7 +470,7 @@ static size_t merge_lds_staged(int P, int cnt) { return merge_lds(P, cnt) + (siz
 static bool merge_can_stage(int P, int cnt) { return merge_lds_staged(P, cnt) <= 64 * 1024; }
 
 size_t ctk_mppi_rollout_lds(int P, int H, int pred) {
-    const size_t roll = (size_t)(mppi_carve_floats(P, H) + (pred == CTK_PRED_GRU ? GRU_LDS_FLOATS : 0)) * sizeof(float);
+    const size_t roll = (size_t)(mppi_carve_floats(P, H, mppi_traj(pred)) + (pred == CTK_PRED_GRU ? GRU_EX_FLOATS : 0)) * sizeof(float);
     const size_t tail = merge_lds(P, CTK_MPPI_FUSE_MAX_BLOCKS);
     return roll > tail ? roll : tail;
 }
@@ -475,7 +490,7 @@ static size_t rollout_launch_lds(int P, int H, int pred, int blocks, int* stage_
 hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const MppiK& m,
                                    const float* samples, const float* u_nom, const float* wperm, float* parts, bool log,
                                    const MppiFuse& fuse, hipEvent_t e0, hipEvent_t e1) {
-    const dim3 grid(ctk_mppi_num_blocks(a.N)), block(MPPI_BLOCK);
+    const dim3 grid(ctk_mppi_num_blocks(a.N, pred)), block(MPPI_BLOCK);
     if (ctk_mppi_uses_throughput_kernel(pred, a.N)) {
         const size_t lds_tp = (size_t)(64 * tile_stride(a.P) + 64 + 4 * a.H) * sizeof(float);
         if (log) CTK_LAUNCH((ctk_mppi_rollout_tp<true>), grid, dim3(64), lds_tp, st, e0, e1, a, k, m, samples, u_nom, a.interp, parts);

@@ -18,41 +18,46 @@ constexpr int SAMP_BLOCK = SAMP_TRAJ * SAMP_WAVES;
 // Same anatomy as ctk_mppi_rollout (ctk_mppi.hip): 4-wave prologues (coalesced sample tile -> LDS; inputs
 // of all H steps, input-only cost terms, coalesced write of the plans Q), then the recurrence on one
 // wave (ODE, one trajectory per lane) or on all four (MLP, 16 trajectories per wave on MFMA).
-// LDS carve (floats): tile[64][ts] | ubuf[64][us] | cin[4][64] | base[H] | scale[H] | (GRU) weight table
-__host__ __device__ inline int affine_carve_floats(int H) {
-    const int f = SAMP_TRAJ * tile_stride(H) + SAMP_TRAJ * ((H + 1) | 1) + SAMP_WAVES * SAMP_TRAJ + 2 * H;
+// GRU: the four waves share ONE 16-trajectory column block (ctk_gru.h), so a workgroup owns 16 trajectories.
+// LDS carve (floats): tile[TRAJ][ts] | ubuf[TRAJ][us] | cin[256/TRAJ][TRAJ] | base[H] | scale[H] | (GRU) exchange slots
+__host__ __device__ inline int affine_carve_floats(int H, int traj) {
+    const int f = traj * tile_stride(H) + traj * ((H + 1) | 1) + SAMP_BLOCK + 2 * H;
     return (f + 3) & ~3;
 }
+__host__ __device__ inline int affine_traj(int pred) { return pred == CTK_PRED_GRU ? GRU_TRAJ : SAMP_TRAJ; }
 
-template <int PRED, bool TRAJ>
+template <int PRED, bool WTRAJ>
 __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(RolloutArgs a, EnvK k, const float* __restrict__ samples,
                                                                  int rng_kind, const float* __restrict__ base,
                                                                  const float* __restrict__ scale,
                                                                  const float* __restrict__ wperm) {
     extern __shared__ float lds[];
+    constexpr int TRAJ = (PRED == CTK_PRED_GRU) ? GRU_TRAJ : SAMP_TRAJ;
+    constexpr int CHUNKS = SAMP_BLOCK / TRAJ;
     const int H = a.H, ts = tile_stride(a.P), us = (H + 1) | 1;   // P == H here: one sample per step
     float* tile = lds;
-    float* ubuf = tile + SAMP_TRAJ * ts;
-    float* cin_s = ubuf + SAMP_TRAJ * us;
-    float* base_s = cin_s + SAMP_WAVES * SAMP_TRAJ;
+    float* ubuf = tile + TRAJ * ts;
+    float* cin_s = ubuf + TRAJ * us;
+    float* base_s = cin_s + SAMP_BLOCK;
     float* scale_s = base_s + H;
-    float* gru_s = lds + affine_carve_floats(H);
+    float* gru_ex = lds + affine_carve_floats(H, TRAJ);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int row0 = blockIdx.x * SAMP_TRAJ;
+    const int row0 = blockIdx.x * TRAJ;
     const int n = row0 + lane;
-    const bool valid = n < a.N;
+    const bool valid = lane < TRAJ && n < a.N;
 
-    load_tile_early<SAMP_TRAJ, SAMP_BLOCK>(tile, samples, a, row0, 1.0f, rng_kind, [&] {
+    load_tile_early<TRAJ, SAMP_BLOCK>(tile, samples, a, row0, 1.0f, rng_kind, [&] {
         for (int h = t; h < H; h += SAMP_BLOCK) { base_s[h] = base[h]; scale_s[h] = scale[h]; }
     });
-    if constexpr (PRED == CTK_PRED_GRU) gru_stage_weights<SAMP_BLOCK>(gru_s, wperm);
     __syncthreads();
 
-    {   // inputs of all H steps + input-only stage-cost terms; wave w takes a contiguous chunk of steps
-        const float* my = tile + lane * ts;
+    {   // inputs of all H steps + input-only stage-cost terms; thread (trajectory t % TRAJ, chunk t / TRAJ — lane and
+        // wave when TRAJ = 64) takes a contiguous chunk of steps
+        const int ptraj = t % TRAJ, chunk = t / TRAJ;
+        const float* my = tile + ptraj * ts;
         auto input_at = [&](int h) { return fminf(fmaxf(base_s[h] + my[h] * scale_s[h], a.lo), a.hi); };
-        const int Hc = (H + SAMP_WAVES - 1) / SAMP_WAVES;
-        const int h0 = wave * Hc, h1 = min(H, h0 + Hc);
+        const int Hc = (H + CHUNKS - 1) / CHUNKS;
+        const int h0 = chunk * Hc, h1 = min(H, h0 + Hc);
         float cin = 0.0f;
         float uprev = (h0 == 0 || h0 >= H) ? (a.u_prev_dev ? *a.u_prev_dev : a.u_prev) : input_at(h0 - 1);
 #pragma unroll 2
@@ -60,14 +65,14 @@ __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(RolloutArgs a, 
             const float u = input_at(h);
             cin += stage_cost_input(k, u, uprev);
             uprev = u;
-            ubuf[lane * us + h] = u;
+            ubuf[ptraj * us + h] = u;
         }
-        cin_s[wave * SAMP_TRAJ + lane] = cin;
+        cin_s[chunk * TRAJ + ptraj] = cin;
     }
     __syncthreads();
 
     {   // the plans, coalesced: Q[row0*H + i] for the block's contiguous span (elite refit / logging read it)
-        const int total = min(SAMP_TRAJ, a.N - row0) * H;
+        const int total = min(TRAJ, a.N - row0) * H;
         float* dst = a.Q_out + (size_t)row0 * H;
         for (int i = t; i < total; i += SAMP_BLOCK) {
             const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i;
@@ -81,41 +86,47 @@ __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(RolloutArgs a, 
             float amax = 0.0f;
             auto F_at = [&](int h) { return k.u_max * myu[h]; };
             float J;
-            if (k.intermediate_steps == 1) J = recur_ode_state_cost<TRAJ, false, true>(a, k, n, valid, F_at, &amax);
-            else J = recur_ode_state_cost<TRAJ, true, false>(a, k, n, valid, F_at, &amax);
+            if (k.intermediate_steps == 1) J = recur_ode_state_cost<WTRAJ, false, true>(a, k, n, valid, F_at, &amax);
+            else J = recur_ode_state_cost<WTRAJ, true, false>(a, k, n, valid, F_at, &amax);
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0))
-                J = recur_ode_state_cost<TRAJ, true, false>(a, k, n, valid, F_at, &amax);
+                J = recur_ode_state_cost<WTRAJ, true, false>(a, k, n, valid, F_at, &amax);
             J += (cin_s[lane] + cin_s[SAMP_TRAJ + lane]) + (cin_s[2 * SAMP_TRAJ + lane] + cin_s[3 * SAMP_TRAJ + lane]);
             if (valid) a.J[n] = J * a.inv_Hp1;
         }
-    } else {
+    } else if constexpr (PRED == CTK_PRED_MLP) {
         const int tr = wave * CTK_MLP_TRAJ_PER_WAVE + (lane & 15);
         const float* myu = ubuf + tr * us;
-        float J;
-        if constexpr (PRED == CTK_PRED_MLP) {
-            const MlpFwdW w = mlp_load_fwd(wperm);
-            J = rollout_mlp<false, TRAJ, false>(a, k, w, row0 + wave * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return myu[h]; });
-        } else {
-            J = rollout_gru<false, TRAJ, false>(a, k, gru_s, wperm + GRU_LDS_FLOATS, row0 + wave * CTK_MLP_TRAJ_PER_WAVE,
-                                                [&](int h) { return myu[h]; });
-        }
+        const MlpFwdW w = mlp_load_fwd(wperm);
+        float J = rollout_mlp<false, WTRAJ, false>(a, k, w, row0 + wave * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return myu[h]; });
         J += ((cin_s[tr] + cin_s[SAMP_TRAJ + tr]) + (cin_s[2 * SAMP_TRAJ + tr] + cin_s[3 * SAMP_TRAJ + tr])) * a.inv_Hp1;
         if (lane < 16 && row0 + tr < a.N) a.J[row0 + tr] = J;
+    } else {
+        // the four waves share the workgroup's 16 trajectories; wave 0 ends with J (lane = trajectory for lanes 0..15)
+        const float* myu = ubuf + (lane & 15) * us;
+        float J = rollout_gru<WTRAJ, false>(a, k, wperm, wperm + GRU_TABLE_FLOATS, gru_ex, row0, [&](int h) { return myu[h]; });
+        if (wave == 0 && valid) {
+            float cs = 0.0f;
+#pragma unroll
+            for (int cnk = 0; cnk < CHUNKS; ++cnk) cs += cin_s[cnk * TRAJ + lane];
+            a.J[n] = J + cs * a.inv_Hp1;
+        }
     }
 }
 
-// predictor.update(s, Q0) for the GRU (optimizer_mppi.py:195-197): one wave; all 16 MFMA columns carry
-// the same (s, u); the weights stream from memory (one step: no point staging them); the lanes of column 0
-// write the new hidden state back in place (table | hidden, see ctk_api.hip:permute_gru_weights).
-__global__ __launch_bounds__(64) void ctk_gru_advance(float s0, float s1, float s2, float s3, const float* __restrict__ u_dev,
-                                                      float u_val, float* __restrict__ wperm) {
-    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
-    float* hidden = wperm + GRU_LDS_FLOATS;
+// predictor.update(s, Q0) for the GRU (optimizer_mppi.py:195-197): one workgroup of four waves (the split
+// step of ctk_gru.h); all 16 MFMA columns carry the same (s, u); wave 0's lanes of column 0 write the new
+// hidden state back in place (table | hidden, see ctk_api.hip:permute_gru_weights).
+__global__ __launch_bounds__(GRU_BLOCK) void ctk_gru_advance(float s0, float s1, float s2, float s3, const float* __restrict__ u_dev,
+                                                             float u_val, float* __restrict__ wperm) {
+    __shared__ __attribute__((aligned(16))) float ex[GRU_EX_FLOATS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    float* hidden = wperm + GRU_TABLE_FLOATS;
+    const GruW w = gru_load_weights(wperm, wave, lane);
     GruState st = gru_load_state(hidden, g);
     const float sv = g == 0 ? s0 : (g == 1 ? s1 : (g == 2 ? s2 : s3));
     const float u = u_dev ? *u_dev : u_val;
-    (void)gru_step(wperm + lane, st, sv, u, g);
-    if (c == 0) {
+    (void)gru_step(w, st, sv, u, g, ex, wave, lane);   // its barriers order every wave's loads of `hidden` before the stores below
+    if (wave == 0 && c == 0) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -127,7 +138,7 @@ __global__ __launch_bounds__(64) void ctk_gru_advance(float s0, float s1, float 
 }
 
 hipError_t ctk_launch_gru_advance(hipStream_t st, const float* s, const float* u_dev, float u_val, float* wperm) {
-    hipLaunchKernelGGL(ctk_gru_advance, dim3(1), dim3(64), 0, st, s[0], s[1], s[2], s[3], u_dev, u_val, wperm);
+    hipLaunchKernelGGL(ctk_gru_advance, dim3(1), dim3(GRU_BLOCK), 0, st, s[0], s[1], s[2], s[3], u_dev, u_val, wperm);
     return hipGetLastError();
 }
 
@@ -329,7 +340,8 @@ const char* ctk_affine_rollout_name(int pred, bool log) {
 hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const float* samples,
                                      int rng_kind, const float* base, const float* scale, const float* wperm, bool log,
                                      hipEvent_t e0, hipEvent_t e1) {
-    const dim3 grid((a.N + SAMP_TRAJ - 1) / SAMP_TRAJ), block(SAMP_BLOCK);
+    const int tr = affine_traj(pred);
+    const dim3 grid((a.N + tr - 1) / tr), block(SAMP_BLOCK);
     const size_t lds = ctk_affine_rollout_lds(a.H, pred);
     if (pred == CTK_PRED_ODE) {
         if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
@@ -345,7 +357,7 @@ hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs
 }
 
 size_t ctk_affine_rollout_lds(int H, int pred) {
-    return (size_t)(affine_carve_floats(H) + (pred == CTK_PRED_GRU ? GRU_LDS_FLOATS : 0)) * sizeof(float);
+    return (size_t)(affine_carve_floats(H, affine_traj(pred)) + (pred == CTK_PRED_GRU ? GRU_EX_FLOATS : 0)) * sizeof(float);
 }
 
 hipError_t ctk_launch_select_topk(hipStream_t st, const float* J, int N, int K, int* idx_out, int ldj) {

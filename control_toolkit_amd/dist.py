@@ -12,11 +12,12 @@ import numpy as np
 
 
 class ShardedMPPI:
-    def __init__(self, engine, rank: int, world_size: int, group=None, device=None):
+    def __init__(self, engine, rank: int, world_size: int, group=None, device=None, always_collective: bool = False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.engine, self.rank, self.world_size, self.group = engine, rank, world_size, group
+        self.always_collective = always_collective   # issue the all-gather even for one rank (rehearsal of the RCCL path)
         self.rec = int(engine.mppi_partial_size())
         self.device = device if device is not None else torch.device("cpu")
         self.mine = torch.zeros(self.rec, dtype=torch.float32, device=self.device)
@@ -26,7 +27,7 @@ class ShardedMPPI:
         """samples: this rank's slice of the draws (host array / device pointer) or None (device
         Philox addressed by GLOBAL rollout index, so the result does not depend on world_size)."""
         self.engine.mppi_step_begin(s, self.mine.data_ptr(), samples, u_prev=u_prev)
-        if self.world_size > 1:
+        if self.world_size > 1 or self.always_collective:
             self.dist.all_gather_into_tensor(self.all, self.mine, group=self.group)
             parts = self.all
         else:
