@@ -1,29 +1,71 @@
 """Cost side of the boundary.  `cost_function_base` semantics (reference
 Cost_Functions/__init__.py:38-93: MAX_COST shift, zero default terminal cost, mean over H+1)
-are implemented inside the rollout kernels; this wrapper carries the cost PARAMETERS and the
-hot-reload flag of reference Cost_Functions/cost_function_wrapper.py:71-74."""
+are implemented inside the rollout kernels; this wrapper carries the cost PARAMETERS — the declarative
+description the kernels take as constants — and the hot reload of reference
+Cost_Functions/cost_function_wrapper.py:56-74 + CostFunctionUpdater.py end to end:
+
+    config_cost_function.yml  --(watcher thread sets a flag)-->  controller_mpc.step():
+        update_cost_parameters_from_config()  -->  optimizer._sync_parameters()  -->  ctk_set_param
+
+The YAML has the reference's layout (Control_Toolkit_ASF_Template/config_cost_function.yml):
+
+    cost_function_name_default: default
+    CartPole:
+      default:
+        dd_weight: 600.0      # any subset of DEFAULT_COST; unknown keys are an error (the kernels implement
+        ep_weight: 20000.0    # exactly these terms: oracle/ctk_oracle.py:Cost)
+"""
+import os
+
+from .CostFunctionUpdater import CostFunctionUpdater
 
 DEFAULT_COST = dict(dd_weight=600.0, ep_weight=20000.0, ekp_weight=80.0, cc_weight=1.0, ccrc_weight=1.0, R=1.0,
                     x_scale=0.198, terminal_weight=0.0)
 DEFAULT_ATTRIBUTES = dict(target_position=0.0, target_equilibrium=1.0)
+DEFAULT_CONFIG_PATH = os.path.join("Control_Toolkit_ASF", "config_cost_function.yml")   # reference cost_function_wrapper.py:14
+
+
+def _checked(section, where):
+    if not isinstance(section, dict):
+        raise ValueError(f"{where}: expected a mapping of cost parameters")
+    unknown = set(section) - set(DEFAULT_COST)
+    if unknown:
+        raise ValueError(f"{where}: unknown cost parameters {sorted(unknown)} (built: {sorted(DEFAULT_COST)})")
+    return {k: float(v) for k, v in section.items()}
 
 
 class CostFunctionWrapper:
     MAX_COST = 0.0
 
-    def __init__(self, parameters=None):
+    def __init__(self, parameters=None, config_path=None, watch: bool = True):
+        """parameters: explicit values (highest precedence at construction).  config_path: the cost YAML; if
+        None and Control_Toolkit_ASF/config_cost_function.yml exists in the working directory (the reference's
+        CWD-relative convention) that file is used.  watch: start the CostFunctionUpdater thread in configure()."""
         self.parameters = dict(DEFAULT_COST)
         if parameters:
-            unknown = set(parameters) - set(DEFAULT_COST)
-            if unknown:
-                raise ValueError(f"unknown cost parameters {sorted(unknown)}")
-            self.parameters.update(parameters)
+            self.parameters.update(_checked(parameters, "CostFunctionWrapper(parameters=...)"))
+        self._explicit = dict(parameters or {})
+        self.config_path = config_path if config_path is not None else (DEFAULT_CONFIG_PATH if os.path.isfile(DEFAULT_CONFIG_PATH) else None)
+        self.watch = watch
+        self.config = None            # the YAML section in force (set by configure / the updater)
+        self.cost_function_name_default = "default"
+        self.cost_function_name = None
+        self.cost_function_updater = None
         self.reload_cost_parameters_from_config_flag = False
         self.logged_attributes = {}
-        self.version = 0          # bumped whenever parameters change; optimizers re-upload
+        self.version = 0          # bumped whenever parameters change
         self.batch_size = self.horizon = None
         self.variable_parameters = None
         self.cost_function = self  # reference: wrapper.cost_function.logged_attributes (controller_mpc.py:91)
+
+    # reference cost_function_wrapper.py:76-88
+    def update_cost_function_name_from_specification(self, cost_function_specification=None):
+        if cost_function_specification is None:
+            self.cost_function_name = self.cost_function_name_default.replace("-", "_")
+        elif isinstance(cost_function_specification, str):
+            self.cost_function_name = cost_function_specification.replace("-", "_")
+        else:
+            raise ValueError(f"Cannot interpret cost function specification {cost_function_specification}.")
 
     def configure(self, batch_size, horizon, variable_parameters=None, environment_name=None,
                   computation_library=None, cost_function_specification=None):
@@ -31,19 +73,41 @@ class CostFunctionWrapper:
         self.variable_parameters = variable_parameters
         self.environment_name = environment_name
         self.cost_function_specification = cost_function_specification
+        if self.config_path is not None:
+            from yaml import safe_load
+            whole = safe_load(open(self.config_path, "r")) or {}
+            self.cost_function_name_default = str(whole.get("cost_function_name_default", "default"))
+            self.update_cost_function_name_from_specification(cost_function_specification)
+            try:
+                section = whole[environment_name][self.cost_function_name]
+            except (KeyError, TypeError):
+                raise KeyError(f"{self.config_path}: no section [{environment_name}][{self.cost_function_name}]") from None
+            self.config = section
+            self.parameters.update(_checked(section, f"{self.config_path}[{environment_name}][{self.cost_function_name}]"))
+            self.parameters.update(self._explicit)
+            self.cost_function_updater = CostFunctionUpdater(self, environment_name, self.cost_function_name,   # reference :69
+                                                             start_thread=self.watch)
+        else:
+            self.update_cost_function_name_from_specification(cost_function_specification)
 
     def set_parameters(self, **kw):
-        unknown = set(kw) - set(DEFAULT_COST)
-        if unknown:
-            raise ValueError(f"unknown cost parameters {sorted(unknown)}")
-        self.parameters.update(kw)
+        """Programmatic equivalent of editing the YAML: takes effect at the next controller step."""
+        self.config = dict(self.config or {}, **_checked(kw, "set_parameters"))
         self.reload_cost_parameters_from_config_flag = True
 
+    def reload_cost_parameters_from_config(self):
+        # the reference's cost functions re-read their attributes from self.config here
+        self.parameters.update(_checked(self.config or {}, "cost YAML reload"))
+        self.version += 1
+
     def update_cost_parameters_from_config(self):
-        # reference cost_function_wrapper.py:71-74 (flag set by the YAML watchdog thread)
+        # reference cost_function_wrapper.py:71-74 (flag set by the watcher thread)
         if self.reload_cost_parameters_from_config_flag:
-            self.version += 1
             self.reload_cost_parameters_from_config_flag = False
+            self.reload_cost_parameters_from_config()
 
     def copy(self):
-        return CostFunctionWrapper(self.parameters)
+        c = CostFunctionWrapper(self.parameters, watch=False)
+        c.config_path = None          # a copy carries values, it does not watch (one watcher per path)
+        c.cost_function_name = self.cost_function_name
+        return c

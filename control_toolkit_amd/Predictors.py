@@ -45,6 +45,30 @@ class PredictorWrapper:
         self.dt = dt
         self.variable_parameters = variable_parameters
 
+    @classmethod
+    def from_yaml(cls, path, section=None):
+        """Declarative predictor description -> kernel constants.  YAML keys (all optional):
+            dynamics: {g, m_cart, m_pole, L, u_max, M_fric, J_fric}     # the ODE's physical parameters
+            intermediate_steps: 1                                        # Euler sub-steps per mpc_timestep
+            weights_file: net.npy | net.npz (key `weights`)              # flat fp32 network weights (MLP 1380 / GRU 10212)
+        `section`: optional top-level key (e.g. the environment name).  Weight files are read with
+        numpy.load(allow_pickle=False) only."""
+        import os
+        from yaml import safe_load
+        cfg = safe_load(open(path, "r")) or {}
+        if section is not None:
+            cfg = cfg[section]
+        unknown = set(cfg) - {"dynamics", "intermediate_steps", "weights_file"}
+        if unknown:
+            raise ValueError(f"{path}: unknown predictor keys {sorted(unknown)}")
+        weights = None
+        if cfg.get("weights_file"):
+            wf = cfg["weights_file"]
+            wf = wf if os.path.isabs(wf) else os.path.join(os.path.dirname(os.path.abspath(path)), wf)
+            data = np.load(wf, allow_pickle=False)
+            weights = data["weights"] if hasattr(data, "files") else data
+        return cls(cfg.get("dynamics"), weights, int(cfg.get("intermediate_steps", 1)))
+
     def copy(self):
         return PredictorWrapper(self.parameters, self.weights, self.intermediate_steps)
 

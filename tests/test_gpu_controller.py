@@ -141,3 +141,44 @@ def test_all_optimizers_balance_the_pole_with_device_rng(name, cfg):
         s = pred.step(s.reshape(1, 4), np.array([u], np.float32))[0]
     if name != "random-action-hip":
         assert abs(s[2]) < 0.3, f"pole fell: angle {s[2]}"
+
+
+def test_cost_yaml_edit_reaches_the_kernels_within_one_step(tmp_path):
+    """SURVEY 8f rank 2, hot reload end to end: edit config_cost_function.yml -> watcher flag -> controller_mpc.step
+    consumes it (controller_mpc.py:101) -> ctk_set_param -> the very next rollout is costed with the new weights
+    (checked against the oracle with those weights)."""
+    from control_toolkit_amd.Cost_Functions import CostFunctionUpdater
+    y = tmp_path / "config_cost_function.yml"
+    y.write_text("cost_function_name_default: default\nCartPole:\n  default:\n    dd_weight: 600.0\n    ep_weight: 20000.0\n")
+    N, H = 128, 15
+    opt_cfg = dict(seed=3, mpc_horizon=H, num_rollouts=N, cc_weight=1.0, R=1.0, LBD=100.0, NU=1000.0, SQRTRHOINV=0.03,
+                   period_interpolation_inducing_points=1, mpc_timestep=0.02, rng_mode="host")
+    c = controller_mpc("CartPole", LIMITS, {"target_position": 0.0, "target_equilibrium": 1.0},
+                       config_controllers={"mpc": dict(CTRL_CFG["mpc"], calculate_optimal_trajectory=False)},
+                       config_optimizers={"mppi-hip": opt_cfg}, predictor=PredictorWrapper(),
+                       cost_function=CostFunctionWrapper(config_path=str(y), watch=False))
+    c.configure()
+    rng = np.random.default_rng(0)
+    noise = [rng.standard_normal((N, H, 1)).astype(np.float32) for _ in range(2)]
+    c.optimizer.rng = ReplayRng(noise)
+    s = np.array([0.05, 0.0, 0.4, 0.1], np.float32)
+
+    def oracle_J(env, noise_t, u_nom, u_prev):
+        o = O.MPPI(O.Predictor("ODE", dt=0.02, env=env), O.Cost(env), num_rollouts=N, mpc_horizon=H,
+                   period_interpolation_inducing_points=1)
+        o.u_nom = u_nom.copy(); o.u = np.float32(u_prev)
+        o.step(s, noise_t)
+        return o.J
+
+    J_ref0 = oracle_J(O.EnvParams(), noise[0], np.zeros((1, H, 1), np.float32), 0.0)
+    u0 = c.step(s)
+    np.testing.assert_allclose(c.optimizer.logging_values["J_logged"], J_ref0, rtol=3e-5)
+    u_nom0 = np.asarray(c.optimizer.u_nom, np.float32).reshape(1, H, 1).copy()
+    import time; time.sleep(0.01)
+    y.write_text("cost_function_name_default: default\nCartPole:\n  default:\n    dd_weight: 50.0\n    ep_weight: 5000.0\n    ekp_weight: 10.0\n")
+    assert c.cost_function.cost_function_updater.poll_now()
+    c.step(s)                                                             # consumes the flag, uploads, rolls out
+    assert c.optimizer.engine.get_param("dd_weight") == 50.0 and c.optimizer.engine.get_param("ekp_weight") == 10.0
+    J_ref1 = oracle_J(O.EnvParams(dd_weight=50.0, ep_weight=5000.0, ekp_weight=10.0), noise[1], u_nom0, float(np.asarray(u0).reshape(-1)[0]))
+    np.testing.assert_allclose(c.optimizer.logging_values["J_logged"], J_ref1, rtol=3e-5)
+    CostFunctionUpdater.stop_all_watchers()

@@ -133,3 +133,59 @@ def test_controller_config_errors_match_reference():
     c.update_logs({"Q_logged": np.ones((2, 3, 1), np.float32), "J_logged": np.ones(2, np.float32)})
     out = c.get_outputs()                                               # stacked along axis 0 (:159-168)
     assert out["Q_logged"].shape == (2, 2, 3, 1) and out["s_logged"] is None
+
+
+def test_cost_yaml_hot_reload_and_declarative_predictor(tmp_path):
+    """reference cost_function_wrapper.py:56-74 + CostFunctionUpdater.py: YAML section -> parameters, a watcher
+    raises the flag on modification, the controller consumes it at the top of step()."""
+    import time
+    from control_toolkit_amd.Cost_Functions import CostFunctionWrapper, CostFunctionUpdater, DEFAULT_COST
+    from control_toolkit_amd.Predictors import PredictorWrapper
+    y = tmp_path / "config_cost_function.yml"
+    y.write_text("cost_function_name_default: quadratic-boundary\nCartPole:\n  quadratic_boundary:\n    dd_weight: 100.0\n    R: 2.0\n"
+                 "  other:\n    ep_weight: 1.0\n")
+    c = CostFunctionWrapper(config_path=str(y), watch=False)
+    c.configure(8, 5, environment_name="CartPole")
+    assert c.cost_function_name == "quadratic_boundary"                  # default name, '-' -> '_' (reference :76-88)
+    assert c.parameters["dd_weight"] == 100.0 and c.parameters["R"] == 2.0 and c.parameters["ep_weight"] == DEFAULT_COST["ep_weight"]
+    assert str(y) in CostFunctionUpdater.active_watchers
+    assert not c.cost_function_updater.poll_now()                        # unchanged file: no flag
+    time.sleep(0.01)
+    y.write_text("cost_function_name_default: quadratic-boundary\nCartPole:\n  quadratic_boundary:\n    dd_weight: 7.5\n    R: 2.0\n")
+    assert c.cost_function_updater.poll_now() and c.reload_cost_parameters_from_config_flag
+    assert c.parameters["dd_weight"] == 100.0                            # nothing changes until the controller consumes the flag
+    c.update_cost_parameters_from_config()
+    assert c.parameters["dd_weight"] == 7.5 and c.version == 1 and not c.reload_cost_parameters_from_config_flag
+    # a second wrapper on the same path replaces the first watcher (reference :22-24); explicit spec selects the section
+    c2 = CostFunctionWrapper(config_path=str(y), watch=True)
+    y.write_text("CartPole:\n  other:\n    ep_weight: 1.0\n")
+    c2.configure(8, 5, environment_name="CartPole", cost_function_specification="other")
+    assert CostFunctionUpdater.active_watchers[str(y)] is c2.cost_function_updater and c2.parameters["ep_weight"] == 1.0
+    time.sleep(0.01)
+    y.write_text("CartPole:\n  other:\n    ep_weight: 3.0\n")
+    t0 = time.time()
+    while not c2.reload_cost_parameters_from_config_flag and time.time() - t0 < 5:
+        time.sleep(0.02)                                                  # the watcher thread, not poll_now
+    assert c2.reload_cost_parameters_from_config_flag
+    c2.update_cost_parameters_from_config()
+    assert c2.parameters["ep_weight"] == 3.0
+    CostFunctionUpdater.stop_all_watchers()
+    assert CostFunctionUpdater.active_watchers == {}
+    with pytest.raises(ValueError, match="unknown cost parameters"):
+        bad = tmp_path / "bad.yml"; bad.write_text("CartPole:\n  default:\n    not_a_term: 1.0\n")
+        CostFunctionWrapper(config_path=str(bad), watch=False).configure(8, 5, environment_name="CartPole")
+    with pytest.raises(KeyError):
+        CostFunctionWrapper(config_path=str(y), watch=False).configure(8, 5, environment_name="Acrobot")
+    with pytest.raises(FileNotFoundError):
+        CostFunctionWrapper(config_path=str(tmp_path / "missing.yml"), watch=False).configure(8, 5, environment_name="CartPole")
+    # declarative predictor: YAML -> dynamics constants + weights file
+    np.save(tmp_path / "net.npy", np.arange(1380, dtype=np.float32))
+    p = tmp_path / "predictor.yml"
+    p.write_text("CartPole:\n  dynamics: {m_pole: 0.1, L: 0.25}\n  intermediate_steps: 2\n  weights_file: net.npy\n")
+    pw = PredictorWrapper.from_yaml(str(p), "CartPole")
+    assert pw.parameters["m_pole"] == 0.1 and pw.parameters["g"] == 9.81 and pw.intermediate_steps == 2 and pw.weights.size == 1380
+    pw.configure(batch_size=4, dt=0.02, predictor_specification="MLP")
+    assert pw.kind == "MLP"
+    with pytest.raises(ValueError):
+        q = tmp_path / "q.yml"; q.write_text("dynamics: {}\nfoo: 1\n")
+        PredictorWrapper.from_yaml(str(q))
