@@ -103,14 +103,39 @@ class template_controller(ABC):
     def has_optimizer(self):
         return self._has_optimizer
 
+    @staticmethod
+    def _stack(v):
+        from ..Optimizers import DeviceLogEntry
+        if len(v) == 0:
+            return None
+        if all(isinstance(x, DeviceLogEntry) for x in v):
+            return DeviceLogEntry.gather(v)          # one transfer per run of consecutive steps
+        arrs = [x.numpy() if isinstance(x, DeviceLogEntry) else np.asarray(x) for x in v]
+        if len({a.shape for a in arrs}) > 1:     # RPGD logs self.u BEFORE updating it (optimizer_rpgd.py:433,523): 0.0, then [u]
+            arrs = [a.reshape(-1) for a in arrs]
+        return np.stack(arrs, axis=0)
+
     def get_outputs(self):
         # reference :159-168
-        return {name: np.stack(v, axis=0) if len(v) > 0 else None for name, v in self.logs.items()}
+        return {name: self._stack(v) for name, v in self.logs.items()}
 
     def update_logs(self, logging_values: dict) -> None:
-        # reference :170-178 (logged arrays are copies)
+        # reference :170-178 (logged arrays are copies).  Entries that live in the engine's HBM log ring
+        # (optimizer option logging_on_device) stay there: the handle is kept and the data moves in get_outputs();
+        # when the ring is about to wrap, what it holds is brought to the host first.
+        from ..Optimizers import DeviceLogEntry
         if self.controller_logging:
             for name in self.save_vars:
                 var = logging_values.get(name, None)
-                if var is not None:
+                if var is None:
+                    continue
+                if isinstance(var, DeviceLogEntry):
+                    log = self.logs[name]
+                    pending = [x for x in log if isinstance(x, DeviceLogEntry)]
+                    if pending and var.step - pending[0].step + 1 >= var.engine.log_capacity:
+                        host = DeviceLogEntry.gather(pending)
+                        it = iter(host)
+                        self.logs[name] = log = [next(it) if isinstance(x, DeviceLogEntry) else x for x in log]
+                    log.append(var)
+                else:
                     self.logs[name].append(np.array(var, copy=True))

@@ -8,6 +8,46 @@ from ..others.globals_and_utils import create_rng
 from .._capi import CtkEngine, PARAMS
 
 
+def logging_kwargs(kwargs: dict) -> dict:
+    """the optional YAML keys of this build that every optimizer forwards to template_optimizer"""
+    return {k: kwargs[k] for k in ("logging_on_device", "logging_capacity") if k in kwargs}
+
+
+class DeviceLogEntry:
+    """One logged tensor of one MPC step, resident in the engine's HBM log ring (ctk_log_enable).  Quacks like
+    the device tensors the reference's optimizers put into `logging_values` (`.numpy()`, which
+    template_controller.update_logs calls, reference Controllers/__init__.py:170-178) and like an array
+    (`__array__`, `.shape`, `.copy()`); the transfer happens only when somebody looks."""
+    __slots__ = ("engine", "name", "step", "shape")
+
+    def __init__(self, engine, name: str, step: int, shape):
+        self.engine, self.name, self.step, self.shape = engine, name, step, tuple(shape)
+
+    def numpy(self) -> np.ndarray:
+        return self.engine.log_read(self.name, self.step, 1)[0]
+
+    def copy(self) -> np.ndarray:
+        return self.numpy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    @staticmethod
+    def gather(entries) -> np.ndarray:
+        """Stack a list of entries along axis 0 with one transfer per run of consecutive steps
+        (template_controller.get_outputs, reference Controllers/__init__.py:159-168)."""
+        out, i = [], 0
+        while i < len(entries):
+            j = i
+            while (j + 1 < len(entries) and entries[j + 1].engine is entries[i].engine
+                   and entries[j + 1].name == entries[i].name and entries[j + 1].step == entries[j].step + 1):
+                j += 1
+            out.append(entries[i].engine.log_read(entries[i].name, entries[i].step, j - i + 1))
+            i = j + 1
+        return np.concatenate(out, axis=0)
+
+
 class template_optimizer:
     supported_computation_libraries = (HipLibrary,)
     engine_name = None   # "mppi" | "cem" | "rpgd" | "random_action"
@@ -15,7 +55,8 @@ class template_optimizer:
     def __init__(self, predictor, cost_function, control_limits: "Tuple[np.ndarray, np.ndarray]",
                  optimizer_logging: bool, seed, num_rollouts: int, mpc_horizon: int,
                  computation_library: "ComputationLibrary", rng_mode: str = "device", device: int = 0,
-                 calculate_optimal_trajectory: bool = False, **kwargs) -> None:
+                 calculate_optimal_trajectory: bool = False, logging_on_device: bool = False,
+                 logging_capacity: int = 4096, **kwargs) -> None:
         # reference :27-28
         if not isinstance(computation_library, self.supported_computation_libraries):
             raise ValueError(f"The optimizer {self.__class__.__name__} does not support "
@@ -35,6 +76,10 @@ class template_optimizer:
         self.seed = getattr(self.rng, "seed", 0 if seed is None else seed)
         self.logging_values = {}
         self.optimizer_logging = optimizer_logging
+        # logging_on_device: keep Q / J / trajectories / ages of every step in an HBM ring (capacity in steps) and
+        # hand out DeviceLogEntry handles instead of copying ~1 MB to the host per step
+        self.logging_on_device = bool(logging_on_device) and bool(optimizer_logging)
+        self.logging_capacity = int(logging_capacity)
         self.calculate_optimal_trajectory = bool(calculate_optimal_trajectory)
         self.device = device
         self.engine: CtkEngine = None
@@ -86,6 +131,8 @@ class template_optimizer:
             materialize_trajectories=bool(self.optimizer_logging), **engine_kwargs)
         if self.predictor.kind in ("MLP", "GRU"):
             self.engine.set_predictor_weights(self.predictor.weights)
+        if self.logging_on_device:
+            self.engine.log_enable(self.logging_capacity)
         self._param_cache = {}
         self._cost_version = None
         self._sync_parameters(force=True)
@@ -121,11 +168,19 @@ class template_optimizer:
             raise ValueError(f"state must have shape (4,), got {s.shape}")
         return s
 
+    def _logged(self, name: str):
+        """the tensor `name` of the step just completed: a host array, or its handle in the device log"""
+        if not self.logging_on_device:
+            return self.engine.read(name)
+        N, H = self.num_rollouts, self.mpc_horizon
+        shape = {"Q": (N, H, 1), "J": (N,), "TRAJ": (N, H + 1, 4), "AGES": (N,)}[name]
+        return DeviceLogEntry(self.engine, name, self.engine.log_count() - 1, shape)
+
     def _fill_logging(self, s_in, u):
         # reference optimizer_mppi.py:214-218 / optimizer_cem_tf.py:104-108
-        self.rollout_trajectories = self.engine.read("TRAJ")
-        self.logging_values["Q_logged"] = self.engine.read("Q")
-        self.logging_values["J_logged"] = self.engine.read("J")
+        self.rollout_trajectories = self._logged("TRAJ")
+        self.logging_values["Q_logged"] = self._logged("Q")
+        self.logging_values["J_logged"] = self._logged("J")
         self.logging_values["rollout_trajectories_logged"] = self.rollout_trajectories
         self.logging_values["u_logged"] = u
 

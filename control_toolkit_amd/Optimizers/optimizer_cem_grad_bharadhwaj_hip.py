@@ -4,7 +4,7 @@ from typing import Tuple
 
 import numpy as np
 
-from . import template_optimizer
+from . import template_optimizer, logging_kwargs
 from ..computation_library import HipLibrary
 
 
@@ -21,7 +21,7 @@ class optimizer_cem_grad_bharadhwaj_hip(template_optimizer):
                          optimizer_logging=optimizer_logging, seed=seed, num_rollouts=num_rollouts,
                          mpc_horizon=mpc_horizon, computation_library=computation_library,
                          calculate_optimal_trajectory=calculate_optimal_trajectory,
-                         rng_mode=kwargs.get("rng_mode", "device"), device=kwargs.get("device", 0))
+                         rng_mode=kwargs.get("rng_mode", "device"), device=kwargs.get("device", 0), **logging_kwargs(kwargs))
         self.cem_outer_it, self.cem_best_k = cem_outer_it, cem_best_k
         self.cem_initial_action_stdev, self.cem_stdev_min = cem_initial_action_stdev, cem_stdev_min
         self.learning_rate, self.gradmax_clip = learning_rate, gradmax_clip
@@ -55,8 +55,8 @@ class optimizer_cem_grad_bharadhwaj_hip(template_optimizer):
         u_prev = np.asarray(self.u, np.float32).reshape(-1)[:1]
         self.u = np.squeeze(self.engine.step(s, draws, u_prev=u_prev))
         if self.optimizer_logging:                                                   # :170-175
-            self.logging_values["Q_logged"] = self.engine.read("Q")
-            self.logging_values["J_logged"] = self.engine.read("J")
+            self.logging_values["Q_logged"] = self._logged("Q")
+            self.logging_values["J_logged"] = self._logged("J")
             self.logging_values["u_logged"] = self.u
         self.count += 1
         return self.u

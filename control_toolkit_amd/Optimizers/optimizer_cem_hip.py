@@ -4,7 +4,7 @@ from typing import Tuple
 
 import numpy as np
 
-from . import template_optimizer
+from . import template_optimizer, logging_kwargs
 from ..computation_library import HipLibrary
 
 
@@ -20,7 +20,7 @@ class optimizer_cem_hip(template_optimizer):
                          optimizer_logging=optimizer_logging, seed=seed, num_rollouts=num_rollouts,
                          mpc_horizon=mpc_horizon, computation_library=computation_library,
                          calculate_optimal_trajectory=calculate_optimal_trajectory,
-                         rng_mode=kwargs.get("rng_mode", "device"), device=kwargs.get("device", 0))
+                         rng_mode=kwargs.get("rng_mode", "device"), device=kwargs.get("device", 0), **logging_kwargs(kwargs))
         self.cem_outer_it = cem_outer_it
         self.cem_initial_action_stdev = cem_initial_action_stdev
         self.cem_stdev_min = cem_stdev_min

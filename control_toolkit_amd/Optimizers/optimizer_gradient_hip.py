@@ -4,7 +4,7 @@ from typing import Tuple
 
 import numpy as np
 
-from . import template_optimizer
+from . import template_optimizer, logging_kwargs
 from ..computation_library import HipLibrary
 
 
@@ -21,7 +21,7 @@ class optimizer_gradient_hip(template_optimizer):
                          optimizer_logging=optimizer_logging, seed=seed, num_rollouts=num_rollouts,
                          mpc_horizon=mpc_horizon, computation_library=computation_library,
                          calculate_optimal_trajectory=calculate_optimal_trajectory,
-                         rng_mode=kwargs.get("rng_mode", "device"), device=kwargs.get("device", 0))
+                         rng_mode=kwargs.get("rng_mode", "device"), device=kwargs.get("device", 0), **logging_kwargs(kwargs))
         self.gradient_steps = gradient_steps
         self.initial_action_stdev = initial_action_stdev     # declared by the reference, unused there too (:52)
         self.learning_rate = learning_rate
@@ -49,8 +49,8 @@ class optimizer_gradient_hip(template_optimizer):
         u_prev = np.asarray(self.u, np.float32).reshape(-1)[:1]
         self.u = np.squeeze(self.engine.step(s, tail, u_prev=u_prev))
         if self.optimizer_logging:                                         # :135-140
-            self.logging_values["Q_logged"] = self.engine.read("Q")
-            self.logging_values["J_logged"] = self.engine.read("J")
+            self.logging_values["Q_logged"] = self._logged("Q")
+            self.logging_values["J_logged"] = self._logged("J")
             self.logging_values["u_logged"] = self.u
         self.count += 1
         return self.u

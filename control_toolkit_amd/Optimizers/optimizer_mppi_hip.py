@@ -4,7 +4,7 @@ from typing import Tuple
 
 import numpy as np
 
-from . import template_optimizer
+from . import template_optimizer, logging_kwargs
 from ..computation_library import HipLibrary
 
 
@@ -20,7 +20,7 @@ class optimizer_mppi_hip(template_optimizer):
                          optimizer_logging=optimizer_logging, seed=seed, num_rollouts=num_rollouts,
                          mpc_horizon=mpc_horizon, computation_library=computation_library,
                          calculate_optimal_trajectory=calculate_optimal_trajectory,
-                         rng_mode=kwargs.get("rng_mode", "device"), device=kwargs.get("device", 0))
+                         rng_mode=kwargs.get("rng_mode", "device"), device=kwargs.get("device", 0), **logging_kwargs(kwargs))
         self.cc_weight, self.R, self.LBD, self.NU = cc_weight, R, LBD, NU
         self._SQRTRHOINV = SQRTRHOINV
         self.period_interpolation_inducing_points = period_interpolation_inducing_points

@@ -4,7 +4,7 @@ from typing import Tuple
 
 import numpy as np
 
-from . import template_optimizer
+from . import template_optimizer, logging_kwargs
 from ..computation_library import HipLibrary
 
 
@@ -23,7 +23,7 @@ class optimizer_rpgd_hip(template_optimizer):
                          optimizer_logging=optimizer_logging, seed=seed, num_rollouts=num_rollouts,
                          mpc_horizon=mpc_horizon, computation_library=computation_library,
                          calculate_optimal_trajectory=calculate_optimal_trajectory,
-                         rng_mode=kwargs.get("rng_mode", "device"), device=kwargs.get("device", 0))
+                         rng_mode=kwargs.get("rng_mode", "device"), device=kwargs.get("device", 0), **logging_kwargs(kwargs))
         self.outer_its = outer_its
         self.sample_stdev, self.sample_mean = sample_stdev, sample_mean
         self.sample_whole_control_space = sample_whole_control_space
@@ -83,9 +83,9 @@ class optimizer_rpgd_hip(template_optimizer):
         u = self.engine.step(s, draws, u_prev=u_prev)
         self.u_nom = self.engine.read("U_NOM")                      # :426
         if self.optimizer_logging:                                   # :428-433
-            self.logging_values["Q_logged"] = self.engine.read("Q")
-            self.logging_values["J_logged"] = self.engine.read("J")
-            self.logging_values["trajectory_ages_logged"] = self.engine.read("AGES")
+            self.logging_values["Q_logged"] = self._logged("Q")
+            self.logging_values["J_logged"] = self._logged("J")
+            self.logging_values["trajectory_ages_logged"] = self._logged("AGES")
             self.logging_values["u_logged"] = self.u
         self.optimal_control_sequence = self.u_nom                   # :435
         self.count += 1

@@ -91,6 +91,9 @@ SYMBOLS = {
     "ctk_profile_enable": (C.c_int, [_H, C.c_int]),
     "ctk_profile_read": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ctk_dominant_kernel": (C.c_char_p, [_H]),
+    "ctk_log_enable": (C.c_int, [_H, C.c_size_t]),
+    "ctk_log_count": (C.c_size_t, [_H]),
+    "ctk_log_read": (C.c_int, [_H, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
 }
 
 
@@ -373,6 +376,23 @@ class CtkEngine:
         if name == "BEST_IDX":
             return out.astype(np.int64)
         return out.reshape(shapes[name])
+
+    # device-resident step log (include/ctk_hip.h: ctk_log_*)
+    def log_enable(self, capacity_steps: int):
+        self._check(self._lib.ctk_log_enable(self._h, int(capacity_steps)))
+        self.log_capacity = int(capacity_steps)
+
+    def log_count(self) -> int:
+        return int(self._lib.ctk_log_count(self._h))
+
+    def log_read(self, name: str, first_step: int, n_steps: int) -> np.ndarray:
+        N, H = self.N, self.H
+        shape = {"Q": (N, H, 1), "J": (N,), "TRAJ": (N, H + 1, 4), "AGES": (N,)}[name]
+        out = np.empty((int(n_steps),) + shape, np.float32)
+        n = C.c_size_t()
+        self._check(self._lib.ctk_log_read(self._h, BUFFERS[name], int(first_step), int(n_steps), _ptr(out), out.size, C.byref(n)))
+        assert n.value == out.size
+        return out
 
     def get_state(self) -> np.ndarray:
         n = int(self._lib.ctk_state_size(self._h))

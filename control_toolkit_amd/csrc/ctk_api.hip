@@ -11,6 +11,7 @@
 #include "ctk_device.h"   // tile_stride
 #include "ctk_mlp.h"      // mlp_hid, per-lane weight layout
 #include "ctk_gru.h"      // GRU per-lane table layout
+#include <algorithm>
 
 namespace {
 
@@ -73,7 +74,10 @@ struct ctk_handle {
     int* d_shard_idx = nullptr; size_t shard_idx_cap = 0;
     const float* shard_last_cands = nullptr;
     float shard_s[CTK_S] = {0, 0, 0, 0}; float shard_uprev = 0.0f; bool shard_has_uprev = false;
-    bool have_weights = false;  // MLP weights uploaded
+    bool have_weights = false;  // network weights uploaded
+    // device-resident step log (ctk_log_enable): rings of `log_cap` slots
+    size_t log_cap = 0, log_count = 0;
+    float* d_log[4] = {nullptr, nullptr, nullptr, nullptr};   // Q, J, TRAJ, AGES
     // profiling
     bool prof = false;
     int prof_every = 1;         // time every n-th dominant-kernel launch (timing a launch costs ~8 us of host time)
@@ -302,6 +306,70 @@ struct ProfSlot {
     }
 };
 
+// Where a readable tensor lives right now (shared by ctk_read and the step log).
+int locate_buffer(ctk_handle* h, int which, const float** src_out, size_t* n_out, bool* is_int_out) {
+    const size_t N = h->N, H = h->H;
+    const float* src = nullptr; size_t n = 0; bool is_int = false;
+    switch (which) {
+        case CTK_BUF_Q: src = h->cfg.optimizer == CTK_OPT_RPGD ? h->d_pop[h->rcur ^ 1] : (h->variant == CTK_OPT_CEM_NAIVE_GRAD ? h->d_pop[0] : (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ ? h->d_pop[h->rcur] : h->d_Q));
+            n = N * H; break;
+        case CTK_BUF_PLAN: if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: PLAN is an RPGD buffer");
+            src = h->d_pop[h->rcur]; n = N * H; break;
+        case CTK_BUF_ADAM_M:
+            if (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) { src = h->d_m[0]; n = N * H; break; }
+            if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: ADAM_M is an RPGD buffer");
+            src = h->d_m[h->rcur]; n = N * H; break;
+        case CTK_BUF_ADAM_V:
+            if (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) { src = h->d_v[0]; n = N * H; break; }
+            if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: ADAM_V is an RPGD buffer");
+            src = h->d_v[h->rcur]; n = N * H; break;
+        case CTK_BUF_AGES: if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: AGES is an RPGD buffer");
+            src = h->d_ages[h->rcur]; n = N; break;
+        case CTK_BUF_J: src = h->d_J; n = N; break;
+        case CTK_BUF_TRAJ:
+            if (!h->d_traj) return fail(h, CTK_ERR_STATE, "ctk_read: trajectories not materialised (cfg.materialize_trajectories == 0)");
+            src = h->d_traj; n = N * (H + 1) * CTK_S; break;
+        case CTK_BUF_U_NOM: src = h->d_unom[h->cfg.optimizer == CTK_OPT_MPPI ? h->cur : 0]; n = H; break;
+        case CTK_BUF_STD: src = h->d_std; n = H; break;
+        case CTK_BUF_BEST_IDX:
+            src = (const float*)h->d_idx; is_int = true;
+            n = h->cfg.optimizer == CTK_OPT_CEM ? (size_t)h->cfg.cem_best_k : (h->cfg.optimizer == CTK_OPT_RPGD ? (size_t)h->cfg.opt_keep_k : 1);
+            break;
+        default: return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: buffer not available for this optimizer");
+    }
+    *src_out = src; *n_out = n; *is_int_out = is_int;
+    return CTK_OK;
+}
+
+// floats per step of ring `i` (Q, J, TRAJ, AGES); 0 = not logged for this handle
+size_t log_slot_floats(const ctk_handle* h, int i) {
+    const size_t N = h->N, H = h->H;
+    switch (i) {
+        case 0: return N * H;
+        case 1: return N;
+        case 2: return h->d_traj ? N * (H + 1) * CTK_S : 0;
+        default: return h->cfg.optimizer == CTK_OPT_RPGD ? N : 0;
+    }
+}
+
+// append this step's tensors to the rings: one launch, behind the step on the stream (the result is out already)
+int log_step(ctk_handle* h) {
+    static const int which[4] = {CTK_BUF_Q, CTK_BUF_J, CTK_BUF_TRAJ, CTK_BUF_AGES};
+    const size_t slot = h->log_count % h->log_cap;
+    CopyJob jobs[4];
+    for (int i = 0; i < 4; ++i) {
+        jobs[i] = CopyJob{nullptr, nullptr, 0u};
+        const size_t n = log_slot_floats(h, i);
+        if (n == 0 || !h->d_log[i]) continue;
+        const float* src; size_t cnt; bool is_int;
+        if (int rc = locate_buffer(h, which[i], &src, &cnt, &is_int)) return rc;
+        jobs[i] = CopyJob{src, h->d_log[i] + slot * n, (unsigned)n};
+    }
+    HIP_TRY(h, ctk_launch_copy4(h->stream, jobs));
+    ++h->log_count;
+    return CTK_OK;
+}
+
 // Completion of a step = the publishing kernel's single 8-byte system-scope store {u, seq} landing in
 // the pinned host slot.  Polling it avoids the completion-signal round trip of
 // hipStreamSynchronize (several microseconds per step); the spin is bounded, and on timeout the
@@ -322,7 +390,7 @@ int finish_step(ctk_handle* h, float* u_out) {
     if (u_out) u_out[0] = *reinterpret_cast<volatile float*>(h->h_u);
     ++h->seq;
     ++h->call;
-    return CTK_OK;
+    return h->log_cap ? log_step(h) : CTK_OK;
 }
 
 int check_predictor(ctk_handle* h) {
@@ -735,6 +803,7 @@ void ctk_destroy(ctk_handle* h) {
                     h->d_pop[0], h->d_pop[1], h->d_m[0], h->d_m[1], h->d_v[0], h->d_v[1], h->d_ages[0], h->d_ages[1], h->d_bc, h->d_scratch};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->d_shard_idx) hipFree(h->d_shard_idx);
+    for (float* p : h->d_log) if (p) hipFree(p);
     if (h->h_u) hipHostFree(h->h_u);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -1075,35 +1144,8 @@ int ctk_rollout(ctk_handle* h, const float* s, const float* u_prev, const float*
 int ctk_read(ctk_handle* h, int which, float* dst, size_t cap, size_t* n_out) {
     if (!h || !dst) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: NULL destination") : CTK_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    const size_t N = h->N, H = h->H;
     const float* src = nullptr; size_t n = 0; bool is_int = false;
-    switch (which) {
-        case CTK_BUF_Q: src = h->cfg.optimizer == CTK_OPT_RPGD ? h->d_pop[h->rcur ^ 1] : (h->variant == CTK_OPT_CEM_NAIVE_GRAD ? h->d_pop[0] : (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ ? h->d_pop[h->rcur] : h->d_Q));
-            n = N * H; break;
-        case CTK_BUF_PLAN: if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: PLAN is an RPGD buffer");
-            src = h->d_pop[h->rcur]; n = N * H; break;
-        case CTK_BUF_ADAM_M:
-            if (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) { src = h->d_m[0]; n = N * H; break; }
-            if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: ADAM_M is an RPGD buffer");
-            src = h->d_m[h->rcur]; n = N * H; break;
-        case CTK_BUF_ADAM_V:
-            if (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) { src = h->d_v[0]; n = N * H; break; }
-            if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: ADAM_V is an RPGD buffer");
-            src = h->d_v[h->rcur]; n = N * H; break;
-        case CTK_BUF_AGES: if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: AGES is an RPGD buffer");
-            src = h->d_ages[h->rcur]; n = N; break;
-        case CTK_BUF_J: src = h->d_J; n = N; break;
-        case CTK_BUF_TRAJ:
-            if (!h->d_traj) return fail(h, CTK_ERR_STATE, "ctk_read: trajectories not materialised (cfg.materialize_trajectories == 0)");
-            src = h->d_traj; n = N * (H + 1) * CTK_S; break;
-        case CTK_BUF_U_NOM: src = h->d_unom[h->cfg.optimizer == CTK_OPT_MPPI ? h->cur : 0]; n = H; break;
-        case CTK_BUF_STD: src = h->d_std; n = H; break;
-        case CTK_BUF_BEST_IDX:
-            src = (const float*)h->d_idx; is_int = true;
-            n = h->cfg.optimizer == CTK_OPT_CEM ? (size_t)h->cfg.cem_best_k : (h->cfg.optimizer == CTK_OPT_RPGD ? (size_t)h->cfg.opt_keep_k : 1);
-            break;
-        default: return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: buffer not available for this optimizer");
-    }
+    if (int rc = locate_buffer(h, which, &src, &n, &is_int)) return rc;
     if (cap < n) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: destination too small");
     HIP_TRY(h, hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1218,5 +1260,49 @@ int ctk_profile_read(ctk_handle* h, float* ms_out, size_t cap, size_t* n_out) {
 }
 
 const char* ctk_dominant_kernel(const ctk_handle* h) { return h ? h->dominant.c_str() : ""; }
+
+int ctk_log_enable(ctk_handle* h, size_t capacity_steps) {
+    if (!h) return CTK_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 4; ++i) { if (h->d_log[i]) HIP_TRY(h, hipFree(h->d_log[i])); h->d_log[i] = nullptr; }
+    h->log_cap = 0; h->log_count = 0;
+    if (capacity_steps == 0) return CTK_OK;
+    for (int i = 0; i < 4; ++i) {
+        const size_t n = log_slot_floats(h, i);
+        if (n == 0) continue;
+        if (hipMalloc((void**)&h->d_log[i], capacity_steps * n * sizeof(float)) != hipSuccess) {
+            for (int j = 0; j < 4; ++j) { if (h->d_log[j]) hipFree(h->d_log[j]); h->d_log[j] = nullptr; }
+            return fail(h, CTK_ERR_HIP, "ctk_log_enable: not enough device memory for the requested capacity");
+        }
+    }
+    h->log_cap = capacity_steps;
+    return CTK_OK;
+}
+
+size_t ctk_log_count(const ctk_handle* h) { return h ? h->log_count : 0; }
+
+int ctk_log_read(ctk_handle* h, int which, size_t first_step, size_t n_steps, float* dst, size_t cap, size_t* n_out) {
+    if (!h || !dst) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_log_read: NULL destination") : CTK_ERR_INVALID_ARGUMENT;
+    if (h->log_cap == 0) return fail(h, CTK_ERR_STATE, "ctk_log_read: logging is not enabled (ctk_log_enable)");
+    const int ring = which == CTK_BUF_Q ? 0 : which == CTK_BUF_J ? 1 : which == CTK_BUF_TRAJ ? 2 : which == CTK_BUF_AGES ? 3 : -1;
+    if (ring < 0 || !h->d_log[ring]) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_log_read: this tensor is not logged for this handle");
+    if (first_step + n_steps > h->log_count) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_log_read: steps not logged yet");
+    if (h->log_count > h->log_cap && first_step < h->log_count - h->log_cap)
+        return fail(h, CTK_ERR_STATE, "ctk_log_read: the oldest requested step has been overwritten (ring capacity)");
+    const size_t n = log_slot_floats(h, ring);
+    if (cap < n_steps * n) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_log_read: destination too small");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    size_t done = 0;
+    while (done < n_steps) {   // at most two contiguous runs (ring wrap)
+        const size_t slot = (first_step + done) % h->log_cap;
+        const size_t run = std::min(n_steps - done, h->log_cap - slot);
+        HIP_TRY(h, hipMemcpyAsync(dst + done * n, h->d_log[ring] + slot * n, run * n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        done += run;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (n_out) *n_out = n_steps * n;
+    return CTK_OK;
+}
 
 }  // extern "C"

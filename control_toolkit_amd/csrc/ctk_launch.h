@@ -38,6 +38,10 @@ hipError_t ctk_launch_mppi_update(hipStream_t st, const float* parts, int n_part
                                   const InterpEntry* interp, const float* u_nom_in, float* u_nom_out, float lo, float hi,
                                   float* u_dev, float* u_host, uint32_t seq);
 
+// up to four device-to-device copies in ONE launch (the step log, ctk_api.hip:log_step); n_i floats each, n_i == 0 skips
+struct CopyJob { const float* src; float* dst; unsigned n; };
+hipError_t ctk_launch_copy4(hipStream_t st, const CopyJob (&jobs)[4]);
+
 // ---- ctk_sampled.hip : u[n,h] = clip(base[h] + sample[n,h] * scale[h]) rollouts, selection ----
 const char* ctk_affine_rollout_name(int pred, bool log);
 size_t ctk_affine_rollout_lds(int H, int pred = 0);

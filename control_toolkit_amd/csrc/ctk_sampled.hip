@@ -331,6 +331,35 @@ __global__ __launch_bounds__(256) void ctk_pack_candidates(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// step log: four contiguous copies in one launch; blockIdx.y selects the job, float4 body + scalar tail
+struct CopyJobs { CopyJob j[4]; };
+__global__ __launch_bounds__(256) void ctk_log_copy(CopyJobs jobs) {
+    const CopyJob job = jobs.j[blockIdx.y];
+    const unsigned n = job.n;
+    const unsigned tid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    if (((reinterpret_cast<uintptr_t>(job.src) | reinterpret_cast<uintptr_t>(job.dst)) & 15) == 0) {
+        const float4* s4 = reinterpret_cast<const float4*>(job.src);
+        float4* d4 = reinterpret_cast<float4*>(job.dst);
+        const unsigned n4 = n >> 2;
+        for (unsigned i = tid; i < n4; i += stride) d4[i] = s4[i];
+        for (unsigned i = (n4 << 2) + tid; i < n; i += stride) job.dst[i] = job.src[i];
+    } else {
+        for (unsigned i = tid; i < n; i += stride) job.dst[i] = job.src[i];
+    }
+}
+
+hipError_t ctk_launch_copy4(hipStream_t st, const CopyJob (&jobs)[4]) {
+    CopyJobs cj;
+    unsigned nmax = 0;
+    for (int i = 0; i < 4; ++i) { cj.j[i] = jobs[i]; nmax = jobs[i].n > nmax ? jobs[i].n : nmax; }
+    if (nmax == 0) return hipSuccess;
+    unsigned blocks = (nmax / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+    hipLaunchKernelGGL(ctk_log_copy, dim3(blocks, 4), dim3(256), 0, st, cj);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 const char* ctk_affine_rollout_name(int pred, bool log) {
     if (pred == CTK_PRED_ODE) return log ? "ctk_affine_rollout<0, true>" : "ctk_affine_rollout<0, false>";
     if (pred == CTK_PRED_GRU) return log ? "ctk_affine_rollout<2, true>" : "ctk_affine_rollout<2, false>";

@@ -278,6 +278,22 @@ int ctk_profile_read(ctk_handle* h, float* ms_out, size_t cap, size_t* n_out);
 /* name of the dominant kernel (as it appears in rocprofv3 --kernel-trace) */
 const char* ctk_dominant_kernel(const ctk_handle* h);
 
+/* -------------------------------------------------------------------------------------------
+ * device-resident step log.  Replaces the per-step to_numpy() of `optimizer_logging`
+ * (optimizer_mppi.py:214-218, optimizer_cem_tf.py:104-108, optimizer_rpgd.py:428-433) + the per-step copies of
+ * template_controller.update_logs (Controllers/__init__.py:170-178): after every completed step ONE copy
+ * kernel appends Q [N,H,C], J [N], the rollout trajectories [N,H+1,S] (if materialised) and, for RPGD, the
+ * trajectory ages [N] to a ring in HBM (what ctk_read would return for CTK_BUF_Q / J / TRAJ / AGES at that
+ * moment); the host fetches any run of steps in one transfer when it wants them
+ * (template_controller.get_outputs, Controllers/__init__.py:159-168).
+ * capacity_steps > 0 allocates the ring (capacity * (N*H + 2N + N*(H+1)*S) floats) and starts logging;
+ * 0 stops and frees.  Steps older than `capacity` are overwritten; reading them is CTK_ERR_STATE.
+ * ----------------------------------------------------------------------------------------- */
+int ctk_log_enable(ctk_handle* h, size_t capacity_steps);
+size_t ctk_log_count(const ctk_handle* h); /* steps logged since ctk_log_enable */
+/* which: CTK_BUF_Q | CTK_BUF_J | CTK_BUF_TRAJ | CTK_BUF_AGES; steps [first_step, first_step + n_steps)   */
+int ctk_log_read(ctk_handle* h, int which, size_t first_step, size_t n_steps, float* dst, size_t cap, size_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

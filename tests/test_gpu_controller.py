@@ -182,3 +182,51 @@ def test_cost_yaml_edit_reaches_the_kernels_within_one_step(tmp_path):
     J_ref1 = oracle_J(O.EnvParams(dd_weight=50.0, ep_weight=5000.0, ekp_weight=10.0), noise[1], u_nom0, float(np.asarray(u0).reshape(-1)[0]))
     np.testing.assert_allclose(c.optimizer.logging_values["J_logged"], J_ref1, rtol=3e-5)
     CostFunctionUpdater.stop_all_watchers()
+
+
+@pytest.mark.parametrize("opt_name", ["mppi-hip", "rpgd-hip", "cem-hip"])
+def test_device_resident_log_equals_host_logging(opt_name):
+    """`logging_on_device` keeps Q / J / trajectories / ages of every step in an HBM ring and
+    get_outputs() fetches runs of steps in one transfer — same arrays as the per-step host copies of the
+    reference path (Controllers/__init__.py:159-178), including across a ring wrap (capacity 3, 8 steps)."""
+    from control_toolkit_amd.Optimizers import DeviceLogEntry
+    N, H, steps = 96, 12, 8
+    base = dict(seed=5, mpc_horizon=H, num_rollouts=N, mpc_timestep=0.02)
+    if opt_name == "mppi-hip":
+        cfg = dict(base, cc_weight=1.0, R=1.0, LBD=100.0, NU=1000.0, SQRTRHOINV=0.03, period_interpolation_inducing_points=3)
+    elif opt_name == "cem-hip":
+        cfg = dict(base, cem_outer_it=2, cem_best_k=12, cem_initial_action_stdev=0.5, cem_stdev_min=0.01, warmup=False, warmup_iterations=1)
+    else:
+        d = load("rpgd_ode_small.npz")
+        cfg = dict(base, rtol=1e-3, **rpgd_kwargs_from(d))
+    outs = []
+    for on_device in (False, True):
+        c = controller_mpc("CartPole", LIMITS, {"target_position": 0.0, "target_equilibrium": 1.0},
+                           config_controllers={"mpc": dict(CTRL_CFG["mpc"], optimizer=opt_name, calculate_optimal_trajectory=False)},
+                           config_optimizers={opt_name: dict(cfg, logging_on_device=on_device, logging_capacity=3)},
+                           predictor=PredictorWrapper(), cost_function=CostFunctionWrapper())
+        c.configure()
+        s = np.array([0.02, 0.0, 0.3, -0.1], np.float32)
+        for t in range(steps):
+            u = c.step(s)
+            lv = c.optimizer.logging_values
+            if on_device:
+                assert isinstance(lv["Q_logged"], DeviceLogEntry) and lv["Q_logged"].shape == (N, H, 1)
+                if t == 4:     # a handle is usable like the array it stands for
+                    np.testing.assert_array_equal(np.asarray(lv["J_logged"]), c.optimizer.engine.read("J"))
+                    np.testing.assert_array_equal(lv["Q_logged"].numpy(), c.optimizer.engine.read("Q"))
+            s = (s + np.float32(0.01) * np.float32(t + 1) * np.array([1, -1, 2, 0.5], np.float32)).astype(np.float32)
+        outs.append(c.get_outputs())
+        if on_device:
+            e = c.optimizer.engine
+            assert e.log_count() == steps
+            with pytest.raises(Exception, match="overwritten"):
+                e.log_read("J", 0, 1)                    # capacity 3: step 0 is long gone from the ring
+            assert e.log_read("J", steps - 3, 3).shape == (3, N)
+    host, dev = outs
+    for k in ("Q_logged", "J_logged", "rollout_trajectories_logged", "s_logged", "u_logged", "trajectory_ages_logged"):
+        if host[k] is None:
+            assert dev[k] is None
+            continue
+        assert dev[k].shape == host[k].shape and dev[k].shape[0] == steps
+        np.testing.assert_array_equal(dev[k], host[k])   # device Philox, same seed: bit-identical runs
