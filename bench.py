@@ -210,7 +210,12 @@ def main():
     if world > 1 or args.force_sharded or force_pg:
         # the collective runs on torch's stream: issue the engine's kernels there too
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
-        sharded = ShardedMPPI(eng, rank, world, device=dev, always_collective=force_pg)
+        # record exchange between the ranks: direct peer-to-peer stores over xGMI (falls back to the RCCL all-gather,
+        # collectively, if the IPC set-up or its self-test fails on any rank); CTK_BENCH_EXCHANGE=rccl forces RCCL
+        sharded = ShardedMPPI(eng, rank, world, device=dev, always_collective=force_pg,
+                              exchange=os.environ.get("CTK_BENCH_EXCHANGE", "p2p"))
+        if rank == 0 and sharded.p2p_error:
+            print(f"[bench] p2p exchange unavailable ({sharded.p2p_error}); using the RCCL all-gather", file=sys.stderr)
     if w["opt"] == "rpgd":
         eng.reset()
 
@@ -286,7 +291,9 @@ def main():
             "config": {"workload": f"{w['opt'].upper()} N={N} per GPU, H={H}, period={p}, predictor {w['pred']} "
                                    f"(4 states, 1 input) [{args.workload}]",
                        "samples": args.samples if w["opt"] == "mppi" else "device-rng", "global_rollouts": N * world,
-                       "parallelism": (f"rollout shards x{world}, 1 all-gather of {P + 2} floats per step" if world > 1
+                       "parallelism": ((f"rollout shards x{world}, records of {P + 2} floats exchanged by peer-to-peer stores over xGMI"
+                                        if sharded.exchange == "p2p" else
+                                        f"rollout shards x{world}, 1 all-gather of {P + 2} floats per step (RCCL)") if world > 1
                                        else "single GPU")},
             "step_ms_median": float(np.median(ps)), "step_ms_p95": float(np.percentile(ps, 95)),
             "roofline": roof,

@@ -91,6 +91,10 @@ SYMBOLS = {
     "ctk_profile_enable": (C.c_int, [_H, C.c_int]),
     "ctk_profile_read": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ctk_dominant_kernel": (C.c_char_p, [_H]),
+    "ctk_p2p_alloc": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
+    "ctk_p2p_connect": (C.c_int, [_H, C.c_void_p]),
+    "ctk_p2p_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ctk_p2p_close": (C.c_int, [_H]),
     "ctk_log_enable": (C.c_int, [_H, C.c_size_t]),
     "ctk_log_count": (C.c_size_t, [_H]),
     "ctk_log_read": (C.c_int, [_H, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -307,6 +311,31 @@ class CtkEngine:
     def mppi_step_end(self, parts_dev_ptr: int, n_parts: int) -> np.ndarray:
         self._check(self._lib.ctk_mppi_step_end(self._h, C.c_void_p(parts_dev_ptr), int(n_parts), _ptr(self._u)))
         return self._u.copy()
+
+    # ---- sharded MPPI over peer-to-peer stores (include/ctk_hip.h: ctk_p2p_*) -------------------------
+    def p2p_alloc(self, rank: int, world: int) -> bytes:
+        buf = C.create_string_buffer(64)
+        self._check(self._lib.ctk_p2p_alloc(self._h, int(rank), int(world), buf))
+        return bytes(buf.raw)
+
+    def p2p_connect(self, handles) -> None:
+        blob = b"".join(bytes(h) for h in handles)
+        self._check(self._lib.ctk_p2p_connect(self._h, C.c_char_p(blob)))
+
+    def p2p_step(self, s, samples=None, u_prev=None) -> np.ndarray:
+        s = _f32(s).reshape(-1)
+        up = None if u_prev is None else _f32(u_prev).reshape(-1)[:1].copy()
+        if samples is None:
+            sp, loc = None, LOC_NONE
+        elif isinstance(samples, int):
+            sp, loc = C.c_void_p(samples), LOC_DEVICE
+        else:
+            arr = _f32(samples); sp, loc = _ptr(arr), LOC_HOST
+        self._check(self._lib.ctk_p2p_step(self._h, _ptr(s), _ptr(up), sp, loc, _ptr(self._u)))
+        return self._u.copy()
+
+    def p2p_close(self) -> None:
+        self._check(self._lib.ctk_p2p_close(self._h))
 
     # ---- sharded CEM / random-action ---------------------------------------------------------------
     def shard_candidates_size(self) -> int:

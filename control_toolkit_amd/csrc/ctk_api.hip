@@ -12,6 +12,7 @@
 #include "ctk_mlp.h"      // mlp_hid, per-lane weight layout
 #include "ctk_gru.h"      // GRU per-lane table layout
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -75,6 +76,12 @@ struct ctk_handle {
     const float* shard_last_cands = nullptr;
     float shard_s[CTK_S] = {0, 0, 0, 0}; float shard_uprev = 0.0f; bool shard_has_uprev = false;
     bool have_weights = false;  // network weights uploaded
+    // peer-to-peer sharded MPPI (ctk_p2p_*)
+    int p2p_rank = -1, p2p_world = 0;
+    bool p2p_connected = false;
+    float* p2p_bufs[CTK_P2P_MAX_WORLD] = {};   // [rank] = my own uncached buffer, the others IPC mappings
+    uint32_t p2p_seq = 1;
+    double p2p_timeout_s = 5.0;
     // device-resident step log (ctk_log_enable): rings of `log_cap` slots
     size_t log_cap = 0, log_count = 0;
     float* d_log[4] = {nullptr, nullptr, nullptr, nullptr};   // Q, J, TRAJ, AGES
@@ -804,6 +811,7 @@ void ctk_destroy(ctk_handle* h) {
     for (void* b : bufs) if (b) hipFree(b);
     if (h->d_shard_idx) hipFree(h->d_shard_idx);
     for (float* p : h->d_log) if (p) hipFree(p);
+    ctk_p2p_close(h);
     if (h->h_u) hipHostFree(h->h_u);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -1260,6 +1268,91 @@ int ctk_profile_read(ctk_handle* h, float* ms_out, size_t cap, size_t* n_out) {
 }
 
 const char* ctk_dominant_kernel(const ctk_handle* h) { return h ? h->dominant.c_str() : ""; }
+
+int ctk_p2p_close(ctk_handle* h) {
+    if (!h) return CTK_ERR_INVALID_ARGUMENT;
+    if (h->p2p_world == 0) return CTK_OK;
+    hipSetDevice(h->cfg.device);
+    hipStreamSynchronize(h->stream);
+    for (int w = 0; w < h->p2p_world; ++w) {
+        if (!h->p2p_bufs[w]) continue;
+        if (w == h->p2p_rank) hipFree(h->p2p_bufs[w]); else hipIpcCloseMemHandle(h->p2p_bufs[w]);
+        h->p2p_bufs[w] = nullptr;
+    }
+    h->p2p_world = 0; h->p2p_rank = -1; h->p2p_connected = false;
+    return CTK_OK;
+}
+
+int ctk_p2p_alloc(ctk_handle* h, int rank, int world, void* handle_out) {
+    if (!h || !handle_out) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_p2p_alloc: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
+    if (h->cfg.optimizer != CTK_OPT_MPPI) return fail(h, CTK_ERR_STATE, "ctk_p2p_alloc: handle is not MPPI");
+    if (world < 1 || world > CTK_P2P_MAX_WORLD || rank < 0 || rank >= world)
+        return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_p2p_alloc: need 0 <= rank < world <= 16");
+    static_assert(sizeof(hipIpcMemHandle_t) == CTK_P2P_HANDLE_BYTES, "handle size");
+    ctk_p2p_close(h);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t bytes = ctk_p2p_buffer_floats(world, h->P) * sizeof(float);
+    float* buf = nullptr;
+    HIP_TRY(h, hipExtMallocWithFlags((void**)&buf, bytes, hipDeviceMallocUncached));
+    HIP_TRY(h, hipMemset(buf, 0, bytes));
+    HIP_TRY(h, hipDeviceSynchronize());
+    hipIpcMemHandle_t hd;
+    hipError_t e = hipIpcGetMemHandle(&hd, buf);
+    if (e != hipSuccess) { hipFree(buf); return fail(h, CTK_ERR_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e)); }
+    std::memcpy(handle_out, &hd, sizeof(hd));
+    h->p2p_rank = rank; h->p2p_world = world; h->p2p_bufs[rank] = buf; h->p2p_seq = 1; h->p2p_connected = false;
+    if (const char* t = std::getenv("CTK_P2P_TIMEOUT_S")) { const double v = std::atof(t); if (v > 0.0) h->p2p_timeout_s = v; }
+    return CTK_OK;
+}
+
+int ctk_p2p_connect(ctk_handle* h, const void* handles) {
+    if (!h || !handles) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_p2p_connect: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
+    if (h->p2p_world == 0) return fail(h, CTK_ERR_STATE, "ctk_p2p_connect: call ctk_p2p_alloc first");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    for (int w = 0; w < h->p2p_world; ++w) {
+        if (w == h->p2p_rank) continue;
+        hipIpcMemHandle_t hd;
+        std::memcpy(&hd, (const char*)handles + (size_t)w * CTK_P2P_HANDLE_BYTES, sizeof(hd));
+        void* p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return fail(h, CTK_ERR_HIP, std::string("hipIpcOpenMemHandle (rank ") + std::to_string(w) + "): " + hipGetErrorString(e));
+        h->p2p_bufs[w] = (float*)p;
+    }
+    h->p2p_connected = true;
+    return CTK_OK;
+}
+
+int ctk_p2p_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int samples_loc, float* u_out) {
+    if (!h || !s) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_p2p_step: NULL state") : CTK_ERR_INVALID_ARGUMENT;
+    if (!h->p2p_connected) return fail(h, CTK_ERR_STATE, "ctk_p2p_step: call ctk_p2p_alloc and ctk_p2p_connect first");
+    if (h->mppi_pending) return fail(h, CTK_ERR_STATE, "ctk_p2p_step: a begin/end sharded step is pending");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    for (int i = 0; i < CTK_S; ++i) h->mppi_s[i] = s[i];
+    const int W = h->p2p_world, rs = 2 + h->P, par = (int)(h->p2p_seq & 1u);
+    float* my_slot = h->p2p_bufs[h->p2p_rank] + (size_t)(par * W + h->p2p_rank) * rs;
+    if (mppi_can_fuse(h)) {
+        if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 2, my_slot)) return rc;
+    } else {
+        if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 0, nullptr)) return rc;
+        const float* parts; int n_parts;
+        if (int rc = mppi_reduce_blocks(h, &parts, &n_parts)) return rc;
+        HIP_TRY(h, ctk_launch_mppi_merge_partial(h->stream, parts, n_parts, n_parts, h->P, h->mk.neg_inv_lbd, my_slot));
+    }
+    uint32_t* err = reinterpret_cast<uint32_t*>(h->h_u_dev) + 2;
+    const int nxt = h->cur ^ 1;
+    HIP_TRY(h, ctk_launch_mppi_p2p_exchange(h->stream, h->p2p_bufs, h->p2p_rank, W, h->P, h->p2p_seq, err, h->p2p_timeout_s,
+                                            h->mk.neg_inv_lbd, h->H, h->d_interp, h->d_unom[h->cur], h->d_unom[nxt],
+                                            h->cfg.action_low, h->cfg.action_high, h->d_u, h->h_u_dev, h->seq));
+    h->cur = nxt;
+    ++h->p2p_seq;
+    if (int rc = mppi_advance_hidden(h)) return rc;
+    if (int rc = finish_step(h, u_out)) return rc;
+    if (reinterpret_cast<volatile uint32_t*>(h->h_u)[2] != 0) {
+        reinterpret_cast<volatile uint32_t*>(h->h_u)[2] = 0;
+        return fail(h, CTK_ERR_STATE, "ctk_p2p_step: timed out waiting for a peer's record (a rank is gone or out of step)");
+    }
+    return CTK_OK;
+}
 
 int ctk_log_enable(ctk_handle* h, size_t capacity_steps) {
     if (!h) return CTK_ERR_INVALID_ARGUMENT;

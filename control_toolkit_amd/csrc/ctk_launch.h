@@ -34,6 +34,13 @@ hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& 
                                    const MppiFuse& fuse, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t ctk_launch_mppi_merge_partial(hipStream_t st, const float* parts, int n_parts, int per_block, int P,
                                          float neg_inv_lbd, float* out_rec);
+// direct peer-to-peer record exchange + merge + update (ctk_mppi.hip: ctk_mppi_p2p_exchange)
+constexpr int CTK_P2P_MAX_WORLD = 16;
+size_t ctk_p2p_buffer_floats(int world, int P);
+hipError_t ctk_launch_mppi_p2p_exchange(hipStream_t st, float* const* bufs, int rank, int world, int P, uint32_t p2p_seq,
+                                        uint32_t* err_host, double timeout_s, float neg_inv_lbd, int H, const InterpEntry* interp,
+                                        const float* u_nom_in, float* u_nom_out, float lo, float hi, float* u_dev, float* u_host,
+                                        uint32_t seq);
 hipError_t ctk_launch_mppi_update(hipStream_t st, const float* parts, int n_parts, int P, float neg_inv_lbd, int H,
                                   const InterpEntry* interp, const float* u_nom_in, float* u_nom_out, float lo, float hi,
                                   float* u_dev, float* u_host, uint32_t seq);

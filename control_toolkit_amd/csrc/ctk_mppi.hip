@@ -46,9 +46,12 @@ __host__ __device__ inline int ubuf_stride(int H) { return (H + 1) | 1; }
 constexpr int MERGE_BLOCK = 256;
 constexpr int MERGE_CHUNK = 1024;
 
-template <bool SC1>
+// LD: 0 plain loads (records written by an earlier launch); 1 agent-scope (handed over inside ONE launch);
+//     2 system-scope (records stored by peer GPUs into this GPU's uncached exchange buffer, ctk_mppi_p2p_exchange)
+template <int LD>
 CTK_DEV float ld_rec(const float* p) {
-    if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (LD == 1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if constexpr (LD == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     else return *p;
 }
 CTK_DEV void st_rec(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -68,7 +71,7 @@ struct MppiUpdateArgs {
 
 // scratch: >= 8 + (P + 1) + min(cnt, MERGE_CHUNK) floats of LDS, plus cnt*(2+P) more when `stage`
 // (all records fetched into LDS by ONE wide pass: one memory round trip instead of one per record).
-template <bool FINAL, bool SC1>
+template <bool FINAL, int SC1>
 CTK_DEV void mppi_merge_block(float* scratch, const float* base, int cnt, int P, float neg_inv_lbd, float* out_rec,
                               const MppiUpdateArgs& up, bool stage) {
     float* red = scratch;             // [4] cross-wave scratch
@@ -155,6 +158,62 @@ CTK_DEV void mppi_merge_block(float* scratch, const float* base, int cnt, int P,
             if (h == 0) publish_u(up.u_dev, up.u_host, o, up.seq);   // :191 u = u_nom[0,0,:]
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU exchange without a collective library call (xGMI is point-to-point): every rank owns an
+// uncached, IPC-exported exchange buffer  recs[2 parities][W][2+P] | flags[2][W]  that all peers have mapped.
+// One 256-thread block per rank and step: store my shard record into slot [parity][rank] of EVERY rank's
+// buffer (system-scope stores over xGMI), fence, raise flag [parity][rank] = seq there; wait until all W
+// flags in MY buffer carry seq; merge the W records and apply the MPPI update — every rank arrives at the
+// identical u_nom.  Parity double-buffering: a peer can run at most one step ahead (it needs my flag of step
+// seq+1 to finish that step), so it never overwrites a slot I am still reading.  The wait is bounded by a
+// wall-clock timeout; on expiry the step publishes NaN and an error word the host turns into CTK_ERR_STATE.
+// ---------------------------------------------------------------------------------------------
+struct P2PArgs {
+    float* bufs[CTK_P2P_MAX_WORLD];   // exchange buffer of every rank (bufs[rank] is local memory)
+    int rank, world, rs;              // rs = 2 + P floats per record
+    uint32_t seq;
+    uint32_t* err_host;               // pinned, device-visible error word
+    unsigned long long timeout_ticks; // wall_clock64 ticks (100 MHz)
+};
+
+__global__ __launch_bounds__(MERGE_BLOCK) void ctk_mppi_p2p_exchange(P2PArgs x, int P, float neg_inv_lbd, MppiUpdateArgs up, int stage_ok) {
+    extern __shared__ float lds[];
+    __shared__ int bad;
+    const int t = threadIdx.x, W = x.world, rs = x.rs, par = (int)(x.seq & 1u);
+    float* mine = x.bufs[x.rank];
+    const size_t slot = (size_t)(par * W + x.rank) * rs, flags0 = (size_t)2 * W * rs;
+    if (t == 0) bad = 0;
+    for (int w = 0; w < W; ++w) {
+        if (w == x.rank) continue;
+        float* dst = x.bufs[w] + slot;
+        for (int i = t; i < rs; i += MERGE_BLOCK)
+            __hip_atomic_store(dst + i, ld_rec<2>(mine + slot + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (t < W) {
+        uint32_t* f = reinterpret_cast<uint32_t*>(x.bufs[t] + flags0) + par * W + x.rank;
+        __hip_atomic_store(f, x.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (t < W) {
+        const uint32_t* f = reinterpret_cast<const uint32_t*>(mine + flags0) + par * W + t;
+        const unsigned long long t0 = wall_clock64();
+        while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - x.seq) < 0) {
+            if (wall_clock64() - t0 > x.timeout_ticks) { atomicExch(&bad, 1); break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    __syncthreads();
+    if (bad) {
+        if (t == 0) {
+            __hip_atomic_store(x.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            publish_u(up.u_dev, up.u_host, __builtin_nanf(""), up.seq);
+        }
+        return;
+    }
+    mppi_merge_block<true, 2>(lds, mine + (size_t)par * W * rs, W, P, neg_inv_lbd, nullptr, up, stage_ok != 0);
 }
 
 // grid.x blocks; block b merges records [b*per_block, ...)
@@ -520,6 +579,24 @@ hipError_t ctk_launch_mppi_merge_partial(hipStream_t st, const float* parts, int
     const bool stage = merge_can_stage(P, per_block);
     hipLaunchKernelGGL(ctk_mppi_merge<false>, dim3(blocks), dim3(MERGE_BLOCK), stage ? merge_lds_staged(P, per_block) : merge_lds(P, per_block),
                        st, parts, n_parts, per_block, P, neg_inv_lbd, out_rec, MppiUpdateArgs{}, stage ? 1 : 0);
+    return hipGetLastError();
+}
+
+size_t ctk_p2p_buffer_floats(int world, int P) { return (size_t)2 * world * (2 + P) + (size_t)2 * world; }
+
+hipError_t ctk_launch_mppi_p2p_exchange(hipStream_t st, float* const* bufs, int rank, int world, int P, uint32_t p2p_seq,
+                                        uint32_t* err_host, double timeout_s, float neg_inv_lbd, int H, const InterpEntry* interp,
+                                        const float* u_nom_in, float* u_nom_out, float lo, float hi, float* u_dev, float* u_host,
+                                        uint32_t seq) {
+    P2PArgs x{};
+    for (int w = 0; w < world; ++w) x.bufs[w] = bufs[w];
+    x.rank = rank; x.world = world; x.rs = 2 + P; x.seq = p2p_seq; x.err_host = err_host;
+    x.timeout_ticks = (unsigned long long)(timeout_s * 1.0e8);
+    const bool stage = merge_can_stage(P, world);
+    hipLaunchKernelGGL(ctk_mppi_p2p_exchange, dim3(1), dim3(MERGE_BLOCK), stage ? merge_lds_staged(P, world) : merge_lds(P, world), st,
+                       x, P, neg_inv_lbd,
+                       MppiUpdateArgs{nullptr, nullptr, nullptr, nullptr, H, interp, u_nom_in, u_nom_out, lo, hi, u_dev, u_host, seq},
+                       stage ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -12,7 +12,14 @@ import numpy as np
 
 
 class ShardedMPPI:
-    def __init__(self, engine, rank: int, world_size: int, group=None, device=None, always_collective: bool = False):
+    """exchange = "rccl": ctk_mppi_step_begin -> all_gather_into_tensor -> ctk_mppi_step_end.
+    exchange = "p2p" : the ranks' exchange kernels store their records straight into each other's HBM over xGMI
+    (ctk_p2p_*, HIP IPC mappings set up once through the process group): no collective launch and no host
+    round trip inside a step.  One node only.  If the set-up or the two self-test steps fail on any rank, all
+    ranks fall back to "rccl" together (the decision is itself all-reduced)."""
+
+    def __init__(self, engine, rank: int, world_size: int, group=None, device=None, always_collective: bool = False,
+                 exchange: str = "rccl"):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -22,10 +29,72 @@ class ShardedMPPI:
         self.device = device if device is not None else torch.device("cpu")
         self.mine = torch.zeros(self.rec, dtype=torch.float32, device=self.device)
         self.all = torch.zeros(self.rec * world_size, dtype=torch.float32, device=self.device)
+        self.exchange = "rccl"
+        self.p2p_error = None
+        if exchange == "p2p" and world_size > 1:
+            self._try_p2p(device)
+        elif exchange not in ("rccl", "p2p"):
+            raise ValueError(f"exchange must be 'rccl' or 'p2p', got {exchange!r}")
+
+    def _all_ok(self, ok: bool, device) -> bool:
+        dist, torch = self.dist, self.torch
+        backend = dist.get_backend(self.group)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
+
+    def _try_p2p(self, device):
+        dist = self.dist
+        ok, handle = True, b"\0" * 64
+        try:
+            handle = self.engine.p2p_alloc(self.rank, self.world_size)
+        except Exception as e:   # noqa: BLE001 — any failure means "use RCCL", decided collectively below
+            ok, self.p2p_error = False, f"alloc: {e}"
+        handles = [None] * self.world_size
+        dist.all_gather_object(handles, handle, group=self.group)
+        if ok:
+            try:
+                self.engine.p2p_connect(handles)
+            except Exception as e:   # noqa: BLE001
+                ok, self.p2p_error = False, f"connect: {e}"
+        ok = self._all_ok(ok, device)
+        if ok:
+            # self-test: two exchange steps (both parities) must complete on every rank and reproduce the plan of
+            # the RCCL path.  Every rank runs the same sequence of collectives whatever happens locally.
+            state = self.engine.get_state()
+            s0 = np.zeros(4, np.float32)
+            # explicit draws (the device sampler advances with every step, the two paths would see different noise)
+            noise = np.random.default_rng(1234 + self.rank).standard_normal(self.engine.samples_needed()).astype(np.float32)
+            u_p2p = plan_p2p = None
+            dist.barrier(group=self.group)
+            try:
+                self.engine.p2p_step(s0, noise)
+                u_p2p = self.engine.p2p_step(s0, noise)
+                plan_p2p = self.engine.read("U_NOM")
+            except Exception as e:   # noqa: BLE001
+                ok, self.p2p_error = False, f"self-test: {e}"
+            ok = self._all_ok(ok, device)
+            self.engine.set_state(state)
+            if ok:
+                self.step(s0, noise)                # exchange == "rccl" here
+                u_rccl = self.step(s0, noise)
+                if not (np.allclose(u_p2p, u_rccl, rtol=1e-4, atol=2e-5)
+                        and np.allclose(plan_p2p, self.engine.read("U_NOM"), rtol=1e-4, atol=2e-5)):
+                    ok, self.p2p_error = False, "self-test: p2p and rccl plans differ"
+                self.engine.set_state(state)
+                ok = self._all_ok(ok, device)
+        self.exchange = "p2p" if ok else "rccl"
+        if not ok:
+            try:
+                self.engine.p2p_close()
+            except Exception:   # noqa: BLE001
+                pass
 
     def step(self, s, samples=None, u_prev=None) -> np.ndarray:
         """samples: this rank's slice of the draws (host array / device pointer) or None (device
         Philox addressed by GLOBAL rollout index, so the result does not depend on world_size)."""
+        if self.exchange == "p2p":
+            return self.engine.p2p_step(s, samples, u_prev=u_prev)
         self.engine.mppi_step_begin(s, self.mine.data_ptr(), samples, u_prev=u_prev)
         if self.world_size > 1 or self.always_collective:
             self.dist.all_gather_into_tensor(self.all, self.mine, group=self.group)

@@ -279,6 +279,23 @@ int ctk_profile_read(ctk_handle* h, float* ms_out, size_t cap, size_t* n_out);
 const char* ctk_dominant_kernel(const ctk_handle* h);
 
 /* -------------------------------------------------------------------------------------------
+ * sharded MPPI over peer-to-peer stores (no counterpart in the reference).  Alternative to
+ * ctk_mppi_step_begin / all-gather / ctk_mppi_step_end for ranks on ONE node: every rank owns an uncached
+ * exchange buffer that all peers map through HIP IPC; per step each rank's exchange kernel stores its
+ * (2+P)-float record into every peer's buffer over xGMI, raises a flag, waits for all flags in its own
+ * buffer (bounded by a timeout) and merges — no host round trip and no collective-library launch between the
+ * rollout and the update.  Protocol: every rank calls ctk_p2p_alloc (returns a CTK_P2P_HANDLE_BYTES handle),
+ * the caller exchanges the handles by any means (torch.distributed all_gather_object), every rank calls
+ * ctk_p2p_connect with all handles in rank order, then ctk_p2p_step in lockstep (same number of calls on
+ * every rank).  world <= 16.  A timeout (peer gone) surfaces as CTK_ERR_STATE.
+ * ----------------------------------------------------------------------------------------- */
+#define CTK_P2P_HANDLE_BYTES 64
+int ctk_p2p_alloc(ctk_handle* h, int rank, int world, void* handle_out);
+int ctk_p2p_connect(ctk_handle* h, const void* handles);
+int ctk_p2p_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int samples_loc, float* u_out);
+int ctk_p2p_close(ctk_handle* h);
+
+/* -------------------------------------------------------------------------------------------
  * device-resident step log.  Replaces the per-step to_numpy() of `optimizer_logging`
  * (optimizer_mppi.py:214-218, optimizer_cem_tf.py:104-108, optimizer_rpgd.py:428-433) + the per-step copies of
  * template_controller.update_logs (Controllers/__init__.py:170-178): after every completed step ONE copy
