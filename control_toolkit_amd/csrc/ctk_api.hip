@@ -42,6 +42,7 @@ struct ctk_handle {
     float* d_parts2 = nullptr;
     float* d_parts3 = nullptr;
     unsigned* d_counter = nullptr;   // ticket counter of the fused in-launch merge
+    unsigned long long* d_ll = nullptr;   // {value, seq} record words of the low-latency in-launch hand-off
     float* d_unom[2] = {nullptr, nullptr};   // MPPI u_nom ping-pong / CEM mu in [0]
     int cur = 0;
     float* d_std = nullptr;     // CEM
@@ -422,7 +423,7 @@ int mppi_rollout(ctk_handle* h, const float* s, const float* u_prev, const float
     const bool log = h->cfg.materialize_trajectories != 0;
     if (int rc = check_predictor(h)) return rc;
     MppiFuse fz;
-    fz.mode = fuse_mode; fz.counter = h->d_counter; fz.out_rec = partial_dev;
+    fz.mode = fuse_mode; fz.counter = h->d_counter; fz.out_rec = partial_dev; fz.ll = h->d_ll;
     fz.u_nom_out = h->d_unom[h->cur ^ 1]; fz.u_dev = h->d_u; fz.u_host = h->h_u_dev; fz.seq = h->seq;
     ProfSlot ps(h);
     HIP_TRY(h, ctk_launch_mppi_rollout(h->stream, h->cfg.predictor, a, h->k, h->mk, d_s, h->d_unom[h->cur], h->d_wperm,
@@ -751,6 +752,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     TRY_CREATE(dev_alloc(h, &h->d_parts2, ((nblk + 31) / 32) * (2 + P)));
     TRY_CREATE(dev_alloc(h, &h->d_parts3, ((nblk + 1023) / 1024) * (2 + P)));
     TRY_CREATE(dev_alloc(h, &h->d_counter, 1));
+    if (nblk <= (size_t)CTK_MPPI_FUSE_MAX_BLOCKS && !std::getenv("CTK_NO_LL")) TRY_CREATE(dev_alloc(h, &h->d_ll, nblk * (2 + P)));
     TRY_CREATE(dev_alloc(h, &h->d_unom[0], H));
     TRY_CREATE(dev_alloc(h, &h->d_unom[1], H));
     TRY_CREATE(dev_alloc(h, &h->d_std, H));
@@ -806,7 +808,7 @@ void ctk_destroy(ctk_handle* h) {
     hipStreamSynchronize(h->stream);   // also correct for the null (default) stream handed in by ctk_set_stream
     for (auto& e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     void* bufs[] = {h->d_interp, h->d_samples, h->d_J, h->d_Q, h->d_traj, h->d_parts, h->d_parts2, h->d_parts3, h->d_unom[0], h->d_unom[1],
-                    h->d_std, h->d_base, h->d_scale, h->d_idx, h->d_u, h->d_weights, h->d_wperm, h->d_counter,
+                    h->d_std, h->d_base, h->d_scale, h->d_idx, h->d_u, h->d_weights, h->d_wperm, h->d_counter, h->d_ll,
                     h->d_pop[0], h->d_pop[1], h->d_m[0], h->d_m[1], h->d_v[0], h->d_v[1], h->d_ages[0], h->d_ages[1], h->d_bc, h->d_scratch};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->d_shard_idx) hipFree(h->d_shard_idx);

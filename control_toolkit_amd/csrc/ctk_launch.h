@@ -26,6 +26,7 @@ struct MppiFuse {
     int mode = 0;              // 0 records only, 1 merge + update u_nom/u, 2 merge into ONE record (sharded step_begin)
     unsigned* counter = nullptr;
     float* out_rec = nullptr;  // mode 2
+    unsigned long long* ll = nullptr;   // [blocks][2+P] {value, seq} words: low-latency hand-off (else ticket + fetch)
     float* u_nom_out = nullptr, *u_dev = nullptr, *u_host = nullptr;   // mode 1
     uint32_t seq = 0;          // sequence number published with u (mode 1)
 };

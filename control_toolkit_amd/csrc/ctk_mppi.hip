@@ -73,14 +73,14 @@ struct MppiUpdateArgs {
 // (all records fetched into LDS by ONE wide pass: one memory round trip instead of one per record).
 template <bool FINAL, int SC1>
 CTK_DEV void mppi_merge_block(float* scratch, const float* base, int cnt, int P, float neg_inv_lbd, float* out_rec,
-                              const MppiUpdateArgs& up, bool stage) {
+                              const MppiUpdateArgs& up, int stage) {
     float* red = scratch;             // [4] cross-wave scratch
     float* b_s = scratch + 8;         // [P + 1] merged numerator
     float* sc_s = b_s + P + 1;        // [chunk] per-record rescale factors
     float* st_s = sc_s + (cnt < MERGE_CHUNK ? cnt : MERGE_CHUNK);   // [cnt][2+P] staged records
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int rs = 2 + P;
-    if (stage) {
+    if (stage == 1) {
         const int tot = cnt * rs;
         for (int i0 = 0; i0 < tot; i0 += 4 * MERGE_BLOCK) {
             float v[4];
@@ -97,7 +97,7 @@ CTK_DEV void mppi_merge_block(float* scratch, const float* base, int cnt, int P,
         }
         __syncthreads();
     }
-    auto rec_at = [&](int i, int f) -> float { return stage ? st_s[i * rs + f] : ld_rec<SC1>(base + (size_t)i * rs + f); };
+    auto rec_at = [&](int i, int f) -> float { return stage != 0 ? st_s[i * rs + f] : ld_rec<SC1>(base + (size_t)i * rs + f); };
 
     float r = INFINITY;
     for (int i = t; i < cnt; i += MERGE_BLOCK) r = fminf(r, rec_at(i, 0));
@@ -213,7 +213,17 @@ __global__ __launch_bounds__(MERGE_BLOCK) void ctk_mppi_p2p_exchange(P2PArgs x, 
         }
         return;
     }
-    mppi_merge_block<true, 2>(lds, mine + (size_t)par * W * rs, W, P, neg_inv_lbd, nullptr, up, stage_ok != 0);
+    mppi_merge_block<true, 2>(lds, mine + (size_t)par * W * rs, W, P, neg_inv_lbd, nullptr, up, stage_ok != 0 ? 1 : 0);
+}
+
+// start of the staged records inside the merge scratch (see mppi_merge_block)
+CTK_DEV float* merge_stage_ptr(float* scratch, int cnt, int P) { return scratch + 8 + (P + 1) + (cnt < MERGE_CHUNK ? cnt : MERGE_CHUNK); }
+
+// Low-latency hand-off of a record word: value and the launch's sequence number travel in ONE 8-byte store, so
+// the reader polls the data itself — no "drain my stores, then signal" step and no ticket (cf. RCCL's LL protocol).
+CTK_DEV void ll_store(unsigned long long* p, float v, uint32_t seq) {
+    __hip_atomic_store(p, ((unsigned long long)seq << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // grid.x blocks; block b merges records [b*per_block, ...)
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(MERGE_BLOCK) void ctk_mppi_merge(const float* __res
     const int first = blockIdx.x * per_block;
     const int cnt = min(per_block, n_parts - first);
     mppi_merge_block<FINAL, false>(lds, parts + (size_t)first * (2 + P), cnt, P, neg_inv_lbd,
-                                   out_rec ? out_rec + (size_t)blockIdx.x * (2 + P) : nullptr, up, stage_ok != 0);
+                                   out_rec ? out_rec + (size_t)blockIdx.x * (2 + P) : nullptr, up, stage_ok != 0 ? 1 : 0);
 }
 
 // floats of the rollout carve (everything but the GRU exchange slots), rounded up so that what follows is
@@ -243,6 +253,7 @@ __host__ __device__ inline int mppi_traj(int pred) { return pred == CTK_PRED_GRU
 struct FuseArgs {
     int mode;             // 0: records only; 1: last block merges + updates u_nom/u; 2: last block emits ONE merged record
     int stage_ok;         // the launch's LDS holds all records staged (merge_lds with staging)
+    unsigned long long* ll;   // {value, seq} words [blocks][2+P] for the low-latency hand-off (needs stage_ok); nullptr: ticket path
     unsigned* counter;    // zero before the launch; the last block resets it
     float* out_rec;       // mode 2
     MppiUpdateArgs up;    // mode 1
@@ -274,6 +285,7 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
     const int row0 = blockIdx.x * TRAJ;
     const int n = row0 + lane;                 // wave 0's view: lane = trajectory of the workgroup
     const bool valid = lane < TRAJ && n < a.N;
+    const bool use_ll = fz.mode != 0 && fz.ll != nullptr;   // kernel-argument uniform
 
     const uint32_t ka_sink = kernarg_prefetch<sizeof(RolloutArgs) + sizeof(EnvK) + sizeof(MppiK) + 5 * sizeof(void*) + sizeof(FuseArgs)>();
     STAMP(0);
@@ -385,8 +397,13 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
         const float asum = wave_sum(e);
         if (lane < TRAJ) e_s[lane] = e;
         if (lane == 0) {
-            float* rec = parts + (size_t)blockIdx.x * (2 + P);
-            st_rec(rec, rho); st_rec(rec + 1, asum);
+            if (use_ll) {
+                unsigned long long* rl = fz.ll + (size_t)blockIdx.x * (2 + P);
+                ll_store(rl, rho, fz.up.seq); ll_store(rl + 1, asum, fz.up.seq);
+            } else {
+                float* rec = parts + (size_t)blockIdx.x * (2 + P);
+                st_rec(rec, rho); st_rec(rec + 1, asum);
+            }
         }
     }
     __syncthreads();
@@ -401,8 +418,40 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
     }
     __syncthreads();
     float* rec = parts + (size_t)blockIdx.x * (2 + P);
-    for (int p = t; p < P; p += MPPI_BLOCK) st_rec(rec + 2 + p, (col_s[p] + col_s[P + p]) + (col_s[2 * P + p] + col_s[3 * P + p]));
+    for (int p = t; p < P; p += MPPI_BLOCK) {
+        const float v = (col_s[p] + col_s[P + p]) + (col_s[2 * P + p] + col_s[3 * P + p]);
+        if (use_ll) ll_store(fz.ll + (size_t)blockIdx.x * (2 + P) + 2 + p, v, fz.up.seq);
+        else st_rec(rec + 2 + p, v);
+    }
     STAMP(5);
+
+    // ---- fused tail, low-latency form: block 0 polls every record word until it carries this launch's sequence
+    //      number (the words ARE the data), staging them in LDS, then merges.  One memory round trip after the
+    //      slowest block's stores instead of three (drain stores / ticket / fetch).  The other blocks are done.
+    //      Every block of the grid finishes unconditionally, so the wait terminates; it is bounded anyway.
+    if (use_ll) {
+        if (blockIdx.x == 0) {
+            __syncthreads();                      // col_s / tile are dead: the merge scratch may overwrite them
+            const int nb = (int)gridDim.x, tot = nb * (2 + P);
+            float* st = merge_stage_ptr(lds, nb, P);
+            for (int i = t; i < tot; i += MPPI_BLOCK) {
+                unsigned long long w = __hip_atomic_load(fz.ll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int spin = 0; (uint32_t)(w >> 32) != fz.up.seq && spin < (1 << 22); ++spin) {
+                    __builtin_amdgcn_s_sleep(1);
+                    w = __hip_atomic_load(fz.ll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                st[i] = (uint32_t)(w >> 32) == fz.up.seq ? __builtin_bit_cast(float, (uint32_t)w) : __builtin_nanf("");
+            }
+            __syncthreads();
+            const size_t scratch_floats = 8 + P + 1 + min(nb, MERGE_CHUNK) + (size_t)tot;
+            if (scratch_floats <= (size_t)(w0_s - lds)) { fz.up.w0_l = w0_s; fz.up.w1_l = w1_s; fz.up.un_l = un_s; fz.up.i0_l = i0_s; }
+            if (fz.mode == 1) mppi_merge_block<true, 0>(lds, nullptr, nb, P, m.neg_inv_lbd, nullptr, fz.up, 2);
+            else mppi_merge_block<false, 0>(lds, nullptr, nb, P, m.neg_inv_lbd, fz.out_rec, fz.up, 2);
+        }
+        STAMP(6);
+        kernarg_prefetch_sink(ka_sink, parts);
+        return;
+    }
 
     // ---- fused tail: hand-off of the block records inside the launch (cdna_hip_programming.md G16,
     //      sc1 form: every record store above is a write-through agent-scope store, every storing wave
@@ -424,8 +473,8 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
             // whenever the scratch ends below them
             const size_t scratch_floats = 8 + P + 1 + min((int)gridDim.x, MERGE_CHUNK) + (fz.stage_ok ? (size_t)gridDim.x * (2 + P) : 0);
             if (scratch_floats <= (size_t)(w0_s - lds)) { fz.up.w0_l = w0_s; fz.up.w1_l = w1_s; fz.up.un_l = un_s; fz.up.i0_l = i0_s; }
-            if (fz.mode == 1) mppi_merge_block<true, true>(lds, parts, (int)gridDim.x, P, m.neg_inv_lbd, nullptr, fz.up, fz.stage_ok != 0);
-            else mppi_merge_block<false, true>(lds, parts, (int)gridDim.x, P, m.neg_inv_lbd, fz.out_rec, fz.up, fz.stage_ok != 0);
+            if (fz.mode == 1) mppi_merge_block<true, 1>(lds, parts, (int)gridDim.x, P, m.neg_inv_lbd, nullptr, fz.up, fz.stage_ok != 0 ? 1 : 0);
+            else mppi_merge_block<false, 1>(lds, parts, (int)gridDim.x, P, m.neg_inv_lbd, fz.out_rec, fz.up, fz.stage_ok != 0 ? 1 : 0);
             if (t == 0) __hip_atomic_store(fz.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -559,6 +608,7 @@ hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& 
     FuseArgs fz{};
     const size_t lds = rollout_launch_lds(a.P, a.H, pred, (int)grid.x, &fz.stage_ok);
     fz.mode = fuse.mode; fz.counter = fuse.counter; fz.out_rec = fuse.out_rec;
+    fz.ll = (fuse.mode != 0 && fz.stage_ok) ? fuse.ll : nullptr;
     fz.up = MppiUpdateArgs{nullptr, nullptr, nullptr, nullptr, a.H, a.interp, u_nom, fuse.u_nom_out, a.lo, a.hi, fuse.u_dev, fuse.u_host, fuse.seq};
     if (pred == CTK_PRED_ODE) {
         if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
