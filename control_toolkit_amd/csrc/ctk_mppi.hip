@@ -259,14 +259,20 @@ struct FuseArgs {
     MppiUpdateArgs up;    // mode 1
 };
 
+// Argument order: the 14 dwords the first global loads depend on come first — with
+// -amdgpu-kernarg-preload-count=14 (Makefile) the command processor delivers them in SGPRs at wave launch, so the
+// sample loads do not wait for a cold scalar-cache miss on the kernel-argument segment (MI355X: gfx940+ feature).
+// N_/H_/P_/pmagic_ duplicate fields of `a` for that reason.
 template <int PRED, bool LOG>
-__global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, EnvK k, MppiK m,
-                                                               const float* __restrict__ samples,
+__global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __restrict__ samples,
                                                                const float* __restrict__ u_nom,
                                                                const InterpEntry* __restrict__ interp,
                                                                const float* __restrict__ wperm,
-                                                               float* __restrict__ parts, FuseArgs fz) {
+                                                               float* __restrict__ parts, int N_, int H_, int P_,
+                                                               uint32_t pmagic_, RolloutArgs a_in, EnvK k, MppiK m, FuseArgs fz) {
     extern __shared__ float lds[];
+    RolloutArgs a = a_in;
+    a.N = N_; a.H = H_; a.P = P_; a.p_magic = pmagic_;
     constexpr int TRAJ = (PRED == CTK_PRED_GRU) ? GRU_TRAJ : MPPI_TRAJ;   // trajectories of this workgroup
     constexpr int CHUNKS = MPPI_BLOCK / TRAJ;                             // horizon chunks of prologue 2 (4 / 16)
     constexpr int RPW = TRAJ / MPPI_WAVES;                                // tile rows per wave in the epilogue
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
     const bool valid = lane < TRAJ && n < a.N;
     const bool use_ll = fz.mode != 0 && fz.ll != nullptr;   // kernel-argument uniform
 
-    const uint32_t ka_sink = kernarg_prefetch<sizeof(RolloutArgs) + sizeof(EnvK) + sizeof(MppiK) + 5 * sizeof(void*) + sizeof(FuseArgs)>();
+    const uint32_t ka_sink = kernarg_prefetch<sizeof(RolloutArgs) + sizeof(EnvK) + sizeof(MppiK) + 5 * sizeof(void*) + 16 + sizeof(FuseArgs)>();
     STAMP(0);
     // ---- prologue 1 (256 threads): per-step tables (interpolation entry, shifted nominal input) and
     //      the sample tile (coalesced HBM read or Philox draw) into LDS ------------------------------
@@ -307,8 +313,13 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
     //      t % TRAJ, chunk t / TRAJ — lane and wave when TRAJ = 64) takes the contiguous steps [chunk*Hc,
     //      (chunk+1)*Hc) so that u[h-1] is at hand (recomputed once per chunk).
     //      ubuf receives u (MLP, GRU) or the force u_max*u (ODE).
-    {
-        const int ptraj = t % TRAJ, chunk = t / TRAJ;
+    //      ODE: done in two phases so that the recurrence wave waits for the first S1 steps' inputs only: phase A
+    //      (all four waves) prepares steps [0, S1); then wave 0 runs the recurrence over them while waves 1..3
+    //      prepare [S1, H) and are at the second barrier long before wave 0 gets there.
+    constexpr bool ODE = PRED == CTK_PRED_ODE;
+    const int S1 = ODE ? min(H, 16) : H;
+    float corr_keep = 0.0f;               // ODE: a wave's phase-A partial, carried into its phase-B sum
+    auto prologue2 = [&](int ptraj, int hbeg, int hend, int slot, float carry) {
         const int pn = row0 + ptraj;
         const bool pvalid = pn < a.N;
         const float* my = tile + ptraj * ts;
@@ -322,8 +333,7 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
             }
             return fminf(fmaxf(un_s[h] + du, a.lo), a.hi);            // optimizer_mppi.py:186-187
         };
-        const int Hc = (H + CHUNKS - 1) / CHUNKS;
-        const int h0 = chunk * Hc, h1 = min(H, h0 + Hc);
+        const int h0 = hbeg, h1 = hend;
         float corr = 0.0f, cin = 0.0f, dummy;
         float uprev = (h0 == 0 || h0 >= H) ? (a.u_prev_dev ? *a.u_prev_dev : a.u_prev) : input_at(h0 - 1, dummy);
 #pragma unroll 2
@@ -339,7 +349,16 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
             }
         }
         // mean over H+1 applies to the stage costs, not to the MPPI correction (optimizer_mppi.py:158-161)
-        corr_s[chunk * TRAJ + ptraj] = corr + cin * a.inv_Hp1;
+        const float part = carry + (corr + cin * a.inv_Hp1);
+        if (slot >= 0) corr_s[slot * TRAJ + ptraj] = part;
+        return part;
+    };
+    if constexpr (ODE) {
+        const int Ha = (S1 + MPPI_WAVES - 1) / MPPI_WAVES;                       // phase A: wave w takes [w*Ha, (w+1)*Ha) of [0, S1)
+        corr_keep = prologue2(lane, min(S1, wave * Ha), min(S1, wave * Ha + Ha), wave == 0 ? 0 : -1, 0.0f);
+    } else {
+        const int Hc = (H + CHUNKS - 1) / CHUNKS, chunk = t / TRAJ;
+        prologue2(t % TRAJ, min(H, chunk * Hc), min(H, chunk * Hc + Hc), chunk, 0.0f);
     }
     __syncthreads();
     STAMP(2);
@@ -348,16 +367,30 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(RolloutArgs a, En
     float J = 0.0f;
     if constexpr (PRED == CTK_PRED_ODE) {
         // wave 0 only: one trajectory per lane, state in registers
+        const float* myF = ubuf + lane * us;
+        auto F_at = [&](int h) { return myF[h]; };
+        State4 st{a.s0[0], a.s0[1], a.s0[2], a.s0[3]};
+        float csum = 0.0f, amax = 0.0f;
+        float4* traj = nullptr;
+        if constexpr (LOG) {
+            if (a.traj_out) traj = reinterpret_cast<float4*>(a.traj_out) + (size_t)n * (H + 1);
+        }
+        const bool single = k.intermediate_steps == 1;
+        if (wave == 0) {                           // steps [0, S1) while the others prepare [S1, H)
+            if (single) recur_ode_range<LOG, false, true>(k, traj, valid, F_at, 0, S1, st, csum, amax);
+            else recur_ode_range<LOG, true, false>(k, traj, valid, F_at, 0, S1, st, csum, amax);
+        } else {
+            const int Hb = (H - S1 + MPPI_WAVES - 2) / (MPPI_WAVES - 1);        // phase B: wave w takes its third of [S1, H)
+            prologue2(lane, min(H, S1 + (wave - 1) * Hb), min(H, S1 + (wave - 1) * Hb + Hb), wave, corr_keep);
+        }
+        __syncthreads();                           // waves 1..3 have been waiting here since ~step 4 of wave 0
         if (wave == 0) {
-            const float* myF = ubuf + lane * us;
-            float amax = 0.0f;
-            auto F_at = [&](int h) { return myF[h]; };
-#ifndef CTK_DIAG_NO_COLD
-            if (k.intermediate_steps == 1) J = recur_ode_state_cost<LOG, false, true>(a, k, n, valid, F_at, &amax);
-            else J = recur_ode_state_cost<LOG, true, false>(a, k, n, valid, F_at, &amax);
-#else
-            J = recur_ode_state_cost<LOG, false, true>(a, k, n, valid, F_at, &amax);
-#endif
+            if (single) recur_ode_range<LOG, false, true>(k, traj, valid, F_at, S1, H, st, csum, amax);
+            else recur_ode_range<LOG, true, false>(k, traj, valid, F_at, S1, H, st, csum, amax);
+            if constexpr (LOG) {
+                if (valid && traj) traj[H] = make_float4(st.x, st.v, st.th, st.om);
+            }
+            J = csum + terminal_cost(k, st);
 #ifndef CTK_DIAG_NO_COLD
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0))   // wave-uniform, ~never
                 J = recur_ode_state_cost<LOG, true, false>(a, k, n, valid, F_at, &amax);
@@ -611,14 +644,14 @@ hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& 
     fz.ll = (fuse.mode != 0 && fz.stage_ok) ? fuse.ll : nullptr;
     fz.up = MppiUpdateArgs{nullptr, nullptr, nullptr, nullptr, a.H, a.interp, u_nom, fuse.u_nom_out, a.lo, a.hi, fuse.u_dev, fuse.u_host, fuse.seq};
     if (pred == CTK_PRED_ODE) {
-        if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
-        else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
+        if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, wperm, parts, a.N, a.H, a.P, a.p_magic, a, k, m, fz);
+        else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, wperm, parts, a.N, a.H, a.P, a.p_magic, a, k, m, fz);
     } else if (pred == CTK_PRED_MLP) {
-        if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_MLP, true>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
-        else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_MLP, false>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
+        if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_MLP, true>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, wperm, parts, a.N, a.H, a.P, a.p_magic, a, k, m, fz);
+        else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_MLP, false>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, wperm, parts, a.N, a.H, a.P, a.p_magic, a, k, m, fz);
     } else {
-        if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_GRU, true>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
-        else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_GRU, false>), grid, block, lds, st, e0, e1, a, k, m, samples, u_nom, a.interp, wperm, parts, fz);
+        if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_GRU, true>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, wperm, parts, a.N, a.H, a.P, a.p_magic, a, k, m, fz);
+        else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_GRU, false>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, wperm, parts, a.N, a.H, a.P, a.p_magic, a, k, m, fz);
     }
     return hipGetLastError();
 }

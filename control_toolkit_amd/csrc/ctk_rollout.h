@@ -128,20 +128,16 @@ CTK_DEV float rollout_ode(const RolloutArgs& a, const EnvK& k, int n, bool valid
 // critical path together with the input-only cost terms), the per-step work is {sincos, state cost,
 // Euler step}.  Returns sum_h (dd + ep + ekp) + terminal; *amax = max |angle| seen (range check of the
 // fast sincos, done once after the loop by the caller).
+// steps [hb, he) of the recurrence; s / csum / am are carried so that the caller may split the horizon
+// (ctk_mppi_rollout runs the first steps while the other waves still prepare the inputs of the later ones)
 template <bool WRITE_TRAJ, bool CHECKED, bool SINGLE, class FFn>
-CTK_DEV float recur_ode_state_cost(const RolloutArgs& a, const EnvK& k, int n, bool valid, FFn&& ffn, float* amax) {
-    State4 s{a.s0[0], a.s0[1], a.s0[2], a.s0[3]};
-    float csum = 0.0f, am = 0.0f;
-    const int H = a.H;
-    float4* traj = nullptr;
-    if constexpr (WRITE_TRAJ) {
-        if (a.traj_out) traj = reinterpret_cast<float4*>(a.traj_out) + (size_t)n * (H + 1);
-    }
-    float F_next = ffn(0);
+CTK_DEV void recur_ode_range(const EnvK& k, float4* traj, bool valid, FFn&& ffn, int hb, int he, State4& s, float& csum, float& am) {
+    if (hb >= he) return;
+    float F_next = ffn(hb);
 #pragma unroll 2
-    for (int h = 0; h < H; ++h) {
+    for (int h = hb; h < he; ++h) {
         const float F = F_next;
-        if (h + 1 < H) F_next = ffn(h + 1);
+        if (h + 1 < he) F_next = ffn(h + 1);
         float sn, cs;
         if constexpr (CHECKED) ctk_sincosf(s.th, &sn, &cs);
         else { ctk_sincosf_fast(s.th, &sn, &cs); am = fmaxf(am, fabsf(s.th)); }
@@ -158,6 +154,18 @@ CTK_DEV float recur_ode_state_cost(const RolloutArgs& a, const EnvK& k, int n, b
             }
         }
     }
+}
+
+template <bool WRITE_TRAJ, bool CHECKED, bool SINGLE, class FFn>
+CTK_DEV float recur_ode_state_cost(const RolloutArgs& a, const EnvK& k, int n, bool valid, FFn&& ffn, float* amax) {
+    State4 s{a.s0[0], a.s0[1], a.s0[2], a.s0[3]};
+    float csum = 0.0f, am = 0.0f;
+    const int H = a.H;
+    float4* traj = nullptr;
+    if constexpr (WRITE_TRAJ) {
+        if (a.traj_out) traj = reinterpret_cast<float4*>(a.traj_out) + (size_t)n * (H + 1);
+    }
+    recur_ode_range<WRITE_TRAJ, CHECKED, SINGLE>(k, traj, valid, ffn, 0, H, s, csum, am);
     if constexpr (WRITE_TRAJ) {
         if (valid && traj) traj[H] = make_float4(s.x, s.v, s.th, s.om);
     }

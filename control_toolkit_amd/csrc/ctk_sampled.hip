@@ -27,11 +27,14 @@ __host__ __device__ inline int affine_carve_floats(int H, int traj) {
 __host__ __device__ inline int affine_traj(int pred) { return pred == CTK_PRED_GRU ? GRU_TRAJ : SAMP_TRAJ; }
 
 template <int PRED, bool WTRAJ>
-__global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(RolloutArgs a, EnvK k, const float* __restrict__ samples,
-                                                                 int rng_kind, const float* __restrict__ base,
+// (argument order: see ctk_mppi_rollout — the leading 14 dwords are preloaded into SGPRs at wave launch)
+__global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(const float* __restrict__ samples, const float* __restrict__ base,
                                                                  const float* __restrict__ scale,
-                                                                 const float* __restrict__ wperm) {
+                                                                 const float* __restrict__ wperm, int rng_kind, int N_, int H_,
+                                                                 int P_, uint32_t pmagic_, RolloutArgs a_in, EnvK k) {
     extern __shared__ float lds[];
+    RolloutArgs a = a_in;
+    a.N = N_; a.H = H_; a.P = P_; a.p_magic = pmagic_;
     constexpr int TRAJ = (PRED == CTK_PRED_GRU) ? GRU_TRAJ : SAMP_TRAJ;
     constexpr int CHUNKS = SAMP_BLOCK / TRAJ;
     const int H = a.H, ts = tile_stride(a.P), us = (H + 1) | 1;   // P == H here: one sample per step
@@ -373,14 +376,14 @@ hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs
     const dim3 grid((a.N + tr - 1) / tr), block(SAMP_BLOCK);
     const size_t lds = ctk_affine_rollout_lds(a.H, pred);
     if (pred == CTK_PRED_ODE) {
-        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
-        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
+        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k);
+        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k);
     } else if (pred == CTK_PRED_MLP) {
-        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_MLP, true>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
-        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_MLP, false>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
+        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_MLP, true>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k);
+        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_MLP, false>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k);
     } else {
-        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_GRU, true>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
-        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_GRU, false>), grid, block, lds, st, e0, e1, a, k, samples, rng_kind, base, scale, wperm);
+        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_GRU, true>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k);
+        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_GRU, false>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k);
     }
     return hipGetLastError();
 }

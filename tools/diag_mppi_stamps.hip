@@ -18,7 +18,7 @@ int main(int argc, char** argv) {
     std::vector<float> noise((size_t)N * P);
     unsigned s = 1; for (auto& v : noise) { s = s * 1664525u + 1013904223u; v = ((s >> 8) * (1.f / 16777216.f) - 0.5f) * 3.f; }
     float *d_noise, *d_unom, *d_J, *d_parts; InterpEntry* d_tab; unsigned long long* d_st;
-    const int nb = ctk_mppi_num_blocks(N);
+    const int nb = ctk_mppi_num_blocks(N, CTK_PRED_ODE);
     CK(hipMalloc(&d_noise, noise.size() * 4)); CK(hipMalloc(&d_unom, H * 4)); CK(hipMalloc(&d_J, N * 4));
     CK(hipMalloc(&d_parts, (size_t)nb * (2 + P) * 4)); CK(hipMalloc(&d_tab, H * sizeof(InterpEntry))); CK(hipMalloc(&d_st, nb * 16 * 8)); CK(hipMemset(d_st, 0, nb * 16 * 8));
     CK(hipMemcpy(d_noise, noise.data(), noise.size() * 4, hipMemcpyHostToDevice));
@@ -26,17 +26,19 @@ int main(int argc, char** argv) {
     RolloutArgs a{}; a.s0[0] = 0.05f; a.s0[1] = -0.1f; a.s0[2] = 2.8f; a.s0[3] = 0.4f; a.lo = -1; a.hi = 1; a.N = N; a.H = H; a.P = P;
     a.inv_Hp1 = 1.f / (H + 1); a.p_magic = (uint32_t)((0x100000000ull + P - 1) / P); a.identity_interp = 1; a.interp = d_tab; a.J = d_J; a.stamps = d_st;
     unsigned* d_cnt; float *d_unom2, *d_u, *h_u; CK(hipMalloc(&d_cnt, 4)); CK(hipMemset(d_cnt, 0, 4)); CK(hipMalloc(&d_unom2, H * 4)); CK(hipMalloc(&d_u, 4)); CK(hipHostMalloc(&h_u, 64, hipHostMallocMapped));
-    MppiFuse fz; fz.mode = argc > 3 ? atoi(argv[3]) : 1; fz.counter = d_cnt; fz.u_nom_out = d_unom2; fz.u_dev = d_u; fz.u_host = h_u;
+    unsigned long long* d_ll; CK(hipMalloc(&d_ll, (size_t)nb * (2 + P) * 8)); CK(hipMemset(d_ll, 0, (size_t)nb * (2 + P) * 8));
+    MppiFuse fz; fz.mode = argc > 3 ? atoi(argv[3]) : 1; fz.counter = d_cnt; fz.ll = (argc > 4 && atoi(argv[4]) == 0) ? nullptr : d_ll; fz.u_nom_out = d_unom2; fz.u_dev = d_u; fz.u_host = h_u;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms = 0;
     for (int it = 0; it < 20; ++it) {
         CK(hipEventRecord(e0, 0));
+        fz.seq = (uint32_t)(it + 1);
         CK(ctk_launch_mppi_rollout(0, CTK_PRED_ODE, a, k, m, d_noise, d_unom, nullptr, d_parts, false, fz));
         CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize()); CK(hipEventElapsedTime(&ms, e0, e1));
     }
     std::vector<unsigned long long> st(nb * 16);
     CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
-    const char* names[6] = {"tile load", "inputs (interp/clip/corr)", "recurrence (wave 0)", "softmin partial", "column sums + store", "fused tail (ticket; last block merges)"};
+    const char* names[6] = {"tile load", "inputs (interp/clip/corr)", "recurrence (wave 0)", "softmin partial", "column sums + store", "fused tail (hand-off + merge)"};
     printf("N=%d H=%d blocks=%d  event time %.2f us (stamped build)\n", N, H, nb, ms * 1e3);
     for (int ph = 0; ph < 6; ++ph) {
         std::vector<double> d;
