@@ -378,21 +378,23 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
         const bool single = k.intermediate_steps == 1;
         if (wave == 0) {                           // steps [0, S1) while the others prepare [S1, H)
             if (single) recur_ode_range<LOG, false, true>(k, traj, valid, F_at, 0, S1, st, csum, amax);
-            else recur_ode_range<LOG, true, false>(k, traj, valid, F_at, 0, S1, st, csum, amax);
         } else {
             const int Hb = (H - S1 + MPPI_WAVES - 2) / (MPPI_WAVES - 1);        // phase B: wave w takes its third of [S1, H)
             prologue2(lane, min(H, S1 + (wave - 1) * Hb), min(H, S1 + (wave - 1) * Hb + Hb), wave, corr_keep);
         }
         __syncthreads();                           // waves 1..3 have been waiting here since ~step 4 of wave 0
         if (wave == 0) {
-            if (single) recur_ode_range<LOG, false, true>(k, traj, valid, F_at, S1, H, st, csum, amax);
-            else recur_ode_range<LOG, true, false>(k, traj, valid, F_at, S1, H, st, csum, amax);
-            if constexpr (LOG) {
-                if (valid && traj) traj[H] = make_float4(st.x, st.v, st.th, st.om);
+            if (single) {
+                recur_ode_range<LOG, false, true>(k, traj, valid, F_at, S1, H, st, csum, amax);
+                if constexpr (LOG) {
+                    if (valid && traj) traj[H] = make_float4(st.x, st.v, st.th, st.om);
+                }
+                J = csum + terminal_cost(k, st);
             }
-            J = csum + terminal_cost(k, st);
 #ifndef CTK_DIAG_NO_COLD
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0))   // wave-uniform, ~never
+            // Euler sub-steps (intermediate_steps > 1), or an angle beyond the fast sincos range somewhere in the
+            // wave (~never): the whole horizon with the checked sincos, all inputs being ready by now
+            if (!single || __builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0))
                 J = recur_ode_state_cost<LOG, true, false>(a, k, n, valid, F_at, &amax);
 #endif
             J *= a.inv_Hp1;
