@@ -145,10 +145,34 @@ def cpu_baseline(w, budget_s=12.0):
     while True:
         u = step(s); s = plant_step(s.copy(), u); n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 200:
+        if el > budget_s:
             break
     return {"value": N * H * n / el, "unit": "trajectory-steps/s", "cores": 1, "kind": "port",
             "sample": f"{n} {w['opt'].upper()} steps of N={N}, H={H} (oracle/ctk_oracle.py, NumPy fp32, single thread), {el:.1f} s"}
+
+
+def large_n_point(torch, CtkEngine, dev, H, p, N=1 << 20, steps=12):
+    """The same MPPI step at N = 2^20 (outside the timed region, not part of `value`): where the path sits against
+    the HBM roofline once the chip is full.  BASELINE's size occupies 16 of 256 CUs, so its own fraction says
+    nothing about the kernel's efficiency; this does (scaled-N sweep)."""
+    eng = CtkEngine("mppi", "ODE", num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p, seed=1)
+    P = eng.mppi_partial_size() - 2
+    buf = torch.randn((N, P, 1), device=dev, dtype=torch.float32)
+    s = np.array([0.05, -0.1, 2.8, 0.4], np.float32)
+    for _ in range(3):
+        eng.step(s, buf.data_ptr())
+    eng.profile_enable(True, every=1)
+    for _ in range(steps):
+        eng.step(s, buf.data_ptr())
+    k_ms = float(np.mean(eng.profile_read()))
+    name = eng.dominant_kernel()
+    eng.close()
+    alg = 4 * N * P + 4 * N + 8 * H + 16
+    ach = alg / (k_ms * 1e-3) / 1e9
+    return {"N": N, "kernel": name, "kernel_us": k_ms * 1e3, "bound": "valu", "achieved": ach, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "trajectory_steps_per_s_kernel": N * H / (k_ms * 1e-3),
+            "note": "VALU-bound before it is HBM-bound: ~60 fp32 instructions incl. sin/cos per 4 compulsory bytes; PMC: VALU "
+                    "utilisation 76 % at this size (profiles/r01_mppi_largeN_pmc.txt)"}
 
 
 def main():
@@ -160,6 +184,7 @@ def main():
     ap.add_argument("--samples", default="buffer", choices=["buffer", "device-rng"],
                     help="MPPI: [N,P,C] N(0,1) sample buffers resident in HBM (north_star) or the in-kernel Philox sampler")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-n", action="store_true", help="skip the scaled-N roofline point (same kernel family, N = 2^20)")
     ap.add_argument("--force-sharded", action="store_true", help="use the begin / all-gather / end path even with one rank")
     args = ap.parse_args()
 
@@ -298,6 +323,8 @@ def main():
             "step_ms_median": float(np.median(ps)), "step_ms_p95": float(np.percentile(ps, 95)),
             "roofline": roof,
         }
+        if not args.no_large_n and world == 1 and args.workload == "mppi_cfg2":
+            out["roofline_large_n"] = large_n_point(torch, CtkEngine, dev, H, p)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
