@@ -156,3 +156,34 @@ def test_errors_are_loud():
     with pytest.raises(Exception):
         e.read("TRAJ")      # not materialised
     e.close()
+
+
+@pytest.mark.parametrize("N,H,p,isteps", [(40000, 12, 1, 1), (70001, 10, 3, 1), (131072, 6, 1, 1), (66000, 8, 2, 2)])
+def test_mppi_throughput_variants_match_oracle(N, H, p, isteps):
+    from control_toolkit_amd import CtkEngine
+    """N >= 32768 takes the single-wave throughput kernel (inputs formed inline, half the LDS) and a tree of merge
+    launches; against the oracle, logging on and off, ragged N, Euler sub-steps."""
+    env = O.EnvParams(terminal_weight=0.2)
+    pred = O.Predictor("ODE", dt=0.02, intermediate_steps=isteps, env=env)
+    o = O.MPPI(pred, O.Cost(env), num_rollouts=N, mpc_horizon=H, period_interpolation_inducing_points=p)
+    engines = [CtkEngine("mppi", "ODE", num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p,
+                         intermediate_steps=isteps, materialize_trajectories=log) for log in (True, False)]
+    for e in engines:
+        apply_env(e, env)
+    name = engines[1].dominant_kernel()
+    assert "ctk_mppi_rollout_tp" in name
+    rng = np.random.default_rng(N)
+    s = np.array([0.1, -0.2, 2.5, 0.7], np.float32)
+    for t in range(2):
+        noise = rng.standard_normal((N, o.P, 1)).astype(np.float32)
+        uo = o.step(s, noise)
+        for e in engines:
+            ug = e.step(s, noise)
+            np.testing.assert_allclose(e.read("J"), o.J, rtol=3e-5)
+            np.testing.assert_allclose(e.read("U_NOM"), o.u_nom, **U_TOL)
+            np.testing.assert_allclose(ug[0], uo, **U_TOL)
+        np.testing.assert_allclose(engines[0].read("TRAJ"), o.rollout_trajectories, rtol=1e-4, atol=1e-5 * H)
+        np.testing.assert_allclose(engines[0].read("Q"), o.u_run, rtol=1e-6, atol=5e-6)   # interpolation: FMA vs the oracle's matmul
+        s = pred.step(s.reshape(1, 4), np.array([uo], np.float32))[0]
+    for e in engines:
+        e.close()
