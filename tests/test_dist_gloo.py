@@ -99,3 +99,82 @@ def test_sharded_mppi_two_ranks_gloo():
     np.testing.assert_array_equal(res[0][1], res[1][1])             # identical on both ranks, no 2nd collective
     np.testing.assert_allclose(res[0][1], ref, rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(res[0][2], full.u_nom, rtol=1e-4, atol=2e-5)
+
+
+class FakeP2PEngine:
+    """Engine surface ShardedMPPI's p2p set-up touches, with a failure injected on ONE rank: whatever happens
+    locally, both ranks must run the same sequence of collectives and end on the same exchange."""
+
+    def __init__(self, rank, mode):
+        self.rank, self.mode, self.plan, self.closed = rank, mode, 0.0, False
+
+    def mppi_partial_size(self): return 4
+    def samples_needed(self): return 8
+    def get_state(self): return np.zeros(3, np.float32)
+    def set_state(self, st): self.plan = 0.0
+    def read(self, name): return np.full((1, 3, 1), self.plan, np.float32)
+
+    def p2p_alloc(self, rank, world):
+        if self.mode == "alloc_fail" and rank == 1:
+            raise RuntimeError("hipIpcGetMemHandle: invalid argument")
+        return bytes(64)
+
+    def p2p_connect(self, handles):
+        assert len(handles) == 2 and all(len(h) == 64 for h in handles)
+        if self.mode == "connect_fail" and self.rank == 0:
+            raise RuntimeError("hipIpcOpenMemHandle: invalid device pointer")
+
+    def p2p_step(self, s, samples=None, u_prev=None):
+        if self.mode == "step_fail" and self.rank == 1:
+            raise RuntimeError("ctk_p2p_step: timed out waiting for a peer's record")
+        self.plan = 2.0 if (self.mode == "differs" and self.rank == 0) else 1.0
+        return np.array([self.plan], np.float32)
+
+    def p2p_close(self): self.closed = True
+    def mppi_step_begin(self, s, ptr, samples=None, u_prev=None): pass
+
+    def mppi_step_end(self, ptr, n):
+        self.plan = 1.0
+        return np.array([1.0], np.float32)
+
+
+def _p2p_worker(rank, world, port, modes, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from control_toolkit_amd.dist import ShardedMPPI
+    res = {}
+    for mode in modes:
+        eng = FakeP2PEngine(rank, mode)
+        sh = ShardedMPPI(eng, rank, world, exchange="p2p")
+        u = sh.step(np.zeros(4, np.float32))                 # the step after the set-up still lines up across ranks
+        dist.barrier()
+        res[mode] = (sh.exchange, sh.p2p_error, eng.closed, float(u[0]))
+    out_q.put((rank, res))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_p2p_setup_falls_back_collectively():
+    modes = ["ok", "alloc_fail", "connect_fail", "step_fail", "differs"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 991) % 2000)
+    procs = [ctx.Process(target=_p2p_worker, args=(r, 2, port, modes, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = dict(q.get(timeout=100) for _ in procs)
+    for pr in procs:
+        pr.join(timeout=30)
+        assert pr.exitcode == 0
+    for mode in modes:
+        ex0, err0, closed0, u0 = res[0][mode]
+        ex1, err1, closed1, u1 = res[1][mode]
+        assert ex0 == ex1 == ("p2p" if mode == "ok" else "rccl"), (mode, res[0][mode], res[1][mode])
+        assert u0 == u1 == 1.0
+        if mode != "ok":
+            assert closed0 and closed1 and (err0 or err1)
+    with pytest.raises(ValueError):
+        from control_toolkit_amd.dist import ShardedMPPI
+        ShardedMPPI(FakeP2PEngine(0, "ok"), 0, 1, exchange="smoke-signals")
