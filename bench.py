@@ -262,7 +262,7 @@ def main():
         plant_step(s, step_fn(s, ptrs[i & 15])[0])
     # dispatch-timestamp timing of the dominant kernel on a sparse sample of the timed launches: timing a
     # launch costs ~8 us of host time (measured), so timing all of them would distort the metric
-    prof_every = 1 if args.steps < 40 else 8
+    prof_every = 1 if args.steps < 40 else 16
     eng.profile_enable(True, every=prof_every)
     if world > 1 or force_pg:
         dist.barrier()
