@@ -82,6 +82,7 @@ struct ctk_handle {
     bool p2p_connected = false;
     float* p2p_bufs[CTK_P2P_MAX_WORLD] = {};   // [rank] = my own uncached buffer, the others IPC mappings
     uint32_t p2p_seq = 1;
+    void* d_p2p_args = nullptr;                // device-resident P2PArgs for the in-launch exchange (fuse mode 3)
     double p2p_timeout_s = 5.0;
     // device-resident step log (ctk_log_enable): rings of `log_cap` slots
     size_t log_cap = 0, log_count = 0;
@@ -424,6 +425,7 @@ int mppi_rollout(ctk_handle* h, const float* s, const float* u_prev, const float
     if (int rc = check_predictor(h)) return rc;
     MppiFuse fz;
     fz.mode = fuse_mode; fz.counter = h->d_counter; fz.out_rec = partial_dev; fz.ll = h->d_ll;
+    if (fuse_mode == 3) { fz.p2p = h->d_p2p_args; fz.p2p_seq = h->p2p_seq; fz.p2p_world = h->p2p_world; }
     fz.u_nom_out = h->d_unom[h->cur ^ 1]; fz.u_dev = h->d_u; fz.u_host = h->h_u_dev; fz.seq = h->seq;
     ProfSlot ps(h);
     HIP_TRY(h, ctk_launch_mppi_rollout(h->stream, h->cfg.predictor, a, h->k, h->mk, d_s, h->d_unom[h->cur], h->d_wperm,
@@ -1281,6 +1283,7 @@ int ctk_p2p_close(ctk_handle* h) {
         if (w == h->p2p_rank) hipFree(h->p2p_bufs[w]); else hipIpcCloseMemHandle(h->p2p_bufs[w]);
         h->p2p_bufs[w] = nullptr;
     }
+    if (h->d_p2p_args) { hipFree(h->d_p2p_args); h->d_p2p_args = nullptr; }
     h->p2p_world = 0; h->p2p_rank = -1; h->p2p_connected = false;
     return CTK_OK;
 }
@@ -1320,6 +1323,12 @@ int ctk_p2p_connect(ctk_handle* h, const void* handles) {
         if (e != hipSuccess) return fail(h, CTK_ERR_HIP, std::string("hipIpcOpenMemHandle (rank ") + std::to_string(w) + "): " + hipGetErrorString(e));
         h->p2p_bufs[w] = (float*)p;
     }
+    {   // description of the exchange for the in-launch form (the rollout launch's block 0 does it)
+        std::vector<char> host(ctk_p2p_args_bytes());
+        ctk_p2p_fill_args(host.data(), h->p2p_bufs, h->p2p_rank, h->p2p_world, h->P, reinterpret_cast<uint32_t*>(h->h_u_dev) + 2, h->p2p_timeout_s);
+        if (!h->d_p2p_args) HIP_TRY(h, hipMalloc(&h->d_p2p_args, host.size()));
+        HIP_TRY(h, hipMemcpy(h->d_p2p_args, host.data(), host.size(), hipMemcpyHostToDevice));
+    }
     h->p2p_connected = true;
     return CTK_OK;
 }
@@ -1332,19 +1341,25 @@ int ctk_p2p_step(ctk_handle* h, const float* s, const float* u_prev, const float
     for (int i = 0; i < CTK_S; ++i) h->mppi_s[i] = s[i];
     const int W = h->p2p_world, rs = 2 + h->P, par = (int)(h->p2p_seq & 1u);
     float* my_slot = h->p2p_bufs[h->p2p_rank] + (size_t)(par * W + h->p2p_rank) * rs;
-    if (mppi_can_fuse(h)) {
-        if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 2, my_slot)) return rc;
-    } else {
-        if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 0, nullptr)) return rc;
-        const float* parts; int n_parts;
-        if (int rc = mppi_reduce_blocks(h, &parts, &n_parts)) return rc;
-        HIP_TRY(h, ctk_launch_mppi_merge_partial(h->stream, parts, n_parts, n_parts, h->P, h->mk.neg_inv_lbd, my_slot));
-    }
     uint32_t* err = reinterpret_cast<uint32_t*>(h->h_u_dev) + 2;
     const int nxt = h->cur ^ 1;
-    HIP_TRY(h, ctk_launch_mppi_p2p_exchange(h->stream, h->p2p_bufs, h->p2p_rank, W, h->P, h->p2p_seq, err, h->p2p_timeout_s,
-                                            h->mk.neg_inv_lbd, h->H, h->d_interp, h->d_unom[h->cur], h->d_unom[nxt],
-                                            h->cfg.action_low, h->cfg.action_high, h->d_u, h->h_u_dev, h->seq));
+    static const bool two_launches = std::getenv("CTK_P2P_TWO_LAUNCHES") != nullptr;   // A/B switch
+    if (mppi_can_fuse(h) && h->d_ll && !two_launches && ctk_p2p_can_fuse(h->P, W, mppi_block_parts(h))) {
+        // ONE launch: rollout, local merge, exchange with the peers, global merge, update (fuse mode 3)
+        if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 3, my_slot)) return rc;
+    } else {
+        if (mppi_can_fuse(h)) {
+            if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 2, my_slot)) return rc;
+        } else {
+            if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 0, nullptr)) return rc;
+            const float* parts; int n_parts;
+            if (int rc = mppi_reduce_blocks(h, &parts, &n_parts)) return rc;
+            HIP_TRY(h, ctk_launch_mppi_merge_partial(h->stream, parts, n_parts, n_parts, h->P, h->mk.neg_inv_lbd, my_slot));
+        }
+        HIP_TRY(h, ctk_launch_mppi_p2p_exchange(h->stream, h->p2p_bufs, h->p2p_rank, W, h->P, h->p2p_seq, err, h->p2p_timeout_s,
+                                                h->mk.neg_inv_lbd, h->H, h->d_interp, h->d_unom[h->cur], h->d_unom[nxt],
+                                                h->cfg.action_low, h->cfg.action_high, h->d_u, h->h_u_dev, h->seq));
+    }
     h->cur = nxt;
     ++h->p2p_seq;
     if (int rc = mppi_advance_hidden(h)) return rc;

@@ -23,10 +23,14 @@ constexpr int CTK_MPPI_FUSE_MAX_BLOCKS = 64;     // beyond this the last block's
 // throughput-oriented single-wave block (half the LDS, 2x the resident recurrence waves per CU).
 constexpr int CTK_MPPI_THROUGHPUT_MIN_N = 32768;
 struct MppiFuse {
-    int mode = 0;              // 0 records only, 1 merge + update u_nom/u, 2 merge into ONE record (sharded step_begin)
+    int mode = 0;              // 0 records only, 1 merge + update u_nom/u, 2 merge into ONE record (sharded step_begin),
+                               // 3 = 2 + peer-to-peer exchange + update in the same launch (ctk_p2p_step)
     unsigned* counter = nullptr;
     float* out_rec = nullptr;  // mode 2
     unsigned long long* ll = nullptr;   // [blocks][2+P] {value, seq} words: low-latency hand-off (else ticket + fetch)
+    const void* p2p = nullptr;          // mode 3 (needs ll): device-resident P2PArgs; block 0 exchanges with the peers and updates
+    uint32_t p2p_seq = 0;
+    int p2p_world = 0;
     float* u_nom_out = nullptr, *u_dev = nullptr, *u_host = nullptr;   // mode 1
     uint32_t seq = 0;          // sequence number published with u (mode 1)
 };
@@ -38,6 +42,10 @@ hipError_t ctk_launch_mppi_merge_partial(hipStream_t st, const float* parts, int
 // direct peer-to-peer record exchange + merge + update (ctk_mppi.hip: ctk_mppi_p2p_exchange)
 constexpr int CTK_P2P_MAX_WORLD = 16;
 size_t ctk_p2p_buffer_floats(int world, int P);
+size_t ctk_p2p_args_bytes();   // sizeof the device-resident exchange description
+// fills `dst` (host memory, ctk_p2p_args_bytes()) for upload
+void ctk_p2p_fill_args(void* dst, float* const* bufs, int rank, int world, int P, uint32_t* err_host, double timeout_s);
+bool ctk_p2p_can_fuse(int P, int world, int blocks);   // the rollout launch's LDS can stage `world` records too
 hipError_t ctk_launch_mppi_p2p_exchange(hipStream_t st, float* const* bufs, int rank, int world, int P, uint32_t p2p_seq,
                                         uint32_t* err_host, double timeout_s, float neg_inv_lbd, int H, const InterpEntry* interp,
                                         const float* u_nom_in, float* u_nom_out, float lo, float hi, float* u_dev, float* u_host,

@@ -28,6 +28,7 @@
 #include "ctk_mlp.h"
 #include "ctk_gru.h"
 #include "ctk_launch.h"
+#include <cstring>
 
 constexpr int MPPI_TRAJ = 64;     // trajectories per block: one wave runs the recurrence
 constexpr int MPPI_WAVES = 4;     // waves per block: the prologue / epilogue are spread over all four
@@ -178,13 +179,14 @@ struct P2PArgs {
     unsigned long long timeout_ticks; // wall_clock64 ticks (100 MHz)
 };
 
-__global__ __launch_bounds__(MERGE_BLOCK) void ctk_mppi_p2p_exchange(P2PArgs x, int P, float neg_inv_lbd, MppiUpdateArgs up, int stage_ok) {
-    extern __shared__ float lds[];
-    __shared__ int bad;
+// the exchange, by one 256-thread block (its own launch, or the tail of the rollout launch's block 0); `bad` is a
+// workgroup-shared word
+CTK_DEV void p2p_exchange_and_update(float* lds, int* bad, const P2PArgs& x, int P, float neg_inv_lbd, const MppiUpdateArgs& up,
+                                     int stage_ok) {
     const int t = threadIdx.x, W = x.world, rs = x.rs, par = (int)(x.seq & 1u);
     float* mine = x.bufs[x.rank];
     const size_t slot = (size_t)(par * W + x.rank) * rs, flags0 = (size_t)2 * W * rs;
-    if (t == 0) bad = 0;
+    if (t == 0) *bad = 0;
     for (int w = 0; w < W; ++w) {
         if (w == x.rank) continue;
         float* dst = x.bufs[w] + slot;
@@ -201,12 +203,12 @@ __global__ __launch_bounds__(MERGE_BLOCK) void ctk_mppi_p2p_exchange(P2PArgs x, 
         const uint32_t* f = reinterpret_cast<const uint32_t*>(mine + flags0) + par * W + t;
         const unsigned long long t0 = wall_clock64();
         while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - x.seq) < 0) {
-            if (wall_clock64() - t0 > x.timeout_ticks) { atomicExch(&bad, 1); break; }
+            if (wall_clock64() - t0 > x.timeout_ticks) { atomicExch(bad, 1); break; }
             __builtin_amdgcn_s_sleep(4);
         }
     }
     __syncthreads();
-    if (bad) {
+    if (*bad) {
         if (t == 0) {
             __hip_atomic_store(x.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             publish_u(up.u_dev, up.u_host, __builtin_nanf(""), up.seq);
@@ -214,6 +216,12 @@ __global__ __launch_bounds__(MERGE_BLOCK) void ctk_mppi_p2p_exchange(P2PArgs x, 
         return;
     }
     mppi_merge_block<true, 2>(lds, mine + (size_t)par * W * rs, W, P, neg_inv_lbd, nullptr, up, stage_ok != 0 ? 1 : 0);
+}
+
+__global__ __launch_bounds__(MERGE_BLOCK) void ctk_mppi_p2p_exchange(P2PArgs x, int P, float neg_inv_lbd, MppiUpdateArgs up, int stage_ok) {
+    extern __shared__ float lds[];
+    __shared__ int bad;
+    p2p_exchange_and_update(lds, &bad, x, P, neg_inv_lbd, up, stage_ok);
 }
 
 // start of the staged records inside the merge scratch (see mppi_merge_block)
@@ -253,6 +261,8 @@ __host__ __device__ inline int mppi_traj(int pred) { return pred == CTK_PRED_GRU
 struct FuseArgs {
     int mode;             // 0: records only; 1: last block merges + updates u_nom/u; 2: last block emits ONE merged record
     int stage_ok;         // the launch's LDS holds all records staged (merge_lds with staging)
+    const P2PArgs* p2p;   // mode 3: device-resident exchange description (ctk_p2p_connect); block 0 goes on to exchange + update
+    uint32_t p2p_seq;     // mode 3: this step's exchange sequence number (parity = buffer half)
     unsigned long long* ll;   // {value, seq} words [blocks][2+P] for the low-latency hand-off (needs stage_ok); nullptr: ticket path
     unsigned* counter;    // zero before the launch; the last block resets it
     float* out_rec;       // mode 2
@@ -482,6 +492,19 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
             if (scratch_floats <= (size_t)(w0_s - lds)) { fz.up.w0_l = w0_s; fz.up.w1_l = w1_s; fz.up.un_l = un_s; fz.up.i0_l = i0_s; }
             if (fz.mode == 1) mppi_merge_block<true, 0>(lds, nullptr, nb, P, m.neg_inv_lbd, nullptr, fz.up, 2);
             else mppi_merge_block<false, 0>(lds, nullptr, nb, P, m.neg_inv_lbd, fz.out_rec, fz.up, 2);
+            if (fz.mode == 3) {
+                // sharded step over peer-to-peer stores, all in this launch: the shard's record (just written to
+                // fz.out_rec = this rank's slot of its own exchange buffer by this block) goes to every peer, their
+                // records arrive, merge, update (ctk_mppi_p2p_exchange's body)
+                __shared__ int bad;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record's stores have landed
+                __syncthreads();
+                P2PArgs x = *fz.p2p;
+                x.seq = fz.p2p_seq;
+                const size_t scratch_w = 8 + P + 1 + min(x.world, MERGE_CHUNK) + (size_t)x.world * (2 + P);
+                if (scratch_w > (size_t)(w0_s - lds)) { fz.up.w0_l = nullptr; fz.up.w1_l = nullptr; fz.up.un_l = nullptr; fz.up.i0_l = nullptr; }
+                p2p_exchange_and_update(lds, &bad, x, P, m.neg_inv_lbd, fz.up, 1);
+            }
         }
         STAMP(6);
         kernarg_prefetch_sink(ka_sink, parts);
@@ -641,9 +664,14 @@ hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& 
         return hipGetLastError();
     }
     FuseArgs fz{};
-    const size_t lds = rollout_launch_lds(a.P, a.H, pred, (int)grid.x, &fz.stage_ok);
+    size_t lds = rollout_launch_lds(a.P, a.H, pred, (int)grid.x, &fz.stage_ok);
+    if (fuse.mode == 3) {   // the tail also stages the `world` records of the exchange
+        const size_t need = merge_lds_staged(a.P, fuse.p2p_world);
+        if (need > lds) lds = need;
+    }
     fz.mode = fuse.mode; fz.counter = fuse.counter; fz.out_rec = fuse.out_rec;
     fz.ll = (fuse.mode != 0 && fz.stage_ok) ? fuse.ll : nullptr;
+    fz.p2p = static_cast<const P2PArgs*>(fuse.p2p); fz.p2p_seq = fuse.p2p_seq;
     fz.up = MppiUpdateArgs{nullptr, nullptr, nullptr, nullptr, a.H, a.interp, u_nom, fuse.u_nom_out, a.lo, a.hi, fuse.u_dev, fuse.u_host, fuse.seq};
     if (pred == CTK_PRED_ODE) {
         if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, wperm, parts, a.N, a.H, a.P, a.p_magic, a, k, m, fz);
@@ -668,6 +696,17 @@ hipError_t ctk_launch_mppi_merge_partial(hipStream_t st, const float* parts, int
 }
 
 size_t ctk_p2p_buffer_floats(int world, int P) { return (size_t)2 * world * (2 + P) + (size_t)2 * world; }
+size_t ctk_p2p_args_bytes() { return sizeof(P2PArgs); }
+void ctk_p2p_fill_args(void* dst, float* const* bufs, int rank, int world, int P, uint32_t* err_host, double timeout_s) {
+    P2PArgs x{};
+    for (int w = 0; w < world; ++w) x.bufs[w] = bufs[w];
+    x.rank = rank; x.world = world; x.rs = 2 + P; x.seq = 0; x.err_host = err_host;
+    x.timeout_ticks = (unsigned long long)(timeout_s * 1.0e8);
+    std::memcpy(dst, &x, sizeof(x));
+}
+bool ctk_p2p_can_fuse(int P, int world, int blocks) {
+    return blocks <= CTK_MPPI_FUSE_MAX_BLOCKS && merge_can_stage(P, blocks) && merge_can_stage(P, world);
+}
 
 hipError_t ctk_launch_mppi_p2p_exchange(hipStream_t st, float* const* bufs, int rank, int world, int P, uint32_t p2p_seq,
                                         uint32_t* err_host, double timeout_s, float neg_inv_lbd, int H, const InterpEntry* interp,
