@@ -15,8 +15,10 @@ class ShardedMPPI:
     """exchange = "rccl": ctk_mppi_step_begin -> all_gather_into_tensor -> ctk_mppi_step_end.
     exchange = "p2p" : the ranks' exchange kernels store their records straight into each other's HBM over xGMI
     (ctk_p2p_*, HIP IPC mappings set up once through the process group): no collective launch and no host
-    round trip inside a step.  One node only.  If the set-up or the two self-test steps fail on any rank, all
+    round trip inside a step.  One node only.  If the set-up or the self-test steps fail on any rank, all
     ranks fall back to "rccl" together (the decision is itself all-reduced)."""
+
+    SELF_TEST_STEPS = 16
 
     def __init__(self, engine, rank: int, world_size: int, group=None, device=None, always_collective: bool = False,
                  exchange: str = "rccl"):
@@ -68,16 +70,16 @@ class ShardedMPPI:
             u_p2p = plan_p2p = None
             dist.barrier(group=self.group)
             try:
-                self.engine.p2p_step(s0, noise)
-                u_p2p = self.engine.p2p_step(s0, noise)
+                for _ in range(self.SELF_TEST_STEPS):       # both buffer halves, many times
+                    u_p2p = self.engine.p2p_step(s0, noise)
                 plan_p2p = self.engine.read("U_NOM")
             except Exception as e:   # noqa: BLE001
                 ok, self.p2p_error = False, f"self-test: {e}"
             ok = self._all_ok(ok, device)
             self.engine.set_state(state)
             if ok:
-                self.step(s0, noise)                # exchange == "rccl" here
-                u_rccl = self.step(s0, noise)
+                for _ in range(self.SELF_TEST_STEPS):       # exchange == "rccl" here
+                    u_rccl = self.step(s0, noise)
                 if not (np.allclose(u_p2p, u_rccl, rtol=1e-4, atol=2e-5)
                         and np.allclose(plan_p2p, self.engine.read("U_NOM"), rtol=1e-4, atol=2e-5)):
                     ok, self.p2p_error = False, "self-test: p2p and rccl plans differ"
