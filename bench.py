@@ -301,10 +301,12 @@ def main():
             ach = alg_bytes / (kms * 1e-3) / 1e9 if ok else None
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS if ach else None,
-                    "traffic": 261645 if args.workload == "mppi_cfg2" and samples_in_hbm else None,
+                    "traffic": 511227 if args.workload == "mppi_cfg2" and samples_in_hbm else None,
                     "note": "issue/latency-bound at this size, not HBM-bound: 0.2 MB per launch vs an H-step dependent "
-                            "recurrence (~65 VALU instructions per step on one wave per 64 trajectories); traffic = "
-                            "FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/), DESIGN.md 5"}
+                            "recurrence (~60 VALU instructions per step on one wave per 64 trajectories); traffic = "
+                            "(2 x FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 --pmc passes with the guide's gfx950 factor on "
+                            "FETCH_SIZE (profiles/): 200 KiB of samples + ~270 KiB of per-launch fixed fetches (each of the 8 XCDs' "
+                            "L2 starts cold: kernel code, arguments, tables) + record polling, DESIGN.md 5"}
         roof.update({"kernel": eng.dominant_kernel(), "kernel_us": kms * 1e3, "algorithmic_bytes": alg_bytes,
                      "kernel_timed_launches": int(len(kern_ms)), "kernel_timed_every": prof_every})
         ps = per_step * 1e3
