@@ -479,13 +479,25 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
             __syncthreads();                      // col_s / tile are dead: the merge scratch may overwrite them
             const int nb = (int)gridDim.x, tot = nb * (2 + P);
             float* st = merge_stage_ptr(lds, nb, P);
-            for (int i = t; i < tot; i += MPPI_BLOCK) {
-                unsigned long long w = __hip_atomic_load(fz.ll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (int spin = 0; (uint32_t)(w >> 32) != fz.up.seq && spin < (1 << 22); ++spin) {
-                    __builtin_amdgcn_s_sleep(1);
-                    w = __hip_atomic_load(fz.ll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            constexpr int LLW = 8;                // words in flight per thread: the first pass over a thread's words is
+            for (int i0 = t; i0 < tot; i0 += MPPI_BLOCK * LLW) {   // one pipelined batch of loads, not LLW round trips
+                unsigned long long w[LLW];
+#pragma unroll
+                for (int j = 0; j < LLW; ++j) {
+                    const int i = i0 + j * MPPI_BLOCK;
+                    if (i < tot) w[j] = __hip_atomic_load(fz.ll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                st[i] = (uint32_t)(w >> 32) == fz.up.seq ? __builtin_bit_cast(float, (uint32_t)w) : __builtin_nanf("");
+#pragma unroll
+                for (int j = 0; j < LLW; ++j) {
+                    const int i = i0 + j * MPPI_BLOCK;
+                    if (i < tot) {
+                        for (int spin = 0; (uint32_t)(w[j] >> 32) != fz.up.seq && spin < (1 << 22); ++spin) {
+                            __builtin_amdgcn_s_sleep(1);
+                            w[j] = __hip_atomic_load(fz.ll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        st[i] = (uint32_t)(w[j] >> 32) == fz.up.seq ? __builtin_bit_cast(float, (uint32_t)w[j]) : __builtin_nanf("");
+                    }
+                }
             }
             __syncthreads();
             const size_t scratch_floats = 8 + P + 1 + min(nb, MERGE_CHUNK) + (size_t)tot;
