@@ -411,7 +411,7 @@ int check_predictor(ctk_handle* h) {
 // ---- MPPI ------------------------------------------------------------------------------------
 int mppi_block_parts(const ctk_handle* h) { return ctk_mppi_num_blocks(h->N, h->cfg.predictor); }
 bool mppi_can_fuse(const ctk_handle* h) {
-    return mppi_block_parts(h) <= CTK_MPPI_FUSE_MAX_BLOCKS && !ctk_mppi_uses_throughput_kernel(h->cfg.predictor, h->N);
+    return !ctk_mppi_uses_throughput_kernel(h->cfg.predictor, h->N) && ctk_mppi_fusable(h->P, mppi_block_parts(h), h->d_ll != nullptr);
 }
 
 // fuse_mode: 0 block records only; 1 the last block also merges + updates (single-GPU step);
@@ -754,7 +754,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     TRY_CREATE(dev_alloc(h, &h->d_parts2, ((nblk + 31) / 32) * (2 + P)));
     TRY_CREATE(dev_alloc(h, &h->d_parts3, ((nblk + 1023) / 1024) * (2 + P)));
     TRY_CREATE(dev_alloc(h, &h->d_counter, 1));
-    if (nblk <= (size_t)CTK_MPPI_FUSE_MAX_BLOCKS && !std::getenv("CTK_NO_LL")) TRY_CREATE(dev_alloc(h, &h->d_ll, nblk * (2 + P)));
+    if (nblk <= (size_t)CTK_MPPI_FUSE_MAX_BLOCKS_LL && !std::getenv("CTK_NO_LL")) TRY_CREATE(dev_alloc(h, &h->d_ll, nblk * (2 + P)));
     TRY_CREATE(dev_alloc(h, &h->d_unom[0], H));
     TRY_CREATE(dev_alloc(h, &h->d_unom[1], H));
     TRY_CREATE(dev_alloc(h, &h->d_std, H));

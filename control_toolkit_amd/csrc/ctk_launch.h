@@ -18,7 +18,10 @@ bool ctk_mppi_uses_throughput_kernel(int pred, int N);
 size_t ctk_mppi_rollout_lds(int P, int H, int pred = 0);
 // wperm: per-lane permuted MLP weights (ctk_api.hip: permute_mlp_weights), nullptr for the ODE predictor
 // In-launch merge by the last block to finish (<= CTK_MPPI_FUSE_MAX_BLOCKS blocks).
-constexpr int CTK_MPPI_FUSE_MAX_BLOCKS = 64;     // beyond this the last block's serial record fetch costs more than a launch
+constexpr int CTK_MPPI_FUSE_MAX_BLOCKS = 64;     // ticket form: beyond this the last block's serial record fetch costs more than a launch
+constexpr int CTK_MPPI_FUSE_MAX_BLOCKS_LL = 128; // {value, seq} form (records staged in LDS): measured 26.7 vs 29.5 us at 128 blocks, 30.8 vs 29.1 at 256
+// can a rollout launch of `blocks` workgroups merge and update in-launch?  (have_ll: the handle owns the LL word buffer)
+bool ctk_mppi_fusable(int P, int blocks, bool have_ll);
 // From this many rollouts on (ODE predictor) the latency-oriented 4-wave block gives way to the
 // throughput-oriented single-wave block (half the LDS, 2x the resident recurrence waves per CU).
 constexpr int CTK_MPPI_THROUGHPUT_MIN_N = 32768;

@@ -57,7 +57,7 @@ def test_gru_plain_rollout_and_hidden_state_match_oracle():
 
 @pytest.mark.parametrize("N,H,p", [(1024, 50, 1), (2048, 40, 10), (16, 5, 2), (70, 12, 5), (8192, 20, 1)])
 def test_mppi_gru_matches_oracle(N, H, p):
-    """N = 8192 takes the unfused path (128 blocks > CTK_MPPI_FUSE_MAX_BLOCKS): both advance the hidden state."""
+    """N = 8192 = 512 GRU workgroups takes the unfused path (> CTK_MPPI_FUSE_MAX_BLOCKS_LL): both advance the hidden state."""
     env = O.EnvParams(terminal_weight=0.25)
     w = O.gru_default_weights(1)
     pred = O.Predictor("GRU", dt=0.02, env=env, weights=w)
