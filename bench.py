@@ -301,7 +301,7 @@ def main():
             ach = alg_bytes / (kms * 1e-3) / 1e9 if ok else None
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS if ach else None,
-                    "traffic": 511227 if args.workload == "mppi_cfg2" and samples_in_hbm else None,
+                    "traffic": 514891 if args.workload == "mppi_cfg2" and samples_in_hbm else None,
                     "note": "issue/latency-bound at this size, not HBM-bound: 0.2 MB per launch vs an H-step dependent "
                             "recurrence (~60 VALU instructions per step on one wave per 64 trajectories); traffic = "
                             "(2 x FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 --pmc passes with the guide's gfx950 factor on "
