@@ -1,0 +1,39 @@
+"""-m gpu: bench.py keeps its contract — exactly ONE JSON line on stdout (native libraries' banners go to stderr),
+the required keys, the roofline / cpu_baseline objects, and consistency between value and ms_per_step."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "10", "--no-large-n"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=550)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 60 and d["warmup"] == 10 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "MPPI N=1024" in d["config"]["workload"] and "H=50" in d["config"]["workload"]
+    assert abs(d["value"] - 1024 * 50 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert d["value"] > 1e8                                            # far above the 1e6 target on any healthy box
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel"].startswith("ctk_mppi_rollout")
+    assert rf["kernel_timed_launches"] >= 3 and 5.0 < rf["kernel_us"] < 100.0
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 1e5
