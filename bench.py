@@ -151,6 +151,27 @@ def cpu_baseline(w, budget_s=12.0):
             "sample": f"{n} {w['opt'].upper()} steps of N={N}, H={H} (oracle/ctk_oracle.py, NumPy fp32, single thread), {el:.1f} s"}
 
 
+def cpu_baseline_torch(w, budget_s=4.0):
+    """Second CPU leg (SURVEY 8d ii): the same MPPI step as batched torch-CPU ops on all host cores — the shape of
+    the reference's own PyTorch backend run on a CPU.  At this problem size it is slower than the single-thread
+    NumPy port above (a few microseconds of framework overhead on each of the ~2000 small tensor ops of a step)."""
+    from oracle import ctk_oracle as O
+    from oracle.ctk_oracle_torch import TorchMPPI
+    pred = O.Predictor("ODE")
+    o = O.MPPI(pred, O.Cost(pred.env), num_rollouts=w["N"], mpc_horizon=w["H"], period_interpolation_inducing_points=w["p"])
+    t = TorchMPPI(o, threads=os.cpu_count() or 1)
+    noise = np.random.default_rng(0).standard_normal((w["N"], o.P, 1)).astype(np.float32)
+    s = np.array([0.05, -0.1, 2.8, 0.4], np.float32)
+    t.step(s, noise)
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < budget_s:
+        plant_step(s, t.step(s, noise)); n += 1
+    el = time.perf_counter() - t0
+    return {"value": w["N"] * w["H"] * n / el, "unit": "trajectory-steps/s", "cores": t.threads, "kind": "port",
+            "sample": f"{n} MPPI steps of N={w['N']}, H={w['H']} (oracle/ctk_oracle_torch.py, torch-CPU fp32 batched ops, "
+                      f"{t.threads} threads), {el:.1f} s"}
+
+
 def large_n_point(torch, CtkEngine, dev, H, p, N=1 << 20, steps=12):
     """The same MPPI step at N = 2^20 (outside the timed region, not part of `value`): where the path sits against
     the HBM roofline once the chip is full.  BASELINE's size occupies 16 of 256 CUs, so its own fraction says
@@ -329,6 +350,8 @@ def main():
             out["roofline_large_n"] = large_n_point(torch, CtkEngine, dev, H, p)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w)
+            if w["opt"] == "mppi" and w["pred"] == "ODE":
+                out["cpu_baseline_torch"] = cpu_baseline_torch(w)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     os.close(result_fd)
     eng.close()

@@ -74,7 +74,7 @@ def test_product_never_imports_the_oracle():
                     assert not pat.search(line), f"{f}: {line.strip()}"
     for f in ("bench.py",):
         body = open(os.path.join(ROOT, f)).read()
-        assert body.count("from oracle import") == 1 and "def cpu_baseline" in body   # only the cpu_baseline leg
+        assert body.count("from oracle") == 3 and "def cpu_baseline" in body           # only inside the two cpu_baseline legs
 
 
 def test_hip_library_gate_and_optimizer_discovery():

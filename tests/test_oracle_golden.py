@@ -198,3 +198,21 @@ def test_device_noise_statistics_and_sharding():
     np.testing.assert_array_equal(a[1024:2048], b)
     u = O.device_noise(seed=7, stream=1, call=0, first_row=0, rows=1024, cols=7, kind="uniform")
     assert u.min() >= 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.02
+
+
+def test_torch_cpu_restatement_matches_the_numpy_oracle():
+    """bench.py's second CPU leg (oracle/ctk_oracle_torch.py) is the pinned NumPy oracle's MPPI step in torch ops."""
+    from oracle.ctk_oracle_torch import TorchMPPI
+    env = O.EnvParams(terminal_weight=0.2)
+    pred = O.Predictor("ODE", env=env)
+    for (N, H, p) in [(64, 12, 5), (200, 30, 1)]:
+        o = O.MPPI(pred, O.Cost(env), num_rollouts=N, mpc_horizon=H, period_interpolation_inducing_points=p)
+        t = TorchMPPI(O.MPPI(pred, O.Cost(env), num_rollouts=N, mpc_horizon=H, period_interpolation_inducing_points=p))
+        rng = np.random.default_rng(N)
+        s = np.array([0.05, -0.1, 2.8, 0.4], np.float32)
+        for _ in range(3):
+            noise = rng.standard_normal((N, o.P, 1)).astype(np.float32)
+            uo, ut = float(o.step(s, noise)), t.step(s, noise)
+            np.testing.assert_allclose(t.J.numpy(), o.J, rtol=2e-5)
+            np.testing.assert_allclose(t.u_nom.numpy(), o.u_nom.reshape(-1), rtol=1e-4, atol=2e-5)
+            assert abs(uo - ut) < 2e-5
