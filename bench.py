@@ -159,7 +159,7 @@ def cpu_baseline_torch(w, budget_s=4.0):
     from oracle.ctk_oracle_torch import TorchMPPI
     pred = O.Predictor("ODE")
     o = O.MPPI(pred, O.Cost(pred.env), num_rollouts=w["N"], mpc_horizon=w["H"], period_interpolation_inducing_points=w["p"])
-    t = TorchMPPI(o, threads=os.cpu_count() or 1)
+    t = TorchMPPI(o, threads=max(1, min(16, len(os.sched_getaffinity(0)))))   # a one-GPU box's CPU share is 16 cores
     noise = np.random.default_rng(0).standard_normal((w["N"], o.P, 1)).astype(np.float32)
     s = np.array([0.05, -0.1, 2.8, 0.4], np.float32)
     t.step(s, noise)
