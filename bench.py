@@ -140,6 +140,11 @@ def cpu_baseline(w, budget_s=12.0):
         o.optimizer_reset(rng.random((N, o.P, 1), dtype=np.float32))
         dr = rng.random((N - o.k, o.P, 1), dtype=np.float32)
         step = lambda s: o.step(s, dr)
+    try:                                   # "cores": 1 must hold for the BLAS calls inside NumPy too
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)
+    except Exception:                      # noqa: BLE001 — not installed: NumPy's own default applies
+        limiter = None
     step(s)   # warm-up
     t0 = time.perf_counter(); n = 0
     while True:
@@ -147,6 +152,8 @@ def cpu_baseline(w, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s:
             break
+    if limiter is not None:
+        limiter.restore_original_limits()
     return {"value": N * H * n / el, "unit": "trajectory-steps/s", "cores": 1, "kind": "port",
             "sample": f"{n} {w['opt'].upper()} steps of N={N}, H={H} (oracle/ctk_oracle.py, NumPy fp32, single thread), {el:.1f} s"}
 
