@@ -41,6 +41,7 @@ WORKLOADS = {
     "mppi_cfg5_shard": dict(opt="mppi", pred="MLP", N=8192, H=100, p=10, kw={}),
     # recurrent predictor (2x32 GRU, weights in LDS) at the headline MPPI size
     "mppi_gru": dict(opt="mppi", pred="GRU", N=1024, H=50, p=1, kw={}),
+    "mppi_mlp": dict(opt="mppi", pred="MLP", N=1024, H=50, p=1, kw={}),
     # the reference's own default problem sizes (Control_Toolkit_ASF_Template/config_optimizers.yml)
     "mppi_default": dict(opt="mppi", pred="ODE", N=3500, H=35, p=10, kw={}),
     "cem_default": dict(opt="cem", pred="ODE", N=200, H=40, p=1,

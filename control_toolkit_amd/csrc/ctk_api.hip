@@ -77,6 +77,8 @@ struct ctk_handle {
     const float* shard_last_cands = nullptr;
     float shard_s[CTK_S] = {0, 0, 0, 0}; float shard_uprev = 0.0f; bool shard_has_uprev = false;
     bool have_weights = false;  // network weights uploaded
+    float hidden_scale = 1.0f;        // GRU: max(1, max |h|) of a caller-set hidden state (units stay within it)
+    float net_out_bound = INFINITY;   // GRU: max_g (sum_j |W_o[g,j]| + |b_o[g]|) >= any predicted state component (|h| <= 1)
     // peer-to-peer sharded MPPI (ctk_p2p_*)
     int p2p_rank = -1, p2p_world = 0;
     bool p2p_connected = false;
@@ -302,6 +304,8 @@ RolloutArgs make_args(ctk_handle* h, const float* s, const float* u_prev, int N,
     a.call = h->call;
     a.stream_id = 0;
     a.global_row0 = h->cfg.global_rollout_offset;
+    // GRU rollouts: the angle the cost sees is s[2] at h = 0 and a network output afterwards
+    a.fast_cos_ok = (std::fabs(s[2]) <= CTK_SINCOS_FAST_LIMIT && h->net_out_bound * h->hidden_scale <= CTK_SINCOS_FAST_LIMIT) ? 1 : 0;
     return a;
 }
 
@@ -881,6 +885,12 @@ int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n) {
     HIP_TRY(h, hipMemcpyAsync(h->d_weights, w, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
     if (gru) HIP_TRY(h, hipMemsetAsync(h->d_wperm + GRU_TABLE_FLOATS, 0, GRU_HIDDEN_FLOATS * sizeof(float), h->stream));
     const std::vector<float> perm = gru ? permute_gru_weights(w) : permute_mlp_weights(w);
+    if (gru) {   // |h2| <= 1 (convex mix of tanh values and the previous state, which starts at 0 or at what the caller set)
+        const float* Wo = w + GRU_NW_RAW - 4 * 32 - 4; const float* bo = Wo + 4 * 32;
+        float bound = 0.0f;
+        for (int g = 0; g < 4; ++g) { float r = std::fabs(bo[g]); for (int j = 0; j < 32; ++j) r += std::fabs(Wo[g * 32 + j]); bound = std::max(bound, r); }
+        h->net_out_bound = bound;
+    }
     HIP_TRY(h, hipMemcpyAsync(h->d_wperm, perm.data(), perm.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->have_weights = true;
@@ -913,6 +923,8 @@ int ctk_predictor_set_hidden(ctk_handle* h, const float* src, size_t n) {
     if (h->cfg.predictor != CTK_PRED_GRU) return fail(h, CTK_ERR_STATE, "ctk_predictor_set_hidden: predictor has no hidden state");
     if (src && n != (size_t)GRU_HIDDEN_FLOATS) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_predictor_set_hidden: expected 64 floats");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    h->hidden_scale = 1.0f;
+    if (src) for (int i = 0; i < GRU_HIDDEN_FLOATS; ++i) h->hidden_scale = std::max(h->hidden_scale, std::fabs(src[i]));
     if (src) HIP_TRY(h, hipMemcpyAsync(h->d_wperm + GRU_TABLE_FLOATS, src, GRU_HIDDEN_FLOATS * sizeof(float), hipMemcpyHostToDevice, h->stream));
     else HIP_TRY(h, hipMemsetAsync(h->d_wperm + GRU_TABLE_FLOATS, 0, GRU_HIDDEN_FLOATS * sizeof(float), h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -82,5 +82,6 @@ struct RolloutArgs {
     // counter-based RNG (samples == nullptr)
     uint32_t seed_lo, seed_hi, call, stream_id;
     int global_row0;
+    int fast_cos_ok;         // network predictors: every angle the cost will see is inside the unchecked cos range (host-side bound)
     unsigned long long* stamps;   // diagnostic builds only (-DCTK_STAMPS): 8 s_memtime stamps per block
 };

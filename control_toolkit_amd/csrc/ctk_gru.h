@@ -153,13 +153,12 @@ CTK_DEV float gru_step(const GruW& w, GruState& st, float sv, float u, int g, fl
 // Rolls the workgroup's 16 trajectories (first one = traj0) from the carried hidden state h0; called by all
 // four waves.  ufn(h): input of trajectory c = lane & 15.  Returns J of trajectory c in every lane of WAVE 0
 // (the other waves return 0; wave 0 carries the cost terms, wave 2 the trajectory stores).
-template <bool WRITE_TRAJ, bool INPUT_COST, class UFn>
-CTK_DEV float rollout_gru(const RolloutArgs& a, const EnvK& k, const float* __restrict__ table, const float* __restrict__ h0,
-                          float* ex, int traj0, UFn&& ufn) {
+template <bool WRITE_TRAJ, bool INPUT_COST, bool FASTCOS, class UFn>
+CTK_DEV float rollout_gru_impl(const RolloutArgs& a, const EnvK& k, const GruW& w, const float* __restrict__ h0,
+                               float* ex, int traj0, UFn&& ufn) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int n = traj0 + c;
     const bool valid = n < a.N;
-    const GruW w = gru_load_weights(table, wave, lane);
     const MlpCostK ck = mlp_cost_coeffs(k, g, INPUT_COST);
     GruState st = gru_load_state(h0, g);
     float sv = a.s0[g];
@@ -170,7 +169,7 @@ CTK_DEV float rollout_gru(const RolloutArgs& a, const EnvK& k, const float* __re
     for (int h = 0; h < H; ++h) {
         const float u = u_next;
         if (h + 1 < H) u_next = ufn(h + 1);
-        if (wave == 0) csum += mlp_stage_cost_share<true>(k, ck, sv, u, uprev);
+        if (wave == 0) csum += mlp_stage_cost_share<!FASTCOS>(k, ck, sv, u, uprev);
         if constexpr (WRITE_TRAJ) {
             if (wave == 2 && valid && a.traj_out) a.traj_out[((size_t)n * (H + 1) + h) * CTK_S + g] = sv;
         }
@@ -183,4 +182,14 @@ CTK_DEV float rollout_gru(const RolloutArgs& a, const EnvK& k, const float* __re
     if (wave != 0) return 0.0f;
     csum += mlp_terminal_cost_share(k, ck, g, sv);
     return sum_over_groups(csum) * a.inv_Hp1;
+}
+
+// FASTCOS (a.fast_cos_ok, decided on the host from a bound on the network's outputs): the unchecked cos in the
+// per-step cost on wave 0 — it sits on the workgroup's critical path, the other waves wait for it at the next barrier
+template <bool WRITE_TRAJ, bool INPUT_COST, class UFn>
+CTK_DEV float rollout_gru(const RolloutArgs& a, const EnvK& k, const float* __restrict__ table, const float* __restrict__ h0,
+                          float* ex, int traj0, UFn&& ufn) {
+    const GruW w = gru_load_weights(table, threadIdx.x >> 6, threadIdx.x & 63);
+    if (a.fast_cos_ok) return rollout_gru_impl<WRITE_TRAJ, INPUT_COST, true>(a, k, w, h0, ex, traj0, ufn);
+    return rollout_gru_impl<WRITE_TRAJ, INPUT_COST, false>(a, k, w, h0, ex, traj0, ufn);
 }

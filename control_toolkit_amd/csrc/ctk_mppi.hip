@@ -273,7 +273,10 @@ struct FuseArgs {
 // -amdgpu-kernarg-preload-count=14 (Makefile) the command processor delivers them in SGPRs at wave launch, so the
 // sample loads do not wait for a cold scalar-cache miss on the kernel-argument segment (MI355X: gfx940+ feature).
 // N_/H_/P_/pmagic_ duplicate fields of `a` for that reason.
-template <int PRED, bool LOG>
+// P2P: the instantiations whose merging block goes on to exchange records with peer GPUs (fuse mode 3, ctk_p2p_step);
+// kept apart because that tail costs the network-predictor kernels registers they need in the recurrence (measured:
+// GRU 83 -> 109 us per launch when every instantiation carried it).
+template <int PRED, bool LOG, bool P2P = false>
 __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __restrict__ samples,
                                                                const float* __restrict__ u_nom,
                                                                const InterpEntry* __restrict__ interp,
@@ -479,7 +482,9 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
             __syncthreads();                      // col_s / tile are dead: the merge scratch may overwrite them
             const int nb = (int)gridDim.x, tot = nb * (2 + P);
             float* st = merge_stage_ptr(lds, nb, P);
-            constexpr int LLW = 8;                // words in flight per thread: the first pass over a thread's words is
+            // (the network-predictor instantiations sit at the 128-VGPR boundary of 4 waves/SIMD: a deeper batch there
+            //  spills the recurrence's registers to scratch — measured 83 -> 109 us for the GRU — so they keep 2)
+            constexpr int LLW = ODE ? 8 : 2;      // words in flight per thread: the first pass over a thread's words is
             for (int i0 = t; i0 < tot; i0 += MPPI_BLOCK * LLW) {   // one pipelined batch of loads, not LLW round trips
                 unsigned long long w[LLW];
 #pragma unroll
@@ -504,7 +509,7 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
             if (scratch_floats <= (size_t)(w0_s - lds)) { fz.up.w0_l = w0_s; fz.up.w1_l = w1_s; fz.up.un_l = un_s; fz.up.i0_l = i0_s; }
             if (fz.mode == 1) mppi_merge_block<true, 0>(lds, nullptr, nb, P, m.neg_inv_lbd, nullptr, fz.up, 2);
             else mppi_merge_block<false, 0>(lds, nullptr, nb, P, m.neg_inv_lbd, fz.out_rec, fz.up, 2);
-            if (fz.mode == 3) {
+            if constexpr (P2P) {
                 // sharded step over peer-to-peer stores, all in this launch: the shard's record (just written to
                 // fz.out_rec = this rank's slot of its own exchange buffer by this block) goes to every peer, their
                 // records arrive, merge, update (ctk_mppi_p2p_exchange's body)
@@ -685,16 +690,17 @@ hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& 
     fz.ll = (fuse.mode != 0 && fz.stage_ok) ? fuse.ll : nullptr;
     fz.p2p = static_cast<const P2PArgs*>(fuse.p2p); fz.p2p_seq = fuse.p2p_seq;
     fz.up = MppiUpdateArgs{nullptr, nullptr, nullptr, nullptr, a.H, a.interp, u_nom, fuse.u_nom_out, a.lo, a.hi, fuse.u_dev, fuse.u_host, fuse.seq};
-    if (pred == CTK_PRED_ODE) {
-        if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, wperm, parts, a.N, a.H, a.P, a.p_magic, a, k, m, fz);
-        else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, wperm, parts, a.N, a.H, a.P, a.p_magic, a, k, m, fz);
-    } else if (pred == CTK_PRED_MLP) {
-        if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_MLP, true>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, wperm, parts, a.N, a.H, a.P, a.p_magic, a, k, m, fz);
-        else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_MLP, false>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, wperm, parts, a.N, a.H, a.P, a.p_magic, a, k, m, fz);
-    } else {
-        if (log) CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_GRU, true>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, wperm, parts, a.N, a.H, a.P, a.p_magic, a, k, m, fz);
-        else CTK_LAUNCH((ctk_mppi_rollout<CTK_PRED_GRU, false>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, wperm, parts, a.N, a.H, a.P, a.p_magic, a, k, m, fz);
-    }
+#define CTK_MPPI_LAUNCH(PREDV, LOGV, P2PV) CTK_LAUNCH((ctk_mppi_rollout<PREDV, LOGV, P2PV>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, wperm, parts, a.N, a.H, a.P, a.p_magic, a, k, m, fz)
+#define CTK_MPPI_LAUNCH_PRED(PREDV)                                                            \
+    do {                                                                                       \
+        if (fuse.mode == 3) { if (log) CTK_MPPI_LAUNCH(PREDV, true, true); else CTK_MPPI_LAUNCH(PREDV, false, true); } \
+        else { if (log) CTK_MPPI_LAUNCH(PREDV, true, false); else CTK_MPPI_LAUNCH(PREDV, false, false); }             \
+    } while (0)
+    if (pred == CTK_PRED_ODE) CTK_MPPI_LAUNCH_PRED(CTK_PRED_ODE);
+    else if (pred == CTK_PRED_MLP) CTK_MPPI_LAUNCH_PRED(CTK_PRED_MLP);
+    else CTK_MPPI_LAUNCH_PRED(CTK_PRED_GRU);
+#undef CTK_MPPI_LAUNCH_PRED
+#undef CTK_MPPI_LAUNCH
     return hipGetLastError();
 }
 
