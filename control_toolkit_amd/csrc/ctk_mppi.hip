@@ -482,9 +482,7 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
             __syncthreads();                      // col_s / tile are dead: the merge scratch may overwrite them
             const int nb = (int)gridDim.x, tot = nb * (2 + P);
             float* st = merge_stage_ptr(lds, nb, P);
-            // (the network-predictor instantiations sit at the 128-VGPR boundary of 4 waves/SIMD: a deeper batch there
-            //  spills the recurrence's registers to scratch — measured 83 -> 109 us for the GRU — so they keep 2)
-            constexpr int LLW = ODE ? 8 : 2;      // words in flight per thread: the first pass over a thread's words is
+            constexpr int LLW = 8;                // words in flight per thread: the first pass over a thread's words is
             for (int i0 = t; i0 < tot; i0 += MPPI_BLOCK * LLW) {   // one pipelined batch of loads, not LLW round trips
                 unsigned long long w[LLW];
 #pragma unroll
