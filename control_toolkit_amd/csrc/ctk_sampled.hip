@@ -54,56 +54,91 @@ __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(const float* __
     });
     __syncthreads();
 
-    {   // inputs of all H steps + input-only stage-cost terms; thread (trajectory t % TRAJ, chunk t / TRAJ — lane and
-        // wave when TRAJ = 64) takes a contiguous chunk of steps
-        const int ptraj = t % TRAJ, chunk = t / TRAJ;
+    // inputs of the steps [hbeg, hend) of trajectory ptraj into ubuf + their input-only stage-cost terms (returned)
+    auto prepare = [&](int ptraj, int hbeg, int hend) {
         const float* my = tile + ptraj * ts;
         auto input_at = [&](int h) { return fminf(fmaxf(base_s[h] + my[h] * scale_s[h], a.lo), a.hi); };
-        const int Hc = (H + CHUNKS - 1) / CHUNKS;
-        const int h0 = chunk * Hc, h1 = min(H, h0 + Hc);
         float cin = 0.0f;
-        float uprev = (h0 == 0 || h0 >= H) ? (a.u_prev_dev ? *a.u_prev_dev : a.u_prev) : input_at(h0 - 1);
+        float uprev = (hbeg == 0 || hbeg >= H) ? (a.u_prev_dev ? *a.u_prev_dev : a.u_prev) : input_at(hbeg - 1);
 #pragma unroll 2
-        for (int h = h0; h < h1; ++h) {
+        for (int h = hbeg; h < hend; ++h) {
             const float u = input_at(h);
             cin += stage_cost_input(k, u, uprev);
             uprev = u;
             ubuf[ptraj * us + h] = u;
         }
-        cin_s[chunk * TRAJ + ptraj] = cin;
-    }
-    __syncthreads();
-
-    {   // the plans, coalesced: Q[row0*H + i] for the block's contiguous span (elite refit / logging read it)
+        return cin;
+    };
+    // the plans, coalesced: Q[row0*H + i] for the block's contiguous span (elite refit / logging read it)
+    auto write_plans = [&](int first, int stride) {
         const int total = min(TRAJ, a.N - row0) * H;
         float* dst = a.Q_out + (size_t)row0 * H;
-        for (int i = t; i < total; i += SAMP_BLOCK) {
+        for (int i = first; i < total; i += stride) {
             const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i;
             dst[i] = ubuf[r * us + (i - r * H)];
         }
-    }
+    };
 
     if constexpr (PRED == CTK_PRED_ODE) {
+        // Two phases, as in ctk_mppi_rollout: all four waves prepare the first S1 steps; then wave 0 runs the recurrence
+        // over them while waves 1..3 prepare the rest; they meet when wave 0 reaches step S1, after which waves 1..3
+        // write the plans out while wave 0 finishes the horizon.  Per-wave sums of the input-only terms: a wave's
+        // phase-A part is carried into its phase-B sum (slot = wave).
+        const int S1 = min(H, 16), Ha = (S1 + SAMP_WAVES - 1) / SAMP_WAVES;
+        const float cin_a = prepare(lane, min(S1, wave * Ha), min(S1, wave * Ha + Ha));
+        if (wave == 0) cin_s[lane] = cin_a;
+        __syncthreads();
+        const float* myu = ubuf + lane * us;
+        auto F_at = [&](int h) { return k.u_max * myu[h]; };
+        State4 st{a.s0[0], a.s0[1], a.s0[2], a.s0[3]};
+        float csum = 0.0f, amax = 0.0f;
+        float4* traj = nullptr;
+        if constexpr (WTRAJ) {
+            if (a.traj_out) traj = reinterpret_cast<float4*>(a.traj_out) + (size_t)n * (H + 1);
+        }
+        const bool single = k.intermediate_steps == 1;
         if (wave == 0) {
-            const float* myu = ubuf + lane * us;
-            float amax = 0.0f;
-            auto F_at = [&](int h) { return k.u_max * myu[h]; };
-            float J;
-            if (k.intermediate_steps == 1) J = recur_ode_state_cost<WTRAJ, false, true>(a, k, n, valid, F_at, &amax);
-            else J = recur_ode_state_cost<WTRAJ, true, false>(a, k, n, valid, F_at, &amax);
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0))
+            if (single) recur_ode_range<WTRAJ, false, true>(k, traj, valid, F_at, 0, S1, st, csum, amax);
+        } else {
+            const int Hb = (H - S1 + SAMP_WAVES - 2) / (SAMP_WAVES - 1);
+            cin_s[wave * SAMP_TRAJ + lane] = cin_a + prepare(lane, min(H, S1 + (wave - 1) * Hb), min(H, S1 + (wave - 1) * Hb + Hb));
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float J = 0.0f;
+            if (single) {
+                recur_ode_range<WTRAJ, false, true>(k, traj, valid, F_at, S1, H, st, csum, amax);
+                if constexpr (WTRAJ) {
+                    if (valid && traj) traj[H] = make_float4(st.x, st.v, st.th, st.om);
+                }
+                J = csum + terminal_cost(k, st);
+            }
+            if (!single || __builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0))
                 J = recur_ode_state_cost<WTRAJ, true, false>(a, k, n, valid, F_at, &amax);
             J += (cin_s[lane] + cin_s[SAMP_TRAJ + lane]) + (cin_s[2 * SAMP_TRAJ + lane] + cin_s[3 * SAMP_TRAJ + lane]);
             if (valid) a.J[n] = J * a.inv_Hp1;
+        } else {
+            write_plans(t - 64, SAMP_BLOCK - 64);
         }
-    } else if constexpr (PRED == CTK_PRED_MLP) {
+        return;
+    }
+
+    {   // network predictors: inputs of all H steps first; thread (trajectory t % TRAJ, chunk t / TRAJ)
+        const int ptraj = t % TRAJ, chunk = t / TRAJ;
+        const int Hc = (H + CHUNKS - 1) / CHUNKS;
+        cin_s[chunk * TRAJ + ptraj] = prepare(ptraj, min(H, chunk * Hc), min(H, chunk * Hc + Hc));
+    }
+    __syncthreads();
+    write_plans(t, SAMP_BLOCK);
+
+    if constexpr (PRED == CTK_PRED_MLP) {
         const int tr = wave * CTK_MLP_TRAJ_PER_WAVE + (lane & 15);
         const float* myu = ubuf + tr * us;
         const MlpFwdW w = mlp_load_fwd(wperm);
         float J = rollout_mlp<false, WTRAJ, false>(a, k, w, row0 + wave * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return myu[h]; });
         J += ((cin_s[tr] + cin_s[SAMP_TRAJ + tr]) + (cin_s[2 * SAMP_TRAJ + tr] + cin_s[3 * SAMP_TRAJ + tr])) * a.inv_Hp1;
         if (lane < 16 && row0 + tr < a.N) a.J[row0 + tr] = J;
-    } else {
+    } else if constexpr (PRED == CTK_PRED_GRU) {
         // the four waves share the workgroup's 16 trajectories; wave 0 ends with J (lane = trajectory for lanes 0..15)
         const float* myu = ubuf + (lane & 15) * us;
         float J = rollout_gru<WTRAJ, false>(a, k, wperm, wperm + GRU_TABLE_FLOATS, gru_ex, row0, [&](int h) { return myu[h]; });
