@@ -562,6 +562,15 @@ int random_step(ctk_handle* h, const float* s, const float* u_prev, const float*
     if (int rc = resolve_samples(h, samples, loc, (size_t)h->N * h->H, &d_s)) return rc;
     RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);
     ProfSlot ps(h);
+    static const bool three_launches = std::getenv("CTK_NO_FUSED_ARGMIN") != nullptr;   // A/B switch
+    if (h->cfg.predictor == CTK_PRED_ODE && h->d_ll && !three_launches &&
+        ctk_affine_rollout_blocks(h->cfg.predictor, h->N) <= CTK_AFFINE_BEST_MAX_BLOCKS) {
+        // ONE launch: rollout + arg-min over the block minima + u (optimizer_random_action_tf.py:62-68)
+        const AffineBest bst{h->d_ll, h->seq, h->d_u, h->h_u_dev, h->d_idx};
+        HIP_TRY(h, ctk_launch_affine_rollout(h->stream, h->cfg.predictor, a, h->k, d_s, 1, h->d_base, h->d_scale, h->d_wperm,
+                                             h->cfg.materialize_trajectories != 0, ps.a, ps.b, &bst));
+        return finish_step(h, u_out);
+    }
     HIP_TRY(h, ctk_launch_affine_rollout(h->stream, h->cfg.predictor, a, h->k, d_s, 1, h->d_base, h->d_scale, h->d_wperm,
                                          h->cfg.materialize_trajectories != 0, ps.a, ps.b));
     HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, 1, h->d_idx));

@@ -67,9 +67,14 @@ size_t ctk_affine_rollout_lds(int H, int pred = 0);
 // GRU: hidden <- cell(hidden, [s, u]) for the carried state behind the weight table (ctk_gru.h); u_dev NULL: u_val
 hipError_t ctk_launch_gru_advance(hipStream_t st, const float* s, const float* u_dev, float u_val, float* wperm);
 // samples [N,H] (device) or nullptr (Philox, rng_kind 0 normal / 1 uniform); base/scale [H] device.
+// bst (ODE predictor only, <= CTK_AFFINE_BEST_MAX_BLOCKS workgroups): in-launch arg-min — block 0 picks the cheapest
+// rollout under (J, index), writes its index to idx_out[0] and publishes its first input {u, seq}
+struct AffineBest { unsigned long long* ll; uint32_t seq; float* u_dev; float* u_host; int* idx_out; };
+constexpr int CTK_AFFINE_BEST_MAX_BLOCKS = 128;
+int ctk_affine_rollout_blocks(int pred, int N);
 hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const float* samples,
                                      int rng_kind, const float* base, const float* scale, const float* wperm, bool log,
-                                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const AffineBest* bst = nullptr);
 // Smallest-K selection under the total order (J, index) and CEM refit
 // (optimizer_cem_tf.py:73-78): idx_out[K] ascending, mu/std [H] from Q[idx].
 hipError_t ctk_launch_select_topk(hipStream_t st, const float* J, int N, int K, int* idx_out, int ldj = 1);

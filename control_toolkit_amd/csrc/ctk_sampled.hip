@@ -26,12 +26,47 @@ __host__ __device__ inline int affine_carve_floats(int H, int traj) {
 }
 __host__ __device__ inline int affine_traj(int pred) { return pred == CTK_PRED_GRU ? GRU_TRAJ : SAMP_TRAJ; }
 
+// order-preserving map float -> uint32 (total order; -0.0 < +0.0, NaNs sort last)
+CTK_DEV uint32_t f32_sortable(float f) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+CTK_DEV uint32_t wave_min_u32(uint32_t v) {
+    return __builtin_bit_cast(uint32_t, wave_reduce(__builtin_bit_cast(float, v), [](float a, float b) {
+        const uint32_t x = __builtin_bit_cast(uint32_t, a), y = __builtin_bit_cast(uint32_t, b);
+        return __builtin_bit_cast(float, x < y ? x : y);
+    }));
+}
+
+// Optional in-launch arg-min tail (random-action, optimizer_random_action_tf.py:62-68: u = first input of the cheapest
+// plan): every block hands {key(J), index, first input} of its cheapest rollout to block 0 as {payload, sequence number}
+// words (the hand-off form of ctk_mppi.hip), block 0 picks the global minimum under the total order (J, index) — what
+// ctk_select_topk(K = 1) + ctk_pick_best_first do in two more launches — and publishes u.
+struct BestArgs {
+    unsigned long long* ll;   // [blocks][3] words; nullptr: no tail
+    uint32_t seq;
+    float* u_dev;
+    float* u_host;
+    int* idx_out;
+};
+CTK_DEV void ll_put(unsigned long long* p, uint32_t payload, uint32_t seq) {
+    __hip_atomic_store(p, ((unsigned long long)seq << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+CTK_DEV uint32_t ll_get(const unsigned long long* p, uint32_t seq) {
+    unsigned long long w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spin = 0; (uint32_t)(w >> 32) != seq && spin < (1 << 22); ++spin) {
+        __builtin_amdgcn_s_sleep(1);
+        w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return (uint32_t)w;
+}
+
 template <int PRED, bool WTRAJ>
 // (argument order: see ctk_mppi_rollout — the leading 14 dwords are preloaded into SGPRs at wave launch)
 __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(const float* __restrict__ samples, const float* __restrict__ base,
                                                                  const float* __restrict__ scale,
                                                                  const float* __restrict__ wperm, int rng_kind, int N_, int H_,
-                                                                 int P_, uint32_t pmagic_, RolloutArgs a_in, EnvK k) {
+                                                                 int P_, uint32_t pmagic_, RolloutArgs a_in, EnvK k, BestArgs best) {
     extern __shared__ float lds[];
     RolloutArgs a = a_in;
     a.N = N_; a.H = H_; a.P = P_; a.p_magic = pmagic_;
@@ -116,7 +151,33 @@ __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(const float* __
             if (!single || __builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0))
                 J = recur_ode_state_cost<WTRAJ, true, false>(a, k, n, valid, F_at, &amax);
             J += (cin_s[lane] + cin_s[SAMP_TRAJ + lane]) + (cin_s[2 * SAMP_TRAJ + lane] + cin_s[3 * SAMP_TRAJ + lane]);
-            if (valid) a.J[n] = J * a.inv_Hp1;
+            J *= a.inv_Hp1;
+            if (valid) a.J[n] = J;
+            if (best.ll) {
+                const uint32_t key = valid ? f32_sortable(J) : 0xFFFFFFFFu;
+                const uint32_t kmin = wave_min_u32(key);
+                const uint32_t imin = wave_min_u32(key == kmin && valid ? (uint32_t)n : 0x7FFFFFFFu);   // ties: smallest index
+                if (lane == 0) {
+                    unsigned long long* r = best.ll + (size_t)blockIdx.x * 3;
+                    ll_put(r, kmin, best.seq);
+                    ll_put(r + 1, imin, best.seq);
+                    ll_put(r + 2, imin < (uint32_t)a.N ? __builtin_bit_cast(uint32_t, ubuf[(imin - (uint32_t)row0) * us]) : 0u, best.seq);
+                }
+                if (blockIdx.x == 0) {              // every block finishes unconditionally: the polls terminate (and are bounded)
+                    uint32_t bk = 0xFFFFFFFFu, bi = 0x7FFFFFFFu, bu = 0;
+                    for (int b = lane; b < (int)gridDim.x; b += 64) {
+                        const uint32_t kb = ll_get(best.ll + (size_t)b * 3, best.seq), ib = ll_get(best.ll + (size_t)b * 3 + 1, best.seq);
+                        const uint32_t ub = ll_get(best.ll + (size_t)b * 3 + 2, best.seq);
+                        if (kb < bk || (kb == bk && ib < bi)) { bk = kb; bi = ib; bu = ub; }
+                    }
+                    const uint32_t gk = wave_min_u32(bk);
+                    const uint32_t gi = wave_min_u32(bk == gk ? bi : 0x7FFFFFFFu);
+                    if (bk == gk && bi == gi) {     // exactly one lane holds the winner
+                        best.idx_out[0] = (int)gi;
+                        publish_u(best.u_dev, best.u_host, __builtin_bit_cast(float, bu), best.seq);
+                    }
+                }
+            }
         } else {
             write_plans(t - 64, SAMP_BLOCK - 64);
         }
@@ -193,11 +254,6 @@ constexpr int SEL_WAVES = 16;
 constexpr int SEL_ROWS = 16;
 constexpr int SEL_CHUNK = 1024;   // keys per wave and pass (LDS: 16 waves x 1024 x 4 B = 64 KiB)
 
-// order-preserving map float -> uint32 (total order; -0.0 < +0.0, NaNs sort last)
-CTK_DEV uint32_t f32_sortable(float f) {
-    const uint32_t u = __builtin_bit_cast(uint32_t, f);
-    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-}
 
 // J_i = J[i * ldj] (ldj = 1 for a plain cost vector; candidate records of the sharded path are strided)
 __global__ __launch_bounds__(64 * SEL_WAVES) void ctk_select_topk(const float* __restrict__ J, int ldj, int N, int K,
@@ -406,22 +462,26 @@ const char* ctk_affine_rollout_name(int pred, bool log) {
 
 hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const float* samples,
                                      int rng_kind, const float* base, const float* scale, const float* wperm, bool log,
-                                     hipEvent_t e0, hipEvent_t e1) {
+                                     hipEvent_t e0, hipEvent_t e1, const AffineBest* bst) {
+    BestArgs bargs{nullptr, 0u, nullptr, nullptr, nullptr};
+    if (bst && bst->ll && pred == CTK_PRED_ODE) bargs = BestArgs{bst->ll, bst->seq, bst->u_dev, bst->u_host, bst->idx_out};
     const int tr = affine_traj(pred);
     const dim3 grid((a.N + tr - 1) / tr), block(SAMP_BLOCK);
     const size_t lds = ctk_affine_rollout_lds(a.H, pred);
     if (pred == CTK_PRED_ODE) {
-        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k);
-        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k);
+        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
+        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
     } else if (pred == CTK_PRED_MLP) {
-        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_MLP, true>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k);
-        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_MLP, false>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k);
+        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_MLP, true>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
+        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_MLP, false>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
     } else {
-        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_GRU, true>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k);
-        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_GRU, false>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k);
+        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_GRU, true>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
+        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_GRU, false>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
     }
     return hipGetLastError();
 }
+
+int ctk_affine_rollout_blocks(int pred, int N) { const int tr = affine_traj(pred); return (N + tr - 1) / tr; }
 
 size_t ctk_affine_rollout_lds(int H, int pred) {
     return (size_t)(affine_carve_floats(H, affine_traj(pred)) + (pred == CTK_PRED_GRU ? GRU_EX_FLOATS : 0)) * sizeof(float);
