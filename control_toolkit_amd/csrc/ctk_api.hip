@@ -595,7 +595,7 @@ int rpgd_warm(ctk_handle* h, const RolloutArgs& a, int n_new, int gather, int re
     return CTK_OK;
 }
 
-int rpgd_descent(ctk_handle* h, const float* s, const float* u_prev) {
+int rpgd_descent(ctk_handle* h, const float* s, const float* u_prev, const RpgdFusedWarm* fused = nullptr) {
     const ctk_config& c = h->cfg;
     const int iters = rpgd_iterations(h);
     RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);   // p_magic divides by H in the descent kernel
@@ -603,7 +603,7 @@ int rpgd_descent(ctk_handle* h, const float* s, const float* u_prev) {
     HIP_TRY(h, ctk_launch_rpgd_descent(h->stream, c.predictor, a, h->k, c.learning_rate, c.adam_beta_1, c.adam_beta_2,
                                        c.adam_epsilon, c.gradmax_clip, h->d_pop[h->rcur], h->d_m[h->rcur], h->d_v[h->rcur], h->d_bc,
                                        h->bc_len, h->adam_step, iters, h->d_wperm, h->d_scratch, ps.a, ps.b,
-                                       h->variant == CTK_OPT_GRADIENT ? 1 : 0));
+                                       h->variant == CTK_OPT_GRADIENT ? 1 : 0, fused));
     h->adam_step += iters;
     return CTK_OK;
 }
@@ -620,6 +620,18 @@ int rpgd_reset(ctk_handle* h, const float* draws, int loc) {
     return CTK_OK;
 }
 
+// description of the warm start for the single-launch step (N <= 64): the arguments rpgd_warm would pass
+RpgdFusedWarm rpgd_fused(ctk_handle* h, int K, int n_new, int gather, const float* d_draws, int from, int to, int fresh_tail) {
+    const ctk_config& c = h->cfg;
+    return RpgdFusedWarm{K, h->d_idx, h->P, n_new, gather, c.shift_previous, c.sampling_distribution, fresh_tail,
+                         c.sample_stdev, c.sample_mean, c.sample_min, c.sample_max, d_draws, h->d_ages[from],
+                         h->d_pop[to], h->d_m[to], h->d_v[to], h->d_ages[to], h->d_interp, h->d_unom[0], h->d_u, h->h_u_dev, h->seq};
+}
+bool rpgd_can_fuse(const ctk_handle* h) {
+    static const bool off = std::getenv("CTK_NO_RPGD_FUSED") != nullptr;   // A/B switch
+    return !off && h->N <= CTK_RPGD_FUSED_MAX_N;
+}
+
 int rpgd_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc, float* u_out) {
     if (!h->rpgd_ready) return fail(h, CTK_ERR_STATE, "RPGD: call ctk_reset (optimizer_reset) before the first step");
     if (int rc = check_predictor(h)) return rc;
@@ -631,10 +643,15 @@ int rpgd_step(ctk_handle* h, const float* s, const float* u_prev, const float* s
         // every plan shifted by one with a FRESH uniform tail input (:137-144), moments shifted by one (:147-166)
         const float* d_tail = nullptr;
         if (int rc = resolve_samples(h, samples, loc, (size_t)h->N, &d_tail)) return rc;
-        if (int rc = rpgd_descent(h, s, u_prev)) return rc;
-        HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, 1, h->d_idx));
-        RolloutArgs ag = make_args(h, s, u_prev, h->N, h->P);
-        if (int rc = rpgd_warm(h, ag, 0, 0, 0, d_tail, cur, nxt, nullptr, nullptr, 0, 1)) return rc;
+        if (rpgd_can_fuse(h)) {
+            const RpgdFusedWarm fw = rpgd_fused(h, 1, 0, 0, d_tail, cur, nxt, 1);
+            if (int rc = rpgd_descent(h, s, u_prev, &fw)) return rc;
+        } else {
+            if (int rc = rpgd_descent(h, s, u_prev)) return rc;
+            HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, 1, h->d_idx));
+            RolloutArgs ag = make_args(h, s, u_prev, h->N, h->P);
+            if (int rc = rpgd_warm(h, ag, 0, 0, 0, d_tail, cur, nxt, nullptr, nullptr, 0, 1)) return rc;
+        }
         h->rcur = nxt;
         ++h->count;
         return finish_step(h, u_out);
@@ -643,10 +660,15 @@ int rpgd_step(ctk_handle* h, const float* s, const float* u_prev, const float* s
     const float* d_draws = nullptr;
     if (resample)
         if (int rc = resolve_samples(h, samples, loc, (size_t)(h->N - c.opt_keep_k) * h->P, &d_draws)) return rc;
-    if (int rc = rpgd_descent(h, s, u_prev)) return rc;
-    HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, c.opt_keep_k, h->d_idx));   // :345-346
-    RolloutArgs aw = make_args(h, s, u_prev, h->N, h->P);
-    if (int rc = rpgd_warm(h, aw, resample ? h->N - c.opt_keep_k : 0, resample ? 1 : 0, 0, d_draws, cur, nxt)) return rc;
+    if (rpgd_can_fuse(h)) {   // one workgroup holds the population: descent, keep-k and warm start in ONE launch
+        const RpgdFusedWarm fw = rpgd_fused(h, c.opt_keep_k, resample ? h->N - c.opt_keep_k : 0, resample ? 1 : 0, d_draws, cur, nxt, 0);
+        if (int rc = rpgd_descent(h, s, u_prev, &fw)) return rc;
+    } else {
+        if (int rc = rpgd_descent(h, s, u_prev)) return rc;
+        HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, c.opt_keep_k, h->d_idx));   // :345-346
+        RolloutArgs aw = make_args(h, s, u_prev, h->N, h->P);
+        if (int rc = rpgd_warm(h, aw, resample ? h->N - c.opt_keep_k : 0, resample ? 1 : 0, 0, d_draws, cur, nxt)) return rc;
+    }
     h->rcur = nxt;
     ++h->count;
     return finish_step(h, u_out);

@@ -99,10 +99,21 @@ const char* ctk_rpgd_descent_name(int pred);
 size_t ctk_rpgd_descent_lds(int pred, int H, bool* tape_in_lds);
 size_t ctk_rpgd_scratch_floats(int pred, int N, int H);
 // All `iters` clipped-gradient Adam iterations + the final cost pass; bc_table[2*(t-1)] = 1-b1^t, [..+1] = 1-b2^t
+// Single-workgroup step (N <= 64): keep-k selection + warm start as the tail of the descent launch (ctk_rpgd.hip: FusedWarm).
+// Q/m/v of the descent are the old population; the rest describes the new one (arguments of ctk_launch_rpgd_warmstart).
+struct RpgdFusedWarm {
+    int K; int* idx_out;
+    int P, n_new, gather, shift_previous, sampling_distribution, fresh_tail;
+    float sample_stdev, sample_mean, sample_min, sample_max;
+    const float* draws; const float* ages_old;
+    float* Q_new; float* m_new; float* v_new; float* ages_new;
+    const InterpEntry* interp; float* u_nom; float* u_dev; float* u_host; uint32_t seq;
+};
+constexpr int CTK_RPGD_FUSED_MAX_N = 64;
 hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, float lr, float b1, float b2,
                                    float eps, float clip, float* Q, float* m, float* v, const float* bc_table, int bc_len,
                                    int t0, int iters, const float* wperm, float* scratch, hipEvent_t ev_start = nullptr,
-                                   hipEvent_t ev_stop = nullptr, int rule = 0);
+                                   hipEvent_t ev_stop = nullptr, int rule = 0, const RpgdFusedWarm* fused = nullptr);
 hipError_t ctk_launch_rpgd_warmstart(hipStream_t st, const RolloutArgs& a, int N, int H, int P, int n_new, int gather, int shift_previous,
                                      int sampling_distribution, int reset, float lo, float hi, float sample_stdev,
                                      float sample_mean, float sample_min, float sample_max, const float* draws, const int* idx,

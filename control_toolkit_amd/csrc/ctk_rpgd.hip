@@ -193,12 +193,125 @@ CTK_DEV float adam_update(const AdamK& ad, float q, float g, float& m, float& v,
     return fminf(fmaxf(qn, lo), hi);
 }
 
+// ---------------------------------------------------------------------------------------------
+// warm start / resampling / reset.  One thread per (row, h) of the NEW population.
+//   new row i <  n_new : fresh sample (sample_actions :275-296), moments 0, age 0
+//   new row i >= n_new : keeper idx[i - n_new] (or row i itself when gather == 0): plan shifted
+//                        by shift_previous repeating the last input (:377-379), moments shifted by
+//                        ONE and zero-filled (:465,:501), age kept; then every age += 1 (:514)
+// ---------------------------------------------------------------------------------------------
+struct WarmArgs {
+    int N, H, P, n_new, gather, shift_previous, sampling_distribution, reset;
+    float lo, hi, sample_stdev, sample_mean, sample_min, sample_max;
+    // sharded step (SURVEY 8e): keepers and the best plan come from the all-gathered keeper records
+    // {J, global index, age, Q[H], m[H], v[H]} instead of this handle's own rows
+    const float* recs;     // nullptr: single-handle step
+    int rs;                // record stride (3 + 3H)
+    int keeper_base;       // index (in the global sorted keeper list) of the first keeper this shard hosts
+    int fresh_tail;        // gradient_tf: the shifted-in tail input is a fresh U[lo,hi) draw per plan
+                           // (optimizer_gradient_tf.py:137-144) instead of a repeat of the last input
+};
+
+// pointers of one warm start (old population -> new population)
+struct WarmPtrs {
+    const float* draws; const int* idx; const float* Q_old; const float* m_old; const float* v_old; const float* ages_old;
+    float* Q_new; float* m_new; float* v_new; float* ages_new; const InterpEntry* interp; float* u_nom; float* u_dev; float* u_host;
+    uint32_t seq;
+};
+
+// element `gid` (= row * H + h) of the new population; elements 0..H-1 also copy the best plan out and publish u
+CTK_DEV void rpgd_warm_element(const WarmArgs& w, const RolloutArgs& a, const WarmPtrs& p, int gid) {
+    const float* __restrict__ draws = p.draws; const int* __restrict__ idx = p.idx;
+    const float* __restrict__ Q_old = p.Q_old; const float* __restrict__ m_old = p.m_old; const float* __restrict__ v_old = p.v_old;
+    const float* __restrict__ ages_old = p.ages_old;
+    float* __restrict__ Q_new = p.Q_new; float* __restrict__ m_new = p.m_new; float* __restrict__ v_new = p.v_new;
+    float* __restrict__ ages_new = p.ages_new; const InterpEntry* __restrict__ interp = p.interp;
+    float* __restrict__ u_nom = p.u_nom; float* __restrict__ u_dev = p.u_dev; float* __restrict__ u_host = p.u_host;
+    const uint32_t seq = p.seq;
+    const int H = w.H;
+    if (gid < w.N * H) {
+        const int i = gid / H, h = gid - i * H;
+        float q, mm = 0.0f, vv = 0.0f;
+        if (i < w.n_new) {
+            const InterpEntry e = interp[h];
+            float y[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = min(e.i0 + j, w.P - 1);
+                float d;
+                if (draws != nullptr) {
+                    d = draws[(size_t)i * w.P + col];
+                } else {
+                    float d4[4];
+                    draw4(a, (uint32_t)(a.global_row0 + i), (uint32_t)(col >> 2), w.sampling_distribution == 0 ? 1 : 0, d4);
+                    d = d4[col & 3];
+                }
+                const float raw = w.sampling_distribution == 0 ? d * (w.sample_max - w.sample_min) + w.sample_min   // uniform
+                                                                : d * w.sample_stdev + w.sample_mean;                // normal
+                y[j] = fminf(fmaxf(raw, w.lo), w.hi);                                                                // :292
+            }
+            q = y[0] * e.w0 + (e.i0 + 1 < w.P ? y[1] * e.w1 : 0.0f);                                                 // :294
+        } else if (w.gather && w.recs) {
+            const float* rec = w.recs + (size_t)idx[w.keeper_base + i - w.n_new] * w.rs;
+            const int hs = min(h + w.shift_previous, H - 1);
+            q = rec[3 + hs];
+            if (h + 1 < H) { mm = rec[3 + H + h + 1]; vv = rec[3 + 2 * H + h + 1]; }
+        } else {
+            const int src = w.gather ? idx[i - w.n_new] : i;
+            const int hs = min(h + w.shift_previous, H - 1);
+            q = Q_old[(size_t)src * H + hs];
+            if (w.fresh_tail && h + w.shift_previous >= H) {
+                float d;
+                if (draws != nullptr) {
+                    d = draws[i];
+                } else {
+                    float d4[4];
+                    draw4(a, (uint32_t)(a.global_row0 + i), 0u, 1, d4);
+                    d = d4[0];
+                }
+                q = d * (w.hi - w.lo) + w.lo;
+            }
+            if (h + 1 < H) { mm = m_old[(size_t)src * H + h + 1]; vv = v_old[(size_t)src * H + h + 1]; }
+        }
+        Q_new[gid] = q; m_new[gid] = mm; v_new[gid] = vv;
+        if (h == 0) {
+            float age = 0.0f;
+            if (i >= w.n_new) {
+                if (w.gather && w.recs) age = w.recs[(size_t)idx[w.keeper_base + i - w.n_new] * w.rs + 2];
+                else age = ages_old[w.gather ? idx[i - w.n_new] : i];
+            }
+            ages_new[i] = w.reset ? 0.0f : age + 1.0f;
+        }
+    }
+    if (!w.reset && gid < H) {
+        // u_nom = Q_tf[best_idx[0]] BEFORE the warm start (:426)
+        const float q = w.recs ? w.recs[(size_t)idx[0] * w.rs + 3 + gid] : Q_old[(size_t)idx[0] * H + gid];
+        u_nom[gid] = q;
+        if (gid == 0) publish_u(u_dev, u_host, q, seq);   // :523
+    }
+}
+
+// this shard's best plans with their optimizer state, sorted: {J, global index, age, Q[H], m[H], v[H]}
+
+__global__ __launch_bounds__(256) void ctk_rpgd_warmstart(WarmArgs w, RolloutArgs a, WarmPtrs p) {
+    rpgd_warm_element(w, a, p, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Single-workgroup RPGD step (N <= 64, the reference's default is 32): keep-k selection and the warm start run as the tail
+// of the descent launch — the whole optimizer_rpgd.py:388-524 step in ONE launch instead of three.
+struct FusedWarm {
+    int enabled, K;
+    int* idx_out;          // [K] best indices (ascending cost), as ctk_select_topk writes them
+    WarmArgs w;
+    WarmPtrs p;            // p.idx is ignored (the tail's own selection is used)
+};
+
 template <int PRED>
 __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_descent(RolloutArgs a, EnvK k, AdamK ad, float* __restrict__ Q,
                                                              float* __restrict__ m, float* __restrict__ v,
                                                              const float* __restrict__ bc_table, int bc_len, int t0, int iters,
                                                              const float* __restrict__ wperm, float* __restrict__ scratch,
-                                                             int tape_in_lds) {
+                                                             int tape_in_lds, FusedWarm fw) {
     extern __shared__ float lds[];
     const int H = a.H;
     float* q_s = lds;                       // [H][65]
@@ -282,100 +395,30 @@ __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_descent(RolloutArgs a, EnvK
         const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;
         Q[gbase + i] = q_s[h * RP_LD + r];
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// warm start / resampling / reset.  One thread per (row, h) of the NEW population.
-//   new row i <  n_new : fresh sample (sample_actions :275-296), moments 0, age 0
-//   new row i >= n_new : keeper idx[i - n_new] (or row i itself when gather == 0): plan shifted
-//                        by shift_previous repeating the last input (:377-379), moments shifted by
-//                        ONE and zero-filled (:465,:501), age kept; then every age += 1 (:514)
-// ---------------------------------------------------------------------------------------------
-struct WarmArgs {
-    int N, H, P, n_new, gather, shift_previous, sampling_distribution, reset;
-    float lo, hi, sample_stdev, sample_mean, sample_min, sample_max;
-    // sharded step (SURVEY 8e): keepers and the best plan come from the all-gathered keeper records
-    // {J, global index, age, Q[H], m[H], v[H]} instead of this handle's own rows
-    const float* recs;     // nullptr: single-handle step
-    int rs;                // record stride (3 + 3H)
-    int keeper_base;       // index (in the global sorted keeper list) of the first keeper this shard hosts
-    int fresh_tail;        // gradient_tf: the shifted-in tail input is a fresh U[lo,hi) draw per plan
-                           // (optimizer_gradient_tf.py:137-144) instead of a repeat of the last input
-};
-
-__global__ __launch_bounds__(256) void ctk_rpgd_warmstart(WarmArgs w, RolloutArgs a, const float* __restrict__ draws,
-                                                          const int* __restrict__ idx, const float* __restrict__ Q_old,
-                                                          const float* __restrict__ m_old, const float* __restrict__ v_old,
-                                                          const float* __restrict__ ages_old, float* __restrict__ Q_new,
-                                                          float* __restrict__ m_new, float* __restrict__ v_new,
-                                                          float* __restrict__ ages_new, const InterpEntry* __restrict__ interp,
-                                                          float* __restrict__ u_nom, float* __restrict__ u_dev,
-                                                          float* __restrict__ u_host, uint32_t seq) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int H = w.H;
-    if (gid < w.N * H) {
-        const int i = gid / H, h = gid - i * H;
-        float q, mm = 0.0f, vv = 0.0f;
-        if (i < w.n_new) {
-            const InterpEntry e = interp[h];
-            float y[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = min(e.i0 + j, w.P - 1);
-                float d;
-                if (draws != nullptr) {
-                    d = draws[(size_t)i * w.P + col];
-                } else {
-                    float d4[4];
-                    draw4(a, (uint32_t)(a.global_row0 + i), (uint32_t)(col >> 2), w.sampling_distribution == 0 ? 1 : 0, d4);
-                    d = d4[col & 3];
-                }
-                const float raw = w.sampling_distribution == 0 ? d * (w.sample_max - w.sample_min) + w.sample_min   // uniform
-                                                                : d * w.sample_stdev + w.sample_mean;                // normal
-                y[j] = fminf(fmaxf(raw, w.lo), w.hi);                                                                // :292
-            }
-            q = y[0] * e.w0 + (e.i0 + 1 < w.P ? y[1] * e.w1 : 0.0f);                                                 // :294
-        } else if (w.gather && w.recs) {
-            const float* rec = w.recs + (size_t)idx[w.keeper_base + i - w.n_new] * w.rs;
-            const int hs = min(h + w.shift_previous, H - 1);
-            q = rec[3 + hs];
-            if (h + 1 < H) { mm = rec[3 + H + h + 1]; vv = rec[3 + 2 * H + h + 1]; }
-        } else {
-            const int src = w.gather ? idx[i - w.n_new] : i;
-            const int hs = min(h + w.shift_previous, H - 1);
-            q = Q_old[(size_t)src * H + hs];
-            if (w.fresh_tail && h + w.shift_previous >= H) {
-                float d;
-                if (draws != nullptr) {
-                    d = draws[i];
-                } else {
-                    float d4[4];
-                    draw4(a, (uint32_t)(a.global_row0 + i), 0u, 1, d4);
-                    d = d4[0];
-                }
-                q = d * (w.hi - w.lo) + w.lo;
-            }
-            if (h + 1 < H) { mm = m_old[(size_t)src * H + h + 1]; vv = v_old[(size_t)src * H + h + 1]; }
+    if (fw.enabled) {   // one workgroup holds the whole population (host guarantees gridDim.x == 1)
+        __threadfence();
+        __syncthreads();                                   // Q, m, v, J of this launch are visible to every thread of the block
+        uint32_t* key_s = reinterpret_cast<uint32_t*>(g_s);   // g_s is dead: [64] keys, then [64] indices
+        int* idx_s = reinterpret_cast<int*>(g_s) + 64;
+        if (t < 64) {
+            const float Jt = t < a.N ? __hip_atomic_load(a.J + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INFINITY;
+            const uint32_t u = __builtin_bit_cast(uint32_t, Jt);
+            key_s[t] = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);   // order-preserving map (ctk_sampled.hip:f32_sortable)
         }
-        Q_new[gid] = q; m_new[gid] = mm; v_new[gid] = vv;
-        if (h == 0) {
-            float age = 0.0f;
-            if (i >= w.n_new) {
-                if (w.gather && w.recs) age = w.recs[(size_t)idx[w.keeper_base + i - w.n_new] * w.rs + 2];
-                else age = ages_old[w.gather ? idx[i - w.n_new] : i];
-            }
-            ages_new[i] = w.reset ? 0.0f : age + 1.0f;
+        __syncthreads();
+        if (t < a.N) {                                      // rank under the total order (J, index): ctk_select_topk
+            const uint32_t ki = key_s[t];
+            int rk = 0;
+            for (int j = 0; j < a.N; ++j) { const uint32_t kj = key_s[j]; rk += (kj < ki) | ((kj == ki) & (j < t)); }
+            if (rk < fw.K) { idx_s[rk] = t; fw.idx_out[rk] = t; }
         }
-    }
-    if (!w.reset && gid < H) {
-        // u_nom = Q_tf[best_idx[0]] BEFORE the warm start (:426)
-        const float q = w.recs ? w.recs[(size_t)idx[0] * w.rs + 3 + gid] : Q_old[(size_t)idx[0] * H + gid];
-        u_nom[gid] = q;
-        if (gid == 0) publish_u(u_dev, u_host, q, seq);   // :523
+        __syncthreads();
+        WarmPtrs p = fw.p;
+        p.idx = idx_s;
+        for (int gid = t; gid < max(fw.w.N * H, H); gid += RP_BLOCK) rpgd_warm_element(fw.w, a, p, gid);
     }
 }
 
-// this shard's best plans with their optimizer state, sorted: {J, global index, age, Q[H], m[H], v[H]}
 __global__ __launch_bounds__(256) void ctk_rpgd_pack_keepers(const float* __restrict__ J, const float* __restrict__ Q,
                                                              const float* __restrict__ m, const float* __restrict__ v,
                                                              const float* __restrict__ ages, const int* __restrict__ idx, int K,
@@ -420,17 +463,26 @@ size_t ctk_rpgd_scratch_floats(int pred, int N, int H) {
 
 hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, float lr, float b1, float b2,
                                    float eps, float clip, float* Q, float* m, float* v, const float* bc_table, int bc_len,
-                                   int t0, int iters, const float* wperm, float* scratch, hipEvent_t e0, hipEvent_t e1, int rule) {
+                                   int t0, int iters, const float* wperm, float* scratch, hipEvent_t e0, hipEvent_t e1, int rule,
+                                   const RpgdFusedWarm* fused) {
     AdamK ad{lr, b1, b2, (float)(1.0 - (double)b1), (float)(1.0 - (double)b2), eps, clip, rule};
     bool tape_in_lds = false;
     const size_t lds = ctk_rpgd_descent_lds(pred, a.H, &tape_in_lds);
     const dim3 grid((a.N + RP_TRAJ - 1) / RP_TRAJ), block(RP_BLOCK);
+    FusedWarm fw{};
+    if (fused && grid.x == 1) {
+        fw.enabled = 1; fw.K = fused->K; fw.idx_out = fused->idx_out;
+        fw.w = WarmArgs{a.N, a.H, fused->P, fused->n_new, fused->gather, fused->shift_previous, fused->sampling_distribution, 0, a.lo, a.hi,
+                        fused->sample_stdev, fused->sample_mean, fused->sample_min, fused->sample_max, nullptr, 3 + 3 * a.H, 0, fused->fresh_tail};
+        fw.p = WarmPtrs{fused->draws, nullptr, Q, m, v, fused->ages_old, fused->Q_new, fused->m_new, fused->v_new, fused->ages_new,
+                        fused->interp, fused->u_nom, fused->u_dev, fused->u_host, fused->seq};
+    }
     if (pred == CTK_PRED_ODE)
         CTK_LAUNCH((ctk_rpgd_descent<CTK_PRED_ODE>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm,
-                   scratch, tape_in_lds ? 1 : 0);
+                   scratch, tape_in_lds ? 1 : 0, fw);
     else
         CTK_LAUNCH((ctk_rpgd_descent<CTK_PRED_MLP>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm,
-                   scratch, 0);
+                   scratch, 0, fw);
     return hipGetLastError();
 }
 
@@ -444,7 +496,7 @@ hipError_t ctk_launch_rpgd_warmstart(hipStream_t st, const RolloutArgs& a, int N
     WarmArgs w{N, H, P, n_new, gather, shift_previous, sampling_distribution, reset, lo, hi, sample_stdev, sample_mean, sample_min, sample_max,
                recs, rs, keeper_base, fresh_tail};
     const int total = N * H;
-    hipLaunchKernelGGL(ctk_rpgd_warmstart, dim3((total + 255) / 256), dim3(256), 0, st, w, a, draws, idx, Q_old, m_old, v_old, ages_old,
-                       Q_new, m_new, v_new, ages_new, interp, u_nom, u_dev, u_host, seq);
+    const WarmPtrs p{draws, idx, Q_old, m_old, v_old, ages_old, Q_new, m_new, v_new, ages_new, interp, u_nom, u_dev, u_host, seq};
+    hipLaunchKernelGGL(ctk_rpgd_warmstart, dim3((total + 255) / 256), dim3(256), 0, st, w, a, p);
     return hipGetLastError();
 }
