@@ -57,6 +57,16 @@ class CostFunctionUpdater:
         except Exception:
             return False                                                # half-written file: keep the old config, retry
         self._stamp = stamp
+        # validate HERE, not in the control loop: an invalid edit (typo, unknown key) keeps the config in force and is
+        # logged, so controller_mpc.step never raises because of a file somebody is editing
+        check = getattr(self.cost_function, "validate_config", None)
+        if check is not None:
+            try:
+                check(section)
+            except ValueError as e:
+                import logging
+                logging.getLogger(__name__).warning("%s: edit ignored, previous cost parameters stay in force (%s)", self.config_path, e)
+                return False
         self.cost_function.config = section
         self.cost_function.reload_cost_parameters_from_config_flag = True
         return True

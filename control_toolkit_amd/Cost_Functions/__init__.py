@@ -95,9 +95,15 @@ class CostFunctionWrapper:
         self.config = dict(self.config or {}, **_checked(kw, "set_parameters"))
         self.reload_cost_parameters_from_config_flag = True
 
+    def validate_config(self, section):
+        """raises ValueError for a section this cost function cannot take (CostFunctionUpdater.poll_now)"""
+        _checked(section, "cost YAML reload")
+
     def reload_cost_parameters_from_config(self):
-        # the reference's cost functions re-read their attributes from self.config here
+        # the reference's cost functions re-read their attributes from self.config here; constructor-supplied
+        # parameters keep their precedence over the file, as at configure()
         self.parameters.update(_checked(self.config or {}, "cost YAML reload"))
+        self.parameters.update(self._explicit)
         self.version += 1
 
     def update_cost_parameters_from_config(self):

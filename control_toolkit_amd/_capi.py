@@ -71,6 +71,8 @@ SYMBOLS = {
     "ctk_predictor_set_hidden": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
     "ctk_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ctk_samples_needed": (C.c_size_t, [_H]),
+    "ctk_rng_get_position": (C.c_int, [_H, C.POINTER(C.c_uint32)]),
+    "ctk_rng_set_position": (C.c_int, [_H, C.c_uint32]),
     "ctk_rollout": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ctk_mppi_partial_size": (C.c_size_t, [_H]),
     "ctk_mppi_step_begin": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -253,6 +255,14 @@ class CtkEngine:
 
     def samples_needed(self) -> int:
         return int(self._lib.ctk_samples_needed(self._h))
+
+    def rng_position(self) -> int:
+        v = C.c_uint32()
+        self._check(self._lib.ctk_rng_get_position(self._h, C.byref(v)))
+        return int(v.value)
+
+    def set_rng_position(self, call: int):
+        self._check(self._lib.ctk_rng_set_position(self._h, int(call) & 0xFFFFFFFF))
 
     def samples_needed_reset(self) -> int:
         """RPGD: raw draws optimizer_reset consumes (N * P)."""

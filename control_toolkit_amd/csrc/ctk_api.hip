@@ -403,7 +403,26 @@ int finish_step(ctk_handle* h, float* u_out) {
     if (u_out) u_out[0] = *reinterpret_cast<volatile float*>(h->h_u);
     ++h->seq;
     ++h->call;
+    // error word behind {u, seq}: a bounded device-side wait ran out (1: a peer's record never arrived,
+    // ctk_mppi.hip:p2p_exchange_and_update; 2: a block record of the in-launch hand-off never arrived) — the published
+    // result is NaN or built from a stale record, never silently wrong
+    volatile uint32_t* errw = reinterpret_cast<volatile uint32_t*>(h->h_u) + 2;
+    if (const uint32_t dev_err = *errw) {
+        *errw = 0;
+        return fail(h, CTK_ERR_STATE, dev_err == 1 ? "timed out waiting for a peer's record (a rank is gone or out of step)"
+                                                   : "in-launch record hand-off timed out (a workgroup's record never arrived)");
+    }
     return h->log_cap ? log_step(h) : CTK_OK;
+}
+
+// Every launch attempt consumes a sequence number: if a step fails between its launch and finish_step, the next
+// launch must not reuse the number (record words of the failed launch already carry it).
+template <class F>
+int guarded(ctk_handle* h, F&& body) {
+    const uint32_t seq0 = h->seq;
+    const int rc = body();
+    if (rc != CTK_OK && h->seq == seq0) ++h->seq;
+    return rc;
 }
 
 int check_predictor(ctk_handle* h) {
@@ -964,8 +983,21 @@ int ctk_predictor_set_hidden(ctk_handle* h, const float* src, size_t n) {
 
 size_t ctk_samples_needed(const ctk_handle* h) { return h ? samples_needed(h) : 0; }
 
+int ctk_rng_get_position(const ctk_handle* h, uint32_t* call) {
+    if (!h || !call) return CTK_ERR_INVALID_ARGUMENT;
+    *call = h->call;
+    return CTK_OK;
+}
+
+int ctk_rng_set_position(ctk_handle* h, uint32_t call) {
+    if (!h) return CTK_ERR_INVALID_ARGUMENT;
+    h->call = call;
+    return CTK_OK;
+}
+
 int ctk_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int samples_loc, float* u_out) {
     if (!h || !s) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_step: NULL state") : CTK_ERR_INVALID_ARGUMENT;
+    return guarded(h, [&]() -> int {
     if (h->mppi_pending) return fail(h, CTK_ERR_STATE, "ctk_step: a sharded step is pending (call ctk_mppi_step_end)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     switch (h->cfg.optimizer) {
@@ -987,6 +1019,7 @@ int ctk_step(ctk_handle* h, const float* s, const float* u_prev, const float* sa
         case CTK_OPT_RPGD: return rpgd_step(h, s, u_prev, samples, samples_loc, u_out);
     }
     return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_step: unknown optimizer");
+    });
 }
 
 size_t ctk_mppi_partial_size(const ctk_handle* h) { return h ? (size_t)(2 + h->P) : 0; }
@@ -994,6 +1027,7 @@ size_t ctk_mppi_partial_size(const ctk_handle* h) { return h ? (size_t)(2 + h->P
 int ctk_mppi_step_begin(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int samples_loc,
                         float* partial_dev) {
     if (!h || !s || !partial_dev) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_mppi_step_begin: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
+    return guarded(h, [&]() -> int {
     if (h->cfg.optimizer != CTK_OPT_MPPI) return fail(h, CTK_ERR_STATE, "ctk_mppi_step_begin: handle is not MPPI");
     if (h->mppi_pending) return fail(h, CTK_ERR_STATE, "ctk_mppi_step_begin: previous sharded step not ended");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -1008,14 +1042,17 @@ int ctk_mppi_step_begin(ctk_handle* h, const float* s, const float* u_prev, cons
     }
     h->mppi_pending = true;
     return CTK_OK;
+    });
 }
 
 int ctk_mppi_step_end(ctk_handle* h, const float* parts_dev, int n_parts, float* u_out) {
     if (!h || !parts_dev || n_parts < 1) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_mppi_step_end: bad argument") : CTK_ERR_INVALID_ARGUMENT;
+    return guarded(h, [&]() -> int {
     if (!h->mppi_pending) return fail(h, CTK_ERR_STATE, "ctk_mppi_step_end: no sharded step pending");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     h->mppi_pending = false;
     return mppi_update(h, parts_dev, n_parts, u_out);
+    });
 }
 
 // ---- sharded CEM / random-action ----------------------------------------------------------------
@@ -1033,6 +1070,7 @@ int ctk_shard_iterations(const ctk_handle* h) {
 
 int ctk_shard_iter_begin(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int samples_loc, float* cand_dev) {
     if (!h || !s || !cand_dev) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_shard_iter_begin: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
+    return guarded(h, [&]() -> int {
     const bool cem = h->cfg.optimizer == CTK_OPT_CEM;
     if (!cem && h->cfg.optimizer != CTK_OPT_RANDOM_ACTION) return fail(h, CTK_ERR_STATE, "ctk_shard_iter_begin: CEM / random-action handles only");
     if (h->variant != h->cfg.optimizer) return fail(h, CTK_ERR_UNSUPPORTED, "ctk_shard_iter_begin: not built for this optimizer variant");
@@ -1051,10 +1089,12 @@ int ctk_shard_iter_begin(ctk_handle* h, const float* s, const float* u_prev, con
     HIP_TRY(h, ctk_launch_pack_candidates(h->stream, h->d_J, h->d_Q, h->d_idx, K, h->H, h->cfg.global_rollout_offset, cand_dev));
     h->shard_pending = true;
     return CTK_OK;
+    });
 }
 
 int ctk_shard_iter_end(ctk_handle* h, const float* cands_all_dev, int n_ranks) {
     if (!h || !cands_all_dev || n_ranks < 1) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_shard_iter_end: bad argument") : CTK_ERR_INVALID_ARGUMENT;
+    return guarded(h, [&]() -> int {
     if (!h->shard_pending) return fail(h, CTK_ERR_STATE, "ctk_shard_iter_end: no iteration pending");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const int K = shard_k(h), rs = 2 + h->H, M = n_ranks * K;
@@ -1073,10 +1113,12 @@ int ctk_shard_iter_end(ctk_handle* h, const float* cands_all_dev, int n_ranks) {
     h->shard_pending = false;
     ++h->shard_it;
     return CTK_OK;
+    });
 }
 
 int ctk_shard_finish(ctk_handle* h, float* u_out) {
     if (!h) return CTK_ERR_INVALID_ARGUMENT;
+    return guarded(h, [&]() -> int {
     if (h->shard_pending || h->shard_it == 0 || !h->shard_last_cands) return fail(h, CTK_ERR_STATE, "ctk_shard_finish: no completed iteration");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const int rs = 2 + h->H;
@@ -1091,6 +1133,7 @@ int ctk_shard_finish(ctk_handle* h, float* u_out) {
     h->shard_it = 0;
     h->shard_last_cands = nullptr;
     return finish_step(h, u_out);
+    });
 }
 
 // ---- sharded RPGD --------------------------------------------------------------------------------
@@ -1114,6 +1157,7 @@ size_t ctk_rpgd_fresh_rows(const ctk_handle* h, int n_ranks) {
 
 int ctk_rpgd_step_begin(ctk_handle* h, const float* s, const float* u_prev, float* keep_dev) {
     if (!h || !s || !keep_dev) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_rpgd_step_begin: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
+    return guarded(h, [&]() -> int {
     if (h->cfg.optimizer != CTK_OPT_RPGD || h->variant != CTK_OPT_RPGD) return fail(h, CTK_ERR_STATE, "ctk_rpgd_step_begin: handle is not RPGD");
     if (!h->rpgd_ready) return fail(h, CTK_ERR_STATE, "RPGD: call ctk_reset (optimizer_reset) before the first step");
     if (h->shard_pending) return fail(h, CTK_ERR_STATE, "ctk_rpgd_step_begin: previous sharded step not ended");
@@ -1129,10 +1173,12 @@ int ctk_rpgd_step_begin(ctk_handle* h, const float* s, const float* u_prev, floa
                                             h->H, h->cfg.global_rollout_offset, keep_dev));
     h->shard_pending = true;
     return CTK_OK;
+    });
 }
 
 int ctk_rpgd_step_end(ctk_handle* h, const float* keep_all_dev, int n_ranks, const float* draws, int draws_loc, float* u_out) {
     if (!h || !keep_all_dev || n_ranks < 1) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_rpgd_step_end: bad argument") : CTK_ERR_INVALID_ARGUMENT;
+    return guarded(h, [&]() -> int {
     if (h->cfg.optimizer != CTK_OPT_RPGD || !h->shard_pending) return fail(h, CTK_ERR_STATE, "ctk_rpgd_step_end: no sharded RPGD step pending");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const ctk_config& c = h->cfg;
@@ -1161,6 +1207,7 @@ int ctk_rpgd_step_end(ctk_handle* h, const float* keep_all_dev, int n_ranks, con
     ++h->count;
     h->shard_pending = false;
     return finish_step(h, u_out);
+    });
 }
 
 int ctk_rollout(ctk_handle* h, const float* s, const float* u_prev, const float* Q, int n, float* traj_out, float* J_out) {
@@ -1378,6 +1425,7 @@ int ctk_p2p_connect(ctk_handle* h, const void* handles) {
 
 int ctk_p2p_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int samples_loc, float* u_out) {
     if (!h || !s) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_p2p_step: NULL state") : CTK_ERR_INVALID_ARGUMENT;
+    return guarded(h, [&]() -> int {
     if (!h->p2p_connected) return fail(h, CTK_ERR_STATE, "ctk_p2p_step: call ctk_p2p_alloc and ctk_p2p_connect first");
     if (h->mppi_pending) return fail(h, CTK_ERR_STATE, "ctk_p2p_step: a begin/end sharded step is pending");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -1406,12 +1454,8 @@ int ctk_p2p_step(ctk_handle* h, const float* s, const float* u_prev, const float
     h->cur = nxt;
     ++h->p2p_seq;
     if (int rc = mppi_advance_hidden(h)) return rc;
-    if (int rc = finish_step(h, u_out)) return rc;
-    if (reinterpret_cast<volatile uint32_t*>(h->h_u)[2] != 0) {
-        reinterpret_cast<volatile uint32_t*>(h->h_u)[2] = 0;
-        return fail(h, CTK_ERR_STATE, "ctk_p2p_step: timed out waiting for a peer's record (a rank is gone or out of step)");
-    }
-    return CTK_OK;
+    return finish_step(h, u_out);   // a peer time-out comes back as CTK_ERR_STATE through the error word
+    });
 }
 
 int ctk_log_enable(ctk_handle* h, size_t capacity_steps) {

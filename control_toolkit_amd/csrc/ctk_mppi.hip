@@ -482,6 +482,7 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
             __syncthreads();                      // col_s / tile are dead: the merge scratch may overwrite them
             const int nb = (int)gridDim.x, tot = nb * (2 + P);
             float* st = merge_stage_ptr(lds, nb, P);
+            bool expired = false;                 // a bounded poll ran out: surfaced to the host through the error word
             constexpr int LLW = 8;                // words in flight per thread: the first pass over a thread's words is
             for (int i0 = t; i0 < tot; i0 += MPPI_BLOCK * LLW) {   // one pipelined batch of loads, not LLW round trips
                 unsigned long long w[LLW];
@@ -498,10 +499,15 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
                             __builtin_amdgcn_s_sleep(1);
                             w[j] = __hip_atomic_load(fz.ll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
-                        st[i] = (uint32_t)(w[j] >> 32) == fz.up.seq ? __builtin_bit_cast(float, (uint32_t)w[j]) : __builtin_nanf("");
+                        const bool got = (uint32_t)(w[j] >> 32) == fz.up.seq;
+                        expired |= !got;
+                        st[i] = got ? __builtin_bit_cast(float, (uint32_t)w[j]) : __builtin_nanf("");
                     }
                 }
             }
+            // ctk_api.hip:finish_step turns a non-zero error word (the dword behind {u, seq}) into CTK_ERR_STATE
+            if (expired && fz.up.u_host)
+                __hip_atomic_store(reinterpret_cast<uint32_t*>(fz.up.u_host) + 2, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __syncthreads();
             const size_t scratch_floats = 8 + P + 1 + min(nb, MERGE_CHUNK) + (size_t)tot;
             if (scratch_floats <= (size_t)(w0_s - lds)) { fz.up.w0_l = w0_s; fz.up.w1_l = w1_s; fz.up.un_l = un_s; fz.up.i0_l = i0_s; }

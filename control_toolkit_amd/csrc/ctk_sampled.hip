@@ -52,12 +52,14 @@ struct BestArgs {
 CTK_DEV void ll_put(unsigned long long* p, uint32_t payload, uint32_t seq) {
     __hip_atomic_store(p, ((unsigned long long)seq << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-CTK_DEV uint32_t ll_get(const unsigned long long* p, uint32_t seq) {
+// *expired is raised when the bounded poll runs out (the payload is then stale: the caller reports it, see below)
+CTK_DEV uint32_t ll_get(const unsigned long long* p, uint32_t seq, bool* expired) {
     unsigned long long w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int spin = 0; (uint32_t)(w >> 32) != seq && spin < (1 << 22); ++spin) {
         __builtin_amdgcn_s_sleep(1);
         w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if ((uint32_t)(w >> 32) != seq) *expired = true;
     return (uint32_t)w;
 }
 
@@ -165,11 +167,14 @@ __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(const float* __
                 }
                 if (blockIdx.x == 0) {              // every block finishes unconditionally: the polls terminate (and are bounded)
                     uint32_t bk = 0xFFFFFFFFu, bi = 0x7FFFFFFFu, bu = 0;
+                    bool expired = false;
                     for (int b = lane; b < (int)gridDim.x; b += 64) {
-                        const uint32_t kb = ll_get(best.ll + (size_t)b * 3, best.seq), ib = ll_get(best.ll + (size_t)b * 3 + 1, best.seq);
-                        const uint32_t ub = ll_get(best.ll + (size_t)b * 3 + 2, best.seq);
+                        const uint32_t kb = ll_get(best.ll + (size_t)b * 3, best.seq, &expired), ib = ll_get(best.ll + (size_t)b * 3 + 1, best.seq, &expired);
+                        const uint32_t ub = ll_get(best.ll + (size_t)b * 3 + 2, best.seq, &expired);
                         if (kb < bk || (kb == bk && ib < bi)) { bk = kb; bi = ib; bu = ub; }
                     }
+                    // a stale record may have won or lost wrongly: tell the host (ctk_api.hip:finish_step -> CTK_ERR_STATE)
+                    if (expired) __hip_atomic_store(reinterpret_cast<uint32_t*>(best.u_host) + 2, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     const uint32_t gk = wave_min_u32(bk);
                     const uint32_t gi = wave_min_u32(bk == gk ? bi : 0x7FFFFFFFu);
                     if (bk == gk && bi == gi) {     // exactly one lane holds the winner

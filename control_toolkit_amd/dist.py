@@ -11,6 +11,32 @@ from __future__ import annotations
 import numpy as np
 
 
+def _bind_stream(engine, torch, device):
+    """The collective runs on torch's current stream of `device`; the engine's begin/end kernels read and write
+    the exchanged records, so they must be ordered with it: put the engine on the same stream (include/ctk_hip.h:
+    ctk_set_stream).  CPU tensors (gloo tests with a stand-in engine): nothing to order."""
+    if device is not None and getattr(device, "type", "cpu") == "cuda" and hasattr(engine, "set_stream"):
+        engine.set_stream(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _EngineSnapshot:
+    """Everything a step changes, for the p2p self-test's rollback: the warm-start state (ctk_get_state), the
+    recurrent predictor's carried hidden state and the Philox position."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.state = engine.get_state()
+        self.hidden = engine.predictor_get_hidden() if getattr(engine, "predictor_hidden_size", lambda: 0)() else None
+        self.call = engine.rng_position() if hasattr(engine, "rng_position") else None
+
+    def restore(self):
+        self.engine.set_state(self.state)
+        if self.hidden is not None:
+            self.engine.predictor_set_hidden(self.hidden)
+        if self.call is not None:
+            self.engine.set_rng_position(self.call)
+
+
 class ShardedMPPI:
     """exchange = "rccl": ctk_mppi_step_begin -> all_gather_into_tensor -> ctk_mppi_step_end.
     exchange = "p2p" : the ranks' exchange kernels store their records straight into each other's HBM over xGMI
@@ -33,6 +59,7 @@ class ShardedMPPI:
         self.all = torch.zeros(self.rec * world_size, dtype=torch.float32, device=self.device)
         self.exchange = "rccl"
         self.p2p_error = None
+        _bind_stream(engine, torch, self.device)
         if exchange == "p2p" and world_size > 1:
             self._try_p2p(device)
         elif exchange not in ("rccl", "p2p"):
@@ -63,8 +90,8 @@ class ShardedMPPI:
         if ok:
             # self-test: two exchange steps (both parities) must complete on every rank and reproduce the plan of
             # the RCCL path.  Every rank runs the same sequence of collectives whatever happens locally.
-            state = self.engine.get_state()
-            s0 = np.zeros(4, np.float32)
+            snap = _EngineSnapshot(self.engine)
+            s0 = np.zeros(int(getattr(self.engine, "S", 4)), np.float32)
             # explicit draws (the device sampler advances with every step, the two paths would see different noise)
             noise = np.random.default_rng(1234 + self.rank).standard_normal(self.engine.samples_needed()).astype(np.float32)
             u_p2p = plan_p2p = None
@@ -76,14 +103,14 @@ class ShardedMPPI:
             except Exception as e:   # noqa: BLE001
                 ok, self.p2p_error = False, f"self-test: {e}"
             ok = self._all_ok(ok, device)
-            self.engine.set_state(state)
+            snap.restore()
             if ok:
                 for _ in range(self.SELF_TEST_STEPS):       # exchange == "rccl" here
                     u_rccl = self.step(s0, noise)
                 if not (np.allclose(u_p2p, u_rccl, rtol=1e-4, atol=2e-5)
                         and np.allclose(plan_p2p, self.engine.read("U_NOM"), rtol=1e-4, atol=2e-5)):
                     ok, self.p2p_error = False, "self-test: p2p and rccl plans differ"
-                self.engine.set_state(state)
+                snap.restore()
                 ok = self._all_ok(ok, device)
         self.exchange = "p2p" if ok else "rccl"
         if not ok:
@@ -119,6 +146,7 @@ class ShardedTopK:
         self.engine, self.rank, self.world_size, self.group = engine, rank, world_size, group
         self.rec = int(engine.shard_candidates_size())
         self.device = device if device is not None else torch.device("cpu")
+        _bind_stream(engine, torch, self.device)
         self.mine = torch.zeros(self.rec, dtype=torch.float32, device=self.device)
         self.all = torch.zeros(self.rec * world_size, dtype=torch.float32, device=self.device)
 
@@ -149,6 +177,7 @@ class ShardedRPGD:
         self.engine, self.rank, self.world_size, self.group = engine, rank, world_size, group
         self.rec = int(engine.rpgd_keepers_size())
         self.device = device if device is not None else torch.device("cpu")
+        _bind_stream(engine, torch, self.device)
         self.mine = torch.zeros(self.rec, dtype=torch.float32, device=self.device)
         self.all = torch.zeros(self.rec * world_size, dtype=torch.float32, device=self.device)
 

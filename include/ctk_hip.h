@@ -13,7 +13,10 @@
  * Every function that returns int returns 0 on success and a ctk_status otherwise;
  * ctk_last_error() gives the message.  A handle is NOT thread-safe (the reference caller is a
  * single-threaded loop, controller_server/controller_server.py:55-86); all work of a handle
- * is issued on one HIP stream.  The library never falls back to a CPU path: without a usable
+ * is issued on one HIP stream.  Device pointers handed to the begin/end entry points (records that a
+ * collective fills or reads) are accessed on THAT stream: a caller that runs the collective on another
+ * stream must first ctk_set_stream() the handle onto it (control_toolkit_amd/dist.py does), or order the
+ * two streams with events.  The library never falls back to a CPU path: without a usable
  * gfx950 device ctk_create() fails.
  */
 #ifndef CTK_HIP_H
@@ -198,6 +201,13 @@ int ctk_step(ctk_handle* h, const float* s, const float* u_prev,
 
 /* Number of raw draws (floats) the NEXT ctk_step consumes from `samples` (0 if none).        */
 size_t ctk_samples_needed(const ctk_handle* h);
+
+/* Position of the on-device Philox stream = the number of completed steps/resets that drew (the `call` word of
+ * the counter).  Together with ctk_get_state (and ctk_predictor_get_hidden for a recurrent predictor) it makes a
+ * handle resumable bit-for-bit: reference create_rng(seed) returns a generator object whose state the caller can
+ * save and restore (others/globals_and_utils.py:86-99).                                                          */
+int ctk_rng_get_position(const ctk_handle* h, uint32_t* call);
+int ctk_rng_set_position(ctk_handle* h, uint32_t call);
 
 /* predictor.predict_core(s, Q) + cost_function.get_trajectory_cost(traj, Q, u_prev)
  * (call sites optimizer_mppi.py:188,199-202; Cost_Functions/__init__.py:74-93) for n <= N
