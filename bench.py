@@ -1,20 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the hot path on MI355X.
 
-Metric (BASELINE.json): trajectory-steps/sec = N*H / wall(controller.step).  Default workload =
-BASELINE configs[1]: MPPI, N=1024, H=50, 4-state analytic cart-pole; one "step" = one full MPPI
-iteration (sample buffer resident in HBM -> fused rollout+cost -> soft-min merge/update -> u back on
-the host), timed at the optimizer.step boundary, closed loop against a host plant step.
+Metric (BASELINE.json): trajectory-steps/sec = N*H / wall(controller.step).  One "step" = one call of
+`controller_mpc.step(s)` (reference Controllers/controller_mpc.py:99-106) -> `optimizer.step` -> ONE pass of the hot
+path over one batch of synthetic input, closed loop against a host plant step, logging off.
 
-  python bench.py --gpus 1 --steps 200 --warmup 20
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus 1 --steps 200 --warmup 20            # BASELINE configs[1]: MPPI N=1024, H=50, cart-pole ODE
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node G --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus G --steps K --warmup W   # BASELINE configs[4]: MPPI N=65536 (global), H=100, MLP
 
-N > 1: weak scaling — every rank rolls out its own shard (global population = N_local * ranks), one
-all-gather of the (2+P)-float soft-min record per step over RCCL (control_toolkit_amd/dist.py).
-Other BASELINE configs are parity-test cases; `--workload` times them too (not the headline line).
+What the ONE JSON line holds:
+  value / ms_per_step   the timed region: K calls at the boundary named in config.boundary, samples as in config.samples
+  modes                 the same K-step protocol repeated (outside the timed region) for the other three combinations of
+                        boundary in {controller_mpc.step, engine (ctypes ctk_step)} x samples in {buffer, device-rng}:
+                        "buffer" = [N,P,C] N(0,1) draws resident in HBM before the region starts (a pool of 16);
+                        "device-rng" = drawn inside the step by the in-kernel Philox sampler, as the reference samples
+                        inside step() (optimizer_mppi.py:173-175)
+  roofline              dominant kernel, timed by its dispatch timestamps in a SEPARATE pass after the timed region
+  cpu_baseline          the oracle on this box's host cores (bounded sample)
+
+G > 1: strong scaling of BASELINE configs[4] — N = 65536 rollouts split over the ranks, one RCCL all-gather of the
+(2+P)-float soft-min record per step (control_toolkit_amd/dist.py).  Other BASELINE configs are parity-test cases;
+`--workload` times them too (not the headline line).
 """
 import argparse
+import glob
+import hashlib
 import json
 import math
 import os
@@ -29,29 +40,28 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA = fp32 vector rate (spec)
 
+RPGD_KW = dict(outer_its=20, resamp_per=10, shift_previous=1, sampling_distribution=0, sample_min=-1.0, sample_max=1.0,
+               learning_rate=0.05, gradmax_clip=5.0)
 WORKLOADS = {
-    # name: dict(optimizer, predictor, N, H, period, engine kwargs, rollouts per step fwd/bwd)
+    # name: optimizer, predictor, N (GLOBAL rollouts), H, interpolation period, engine kwargs
     "mppi_cfg2": dict(opt="mppi", pred="ODE", N=1024, H=50, p=1, kw={}),
     "mppi_cfg2_interp": dict(opt="mppi", pred="ODE", N=1024, H=50, p=10, kw={}),
     "cem_cfg3": dict(opt="cem", pred="ODE", N=4096, H=30, p=1,
                      kw=dict(cem_outer_it=3, cem_best_k=409, cem_initial_action_stdev=0.5, cem_stdev_min=0.01)),
-    "rpgd_cfg4": dict(opt="rpgd", pred="MLP", N=256, H=50, p=10,
-                      kw=dict(outer_its=20, resamp_per=10, shift_previous=1, opt_keep_k=64, sampling_distribution=0,
-                              sample_min=-1.0, sample_max=1.0, learning_rate=0.05, gradmax_clip=5.0)),
-    "mppi_cfg5_shard": dict(opt="mppi", pred="MLP", N=8192, H=100, p=10, kw={}),
-    # recurrent predictor (2x32 GRU, weights in LDS) at the headline MPPI size
+    "rpgd_cfg4": dict(opt="rpgd", pred="MLP", N=256, H=50, p=10, kw=dict(RPGD_KW, opt_keep_k=64)),
+    # BASELINE configs[4]: the sharded configuration (strong scaling: N is split over the ranks)
+    "mppi_cfg5": dict(opt="mppi", pred="MLP", N=65536, H=100, p=10, kw={}),
+    "mppi_cfg5_shard": dict(opt="mppi", pred="MLP", N=8192, H=100, p=10, kw={}),   # one rank's share at G = 8
+    # recurrent predictor (2x32 GRU) at the headline MPPI size
     "mppi_gru": dict(opt="mppi", pred="GRU", N=1024, H=50, p=1, kw={}),
     "mppi_mlp": dict(opt="mppi", pred="MLP", N=1024, H=50, p=1, kw={}),
     # the reference's own default problem sizes (Control_Toolkit_ASF_Template/config_optimizers.yml)
     "mppi_default": dict(opt="mppi", pred="ODE", N=3500, H=35, p=10, kw={}),
     "cem_default": dict(opt="cem", pred="ODE", N=200, H=40, p=1,
                         kw=dict(cem_outer_it=3, cem_best_k=40, cem_initial_action_stdev=0.5, cem_stdev_min=0.01)),
-    "rpgd_default": dict(opt="rpgd", pred="ODE", N=32, H=40, p=10,
-                         kw=dict(outer_its=2, resamp_per=10, shift_previous=1, opt_keep_k=8, sampling_distribution=0,
-                                 sample_min=-1.0, sample_max=1.0, learning_rate=0.05, gradmax_clip=5.0)),
+    "rpgd_default": dict(opt="rpgd", pred="ODE", N=32, H=40, p=10, kw=dict(RPGD_KW, outer_its=2, opt_keep_k=8)),
     "random_default": dict(opt="random_action", pred="ODE", N=320, H=35, p=1, kw={}),
 }
-
 
 _G, _MC, _MP, _L, _UMAX, _MF, _JF = 9.81, 0.230, 0.087, 0.1975, 2.62, 4.77, 2.5e-4
 _INV_MT = 1.0 / (_MC + _MP)
@@ -89,9 +99,9 @@ def gru_weights(seed=0):
     return np.concatenate([a.ravel() for a in parts]).astype(np.float32)
 
 
-def algorithmic(w, P, samples_in_hbm):
-    """compulsory bytes (and MLP flops) of the DOMINANT kernel's launch."""
-    N, H, C, S = w["N"], w["H"], 1, 4
+def algorithmic(w, N, P, samples_in_hbm):
+    """compulsory bytes (and network flops) of ONE launch of the dominant kernel over N rollouts."""
+    H, C, S = w["H"], 1, 4
     flops = None
     if w["opt"] == "mppi":
         b = (4 * N * P * C if samples_in_hbm else 0) + 4 * N + 8 * H * C + 4 * S
@@ -108,10 +118,13 @@ def algorithmic(w, P, samples_in_hbm):
         if w["pred"] == "MLP":
             flops = 2624 * N * H * (2 * its + 1)
     else:
-        b = 4 * N * H * C + 4 * N
+        b = (4 * N * H * C if samples_in_hbm else 0) + 4 * N
     return b, flops
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baselines (the oracle = checker, timed here as the reported CPU port; never part of the product path)
+# ------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(w, budget_s=12.0):
     """The oracle (NumPy fp32 restatement of the reference's batched-tensor path) timed on the host
     cores of this box, on a bounded sample of the same workload."""
@@ -180,6 +193,48 @@ def cpu_baseline_torch(w, budget_s=4.0):
                       f"{t.threads} threads), {el:.1f} s"}
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# HBM traffic of the dominant kernel: read from the newest profiles/*traffic*.json that was taken from THESE sources
+# ------------------------------------------------------------------------------------------------------------------
+KERNEL_SOURCES = ("ctk_mppi.hip", "ctk_rollout.h", "ctk_device.h", "ctk_common.h", "ctk_mlp.h", "ctk_gru.h", "Makefile")
+
+
+def kernel_source_digest():
+    """sha256 over the sources the MPPI rollout kernel is compiled from (the GPU box has no .git: a content hash, not a
+    commit id, is what can be checked there)."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        path = os.path.join(ROOT, "control_toolkit_amd", "csrc", name)
+        if os.path.exists(path):
+            h.update(name.encode()); h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
+def recorded_traffic(workload, samples, kernel):
+    """(bytes per launch or None, note).  A record is used only if it names this workload / sample mode / kernel AND the
+    kernel sources have not changed since it was taken (tools/pmc_traffic.py writes the digest) — otherwise null."""
+    digest = kernel_source_digest()
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True)
+    stale = None
+    for path in cands:
+        try:
+            rec = json.load(open(path))
+        except Exception:   # noqa: BLE001
+            continue
+        if rec.get("workload") != workload or rec.get("samples") != samples or rec.get("kernel") != kernel:
+            continue
+        if rec.get("source_sha256") != digest:
+            stale = stale or os.path.basename(path)
+            continue
+        return rec.get("traffic_bytes_per_launch"), (f"{os.path.basename(path)} (commit {rec.get('commit', '?')}, kernel sources unchanged since): "
+                                                      f"2 x FETCH_SIZE {rec.get('fetch_size_kib')} KiB + WRITE_SIZE {rec.get('write_size_kib')} KiB per launch, "
+                                                      "separate rocprofv3 --pmc passes, the guide's gfx950 factor 2 on FETCH_SIZE")
+    if stale:
+        return None, f"no valid record: {stale} was taken from older kernel sources (re-run tools/pmc_traffic.py)"
+    return None, "no PMC record for this workload / sample mode under profiles/"
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def large_n_point(torch, CtkEngine, dev, H, p, N=1 << 20, steps=12):
     """The same MPPI step at N = 2^20 (outside the timed region, not part of `value`): where the path sits against
     the HBM roofline once the chip is full.  BASELINE's size occupies 16 of 256 CUs, so its own fraction says
@@ -200,8 +255,42 @@ def large_n_point(torch, CtkEngine, dev, H, p, N=1 << 20, steps=12):
     ach = alg / (k_ms * 1e-3) / 1e9
     return {"N": N, "kernel": name, "kernel_us": k_ms * 1e3, "bound": "valu", "achieved": ach, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "trajectory_steps_per_s_kernel": N * H / (k_ms * 1e-3),
-            "note": "VALU-bound before it is HBM-bound: ~60 fp32 instructions incl. sin/cos per 4 compulsory bytes; PMC: VALU "
-                    "utilisation 76 % at this size (profiles/r01_mppi_largeN_pmc.txt)"}
+            "note": "VALU-bound before it is HBM-bound (DESIGN.md 5: instructions per trajectory-step vs 4 compulsory bytes)"}
+
+
+def build_controller(w, N_local, local_rank, rank, rng_mode):
+    """controller_mpc around `<optimizer>-hip` exactly as a reference caller would build it
+    (Controllers/controller_mpc.py:24-96; tests/test_gpu_controller.py does the same against the golden closed loop)."""
+    from control_toolkit_amd.Controllers.controller_mpc import controller_mpc
+    from control_toolkit_amd.Predictors import PredictorWrapper
+    from control_toolkit_amd.Cost_Functions import CostFunctionWrapper
+    name = {"mppi": "mppi-hip", "cem": "cem-hip", "rpgd": "rpgd-hip", "random_action": "random-action-hip"}[w["opt"]]
+    H, p, kw = w["H"], w["p"], w["kw"]
+    common = dict(seed=1, mpc_horizon=H, num_rollouts=N_local, mpc_timestep=0.02, rng_mode=rng_mode, device=local_rank)
+    if w["opt"] == "mppi":
+        oc = dict(common, cc_weight=1.0, R=1.0, LBD=100.0, NU=1000.0, SQRTRHOINV=0.03, period_interpolation_inducing_points=p,
+                  global_rollout_offset=rank * N_local)
+    elif w["opt"] == "cem":
+        oc = dict(common, cem_outer_it=kw["cem_outer_it"], cem_initial_action_stdev=kw["cem_initial_action_stdev"],
+                  cem_stdev_min=kw["cem_stdev_min"], cem_best_k=kw["cem_best_k"], warmup=False, warmup_iterations=0)
+    elif w["opt"] == "rpgd":
+        oc = dict(common, outer_its=kw["outer_its"], sample_stdev=0.5, sample_mean=0.0, sample_whole_control_space=True,
+                  uniform_dist_min=-1.0, uniform_dist_max=1.0, resamp_per=kw["resamp_per"], period_interpolation_inducing_points=p,
+                  SAMPLING_DISTRIBUTION="uniform", shift_previous=kw["shift_previous"], warmup=False, warmup_iterations=0,
+                  learning_rate=kw["learning_rate"], opt_keep_k_ratio=kw["opt_keep_k"] / N_local, gradmax_clip=kw["gradmax_clip"],
+                  rtol=1e-3, adam_beta_1=0.9, adam_beta_2=0.999, adam_epsilon=1e-8)
+    else:
+        oc = dict(common)
+    weights = mlp_weights(0) if w["pred"] == "MLP" else gru_weights(0) if w["pred"] == "GRU" else None
+    cc = {"mpc": {"optimizer": name, "predictor_specification": w["pred"], "cost_function_specification": "default",
+                  "computation_library": "hip", "controller_logging": False, "calculate_optimal_trajectory": False,
+                  "device": f"gpu:{local_rank}"}}
+    c = controller_mpc("CartPole", (np.array([-1.0], np.float32), np.array([1.0], np.float32)),
+                       {"target_position": 0.0, "target_equilibrium": 1.0}, config_controllers=cc,
+                       config_optimizers={name: oc}, predictor=PredictorWrapper(weights=weights),
+                       cost_function=CostFunctionWrapper(watch=False))
+    c.configure()
+    return c
 
 
 def main():
@@ -209,11 +298,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="mppi_cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: mppi_cfg2 (BASELINE configs[1]) on one GPU, mppi_cfg5 (configs[4], N split over the ranks) on several")
     ap.add_argument("--samples", default="buffer", choices=["buffer", "device-rng"],
-                    help="MPPI: [N,P,C] N(0,1) sample buffers resident in HBM (north_star) or the in-kernel Philox sampler")
+                    help="sample mode of the TIMED region (both are reported): buffers resident in HBM, or the in-kernel Philox sampler")
+    ap.add_argument("--boundary", default="controller", choices=["controller", "engine"],
+                    help="boundary of the TIMED region (both are reported): controller_mpc.step or the ctypes engine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-n", action="store_true", help="skip the scaled-N roofline point (same kernel family, N = 2^20)")
+    ap.add_argument("--no-modes", action="store_true", help="skip the three extra boundary x samples passes")
     ap.add_argument("--force-sharded", action="store_true", help="use the begin / all-gather / end path even with one rank")
     args = ap.parse_args()
 
@@ -226,7 +319,8 @@ def main():
     import torch
     import torch.distributed as dist
     from control_toolkit_amd import CtkEngine
-    from control_toolkit_amd.dist import ShardedMPPI
+    from control_toolkit_amd.dist import ShardedMPPI, ShardedTopK, ShardedRPGD
+    from control_toolkit_amd.others.globals_and_utils import DeviceBufferRng, DeviceRng
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -240,130 +334,211 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # rehearsal hook: a ONE-rank RCCL group with the collective actually issued, to exercise the RCCL call path
-    # (init, all_gather_into_tensor / all_reduce / barrier on torch's stream) on a one-GPU box
     force_pg = os.environ.get("CTK_BENCH_FORCE_PG") == "1"
-    if world > 1 or force_pg:
+    use_pg = world > 1 or force_pg
+    if use_pg:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    w = WORKLOADS[args.workload]
-    if world > 1 and w["opt"] != "mppi":
-        raise SystemExit("only the MPPI workloads are sharded (DESIGN.md 6)")
-    N, H, p = w["N"], w["H"], w["p"]
-    eng = CtkEngine(w["opt"], w["pred"], num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p,
-                    seed=1, device=local_rank, global_rollout_offset=rank * N, **w["kw"])
-    if w["pred"] == "MLP":
-        eng.set_predictor_weights(mlp_weights(0))
-    elif w["pred"] == "GRU":
-        eng.set_predictor_weights(gru_weights(0))
+    wname = args.workload or ("mppi_cfg2" if world == 1 else "mppi_cfg5")
+    w = WORKLOADS[wname]
+    Ng, H, p = w["N"], w["H"], w["p"]
+    if Ng % world:
+        raise SystemExit(f"{wname}: {Ng} rollouts do not split evenly over {world} ranks")
+    N = Ng // world                                          # strong scaling: this rank's shard
+    sharded_run = world > 1 or args.force_sharded or force_pg
+    if sharded_run and w["opt"] == "rpgd" and w["kw"]["opt_keep_k"] > Ng:
+        raise SystemExit("opt_keep_k exceeds the population")
+
+    # ---- the product objects: controller_mpc (+ its engine) for the single-GPU boundary, Sharded* for G > 1 -------
+    ekw = dict(w["kw"])
+    ctrl = None
+    if not sharded_run:
+        ctrl = build_controller(w, N, local_rank, rank, "device")
+        eng = ctrl.optimizer.engine
+    else:
+        eng = CtkEngine(w["opt"], w["pred"], num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p,
+                        seed=1, device=local_rank, global_rollout_offset=rank * N, **ekw)
+        if w["pred"] == "MLP":
+            eng.set_predictor_weights(mlp_weights(0))
+        elif w["pred"] == "GRU":
+            eng.set_predictor_weights(gru_weights(0))
     P = eng.mppi_partial_size() - 2
-    sharded = None
-    if world > 1 or args.force_sharded or force_pg:
-        # the collective runs on torch's stream: issue the engine's kernels there too
-        eng.set_stream(torch.cuda.current_stream().cuda_stream)
-        # record exchange between the ranks: direct peer-to-peer stores over xGMI (falls back to the RCCL all-gather,
-        # collectively, if the IPC set-up or its self-test fails on any rank); CTK_BENCH_EXCHANGE=rccl forces RCCL
-        sharded = ShardedMPPI(eng, rank, world, device=dev, always_collective=force_pg,
-                              exchange=os.environ.get("CTK_BENCH_EXCHANGE", "p2p"))
-        if rank == 0 and sharded.p2p_error:
-            print(f"[bench] p2p exchange unavailable ({sharded.p2p_error}); using the RCCL all-gather", file=sys.stderr)
+    sharded, exchange_note = None, "single GPU"
+    if sharded_run:
+        if w["opt"] == "mppi":
+            want = os.environ.get("CTK_BENCH_EXCHANGE", "rccl")   # headline: the RCCL all-gather north_star names; p2p is opt-in
+            sharded = ShardedMPPI(eng, rank, world, device=dev, always_collective=force_pg, exchange=want)
+            if want == "p2p" and sharded.exchange != "p2p":
+                exchange_note = (f"rollout shards x{world}, 1 all-gather of {P + 2} floats per step (RCCL) — peer-to-peer exchange was "
+                                 f"requested but unavailable ({sharded.p2p_error}); fell back collectively")
+            elif sharded.exchange == "p2p":
+                exchange_note = f"rollout shards x{world}, records of {P + 2} floats exchanged by peer-to-peer stores over xGMI (opt-in)"
+            else:
+                exchange_note = f"rollout shards x{world}, 1 all-gather of {P + 2} floats per step (RCCL)"
+        elif w["opt"] in ("cem", "random_action"):
+            sharded = ShardedTopK(eng, rank, world, device=dev)
+            exchange_note = f"rollout shards x{world}, 1 all-gather of {sharded.rec} floats (best-K records) per outer iteration (RCCL)"
+        else:
+            eng.reset()
+            sharded = ShardedRPGD(eng, rank, world, device=dev)
+            exchange_note = f"rollout shards x{world}, 1 all-gather of {sharded.rec} floats (keeper records) per step (RCCL)"
+
+    # synthetic inputs, resident in HBM before any timed region: a pool of sample buffers
+    need = max(int(eng.samples_needed()), N * max(P, H), 1)
     if w["opt"] == "rpgd":
-        eng.reset()
-
-    # synthetic inputs, resident in HBM before the timed region: a pool of sample buffers (MPPI)
-    pool = None
-    samples_in_hbm = w["opt"] == "mppi" and args.samples == "buffer"
-    if samples_in_hbm:
-        g = torch.Generator(device=dev); g.manual_seed(1 + rank)
-        pool = [torch.randn((N, P, 1), generator=g, device=dev, dtype=torch.float32) for _ in range(16)]
-        ptrs = [t.data_ptr() for t in pool]
+        need = max(need, N * P)
+    g = torch.Generator(device=dev); g.manual_seed(1 + rank)
+    uniform = w["opt"] in ("random_action", "rpgd")
+    pool = [(torch.rand if uniform else torch.randn)((need,), generator=g, device=dev, dtype=torch.float32) for _ in range(16)]
+    ptrs = [t.data_ptr() for t in pool]
     rng0 = np.random.default_rng(0)
-    s = np.array([rng0.uniform(-0.2, 0.2), rng0.uniform(-0.5, 0.5), rng0.uniform(-np.pi, np.pi), rng0.uniform(-2, 2)], np.float32)
+    s0 = np.array([rng0.uniform(-0.2, 0.2), rng0.uniform(-0.5, 0.5), rng0.uniform(-np.pi, np.pi), rng0.uniform(-2, 2)], np.float32)
 
-    step_fn = sharded.step if sharded is not None else eng.step
-    if pool is None:
-        ptrs = [None] * 16
+    def make_step(boundary, samples):
+        """a callable s -> u for one boundary x sample-mode combination"""
+        if sharded is not None:
+            if w["opt"] == "rpgd":
+                return lambda s, i: sharded.step(s, None)          # fresh rows by device Philox (global row index)
+            if samples == "buffer" and w["opt"] == "mppi":
+                return lambda s, i: sharded.step(s, ptrs[i & 15])
+            return lambda s, i: sharded.step(s, None)
+        if boundary == "controller":
+            ctrl.optimizer.rng = DeviceBufferRng(ptrs, seed=1) if samples == "buffer" else DeviceRng(1)
+            return lambda s, i: ctrl.step(s)
+        if w["opt"] == "rpgd":                                     # the engine decides when it needs draws
+            return (lambda s, i: eng.step(s, ptrs[i & 15] if eng.samples_needed() else None)) if samples == "buffer" else (lambda s, i: eng.step(s, None))
+        return (lambda s, i: eng.step(s, ptrs[i & 15])) if samples == "buffer" else (lambda s, i: eng.step(s, None))
 
-    for i in range(args.warmup):
-        plant_step(s, step_fn(s, ptrs[i & 15])[0])
-    # dispatch-timestamp timing of the dominant kernel on a sparse sample of the timed launches: timing a
-    # launch costs ~8 us of host time (measured), so timing all of them would distort the metric
-    prof_every = 1 if args.steps < 40 else 16
-    eng.profile_enable(True, every=prof_every)
-    if world > 1 or force_pg:
-        dist.barrier()
-    torch.cuda.synchronize()
-    per_step = np.empty(args.steps)
-    t0 = time.perf_counter()
-    ta = t0
-    for i in range(args.steps):
-        plant_step(s, step_fn(s, ptrs[i & 15])[0])        # controller.step, then the plant: closed loop
-        tb = time.perf_counter(); per_step[i] = tb - ta; ta = tb
-    torch.cuda.synchronize()
-    if world > 1 or force_pg:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    def run_region(step_fn, steps, warmup, timed_region):
+        """W warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+        s = s0.copy()
+        for i in range(warmup):
+            plant_step(s, np.asarray(step_fn(s, i)).reshape(-1)[0])
+        if use_pg:
+            dist.barrier()
+        torch.cuda.synchronize()
+        per_step = np.empty(steps)
+        t0 = time.perf_counter(); ta = t0
+        for i in range(steps):
+            plant_step(s, np.asarray(step_fn(s, i)).reshape(-1)[0])   # controller.step, then the plant: closed loop
+            tb = time.perf_counter(); per_step[i] = tb - ta; ta = tb
+        torch.cuda.synchronize()
+        if use_pg:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if use_pg:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, per_step
+
+    boundary = "sharded" if sharded is not None else args.boundary
+    samples = args.samples
+    elapsed, per_step = run_region(make_step(boundary, samples), args.steps, args.warmup, True)
+
+    # ---- the other boundary x sample-mode combinations, same protocol, outside the timed region ------------------
+    modes = {}
+    if sharded is None and not args.no_modes:
+        for b in ("controller", "engine"):
+            for sm in ("buffer", "device-rng"):
+                if (b, sm) == (boundary, samples):
+                    el, ps = elapsed, per_step
+                else:
+                    el, ps = run_region(make_step(b, sm), args.steps, min(args.warmup, 5), False)
+                modes[f"{'controller_mpc.step' if b == 'controller' else 'engine.step'}/{sm}"] = {
+                    "value": Ng * H * args.steps / el, "ms_per_step": el / args.steps * 1e3, "step_ms_median": float(np.median(ps) * 1e3)}
+
+    # ---- dominant-kernel time: a separate pass with every launch timed through its dispatch timestamps (timing a
+    #      launch costs host time, so it stays out of the timed region) --------------------------------------------
+    kstep = make_step("sharded" if sharded is not None else "engine", samples)
+    kpass = max(8, min(64, args.steps))
+    s = s0.copy()
+    eng.profile_enable(True, every=1)
+    for i in range(kpass):
+        plant_step(s, np.asarray(kstep(s, i)).reshape(-1)[0])
     kern_ms = eng.profile_read()
     eng.profile_enable(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1 or force_pg:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
     if rank == 0:
-        total_units = N * H * world * args.steps
+        total_units = Ng * H * args.steps
         kms = float(np.mean(kern_ms)) if len(kern_ms) else float("nan")
-        alg_bytes, alg_flops = algorithmic(w, P, samples_in_hbm)
+        samples_in_hbm = samples == "buffer" and w["opt"] in ("mppi", "cem", "random_action")
+        alg_bytes, alg_flops = algorithmic(w, N, P, samples_in_hbm)
         ok = kms == kms and kms > 0
+        kname = eng.dominant_kernel()
         if alg_flops is not None:
             ach = alg_flops / (kms * 1e-3) / 1e12 if ok else None
             roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                     "frac": ach / MFMA_F32_PEAK_TF if ach else None, "traffic": None, "algorithmic_flops": alg_flops,
-                    "note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32) for exact-fp32 parity; "
-                            + ("16 trajectories per workgroup, the GRU step split over its 4 waves (ctk_gru.h); latency-bound: "
-                               "64 workgroups on 256 CUs at this size" if w["pred"] == "GRU" else "16 trajectories per wave")}
+                    "note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32) for exact-fp32 parity; per launch of this rank's shard"}
         else:
             ach = alg_bytes / (kms * 1e-3) / 1e9 if ok else None
+            traffic, tnote = recorded_traffic(wname, samples, kname)
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS if ach else None,
-                    "traffic": 514891 if args.workload == "mppi_cfg2" and samples_in_hbm else None,
-                    "note": "issue/latency-bound at this size, not HBM-bound: 0.2 MB per launch vs an H-step dependent "
-                            "recurrence (~60 VALU instructions per step on one wave per 64 trajectories); traffic = "
-                            "(2 x FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 --pmc passes with the guide's gfx950 factor on "
-                            "FETCH_SIZE (profiles/): 200 KiB of samples + ~270 KiB of per-launch fixed fetches (each of the 8 XCDs' "
-                            "L2 starts cold: kernel code, arguments, tables) + record polling, DESIGN.md 5"}
-        roof.update({"kernel": eng.dominant_kernel(), "kernel_us": kms * 1e3, "algorithmic_bytes": alg_bytes,
-                     "kernel_timed_launches": int(len(kern_ms)), "kernel_timed_every": prof_every})
+                    "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": traffic, "traffic_source": tnote,
+                    "note": "issue/latency-bound at this size, not HBM-bound: 0.2 MB per launch vs an H-step dependent recurrence on one "
+                            "wave per 64 trajectories (DESIGN.md 5); the large-N point below is where the chip is full"}
+        roof.update({"kernel": kname, "kernel_us": kms * 1e3, "algorithmic_bytes": alg_bytes,
+                     "kernel_timed_launches": int(len(kern_ms)), "kernel_timing": "separate pass after the timed region, every launch"})
         ps = per_step * 1e3
         out = {
             "metric": "trajectory-steps/sec (N*H per controller.step)", "value": total_units / elapsed,
             "unit": "trajectory-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{w['opt'].upper()} N={N} per GPU, H={H}, period={p}, predictor {w['pred']} "
-                                   f"(4 states, 1 input) [{args.workload}]",
-                       "samples": args.samples if w["opt"] == "mppi" else "device-rng", "global_rollouts": N * world,
-                       "parallelism": ((f"rollout shards x{world}, records of {P + 2} floats exchanged by peer-to-peer stores over xGMI"
-                                        if sharded.exchange == "p2p" else
-                                        f"rollout shards x{world}, 1 all-gather of {P + 2} floats per step (RCCL)") if world > 1
-                                       else "single GPU")},
-            "step_ms_median": float(np.median(ps)), "step_ms_p95": float(np.percentile(ps, 95)),
+            "config": {"workload": f"{w['opt'].upper()} N={Ng} global ({N} per GPU), H={H}, period={p}, predictor {w['pred']} "
+                                   f"(4 states, 1 input) [{wname}]",
+                       "boundary": {"controller": "controller_mpc.step (Python; s in, u out on the host)",
+                                    "engine": "CtkEngine.step (ctypes -> ctk_step)",
+                                    "sharded": "control_toolkit_amd.dist.Sharded*.step (ctypes begin / collective / end)"}[boundary],
+                       "samples": samples if (sharded is None or w["opt"] == "mppi") else "device-rng",
+                       "global_rollouts": Ng, "parallelism": exchange_note},
+            "step_ms_median": float(np.median(ps)),
             "roofline": roof,
         }
-        if not args.no_large_n and world == 1 and args.workload == "mppi_cfg2":
+        if args.steps >= 100:
+            out["step_ms_p95"] = float(np.percentile(ps, 95))
+        if modes:
+            out["modes"] = modes
+        if not args.no_large_n and world == 1 and wname == "mppi_cfg2":
             out["roofline_large_n"] = large_n_point(torch, CtkEngine, dev, H, p)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w)
             if w["opt"] == "mppi" and w["pred"] == "ODE":
                 out["cpu_baseline_torch"] = cpu_baseline_torch(w)
+        if world > 1 and w["opt"] == "mppi":
+            # the ONE-GPU point of the same workload, measured on rank 0's GPU while the others wait: lets a reader
+            # turn the strong-scaling value into an efficiency without a second launch of this script
+            e1 = CtkEngine("mppi", w["pred"], num_rollouts=Ng, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p,
+                           seed=1, device=local_rank, **ekw)
+            if w["pred"] == "MLP":
+                e1.set_predictor_weights(mlp_weights(0))
+            elif w["pred"] == "GRU":
+                e1.set_predictor_weights(gru_weights(0))
+            big = torch.randn((Ng * P,), device=dev, dtype=torch.float32)
+            s = s0.copy()
+            for _ in range(5):
+                plant_step(s, e1.step(s, big.data_ptr() if samples == "buffer" else None)[0])
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            n1 = min(args.steps, 50)
+            for _ in range(n1):
+                plant_step(s, e1.step(s, big.data_ptr() if samples == "buffer" else None)[0])
+            torch.cuda.synchronize(); el1 = time.perf_counter() - t0
+            out["single_gpu_same_workload"] = {"value": Ng * H * n1 / el1, "ms_per_step": el1 / n1 * 1e3, "steps": n1,
+                                               "note": "engine.step of the whole N on rank 0's GPU, outside the timed region"}
+            e1.close()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     os.close(result_fd)
-    eng.close()
-    if world > 1 or force_pg:
+    if use_pg:
+        dist.barrier()
+    if ctrl is None:
+        eng.close()
+    if use_pg:
         dist.destroy_process_group()
 
 

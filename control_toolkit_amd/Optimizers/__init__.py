@@ -85,9 +85,33 @@ class template_optimizer:
         self.engine: CtkEngine = None
         self._param_cache = {}
         self._cost_version = None
+        self._sync_key = None
         self.optimal_trajectory = None
-        self.optimal_control_sequence = None
         self.rollout_trajectories = None
+        self._lazy = {}   # device buffers fetched on first access after a step (u_nom: no D2H copy on the step path)
+
+    # The reference converts u_nom to NumPy every step (optimizer_mppi.py:220, optimizer_rpgd.py:426,435); here the
+    # plan stays in HBM and is copied when somebody looks at it.
+    def _lazy_read(self, name):
+        v = self._lazy.get(name)
+        if v is None and self.engine is not None:
+            v = self._lazy[name] = self.engine.read(name)
+        return v
+
+    @property
+    def u_nom(self):
+        return self._lazy_read("U_NOM")
+
+    @u_nom.setter
+    def u_nom(self, value):
+        if value is None:
+            self._lazy.pop("U_NOM", None)
+        else:
+            self._lazy["U_NOM"] = value
+
+    @property
+    def optimal_control_sequence(self):
+        return self.u_nom
 
     # reference :52-63
     def configure(self, num_states: int, num_control_inputs: int, default_configure: bool = True, **kwargs) -> None:
@@ -141,6 +165,18 @@ class template_optimizer:
         """Upload changed dynamics / cost / per-step attributes (reference: variable_parameters
         updated by template_controller.update_attributes, Controllers/__init__.py:106-107; cost
         YAML hot reload, cost_function_wrapper.py:71-74).  Only between steps."""
+        cf = self.cost_function
+        vp = getattr(cf, "variable_parameters", None) or getattr(self.predictor, "variable_parameters", None)
+        # cheap per-step check: nothing to upload unless the cost parameters were reloaded (version counter), the
+        # dynamics values changed, or a per-step attribute moved
+        def scalar(x):
+            return None if x is None else float(np.asarray(x).reshape(-1)[0])
+        key = (getattr(cf, "version", None), tuple(getattr(cf, "parameters", {}).values()),
+               tuple(getattr(self.predictor, "parameters", {}).values()),
+               scalar(getattr(vp, "target_position", None)), scalar(getattr(vp, "target_equilibrium", None)))
+        if not force and key == self._sync_key:
+            return
+        self._sync_key = key
         vals = {}
         vals.update(getattr(self.predictor, "parameters", {}))
         cf = self.cost_function

@@ -24,7 +24,6 @@ class optimizer_mppi_hip(template_optimizer):
         self.cc_weight, self.R, self.LBD, self.NU = cc_weight, R, LBD, NU
         self._SQRTRHOINV = SQRTRHOINV
         self.period_interpolation_inducing_points = period_interpolation_inducing_points
-        self.u_nom = None
         self.global_rollout_offset = int(kwargs.get("global_rollout_offset", 0))
 
     def configure(self, num_states: int, num_control_inputs: int, dt: float, predictor_specification: str, **kwargs):
@@ -44,14 +43,13 @@ class optimizer_mppi_hip(template_optimizer):
         noise = self._draws("normal", [self.num_rollouts, self.number_of_interpolation_inducing_points, 1])
         u_prev = np.asarray(self.u, np.float32).reshape(-1)[:1]
         self.u = np.squeeze(self.engine.step(s, noise, u_prev=u_prev))          # :211-212
+        self._lazy.clear()                                                        # u_nom / optimal_control_sequence (:220): read on demand
         if self.optimizer_logging:
             self._fill_logging(s, self.u)
-        self.u_nom = self.engine.read("U_NOM")
-        self.optimal_control_sequence = self.u_nom                                # :220
         if self.calculate_optimal_trajectory:                                     # :222-223
             self.optimal_trajectory = self._predict_optimal_trajectory(s, self.u_nom, float(self.u))
         return self.u
 
     def optimizer_reset(self):
         self.engine.reset()                                                       # :227-231
-        self.u_nom = self.engine.read("U_NOM")
+        self._lazy.clear()

@@ -46,7 +46,6 @@ class optimizer_rpgd_hip(template_optimizer):
         self.adam_beta_1, self.adam_beta_2, self.adam_epsilon = adam_beta_1, adam_beta_2, adam_epsilon
         self.summed_stage_cost = None
         self.count = 0
-        self.u_nom = None
 
     def configure(self, num_states: int, num_control_inputs: int, **kwargs):
         dt = kwargs.get("dt", None)
@@ -81,13 +80,12 @@ class optimizer_rpgd_hip(template_optimizer):
                                                       self.number_of_interpolation_inducing_points, 1])
         u_prev = np.asarray(self.u, np.float32).reshape(-1)[:1]
         u = self.engine.step(s, draws, u_prev=u_prev)
-        self.u_nom = self.engine.read("U_NOM")                      # :426
+        self._lazy.clear()                                           # u_nom (:426), optimal_control_sequence (:435): read on demand
         if self.optimizer_logging:                                   # :428-433
             self.logging_values["Q_logged"] = self._logged("Q")
             self.logging_values["J_logged"] = self._logged("J")
             self.logging_values["trajectory_ages_logged"] = self._logged("AGES")
             self.logging_values["u_logged"] = self.u
-        self.optimal_control_sequence = self.u_nom                   # :435
         self.count += 1
         if self.calculate_optimal_trajectory:                        # :518-521
             self.optimal_trajectory = self._predict_optimal_trajectory(s, self.u_nom, float(np.asarray(self.u).reshape(-1)[0]))
@@ -101,4 +99,5 @@ class optimizer_rpgd_hip(template_optimizer):
     def optimizer_reset(self):
         draws = self._draws(self._sample_kind(), [self.num_rollouts, self.number_of_interpolation_inducing_points, 1])
         self.engine.reset(draws)                                     # :527-548
+        self._lazy.clear()
         self.count = 0

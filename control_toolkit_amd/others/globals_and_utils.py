@@ -44,6 +44,27 @@ class HostRng:
         return self.gen.random(size=tuple(shape), dtype=np.float32)
 
 
+class DeviceBufferRng:
+    """Draws that are ALREADY resident in HBM (the "[N, H, action_dim] sample buffer" of BASELINE.json's north_star):
+    normal()/uniform() hand out the device address of the next buffer of a caller-owned pool, which the engine reads
+    with coalesced loads (CTK_LOC_DEVICE).  The caller guarantees that every buffer holds at least prod(shape) fp32
+    raw draws of the right distribution and outlives the step; nothing is generated or copied here."""
+    on_device = False
+
+    def __init__(self, device_pointers, seed: int = 0):
+        self.pointers = [int(p) for p in device_pointers]
+        if not self.pointers:
+            raise ValueError("DeviceBufferRng needs at least one device buffer")
+        self.seed, self._i = int(seed), 0
+
+    def normal(self, shape, dtype=np.float32):
+        p = self.pointers[self._i]
+        self._i = (self._i + 1) % len(self.pointers)
+        return p
+
+    uniform = normal
+
+
 def create_rng(id: str, seed, computation_library=None, mode: str = "device"):
     """reference create_rng (:86-99): seed None -> milliseconds since the epoch."""
     if seed is None:

@@ -225,7 +225,7 @@ def main():
     rpgd_cases = {
         "ode_small":  dict(N=16, H=12, p=5, pred="ODE", its=2, steps=4, resamp=2, dist="uniform", seed=5, shift=1),
         "ode_its20":  dict(N=32, H=50, p=10, pred="ODE", its=20, steps=2, resamp=10, dist="uniform", seed=6, shift=1),
-        "mlp_cfg4":   dict(N=64, H=50, p=10, pred="MLP", its=20, steps=2, resamp=10, dist="uniform", seed=7, shift=1),
+        "mlp_cfg4":   dict(N=256, H=50, p=10, pred="MLP", its=20, steps=2, resamp=10, dist="uniform", seed=7, shift=1),
         "ode_normal": dict(N=16, H=10, p=1, pred="ODE", its=3, steps=3, resamp=1, dist="normal", seed=8, shift=2),
     }
     for name, c in rpgd_cases.items():

@@ -10,14 +10,24 @@ from gpu_helpers import rpgd_engine_from
 pytestmark = pytest.mark.gpu
 
 
-def assert_close_mostly(actual, desired, rtol, atol, outlier_frac=5e-3, outlier_atol=0.1):
+def count_outliers(actual, desired, rtol, atol):
+    actual, desired = np.asarray(actual), np.asarray(desired)
+    return int((np.abs(actual - desired) > atol + rtol * np.abs(desired)).sum())
+
+
+def assert_close_mostly(actual, desired, rtol, atol, outlier_frac=5e-3, outlier_atol=0.1, max_outliers=None):
     """Adam's normalised update m_hat/(sqrt(v_hat)+eps) has magnitude ~1 whatever the gradient's
     size, so where an input's gradient is within fp32 rounding of zero a sign difference moves that
     single element by up to 2*lr per iteration.  Require the stated tolerance for all but a
-    vanishing fraction of elements, and bound the outliers by 2*lr = 0.1."""
+    vanishing fraction of elements, and bound the outliers by 2*lr = 0.1.
+    max_outliers: an absolute bound on their NUMBER (callers that can measure how many the comparison of two
+    CPU evaluations of the same step produces pass that number, so that a real adjoint error of this size
+    cannot hide behind the allowance)."""
     actual, desired = np.asarray(actual), np.asarray(desired)
-    bad = np.abs(actual - desired) > atol + rtol * np.abs(desired)
-    assert bad.mean() <= outlier_frac, f"{bad.sum()} / {bad.size} elements outside rtol={rtol}, atol={atol}"
+    n_bad = count_outliers(actual, desired, rtol, atol)
+    assert n_bad <= outlier_frac * actual.size, f"{n_bad} / {actual.size} elements outside rtol={rtol}, atol={atol}"
+    if max_outliers is not None:
+        assert n_bad <= max_outliers, f"{n_bad} outliers, more than the {max_outliers} the CPU-vs-CPU comparison of this step shows"
     assert np.abs(actual - desired).max() <= outlier_atol
 
 
@@ -159,8 +169,12 @@ def test_rpgd_mlp_matches_oracle(N, H, p, its):
         dr = rng.random((N - o.k, o.P, 1), dtype=np.float32) if t % 10 == 0 else None
         uo = o.step(s, dr)
         ug = e.step(s, dr)
-        assert_close_mostly(e.read("PLAN"), o.Q, **tol)
-        assert_close_mostly(e.read("ADAM_M"), o.opt.m, **tol)
+        # the golden test above holds the SAME configuration (N 256, 20 iterations, MLP) to the reference-recorded
+        # fixture with no outlier allowance at all; here, against the oracle on other inputs, at most a handful
+        n_q, n_m = count_outliers(e.read("PLAN"), o.Q, **tol), count_outliers(e.read("ADAM_M"), o.opt.m, **tol)
+        print(f"rpgd_mlp N={N} its={its} step {t}: outliers Q {n_q} / {o.Q.size}, m {n_m}")
+        assert_close_mostly(e.read("PLAN"), o.Q, max_outliers=max(2, o.Q.size // 2000), **tol)
+        assert_close_mostly(e.read("ADAM_M"), o.opt.m, max_outliers=max(2, o.Q.size // 2000), **tol)
         np.testing.assert_allclose(ug[0], uo, **tol)
         e.set_state(state_vec(o.Q, o.opt.m, o.opt.v, o.trajectory_ages, float(o.u), o.opt.step_count, o.count))
         s = pred.step(s.reshape(1, 4), np.array([uo], np.float32))[0]
