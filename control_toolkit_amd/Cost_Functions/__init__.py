@@ -93,6 +93,8 @@ class CostFunctionWrapper:
     def set_parameters(self, **kw):
         """Programmatic equivalent of editing the YAML: takes effect at the next controller step."""
         self.config = dict(self.config or {}, **_checked(kw, "set_parameters"))
+        for k in kw:                        # an explicit later choice replaces the constructor's for that parameter
+            self._explicit.pop(k, None)
         self.reload_cost_parameters_from_config_flag = True
 
     def validate_config(self, section):

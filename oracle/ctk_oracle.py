@@ -41,6 +41,8 @@ PARAM_NAMES = (
 
 @dataclass
 class EnvParams:
+    NAME = "CartPole"
+    S, C = 4, 1
     """Physical + cost parameters of the build-defined cart-pole (state order position,
     positionD, angle, angleD as hinted by reference Controllers/controller_C.py:14-19; weight
     names as in Control_Toolkit_ASF_Template/config_cost_function.yml:11-18; per-step
@@ -66,10 +68,77 @@ class EnvParams:
     def as_array(self) -> np.ndarray:
         return np.array([getattr(self, k) for k in PARAM_NAMES], dtype=np.float32)
 
+    def param_names(self):
+        return PARAM_NAMES
 
-def derived_constants(p: EnvParams, dt: float, intermediate_steps: int = 1) -> dict:
+
+# Second build-defined environment ("a 2-input, 6-state system of your choosing"): a planar
+# quadrotor.  State (x, vx, z, vz, theta, omega), inputs (u1, u2) in [-1, 1] = normalised rotor commands, rotor
+# thrust T_i = (m g / 2) (1 + thrust_gain u_i).  Selected by environment_name / predictor_specification /
+# cost_function_specification exactly like the reference selects its plants (controller_mpc.py:67-82,
+# cost_function_wrapper.py:59-66).  Parity unpinned by nature (the reference's environments are not vendored).
+QUAD2D_PARAM_NAMES = (
+    "g", "mass", "inertia", "arm", "thrust_gain", "drag_lin", "drag_ang",     # dynamics
+    "target_x", "target_z",                                                    # per-step attributes
+    "pos_weight", "ang_weight", "vel_weight", "angvel_weight", "cc_weight", "ccrc_weight",
+    "R", "pos_scale", "terminal_weight",
+)
+
+
+@dataclass
+class Quad2DParams:
+    NAME = "Quad2D"
+    S, C = 6, 2
+    g: float = 9.81
+    mass: float = 0.5
+    inertia: float = 0.004
+    arm: float = 0.12
+    thrust_gain: float = 0.6
+    drag_lin: float = 0.25
+    drag_ang: float = 0.4
+    target_x: float = 0.0
+    target_z: float = 1.0
+    pos_weight: float = 400.0
+    ang_weight: float = 150.0
+    vel_weight: float = 8.0
+    angvel_weight: float = 1.5
+    cc_weight: float = 1.0
+    ccrc_weight: float = 2.0
+    R: float = 1.0
+    pos_scale: float = 0.5
+    terminal_weight: float = 0.0
+
+    def as_array(self) -> np.ndarray:
+        return np.array([getattr(self, k) for k in QUAD2D_PARAM_NAMES], dtype=np.float32)
+
+    def param_names(self):
+        return QUAD2D_PARAM_NAMES
+
+
+ENVIRONMENTS = {"CartPole": EnvParams, "Quad2D": Quad2DParams}
+
+
+def quad2d_constants(p: Quad2DParams, dt: float, intermediate_steps: int = 1) -> dict:
+    """Derived fp32 constants of the planar quadrotor (double, rounded once) — the same expressions as
+    csrc/ctk_env.h: Env<CTK_ENV_QUAD2D>::derive."""
+    q = {k: float(np.float32(getattr(p, k))) for k in QUAD2D_PARAM_NAMES}
+    d = dict(
+        dt=dt / intermediate_steps,
+        g=q["g"],
+        kF=0.5 * q["g"] * q["thrust_gain"],                                        # (T1+T2)/m = g + kF (u1+u2)
+        kM=q["arm"] * 0.5 * q["mass"] * q["g"] * q["thrust_gain"] / q["inertia"],  # arm (T1-T2)/I = kM (u1-u2)
+        c_v=q["drag_lin"], c_w=q["drag_ang"],
+        pos_c=q["pos_weight"] / (q["pos_scale"] * q["pos_scale"]),
+        ccR=q["cc_weight"] * q["R"],
+    )
+    return {k: np.float32(v) for k, v in d.items()}
+
+
+def derived_constants(p, dt: float, intermediate_steps: int = 1) -> dict:
     """Constants the step function uses, computed in double then rounded once to fp32.
-    The C library computes exactly the same expressions (csrc/ctk_params.h: derive_constants)."""
+    The C library computes exactly the same expressions (csrc/ctk_common.h: derive_constants)."""
+    if isinstance(p, Quad2DParams):
+        return quad2d_constants(p, dt, intermediate_steps)
     q = {k: float(np.float32(getattr(p, k))) for k in PARAM_NAMES}  # primary params are fp32
     inv_mt = 1.0 / (q["m_cart"] + q["m_pole"])
     ml = q["m_pole"] * q["L"]
@@ -98,22 +167,27 @@ MLP_IN, MLP_H, MLP_OUT = 5, 32, 4
 MLP_NUM_WEIGHTS = MLP_IN * MLP_H + MLP_H + MLP_H * MLP_H + MLP_H + MLP_H * MLP_OUT + MLP_OUT  # 1380
 
 
-def mlp_default_weights(seed: int = 0) -> np.ndarray:
-    """5->32->32->4 tanh MLP, weights N(0, 1/fan_in), biases N(0, 0.01) from default_rng(seed)
-    (SURVEY.md 8d cfg4).  Flat layout: W1[32,5] b1[32] W2[32,32] b2[32] W3[4,32] b3[4]."""
+def mlp_num_weights(n_in: int = MLP_IN, n_out: int = MLP_OUT) -> int:
+    return n_in * MLP_H + MLP_H + MLP_H * MLP_H + MLP_H + MLP_H * n_out + n_out
+
+
+def mlp_default_weights(seed: int = 0, n_in: int = MLP_IN, n_out: int = MLP_OUT) -> np.ndarray:
+    """(S+C)->32->32->S tanh MLP (cart-pole: 5->32->32->4), weights N(0, 1/fan_in), biases N(0, 0.01) from
+    default_rng(seed).  Flat layout: W1[32,n_in] b1[32] W2[32,32] b2[32] W3[n_out,32] b3[n_out]."""
     rng = np.random.default_rng(seed)
-    W1 = rng.normal(0, 1 / math.sqrt(MLP_IN), (MLP_H, MLP_IN))
+    W1 = rng.normal(0, 1 / math.sqrt(n_in), (MLP_H, n_in))
     b1 = rng.normal(0, 0.1, (MLP_H,))
     W2 = rng.normal(0, 1 / math.sqrt(MLP_H), (MLP_H, MLP_H))
     b2 = rng.normal(0, 0.1, (MLP_H,))
-    W3 = rng.normal(0, 1 / math.sqrt(MLP_H), (MLP_OUT, MLP_H))
-    b3 = rng.normal(0, 0.1, (MLP_OUT,))
+    W3 = rng.normal(0, 1 / math.sqrt(MLP_H), (n_out, MLP_H))
+    b3 = rng.normal(0, 0.1, (n_out,))
     return np.concatenate([a.ravel() for a in (W1, b1, W2, b2, W3, b3)]).astype(np.float32)
 
 
-def mlp_unpack(w: np.ndarray):
+def mlp_unpack(w: np.ndarray, n_in: int = MLP_IN, n_out: int = MLP_OUT):
     w = np.asarray(w, dtype=np.float32)
-    assert w.size == MLP_NUM_WEIGHTS
+    assert w.size == mlp_num_weights(n_in, n_out)
+    MLP_IN, MLP_OUT = n_in, n_out   # noqa: N806 — local shadows for the layout below
     o = 0
     def take(n, shape):
         nonlocal o
@@ -137,29 +211,33 @@ GRU_H = 32
 GRU_NUM_WEIGHTS = (96 * 5 + 96 * 32 + 192) + (96 * 32 + 96 * 32 + 192) + (4 * 32 + 4)   # 10212
 
 
-def gru_default_weights(seed: int = 0) -> np.ndarray:
+def gru_num_weights(n_in: int = MLP_IN, n_out: int = MLP_OUT) -> int:
+    return (96 * n_in + 96 * 32 + 192) + (96 * 32 + 96 * 32 + 192) + (n_out * 32 + n_out)
+
+
+def gru_default_weights(seed: int = 0, n_in: int = MLP_IN, n_out: int = MLP_OUT) -> np.ndarray:
     rng = np.random.default_rng(seed)
     parts = []
-    for I in (MLP_IN, GRU_H):
+    for I in (n_in, GRU_H):
         parts += [rng.normal(0, 1 / math.sqrt(I), (96, I)), rng.normal(0, 1 / math.sqrt(GRU_H), (96, GRU_H)),
                   rng.normal(0, 0.1, (96,)), rng.normal(0, 0.1, (96,))]
-    parts += [rng.normal(0, 1 / math.sqrt(GRU_H), (4, GRU_H)), rng.normal(0, 0.1, (4,))]
+    parts += [rng.normal(0, 1 / math.sqrt(GRU_H), (n_out, GRU_H)), rng.normal(0, 0.1, (n_out,))]
     return np.concatenate([a.ravel() for a in parts]).astype(np.float32)
 
 
-def gru_unpack(w: np.ndarray):
+def gru_unpack(w: np.ndarray, n_in: int = MLP_IN, n_out: int = MLP_OUT):
     w = np.asarray(w, dtype=np.float32)
-    assert w.size == GRU_NUM_WEIGHTS
+    assert w.size == gru_num_weights(n_in, n_out)
     o = 0
     layers = []
-    for I in (MLP_IN, GRU_H):
+    for I in (n_in, GRU_H):
         Wi = w[o:o + 96 * I].reshape(96, I); o += 96 * I
         Wh = w[o:o + 96 * GRU_H].reshape(96, GRU_H); o += 96 * GRU_H
         bi = w[o:o + 96]; o += 96
         bh = w[o:o + 96]; o += 96
         layers.append((Wi, Wh, bi, bh))
-    Wo = w[o:o + 4 * GRU_H].reshape(4, GRU_H); o += 4 * GRU_H
-    bo = w[o:o + 4]
+    Wo = w[o:o + n_out * GRU_H].reshape(n_out, GRU_H); o += n_out * GRU_H
+    bo = w[o:o + n_out]
     return layers, Wo, bo
 
 
@@ -187,17 +265,23 @@ class Predictor:
     weights: Optional[np.ndarray] = None
 
     def __post_init__(self):
+        self.S, self.C = self.env.S, self.env.C
         if self.kind == "MLP" and self.weights is None:
-            self.weights = mlp_default_weights(0)
+            self.weights = mlp_default_weights(0, self.S + self.C, self.S)
         if self.kind == "GRU":
             if self.weights is None:
-                self.weights = gru_default_weights(0)
+                self.weights = gru_default_weights(0, self.S + self.C, self.S)
             self.hidden = np.zeros((2, GRU_H), np.float32)
+
+    def _q2(self, q):
+        """inputs as [N,C] (callers of the C = 1 environment may pass [N])"""
+        q = np.asarray(q, np.float32)
+        return q.reshape(-1, self.C) if q.ndim != 2 else q
 
     # GRU -------------------------------------------------------------------------------------
     def _gru_step(self, s, q, h1, h2):
-        layers, Wo, bo = gru_unpack(self.weights)
-        xin = np.concatenate([s, q[:, None]], axis=1).astype(np.float32)
+        layers, Wo, bo = gru_unpack(self.weights, self.S + self.C, self.S)
+        xin = np.concatenate([s, self._q2(q)], axis=1).astype(np.float32)
         h1n = gru_cell(xin, h1, *layers[0])
         h2n = gru_cell(h1n, h2, *layers[1])
         return (h2n @ Wo.T + bo).astype(np.float32), h1n, h2n
@@ -207,18 +291,58 @@ class Predictor:
         real state and the applied input."""
         if self.kind != "GRU":
             return
-        s = np.asarray(s, np.float32).reshape(1, 4)
-        _, h1, h2 = self._gru_step(s, np.asarray(q0, np.float32).reshape(1), self.hidden[0:1], self.hidden[1:2])
+        s = np.asarray(s, np.float32).reshape(1, self.S)
+        _, h1, h2 = self._gru_step(s, np.asarray(q0, np.float32).reshape(1, self.C), self.hidden[0:1], self.hidden[1:2])
         self.hidden = np.concatenate([h1, h2], 0)
 
     # one predictor step ---------------------------------------------------------------------
     def step(self, s: np.ndarray, q: np.ndarray) -> np.ndarray:
-        """s [N,4] fp32, q [N] fp32 (C = 1) -> next state [N,4] fp32."""
+        """s [N,S] fp32, q [N,C] fp32 ([N] accepted when C = 1) -> next state [N,S] fp32."""
         if self.kind == "ODE":
             return self._ode_step(s, q)
         return self._mlp_step(s, q)[0]
 
+    def _quad_step(self, s, q):
+        k = derived_constants(self.env, self.dt, self.intermediate_steps)
+        x, vx, z, vz, th, om = (s[:, i].copy() for i in range(6))
+        q = self._q2(q)
+        aF = k["g"] + k["kF"] * (q[:, 0] + q[:, 1])        # total thrust / mass
+        aM = k["kM"] * (q[:, 0] - q[:, 1])                 # rotor torque / inertia
+        dt = k["dt"]
+        for _ in range(self.intermediate_steps):
+            sn, cs = np.sin(th), np.cos(th)
+            ax = -aF * sn - k["c_v"] * vx
+            az = aF * cs - k["g"] - k["c_v"] * vz
+            al = aM - k["c_w"] * om
+            x, vx, z, vz, th, om = (x + dt * vx, vx + dt * ax, z + dt * vz, vz + dt * az, th + dt * om, om + dt * al)
+        return np.stack([x, vx, z, vz, th, om], axis=1).astype(np.float32)
+
+    def _quad_vjp(self, s, q, lam):
+        assert self.intermediate_steps == 1, "adjoint restated for intermediate_steps == 1"
+        k = derived_constants(self.env, self.dt, 1)
+        q = self._q2(q)
+        vx, vz, th, om = s[:, 1], s[:, 3], s[:, 4], s[:, 5]
+        lx, lvx, lz, lvz, lth, lom = (lam[:, i] for i in range(6))
+        dt = k["dt"]
+        sn, cs = np.sin(th), np.cos(th)
+        aF = k["g"] + k["kF"] * (q[:, 0] + q[:, 1])
+        a_ax, a_az, a_al = dt * lvx, dt * lvz, dt * lom
+        a_aF = -sn * a_ax + cs * a_az
+        o_x = lx
+        o_vx = lvx + dt * lx - k["c_v"] * a_ax
+        o_z = lz
+        o_vz = lvz + dt * lz - k["c_v"] * a_az
+        o_th = lth - aF * (cs * a_ax + sn * a_az)
+        o_om = lom + dt * lth - k["c_w"] * a_al
+        g0 = k["kF"] * a_aF + k["kM"] * a_al
+        g1 = k["kF"] * a_aF - k["kM"] * a_al
+        return (np.stack([o_x, o_vx, o_z, o_vz, o_th, o_om], 1).astype(np.float32),
+                np.stack([g0, g1], 1).astype(np.float32))
+
     def _ode_step(self, s, q):
+        if isinstance(self.env, Quad2DParams):
+            return self._quad_step(s, q)
+        q = self._q2(q)[:, 0]
         k = derived_constants(self.env, self.dt, self.intermediate_steps)
         x, v, th, om = (s[:, i].copy() for i in range(4))
         F = k["u_max"] * q
@@ -235,8 +359,8 @@ class Predictor:
         return np.stack([x, v, th, om], axis=1).astype(np.float32)
 
     def _mlp_step(self, s, q):
-        W1, b1, W2, b2, W3, b3 = mlp_unpack(self.weights)
-        xin = np.concatenate([s, q[:, None]], axis=1).astype(np.float32)
+        W1, b1, W2, b2, W3, b3 = mlp_unpack(self.weights, self.S + self.C, self.S)
+        xin = np.concatenate([s, self._q2(q)], axis=1).astype(np.float32)
         h1 = np.tanh(xin @ W1.T + b1).astype(np.float32)
         h2 = np.tanh(h1 @ W2.T + b2).astype(np.float32)
         out = (h2 @ W3.T + b3).astype(np.float32)
@@ -244,12 +368,15 @@ class Predictor:
 
     # vector-Jacobian product of one step (used by the RPGD adjoint) ---------------------------
     def step_vjp(self, s, q, lam):
-        """Given lam = dL/ds' [N,4], return (dL/ds [N,4], dL/dq [N])."""
+        """Given lam = dL/ds' [N,S], return (dL/ds [N,S], dL/dq [N,C])."""
         if self.kind == "ODE":
             return self._ode_vjp(s, q, lam)
         return self._mlp_vjp(s, q, lam)
 
     def _ode_vjp(self, s, q, lam):
+        if isinstance(self.env, Quad2DParams):
+            return self._quad_vjp(s, q, lam)
+        q = self._q2(q)[:, 0]
         assert self.intermediate_steps == 1, "adjoint restated for intermediate_steps == 1"
         k = derived_constants(self.env, self.dt, 1)
         x, v, th, om = (s[:, i] for i in range(4))
@@ -279,15 +406,15 @@ class Predictor:
         o_om = lom + dt * lth - k["k_jf"] * a_Nn + f32(2.0) * k["k_ml"] * om * sn * a_A
         g_q = k["u_max"] * a_A
         return (np.stack([o_x, o_v, o_th, o_om], axis=1).astype(np.float32),
-                g_q.astype(np.float32))
+                g_q.astype(np.float32)[:, None])
 
     def _mlp_vjp(self, s, q, lam):
-        W1, b1, W2, b2, W3, b3 = mlp_unpack(self.weights)
+        W1, b1, W2, b2, W3, b3 = mlp_unpack(self.weights, self.S + self.C, self.S)
         _, (xin, h1, h2) = self._mlp_step(s, q)
         d2 = (lam @ W3) * (f32(1.0) - h2 * h2)
         d1 = (d2 @ W2) * (f32(1.0) - h1 * h1)
         din = (d1 @ W1).astype(np.float32)
-        return din[:, :4].copy(), din[:, 4].copy()
+        return din[:, :self.S].copy(), din[:, self.S:].copy()
 
     # reference: PredictorWrapper.predict_core(s[N,S], Q[N,H,C]) -> [N,H+1,S]
     # (shape pinned by optimizer_cem_tf.py:70 and Cost_Functions/__init__.py:81)
@@ -295,18 +422,18 @@ class Predictor:
         s = np.asarray(s, dtype=np.float32)
         Q = np.asarray(Q, dtype=np.float32)
         N, H, C = Q.shape
-        assert C == 1 and s.shape == (N, 4)
-        traj = np.empty((N, H + 1, 4), dtype=np.float32)
+        assert C == self.C and s.shape == (N, self.S)
+        traj = np.empty((N, H + 1, self.S), dtype=np.float32)
         traj[:, 0] = s
         cur = s
         if self.kind == "GRU":
             h1 = np.tile(self.hidden[0:1], (N, 1)); h2 = np.tile(self.hidden[1:2], (N, 1))
             for h in range(H):
-                cur, h1, h2 = self._gru_step(cur, Q[:, h, 0], h1, h2)
+                cur, h1, h2 = self._gru_step(cur, Q[:, h, :], h1, h2)
                 traj[:, h + 1] = cur
             return traj
         for h in range(H):
-            cur = self.step(cur, Q[:, h, 0])
+            cur = self.step(cur, Q[:, h, :])
             traj[:, h + 1] = cur
         return traj
 
@@ -317,12 +444,37 @@ class Predictor:
 class Cost:
     MAX_COST = f32(0.0)   # Cost_Functions/__init__.py:14
 
-    def __init__(self, env: EnvParams, dt: float = 0.02):
+    def __init__(self, env, dt: float = 0.02):
         self.env = env
         self.dt = dt
+        self.S, self.C = env.S, env.C
+        self.quad = isinstance(env, Quad2DParams)
 
     def _k(self):
         return derived_constants(self.env, self.dt, 1)
+
+    # planar quadrotor (build-defined terms: position error, attitude, velocities, input, input change) ------
+    def _quad_state_terms(self, states):
+        k, e = self._k(), self.env
+        dx, dz = states[..., 0] - f32(e.target_x), states[..., 2] - f32(e.target_z)
+        pos = k["pos_c"] * (dx * dx + dz * dz)
+        ang = f32(e.ang_weight) * (f32(1.0) - np.cos(states[..., 4]))
+        return pos.astype(np.float32), ang.astype(np.float32)
+
+    def _prev_inputs(self, inputs, previous_input):
+        """[N,H,C]: the input applied one step earlier (previous_input for h = 0)"""
+        p0 = np.broadcast_to(np.asarray(previous_input, np.float32).reshape(1, 1, self.C), (inputs.shape[0], 1, self.C))
+        return np.concatenate([p0, inputs[:, :-1, :]], axis=1)
+
+    def _quad_stage_cost(self, states, inputs, previous_input):
+        k, e = self._k(), self.env
+        pos, ang = self._quad_state_terms(states)
+        vx, vz, om = states[..., 1], states[..., 3], states[..., 5]
+        vel = f32(e.vel_weight) * (vx * vx + vz * vz) + f32(e.angvel_weight) * om * om
+        du = inputs - self._prev_inputs(inputs, previous_input)
+        cc = k["ccR"] * np.sum(inputs * inputs, axis=2, dtype=np.float32)
+        ccrc = f32(e.ccrc_weight) * np.sum(du * du, axis=2, dtype=np.float32)
+        return (pos + ang + vel + cc + ccrc).astype(np.float32)
 
     def _state_terms(self, states):
         k = self._k()
@@ -337,6 +489,8 @@ class Cost:
     def _get_stage_cost(self, states, inputs, previous_input):
         """states [N,H,4], inputs [N,H,1], previous_input [1] -> [N,H] (build-defined terms:
         dd, ep, ekp, cc, ccrc — names from Control_Toolkit_ASF_Template/config_cost_function.yml)."""
+        if self.quad:
+            return self._quad_stage_cost(states, inputs, previous_input)
         e = self.env
         k = self._k()
         dd, ep, om = self._state_terms(states)
@@ -357,6 +511,9 @@ class Cost:
     def get_terminal_cost(self, terminal_states):
         # default in the reference is zeros[N,1] (Cost_Functions/__init__.py:47); the build's
         # concrete cost overrides it with terminal_weight * (dd + ep) (0 by default).
+        if self.quad:
+            pos, ang = self._quad_state_terms(terminal_states)
+            return (f32(self.env.terminal_weight) * (pos + ang)).astype(np.float32)
         dd, ep, _ = self._state_terms(terminal_states)
         return (f32(self.env.terminal_weight) * (dd + ep)).astype(np.float32)
 
@@ -373,9 +530,19 @@ class Cost:
 
     # gradient pieces for the RPGD adjoint ---------------------------------------------------
     def state_grad(self, states, terminal: bool):
-        """d(stage or terminal cost)/d(state) for states [N,4] -> [N,4]."""
+        """d(stage or terminal cost)/d(state) for states [N,S] -> [N,S]."""
         e = self.env
         k = self._k()
+        if self.quad:
+            z0 = np.zeros_like(states[:, 0])
+            gx = f32(2.0) * k["pos_c"] * (states[:, 0] - f32(e.target_x))
+            gz = f32(2.0) * k["pos_c"] * (states[:, 2] - f32(e.target_z))
+            gth = f32(e.ang_weight) * np.sin(states[:, 4])
+            if terminal:
+                w = f32(e.terminal_weight)
+                return np.stack([w * gx, z0, w * gz, z0, w * gth, z0], 1).astype(np.float32)
+            return np.stack([gx, f32(2.0) * f32(e.vel_weight) * states[:, 1], gz, f32(2.0) * f32(e.vel_weight) * states[:, 3],
+                             gth, f32(2.0) * f32(e.angvel_weight) * states[:, 5]], 1).astype(np.float32)
         x, th, om = states[:, 0], states[:, 2], states[:, 3]
         gx = f32(2.0) * f32(e.dd_weight) * k["inv_xs"] * k["inv_xs"] * (x - f32(e.target_position))
         gth = f32(2.0) * k["ep_c"] * (f32(1.0) - np.cos(th)) * np.sin(th)
@@ -384,6 +551,16 @@ class Cost:
             return np.stack([w * gx, np.zeros_like(gx), w * gth, np.zeros_like(gx)], 1).astype(np.float32)
         gom = f32(2.0) * f32(e.ekp_weight) * om
         return np.stack([gx, np.zeros_like(gx), gth, gom], 1).astype(np.float32)
+
+
+def input_cost_grad(cost: "Cost", Q, u_prev):
+    """d(sum_h stage cost)/dQ through the input-only terms (cc; ccrc towards both neighbours) [N,H,C]; both
+    environments share the form ccR*|u|^2 + ccrc_weight*|u - u_prev|^2."""
+    k, e = cost._k(), cost.env
+    prev = cost._prev_inputs(Q, u_prev)
+    gu = f32(2.0) * k["ccR"] * Q + f32(2.0) * f32(e.ccrc_weight) * (Q - prev)
+    gu[:, :-1, :] -= f32(2.0) * f32(e.ccrc_weight) * (Q[:, 1:, :] - Q[:, :-1, :])
+    return gu.astype(np.float32)
 
 
 def aggregate_trajectory_cost(stage_costs: np.ndarray, terminal_cost: np.ndarray) -> np.ndarray:
@@ -442,6 +619,21 @@ def interpolation_table(horizon: int, period: int):
     return i0, w0, w1
 
 
+def _limits(low, high, C):
+    """control limits as fp32 arrays [C] (the reference's action_low / action_high, Optimizers/__init__.py:42-44)"""
+    lo = np.broadcast_to(np.asarray(low, np.float32).reshape(-1), (C,)).astype(np.float32)
+    hi = np.broadcast_to(np.asarray(high, np.float32).reshape(-1), (C,)).astype(np.float32)
+    if C == 1:
+        return f32(lo[0]), f32(hi[0])      # scalars keep the C = 1 arithmetic (and its fixtures) bit-identical
+    return lo, hi
+
+
+def _u_out(x):
+    """the optimizer's `u`: fp32 scalar for one control input, [C] array otherwise"""
+    x = np.asarray(x, np.float32).reshape(-1)
+    return f32(x[0]) if x.size == 1 else x.copy()
+
+
 # ----------------------------------------------------------------------------------------------
 # MPPI (Optimizers/optimizer_mppi.py)
 # ----------------------------------------------------------------------------------------------
@@ -451,19 +643,20 @@ class MPPI:
                  period_interpolation_inducing_points=10):
         self.predictor, self.cost = predictor, cost
         self.N, self.H = num_rollouts, mpc_horizon
-        self.low, self.high = f32(low), f32(high)
+        self.S, self.C = predictor.S, predictor.C
+        self.low, self.high = _limits(low, high, self.C)
         self.cc_weight, self.R, self.LBD, self.NU = f32(cc_weight), f32(R), float(LBD), f32(NU)
         self.period = period_interpolation_inducing_points
         self.P = num_inducing_points(self.H, self.period)
-        self.M = interpolation_matrix(self.H, self.period, 1)
+        self.M = interpolation_matrix(self.H, self.period, self.C)
         # optimizer_mppi.py:130 — computed in double, stored as fp32
         self.stdev = f32(np.array(SQRTRHOINV) * (1 / np.sqrt(predictor.dt)))
-        self.u = f32(0.0)
+        self.u = _u_out(np.zeros(self.C, np.float32))
         self.optimizer_reset()
 
     def optimizer_reset(self):
         # optimizer_mppi.py:227-231
-        self.u_nom = (f32(0.5) * (self.low + self.high) * np.ones((1, self.H, 1), np.float32)).astype(np.float32)
+        self.u_nom = (f32(0.5) * (self.low + self.high) * np.ones((1, self.H, self.C), np.float32)).astype(np.float32)
 
     def mppi_correction_cost(self, u, delta_u):
         # optimizer_mppi.py:154-155 (u = clipped input, delta_u = unclipped perturbation)
@@ -481,19 +674,19 @@ class MPPI:
 
     def step(self, s: np.ndarray, noise: np.ndarray):
         """One MPPI iteration, optimizer_mppi.py:181-193 + :205-225.
-        noise = standard-normal draws [N,P,1] (what rng.normal returns at :173-175)."""
+        noise = standard-normal draws [N,P,C] (what rng.normal returns at :173-175)."""
         N, H = self.N, self.H
-        s = np.asarray(s, np.float32).reshape(1, 4)
+        s = np.asarray(s, np.float32).reshape(1, self.S)
         s_t = np.tile(s, (N, 1))                                                 # :182
         u_nom = np.concatenate([self.u_nom[:, 1:, :], self.u_nom[:, -1:, :]], 1)  # :184
         delta_u = interpolate(np.asarray(noise, np.float32) * self.stdev, self.M)  # :170-179
         u_run = np.clip(np.tile(u_nom, (N, 1, 1)) + delta_u, self.low, self.high)  # :186-187
         traj = self.predictor.predict_core(s_t, u_run)                           # :188
-        J = self.cost.get_trajectory_cost(traj, u_run, np.array([self.u], np.float32)) \
+        J = self.cost.get_trajectory_cost(traj, u_run, np.asarray(self.u, np.float32).reshape(self.C)) \
             + self.mppi_correction_cost(u_run, delta_u)                          # :158-161
         u_nom = np.clip(u_nom + self.reward_weighted_average(J, delta_u), self.low, self.high)  # :190
         self.u_nom = u_nom.astype(np.float32)
-        self.u = f32(u_nom[0, 0, 0])                                             # :191
+        self.u = _u_out(u_nom[0, 0, :])                                          # :191
         self.predictor.update(s, self.u)                                         # :192,:195-197 (RNN hidden state)
         self.J, self.u_run, self.rollout_trajectories, self.delta_u = J, u_run, traj, delta_u
         return np.array(self.u, dtype=np.float32)
@@ -532,7 +725,8 @@ class CEM:
                  warmup_iterations=250):
         self.predictor, self.cost = predictor, cost
         self.N, self.H = num_rollouts, mpc_horizon
-        self.low, self.high = f32(low), f32(high)
+        self.S, self.C = predictor.S, predictor.C
+        self.low, self.high = _limits(low, high, self.C)
         self.cem_outer_it, self.K = cem_outer_it, cem_best_k
         self.init_std, self.std_min = f32(cem_initial_action_stdev), f32(cem_stdev_min)
         self.warmup, self.warmup_iterations = warmup, warmup_iterations
@@ -540,10 +734,10 @@ class CEM:
 
     def optimizer_reset(self):
         # optimizer_cem_tf.py:113-117
-        self.dist_mue = ((self.low + self.high) * f32(0.5) * np.ones((1, self.H, 1), np.float32)).astype(np.float32)
-        self.stdev = (self.init_std * np.ones((1, self.H, 1), np.float32)).astype(np.float32)
+        self.dist_mue = ((self.low + self.high) * f32(0.5) * np.ones((1, self.H, self.C), np.float32)).astype(np.float32)
+        self.stdev = (self.init_std * np.ones((1, self.H, self.C), np.float32)).astype(np.float32)
         self.count = 0
-        self.u = f32(0.0)
+        self.u = _u_out(np.zeros(self.C, np.float32))
 
     def iterations(self):
         return self.warmup_iterations if (self.warmup and self.count == 0) else self.cem_outer_it  # :92
@@ -552,7 +746,7 @@ class CEM:
         # optimizer_cem_tf.py:61-80
         Q = np.clip(np.tile(self.dist_mue, (self.N, 1, 1)) + noise * self.stdev, self.low, self.high)
         traj = self.predictor.predict_core(s_t, Q)
-        J = self.cost.get_trajectory_cost(traj, Q, np.array([self.u], np.float32))
+        J = self.cost.get_trajectory_cost(traj, Q, np.asarray(self.u, np.float32).reshape(self.C))
         best = argsort_total_order(J)[: self.K]
         elite = Q[best]
         self.dist_mue = np.mean(elite, axis=0, keepdims=True, dtype=np.float32)
@@ -561,18 +755,18 @@ class CEM:
         return Q, elite, J, traj, best
 
     def step(self, s, noise):
-        """noise: standard normal [iterations, N, H, 1] (rng.normal at :64-65, one draw per outer it)."""
-        s_t = np.tile(np.asarray(s, np.float32).reshape(1, 4), (self.N, 1))
+        """noise: standard normal [iterations, N, H, C] (rng.normal at :64-65, one draw per outer it)."""
+        s_t = np.tile(np.asarray(s, np.float32).reshape(1, self.S), (self.N, 1))
         its = self.iterations()
         assert noise.shape[0] == its
         for it in range(its):
             Q, elite, J, traj, best = self.update_distribution(s_t, np.asarray(noise[it], np.float32))
         # :99-102
         self.stdev = np.clip(self.stdev, self.std_min, f32(1.0e8))
-        self.stdev = np.concatenate([self.stdev[:, 1:, :], self.init_std * np.ones((1, 1, 1), np.float32)], 1)
-        self.u = f32(elite[0, 0, 0])
+        self.stdev = np.concatenate([self.stdev[:, 1:, :], self.init_std * np.ones((1, 1, self.C), np.float32)], 1)
+        self.u = _u_out(elite[0, 0, :])
         self.dist_mue = np.concatenate(
-            [self.dist_mue[:, 1:, :], (self.low + self.high) * f32(0.5) * np.ones((1, 1, 1), np.float32)], 1)
+            [self.dist_mue[:, 1:, :], ((self.low + self.high) * f32(0.5) * np.ones((1, 1, self.C), np.float32)).astype(np.float32)], 1)
         self.Q, self.J, self.rollout_trajectories, self.best_idx = Q, J, traj, best
         self.count += 1
         return np.array(self.u, np.float32)
@@ -585,20 +779,21 @@ class RandomAction:
     def __init__(self, predictor, cost, low=-1.0, high=1.0, *, num_rollouts, mpc_horizon):
         self.predictor, self.cost = predictor, cost
         self.N, self.H = num_rollouts, mpc_horizon
-        self.low, self.high = f32(low), f32(high)
-        self.u = f32(0.0)
+        self.S, self.C = predictor.S, predictor.C
+        self.low, self.high = _limits(low, high, self.C)
+        self.u = _u_out(np.zeros(self.C, np.float32))
 
     def optimizer_reset(self):
         pass  # :78-86 draws and discards a sample; no state
 
     def step(self, s, u01):
-        """u01: U[0,1) draws [N,H,1]; rng.uniform(minval, maxval) = u01*(max-min)+min (:56-61)."""
-        s_t = np.tile(np.asarray(s, np.float32).reshape(1, 4), (self.N, 1))
+        """u01: U[0,1) draws [N,H,C]; rng.uniform(minval, maxval) = u01*(max-min)+min (:56-61)."""
+        s_t = np.tile(np.asarray(s, np.float32).reshape(1, self.S), (self.N, 1))
         Q = (np.asarray(u01, np.float32) * (self.high - self.low) + self.low).astype(np.float32)
         traj = self.predictor.predict_core(s_t, Q)
-        J = self.cost.get_trajectory_cost(traj, Q, np.array([self.u], np.float32))  # :43-45
+        J = self.cost.get_trajectory_cost(traj, Q, np.asarray(self.u, np.float32).reshape(self.C))  # :43-45
         best = argsort_total_order(J)[0]                                            # :65-66
-        self.u = f32(Q[best, 0, 0])                                                 # :68
+        self.u = _u_out(Q[best, 0, :])                                              # :68
         self.Q, self.J, self.rollout_trajectories, self.best_idx = Q, J, traj, best
         return np.array(self.u, np.float32)
 
@@ -608,25 +803,19 @@ class RandomAction:
 # ----------------------------------------------------------------------------------------------
 def rollout_cost_and_grad(predictor: Predictor, cost: Cost, s_t, Q, u_prev):
     """Forward rollout + hand-written reverse-mode of J.sum() w.r.t. Q (what autograd does at
-    optimizer_rpgd.py:310-314 / :329-333).  Returns (J[N], traj[N,H+1,4], dJ/dQ[N,H,1])."""
-    N, H, _ = Q.shape
+    optimizer_rpgd.py:310-314 / :329-333).  Returns (J[N], traj[N,H+1,S], dJ/dQ[N,H,C])."""
+    N, H, C = Q.shape
     traj = predictor.predict_core(s_t, Q)
     J = cost.get_trajectory_cost(traj, Q, u_prev)
-    e = cost.env
-    k = derived_constants(e, cost.dt, 1)
     inv = f32(1.0 / (H + 1))   # mean over H+1, Cost_Functions/__init__.py:92
-    u = Q[:, :, 0]
-    prev = np.concatenate([np.broadcast_to(np.asarray(u_prev, np.float32).reshape(1, 1), (N, 1)), u[:, :-1]], 1)
-    # direct input-cost gradient: cc + ccrc (both neighbours)
-    gu = f32(2.0) * k["ccR"] * u + f32(2.0) * f32(e.ccrc_weight) * (u - prev)
-    gu[:, :-1] -= f32(2.0) * f32(e.ccrc_weight) * (u[:, 1:] - u[:, :-1])
-    g = np.zeros((N, H), np.float32)
+    gu = input_cost_grad(cost, Q, u_prev)   # direct input-cost gradient: cc + ccrc (both neighbours)
+    g = np.zeros((N, H, C), np.float32)
     lam = cost.state_grad(traj[:, H], terminal=True) * inv
     for h in range(H - 1, -1, -1):
-        ls, gq = predictor.step_vjp(traj[:, h], u[:, h], lam)
-        g[:, h] = gu[:, h] * inv + gq
+        ls, gq = predictor.step_vjp(traj[:, h], Q[:, h, :], lam)
+        g[:, h, :] = gu[:, h, :] * inv + gq
         lam = cost.state_grad(traj[:, h], terminal=False) * inv + ls
-    return J, traj, g[:, :, None].astype(np.float32)
+    return J, traj, g.astype(np.float32)
 
 
 def clip_by_norm(g, clip, axes=(1, 2)):
@@ -667,7 +856,8 @@ class RPGD:
                  adam_beta_2=0.999, adam_epsilon=1e-8):
         self.predictor, self.cost = predictor, cost
         self.N, self.H = num_rollouts, mpc_horizon
-        self.low, self.high = f32(low), f32(high)
+        self.S, self.C = predictor.S, predictor.C
+        self.low, self.high = _limits(low, high, self.C)
         self.outer_its = outer_its
         self.sample_stdev, self.sample_mean = f32(sample_stdev), f32(sample_mean)
         if sample_whole_control_space:                      # optimizer_rpgd.py:200-206
@@ -677,17 +867,17 @@ class RPGD:
         self.resamp_per = resamp_per
         self.period = period_interpolation_inducing_points
         self.P = num_inducing_points(self.H, self.period)
-        self.M = interpolation_matrix(self.H, self.period, 1)
+        self.M = interpolation_matrix(self.H, self.period, self.C)
         self.dist = SAMPLING_DISTRIBUTION
         self.shift_previous = shift_previous
         self.first_iter_count = warmup_iterations if warmup else outer_its   # :219-221
         self.k = int(max(int(num_rollouts * opt_keep_k_ratio), 1))           # :213
         self.gradmax_clip = f32(gradmax_clip)
         self.opt = Adam(learning_rate, adam_beta_1, adam_beta_2, adam_epsilon)
-        self.u = f32(0.0)
+        self.u = _u_out(np.zeros(self.C, np.float32))
 
     def sample_actions(self, draws):
-        """optimizer_rpgd.py:275-296.  draws [B,P,1]: standard normal (normal) or U[0,1) (uniform)."""
+        """optimizer_rpgd.py:275-296.  draws [B,P,C]: standard normal (normal) or U[0,1) (uniform)."""
         d = np.asarray(draws, np.float32)
         if self.dist == "normal":
             Qn = d * self.sample_stdev + self.sample_mean
@@ -701,29 +891,29 @@ class RPGD:
     def optimizer_reset(self, draws):
         # optimizer_rpgd.py:527-548
         self.Q = self.sample_actions(draws)
-        assert self.Q.shape == (self.N, self.H, 1)
+        assert self.Q.shape == (self.N, self.H, self.C)
         self.count = 0
         self.opt.reset()
         self.trajectory_ages = np.zeros((self.N,), np.float32)
 
     def grad_step(self, s_t):
         # optimizer_rpgd.py:329-338
-        J, _, g = rollout_cost_and_grad(self.predictor, self.cost, s_t, self.Q, np.array([self.u], np.float32))
+        J, _, g = rollout_cost_and_grad(self.predictor, self.cost, s_t, self.Q, np.asarray(self.u, np.float32).reshape(self.C))
         g = clip_by_norm(g, self.gradmax_clip)
         Qn = self.opt.apply(g, self.Q)
         self.Q = np.clip(Qn, self.low, self.high).astype(np.float32)
         return J
 
     def step(self, s, resample_draws=None):
-        """optimizer_rpgd.py:388-524.  resample_draws [N-k,P,1] is consumed when count % resamp_per == 0."""
-        N, k = self.N, self.k
-        s_t = np.tile(np.asarray(s, np.float32).reshape(1, 4), (N, 1))
+        """optimizer_rpgd.py:388-524.  resample_draws [N-k,P,C] is consumed when count % resamp_per == 0."""
+        N, k, C = self.N, self.k, self.C
+        s_t = np.tile(np.asarray(s, np.float32).reshape(1, self.S), (N, 1))
         iters = self.first_iter_count if self.count == 0 else self.outer_its   # :397-400
         for _ in range(iters):
             self.grad_step(s_t)                                                # :404-406
         # get_action, :340-380
         traj = self.predictor.predict_core(s_t, self.Q)
-        J = self.cost.get_trajectory_cost(traj, self.Q, np.array([self.u], np.float32))
+        J = self.cost.get_trajectory_cost(traj, self.Q, np.asarray(self.u, np.float32).reshape(C))
         best_idx = argsort_total_order(J)[:k]
         sp = self.shift_previous
         Qn = np.concatenate([self.Q[:, sp:, :], np.tile(self.Q[:, -1:, :], (1, sp, 1))], axis=1)
@@ -731,14 +921,14 @@ class RPGD:
         m, v = self.opt.m, self.opt.v
         if m is None:   # iters == 0 never happens in practice; keep the oracle total
             m, v = np.zeros_like(self.Q), np.zeros_like(self.Q)
-        shift1 = lambda a: np.concatenate([a[:, 1:, :], np.zeros((a.shape[0], 1, 1), np.float32)], 1)
+        shift1 = lambda a: np.concatenate([a[:, 1:, :], np.zeros((a.shape[0], 1, C), np.float32)], 1)
         if self.count % self.resamp_per == 0:                                  # :449-495
             Qres = self.sample_actions(resample_draws)
             assert Qres.shape[0] == N - k
             Qn = np.concatenate([Qres, Qn[best_idx]], 0)
             self.trajectory_ages = np.concatenate([np.zeros((N - k,), np.float32), self.trajectory_ages[best_idx]], 0)
-            m = np.concatenate([np.zeros((N - k, self.H, 1), np.float32), shift1(m[best_idx])], 0)
-            v = np.concatenate([np.zeros((N - k, self.H, 1), np.float32), shift1(v[best_idx])], 0)
+            m = np.concatenate([np.zeros((N - k, self.H, C), np.float32), shift1(m[best_idx])], 0)
+            v = np.concatenate([np.zeros((N - k, self.H, C), np.float32), shift1(v[best_idx])], 0)
         else:                                                                  # :496-513
             m, v = shift1(m), shift1(v)
         self.opt.m, self.opt.v = m.astype(np.float32), v.astype(np.float32)
@@ -747,7 +937,7 @@ class RPGD:
         self.Q = Qn.astype(np.float32)                                         # :515
         self.count += 1
         self.u_nom, self.J, self.rollout_trajectories, self.best_idx = u_nom, J, traj, best_idx
-        self.u = f32(u_nom[0, 0, 0])                                           # :523
+        self.u = _u_out(u_nom[0, 0, :])                                        # :523
         return np.array(self.u, np.float32)
 
 
@@ -841,38 +1031,39 @@ class GradientTF:
                  warmup=False, warmup_iterations=250):
         self.predictor, self.cost = predictor, cost
         self.N, self.H = num_rollouts, mpc_horizon
-        self.low, self.high = f32(low), f32(high)
+        self.S, self.C = predictor.S, predictor.C
+        self.low, self.high = _limits(low, high, self.C)
         self.gradient_steps = gradient_steps
         self.first_iter_count = warmup_iterations if warmup else gradient_steps     # :66-69
         self.gradmax_clip = f32(gradmax_clip)
         self.opt = KerasAdam(learning_rate, adam_beta_1, adam_beta_2, adam_epsilon)
-        self.u = f32(0.0)
+        self.u = _u_out(np.zeros(self.C, np.float32))
 
     def optimizer_reset(self, u01):
         # :174-185: uniform plans over the whole horizon, Adam weights zeroed
         self.Q = np.clip(np.asarray(u01, np.float32) * (self.high - self.low) + self.low, self.low, self.high).astype(np.float32)
-        assert self.Q.shape == (self.N, self.H, 1)
+        assert self.Q.shape == (self.N, self.H, self.C)
         self.count = 0
         self.opt.reset()
 
     def step(self, s, tail_u01):
         """tail_u01 [N,1,1]: the U[0,1) draws behind rng.uniform([N,1,C], low, high) at :137-142."""
-        s_t = np.tile(np.asarray(s, np.float32).reshape(1, 4), (self.N, 1))
+        s_t = np.tile(np.asarray(s, np.float32).reshape(1, self.S), (self.N, 1))
         iters = self.first_iter_count if self.count == 0 else self.gradient_steps          # :108-112
         for _ in range(iters):                                                             # :116-118, :82-98
-            _, _, g = rollout_cost_and_grad(self.predictor, self.cost, s_t, self.Q, np.array([self.u], np.float32))
+            _, _, g = rollout_cost_and_grad(self.predictor, self.cost, s_t, self.Q, np.asarray(self.u, np.float32).reshape(self.C))
             g = clip_by_norm(g, self.gradmax_clip)
             self.Q = np.clip(self.opt.apply(g, self.Q), self.low, self.high).astype(np.float32)
         traj = self.predictor.predict_core(s_t, self.Q)                                    # :127
-        J = self.cost.get_trajectory_cost(traj, self.Q, np.array([self.u], np.float32))
+        J = self.cost.get_trajectory_cost(traj, self.Q, np.asarray(self.u, np.float32).reshape(self.C))
         best = argsort_total_order(J)[0]                                                   # :130-131
-        self.u = f32(self.Q[best, 0, 0])                                                   # :133
+        self.u = _u_out(self.Q[best, 0, :])                                                   # :133
         self.J, self.Q_refined, self.best_idx = J, self.Q.copy(), best
         self.count += 1
-        Q_s = (np.asarray(tail_u01, np.float32).reshape(self.N, 1, 1) * (self.high - self.low) + self.low).astype(np.float32)
+        Q_s = (np.asarray(tail_u01, np.float32).reshape(self.N, 1, self.C) * (self.high - self.low) + self.low).astype(np.float32)
         self.Q = np.concatenate([self.Q[:, 1:, :], Q_s], axis=1)                            # :143-144
         if self.opt.m is not None:                                                         # :146-166
-            z = np.zeros((self.N, 1, 1), np.float32)
+            z = np.zeros((self.N, 1, self.C), np.float32)
             self.opt.m = np.concatenate([self.opt.m[:, 1:, :], z], 1)
             self.opt.v = np.concatenate([self.opt.v[:, 1:, :], z], 1)
         return np.array(self.u, np.float32)
@@ -884,22 +1075,23 @@ class CEMNaiveGrad:
                  cem_initial_action_stdev=0.5, cem_stdev_min=0.1, cem_best_k=40, learning_rate=0.1, gradmax_clip=10.0):
         self.predictor, self.cost = predictor, cost
         self.N, self.H = num_rollouts, mpc_horizon
-        self.low, self.high = f32(low), f32(high)
+        self.S, self.C = predictor.S, predictor.C
+        self.low, self.high = _limits(low, high, self.C)
         self.cem_outer_it, self.K = cem_outer_it, cem_best_k
         self.init_std, self.std_min = f32(cem_initial_action_stdev), f32(cem_stdev_min)
         self.lr, self.gradmax_clip = f32(learning_rate), f32(gradmax_clip)
-        self.u = f32(0.0)
+        self.u = _u_out(np.zeros(self.C, np.float32))
         self.optimizer_reset()
 
     def optimizer_reset(self):
         # :117-119
-        self.dist_mue = ((self.low + self.high) * f32(0.5) * np.ones((1, self.H, 1), np.float32)).astype(np.float32)
-        self.stdev = (self.init_std * np.ones((1, self.H, 1), np.float32)).astype(np.float32)
+        self.dist_mue = ((self.low + self.high) * f32(0.5) * np.ones((1, self.H, self.C), np.float32)).astype(np.float32)
+        self.stdev = (self.init_std * np.ones((1, self.H, self.C), np.float32)).astype(np.float32)
 
     def step(self, s, noise):
         """noise: standard normal [cem_outer_it, N, H, 1] (rng.normal at :60-61, one draw per outer iteration)."""
-        s_t = np.tile(np.asarray(s, np.float32).reshape(1, 4), (self.N, 1))
-        up = np.array([self.u], np.float32)
+        s_t = np.tile(np.asarray(s, np.float32).reshape(1, self.S), (self.N, 1))
+        up = np.asarray(self.u, np.float32).reshape(self.C)
         for it in range(self.cem_outer_it):                                                # :96-97
             Q = np.clip(np.tile(self.dist_mue, (self.N, 1, 1)) + np.asarray(noise[it], np.float32) * self.stdev,
                         self.low, self.high).astype(np.float32)                           # :60-62
@@ -912,10 +1104,10 @@ class CEMNaiveGrad:
             self.dist_mue = np.mean(elite, axis=0, keepdims=True, dtype=np.float32)        # :82-83
             self.stdev = np.sqrt(np.mean((elite - self.dist_mue) ** 2, axis=0, keepdims=True, dtype=np.float32)).astype(np.float32)
         self.stdev = np.clip(self.stdev, self.std_min, f32(10.0))                          # :101
-        self.stdev = np.concatenate([self.stdev[:, 1:, :], self.init_std * np.ones((1, 1, 1), np.float32)], 1)   # :102
-        self.u = f32(self.dist_mue[0, 0, 0])                                               # :103 — the MEAN's first input
+        self.stdev = np.concatenate([self.stdev[:, 1:, :], self.init_std * np.ones((1, 1, self.C), np.float32)], 1)   # :102
+        self.u = _u_out(self.dist_mue[0, 0, :])                                               # :103 — the MEAN's first input
         self.dist_mue = np.concatenate(
-            [self.dist_mue[:, 1:, :], (self.low + self.high) * f32(0.5) * np.ones((1, 1, 1), np.float32)], 1)   # :104
+            [self.dist_mue[:, 1:, :], (self.low + self.high) * f32(0.5) * np.ones((1, 1, self.C), np.float32)], 1)   # :104
         self.Q, self.J, self.best_idx = Qn, J, best
         return np.array(self.u, np.float32)
 
@@ -929,18 +1121,19 @@ class CEMGradBharadhwaj:
                  adam_beta_2=0.999, adam_epsilon=1e-8, gradmax_clip=5.0, warmup=False, warmup_iterations=250):
         self.predictor, self.cost = predictor, cost
         self.N, self.H = num_rollouts, mpc_horizon
-        self.low, self.high = f32(low), f32(high)
+        self.S, self.C = predictor.S, predictor.C
+        self.low, self.high = _limits(low, high, self.C)
         self.cem_outer_it, self.K = cem_outer_it, cem_best_k
         self.init_std, self.std_min = f32(cem_initial_action_stdev), f32(cem_stdev_min)
         self.gradmax_clip = f32(gradmax_clip)
         self.warmup, self.warmup_iterations = warmup, warmup_iterations
         self.opt = KerasAdam(learning_rate, adam_beta_1, adam_beta_2, adam_epsilon)
-        self.u = f32(0.0)
+        self.u = _u_out(np.zeros(self.C, np.float32))
         self.optimizer_reset()
 
     def optimizer_reset(self):
-        self.dist_mue = ((self.low + self.high) * f32(0.5) * np.ones((1, self.H, 1), np.float32)).astype(np.float32)
-        self.stdev = (self.init_std * np.ones((1, self.H, 1), np.float32)).astype(np.float32)
+        self.dist_mue = ((self.low + self.high) * f32(0.5) * np.ones((1, self.H, self.C), np.float32)).astype(np.float32)
+        self.stdev = (self.init_std * np.ones((1, self.H, self.C), np.float32)).astype(np.float32)
         self.count = 0
 
     def iterations(self):
@@ -951,8 +1144,8 @@ class CEMGradBharadhwaj:
 
     def step(self, s, eps_elite, eps_rest):
         """eps_elite [K,H,1] (:158), eps_rest [iterations, N-K, H, 1] (:94): standard normal draws."""
-        s_t = np.tile(np.asarray(s, np.float32).reshape(1, 4), (self.N, 1))
-        up = np.array([self.u], np.float32)
+        s_t = np.tile(np.asarray(s, np.float32).reshape(1, self.S), (self.N, 1))
+        up = np.asarray(self.u, np.float32).reshape(self.C)
         elite_Q = self._sample(eps_elite)                                                   # :158
         for it in range(self.iterations()):                                                 # :162-163
             Q = np.clip(np.concatenate([elite_Q, self._sample(eps_rest[it])], 0), self.low, self.high).astype(np.float32)   # :94-96
@@ -965,12 +1158,12 @@ class CEMGradBharadhwaj:
             elite_Q = Qn[best]
             self.dist_mue = np.mean(elite_Q, axis=0, keepdims=True, dtype=np.float32)       # :119-120
             self.stdev = np.sqrt(np.mean((elite_Q - self.dist_mue) ** 2, axis=0, keepdims=True, dtype=np.float32)).astype(np.float32)
-        self.u = f32(elite_Q[0, 0, 0])                                                      # :167
+        self.u = _u_out(elite_Q[0, 0, :])                                                      # :167
         # apply_time_delta :130-141
         self.dist_mue = np.concatenate(
-            [self.dist_mue[:, 1:, :], (self.low + self.high) * f32(0.5) * np.ones((1, 1, 1), np.float32)], 1)
+            [self.dist_mue[:, 1:, :], (self.low + self.high) * f32(0.5) * np.ones((1, 1, self.C), np.float32)], 1)
         self.stdev = np.clip(self.stdev, self.std_min, f32(10.0))
-        self.stdev = np.concatenate([self.stdev[:, 1:, :], self.init_std * np.ones((1, 1, 1), np.float32)], 1)
+        self.stdev = np.concatenate([self.stdev[:, 1:, :], self.init_std * np.ones((1, 1, self.C), np.float32)], 1)
         self.Q, self.J, self.best_idx = Qn, J, best
         self.count += 1
         return np.array(self.u, np.float32)

@@ -39,8 +39,9 @@ def main():
     ap.add_argument("--commit", default="unknown"); ap.add_argument("--out", required=True)
     a = ap.parse_args()
     import bench
-    f, nf = mean_counter(a.fetch, "FETCH_SIZE", a.kernel.split("(")[0])
-    w, nw = mean_counter(a.write, "WRITE_SIZE", a.kernel.split("(")[0])
+    prefix = a.kernel.split("(")[0].rstrip(">")     # rocprofv3 prints every template argument: "ctk_mppi_rollout<0, false, false>"
+    f, nf = mean_counter(a.fetch, "FETCH_SIZE", prefix)
+    w, nw = mean_counter(a.write, "WRITE_SIZE", prefix)
     rec = {"workload": a.workload, "samples": a.samples, "kernel": a.kernel, "commit": a.commit,
            "source_sha256": bench.kernel_source_digest(), "fetch_size_kib": round(f, 3), "write_size_kib": round(w, 3),
            "dispatches": [nf, nw],
