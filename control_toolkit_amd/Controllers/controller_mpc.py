@@ -36,8 +36,8 @@ class controller_mpc(template_controller):
             self._config_optimizers = load_yaml(os.path.join("Control_Toolkit_ASF", "config_optimizers.yml"))
         opt_cfg = self._config_optimizers[optimizer_name]
         dt = opt_cfg["mpc_timestep"]                                              # :69,:85
-        self.cost_function = self._cost_function if self._cost_function is not None else CostFunctionWrapper()   # :40
-        self.predictor = self._predictor if self._predictor is not None else PredictorWrapper()                   # :43
+        self.cost_function = self._cost_function if self._cost_function is not None else CostFunctionWrapper(environment_name=self.environment_name)   # :40
+        self.predictor = self._predictor if self._predictor is not None else PredictorWrapper(environment_name=self.environment_name)                   # :43
         self.optimizer = self._make_optimizer(optimizer_name, opt_cfg)            # :56-65
         N, H = self.optimizer.num_rollouts, self.optimizer.mpc_horizon
         shared = dict(computation_library=self.computation_library, variable_parameters=self.variable_parameters)

@@ -5,12 +5,35 @@ import numpy as np
 
 from ..computation_library import ComputationLibrary, HipLibrary
 from ..others.globals_and_utils import create_rng
-from .._capi import CtkEngine, PARAMS
+from .._capi import CtkEngine, ENVIRONMENTS, environment_info
+
+
+def predictor_kind(predictor_specification) -> str:
+    """'ODE' | 'MLP' | 'GRU' from a predictor_specification string (reference controller_mpc.py:67-73; network names follow
+    the convention 'GRU-6IN-32H1-32H2-5OUT-0', Control_Toolkit_ASF_Template/config_controllers.yml:8)."""
+    spec = "ODE" if predictor_specification in (None, "") else str(predictor_specification)
+    up = spec.upper()
+    if up.startswith("ODE"):
+        return "ODE"
+    if up.startswith("GRU"):
+        return "GRU"
+    if up.startswith("MLP") or up.startswith("DENSE"):
+        return "MLP"
+    raise NotImplementedError(f"predictor_specification {spec!r}: only 'ODE', 'MLP' / 'Dense' and 'GRU' networks are built")
+
+
+def caller_side_library_ok(lib) -> bool:
+    """The HIP optimizers compute in the kernels; of the computation library they only use what the CALLER side touches
+    (to_tensor / to_numpy / float32).  Besides HipLibrary any NumPy-semantics library object does — in particular SI_Toolkit's
+    NumpyLibrary, which is what the reference's template_controller builds for `computation_library: numpy`
+    (Controllers/__init__.py:55-56), so the unmodified reference controller can drive these optimizers."""
+    return isinstance(lib, HipLibrary) or str(getattr(lib, "lib", "")).lower() in ("hip", "numpy")
 
 
 def logging_kwargs(kwargs: dict) -> dict:
     """the optional YAML keys of this build that every optimizer forwards to template_optimizer"""
-    return {k: kwargs[k] for k in ("logging_on_device", "logging_capacity") if k in kwargs}
+    return {k: kwargs[k] for k in ("logging_on_device", "logging_capacity", "environment_name", "generic_kernels",
+                                   "predictor_parameters", "predictor_weights_file", "predictor_intermediate_steps") if k in kwargs}
 
 
 class DeviceLogEntry:
@@ -58,7 +81,7 @@ class template_optimizer:
                  calculate_optimal_trajectory: bool = False, logging_on_device: bool = False,
                  logging_capacity: int = 4096, **kwargs) -> None:
         # reference :27-28
-        if not isinstance(computation_library, self.supported_computation_libraries):
+        if not (isinstance(computation_library, self.supported_computation_libraries) or caller_side_library_ok(computation_library)):
             raise ValueError(f"The optimizer {self.__class__.__name__} does not support "
                              f"{getattr(computation_library, 'lib', computation_library)}")
         self.lib = computation_library
@@ -82,6 +105,9 @@ class template_optimizer:
         self.logging_capacity = int(logging_capacity)
         self.calculate_optimal_trajectory = bool(calculate_optimal_trajectory)
         self.device = device
+        # optional keys of this build in the optimizer's YAML entry (swallowed by **kwargs in the reference's ctor too)
+        self._engine_options = {k: kwargs[k] for k in ("environment_name", "generic_kernels", "predictor_parameters",
+                                                       "predictor_weights_file", "predictor_intermediate_steps") if k in kwargs}
         self.engine: CtkEngine = None
         self._param_cache = {}
         self._cost_version = None
@@ -135,60 +161,119 @@ class template_optimizer:
 
     # ---- engine plumbing shared by the *_hip optimizers --------------------------------------
     def _limits(self):
+        """control_limits as fp32 arrays [C] (reference Optimizers/__init__.py:42-44 keeps them as tensors of that shape)"""
+        C = int(self.num_control_inputs)
         lo = np.asarray(self.action_low, np.float32).reshape(-1)
         hi = np.asarray(self.action_high, np.float32).reshape(-1)
-        if lo.size != 1 or hi.size != 1:
-            raise NotImplementedError("only num_control_inputs == 1 is built")
-        return float(lo[0]), float(hi[0])
+        if lo.size not in (1, C) or hi.size not in (1, C):
+            raise ValueError(f"control_limits must have {C} entries (num_control_inputs), got {lo.size} / {hi.size}")
+        return np.broadcast_to(lo, (C,)).copy(), np.broadcast_to(hi, (C,)).copy()
+
+    def _resolve_environment(self) -> str:
+        """Which built environment the caller means: cost_function.environment_name is what controller_mpc hands the
+        cost wrapper (reference controller_mpc.py:75-82); the predictor may name it too; the optimizer's YAML entry may
+        pin it (`environment_name:`).  Names are matched case-insensitively on their stem."""
+        name = (self._engine_options.get("environment_name") or getattr(self.cost_function, "environment_name", None)
+                or getattr(self.predictor, "environment_name", None) or "CartPole")
+        stem = str(name).replace("-", "").replace("_", "").lower()
+        for built in ENVIRONMENTS:
+            if stem.startswith(built.lower()):
+                return built
+        raise NotImplementedError(f"environment {name!r} is not built into libctk_hip.so (have: {sorted(ENVIRONMENTS)})")
+
+    def _resolve_predictor(self, dt, predictor_specification):
+        """(kind, intermediate_steps, weights) from whatever predictor object the controller passed in.  The build's own
+        PredictorWrapper carries them; for a reference-shaped one (SI_Toolkit's PredictorWrapper: configured with
+        predictor_specification, exposes num_states / num_control_inputs) the kind comes from the specification string
+        and weights / sub-steps from the optimizer's own YAML entry (`predictor_weights_file`, `predictor_intermediate_steps`)
+        — the rollout itself lives in the kernels, so nothing else of that object is needed."""
+        pred = self.predictor
+        if getattr(pred, "kind", None) not in ("ODE", "MLP", "GRU"):
+            if hasattr(pred, "configure") and getattr(pred, "batch_size", None) is None:
+                pred.configure(batch_size=self.num_rollouts, dt=dt, computation_library=self.lib,
+                               predictor_specification=predictor_specification)
+        kind = getattr(pred, "kind", None)
+        if kind not in ("ODE", "MLP", "GRU"):
+            kind = predictor_kind(predictor_specification)
+        weights = getattr(pred, "weights", None)
+        wf = self._engine_options.get("predictor_weights_file")
+        if weights is None and wf:
+            data = np.load(wf, allow_pickle=False)
+            weights = data["weights"] if hasattr(data, "files") else data
+        isteps = self._engine_options.get("predictor_intermediate_steps", getattr(pred, "intermediate_steps", 1))
+        return kind, int(isteps), weights
 
     def _build_engine(self, dt, predictor_specification, **engine_kwargs):
-        if self.num_states != 4 or self.num_control_inputs != 1:
-            raise NotImplementedError("the HIP engine is built for num_states == 4, num_control_inputs == 1")
-        if getattr(self.predictor, "kind", None) is None:
-            self.predictor.configure(batch_size=self.num_rollouts, dt=dt, computation_library=self.lib,
-                                     predictor_specification=predictor_specification)
+        env = self._resolve_environment()
+        S, C, _ = environment_info(env)
+        if self.num_states != S or self.num_control_inputs != C:
+            raise ValueError(f"environment {env} has num_states == {S}, num_control_inputs == {C}; the predictor reports "
+                             f"{self.num_states} / {self.num_control_inputs}")
+        kind, isteps, weights = self._resolve_predictor(dt, predictor_specification)
         lo, hi = self._limits()
         self.engine = CtkEngine(
-            self.engine_name, self.predictor.kind, num_rollouts=self.num_rollouts, mpc_horizon=self.mpc_horizon,
-            dt=dt, action_low=lo, action_high=hi, seed=self.seed, device=self.device,
-            intermediate_steps=getattr(self.predictor, "intermediate_steps", 1),
-            materialize_trajectories=bool(self.optimizer_logging), **engine_kwargs)
-        if self.predictor.kind in ("MLP", "GRU"):
-            self.engine.set_predictor_weights(self.predictor.weights)
+            self.engine_name, kind, num_rollouts=self.num_rollouts, mpc_horizon=self.mpc_horizon,
+            dt=dt, action_low=lo, action_high=hi, seed=self.seed, device=self.device, intermediate_steps=isteps,
+            materialize_trajectories=bool(self.optimizer_logging), environment=env,
+            generic_kernels=bool(self._engine_options.get("generic_kernels", False)), **engine_kwargs)
+        if kind in ("MLP", "GRU"):
+            if weights is None:
+                raise ValueError(f"{kind} predictor: no weights (PredictorWrapper(weights=...) or `predictor_weights_file:` in the optimizer's YAML entry)")
+            self.engine.set_predictor_weights(weights)
         if self.logging_on_device:
             self.engine.log_enable(self.logging_capacity)
         self._param_cache = {}
         self._cost_version = None
+        self._sync_key = None
         self._sync_parameters(force=True)
+
+    def _parameter_values(self) -> dict:
+        """Every value the kernels take as a constant, from the objects the controller wired in.  Provider chain, later
+        wins: predictor.parameters (dynamics) < the optimizer YAML's `predictor_parameters` < the cost function's values <
+        per-step attributes of variable_parameters (template_controller.update_attributes, Controllers/__init__.py:106-107).
+        Cost values: the build's wrapper exposes `.parameters`; a reference-shaped wrapper holds the concrete cost object
+        at `.cost_function` (cost_function_wrapper.py:62-66), whose YAML section the reference's updater stores in `.config`
+        (CostFunctionUpdater.py:63-66) and whose weights are plain attributes — both are read, by name."""
+        names = self.engine.param_names
+        vals = {}
+        vals.update(getattr(self.predictor, "parameters", None) or {})
+        vals.update(self._engine_options.get("predictor_parameters") or {})
+        cf = self.cost_function
+        if isinstance(getattr(cf, "parameters", None), dict):
+            vals.update(cf.parameters)
+        else:
+            inner = getattr(cf, "cost_function", None)
+            for n in names:
+                v = getattr(inner, n, None)
+                if isinstance(v, (int, float, np.floating, np.integer)):
+                    vals[n] = float(v)
+            cfgd = getattr(inner, "config", None)
+            if isinstance(cfgd, dict):
+                vals.update({k: v for k, v in cfgd.items() if isinstance(v, (int, float))})
+        vp = getattr(cf, "variable_parameters", None) or getattr(self.predictor, "variable_parameters", None)
+        if vp is not None:
+            for n in names:
+                v = getattr(vp, n, None)
+                if v is not None:
+                    try:
+                        vals[n] = float(np.asarray(v).reshape(-1)[0])
+                    except (TypeError, ValueError):
+                        pass
+        return {k: float(v) for k, v in vals.items() if k in names}
 
     def _sync_parameters(self, force=False):
         """Upload changed dynamics / cost / per-step attributes (reference: variable_parameters
         updated by template_controller.update_attributes, Controllers/__init__.py:106-107; cost
         YAML hot reload, cost_function_wrapper.py:71-74).  Only between steps."""
-        cf = self.cost_function
-        vp = getattr(cf, "variable_parameters", None) or getattr(self.predictor, "variable_parameters", None)
-        # cheap per-step check: nothing to upload unless the cost parameters were reloaded (version counter), the
-        # dynamics values changed, or a per-step attribute moved
-        def scalar(x):
-            return None if x is None else float(np.asarray(x).reshape(-1)[0])
-        key = (getattr(cf, "version", None), tuple(getattr(cf, "parameters", {}).values()),
-               tuple(getattr(self.predictor, "parameters", {}).values()),
-               scalar(getattr(vp, "target_position", None)), scalar(getattr(vp, "target_equilibrium", None)))
+        vals = self._parameter_values()
+        key = tuple(vals.values())
         if not force and key == self._sync_key:
             return
         self._sync_key = key
-        vals = {}
-        vals.update(getattr(self.predictor, "parameters", {}))
-        cf = self.cost_function
-        vals.update(getattr(cf, "parameters", {}))
-        vp = getattr(cf, "variable_parameters", None) or getattr(self.predictor, "variable_parameters", None)
-        for name in ("target_position", "target_equilibrium"):
-            if vp is not None and hasattr(vp, name):
-                vals[name] = float(np.asarray(getattr(vp, name)).reshape(-1)[0])
         for name, v in vals.items():
-            if name in PARAMS and (force or self._param_cache.get(name) != float(v)):
-                self.engine.set_param(name, float(v))
-                self._param_cache[name] = float(v)
+            if force or self._param_cache.get(name) != v:
+                self.engine.set_param(name, v)
+                self._param_cache[name] = v
 
     def _draws(self, kind: str, shape):
         """None => on-device Philox; otherwise RAW host draws of `shape`."""
@@ -200,16 +285,21 @@ class template_optimizer:
         s = np.asarray(s, dtype=np.float32)
         if s.ndim == 2 and s.shape[0] == 1:
             s = s[0]
-        if s.shape != (4,):
-            raise ValueError(f"state must have shape (4,), got {s.shape}")
+        if s.shape != (self.num_states,):
+            raise ValueError(f"state must have shape ({self.num_states},), got {s.shape}")
         return s
+
+    def _u_prev(self):
+        """the previous output as [C] (self.u starts as the scalar 0.0, reference Optimizers/__init__.py:34)"""
+        return np.broadcast_to(np.asarray(self.u, np.float32).reshape(-1), (self.num_control_inputs,)) \
+            if np.size(self.u) == 1 else np.asarray(self.u, np.float32).reshape(-1)
 
     def _logged(self, name: str):
         """the tensor `name` of the step just completed: a host array, or its handle in the device log"""
         if not self.logging_on_device:
             return self.engine.read(name)
         N, H = self.num_rollouts, self.mpc_horizon
-        shape = {"Q": (N, H, 1), "J": (N,), "TRAJ": (N, H + 1, 4), "AGES": (N,)}[name]
+        shape = {"Q": (N, H, self.num_control_inputs), "J": (N,), "TRAJ": (N, H + 1, self.num_states), "AGES": (N,)}[name]
         return DeviceLogEntry(self.engine, name, self.engine.log_count() - 1, shape)
 
     def _fill_logging(self, s_in, u):
@@ -222,5 +312,5 @@ class template_optimizer:
 
     def _predict_optimal_trajectory(self, s, u_nom, u_prev):
         # reference optimizer_mppi.py:199-202: single-trajectory rollout of the nominal plan
-        traj, _ = self.engine.rollout(s, np.asarray(u_nom, np.float32).reshape(1, self.mpc_horizon, 1), u_prev=u_prev)
+        traj, _ = self.engine.rollout(s, np.asarray(u_nom, np.float32).reshape(1, self.mpc_horizon, self.num_control_inputs), u_prev=u_prev)
         return traj

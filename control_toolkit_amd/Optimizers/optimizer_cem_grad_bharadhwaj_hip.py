@@ -49,10 +49,10 @@ class optimizer_cem_grad_bharadhwaj_hip(template_optimizer):
         draws = None
         if not getattr(self.rng, "on_device", False):
             H, K, N = self.mpc_horizon, self.cem_best_k, self.num_rollouts
-            el = self._draws("normal", [K, H, 1])                                    # :158
-            rest = self._draws("normal", [iterations, N - K, H, 1])                  # :94
+            el = self._draws("normal", [K, H, self.num_control_inputs])                                    # :158
+            rest = self._draws("normal", [iterations, N - K, H, self.num_control_inputs])                  # :94
             draws = np.concatenate([el.ravel(), rest.ravel()]).astype(np.float32)
-        u_prev = np.asarray(self.u, np.float32).reshape(-1)[:1]
+        u_prev = self._u_prev()
         self.u = np.squeeze(self.engine.step(s, draws, u_prev=u_prev))
         if self.optimizer_logging:                                                   # :170-175
             self.logging_values["Q_logged"] = self._logged("Q")

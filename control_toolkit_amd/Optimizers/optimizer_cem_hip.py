@@ -44,9 +44,8 @@ class optimizer_cem_hip(template_optimizer):
         s = self._prepare_state(s)
         self._sync_parameters()
         iterations = self.warmup_iterations if self.warmup and self.count == 0 else self.cem_outer_it   # :92
-        noise = self._draws("normal", [iterations, self.num_rollouts, self.mpc_horizon, 1])
-        u_prev = np.asarray(self.u, np.float32).reshape(-1)[:1]
-        self.u = np.squeeze(self.engine.step(s, noise, u_prev=u_prev))
+        noise = self._draws("normal", [iterations, self.num_rollouts, self.mpc_horizon, self.num_control_inputs])   # :64-65
+        self.u = np.squeeze(self.engine.step(s, noise, u_prev=self._u_prev()))
         if self.optimizer_logging:
             self._fill_logging(s, self.u)
         self.count += 1

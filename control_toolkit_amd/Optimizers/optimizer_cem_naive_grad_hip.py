@@ -39,8 +39,8 @@ class optimizer_cem_naive_grad_hip(template_optimizer):
             self.logging_values = {"s_logged": np.asarray(s).copy()}
         s = self._prepare_state(s)
         self._sync_parameters()
-        noise = self._draws("normal", [self.cem_outer_it, self.num_rollouts, self.mpc_horizon, 1])
-        u_prev = np.asarray(self.u, np.float32).reshape(-1)[:1]
+        noise = self._draws("normal", [self.cem_outer_it, self.num_rollouts, self.mpc_horizon, self.num_control_inputs])
+        u_prev = self._u_prev()
         self.u = np.squeeze(self.engine.step(s, noise, u_prev=u_prev))
         if self.optimizer_logging:                                         # :106-110
             self.logging_values["Q_logged"] = self._logged("Q")

@@ -45,8 +45,8 @@ class optimizer_gradient_hip(template_optimizer):
             self.logging_values = {"s_logged": np.asarray(s).copy()}
         s = self._prepare_state(s)
         self._sync_parameters()
-        tail = self._draws("uniform", [self.num_rollouts, 1, 1])          # :137-142
-        u_prev = np.asarray(self.u, np.float32).reshape(-1)[:1]
+        tail = self._draws("uniform", [self.num_rollouts, 1, self.num_control_inputs])          # :137-142
+        u_prev = self._u_prev()
         self.u = np.squeeze(self.engine.step(s, tail, u_prev=u_prev))
         if self.optimizer_logging:                                         # :135-140
             self.logging_values["Q_logged"] = self._logged("Q")
@@ -56,5 +56,5 @@ class optimizer_gradient_hip(template_optimizer):
         return self.u
 
     def optimizer_reset(self):
-        self.engine.reset(self._draws("uniform", [self.num_rollouts, self.mpc_horizon, 1]))   # :174-185
+        self.engine.reset(self._draws("uniform", [self.num_rollouts, self.mpc_horizon, self.num_control_inputs]))   # :174-185
         self.count = 0

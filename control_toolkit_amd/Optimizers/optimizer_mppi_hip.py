@@ -32,7 +32,7 @@ class optimizer_mppi_hip(template_optimizer):
                            SQRTRHOINV=self._SQRTRHOINV,
                            period_interpolation_inducing_points=self.period_interpolation_inducing_points,
                            global_rollout_offset=self.global_rollout_offset)
-        self.number_of_interpolation_inducing_points = self.engine.mppi_partial_size() - 2
+        self.number_of_interpolation_inducing_points = self.engine.inducing_points()
         self.optimizer_reset()
 
     def step(self, s: np.ndarray, time=None):
@@ -40,14 +40,13 @@ class optimizer_mppi_hip(template_optimizer):
             self.logging_values = {"s_logged": np.asarray(s).copy()}
         s = self._prepare_state(s)
         self._sync_parameters()
-        noise = self._draws("normal", [self.num_rollouts, self.number_of_interpolation_inducing_points, 1])
-        u_prev = np.asarray(self.u, np.float32).reshape(-1)[:1]
-        self.u = np.squeeze(self.engine.step(s, noise, u_prev=u_prev))          # :211-212
+        noise = self._draws("normal", [self.num_rollouts, self.number_of_interpolation_inducing_points, self.num_control_inputs])   # :173-175
+        self.u = np.squeeze(self.engine.step(s, noise, u_prev=self._u_prev()))  # :211-212
         self._lazy.clear()                                                        # u_nom / optimal_control_sequence (:220): read on demand
         if self.optimizer_logging:
             self._fill_logging(s, self.u)
         if self.calculate_optimal_trajectory:                                     # :222-223
-            self.optimal_trajectory = self._predict_optimal_trajectory(s, self.u_nom, float(self.u))
+            self.optimal_trajectory = self._predict_optimal_trajectory(s, self.u_nom, self._u_prev())
         return self.u
 
     def optimizer_reset(self):

@@ -27,11 +27,8 @@ class optimizer_rpgd_hip(template_optimizer):
         self.outer_its = outer_its
         self.sample_stdev, self.sample_mean = sample_stdev, sample_mean
         self.sample_whole_control_space = sample_whole_control_space
-        lo, hi = self._limits()
-        if sample_whole_control_space:                      # reference :200-206
-            self.sample_min, self.sample_max = lo, hi
-        else:
-            self.sample_min, self.sample_max = uniform_dist_min, uniform_dist_max
+        # reference :200-206: the whole control space means [action_low[c], action_high[c]] per input
+        self.sample_min, self.sample_max = uniform_dist_min, uniform_dist_max
         self.resamp_per = resamp_per
         self.period_interpolation_inducing_points = period_interpolation_inducing_points
         self.shift_previous = shift_previous
@@ -57,12 +54,13 @@ class optimizer_rpgd_hip(template_optimizer):
             dt, predictor_specification, outer_its=self.outer_its, resamp_per=self.resamp_per,
             shift_previous=self.shift_previous, opt_keep_k=self.opt_keep_k,
             sampling_distribution=0 if self.SAMPLING_DISTRIBUTION == "uniform" else 1,
+            sample_whole_control_space=int(bool(self.sample_whole_control_space)),
             sample_stdev=self.sample_stdev, sample_mean=self.sample_mean, sample_min=self.sample_min,
             sample_max=self.sample_max, learning_rate=self.learning_rate, gradmax_clip=self.gradmax_clip,
             adam_beta_1=self.adam_beta_1, adam_beta_2=self.adam_beta_2, adam_epsilon=self.adam_epsilon,
             warmup=int(bool(self.do_warmup)), warmup_iterations=self.warmup_iterations,
             period_interpolation_inducing_points=self.period_interpolation_inducing_points)
-        self.number_of_interpolation_inducing_points = self.engine.samples_needed_reset() // self.num_rollouts
+        self.number_of_interpolation_inducing_points = self.engine.inducing_points()
         self.optimizer_reset()
 
     def _sample_kind(self):
@@ -77,8 +75,8 @@ class optimizer_rpgd_hip(template_optimizer):
         draws = None
         if need:
             draws = self._draws(self._sample_kind(), [self.num_rollouts - self.opt_keep_k,
-                                                      self.number_of_interpolation_inducing_points, 1])
-        u_prev = np.asarray(self.u, np.float32).reshape(-1)[:1]
+                                                      self.number_of_interpolation_inducing_points, self.num_control_inputs])
+        u_prev = self._u_prev()
         u = self.engine.step(s, draws, u_prev=u_prev)
         self._lazy.clear()                                           # u_nom (:426), optimal_control_sequence (:435): read on demand
         if self.optimizer_logging:                                   # :428-433
@@ -88,8 +86,8 @@ class optimizer_rpgd_hip(template_optimizer):
             self.logging_values["u_logged"] = self.u
         self.count += 1
         if self.calculate_optimal_trajectory:                        # :518-521
-            self.optimal_trajectory = self._predict_optimal_trajectory(s, self.u_nom, float(np.asarray(self.u).reshape(-1)[0]))
-        self.u = np.asarray(u, np.float32).reshape(-1)[:1].copy()    # :523
+            self.optimal_trajectory = self._predict_optimal_trajectory(s, self.u_nom, u_prev)
+        self.u = np.asarray(u, np.float32).reshape(-1).copy()        # :523
         return self.u
 
     @property
@@ -97,7 +95,7 @@ class optimizer_rpgd_hip(template_optimizer):
         return self.engine.read("AGES")
 
     def optimizer_reset(self):
-        draws = self._draws(self._sample_kind(), [self.num_rollouts, self.number_of_interpolation_inducing_points, 1])
+        draws = self._draws(self._sample_kind(), [self.num_rollouts, self.number_of_interpolation_inducing_points, self.num_control_inputs])
         self.engine.reset(draws)                                     # :527-548
         self._lazy.clear()
         self.count = 0

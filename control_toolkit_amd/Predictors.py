@@ -4,20 +4,46 @@ MI355X the rollout is fused into the optimizer kernels, so this object only carr
 predictor *specification* (kind, dt, physical parameters, network weights) to the engine."""
 import numpy as np
 
-DEFAULT_DYNAMICS = dict(g=9.81, m_cart=0.230, m_pole=0.087, L=0.1975, u_max=2.62, M_fric=4.77, J_fric=2.5e-4)
-MLP_NUM_WEIGHTS = 1380   # W1[32,5] b1[32] W2[32,32] b2[32] W3[4,32] b3[4]
-GRU_NUM_WEIGHTS = 10212  # per layer W_i[96,I] W_h[96,32] b_i[96] b_h[96] (I = 5, 32), then W_o[4,32] b_o[4]
+# The environments built into libctk_hip.so (include/ctk_hip.h: ctk_environment): dimensions and the dynamics section of
+# their parameter lists (the cost section lives in Cost_Functions).  Static here so that describing a predictor does not
+# load the library; tests/test_host_cpu.py checks the table against ctk_env_info / ctk_param_name.
+ENVIRONMENT_DIMS = {"CartPole": (4, 1), "Quad2D": (6, 2)}
+DEFAULT_DYNAMICS_BY_ENV = {
+    "CartPole": dict(g=9.81, m_cart=0.230, m_pole=0.087, L=0.1975, u_max=2.62, M_fric=4.77, J_fric=2.5e-4),
+    "Quad2D": dict(g=9.81, mass=0.5, inertia=0.004, arm=0.12, thrust_gain=0.6, drag_lin=0.25, drag_ang=0.4),
+}
+DEFAULT_DYNAMICS = DEFAULT_DYNAMICS_BY_ENV["CartPole"]
+MLP_NUM_WEIGHTS = 1380   # CartPole: W1[32,5] b1[32] W2[32,32] b2[32] W3[4,32] b3[4]
+GRU_NUM_WEIGHTS = 10212  # CartPole: per layer W_i[96,I] W_h[96,32] b_i[96] b_h[96] (I = 5, 32), then W_o[4,32] b_o[4]
+
+
+def network_weight_count(kind: str, num_states: int, num_control_inputs: int) -> int:
+    """flat fp32 weights of the built network shapes: (S+C)-32-32-S tanh MLP; 2x32 GRU + dense 32->S"""
+    I, S = num_states + num_control_inputs, num_states
+    if kind == "MLP":
+        return I * 32 + 32 + 32 * 32 + 32 + 32 * S + S
+    if kind == "GRU":
+        return (96 * I + 96 * 32 + 192) + (96 * 32 + 96 * 32 + 192) + (32 * S + S)
+    return 0
+
+
+def built_environment(name) -> str:
+    stem = str(name or "CartPole").replace("-", "").replace("_", "").lower()
+    for built in ENVIRONMENT_DIMS:
+        if stem.startswith(built.lower()):
+            return built
+    raise NotImplementedError(f"environment {name!r} is not built (have: {sorted(ENVIRONMENT_DIMS)})")
 
 
 class PredictorWrapper:
-    def __init__(self, parameters=None, weights=None, intermediate_steps: int = 1):
-        self.num_states = 4
-        self.num_control_inputs = 1
-        self.parameters = dict(DEFAULT_DYNAMICS)
+    def __init__(self, parameters=None, weights=None, intermediate_steps: int = 1, environment_name: str = "CartPole"):
+        self.environment_name = built_environment(environment_name)
+        self.num_states, self.num_control_inputs = ENVIRONMENT_DIMS[self.environment_name]
+        self.parameters = dict(DEFAULT_DYNAMICS_BY_ENV[self.environment_name])
         if parameters:
-            unknown = set(parameters) - set(DEFAULT_DYNAMICS)
+            unknown = set(parameters) - set(self.parameters)
             if unknown:
-                raise ValueError(f"unknown dynamics parameters {sorted(unknown)}")
+                raise ValueError(f"unknown dynamics parameters {sorted(unknown)} for environment {self.environment_name}")
             self.parameters.update(parameters)
         self.weights = None if weights is None else np.ascontiguousarray(weights, dtype=np.float32).ravel()
         self.intermediate_steps = int(intermediate_steps)
@@ -34,7 +60,7 @@ class PredictorWrapper:
         if kind is None:
             raise NotImplementedError(f"predictor_specification {spec!r}: only 'ODE', 'MLP' and 'GRU' are built")
         if kind in ("MLP", "GRU"):
-            want = MLP_NUM_WEIGHTS if kind == "MLP" else GRU_NUM_WEIGHTS
+            want = network_weight_count(kind, self.num_states, self.num_control_inputs)
             if self.weights is None:
                 raise ValueError(f"{kind} predictor needs weights (PredictorWrapper(weights=...))")
             if self.weights.size != want:
@@ -50,7 +76,8 @@ class PredictorWrapper:
         """Declarative predictor description -> kernel constants.  YAML keys (all optional):
             dynamics: {g, m_cart, m_pole, L, u_max, M_fric, J_fric}     # the ODE's physical parameters
             intermediate_steps: 1                                        # Euler sub-steps per mpc_timestep
-            weights_file: net.npy | net.npz (key `weights`)              # flat fp32 network weights (MLP 1380 / GRU 10212)
+            weights_file: net.npy | net.npz (key `weights`)              # flat fp32 network weights (CartPole: MLP 1380 / GRU 10212)
+            environment_name: CartPole | Quad2D                          # default: `section` if it names a built environment, else CartPole
         `section`: optional top-level key (e.g. the environment name).  Weight files are read with
         numpy.load(allow_pickle=False) only."""
         import os
@@ -58,7 +85,7 @@ class PredictorWrapper:
         cfg = safe_load(open(path, "r")) or {}
         if section is not None:
             cfg = cfg[section]
-        unknown = set(cfg) - {"dynamics", "intermediate_steps", "weights_file"}
+        unknown = set(cfg) - {"dynamics", "intermediate_steps", "weights_file", "environment_name"}
         if unknown:
             raise ValueError(f"{path}: unknown predictor keys {sorted(unknown)}")
         weights = None
@@ -67,10 +94,16 @@ class PredictorWrapper:
             wf = wf if os.path.isabs(wf) else os.path.join(os.path.dirname(os.path.abspath(path)), wf)
             data = np.load(wf, allow_pickle=False)
             weights = data["weights"] if hasattr(data, "files") else data
-        return cls(cfg.get("dynamics"), weights, int(cfg.get("intermediate_steps", 1)))
+        env = cfg.get("environment_name")
+        if env is None:
+            try:
+                env = built_environment(section)
+            except NotImplementedError:
+                env = "CartPole"
+        return cls(cfg.get("dynamics"), weights, int(cfg.get("intermediate_steps", 1)), env)
 
     def copy(self):
-        return PredictorWrapper(self.parameters, self.weights, self.intermediate_steps)
+        return PredictorWrapper(self.parameters, self.weights, self.intermediate_steps, self.environment_name)
 
     def update(self, s=None, Q0=None):
         """RNN hidden-state advance in the reference (optimizer_mppi.py:195-197).  The carried state lives

@@ -18,6 +18,9 @@ _lib = None
 OPTIMIZERS = {"mppi": 0, "cem": 1, "rpgd": 2, "random_action": 3, "gradient": 4, "cem_naive_grad": 5,
               "cem_grad_bharadhwaj": 6}
 PREDICTORS = {"ODE": 0, "MLP": 1, "GRU": 2}
+ENVIRONMENTS = {"CartPole": 0, "Quad2D": 1}          # include/ctk_hip.h: enum ctk_environment
+MAX_STATES, MAX_INPUTS = 8, 4
+# CartPole's parameter names in id order (enum ctk_param); `environment_params(name)` asks the library for any environment's
 PARAMS = ("g", "m_cart", "m_pole", "L", "u_max", "M_fric", "J_fric", "target_position", "target_equilibrium",
           "dd_weight", "ep_weight", "ekp_weight", "cc_weight", "ccrc_weight", "R", "x_scale", "terminal_weight")
 BUFFERS = {"Q": 0, "J": 1, "TRAJ": 2, "U_NOM": 3, "STD": 4, "ADAM_M": 5, "ADAM_V": 6, "AGES": 7, "BEST_IDX": 8, "PLAN": 9}
@@ -36,12 +39,13 @@ class CtkConfig(C.Structure):
         ("num_control_inputs", C.c_int32), ("period_interpolation_inducing_points", C.c_int32),
         ("intermediate_steps", C.c_int32), ("materialize_trajectories", C.c_int32),
         ("global_rollout_offset", C.c_int32), ("seed", C.c_uint64), ("dt", C.c_float),
-        ("action_low", C.c_float), ("action_high", C.c_float),
+        ("environment", C.c_int32), ("generic_kernels", C.c_int32),
+        ("action_low", C.c_float * MAX_INPUTS), ("action_high", C.c_float * MAX_INPUTS),
         ("cc_weight", C.c_float), ("R", C.c_float), ("LBD", C.c_float), ("NU", C.c_float), ("SQRTRHOINV", C.c_float),
         ("cem_outer_it", C.c_int32), ("cem_best_k", C.c_int32), ("warmup", C.c_int32), ("warmup_iterations", C.c_int32),
         ("cem_initial_action_stdev", C.c_float), ("cem_stdev_min", C.c_float),
         ("outer_its", C.c_int32), ("resamp_per", C.c_int32), ("shift_previous", C.c_int32), ("opt_keep_k", C.c_int32),
-        ("sampling_distribution", C.c_int32),
+        ("sampling_distribution", C.c_int32), ("sample_whole_control_space", C.c_int32),
         ("sample_stdev", C.c_float), ("sample_mean", C.c_float), ("sample_min", C.c_float), ("sample_max", C.c_float),
         ("learning_rate", C.c_float), ("gradmax_clip", C.c_float), ("adam_beta_1", C.c_float),
         ("adam_beta_2", C.c_float), ("adam_epsilon", C.c_float),
@@ -64,6 +68,10 @@ SYMBOLS = {
     "ctk_set_stream": (C.c_int, [_H, C.c_void_p]),
     "ctk_set_param": (C.c_int, [_H, C.c_int, C.c_float]),
     "ctk_get_param": (C.c_int, [_H, C.c_int, _FP]),
+    "ctk_env_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ctk_param_name": (C.c_char_p, [C.c_int, C.c_int]),
+    "ctk_environment_name": (C.c_char_p, [C.c_int]),
+    "ctk_predictor_weight_count": (C.c_size_t, [_H]),
     "ctk_set_predictor_weights": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
     "ctk_predictor_hidden_size": (C.c_size_t, [_H]),
     "ctk_predictor_update": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
@@ -128,10 +136,21 @@ def load_library():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.ctk_abi_version() != 2:
+    if lib.ctk_abi_version() != 3:
         raise CtkError("libctk_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def environment_info(name: str):
+    """(S, C, parameter names in id order) of an environment, as the library defines them (ctk_env_info / ctk_param_name)."""
+    if name not in ENVIRONMENTS:
+        raise NotImplementedError(f"environment {name!r} is not built (have: {sorted(ENVIRONMENTS)})")
+    lib, eid = load_library(), ENVIRONMENTS[name]
+    S, Cn, n = C.c_int(), C.c_int(), C.c_int()
+    if lib.ctk_env_info(eid, C.byref(S), C.byref(Cn), C.byref(n)) != 0:
+        raise CtkError(f"ctk_env_info({name}) failed")
+    return S.value, Cn.value, tuple(lib.ctk_param_name(eid, i).decode() for i in range(n.value))
 
 
 def _ptr(a: Optional[np.ndarray]):
@@ -151,8 +170,17 @@ class CtkEngine:
     def __init__(self, optimizer: str, predictor: str, *, num_rollouts: int, mpc_horizon: int, dt: float,
                  action_low: float = -1.0, action_high: float = 1.0, period_interpolation_inducing_points: int = 1,
                  seed: int = 0, device: int = 0, intermediate_steps: int = 1, materialize_trajectories: bool = False,
-                 global_rollout_offset: int = 0, num_states: int = 4, num_control_inputs: int = 1, **kw):
+                 global_rollout_offset: int = 0, num_states: int = None, num_control_inputs: int = None,
+                 environment: str = "CartPole", generic_kernels: bool = False, **kw):
+        """action_low / action_high: scalars (every input) or one value per control input.  environment: the plant +
+        cost the kernels implement ("CartPole", "Quad2D"); num_states / num_control_inputs default to its dimensions and
+        are checked against them.  generic_kernels: run the environment-agnostic template kernels even where a hand-tuned
+        one exists."""
         lib = load_library()
+        S, Cn, self.param_names = environment_info(environment)
+        self.environment, self.S, self.C = environment, S, Cn
+        num_states = S if num_states is None else num_states
+        num_control_inputs = Cn if num_control_inputs is None else num_control_inputs
         if optimizer not in OPTIMIZERS:
             raise ValueError(f"unknown optimizer {optimizer!r}")
         if predictor not in PREDICTORS:
@@ -167,12 +195,19 @@ class CtkEngine:
         cfg.materialize_trajectories = int(bool(materialize_trajectories))
         cfg.global_rollout_offset = int(global_rollout_offset)
         cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-        cfg.dt, cfg.action_low, cfg.action_high = float(dt), float(action_low), float(action_high)
+        cfg.dt = float(dt)
+        cfg.environment, cfg.generic_kernels = ENVIRONMENTS[environment], int(bool(generic_kernels))
+        lo = np.broadcast_to(np.asarray(action_low, np.float32).reshape(-1), (Cn,)) if np.size(action_low) in (1, Cn) else None
+        hi = np.broadcast_to(np.asarray(action_high, np.float32).reshape(-1), (Cn,)) if np.size(action_high) in (1, Cn) else None
+        if lo is None or hi is None:
+            raise ValueError(f"control limits must be scalars or have {Cn} entries (num_control_inputs of {environment})")
+        for c in range(Cn):
+            cfg.action_low[c], cfg.action_high[c] = float(lo[c]), float(hi[c])
         # defaults keep unrelated optimizers' fields valid
         defaults = dict(cc_weight=1.0, R=1.0, LBD=100.0, NU=1000.0, SQRTRHOINV=0.03, cem_outer_it=1, cem_best_k=1,
                         warmup=0, warmup_iterations=0, cem_initial_action_stdev=0.5, cem_stdev_min=0.01,
                         outer_its=1, resamp_per=1, shift_previous=1, opt_keep_k=1, sampling_distribution=0,
-                        sample_stdev=0.5, sample_mean=0.0, sample_min=-1.0, sample_max=1.0, learning_rate=0.05,
+                        sample_whole_control_space=0, sample_stdev=0.5, sample_mean=0.0, sample_min=-1.0, sample_max=1.0, learning_rate=0.05,
                         gradmax_clip=5.0, adam_beta_1=0.9, adam_beta_2=0.999, adam_epsilon=1e-8)
         unknown = set(kw) - set(defaults)
         if unknown:
@@ -190,9 +225,9 @@ class CtkEngine:
             self._h = _H()
             raise (ValueError if rc == 1 else NotImplementedError if rc == 2 else CtkError)(msg)
         # preallocated argument buffers: the per-step call path does no allocation and no ndarray->ctypes casts
-        self._u = np.zeros(1, np.float32)
-        self._s = np.zeros(4, np.float32)
-        self._up = np.zeros(1, np.float32)
+        self._u = np.zeros(Cn, np.float32)
+        self._s = np.zeros(S, np.float32)
+        self._up = np.zeros(Cn, np.float32)
         self._u_p, self._s_p, self._up_p = self._u.ctypes.data, self._s.ctypes.data, self._up.ctypes.data
         self._step_fn = lib.ctk_step
 
@@ -224,12 +259,15 @@ class CtkEngine:
         self._check(self._lib.ctk_set_stream(self._h, C.c_void_p(stream_ptr)))
 
     def set_param(self, name: str, value: float):
-        self._check(self._lib.ctk_set_param(self._h, PARAMS.index(name), float(value)))
+        self._check(self._lib.ctk_set_param(self._h, self.param_names.index(name), float(value)))
 
     def get_param(self, name: str) -> float:
         v = C.c_float()
-        self._check(self._lib.ctk_get_param(self._h, PARAMS.index(name), C.byref(v)))
+        self._check(self._lib.ctk_get_param(self._h, self.param_names.index(name), C.byref(v)))
         return v.value
+
+    def predictor_weight_count(self) -> int:
+        return int(self._lib.ctk_predictor_weight_count(self._h))
 
     def set_predictor_weights(self, w):
         w = _f32(w).ravel()
@@ -265,18 +303,22 @@ class CtkEngine:
         self._check(self._lib.ctk_rng_set_position(self._h, int(call) & 0xFFFFFFFF))
 
     def samples_needed_reset(self) -> int:
-        """RPGD: raw draws optimizer_reset consumes (N * P)."""
+        """RPGD: raw draws optimizer_reset consumes (N * P * C)."""
         return self.N * int(self._lib.ctk_mppi_partial_size(self._h) - 2)
+
+    def inducing_points(self) -> int:
+        """P of the interpolator (others/Interpolator.py:79-84) as the engine uses it"""
+        return int(self._lib.ctk_mppi_partial_size(self._h) - 2) // self.C
 
     def step(self, s, samples=None, loc: int = None, u_prev=None) -> np.ndarray:
         """samples: None (device Philox), a host ndarray (parity mode) or an int device pointer."""
         try:
             self._s[:] = np.asarray(s).reshape(-1)
         except ValueError:
-            raise ValueError("state must have 4 entries") from None
+            raise ValueError(f"state must have {self.S} entries") from None
         up_p = None
         if u_prev is not None:
-            self._up[0] = np.asarray(u_prev).reshape(-1)[0]
+            self._up[:] = np.asarray(u_prev).reshape(-1)[:self.C]
             up_p = self._up_p
         if samples is None:
             sp, loc = None, LOC_NONE
@@ -296,10 +338,12 @@ class CtkEngine:
     def rollout(self, s, Q, u_prev=0.0, want_traj=True):
         Q = _f32(Q)
         n = Q.shape[0]
-        Q = Q.reshape(n, self.H, 1)
+        Q = np.ascontiguousarray(Q.reshape(n, self.H, self.C))
         s = _f32(s).reshape(-1)
-        up = _f32([u_prev]).reshape(1)
-        traj = np.empty((n, self.H + 1, 4), np.float32) if want_traj else None
+        if s.size != self.S:
+            raise ValueError(f"state must have {self.S} entries")
+        up = np.ascontiguousarray(np.broadcast_to(_f32(u_prev).reshape(-1), (self.C,)))
+        traj = np.empty((n, self.H + 1, self.S), np.float32) if want_traj else None
         J = np.empty((n,), np.float32)
         self._check(self._lib.ctk_rollout(self._h, _ptr(s), _ptr(up), _ptr(Q), n, _ptr(traj), _ptr(J)))
         return traj, J
@@ -309,7 +353,7 @@ class CtkEngine:
 
     def mppi_step_begin(self, s, partial_dev_ptr: int, samples=None, u_prev=None):
         s = _f32(s).reshape(-1)
-        up = None if u_prev is None else _f32(u_prev).reshape(-1)[:1].copy()
+        up = None if u_prev is None else _f32(u_prev).reshape(-1)[:self.C].copy()
         if samples is None:
             sp, loc = None, LOC_NONE
         elif isinstance(samples, int):
@@ -334,7 +378,7 @@ class CtkEngine:
 
     def p2p_step(self, s, samples=None, u_prev=None) -> np.ndarray:
         s = _f32(s).reshape(-1)
-        up = None if u_prev is None else _f32(u_prev).reshape(-1)[:1].copy()
+        up = None if u_prev is None else _f32(u_prev).reshape(-1)[:self.C].copy()
         if samples is None:
             sp, loc = None, LOC_NONE
         elif isinstance(samples, int):
@@ -358,7 +402,7 @@ class CtkEngine:
         self._s[:] = np.asarray(s).reshape(-1)
         up_p = None
         if u_prev is not None:
-            self._up[0] = np.asarray(u_prev).reshape(-1)[0]
+            self._up[:] = np.asarray(u_prev).reshape(-1)[:self.C]
             up_p = self._up_p
         if samples is None:
             sp, loc = None, LOC_NONE
@@ -366,8 +410,8 @@ class CtkEngine:
             sp, loc = samples, LOC_DEVICE
         else:
             arr = _f32(samples)
-            if arr.size != self.N * self.H:
-                raise ValueError(f"one iteration consumes {self.N * self.H} draws, got {arr.size}")
+            if arr.size != self.N * self.H * self.C:
+                raise ValueError(f"one iteration consumes {self.N * self.H * self.C} draws, got {arr.size}")
             sp, loc = arr.ctypes.data, LOC_HOST
         self._check(self._lib.ctk_shard_iter_begin(self._h, self._s_p, up_p, sp, loc, cand_dev_ptr))
 
@@ -389,7 +433,7 @@ class CtkEngine:
         self._s[:] = np.asarray(s).reshape(-1)
         up_p = None
         if u_prev is not None:
-            self._up[0] = np.asarray(u_prev).reshape(-1)[0]
+            self._up[:] = np.asarray(u_prev).reshape(-1)[:self.C]
             up_p = self._up_p
         self._check(self._lib.ctk_rpgd_step_begin(self._h, self._s_p, up_p, keep_dev_ptr))
 
@@ -404,14 +448,14 @@ class CtkEngine:
         return self._u.copy()
 
     def read(self, name: str) -> np.ndarray:
-        N, H = self.N, self.H
-        cap = max(N * (H + 1) * 4, N * H, 1)
+        N, H, S, Cn = self.N, self.H, self.S, self.C
+        cap = max(N * (H + 1) * S, N * H * Cn, 1)
         buf = np.empty(cap, np.float32)
         n = C.c_size_t()
         self._check(self._lib.ctk_read(self._h, BUFFERS[name], _ptr(buf), cap, C.byref(n)))
         out = buf[: n.value].copy()
-        shapes = {"Q": (N, H, 1), "J": (N,), "TRAJ": (N, H + 1, 4), "U_NOM": (1, H, 1), "STD": (1, H, 1),
-                  "ADAM_M": (N, H, 1), "ADAM_V": (N, H, 1), "AGES": (N,), "PLAN": (N, H, 1)}
+        shapes = {"Q": (N, H, Cn), "J": (N,), "TRAJ": (N, H + 1, S), "U_NOM": (1, H, Cn), "STD": (1, H, Cn),
+                  "ADAM_M": (N, H, Cn), "ADAM_V": (N, H, Cn), "AGES": (N,), "PLAN": (N, H, Cn)}
         if name == "BEST_IDX":
             return out.astype(np.int64)
         return out.reshape(shapes[name])
@@ -426,7 +470,7 @@ class CtkEngine:
 
     def log_read(self, name: str, first_step: int, n_steps: int) -> np.ndarray:
         N, H = self.N, self.H
-        shape = {"Q": (N, H, 1), "J": (N,), "TRAJ": (N, H + 1, 4), "AGES": (N,)}[name]
+        shape = {"Q": (N, H, self.C), "J": (N,), "TRAJ": (N, H + 1, self.S), "AGES": (N,)}[name]
         out = np.empty((int(n_steps),) + shape, np.float32)
         n = C.c_size_t()
         self._check(self._lib.ctk_log_read(self._h, BUFFERS[name], int(first_step), int(n_steps), _ptr(out), out.size, C.byref(n)))

@@ -11,6 +11,7 @@
 #include "ctk_device.h"   // tile_stride
 #include "ctk_mlp.h"      // mlp_hid, per-lane weight layout
 #include "ctk_gru.h"      // GRU per-lane table layout
+#include "ctk_env.h"      // Env<>: S, C of every environment
 #include <algorithm>
 #include <cstdlib>
 
@@ -27,7 +28,10 @@ struct EventPair {
 struct ctk_handle {
     ctk_config cfg{};
     int N = 0, H = 0, P = 0;
-    float params[CTK_P_COUNT]{};
+    int env = CTK_ENV_CARTPOLE, S = CTK_S, C = CTK_C;   // the environment and its dimensions
+    int HC = 0, PC = 0;         // floats per row of a [.,H,C] / [.,P,C] tensor
+    bool generic = false;       // run the template kernels of ctk_generic.hip (always for environments without tuned kernels)
+    float params[CTK_MAX_PARAMS]{};
     EnvK k{};
     MppiK mk{};
     hipStream_t stream = nullptr;
@@ -56,7 +60,8 @@ struct ctk_handle {
     float* d_weights = nullptr; // raw network weights (MLP [1380] / GRU [10212])
     float* d_wperm = nullptr;   // MLP: per-lane permuted, forward [64][48] then backward [64][28]
                                 // GRU: per-lane table [232][64], then the carried hidden state [2][32]
-    float mppi_s[CTK_S] = {0, 0, 0, 0};   // state of the pending sharded MPPI step (GRU hidden-state advance at step_end)
+    float mppi_s[CTK_MAX_STATES] = {};   // state of the pending sharded MPPI step (GRU hidden-state advance at step_end)
+    float* d_rec = nullptr;     // generic path: the ONE merged soft-min record {rho, a, b[P*C]} of a step
     // RPGD: population, Adam moments, ages (ping-pong), bias-correction table, adjoint scratch
     float* d_pop[2] = {nullptr, nullptr};
     float* d_m[2] = {nullptr, nullptr};
@@ -75,7 +80,7 @@ struct ctk_handle {
     int shard_it = 0;           // iteration index within the current sharded step
     int* d_shard_idx = nullptr; size_t shard_idx_cap = 0;
     const float* shard_last_cands = nullptr;
-    float shard_s[CTK_S] = {0, 0, 0, 0}; float shard_uprev = 0.0f; bool shard_has_uprev = false;
+    float shard_s[CTK_MAX_STATES] = {}; float shard_uprev[CTK_MAX_INPUTS] = {}; bool shard_has_uprev = false;
     bool have_weights = false;  // network weights uploaded
     float hidden_scale = 1.0f;        // GRU: max(1, max |h|) of a caller-set hidden state (units stay within it)
     float net_out_bound = INFINITY;   // GRU: max_g (sum_j |W_o[g,j]| + |b_o[g]|) >= any predicted state component (|h| <= 1)
@@ -146,7 +151,9 @@ std::vector<InterpEntry> build_interp_table(int H, int p, int P) {
 }
 
 void refresh_constants(ctk_handle* h) {
-    h->k = derive_constants(h->params, h->cfg.dt, h->cfg.intermediate_steps);
+    // CartPole's derived constants feed the hand-tuned kernels; the template kernels derive theirs per launch
+    // (ctk_generic.hip: Env<>::derive) from the same primary parameters
+    if (h->env == CTK_ENV_CARTPOLE) h->k = derive_constants(h->params, h->cfg.dt, h->cfg.intermediate_steps);
     const ctk_config& c = h->cfg;
     MppiK m;
     m.stdev = (float)((double)c.SQRTRHOINV * (1.0 / std::sqrt((double)c.dt)));   // optimizer_mppi.py:130
@@ -230,14 +237,34 @@ std::vector<float> permute_gru_weights(const float* raw) {
     return out;
 }
 
-void default_params(float* p) {
-    // oracle/ctk_oracle.py:EnvParams defaults
-    p[CTK_P_G] = 9.81f; p[CTK_P_M_CART] = 0.230f; p[CTK_P_M_POLE] = 0.087f; p[CTK_P_L] = 0.1975f;
-    p[CTK_P_U_MAX] = 2.62f; p[CTK_P_M_FRIC] = 4.77f; p[CTK_P_J_FRIC] = 2.5e-4f;
-    p[CTK_P_TARGET_POSITION] = 0.0f; p[CTK_P_TARGET_EQUILIBRIUM] = 1.0f;
-    p[CTK_P_DD_WEIGHT] = 600.0f; p[CTK_P_EP_WEIGHT] = 20000.0f; p[CTK_P_EKP_WEIGHT] = 80.0f;
-    p[CTK_P_CC_WEIGHT] = 1.0f; p[CTK_P_CCRC_WEIGHT] = 1.0f; p[CTK_P_R] = 1.0f; p[CTK_P_X_SCALE] = 0.198f;
-    p[CTK_P_TERMINAL_WEIGHT] = 0.0f;
+// parameter names (the keys of the cost YAML / dynamics section) and defaults, in enum order:
+// oracle/ctk_oracle.py: EnvParams / Quad2DParams
+const char* const kCartPoleNames[CTK_P_COUNT] = {
+    "g", "m_cart", "m_pole", "L", "u_max", "M_fric", "J_fric", "target_position", "target_equilibrium",
+    "dd_weight", "ep_weight", "ekp_weight", "cc_weight", "ccrc_weight", "R", "x_scale", "terminal_weight"};
+const float kCartPoleDefaults[CTK_P_COUNT] = {9.81f, 0.230f, 0.087f, 0.1975f, 2.62f, 4.77f, 2.5e-4f, 0.0f, 1.0f,
+                                              600.0f, 20000.0f, 80.0f, 1.0f, 1.0f, 1.0f, 0.198f, 0.0f};
+const char* const kQuadNames[CTK_Q_COUNT] = {
+    "g", "mass", "inertia", "arm", "thrust_gain", "drag_lin", "drag_ang", "target_x", "target_z",
+    "pos_weight", "ang_weight", "vel_weight", "angvel_weight", "cc_weight", "ccrc_weight", "R", "pos_scale", "terminal_weight"};
+const float kQuadDefaults[CTK_Q_COUNT] = {9.81f, 0.5f, 0.004f, 0.12f, 0.6f, 0.25f, 0.4f, 0.0f, 1.0f,
+                                          400.0f, 150.0f, 8.0f, 1.5f, 1.0f, 2.0f, 1.0f, 0.5f, 0.0f};
+const EnvInfo kEnvs[CTK_ENV_COUNT] = {
+    {"CartPole", Env<CTK_ENV_CARTPOLE>::S, Env<CTK_ENV_CARTPOLE>::C, CTK_P_COUNT, kCartPoleNames, kCartPoleDefaults},
+    {"Quad2D", Env<CTK_ENV_QUAD2D>::S, Env<CTK_ENV_QUAD2D>::C, CTK_Q_COUNT, kQuadNames, kQuadDefaults},
+};
+const EnvInfo* env_info(int env) { return (env >= 0 && env < CTK_ENV_COUNT) ? &kEnvs[env] : nullptr; }
+
+void default_params(int env, float* p) {
+    const EnvInfo* e = env_info(env);
+    for (int i = 0; i < e->n_params; ++i) p[i] = e->param_defaults[i];
+}
+
+size_t weight_count(int predictor, int S, int C) {   // include/ctk_hip.h: ctk_set_predictor_weights
+    const size_t I = (size_t)S + C;
+    if (predictor == CTK_PRED_MLP) return I * 32 + 32 + 32 * 32 + 32 + 32 * (size_t)S + S;
+    if (predictor == CTK_PRED_GRU) return (96 * I + 96 * 32 + 192) + (96 * 32 + 96 * 32 + 192) + (32 * (size_t)S + S);
+    return 0;
 }
 
 template <class T>
@@ -252,7 +279,7 @@ int cem_iterations(const ctk_handle* h) {   // optimizer_cem_tf.py:92
 }
 
 size_t samples_needed(const ctk_handle* h) {
-    const size_t N = h->N, H = h->H, P = h->P;
+    const size_t N = h->N, H = h->HC, P = h->PC;   // draws per rollout: [H,C] / [P,C] blocks
     switch (h->cfg.optimizer) {
         case CTK_OPT_MPPI: return N * P;
         case CTK_OPT_CEM:
@@ -261,7 +288,7 @@ size_t samples_needed(const ctk_handle* h) {
             return (size_t)cem_iterations(h) * N * H;
         case CTK_OPT_RANDOM_ACTION: return N * H;
         case CTK_OPT_RPGD:
-            if (h->variant == CTK_OPT_GRADIENT) return N;   // the shifted-in tail input of every plan
+            if (h->variant == CTK_OPT_GRADIENT) return N * h->C;   // the shifted-in tail input of every plan [N,1,C]
             return (h->count % h->cfg.resamp_per == 0 && (size_t)h->cfg.opt_keep_k < N) ? (N - (size_t)h->cfg.opt_keep_k) * P : 0;
     }
     return 0;
@@ -287,10 +314,10 @@ int resolve_samples(ctk_handle* h, const float* samples, int loc, size_t n, cons
 
 RolloutArgs make_args(ctk_handle* h, const float* s, const float* u_prev, int N, int P) {
     RolloutArgs a{};
-    for (int i = 0; i < CTK_S; ++i) a.s0[i] = s[i];
-    a.u_prev = u_prev ? u_prev[0] : 0.0f;
+    for (int i = 0; i < h->S; ++i) a.s0[i] = s[i];
+    for (int c = 0; c < h->C; ++c) { a.u_prev[c] = u_prev ? u_prev[c] : 0.0f; a.lo[c] = h->cfg.action_low[c]; a.hi[c] = h->cfg.action_high[c]; }
     a.u_prev_dev = u_prev ? nullptr : h->d_u;
-    a.lo = h->cfg.action_low; a.hi = h->cfg.action_high;
+    a.C = h->C;
     a.N = N; a.H = h->H; a.P = P;
     a.p_magic = P >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)P - 1) / (uint64_t)P) : 0u;
     a.identity_interp = (h->cfg.period_interpolation_inducing_points == 1 && P == h->H) ? 1 : 0;
@@ -305,7 +332,8 @@ RolloutArgs make_args(ctk_handle* h, const float* s, const float* u_prev, int N,
     a.stream_id = 0;
     a.global_row0 = h->cfg.global_rollout_offset;
     // GRU rollouts: the angle the cost sees is s[2] at h = 0 and a network output afterwards
-    a.fast_cos_ok = (std::fabs(s[2]) <= CTK_SINCOS_FAST_LIMIT && h->net_out_bound * h->hidden_scale <= CTK_SINCOS_FAST_LIMIT) ? 1 : 0;
+    a.fast_cos_ok = (h->env == CTK_ENV_CARTPOLE && std::fabs(s[2]) <= CTK_SINCOS_FAST_LIMIT &&
+                     h->net_out_bound * h->hidden_scale <= CTK_SINCOS_FAST_LIMIT) ? 1 : 0;
     return a;
 }
 
@@ -321,7 +349,7 @@ struct ProfSlot {
 
 // Where a readable tensor lives right now (shared by ctk_read and the step log).
 int locate_buffer(ctk_handle* h, int which, const float** src_out, size_t* n_out, bool* is_int_out) {
-    const size_t N = h->N, H = h->H;
+    const size_t N = h->N, H = h->HC;   // [.,H,C] rows
     const float* src = nullptr; size_t n = 0; bool is_int = false;
     switch (which) {
         case CTK_BUF_Q: src = h->cfg.optimizer == CTK_OPT_RPGD ? h->d_pop[h->rcur ^ 1] : (h->variant == CTK_OPT_CEM_NAIVE_GRAD ? h->d_pop[0] : (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ ? h->d_pop[h->rcur] : h->d_Q));
@@ -341,7 +369,7 @@ int locate_buffer(ctk_handle* h, int which, const float** src_out, size_t* n_out
         case CTK_BUF_J: src = h->d_J; n = N; break;
         case CTK_BUF_TRAJ:
             if (!h->d_traj) return fail(h, CTK_ERR_STATE, "ctk_read: trajectories not materialised (cfg.materialize_trajectories == 0)");
-            src = h->d_traj; n = N * (H + 1) * CTK_S; break;
+            src = h->d_traj; n = N * ((size_t)h->H + 1) * h->S; break;
         case CTK_BUF_U_NOM: src = h->d_unom[h->cfg.optimizer == CTK_OPT_MPPI ? h->cur : 0]; n = H; break;
         case CTK_BUF_STD: src = h->d_std; n = H; break;
         case CTK_BUF_BEST_IDX:
@@ -356,11 +384,11 @@ int locate_buffer(ctk_handle* h, int which, const float** src_out, size_t* n_out
 
 // floats per step of ring `i` (Q, J, TRAJ, AGES); 0 = not logged for this handle
 size_t log_slot_floats(const ctk_handle* h, int i) {
-    const size_t N = h->N, H = h->H;
+    const size_t N = h->N;
     switch (i) {
-        case 0: return N * H;
+        case 0: return N * h->HC;
         case 1: return N;
-        case 2: return h->d_traj ? N * (H + 1) * CTK_S : 0;
+        case 2: return h->d_traj ? N * ((size_t)h->H + 1) * h->S : 0;
         default: return h->cfg.optimizer == CTK_OPT_RPGD ? N : 0;
     }
 }
@@ -400,7 +428,10 @@ int finish_step(ctk_handle* h, float* u_out) {
         if (*slot != want) return fail(h, CTK_ERR_HIP, "step finished without publishing its result");
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    if (u_out) u_out[0] = *reinterpret_cast<volatile float*>(h->h_u);
+    if (u_out) {
+        u_out[0] = *reinterpret_cast<volatile float*>(h->h_u);
+        for (int c = 1; c < h->C; ++c) u_out[c] = reinterpret_cast<volatile float*>(h->h_u)[4 + c];   // publish_u_vec
+    }
     ++h->seq;
     ++h->call;
     // error word behind {u, seq}: a bounded device-side wait ran out (1: a peer's record never arrived,
@@ -432,9 +463,10 @@ int check_predictor(ctk_handle* h) {
 }
 
 // ---- MPPI ------------------------------------------------------------------------------------
-int mppi_block_parts(const ctk_handle* h) { return ctk_mppi_num_blocks(h->N, h->cfg.predictor); }
+int mppi_block_parts(const ctk_handle* h) { return h->generic ? ctk_g_rollout_blocks(h->N) : ctk_mppi_num_blocks(h->N, h->cfg.predictor); }
 bool mppi_can_fuse(const ctk_handle* h) {
-    return !ctk_mppi_uses_throughput_kernel(h->cfg.predictor, h->N) && ctk_mppi_fusable(h->P, mppi_block_parts(h), h->d_ll != nullptr);
+    return !h->generic && !ctk_mppi_uses_throughput_kernel(h->cfg.predictor, h->N) &&
+           ctk_mppi_fusable(h->P, mppi_block_parts(h), h->d_ll != nullptr);
 }
 
 // fuse_mode: 0 block records only; 1 the last block also merges + updates (single-GPU step);
@@ -442,10 +474,16 @@ bool mppi_can_fuse(const ctk_handle* h) {
 int mppi_rollout(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc, int fuse_mode,
                  float* partial_dev) {
     const float* d_s = nullptr;
-    if (int rc = resolve_samples(h, samples, loc, (size_t)h->N * h->P, &d_s)) return rc;
+    if (int rc = resolve_samples(h, samples, loc, (size_t)h->N * h->PC, &d_s)) return rc;
     RolloutArgs a = make_args(h, s, u_prev, h->N, h->P);
     const bool log = h->cfg.materialize_trajectories != 0;
     if (int rc = check_predictor(h)) return rc;
+    if (h->generic) {   // template kernel: block records only (merged by the launches that follow)
+        ProfSlot ps(h);
+        HIP_TRY(h, ctk_launch_g_rollout(h->stream, h->env, CTK_G_MODE_MPPI, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s,
+                                        h->d_unom[h->cur], nullptr, 0, h->d_parts, log, ps.a, ps.b));
+        return CTK_OK;
+    }
     MppiFuse fz;
     fz.mode = fuse_mode; fz.counter = h->d_counter; fz.out_rec = partial_dev; fz.ll = h->d_ll;
     if (fuse_mode == 3) { fz.p2p = h->d_p2p_args; fz.p2p_seq = h->p2p_seq; fz.p2p_world = h->p2p_world; }
@@ -465,7 +503,7 @@ int mppi_reduce_blocks(ctk_handle* h, const float** parts, int* n_parts) {
     float* bufs[2] = {h->d_parts2, h->d_parts3};
     int b = 0;
     while (n > 64) {
-        HIP_TRY(h, ctk_launch_mppi_merge_partial(h->stream, src, n, 32, h->P, h->mk.neg_inv_lbd, bufs[b]));
+        HIP_TRY(h, ctk_launch_mppi_merge_partial(h->stream, src, n, 32, h->PC, h->mk.neg_inv_lbd, bufs[b]));
         n = (n + 31) / 32;
         src = bufs[b];
         b ^= 1;
@@ -484,11 +522,75 @@ int mppi_advance_hidden(ctk_handle* h) {
 
 int mppi_update(ctk_handle* h, const float* parts, int n_parts, float* u_out) {
     const int nxt = h->cur ^ 1;
+    if (h->generic) {
+        // merge the records into ONE (the same merge kernel the CartPole path uses; it only sees P*C columns), then the
+        // per-channel update u_nom <- clip(shift(u_nom) + interp(b)/a)
+        const float* rec = parts;
+        if (n_parts > 1) {
+            HIP_TRY(h, ctk_launch_mppi_merge_partial(h->stream, parts, n_parts, n_parts, h->PC, h->mk.neg_inv_lbd, h->d_rec));
+            rec = h->d_rec;
+        }
+        float zero_s[CTK_MAX_STATES] = {};
+        const RolloutArgs a = make_args(h, zero_s, nullptr, h->N, h->P);   // limits per input
+        HIP_TRY(h, ctk_launch_g_mppi_update(h->stream, rec, h->P, h->C, h->H, h->d_interp, h->d_unom[h->cur], h->d_unom[nxt], a, h->d_u,
+                                            h->h_u_dev, h->seq));
+        h->cur = nxt;
+        return finish_step(h, u_out);
+    }
     HIP_TRY(h, ctk_launch_mppi_update(h->stream, parts, n_parts, h->P, h->mk.neg_inv_lbd, h->H, h->d_interp, h->d_unom[h->cur],
-                                      h->d_unom[nxt], h->cfg.action_low, h->cfg.action_high, h->d_u, h->h_u_dev, h->seq));
+                                      h->d_unom[nxt], h->cfg.action_low[0], h->cfg.action_high[0], h->d_u, h->h_u_dev, h->seq));
     h->cur = nxt;
     if (int rc = mppi_advance_hidden(h)) return rc;
     return finish_step(h, u_out);
+}
+
+// u[n,h,c] = clip(base[h,c] + sample[n,h,c] * scale[h,c]) rollouts (CEM, random-action, plain), tuned or template kernel
+int launch_affine(ctk_handle* h, const RolloutArgs& a, const float* d_s, int rng_kind, const float* base, const float* scale, bool log,
+                  const AffineBest* bst = nullptr) {
+    ProfSlot ps(h);
+    if (h->generic)
+        HIP_TRY(h, ctk_launch_g_rollout(h->stream, h->env, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s, base,
+                                        scale, rng_kind, nullptr, log, ps.a, ps.b));
+    else
+        HIP_TRY(h, ctk_launch_affine_rollout(h->stream, h->cfg.predictor, a, h->k, d_s, rng_kind, base, scale, h->d_wperm, log, ps.a, ps.b, bst));
+    return CTK_OK;
+}
+
+// the Adam / SGD descent launch of the RPGD family, tuned (CartPole) or template kernel
+int launch_descent(ctk_handle* h, const RolloutArgs& a, float lr, float b1, float b2, float eps, float* Q, float* m, float* v,
+                   const float* bc, int bc_len, int t0, int iters, int rule, const RpgdFusedWarm* fused = nullptr) {
+    const ctk_config& c = h->cfg;
+    ProfSlot ps(h);
+    if (h->generic)
+        HIP_TRY(h, ctk_launch_g_rpgd_descent(h->stream, h->env, a, h->params, c.dt, c.intermediate_steps, lr, b1, b2, eps, c.gradmax_clip, Q, m, v,
+                                             bc, bc_len, t0, iters, h->d_scratch, ps.a, ps.b, rule));
+    else
+        HIP_TRY(h, ctk_launch_rpgd_descent(h->stream, c.predictor, a, h->k, lr, b1, b2, eps, c.gradmax_clip, Q, m, v, bc, bc_len, t0, iters,
+                                           h->d_wperm, h->d_scratch, ps.a, ps.b, rule, fused));
+    return CTK_OK;
+}
+
+// random-action: u = first input of the cheapest plan (optimizer_random_action_tf.py:65-68)
+int launch_pick_best(ctk_handle* h, const float* Q, const int* idx, int ldq) {
+    if (h->generic) HIP_TRY(h, ctk_launch_g_pick_best_first(h->stream, Q, idx, h->C, h->d_u, h->h_u_dev, h->seq, ldq));
+    else HIP_TRY(h, ctk_launch_pick_best_first(h->stream, Q, idx, h->H, h->d_u, h->h_u_dev, h->seq, ldq));
+    return CTK_OK;
+}
+
+// CEM post-loop (optimizer_cem_tf.py:99-102) + publishing u, tuned or template kernel
+int launch_cem_finish(ctk_handle* h, const float* Q, const int* idx, int ldq, float std_max, int u_from_mu) {
+    const ctk_config& c = h->cfg;
+    if (h->generic) {
+        float zero_s[CTK_MAX_STATES] = {};
+        const RolloutArgs a = make_args(h, zero_s, nullptr, h->N, h->H);
+        HIP_TRY(h, ctk_launch_g_cem_finish(h->stream, Q, idx, h->H, h->C, h->d_unom[0], h->d_std, c.cem_stdev_min, c.cem_initial_action_stdev, a,
+                                           h->d_u, h->h_u_dev, h->seq, ldq, std_max, u_from_mu));
+    } else {
+        const float mid = (c.action_low[0] + c.action_high[0]) * 0.5f;
+        HIP_TRY(h, ctk_launch_cem_finish(h->stream, Q, idx, h->H, h->d_unom[0], h->d_std, c.cem_stdev_min, c.cem_initial_action_stdev, mid,
+                                         h->d_u, h->h_u_dev, h->seq, ldq, std_max, u_from_mu));
+    }
+    return CTK_OK;
 }
 
 // ---- cem-grad-bharadhwaj (variant of the CEM family) ---------------------------------------------
@@ -499,7 +601,7 @@ int mppi_update(ctk_handle* h, const float* parts, int n_parts, float* u_out) {
 int cem_bharadhwaj_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc, float* u_out) {
     const ctk_config& c = h->cfg;
     const int its = cem_iterations(h), K = c.cem_best_k;
-    const size_t H = h->H, n_el = (size_t)K * H, n_rest = (size_t)(h->N - K) * H;
+    const size_t H = h->HC, n_el = (size_t)K * H, n_rest = (size_t)(h->N - K) * H;
     const float* d_s = nullptr;
     if (int rc = resolve_samples(h, samples, loc, n_el + its * n_rest, &d_s)) return rc;
     float* mu = h->d_unom[0];
@@ -509,21 +611,15 @@ int cem_bharadhwaj_step(ctk_handle* h, const float* s, const float* u_prev, cons
         a.stream_id = (uint32_t)it;
         HIP_TRY(h, ctk_launch_cem_build_population(h->stream, a, K, it == 0 ? 1 : 0, h->d_pop[cur ^ 1], h->d_idx, d_s,
                                                    d_s ? d_s + n_el + it * n_rest : nullptr, mu, h->d_std, h->d_pop[cur]));
-        {
-            ProfSlot ps(h);
-            HIP_TRY(h, ctk_launch_rpgd_descent(h->stream, c.predictor, a, h->k, c.learning_rate, c.adam_beta_1, c.adam_beta_2,
-                                               c.adam_epsilon, c.gradmax_clip, h->d_pop[cur], h->d_m[0], h->d_v[0], h->d_bc, h->bc_len,
-                                               h->adam_step, 1, h->d_wperm, h->d_scratch, ps.a, ps.b, 1));
-        }
+        if (int rc = launch_descent(h, a, c.learning_rate, c.adam_beta_1, c.adam_beta_2, c.adam_epsilon, h->d_pop[cur], h->d_m[0], h->d_v[0],
+                                    h->d_bc, h->bc_len, h->adam_step, 1, 1)) return rc;
         ++h->adam_step;
         HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, K, h->d_idx));
-        HIP_TRY(h, ctk_launch_cem_refit(h->stream, h->d_pop[cur], h->d_idx, K, h->H, mu, h->d_std, h->H));
+        HIP_TRY(h, ctk_launch_cem_refit(h->stream, h->d_pop[cur], h->d_idx, K, h->HC, mu, h->d_std, h->HC));
         if (it + 1 < its) cur ^= 1;   // the refined population becomes Q_prev of the next build
     }
     h->rcur = cur;
-    const float mid = (c.action_low + c.action_high) * 0.5f;
-    HIP_TRY(h, ctk_launch_cem_finish(h->stream, h->d_pop[cur], h->d_idx, h->H, mu, h->d_std, c.cem_stdev_min,
-                                     c.cem_initial_action_stdev, mid, h->d_u, h->h_u_dev, h->seq, h->H, 10.0f, 0));   // :167-168,:130-141
+    if (int rc = launch_cem_finish(h, h->d_pop[cur], h->d_idx, h->HC, 10.0f, 0)) return rc;   // :167-168,:130-141
     ++h->count;
     return finish_step(h, u_out);
 }
@@ -533,7 +629,7 @@ int cem_step(ctk_handle* h, const float* s, const float* u_prev, const float* sa
     if (int rc = check_predictor(h)) return rc;
     if (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) return cem_bharadhwaj_step(h, s, u_prev, samples, loc, u_out);
     const int its = cem_iterations(h);
-    const size_t per_it = (size_t)h->N * h->H;
+    const size_t per_it = (size_t)h->N * h->HC;
     const float* d_s = nullptr;
     if (int rc = resolve_samples(h, samples, loc, per_it * its, &d_s)) return rc;
     const bool log = h->cfg.materialize_trajectories != 0;
@@ -546,30 +642,22 @@ int cem_step(ctk_handle* h, const float* s, const float* u_prev, const float* sa
             RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);
             a.stream_id = (uint32_t)it;
             HIP_TRY(h, ctk_launch_sample_plans(h->stream, a, d_s ? d_s + per_it * it : nullptr, mu, h->d_std, h->d_pop[0]));
-            ProfSlot ps(h);
-            HIP_TRY(h, ctk_launch_rpgd_descent(h->stream, c.predictor, a, h->k, c.learning_rate, 0.0f, 0.0f, 0.0f, c.gradmax_clip,
-                                               h->d_pop[0], nullptr, nullptr, nullptr, 0, 0, 1, h->d_wperm, h->d_scratch, ps.a, ps.b, 2));
+            if (int rc = launch_descent(h, a, c.learning_rate, 0.0f, 0.0f, 0.0f, h->d_pop[0], nullptr, nullptr, nullptr, 0, 0, 1, 2)) return rc;
             HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, c.cem_best_k, h->d_idx));
-            HIP_TRY(h, ctk_launch_cem_refit(h->stream, h->d_pop[0], h->d_idx, c.cem_best_k, h->H, mu, h->d_std, h->H));
+            HIP_TRY(h, ctk_launch_cem_refit(h->stream, h->d_pop[0], h->d_idx, c.cem_best_k, h->HC, mu, h->d_std, h->HC));
         }
-        const float mid = (c.action_low + c.action_high) * 0.5f;
-        HIP_TRY(h, ctk_launch_cem_finish(h->stream, h->d_pop[0], h->d_idx, h->H, mu, h->d_std, c.cem_stdev_min,
-                                         c.cem_initial_action_stdev, mid, h->d_u, h->h_u_dev, h->seq, h->H, 10.0f, 1));   // :101-104
+        if (int rc = launch_cem_finish(h, h->d_pop[0], h->d_idx, h->HC, 10.0f, 1)) return rc;   // :101-104
         ++h->count;
         return finish_step(h, u_out);
     }
     for (int it = 0; it < its; ++it) {
         RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);
         a.stream_id = (uint32_t)it;
-        ProfSlot ps(h);
-        HIP_TRY(h, ctk_launch_affine_rollout(h->stream, h->cfg.predictor, a, h->k, d_s ? d_s + per_it * it : nullptr, 0, mu,
-                                             h->d_std, h->d_wperm, log, ps.a, ps.b));
+        if (int rc = launch_affine(h, a, d_s ? d_s + per_it * it : nullptr, 0, mu, h->d_std, log)) return rc;
         HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, h->cfg.cem_best_k, h->d_idx));
-        HIP_TRY(h, ctk_launch_cem_refit(h->stream, h->d_Q, h->d_idx, h->cfg.cem_best_k, h->H, mu, h->d_std, h->H));
+        HIP_TRY(h, ctk_launch_cem_refit(h->stream, h->d_Q, h->d_idx, h->cfg.cem_best_k, h->HC, mu, h->d_std, h->HC));
     }
-    const float mid = (h->cfg.action_low + h->cfg.action_high) * 0.5f;
-    HIP_TRY(h, ctk_launch_cem_finish(h->stream, h->d_Q, h->d_idx, h->H, mu, h->d_std, h->cfg.cem_stdev_min,
-                                     h->cfg.cem_initial_action_stdev, mid, h->d_u, h->h_u_dev, h->seq, h->H));
+    if (int rc = launch_cem_finish(h, h->d_Q, h->d_idx, h->HC, 1.0e8f, 0)) return rc;
     ++h->count;
     return finish_step(h, u_out);
 }
@@ -578,22 +666,20 @@ int cem_step(ctk_handle* h, const float* s, const float* u_prev, const float* sa
 int random_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc, float* u_out) {
     if (int rc = check_predictor(h)) return rc;
     const float* d_s = nullptr;
-    if (int rc = resolve_samples(h, samples, loc, (size_t)h->N * h->H, &d_s)) return rc;
+    if (int rc = resolve_samples(h, samples, loc, (size_t)h->N * h->HC, &d_s)) return rc;
     RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);
-    ProfSlot ps(h);
+    const bool log = h->cfg.materialize_trajectories != 0;
     static const bool three_launches = std::getenv("CTK_NO_FUSED_ARGMIN") != nullptr;   // A/B switch
-    if (h->cfg.predictor == CTK_PRED_ODE && h->d_ll && !three_launches &&
+    if (!h->generic && h->cfg.predictor == CTK_PRED_ODE && h->d_ll && !three_launches &&
         ctk_affine_rollout_blocks(h->cfg.predictor, h->N) <= CTK_AFFINE_BEST_MAX_BLOCKS) {
         // ONE launch: rollout + arg-min over the block minima + u (optimizer_random_action_tf.py:62-68)
         const AffineBest bst{h->d_ll, h->seq, h->d_u, h->h_u_dev, h->d_idx};
-        HIP_TRY(h, ctk_launch_affine_rollout(h->stream, h->cfg.predictor, a, h->k, d_s, 1, h->d_base, h->d_scale, h->d_wperm,
-                                             h->cfg.materialize_trajectories != 0, ps.a, ps.b, &bst));
+        if (int rc = launch_affine(h, a, d_s, 1, h->d_base, h->d_scale, log, &bst)) return rc;
         return finish_step(h, u_out);
     }
-    HIP_TRY(h, ctk_launch_affine_rollout(h->stream, h->cfg.predictor, a, h->k, d_s, 1, h->d_base, h->d_scale, h->d_wperm,
-                                         h->cfg.materialize_trajectories != 0, ps.a, ps.b));
+    if (int rc = launch_affine(h, a, d_s, 1, h->d_base, h->d_scale, log)) return rc;
     HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, 1, h->d_idx));
-    HIP_TRY(h, ctk_launch_pick_best_first(h->stream, h->d_Q, h->d_idx, h->H, h->d_u, h->h_u_dev, h->seq, h->H));
+    if (int rc = launch_pick_best(h, h->d_Q, h->d_idx, h->HC)) return rc;
     return finish_step(h, u_out);
 }
 
@@ -607,10 +693,10 @@ int rpgd_warm(ctk_handle* h, const RolloutArgs& a, int n_new, int gather, int re
               const int* idx = nullptr, const float* recs = nullptr, int keeper_base = 0, int fresh_tail = 0) {
     const ctk_config& c = h->cfg;
     HIP_TRY(h, ctk_launch_rpgd_warmstart(h->stream, a, h->N, h->H, h->P, n_new, gather, c.shift_previous, c.sampling_distribution,
-                                         reset, c.action_low, c.action_high, c.sample_stdev, c.sample_mean, c.sample_min,
+                                         reset, c.sample_whole_control_space, c.sample_stdev, c.sample_mean, c.sample_min,
                                          c.sample_max, d_draws, idx ? idx : h->d_idx, h->d_pop[from], h->d_m[from], h->d_v[from],
                                          h->d_ages[from], h->d_pop[to], h->d_m[to], h->d_v[to], h->d_ages[to], h->d_interp,
-                                         h->d_unom[0], h->d_u, h->h_u_dev, h->seq, recs, 3 + 3 * h->H, keeper_base, fresh_tail));
+                                         h->d_unom[0], h->d_u, h->h_u_dev, h->seq, recs, 3 + 3 * h->HC, keeper_base, fresh_tail));
     return CTK_OK;
 }
 
@@ -618,19 +704,16 @@ int rpgd_descent(ctk_handle* h, const float* s, const float* u_prev, const RpgdF
     const ctk_config& c = h->cfg;
     const int iters = rpgd_iterations(h);
     RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);   // p_magic divides by H in the descent kernel
-    ProfSlot ps(h);
-    HIP_TRY(h, ctk_launch_rpgd_descent(h->stream, c.predictor, a, h->k, c.learning_rate, c.adam_beta_1, c.adam_beta_2,
-                                       c.adam_epsilon, c.gradmax_clip, h->d_pop[h->rcur], h->d_m[h->rcur], h->d_v[h->rcur], h->d_bc,
-                                       h->bc_len, h->adam_step, iters, h->d_wperm, h->d_scratch, ps.a, ps.b,
-                                       h->variant == CTK_OPT_GRADIENT ? 1 : 0, fused));
+    if (int rc = launch_descent(h, a, c.learning_rate, c.adam_beta_1, c.adam_beta_2, c.adam_epsilon, h->d_pop[h->rcur], h->d_m[h->rcur],
+                                h->d_v[h->rcur], h->d_bc, h->bc_len, h->adam_step, iters, h->variant == CTK_OPT_GRADIENT ? 1 : 0, fused)) return rc;
     h->adam_step += iters;
     return CTK_OK;
 }
 
 int rpgd_reset(ctk_handle* h, const float* draws, int loc) {
     const float* d_draws = nullptr;
-    if (int rc = resolve_samples(h, draws, loc, (size_t)h->N * h->P, &d_draws)) return rc;
-    float zero_s[CTK_S] = {0, 0, 0, 0};
+    if (int rc = resolve_samples(h, draws, loc, (size_t)h->N * h->PC, &d_draws)) return rc;
+    float zero_s[CTK_MAX_STATES] = {};
     RolloutArgs a = make_args(h, zero_s, nullptr, h->N, h->P);
     if (int rc = rpgd_warm(h, a, h->N, 0, 1, d_draws, h->rcur, h->rcur)) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -648,7 +731,7 @@ RpgdFusedWarm rpgd_fused(ctk_handle* h, int K, int n_new, int gather, const floa
 }
 bool rpgd_can_fuse(const ctk_handle* h) {
     static const bool off = std::getenv("CTK_NO_RPGD_FUSED") != nullptr;   // A/B switch
-    return !off && h->N <= CTK_RPGD_FUSED_MAX_N;
+    return !off && !h->generic && h->N <= CTK_RPGD_FUSED_MAX_N;
 }
 
 int rpgd_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc, float* u_out) {
@@ -661,7 +744,7 @@ int rpgd_step(ctk_handle* h, const float* s, const float* u_prev, const float* s
         // optimizer_gradient_tf.py:101-173: Keras-Adam descent on all N plans, u = best plan's first input,
         // every plan shifted by one with a FRESH uniform tail input (:137-144), moments shifted by one (:147-166)
         const float* d_tail = nullptr;
-        if (int rc = resolve_samples(h, samples, loc, (size_t)h->N, &d_tail)) return rc;
+        if (int rc = resolve_samples(h, samples, loc, (size_t)h->N * h->C, &d_tail)) return rc;
         if (rpgd_can_fuse(h)) {
             const RpgdFusedWarm fw = rpgd_fused(h, 1, 0, 0, d_tail, cur, nxt, 1);
             if (int rc = rpgd_descent(h, s, u_prev, &fw)) return rc;
@@ -678,7 +761,7 @@ int rpgd_step(ctk_handle* h, const float* s, const float* u_prev, const float* s
     const bool resample = (h->count % c.resamp_per) == 0;                      // :449
     const float* d_draws = nullptr;
     if (resample)
-        if (int rc = resolve_samples(h, samples, loc, (size_t)(h->N - c.opt_keep_k) * h->P, &d_draws)) return rc;
+        if (int rc = resolve_samples(h, samples, loc, (size_t)(h->N - c.opt_keep_k) * h->PC, &d_draws)) return rc;
     if (rpgd_can_fuse(h)) {   // one workgroup holds the population: descent, keep-k and warm start in ONE launch
         const RpgdFusedWarm fw = rpgd_fused(h, c.opt_keep_k, resample ? h->N - c.opt_keep_k : 0, resample ? 1 : 0, d_draws, cur, nxt, 0);
         if (int rc = rpgd_descent(h, s, u_prev, &fw)) return rc;
@@ -691,6 +774,15 @@ int rpgd_step(ctk_handle* h, const float* s, const float* u_prev, const float* s
     h->rcur = nxt;
     ++h->count;
     return finish_step(h, u_out);
+}
+
+// d[i] = vals[i % C] for i < n (a [H,C] tensor whose rows are all `vals`)
+int fill_rows(ctk_handle* h, float* d, const float* vals, int C, int n) {
+    std::vector<float> tmp((size_t)n);
+    for (int i = 0; i < n; ++i) tmp[(size_t)i] = vals[i % C];
+    HIP_TRY(h, hipMemcpyAsync(d, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CTK_OK;
 }
 
 int fill_const(ctk_handle* h, float* d, float v, int n) {
@@ -706,6 +798,8 @@ int fill_const(ctk_handle* h, float* d, float v, int n) {
 extern "C" {
 
 int ctk_abi_version(void) { return CTK_ABI_VERSION; }
+static_assert(CTK_P_COUNT <= CTK_MAX_PARAMS && CTK_Q_COUNT <= CTK_MAX_PARAMS, "parameter table size");
+static_assert(Env<CTK_ENV_QUAD2D>::S <= CTK_MAX_STATES && Env<CTK_ENV_QUAD2D>::C <= CTK_MAX_INPUTS, "environment dimensions");
 
 const char* ctk_last_error(const ctk_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -714,16 +808,20 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     if (!cfg || !out) return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: NULL argument");
     if (cfg->struct_size != sizeof(ctk_config))
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: ctk_config size mismatch (ABI)");
-    if (cfg->num_states != CTK_S || cfg->num_control_inputs != CTK_C)
-        return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: only num_states == 4, num_control_inputs == 1 are built");
+    const EnvInfo* einfo = env_info(cfg->environment);
+    if (!einfo) return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: unknown environment (built: CartPole, Quad2D)");
+    if (cfg->num_states != einfo->S || cfg->num_control_inputs != einfo->C)
+        return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, std::string("ctk_create: environment ") + einfo->name + " has num_states == " +
+                    std::to_string(einfo->S) + ", num_control_inputs == " + std::to_string(einfo->C));
     if (cfg->num_rollouts < 1 || cfg->mpc_horizon < 1 || cfg->mpc_horizon > 1024)
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: need num_rollouts >= 1 and 1 <= mpc_horizon <= 1024");
     if (cfg->period_interpolation_inducing_points < 1 || cfg->intermediate_steps < 1)
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: period_interpolation_inducing_points and intermediate_steps must be >= 1");
     if (!(cfg->dt > 0.0f)) return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: dt must be > 0");
-    if ((long long)cfg->num_rollouts * (cfg->mpc_horizon + 1) * CTK_S > (1ll << 30))
+    if ((long long)cfg->num_rollouts * (cfg->mpc_horizon + 1) * std::max(einfo->S, einfo->C) > (1ll << 30))
         return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: num_rollouts * (mpc_horizon + 1) * num_states must stay below 2^30 (32-bit element indices)");
-    if (!(cfg->action_low <= cfg->action_high)) return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: action_low must be <= action_high");
+    for (int c = 0; c < einfo->C; ++c)
+        if (!(cfg->action_low[c] <= cfg->action_high[c])) return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: action_low must be <= action_high for every control input");
     if (cfg->optimizer < CTK_OPT_MPPI || cfg->optimizer > CTK_OPT_CEM_GRAD_BHARADHWAJ)
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: unknown optimizer");
     // variants run on an engine family: gradient = RPGD machinery without resampling (Keras Adam, fresh tail);
@@ -732,7 +830,8 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     if (cfg->optimizer == CTK_OPT_GRADIENT) {
         mapped.optimizer = CTK_OPT_RPGD;
         mapped.period_interpolation_inducing_points = 1;   // plans are sampled per step, no inducing points (:176-181)
-        mapped.sampling_distribution = 0; mapped.sample_min = cfg->action_low; mapped.sample_max = cfg->action_high;
+        mapped.sampling_distribution = 0; mapped.sample_whole_control_space = 1;
+        mapped.sample_min = cfg->action_low[0]; mapped.sample_max = cfg->action_high[0];
         mapped.shift_previous = 1; mapped.opt_keep_k = 1; mapped.resamp_per = 0x7FFFFFFF;
     } else if (cfg->optimizer == CTK_OPT_CEM_NAIVE_GRAD || cfg->optimizer == CTK_OPT_CEM_GRAD_BHARADHWAJ) {
         mapped.optimizer = CTK_OPT_CEM;
@@ -744,6 +843,10 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     cfg = &mapped;
     if (cfg->predictor != CTK_PRED_ODE && cfg->predictor != CTK_PRED_MLP && cfg->predictor != CTK_PRED_GRU)
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: unknown predictor");
+    // the template kernels roll the analytic model out; the network predictors have (so far) CartPole-shaped MFMA kernels only
+    const bool generic = cfg->environment != CTK_ENV_CARTPOLE || cfg->generic_kernels != 0;
+    if (generic && cfg->predictor != CTK_PRED_ODE)
+        return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: the MLP / GRU predictors are built for the CartPole kernels (environment CartPole, generic_kernels 0)");
     if (cfg->predictor == CTK_PRED_GRU && (cfg->optimizer == CTK_OPT_RPGD || variant != cfg->optimizer))
         return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: the GRU predictor is built forward-only (MPPI, CEM, random-action); no reverse mode for the gradient-based optimizers");
     if (cfg->optimizer == CTK_OPT_CEM && (cfg->cem_best_k < 1 || cfg->cem_best_k > cfg->num_rollouts || cfg->cem_outer_it < 1))
@@ -772,9 +875,11 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     h->cfg = *cfg;
     h->variant = variant;
     h->N = cfg->num_rollouts; h->H = cfg->mpc_horizon;
+    h->env = cfg->environment; h->S = einfo->S; h->C = einfo->C; h->generic = generic;
     const bool interp = (cfg->optimizer == CTK_OPT_MPPI || cfg->optimizer == CTK_OPT_RPGD);
     h->P = interp ? num_inducing_points(h->H, cfg->period_interpolation_inducing_points) : h->H;
-    default_params(h->params);
+    h->HC = h->H * h->C; h->PC = h->P * h->C;
+    default_params(h->env, h->params);
     refresh_constants(h);
 
     auto bail = [&](int rc) { g_create_error = h->err; ctk_destroy(h); return rc; };
@@ -785,12 +890,15 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     HIP_CREATE(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->own_stream = true;
 
-    const size_t N = h->N, H = h->H, P = h->P;
+    const size_t N = h->N, H = h->H, P = h->P, HC = h->HC, PC = h->PC;
+    const bool descends = cfg->optimizer == CTK_OPT_RPGD || variant == CTK_OPT_CEM_NAIVE_GRAD || variant == CTK_OPT_CEM_GRAD_BHARADHWAJ;
     // LDS budget of the rollout tiles (one wave per block): 64 * stride * 4 B <= 160 KiB
     {
-        const size_t lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_lds((int)P, (int)H, cfg->predictor)
-                         : (cfg->optimizer == CTK_OPT_RPGD || variant == CTK_OPT_CEM_NAIVE_GRAD || variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) ? ctk_rpgd_descent_lds(cfg->predictor, (int)H, nullptr)
-                                                          : ctk_affine_rollout_lds((int)H, cfg->predictor);
+        size_t lds;
+        if (generic) lds = descends ? ctk_g_rpgd_descent_lds(h->env, (int)H, nullptr)
+                                    : ctk_g_rollout_lds((int)(cfg->optimizer == CTK_OPT_MPPI ? PC : HC), (int)H, h->C);
+        else lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_lds((int)P, (int)H, cfg->predictor)
+                 : descends ? ctk_rpgd_descent_lds(cfg->predictor, (int)H, nullptr) : ctk_affine_rollout_lds((int)H, cfg->predictor);
         if (lds > 160 * 1024) { h->err = "horizon too long for the LDS sample tiles (160 KiB per CU)"; return bail(CTK_ERR_UNSUPPORTED); }
     }
 
@@ -800,22 +908,23 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     HIP_CREATE(hipStreamSynchronize(h->stream));   // tab goes out of scope below
 
     TRY_CREATE(dev_alloc(h, &h->d_J, N));
-    TRY_CREATE(dev_alloc(h, &h->d_Q, N * H));
-    if (cfg->materialize_trajectories) TRY_CREATE(dev_alloc(h, &h->d_traj, N * (H + 1) * CTK_S));
-    const size_t nblk = (size_t)ctk_mppi_num_blocks((int)N, cfg->predictor);
-    h->parts_cap = nblk * (2 + P);
+    TRY_CREATE(dev_alloc(h, &h->d_Q, N * HC));
+    if (cfg->materialize_trajectories) TRY_CREATE(dev_alloc(h, &h->d_traj, N * (H + 1) * h->S));
+    const size_t nblk = (size_t)mppi_block_parts(h);
+    h->parts_cap = nblk * (2 + PC);
     TRY_CREATE(dev_alloc(h, &h->d_parts, h->parts_cap));
-    TRY_CREATE(dev_alloc(h, &h->d_parts2, ((nblk + 31) / 32) * (2 + P)));
-    TRY_CREATE(dev_alloc(h, &h->d_parts3, ((nblk + 1023) / 1024) * (2 + P)));
+    TRY_CREATE(dev_alloc(h, &h->d_parts2, ((nblk + 31) / 32) * (2 + PC)));
+    TRY_CREATE(dev_alloc(h, &h->d_parts3, ((nblk + 1023) / 1024) * (2 + PC)));
+    TRY_CREATE(dev_alloc(h, &h->d_rec, 2 + PC));
     TRY_CREATE(dev_alloc(h, &h->d_counter, 1));
-    if (nblk <= (size_t)CTK_MPPI_FUSE_MAX_BLOCKS_LL && !std::getenv("CTK_NO_LL")) TRY_CREATE(dev_alloc(h, &h->d_ll, nblk * (2 + P)));
-    TRY_CREATE(dev_alloc(h, &h->d_unom[0], H));
-    TRY_CREATE(dev_alloc(h, &h->d_unom[1], H));
-    TRY_CREATE(dev_alloc(h, &h->d_std, H));
-    TRY_CREATE(dev_alloc(h, &h->d_base, H));
-    TRY_CREATE(dev_alloc(h, &h->d_scale, H));
+    if (!generic && nblk <= (size_t)CTK_MPPI_FUSE_MAX_BLOCKS_LL && !std::getenv("CTK_NO_LL")) TRY_CREATE(dev_alloc(h, &h->d_ll, nblk * (2 + P)));
+    TRY_CREATE(dev_alloc(h, &h->d_unom[0], HC));
+    TRY_CREATE(dev_alloc(h, &h->d_unom[1], HC));
+    TRY_CREATE(dev_alloc(h, &h->d_std, HC));
+    TRY_CREATE(dev_alloc(h, &h->d_base, HC));
+    TRY_CREATE(dev_alloc(h, &h->d_scale, HC));
     TRY_CREATE(dev_alloc(h, &h->d_idx, N));
-    TRY_CREATE(dev_alloc(h, &h->d_u, 1));
+    TRY_CREATE(dev_alloc(h, &h->d_u, CTK_MAX_INPUTS));
     TRY_CREATE(dev_alloc(h, &h->d_weights, cfg->predictor == CTK_PRED_GRU ? GRU_NW_RAW : CTK_MLP_NW));
     TRY_CREATE(dev_alloc(h, &h->d_wperm, cfg->predictor == CTK_PRED_GRU ? (size_t)GRU_TABLE_FLOATS + GRU_HIDDEN_FLOATS
                                                                           : (size_t)64 * (MLP_FWD_PER_LANE + MLP_BWD_PER_LANE)));
@@ -823,11 +932,11 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     std::memset(h->h_u, 0, 64);
     HIP_CREATE(hipHostGetDevicePointer((void**)&h->h_u_dev, h->h_u, 0));
 
-    if (cfg->optimizer == CTK_OPT_RPGD || variant == CTK_OPT_CEM_NAIVE_GRAD || variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) {
+    if (descends) {
         for (int b = 0; b < 2; ++b) {
-            TRY_CREATE(dev_alloc(h, &h->d_pop[b], N * H));
-            TRY_CREATE(dev_alloc(h, &h->d_m[b], N * H));
-            TRY_CREATE(dev_alloc(h, &h->d_v[b], N * H));
+            TRY_CREATE(dev_alloc(h, &h->d_pop[b], N * HC));
+            TRY_CREATE(dev_alloc(h, &h->d_m[b], N * HC));
+            TRY_CREATE(dev_alloc(h, &h->d_v[b], N * HC));
             TRY_CREATE(dev_alloc(h, &h->d_ages[b], N));
         }
         // bias corrections 1 - beta^t in double, rounded to fp32 (optimizer_rpgd.py:73-74); beyond the
@@ -841,15 +950,14 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
         TRY_CREATE(dev_alloc(h, &h->d_bc, bc.size()));
         HIP_CREATE(hipMemcpyAsync(h->d_bc, bc.data(), bc.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
         HIP_CREATE(hipStreamSynchronize(h->stream));
-        TRY_CREATE(dev_alloc(h, &h->d_scratch, ctk_rpgd_scratch_floats(cfg->predictor, (int)N, (int)H)));
+        TRY_CREATE(dev_alloc(h, &h->d_scratch, generic ? ctk_g_rpgd_scratch_floats(h->env, (int)N, (int)H)
+                                                       : ctk_rpgd_scratch_floats(cfg->predictor, (int)N, (int)H)));
     }
-    switch (cfg->optimizer) {
-        case CTK_OPT_RPGD: h->dominant = ctk_rpgd_descent_name(cfg->predictor); break;
-        case CTK_OPT_CEM: if (variant == CTK_OPT_CEM_NAIVE_GRAD || variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) { h->dominant = ctk_rpgd_descent_name(cfg->predictor); break; }
-            h->dominant = ctk_affine_rollout_name(cfg->predictor, cfg->materialize_trajectories != 0); break;
-        case CTK_OPT_MPPI: h->dominant = ctk_mppi_rollout_name(cfg->predictor, cfg->materialize_trajectories != 0, cfg->num_rollouts); break;
-        default: h->dominant = ctk_affine_rollout_name(cfg->predictor, cfg->materialize_trajectories != 0); break;
-    }
+    const bool mat = cfg->materialize_trajectories != 0;
+    if (descends) h->dominant = generic ? ctk_g_rpgd_descent_name(h->env) : ctk_rpgd_descent_name(cfg->predictor);
+    else if (cfg->optimizer == CTK_OPT_MPPI)
+        h->dominant = generic ? ctk_g_rollout_name(h->env, CTK_G_MODE_MPPI, mat) : ctk_mppi_rollout_name(cfg->predictor, mat, cfg->num_rollouts);
+    else h->dominant = generic ? ctk_g_rollout_name(h->env, CTK_G_MODE_AFFINE, mat) : ctk_affine_rollout_name(cfg->predictor, mat);
     if (cfg->optimizer != CTK_OPT_RPGD) TRY_CREATE(ctk_reset(h, nullptr, CTK_LOC_NONE));
     HIP_CREATE(hipStreamSynchronize(h->stream));
     *out = h;
@@ -864,7 +972,7 @@ void ctk_destroy(ctk_handle* h) {
     hipStreamSynchronize(h->stream);   // also correct for the null (default) stream handed in by ctk_set_stream
     for (auto& e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     void* bufs[] = {h->d_interp, h->d_samples, h->d_J, h->d_Q, h->d_traj, h->d_parts, h->d_parts2, h->d_parts3, h->d_unom[0], h->d_unom[1],
-                    h->d_std, h->d_base, h->d_scale, h->d_idx, h->d_u, h->d_weights, h->d_wperm, h->d_counter, h->d_ll,
+                    h->d_std, h->d_base, h->d_scale, h->d_idx, h->d_u, h->d_weights, h->d_wperm, h->d_counter, h->d_ll, h->d_rec,
                     h->d_pop[0], h->d_pop[1], h->d_m[0], h->d_m[1], h->d_v[0], h->d_v[1], h->d_ages[0], h->d_ages[1], h->d_bc, h->d_scratch};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->d_shard_idx) hipFree(h->d_shard_idx);
@@ -887,23 +995,24 @@ int ctk_set_stream(ctk_handle* h, void* hip_stream) {
 int ctk_reset(ctk_handle* h, const float* draws, int draws_loc) {
     if (!h) return CTK_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    const float mid = 0.5f * (h->cfg.action_low + h->cfg.action_high);
+    float mid[CTK_MAX_INPUTS], span[CTK_MAX_INPUTS];
+    for (int c = 0; c < h->C; ++c) { mid[c] = 0.5f * (h->cfg.action_low[c] + h->cfg.action_high[c]); span[c] = h->cfg.action_high[c] - h->cfg.action_low[c]; }
     h->count = 0;
     h->mppi_pending = false;
     h->shard_pending = false; h->shard_it = 0; h->shard_last_cands = nullptr;
     switch (h->cfg.optimizer) {
         case CTK_OPT_MPPI:   // optimizer_mppi.py:227-231 (self.u is NOT reset there)
             h->cur = 0;
-            return fill_const(h, h->d_unom[0], mid, h->H);
+            return fill_rows(h, h->d_unom[0], mid, h->C, h->HC);
         case CTK_OPT_CEM: {  // optimizer_cem_tf.py:113-117 (self.u = 0.0)
-            if (int rc = fill_const(h, h->d_unom[0], (h->cfg.action_low + h->cfg.action_high) * 0.5f, h->H)) return rc;
-            if (int rc = fill_const(h, h->d_std, h->cfg.cem_initial_action_stdev, h->H)) return rc;
+            if (int rc = fill_rows(h, h->d_unom[0], mid, h->C, h->HC)) return rc;
+            if (int rc = fill_const(h, h->d_std, h->cfg.cem_initial_action_stdev, h->HC)) return rc;
             // only optimizer_cem_tf.py:117 resets self.u; the gradient variants' resets leave it (and Adam) alone
-            return h->variant == CTK_OPT_CEM ? fill_const(h, h->d_u, 0.0f, 1) : CTK_OK;
+            return h->variant == CTK_OPT_CEM ? fill_const(h, h->d_u, 0.0f, h->C) : CTK_OK;
         }
         case CTK_OPT_RANDOM_ACTION:   // :78-86 draws and discards a sample
-            if (int rc = fill_const(h, h->d_base, h->cfg.action_low, h->H)) return rc;
-            return fill_const(h, h->d_scale, h->cfg.action_high - h->cfg.action_low, h->H);
+            if (int rc = fill_rows(h, h->d_base, h->cfg.action_low, h->C, h->HC)) return rc;
+            return fill_rows(h, h->d_scale, span, h->C, h->HC);
         case CTK_OPT_RPGD:
             return rpgd_reset(h, draws, draws_loc);
     }
@@ -912,7 +1021,7 @@ int ctk_reset(ctk_handle* h, const float* draws, int draws_loc) {
 
 int ctk_set_param(ctk_handle* h, int id, float value) {
     if (!h) return CTK_ERR_INVALID_ARGUMENT;
-    if (id < 0 || id >= CTK_P_COUNT) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_set_param: unknown parameter id");
+    if (id < 0 || id >= env_info(h->env)->n_params) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_set_param: unknown parameter id for this environment");
     if (h->mppi_pending) return fail(h, CTK_ERR_STATE, "ctk_set_param: illegal between step_begin and step_end");
     h->params[id] = value;
     refresh_constants(h);
@@ -920,16 +1029,37 @@ int ctk_set_param(ctk_handle* h, int id, float value) {
 }
 
 int ctk_get_param(const ctk_handle* h, int id, float* value) {
-    if (!h || !value || id < 0 || id >= CTK_P_COUNT) return CTK_ERR_INVALID_ARGUMENT;
+    if (!h || !value || id < 0 || id >= env_info(h->env)->n_params) return CTK_ERR_INVALID_ARGUMENT;
     *value = h->params[id];
     return CTK_OK;
 }
+
+int ctk_env_info(int environment, int* num_states, int* num_control_inputs, int* n_params) {
+    const EnvInfo* e = env_info(environment);
+    if (!e) return CTK_ERR_INVALID_ARGUMENT;
+    if (num_states) *num_states = e->S;
+    if (num_control_inputs) *num_control_inputs = e->C;
+    if (n_params) *n_params = e->n_params;
+    return CTK_OK;
+}
+
+const char* ctk_param_name(int environment, int id) {
+    const EnvInfo* e = env_info(environment);
+    return (e && id >= 0 && id < e->n_params) ? e->param_names[id] : nullptr;
+}
+
+const char* ctk_environment_name(int environment) {
+    const EnvInfo* e = env_info(environment);
+    return e ? e->name : nullptr;
+}
+
+size_t ctk_predictor_weight_count(const ctk_handle* h) { return h ? weight_count(h->cfg.predictor, h->S, h->C) : 0; }
 
 int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n) {
     if (!h || !w) return CTK_ERR_INVALID_ARGUMENT;
     if (h->cfg.predictor == CTK_PRED_ODE) return fail(h, CTK_ERR_STATE, "ctk_set_predictor_weights: the ODE predictor has no weights");
     const bool gru = h->cfg.predictor == CTK_PRED_GRU;
-    if (n != (size_t)(gru ? GRU_NW_RAW : CTK_MLP_NW))
+    if (n != weight_count(h->cfg.predictor, h->S, h->C))
         return fail(h, CTK_ERR_INVALID_ARGUMENT, gru ? "ctk_set_predictor_weights: expected 10212 floats (GRU)" : "ctk_set_predictor_weights: expected 1380 floats (MLP)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipMemcpyAsync(h->d_weights, w, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -1002,7 +1132,7 @@ int ctk_step(ctk_handle* h, const float* s, const float* u_prev, const float* sa
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     switch (h->cfg.optimizer) {
         case CTK_OPT_MPPI: {
-            for (int i = 0; i < CTK_S; ++i) h->mppi_s[i] = s[i];
+            for (int i = 0; i < h->S; ++i) h->mppi_s[i] = s[i];
             if (mppi_can_fuse(h)) {   // one launch: the last block to finish merges and updates
                 if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 1, nullptr)) return rc;
                 h->cur ^= 1;
@@ -1022,7 +1152,7 @@ int ctk_step(ctk_handle* h, const float* s, const float* u_prev, const float* sa
     });
 }
 
-size_t ctk_mppi_partial_size(const ctk_handle* h) { return h ? (size_t)(2 + h->P) : 0; }
+size_t ctk_mppi_partial_size(const ctk_handle* h) { return h ? (size_t)(2 + h->PC) : 0; }
 
 int ctk_mppi_step_begin(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int samples_loc,
                         float* partial_dev) {
@@ -1031,14 +1161,14 @@ int ctk_mppi_step_begin(ctk_handle* h, const float* s, const float* u_prev, cons
     if (h->cfg.optimizer != CTK_OPT_MPPI) return fail(h, CTK_ERR_STATE, "ctk_mppi_step_begin: handle is not MPPI");
     if (h->mppi_pending) return fail(h, CTK_ERR_STATE, "ctk_mppi_step_begin: previous sharded step not ended");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    for (int i = 0; i < CTK_S; ++i) h->mppi_s[i] = s[i];
+    for (int i = 0; i < h->S; ++i) h->mppi_s[i] = s[i];
     if (mppi_can_fuse(h)) {
         if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 2, partial_dev)) return rc;
     } else {
         if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 0, nullptr)) return rc;
         const float* parts; int n_parts;
         if (int rc = mppi_reduce_blocks(h, &parts, &n_parts)) return rc;
-        HIP_TRY(h, ctk_launch_mppi_merge_partial(h->stream, parts, n_parts, n_parts, h->P, h->mk.neg_inv_lbd, partial_dev));
+        HIP_TRY(h, ctk_launch_mppi_merge_partial(h->stream, parts, n_parts, n_parts, h->PC, h->mk.neg_inv_lbd, partial_dev));
     }
     h->mppi_pending = true;
     return CTK_OK;
@@ -1060,7 +1190,7 @@ static int shard_k(const ctk_handle* h) { return h->cfg.optimizer == CTK_OPT_CEM
 
 size_t ctk_shard_candidates_size(const ctk_handle* h) {
     if (!h || (h->cfg.optimizer != CTK_OPT_CEM && h->cfg.optimizer != CTK_OPT_RANDOM_ACTION)) return 0;
-    return (size_t)shard_k(h) * (2 + h->H);
+    return (size_t)shard_k(h) * (2 + h->HC);
 }
 
 int ctk_shard_iterations(const ctk_handle* h) {
@@ -1078,15 +1208,14 @@ int ctk_shard_iter_begin(ctk_handle* h, const float* s, const float* u_prev, con
     if (int rc = check_predictor(h)) return rc;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const float* d_s = nullptr;
-    if (int rc = resolve_samples(h, samples, samples_loc, (size_t)h->N * h->H, &d_s)) return rc;   // ONE iteration's draws [N,H,C]
+    if (int rc = resolve_samples(h, samples, samples_loc, (size_t)h->N * h->HC, &d_s)) return rc;   // ONE iteration's draws [N,H,C]
     RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);
     a.stream_id = (uint32_t)h->shard_it;
-    ProfSlot ps(h);
-    HIP_TRY(h, ctk_launch_affine_rollout(h->stream, h->cfg.predictor, a, h->k, d_s, cem ? 0 : 1, cem ? h->d_unom[0] : h->d_base,
-                                         cem ? h->d_std : h->d_scale, h->d_wperm, h->cfg.materialize_trajectories != 0, ps.a, ps.b));
+    if (int rc = launch_affine(h, a, d_s, cem ? 0 : 1, cem ? h->d_unom[0] : h->d_base, cem ? h->d_std : h->d_scale,
+                               h->cfg.materialize_trajectories != 0)) return rc;
     const int K = shard_k(h);
     HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, K, h->d_idx));
-    HIP_TRY(h, ctk_launch_pack_candidates(h->stream, h->d_J, h->d_Q, h->d_idx, K, h->H, h->cfg.global_rollout_offset, cand_dev));
+    HIP_TRY(h, ctk_launch_pack_candidates(h->stream, h->d_J, h->d_Q, h->d_idx, K, h->HC, h->cfg.global_rollout_offset, cand_dev));
     h->shard_pending = true;
     return CTK_OK;
     });
@@ -1097,7 +1226,7 @@ int ctk_shard_iter_end(ctk_handle* h, const float* cands_all_dev, int n_ranks) {
     return guarded(h, [&]() -> int {
     if (!h->shard_pending) return fail(h, CTK_ERR_STATE, "ctk_shard_iter_end: no iteration pending");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    const int K = shard_k(h), rs = 2 + h->H, M = n_ranks * K;
+    const int K = shard_k(h), rs = 2 + h->HC, M = n_ranks * K;
     if ((size_t)M > h->shard_idx_cap) {
         if (h->d_shard_idx) HIP_TRY(h, hipFree(h->d_shard_idx));
         h->d_shard_idx = nullptr; h->shard_idx_cap = 0;
@@ -1108,7 +1237,7 @@ int ctk_shard_iter_end(ctk_handle* h, const float* cands_all_dev, int n_ranks) {
     // among equal costs (rank-major, each list sorted), so the positional tie-break is the global one
     HIP_TRY(h, ctk_launch_select_topk(h->stream, cands_all_dev, M, K, h->d_shard_idx, rs));
     if (h->cfg.optimizer == CTK_OPT_CEM)
-        HIP_TRY(h, ctk_launch_cem_refit(h->stream, cands_all_dev + 2, h->d_shard_idx, K, h->H, h->d_unom[0], h->d_std, rs));
+        HIP_TRY(h, ctk_launch_cem_refit(h->stream, cands_all_dev + 2, h->d_shard_idx, K, h->HC, h->d_unom[0], h->d_std, rs));
     h->shard_last_cands = cands_all_dev;
     h->shard_pending = false;
     ++h->shard_it;
@@ -1121,14 +1250,12 @@ int ctk_shard_finish(ctk_handle* h, float* u_out) {
     return guarded(h, [&]() -> int {
     if (h->shard_pending || h->shard_it == 0 || !h->shard_last_cands) return fail(h, CTK_ERR_STATE, "ctk_shard_finish: no completed iteration");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    const int rs = 2 + h->H;
+    const int rs = 2 + h->HC;
     if (h->cfg.optimizer == CTK_OPT_CEM) {
-        const float mid = (h->cfg.action_low + h->cfg.action_high) * 0.5f;
-        HIP_TRY(h, ctk_launch_cem_finish(h->stream, h->shard_last_cands + 2, h->d_shard_idx, h->H, h->d_unom[0], h->d_std,
-                                         h->cfg.cem_stdev_min, h->cfg.cem_initial_action_stdev, mid, h->d_u, h->h_u_dev, h->seq, rs));
+        if (int rc = launch_cem_finish(h, h->shard_last_cands + 2, h->d_shard_idx, rs, 1.0e8f, 0)) return rc;
         ++h->count;
     } else {
-        HIP_TRY(h, ctk_launch_pick_best_first(h->stream, h->shard_last_cands + 2, h->d_shard_idx, h->H, h->d_u, h->h_u_dev, h->seq, rs));
+        if (int rc = launch_pick_best(h, h->shard_last_cands + 2, h->d_shard_idx, rs)) return rc;
     }
     h->shard_it = 0;
     h->shard_last_cands = nullptr;
@@ -1141,7 +1268,7 @@ static int rpgd_local_keep(const ctk_handle* h) { return h->cfg.opt_keep_k < h->
 
 size_t ctk_rpgd_keepers_size(const ctk_handle* h) {
     if (!h || h->cfg.optimizer != CTK_OPT_RPGD) return 0;
-    return (size_t)rpgd_local_keep(h) * (3 + 3 * h->H);
+    return (size_t)rpgd_local_keep(h) * (3 + 3 * h->HC);
 }
 
 // fresh rows this shard must draw at the next step_end (0 on non-resampling steps), given the world size
@@ -1163,14 +1290,14 @@ int ctk_rpgd_step_begin(ctk_handle* h, const float* s, const float* u_prev, floa
     if (h->shard_pending) return fail(h, CTK_ERR_STATE, "ctk_rpgd_step_begin: previous sharded step not ended");
     if (int rc = check_predictor(h)) return rc;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    for (int i = 0; i < CTK_S; ++i) h->shard_s[i] = s[i];
+    for (int i = 0; i < h->S; ++i) h->shard_s[i] = s[i];
     h->shard_has_uprev = u_prev != nullptr;
-    h->shard_uprev = u_prev ? u_prev[0] : 0.0f;
+    for (int c = 0; c < h->C; ++c) h->shard_uprev[c] = u_prev ? u_prev[c] : 0.0f;
     if (int rc = rpgd_descent(h, s, u_prev)) return rc;
     const int kl = rpgd_local_keep(h), cur = h->rcur;
     HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, kl, h->d_idx));
     HIP_TRY(h, ctk_launch_rpgd_pack_keepers(h->stream, h->d_J, h->d_pop[cur], h->d_m[cur], h->d_v[cur], h->d_ages[cur], h->d_idx, kl,
-                                            h->H, h->cfg.global_rollout_offset, keep_dev));
+                                            h->HC, h->cfg.global_rollout_offset, keep_dev));
     h->shard_pending = true;
     return CTK_OK;
     });
@@ -1182,7 +1309,7 @@ int ctk_rpgd_step_end(ctk_handle* h, const float* keep_all_dev, int n_ranks, con
     if (h->cfg.optimizer != CTK_OPT_RPGD || !h->shard_pending) return fail(h, CTK_ERR_STATE, "ctk_rpgd_step_end: no sharded RPGD step pending");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const ctk_config& c = h->cfg;
-    const int kl = rpgd_local_keep(h), M = n_ranks * kl, rs = 3 + 3 * h->H;
+    const int kl = rpgd_local_keep(h), M = n_ranks * kl, rs = 3 + 3 * h->HC;
     if (c.opt_keep_k > M) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_rpgd_step_end: opt_keep_k exceeds the gathered candidates");
     if ((size_t)M > h->shard_idx_cap) {
         if (h->d_shard_idx) HIP_TRY(h, hipFree(h->d_shard_idx));
@@ -1198,8 +1325,8 @@ int ctk_rpgd_step_end(ctk_handle* h, const float* keep_all_dev, int n_ranks, con
     const int keeper_base = (int)(c.global_rollout_offset > first_keeper ? c.global_rollout_offset - first_keeper : 0);
     const float* d_draws = nullptr;
     if (resample && n_fresh > 0)
-        if (int rc = resolve_samples(h, draws, draws_loc, (size_t)n_fresh * h->P, &d_draws)) return rc;
-    const float* up = h->shard_has_uprev ? &h->shard_uprev : nullptr;
+        if (int rc = resolve_samples(h, draws, draws_loc, (size_t)n_fresh * h->PC, &d_draws)) return rc;
+    const float* up = h->shard_has_uprev ? h->shard_uprev : nullptr;
     RolloutArgs aw = make_args(h, h->shard_s, up, h->N, h->P);
     const int cur = h->rcur, nxt = cur ^ 1;
     if (int rc = rpgd_warm(h, aw, resample ? n_fresh : 0, resample ? 1 : 0, 0, d_draws, cur, nxt, h->d_shard_idx, keep_all_dev, keeper_base)) return rc;
@@ -1215,12 +1342,12 @@ int ctk_rollout(ctk_handle* h, const float* s, const float* u_prev, const float*
     if (n < 1 || n > h->N) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_rollout: need 1 <= n <= num_rollouts");
     if (int rc = check_predictor(h)) return rc;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    const size_t H = h->H;
+    const size_t H = h->HC, Hs = h->H;   // H: floats per plan row [H,C]; Hs: horizon steps
     const float* d_s = nullptr;
     if (int rc = resolve_samples(h, Q, CTK_LOC_HOST, (size_t)n * H, &d_s)) return rc;
     float* d_traj = h->d_traj;
     float* tmp_traj = nullptr;
-    if (traj_out && !d_traj) { HIP_TRY(h, hipMalloc((void**)&tmp_traj, (size_t)n * (H + 1) * CTK_S * sizeof(float))); d_traj = tmp_traj; }
+    if (traj_out && !d_traj) { HIP_TRY(h, hipMalloc((void**)&tmp_traj, (size_t)n * (Hs + 1) * h->S * sizeof(float))); d_traj = tmp_traj; }
     // base 0, scale 1, no clipping: the plans are taken as given
     float *d_zero = nullptr, *d_one = nullptr;
     HIP_TRY(h, hipMalloc((void**)&d_zero, 2 * H * sizeof(float)));
@@ -1228,12 +1355,15 @@ int ctk_rollout(ctk_handle* h, const float* s, const float* u_prev, const float*
     std::vector<float> zo(2 * H, 0.0f);
     for (size_t i = 0; i < H; ++i) zo[H + i] = 1.0f;
     HIP_TRY(h, hipMemcpyAsync(d_zero, zo.data(), 2 * H * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    RolloutArgs a = make_args(h, s, u_prev, n, (int)H);
-    a.lo = -INFINITY; a.hi = INFINITY;
+    RolloutArgs a = make_args(h, s, u_prev, n, h->H);
+    for (int c = 0; c < h->C; ++c) { a.lo[c] = -INFINITY; a.hi[c] = INFINITY; }
     a.traj_out = traj_out ? d_traj : nullptr;
-    hipError_t e = ctk_launch_affine_rollout(h->stream, h->cfg.predictor, a, h->k, d_s, 0, d_zero, d_one, h->d_wperm, traj_out != nullptr);
+    hipError_t e = h->generic
+        ? ctk_launch_g_rollout(h->stream, h->env, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s, d_zero, d_one,
+                               0, nullptr, traj_out != nullptr)
+        : ctk_launch_affine_rollout(h->stream, h->cfg.predictor, a, h->k, d_s, 0, d_zero, d_one, h->d_wperm, traj_out != nullptr);
     if (e == hipSuccess && traj_out)
-        e = hipMemcpyAsync(traj_out, d_traj, (size_t)n * (H + 1) * CTK_S * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+        e = hipMemcpyAsync(traj_out, d_traj, (size_t)n * (Hs + 1) * h->S * sizeof(float), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess && J_out) e = hipMemcpyAsync(J_out, h->d_J, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
     hipError_t e2 = hipStreamSynchronize(h->stream);
     hipFree(d_zero);
@@ -1258,19 +1388,19 @@ int ctk_read(ctk_handle* h, int which, float* dst, size_t cap, size_t* n_out) {
 
 size_t ctk_state_size(const ctk_handle* h) {
     if (!h) return 0;
-    const size_t H = h->H;
+    const size_t H = h->HC, C = h->C;   // [H,C] rows; the optimizer's last output u is C floats
     switch (h->cfg.optimizer) {
-        case CTK_OPT_MPPI: return H + 1;
-        case CTK_OPT_CEM: return 2 * H + 2 + (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ ? 2 * (size_t)h->N * H + 1 : 0);
-        case CTK_OPT_RANDOM_ACTION: return 1;
-        case CTK_OPT_RPGD: return 3 * (size_t)h->N * H + (size_t)h->N + 3;
+        case CTK_OPT_MPPI: return H + C;
+        case CTK_OPT_CEM: return 2 * H + C + 1 + (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ ? 2 * (size_t)h->N * H + 1 : 0);
+        case CTK_OPT_RANDOM_ACTION: return C;
+        case CTK_OPT_RPGD: return 3 * (size_t)h->N * H + (size_t)h->N + C + 2;
     }
     return 0;
 }
 
 int ctk_get_state(ctk_handle* h, float* dst, size_t cap) {
     if (!h || !dst) return CTK_ERR_INVALID_ARGUMENT;
-    const size_t n = ctk_state_size(h), H = h->H;
+    const size_t n = ctk_state_size(h), H = h->HC, C = h->C;
     if (cap < n) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_get_state: destination too small");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     size_t o = 0;
@@ -1279,19 +1409,19 @@ int ctk_get_state(ctk_handle* h, float* dst, size_t cap) {
         o += cnt; return e;
     };
     switch (h->cfg.optimizer) {
-        case CTK_OPT_MPPI: HIP_TRY(h, pull(h->d_unom[h->cur], H)); HIP_TRY(h, pull(h->d_u, 1)); break;
-        case CTK_OPT_CEM: HIP_TRY(h, pull(h->d_unom[0], H)); HIP_TRY(h, pull(h->d_std, H)); HIP_TRY(h, pull(h->d_u, 1));
+        case CTK_OPT_MPPI: HIP_TRY(h, pull(h->d_unom[h->cur], H)); HIP_TRY(h, pull(h->d_u, C)); break;
+        case CTK_OPT_CEM: HIP_TRY(h, pull(h->d_unom[0], H)); HIP_TRY(h, pull(h->d_std, H)); HIP_TRY(h, pull(h->d_u, C));
             HIP_TRY(h, hipStreamSynchronize(h->stream)); dst[o++] = (float)h->count;
             if (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) {   // the Keras optimizer's persistent moments and step count
                 HIP_TRY(h, pull(h->d_m[0], (size_t)h->N * H)); HIP_TRY(h, pull(h->d_v[0], (size_t)h->N * H));
                 HIP_TRY(h, hipStreamSynchronize(h->stream)); dst[o++] = (float)h->adam_step;
             }
             break;
-        case CTK_OPT_RANDOM_ACTION: HIP_TRY(h, pull(h->d_u, 1)); break;
+        case CTK_OPT_RANDOM_ACTION: HIP_TRY(h, pull(h->d_u, C)); break;
         case CTK_OPT_RPGD: {
             const size_t NH = (size_t)h->N * H;
             HIP_TRY(h, pull(h->d_pop[h->rcur], NH)); HIP_TRY(h, pull(h->d_m[h->rcur], NH)); HIP_TRY(h, pull(h->d_v[h->rcur], NH));
-            HIP_TRY(h, pull(h->d_ages[h->rcur], h->N)); HIP_TRY(h, pull(h->d_u, 1));
+            HIP_TRY(h, pull(h->d_ages[h->rcur], h->N)); HIP_TRY(h, pull(h->d_u, C));
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             dst[o++] = (float)h->adam_step; dst[o++] = (float)h->count;
             break;
@@ -1306,26 +1436,26 @@ int ctk_set_state(ctk_handle* h, const float* src, size_t n) {
     if (!h || !src) return CTK_ERR_INVALID_ARGUMENT;
     if (n != ctk_state_size(h)) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_set_state: wrong state size");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    const size_t H = h->H;
+    const size_t H = h->HC, C = h->C;
     size_t o = 0;
     auto push = [&](float* dstp, size_t cnt) -> hipError_t {
         hipError_t e = hipMemcpyAsync(dstp, src + o, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream);
         o += cnt; return e;
     };
     switch (h->cfg.optimizer) {
-        case CTK_OPT_MPPI: HIP_TRY(h, push(h->d_unom[h->cur], H)); HIP_TRY(h, push(h->d_u, 1)); break;
-        case CTK_OPT_CEM: HIP_TRY(h, push(h->d_unom[0], H)); HIP_TRY(h, push(h->d_std, H)); HIP_TRY(h, push(h->d_u, 1));
+        case CTK_OPT_MPPI: HIP_TRY(h, push(h->d_unom[h->cur], H)); HIP_TRY(h, push(h->d_u, C)); break;
+        case CTK_OPT_CEM: HIP_TRY(h, push(h->d_unom[0], H)); HIP_TRY(h, push(h->d_std, H)); HIP_TRY(h, push(h->d_u, C));
             h->count = (int)src[o++];
             if (h->variant == CTK_OPT_CEM_GRAD_BHARADHWAJ) {
                 HIP_TRY(h, push(h->d_m[0], (size_t)h->N * H)); HIP_TRY(h, push(h->d_v[0], (size_t)h->N * H));
                 h->adam_step = (int)src[o++];
             }
             break;
-        case CTK_OPT_RANDOM_ACTION: HIP_TRY(h, push(h->d_u, 1)); break;
+        case CTK_OPT_RANDOM_ACTION: HIP_TRY(h, push(h->d_u, C)); break;
         case CTK_OPT_RPGD: {
             const size_t NH = (size_t)h->N * H;
             HIP_TRY(h, push(h->d_pop[h->rcur], NH)); HIP_TRY(h, push(h->d_m[h->rcur], NH)); HIP_TRY(h, push(h->d_v[h->rcur], NH));
-            HIP_TRY(h, push(h->d_ages[h->rcur], h->N)); HIP_TRY(h, push(h->d_u, 1));
+            HIP_TRY(h, push(h->d_ages[h->rcur], h->N)); HIP_TRY(h, push(h->d_u, C));
             h->adam_step = (int)src[o++]; h->count = (int)src[o++];
             h->rpgd_ready = true;
             break;
@@ -1381,6 +1511,7 @@ int ctk_p2p_close(ctk_handle* h) {
 int ctk_p2p_alloc(ctk_handle* h, int rank, int world, void* handle_out) {
     if (!h || !handle_out) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_p2p_alloc: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
     if (h->cfg.optimizer != CTK_OPT_MPPI) return fail(h, CTK_ERR_STATE, "ctk_p2p_alloc: handle is not MPPI");
+    if (h->generic) return fail(h, CTK_ERR_UNSUPPORTED, "ctk_p2p_alloc: the peer-to-peer exchange is built into the CartPole kernels only (use the begin / all-gather / end path)");
     if (world < 1 || world > CTK_P2P_MAX_WORLD || rank < 0 || rank >= world)
         return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_p2p_alloc: need 0 <= rank < world <= 16");
     static_assert(sizeof(hipIpcMemHandle_t) == CTK_P2P_HANDLE_BYTES, "handle size");
@@ -1429,7 +1560,7 @@ int ctk_p2p_step(ctk_handle* h, const float* s, const float* u_prev, const float
     if (!h->p2p_connected) return fail(h, CTK_ERR_STATE, "ctk_p2p_step: call ctk_p2p_alloc and ctk_p2p_connect first");
     if (h->mppi_pending) return fail(h, CTK_ERR_STATE, "ctk_p2p_step: a begin/end sharded step is pending");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    for (int i = 0; i < CTK_S; ++i) h->mppi_s[i] = s[i];
+    for (int i = 0; i < h->S; ++i) h->mppi_s[i] = s[i];
     const int W = h->p2p_world, rs = 2 + h->P, par = (int)(h->p2p_seq & 1u);
     float* my_slot = h->p2p_bufs[h->p2p_rank] + (size_t)(par * W + h->p2p_rank) * rs;
     uint32_t* err = reinterpret_cast<uint32_t*>(h->h_u_dev) + 2;
@@ -1449,7 +1580,7 @@ int ctk_p2p_step(ctk_handle* h, const float* s, const float* u_prev, const float
         }
         HIP_TRY(h, ctk_launch_mppi_p2p_exchange(h->stream, h->p2p_bufs, h->p2p_rank, W, h->P, h->p2p_seq, err, h->p2p_timeout_s,
                                                 h->mk.neg_inv_lbd, h->H, h->d_interp, h->d_unom[h->cur], h->d_unom[nxt],
-                                                h->cfg.action_low, h->cfg.action_high, h->d_u, h->h_u_dev, h->seq));
+                                                h->cfg.action_low[0], h->cfg.action_high[0], h->d_u, h->h_u_dev, h->seq));
     }
     h->cur = nxt;
     ++h->p2p_seq;

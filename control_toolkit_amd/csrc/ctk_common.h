@@ -5,8 +5,8 @@
 #include <stdint.h>
 #include "../../include/ctk_hip.h"
 
-constexpr int CTK_S = 4;          // num_states (position, positionD, angle, angleD)
-constexpr int CTK_C = 1;          // num_control_inputs
+constexpr int CTK_S = 4;          // CartPole: num_states (position, positionD, angle, angleD) — the hand-tuned kernels
+constexpr int CTK_C = 1;          // CartPole: num_control_inputs     (other environments: csrc/ctk_env.h, ctk_generic.hip)
 constexpr int CTK_WAVE = 64;
 constexpr int CTK_MLP_IN = 5, CTK_MLP_H = 32, CTK_MLP_OUT = 4;
 constexpr int CTK_MLP_NW = CTK_MLP_IN * CTK_MLP_H + CTK_MLP_H + CTK_MLP_H * CTK_MLP_H + CTK_MLP_H +
@@ -67,10 +67,11 @@ struct MppiK {
 
 // Arguments every rollout kernel takes by value (no H2D copy for s / u_prev).
 struct RolloutArgs {
-    float s0[CTK_S];
-    float u_prev;            // used when u_prev_dev == nullptr
-    const float* u_prev_dev; // optimizer's own last output, device resident
-    float lo, hi;
+    float s0[CTK_MAX_STATES];
+    float u_prev[CTK_MAX_INPUTS];   // used when u_prev_dev == nullptr
+    const float* u_prev_dev;        // optimizer's own last output [C], device resident
+    float lo[CTK_MAX_INPUTS], hi[CTK_MAX_INPUTS];   // control limits per input
+    int C;                          // num_control_inputs of the environment (1 in the CartPole kernels)
     int N, H, P;
     uint32_t p_magic;        // ceil(2^32 / P): flat / P == umulhi(flat, p_magic) for flat*P < 2^32 (P >= 2)
     int identity_interp;     // period == 1: u[t] = y[t] (column t of the matrix is e_t)

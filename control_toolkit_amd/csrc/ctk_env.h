@@ -1,0 +1,216 @@
+// ctk_env.h — the environment interface of the optimizer kernels.
+//
+// What the reference selects at run time — the plant model behind predictor.predict_core (external SI_Toolkit,
+// controller_mpc.py:67-73) and the concrete cost class Control_Toolkit_ASF.Cost_Functions.<environment>.<name>
+// (cost_function_wrapper.py:59-66) — is here ONE compile-time policy per environment:
+//
+//   template <> struct Env<ID> {
+//       static constexpr int S, C;                    num_states, num_control_inputs
+//       struct / using K;                             derived fp32 constants (host: derive(), double -> fp32 once)
+//       step(k, s, u)                                 one predictor step (intermediate_steps Euler sub-steps), in place
+//       stage_cost(k, s, u, u_prev) / terminal_cost   the concrete cost terms (aggregation = mean over H+1 is the
+//                                                     kernels' job, Cost_Functions/__init__.py:90-93)
+//       step_vjp / stage_grad_state / terminal_grad / input_grad     reverse mode for the gradient-based optimizers
+//   };
+//
+// The template kernels of ctk_generic.hip (MPPI / affine-sampled rollouts / RPGD descent) are written against this
+// interface only; adding an environment = one more specialisation + one line in CTK_FOR_ENV.  CartPole additionally
+// keeps its hand-tuned kernels (ctk_mppi.hip, ctk_sampled.hip, ctk_rpgd.hip); its specialisation here wraps the same
+// device functions, so "generic CartPole" and "tuned CartPole" are the same arithmetic (tests/test_gpu_env.py).
+#pragma once
+#include "ctk_device.h"
+
+template <int ENV>
+struct Env;
+
+// host-side description shared by ctk_api.hip (ctk_env_info / ctk_param_name)
+struct EnvInfo {
+    const char* name;
+    int S, C, n_params;
+    const char* const* param_names;
+    const float* param_defaults;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// CartPole (oracle/ctk_oracle.py: EnvParams, Predictor._ode_step/_ode_vjp, Cost)
+// ---------------------------------------------------------------------------------------------------------------
+template <>
+struct Env<CTK_ENV_CARTPOLE> {
+    static constexpr int S = 4, C = 1;
+    using K = EnvK;
+    static K derive(const float* p, float dt, int isteps) { return derive_constants(p, dt, isteps); }
+
+    CTK_DEV static void step(const K& k, float (&s)[S], const float (&u)[C]) {
+        State4 st{s[0], s[1], s[2], s[3]};
+        float sn, cs;
+        ctk_sincosf(st.th, &sn, &cs);
+        ode_step(k, st, u[0], sn, cs);
+        s[0] = st.x; s[1] = st.v; s[2] = st.th; s[3] = st.om;
+    }
+    CTK_DEV static float stage_cost(const K& k, const float (&s)[S], const float (&u)[C], const float (&up)[C]) {
+        const State4 st{s[0], s[1], s[2], s[3]};
+        return ::stage_cost(k, st, cosf(s[2]), u[0], up[0]);
+    }
+    CTK_DEV static float terminal_cost(const K& k, const float (&s)[S]) {
+        return ::terminal_cost(k, State4{s[0], s[1], s[2], s[3]});
+    }
+    // adjoint of one Euler step (intermediate_steps == 1): lam = dL/ds' -> ds = dL/ds, du = dL/du
+    CTK_DEV static void step_vjp(const K& k, const float (&s)[S], const float (&u)[C], const float (&lam)[S], float (&ds)[S],
+                                 float (&du)[C]) {
+        const float v = s[1], om = s[3];
+        float sn, cs;
+        ctk_sincosf(s[2], &sn, &cs);
+        const float A = k.u_max * u[0] + k.k_ml * om * om * sn - k.M_fric * v;
+        const float tmp = A * k.inv_mt;
+        const float D = k.k43l - k.k_mpl_mt * cs * cs;
+        const float Nn = k.g * sn - cs * tmp - k.k_jf * om;
+        const float thdd = fdiv_pos(Nn, D);
+        const float dt = k.dt;
+        const float a_xdd = dt * lam[1];
+        const float a_thdd = dt * lam[3] - k.k_mpl_mt * cs * a_xdd;
+        float a_tmp = a_xdd;
+        float a_cs = -k.k_mpl_mt * thdd * a_xdd;
+        const float a_Nn = fdiv_pos(a_thdd, D);
+        const float a_D = -a_Nn * thdd;
+        float a_sn = k.g * a_Nn;
+        a_cs = a_cs - tmp * a_Nn - 2.0f * k.k_mpl_mt * cs * a_D;
+        a_tmp = a_tmp - cs * a_Nn;
+        const float a_A = a_tmp * k.inv_mt;
+        a_sn = a_sn + k.k_ml * om * om * a_A;
+        ds[0] = lam[0];
+        ds[1] = lam[1] + dt * lam[0] - k.M_fric * a_A;
+        ds[2] = lam[2] + cs * a_sn - sn * a_cs;
+        ds[3] = lam[3] + dt * lam[2] - k.k_jf * a_Nn + 2.0f * k.k_ml * om * sn * a_A;
+        du[0] = k.u_max * a_A;
+    }
+    CTK_DEV static void stage_grad_state(const K& k, const float (&s)[S], float (&g)[S]) {
+        float sn, cs;
+        ctk_sincosf(s[2], &sn, &cs);
+        g[0] = 2.0f * k.dd_weight * k.inv_xs * k.inv_xs * (s[0] - k.target_position);
+        g[1] = 0.0f;
+        g[2] = 2.0f * k.ep_c * (1.0f - cs) * sn;
+        g[3] = 2.0f * k.ekp_weight * s[3];
+    }
+    CTK_DEV static void terminal_grad(const K& k, const float (&s)[S], float (&g)[S]) {
+        float sn, cs;
+        ctk_sincosf(s[2], &sn, &cs);
+        g[0] = k.terminal_weight * 2.0f * k.dd_weight * k.inv_xs * k.inv_xs * (s[0] - k.target_position);
+        g[1] = 0.0f;
+        g[2] = k.terminal_weight * 2.0f * k.ep_c * (1.0f - cs) * sn;
+        g[3] = 0.0f;
+    }
+    // stage cost's input-only terms cc + ccrc: gradient w.r.t. this step's input (gu) and the previous one (gp)
+    CTK_DEV static void input_grad(const K& k, const float (&u)[C], const float (&up)[C], float (&gu)[C], float (&gp)[C]) {
+        const float d = 2.0f * k.ccrc_weight * (u[0] - up[0]);
+        gu[0] = 2.0f * k.ccR * u[0] + d;
+        gp[0] = -d;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Quad2D — planar quadrotor (oracle/ctk_oracle.py: Quad2DParams, Predictor._quad_step/_quad_vjp, Cost._quad_*)
+// state (x, vx, z, vz, theta, omega); inputs (u1, u2) in [-1, 1]; rotor thrust T_i = (m g / 2)(1 + thrust_gain u_i)
+// ---------------------------------------------------------------------------------------------------------------
+struct QuadK {
+    float dt, g, kF, kM, c_v, c_w;                                                       // dynamics
+    float tx, tz, pos_c, ang_w, vel_w, angvel_w, ccR, ccrc_weight, terminal_weight;      // cost
+    int intermediate_steps;
+};
+
+template <>
+struct Env<CTK_ENV_QUAD2D> {
+    static constexpr int S = 6, C = 2;
+    using K = QuadK;
+    static K derive(const float* p, float dt, int isteps) {
+        auto d = [&](int id) { return (double)p[id]; };
+        K k;
+        k.dt = (float)((double)dt / isteps);
+        k.g = (float)d(CTK_Q_G);
+        k.kF = (float)(0.5 * d(CTK_Q_G) * d(CTK_Q_THRUST_GAIN));
+        k.kM = (float)(d(CTK_Q_ARM) * 0.5 * d(CTK_Q_MASS) * d(CTK_Q_G) * d(CTK_Q_THRUST_GAIN) / d(CTK_Q_INERTIA));
+        k.c_v = (float)d(CTK_Q_DRAG_LIN);
+        k.c_w = (float)d(CTK_Q_DRAG_ANG);
+        k.tx = p[CTK_Q_TARGET_X]; k.tz = p[CTK_Q_TARGET_Z];
+        k.pos_c = (float)(d(CTK_Q_POS_WEIGHT) / (d(CTK_Q_POS_SCALE) * d(CTK_Q_POS_SCALE)));
+        k.ang_w = p[CTK_Q_ANG_WEIGHT]; k.vel_w = p[CTK_Q_VEL_WEIGHT]; k.angvel_w = p[CTK_Q_ANGVEL_WEIGHT];
+        k.ccR = (float)(d(CTK_Q_CC_WEIGHT) * d(CTK_Q_R));
+        k.ccrc_weight = p[CTK_Q_CCRC_WEIGHT];
+        k.terminal_weight = p[CTK_Q_TERMINAL_WEIGHT];
+        k.intermediate_steps = isteps;
+        return k;
+    }
+
+    CTK_DEV static void step(const K& k, float (&s)[S], const float (&u)[C]) {
+        const float aF = k.g + k.kF * (u[0] + u[1]);      // total thrust / mass
+        const float aM = k.kM * (u[0] - u[1]);            // rotor torque / inertia
+        for (int i = 0; i < k.intermediate_steps; ++i) {
+            float sn, cs;
+            ctk_sincosf(s[4], &sn, &cs);
+            const float ax = -aF * sn - k.c_v * s[1];
+            const float az = aF * cs - k.g - k.c_v * s[3];
+            const float al = aM - k.c_w * s[5];
+            const float nx = s[0] + k.dt * s[1], nvx = s[1] + k.dt * ax, nz = s[2] + k.dt * s[3], nvz = s[3] + k.dt * az;
+            const float nth = s[4] + k.dt * s[5], nom = s[5] + k.dt * al;
+            s[0] = nx; s[1] = nvx; s[2] = nz; s[3] = nvz; s[4] = nth; s[5] = nom;
+        }
+    }
+    CTK_DEV static float state_terms(const K& k, const float (&s)[S]) {   // position + attitude (shared by stage and terminal)
+        const float dx = s[0] - k.tx, dz = s[2] - k.tz;
+        return k.pos_c * (dx * dx + dz * dz) + k.ang_w * (1.0f - cosf(s[4]));
+    }
+    CTK_DEV static float stage_cost(const K& k, const float (&s)[S], const float (&u)[C], const float (&up)[C]) {
+        const float vel = k.vel_w * (s[1] * s[1] + s[3] * s[3]) + k.angvel_w * s[5] * s[5];
+        const float d0 = u[0] - up[0], d1 = u[1] - up[1];
+        return state_terms(k, s) + vel + k.ccR * (u[0] * u[0] + u[1] * u[1]) + k.ccrc_weight * (d0 * d0 + d1 * d1);
+    }
+    CTK_DEV static float terminal_cost(const K& k, const float (&s)[S]) { return k.terminal_weight * state_terms(k, s); }
+
+    CTK_DEV static void step_vjp(const K& k, const float (&s)[S], const float (&u)[C], const float (&lam)[S], float (&ds)[S],
+                                 float (&du)[C]) {
+        float sn, cs;
+        ctk_sincosf(s[4], &sn, &cs);
+        const float aF = k.g + k.kF * (u[0] + u[1]);
+        const float dt = k.dt;
+        const float a_ax = dt * lam[1], a_az = dt * lam[3], a_al = dt * lam[5];
+        const float a_aF = -sn * a_ax + cs * a_az;
+        ds[0] = lam[0];
+        ds[1] = lam[1] + dt * lam[0] - k.c_v * a_ax;
+        ds[2] = lam[2];
+        ds[3] = lam[3] + dt * lam[2] - k.c_v * a_az;
+        ds[4] = lam[4] - aF * (cs * a_ax + sn * a_az);
+        ds[5] = lam[5] + dt * lam[4] - k.c_w * a_al;
+        du[0] = k.kF * a_aF + k.kM * a_al;
+        du[1] = k.kF * a_aF - k.kM * a_al;
+    }
+    CTK_DEV static void stage_grad_state(const K& k, const float (&s)[S], float (&g)[S]) {
+        g[0] = 2.0f * k.pos_c * (s[0] - k.tx);
+        g[1] = 2.0f * k.vel_w * s[1];
+        g[2] = 2.0f * k.pos_c * (s[2] - k.tz);
+        g[3] = 2.0f * k.vel_w * s[3];
+        g[4] = k.ang_w * sinf(s[4]);
+        g[5] = 2.0f * k.angvel_w * s[5];
+    }
+    CTK_DEV static void terminal_grad(const K& k, const float (&s)[S], float (&g)[S]) {
+        g[0] = k.terminal_weight * 2.0f * k.pos_c * (s[0] - k.tx);
+        g[1] = 0.0f;
+        g[2] = k.terminal_weight * 2.0f * k.pos_c * (s[2] - k.tz);
+        g[3] = 0.0f;
+        g[4] = k.terminal_weight * k.ang_w * sinf(s[4]);
+        g[5] = 0.0f;
+    }
+    CTK_DEV static void input_grad(const K& k, const float (&u)[C], const float (&up)[C], float (&gu)[C], float (&gp)[C]) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float d = 2.0f * k.ccrc_weight * (u[c] - up[c]);
+            gu[c] = 2.0f * k.ccR * u[c] + d;
+            gp[c] = -d;
+        }
+    }
+};
+
+// dispatch on the runtime environment id: CTK_FOR_ENV(id, ENVV, stmt) runs `stmt` with the constant ENVV
+#define CTK_FOR_ENV(id, ENVV, ...)                                              \
+    do {                                                                        \
+        if ((id) == CTK_ENV_CARTPOLE) { constexpr int ENVV = CTK_ENV_CARTPOLE; __VA_ARGS__; } \
+        else { constexpr int ENVV = CTK_ENV_QUAD2D; __VA_ARGS__; }             \
+    } while (0)

@@ -162,7 +162,7 @@ CTK_DEV float rollout_gru_impl(const RolloutArgs& a, const EnvK& k, const GruW& 
     const MlpCostK ck = mlp_cost_coeffs(k, g, INPUT_COST);
     GruState st = gru_load_state(h0, g);
     float sv = a.s0[g];
-    float uprev = a.u_prev_dev ? *a.u_prev_dev : a.u_prev;
+    float uprev = a.u_prev_dev ? *a.u_prev_dev : a.u_prev[0];
     float csum = 0.0f;
     const int H = a.H;
     float u_next = ufn(0);

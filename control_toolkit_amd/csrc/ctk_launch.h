@@ -114,8 +114,9 @@ hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& 
                                    float eps, float clip, float* Q, float* m, float* v, const float* bc_table, int bc_len,
                                    int t0, int iters, const float* wperm, float* scratch, hipEvent_t ev_start = nullptr,
                                    hipEvent_t ev_stop = nullptr, int rule = 0, const RpgdFusedWarm* fused = nullptr);
+// a.C control inputs, a.lo / a.hi the per-input limits; whole_space: uniform samples span [lo[c], hi[c]] (sample_whole_control_space)
 hipError_t ctk_launch_rpgd_warmstart(hipStream_t st, const RolloutArgs& a, int N, int H, int P, int n_new, int gather, int shift_previous,
-                                     int sampling_distribution, int reset, float lo, float hi, float sample_stdev,
+                                     int sampling_distribution, int reset, int whole_space, float sample_stdev,
                                      float sample_mean, float sample_min, float sample_max, const float* draws, const int* idx,
                                      const float* Q_old, const float* m_old, const float* v_old, const float* ages_old,
                                      float* Q_new, float* m_new, float* v_new, float* ages_new, const InterpEntry* interp,
@@ -123,3 +124,28 @@ hipError_t ctk_launch_rpgd_warmstart(hipStream_t st, const RolloutArgs& a, int N
                                      int rs = 0, int keeper_base = 0, int fresh_tail = 0);
 hipError_t ctk_launch_rpgd_pack_keepers(hipStream_t st, const float* J, const float* Q, const float* m, const float* v,
                                         const float* ages, const int* idx, int K, int H, int global_offset, float* out);
+
+// ---- ctk_generic.hip : environment-agnostic template kernels (ctk_env.h) ------------------------------------
+constexpr int CTK_G_MODE_MPPI = 0, CTK_G_MODE_AFFINE = 1;
+size_t ctk_g_rollout_lds(int cols, int H, int C);
+int ctk_g_rollout_blocks(int N);                 // 64 trajectories per workgroup = block records of one MPPI launch
+const char* ctk_g_rollout_name(int env, int mode, bool log);
+// a.P = inducing points (MPPI) — the launcher turns it into sample columns per row (P*C or H*C); params = the handle's
+// primary parameters of `env` (derived constants are formed per launch on the host, double -> fp32 once)
+hipError_t ctk_launch_g_rollout(hipStream_t st, int env, int mode, const RolloutArgs& a, const float* params, float dt, int isteps,
+                                const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
+                                float* parts, bool log, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+hipError_t ctk_launch_g_mppi_update(hipStream_t st, const float* rec, int P, int C, int H, const InterpEntry* interp, const float* u_nom_in,
+                                    float* u_nom_out, const RolloutArgs& a, float* u_dev, float* u_host, uint32_t seq);
+hipError_t ctk_launch_g_cem_finish(hipStream_t st, const float* Q, const int* idx, int H, int C, float* mu, float* sd, float std_min,
+                                   float init_std, const RolloutArgs& a, float* u_dev, float* u_host, uint32_t seq, int ldq,
+                                   float std_max = 1.0e8f, int u_from_mu = 0);
+hipError_t ctk_launch_g_pick_best_first(hipStream_t st, const float* Q, const int* idx, int C, float* u_dev, float* u_host, uint32_t seq,
+                                        int ldq);
+size_t ctk_g_rpgd_descent_lds(int env, int H, bool* tape_in_lds);
+size_t ctk_g_rpgd_scratch_floats(int env, int N, int H);
+const char* ctk_g_rpgd_descent_name(int env);
+hipError_t ctk_launch_g_rpgd_descent(hipStream_t st, int env, const RolloutArgs& a, const float* params, float dt, int isteps, float lr,
+                                     float b1, float b2, float eps, float clip, float* Q, float* m, float* v, const float* bc_table,
+                                     int bc_len, int t0, int iters, float* scratch, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
+                                     int rule = 0);

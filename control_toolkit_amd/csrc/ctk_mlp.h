@@ -182,7 +182,7 @@ CTK_DEV float rollout_mlp_impl(const RolloutArgs& a, const EnvK& k, const MlpFwd
     const bool valid = n < a.N;
     const MlpCostK ck = mlp_cost_coeffs(k, g, INPUT_COST);
     float sv = a.s0[g];
-    float uprev = a.u_prev_dev ? *a.u_prev_dev : a.u_prev;
+    float uprev = a.u_prev_dev ? *a.u_prev_dev : a.u_prev[0];
     float csum = 0.0f, am = 0.0f;
     const int H = a.H;
     float u_next = ufn(0);

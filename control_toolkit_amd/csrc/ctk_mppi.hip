@@ -344,11 +344,11 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
                 const int i0 = i0_s[h];                               // LDS broadcast reads
                 du = my[i0] * w0_s[h] + my[i0 + 1] * w1_s[h];         // Interpolator.py:97-106
             }
-            return fminf(fmaxf(un_s[h] + du, a.lo), a.hi);            // optimizer_mppi.py:186-187
+            return fminf(fmaxf(un_s[h] + du, a.lo[0]), a.hi[0]);            // optimizer_mppi.py:186-187
         };
         const int h0 = hbeg, h1 = hend;
         float corr = 0.0f, cin = 0.0f, dummy;
-        float uprev = (h0 == 0 || h0 >= H) ? (a.u_prev_dev ? *a.u_prev_dev : a.u_prev) : input_at(h0 - 1, dummy);
+        float uprev = (h0 == 0 || h0 >= H) ? (a.u_prev_dev ? *a.u_prev_dev : a.u_prev[0]) : input_at(h0 - 1, dummy);
 #pragma unroll 2
         for (int h = h0; h < h1; ++h) {
             float du;
@@ -597,13 +597,13 @@ __global__ __launch_bounds__(64) void ctk_mppi_rollout_tp(RolloutArgs a, EnvK k,
     const float* my = tile + lane * ts;
     const bool ident = a.identity_interp != 0;
     float corr = 0.0f, cin = 0.0f;
-    float uprev = a.u_prev_dev ? *a.u_prev_dev : a.u_prev;
+    float uprev = a.u_prev_dev ? *a.u_prev_dev : a.u_prev[0];
     float amax = 0.0f;
     auto F_at = [&](int h) {
         float du;
         if (ident) du = my[h];
         else { const int i0 = i0_s[h]; du = my[i0] * w0_s[h] + my[i0 + 1] * w1_s[h]; }
-        const float u = fminf(fmaxf(un_s[h] + du, a.lo), a.hi);
+        const float u = fminf(fmaxf(un_s[h] + du, a.lo[0]), a.hi[0]);
         corr += m.cc * (m.k_dd * (du * du) + m.R * u * du + m.k_uu * (u * u));
         cin += stage_cost_input(k, u, uprev);
         uprev = u;
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(64) void ctk_mppi_rollout_tp(RolloutArgs a, EnvK k,
     if (k.intermediate_steps == 1) J = recur_ode_state_cost<LOG, false, true>(a, k, n, valid, F_at, &amax);
     else J = recur_ode_state_cost<LOG, true, false>(a, k, n, valid, F_at, &amax);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0)) {
-        corr = 0.0f; cin = 0.0f; uprev = a.u_prev_dev ? *a.u_prev_dev : a.u_prev;
+        corr = 0.0f; cin = 0.0f; uprev = a.u_prev_dev ? *a.u_prev_dev : a.u_prev[0];
         J = recur_ode_state_cost<LOG, true, false>(a, k, n, valid, F_at, &amax);
     }
     J = (J + cin) * a.inv_Hp1 + corr;
@@ -693,7 +693,7 @@ hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& 
     fz.mode = fuse.mode; fz.counter = fuse.counter; fz.out_rec = fuse.out_rec;
     fz.ll = (fuse.mode != 0 && fz.stage_ok) ? fuse.ll : nullptr;
     fz.p2p = static_cast<const P2PArgs*>(fuse.p2p); fz.p2p_seq = fuse.p2p_seq;
-    fz.up = MppiUpdateArgs{nullptr, nullptr, nullptr, nullptr, a.H, a.interp, u_nom, fuse.u_nom_out, a.lo, a.hi, fuse.u_dev, fuse.u_host, fuse.seq};
+    fz.up = MppiUpdateArgs{nullptr, nullptr, nullptr, nullptr, a.H, a.interp, u_nom, fuse.u_nom_out, a.lo[0], a.hi[0], fuse.u_dev, fuse.u_host, fuse.seq};
 #define CTK_MPPI_LAUNCH(PREDV, LOGV, P2PV) CTK_LAUNCH((ctk_mppi_rollout<PREDV, LOGV, P2PV>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, wperm, parts, a.N, a.H, a.P, a.p_magic, a, k, m, fz)
 #define CTK_MPPI_LAUNCH_PRED(PREDV)                                                            \
     do {                                                                                       \

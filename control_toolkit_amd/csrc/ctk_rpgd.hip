@@ -15,6 +15,7 @@
 //        input (:426,:449-516,:523).
 #include "ctk_rollout.h"
 #include "ctk_mlp.h"
+#include "ctk_adam.h"
 #include "ctk_launch.h"
 
 constexpr int RP_TRAJ = 64;
@@ -172,27 +173,6 @@ CTK_DEV float rpgd_backward_mlp(const RolloutArgs& a, const EnvK& k, const MlpBw
     return nrm2;
 }
 
-struct AdamK {
-    float lr, b1, b2, one_m_b1, one_m_b2, eps, clip;
-    int rule;   // 0: in-repo torch Adam (optimizer_rpgd.py:56-82); 1: Keras Adam (gradient_tf, bharadhwaj); 2: plain SGD (cem_naive_grad)
-};
-
-// Adam for one element (optimizer_rpgd.py:68-79 in fp32, scalars rounded to fp32 as torch does)
-CTK_DEV float adam_update(const AdamK& ad, float q, float g, float& m, float& v, float bc1, float bc2, float lo, float hi) {
-    if (ad.rule == 2) return fminf(fmaxf(q - ad.lr * g, lo), hi);   // optimizer_cem_naive_grad_tf.py:70-71
-    m = m * ad.b1 + ad.one_m_b1 * g;
-    v = v * ad.b2 + ad.one_m_b2 * (g * g);
-    if (ad.rule == 1) {
-        // tf.keras.optimizers.Adam (third party; published update rule): lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
-        // var -= lr_t * m / (sqrt(v) + eps)   — epsilon is NOT bias-corrected, unlike the torch branch
-        const float lr_t = ad.lr * sqrtf(bc2) / bc1;
-        return fminf(fmaxf(q - lr_t * m / (sqrtf(v) + ad.eps), lo), hi);
-    }
-    const float m_hat = m / bc1, v_hat = v / bc2;
-    const float qn = q - ad.lr * m_hat / (sqrtf(v_hat) + ad.eps);
-    return fminf(fmaxf(qn, lo), hi);
-}
-
 // ---------------------------------------------------------------------------------------------
 // warm start / resampling / reset.  One thread per (row, h) of the NEW population.
 //   new row i <  n_new : fresh sample (sample_actions :275-296), moments 0, age 0
@@ -202,7 +182,9 @@ CTK_DEV float adam_update(const AdamK& ad, float q, float g, float& m, float& v,
 // ---------------------------------------------------------------------------------------------
 struct WarmArgs {
     int N, H, P, n_new, gather, shift_previous, sampling_distribution, reset;
-    float lo, hi, sample_stdev, sample_mean, sample_min, sample_max;
+    float sample_stdev, sample_mean, sample_min, sample_max;   // sample_min/max < lo/hi only when sample_whole_control_space is off;
+                                                               // otherwise the per-channel limits a.lo / a.hi are the range (whole_space)
+    int whole_space;
     // sharded step: keepers and the best plan come from the all-gathered keeper records
     // {J, global index, age, Q[H], m[H], v[H]} instead of this handle's own rows
     const float* recs;     // nullptr: single-handle step
@@ -219,7 +201,9 @@ struct WarmPtrs {
     uint32_t seq;
 };
 
-// element `gid` (= row * H + h) of the new population; elements 0..H-1 also copy the best plan out and publish u
+// element `gid` (= (row * H + h) * C + c) of the new population [N,H,C]; elements 0..H*C-1 also copy the best plan out and
+// element 0 publishes u.  C = a.C control inputs: the reference's tensors are [N,H,C] throughout (optimizer_rpgd.py:275-296,
+// :377-379, :454-513), a step is C contiguous floats.
 CTK_DEV void rpgd_warm_element(const WarmArgs& w, const RolloutArgs& a, const WarmPtrs& p, int gid) {
     const float* __restrict__ draws = p.draws; const int* __restrict__ idx = p.idx;
     const float* __restrict__ Q_old = p.Q_old; const float* __restrict__ m_old = p.m_old; const float* __restrict__ v_old = p.v_old;
@@ -228,53 +212,54 @@ CTK_DEV void rpgd_warm_element(const WarmArgs& w, const RolloutArgs& a, const Wa
     float* __restrict__ ages_new = p.ages_new; const InterpEntry* __restrict__ interp = p.interp;
     float* __restrict__ u_nom = p.u_nom; float* __restrict__ u_dev = p.u_dev; float* __restrict__ u_host = p.u_host;
     const uint32_t seq = p.seq;
-    const int H = w.H;
-    if (gid < w.N * H) {
-        const int i = gid / H, h = gid - i * H;
+    const int H = w.H, C = a.C, HC = H * C, PC = w.P * C;
+    if (gid < w.N * HC) {
+        const int i = gid / HC, hc = gid - i * HC, h = hc / C, c = hc - h * C;
         float q, mm = 0.0f, vv = 0.0f;
         if (i < w.n_new) {
             const InterpEntry e = interp[h];
+            const float smin = w.whole_space ? a.lo[c] : w.sample_min, smax = w.whole_space ? a.hi[c] : w.sample_max;
             float y[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int col = min(e.i0 + j, w.P - 1);
+                const int col = min(e.i0 + j, w.P - 1) * C + c;      // column of the [P,C] draw block of this row
                 float d;
                 if (draws != nullptr) {
-                    d = draws[(size_t)i * w.P + col];
+                    d = draws[(size_t)i * PC + col];
                 } else {
                     float d4[4];
                     draw4(a, (uint32_t)(a.global_row0 + i), (uint32_t)(col >> 2), w.sampling_distribution == 0 ? 1 : 0, d4);
                     d = d4[col & 3];
                 }
-                const float raw = w.sampling_distribution == 0 ? d * (w.sample_max - w.sample_min) + w.sample_min   // uniform
+                const float raw = w.sampling_distribution == 0 ? d * (smax - smin) + smin                           // uniform
                                                                 : d * w.sample_stdev + w.sample_mean;                // normal
-                y[j] = fminf(fmaxf(raw, w.lo), w.hi);                                                                // :292
+                y[j] = fminf(fmaxf(raw, a.lo[c]), a.hi[c]);                                                          // :292
             }
             q = y[0] * e.w0 + (e.i0 + 1 < w.P ? y[1] * e.w1 : 0.0f);                                                 // :294
         } else if (w.gather && w.recs) {
             const float* rec = w.recs + (size_t)idx[w.keeper_base + i - w.n_new] * w.rs;
             const int hs = min(h + w.shift_previous, H - 1);
-            q = rec[3 + hs];
-            if (h + 1 < H) { mm = rec[3 + H + h + 1]; vv = rec[3 + 2 * H + h + 1]; }
+            q = rec[3 + hs * C + c];
+            if (h + 1 < H) { mm = rec[3 + HC + hc + C]; vv = rec[3 + 2 * HC + hc + C]; }
         } else {
             const int src = w.gather ? idx[i - w.n_new] : i;
             const int hs = min(h + w.shift_previous, H - 1);
-            q = Q_old[(size_t)src * H + hs];
+            q = Q_old[(size_t)src * HC + hs * C + c];
             if (w.fresh_tail && h + w.shift_previous >= H) {
                 float d;
                 if (draws != nullptr) {
-                    d = draws[i];
+                    d = draws[(size_t)i * C + c];
                 } else {
                     float d4[4];
                     draw4(a, (uint32_t)(a.global_row0 + i), 0u, 1, d4);
-                    d = d4[0];
+                    d = d4[c & 3];
                 }
-                q = d * (w.hi - w.lo) + w.lo;
+                q = d * (a.hi[c] - a.lo[c]) + a.lo[c];
             }
-            if (h + 1 < H) { mm = m_old[(size_t)src * H + h + 1]; vv = v_old[(size_t)src * H + h + 1]; }
+            if (h + 1 < H) { mm = m_old[(size_t)src * HC + hc + C]; vv = v_old[(size_t)src * HC + hc + C]; }
         }
         Q_new[gid] = q; m_new[gid] = mm; v_new[gid] = vv;
-        if (h == 0) {
+        if (hc == 0) {
             float age = 0.0f;
             if (i >= w.n_new) {
                 if (w.gather && w.recs) age = w.recs[(size_t)idx[w.keeper_base + i - w.n_new] * w.rs + 2];
@@ -283,11 +268,22 @@ CTK_DEV void rpgd_warm_element(const WarmArgs& w, const RolloutArgs& a, const Wa
             ages_new[i] = w.reset ? 0.0f : age + 1.0f;
         }
     }
-    if (!w.reset && gid < H) {
+    if (!w.reset && gid < HC) {
         // u_nom = Q_tf[best_idx[0]] BEFORE the warm start (:426)
-        const float q = w.recs ? w.recs[(size_t)idx[0] * w.rs + 3 + gid] : Q_old[(size_t)idx[0] * H + gid];
+        const float q = w.recs ? w.recs[(size_t)idx[0] * w.rs + 3 + gid] : Q_old[(size_t)idx[0] * HC + gid];
         u_nom[gid] = q;
-        if (gid == 0) publish_u(u_dev, u_host, q, seq);   // :523
+        if (C == 1) {
+            if (gid == 0) publish_u(u_dev, u_host, q, seq);   // :523
+        } else if (gid == 0) {
+            // one thread publishes the whole input vector: u[c] first (floats 4..), then the {u[0], seq} word the host polls
+            for (int cc = 0; cc < C; ++cc) {
+                const float uc = w.recs ? w.recs[(size_t)idx[0] * w.rs + 3 + cc] : Q_old[(size_t)idx[0] * HC + cc];
+                u_dev[cc] = uc;
+                __hip_atomic_store(u_host + 4 + cc, uc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            const unsigned long long pv = ((unsigned long long)seq << 32) | (unsigned long long)__builtin_bit_cast(unsigned, q);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(u_host), pv, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -323,7 +319,7 @@ __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_descent(RolloutArgs a, EnvK
     const int rows = min(RP_TRAJ, a.N - row0);
     const int total = rows * H;
     const size_t gbase = (size_t)row0 * H;
-    const float uprev0 = a.u_prev_dev ? *a.u_prev_dev : a.u_prev;
+    const float uprev0 = a.u_prev_dev ? *a.u_prev_dev : a.u_prev[0];
 
     // plans of this block -> LDS, transposed to [h][plan] (coalesced global read)
     for (int i = t; i < RP_TRAJ * H; i += RP_BLOCK) {
@@ -351,7 +347,7 @@ __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_descent(RolloutArgs a, EnvK
                 float mm = 0.0f, vv = 0.0f;
                 if (ad.rule != 2) { mm = m[gbase + i]; vv = v[gbase + i]; }
                 const float g = g_s[h * RP_LD + r] * sc_s[r];
-                q_s[h * RP_LD + r] = adam_update(ad, q_s[h * RP_LD + r], g, mm, vv, bc1, bc2, a.lo, a.hi);
+                q_s[h * RP_LD + r] = adam_update(ad, q_s[h * RP_LD + r], g, mm, vv, bc1, bc2, a.lo[0], a.hi[0]);
                 if (ad.rule != 2) { m[gbase + i] = mm; v[gbase + i] = vv; }
             }
             __syncthreads();
@@ -382,7 +378,7 @@ __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_descent(RolloutArgs a, EnvK
                 float mm = 0.0f, vv = 0.0f;
                 if (ad.rule != 2) { mm = m[gbase + i]; vv = v[gbase + i]; }
                 const float gg = g_s[h * RP_LD + r] * sc_s[r];
-                q_s[h * RP_LD + r] = adam_update(ad, q_s[h * RP_LD + r], gg, mm, vv, bc1, bc2, a.lo, a.hi);
+                q_s[h * RP_LD + r] = adam_update(ad, q_s[h * RP_LD + r], gg, mm, vv, bc1, bc2, a.lo[0], a.hi[0]);
                 if (ad.rule != 2) { m[gbase + i] = mm; v[gbase + i] = vv; }
             }
             __syncthreads();
@@ -415,7 +411,7 @@ __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_descent(RolloutArgs a, EnvK
         __syncthreads();
         WarmPtrs p = fw.p;
         p.idx = idx_s;
-        for (int gid = t; gid < max(fw.w.N * H, H); gid += RP_BLOCK) rpgd_warm_element(fw.w, a, p, gid);
+        for (int gid = t; gid < max(fw.w.N * H, H); gid += RP_BLOCK) rpgd_warm_element(fw.w, a, p, gid);   // CartPole: C == 1
     }
 }
 
@@ -472,8 +468,8 @@ hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& 
     FusedWarm fw{};
     if (fused && grid.x == 1) {
         fw.enabled = 1; fw.K = fused->K; fw.idx_out = fused->idx_out;
-        fw.w = WarmArgs{a.N, a.H, fused->P, fused->n_new, fused->gather, fused->shift_previous, fused->sampling_distribution, 0, a.lo, a.hi,
-                        fused->sample_stdev, fused->sample_mean, fused->sample_min, fused->sample_max, nullptr, 3 + 3 * a.H, 0, fused->fresh_tail};
+        fw.w = WarmArgs{a.N, a.H, fused->P, fused->n_new, fused->gather, fused->shift_previous, fused->sampling_distribution, 0,
+                        fused->sample_stdev, fused->sample_mean, fused->sample_min, fused->sample_max, 0, nullptr, 3 + 3 * a.H, 0, fused->fresh_tail};
         fw.p = WarmPtrs{fused->draws, nullptr, Q, m, v, fused->ages_old, fused->Q_new, fused->m_new, fused->v_new, fused->ages_new,
                         fused->interp, fused->u_nom, fused->u_dev, fused->u_host, fused->seq};
     }
@@ -487,15 +483,15 @@ hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& 
 }
 
 hipError_t ctk_launch_rpgd_warmstart(hipStream_t st, const RolloutArgs& a, int N, int H, int P, int n_new, int gather, int shift_previous,
-                                     int sampling_distribution, int reset, float lo, float hi, float sample_stdev,
+                                     int sampling_distribution, int reset, int whole_space, float sample_stdev,
                                      float sample_mean, float sample_min, float sample_max, const float* draws, const int* idx,
                                      const float* Q_old, const float* m_old, const float* v_old, const float* ages_old,
                                      float* Q_new, float* m_new, float* v_new, float* ages_new, const InterpEntry* interp,
                                      float* u_nom, float* u_dev, float* u_host, uint32_t seq, const float* recs, int rs,
                                      int keeper_base, int fresh_tail) {
-    WarmArgs w{N, H, P, n_new, gather, shift_previous, sampling_distribution, reset, lo, hi, sample_stdev, sample_mean, sample_min, sample_max,
-               recs, rs, keeper_base, fresh_tail};
-    const int total = N * H;
+    WarmArgs w{N, H, P, n_new, gather, shift_previous, sampling_distribution, reset, sample_stdev, sample_mean, sample_min, sample_max,
+               whole_space, recs, rs, keeper_base, fresh_tail};
+    const int total = N * H * a.C;
     const WarmPtrs p{draws, idx, Q_old, m_old, v_old, ages_old, Q_new, m_new, v_new, ages_new, interp, u_nom, u_dev, u_host, seq};
     hipLaunchKernelGGL(ctk_rpgd_warmstart, dim3((total + 255) / 256), dim3(256), 0, st, w, a, p);
     return hipGetLastError();

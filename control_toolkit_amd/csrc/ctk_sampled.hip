@@ -94,9 +94,9 @@ __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(const float* __
     // inputs of the steps [hbeg, hend) of trajectory ptraj into ubuf + their input-only stage-cost terms (returned)
     auto prepare = [&](int ptraj, int hbeg, int hend) {
         const float* my = tile + ptraj * ts;
-        auto input_at = [&](int h) { return fminf(fmaxf(base_s[h] + my[h] * scale_s[h], a.lo), a.hi); };
+        auto input_at = [&](int h) { return fminf(fmaxf(base_s[h] + my[h] * scale_s[h], a.lo[0]), a.hi[0]); };
         float cin = 0.0f;
-        float uprev = (hbeg == 0 || hbeg >= H) ? (a.u_prev_dev ? *a.u_prev_dev : a.u_prev) : input_at(hbeg - 1);
+        float uprev = (hbeg == 0 || hbeg >= H) ? (a.u_prev_dev ? *a.u_prev_dev : a.u_prev[0]) : input_at(hbeg - 1);
 #pragma unroll 2
         for (int h = hbeg; h < hend; ++h) {
             const float u = input_at(h);
@@ -355,10 +355,11 @@ __global__ void ctk_pick_best_first(const float* __restrict__ Q, int ldq, const 
 __global__ __launch_bounds__(256) void ctk_sample_plans(RolloutArgs a, const float* __restrict__ samples,
                                                         const float* __restrict__ mu, const float* __restrict__ sd,
                                                         float* __restrict__ Q) {
-    const int H = a.H;
+    const int H = a.H * a.C;                  // a row of [N,H,C] is H*C contiguous floats; h below is the flat (step, input) column
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= a.N * H) return;
     const int n = gid / H, h = gid - n * H;   // gid ranges over N*H: beyond the exactness range of the p_magic trick
+    const int c = h % a.C;
     float e;
     if (samples != nullptr) {
         e = samples[gid];
@@ -367,11 +368,11 @@ __global__ __launch_bounds__(256) void ctk_sample_plans(RolloutArgs a, const flo
         draw4(a, (uint32_t)(a.global_row0 + n), (uint32_t)(h >> 2), 0, d4);
         e = d4[h & 3];
     }
-    Q[gid] = fminf(fmaxf(mu[h] + e * sd[h], a.lo), a.hi);
+    Q[gid] = fminf(fmaxf(mu[h] + e * sd[h], a.lo[c]), a.hi[c]);
 }
 
 hipError_t ctk_launch_sample_plans(hipStream_t st, const RolloutArgs& a, const float* samples, const float* mu, const float* sd, float* Q) {
-    const int total = a.N * a.H;
+    const int total = a.N * a.H * a.C;
     hipLaunchKernelGGL(ctk_sample_plans, dim3((total + 255) / 256), dim3(256), 0, st, a, samples, mu, sd, Q);
     return hipGetLastError();
 }
@@ -383,10 +384,11 @@ __global__ __launch_bounds__(256) void ctk_cem_build_population(RolloutArgs a, i
                                                                 const int* __restrict__ idx, const float* __restrict__ eps_elite,
                                                                 const float* __restrict__ eps_rest, const float* __restrict__ mu,
                                                                 const float* __restrict__ sd, float* __restrict__ Q) {
-    const int H = a.H;
+    const int H = a.H * a.C;                  // flat (step, input) columns of a row, as in ctk_sample_plans
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= a.N * H) return;
     const int n = gid / H, h = gid - n * H;   // gid ranges over N*H: beyond the exactness range of the p_magic trick
+    const int c = h % a.C;
     float q;
     if (n < K && !first) {
         q = Q_prev[(size_t)idx[n] * H + h];
@@ -402,12 +404,12 @@ __global__ __launch_bounds__(256) void ctk_cem_build_population(RolloutArgs a, i
         }
         q = mu[h] + sd[h] * e;                                   // :122-128
     }
-    Q[gid] = fminf(fmaxf(q, a.lo), a.hi);                        // :96
+    Q[gid] = fminf(fmaxf(q, a.lo[c]), a.hi[c]);                        // :96
 }
 
 hipError_t ctk_launch_cem_build_population(hipStream_t st, const RolloutArgs& a, int K, int first, const float* Q_prev, const int* idx,
                                            const float* eps_elite, const float* eps_rest, const float* mu, const float* sd, float* Q) {
-    const int total = a.N * a.H;
+    const int total = a.N * a.H * a.C;
     hipLaunchKernelGGL(ctk_cem_build_population, dim3((total + 255) / 256), dim3(256), 0, st, a, K, first, Q_prev, idx, eps_elite, eps_rest,
                        mu, sd, Q);
     return hipGetLastError();

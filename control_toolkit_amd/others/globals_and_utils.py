@@ -70,7 +70,8 @@ def create_rng(id: str, seed, computation_library=None, mode: str = "device"):
     if seed is None:
         log.info(f"{id}: No random seed specified. Seeding with datetime.")
         seed = int((datetime.now() - datetime(1970, 1, 1)).total_seconds() * 1000.0)
-    if computation_library is not None and not isinstance(computation_library, HipLibrary):
+    tag = str(getattr(computation_library, "lib", "")).lower()
+    if computation_library is not None and not (isinstance(computation_library, HipLibrary) or tag in ("hip", "numpy")):
         raise ValueError(f"create_rng: unsupported computation library {computation_library}")
     if mode == "device":
         return DeviceRng(seed)

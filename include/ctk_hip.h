@@ -9,7 +9,9 @@
  * types).  The ctypes binding a reference maintainer would add is shown in INTEGRATION.md and
  * implemented in control_toolkit_amd/_capi.py.
  *
- * Conventions: all tensors fp32, row-major, batch first ([N,H,C], [N,H+1,S]); S = 4, C = 1.
+ * Conventions: all tensors fp32, row-major, batch first ([N,H,C], [N,H+1,S]); S = num_states and
+ * C = num_control_inputs are properties of the environment (ctk_env_info): the reference's optimizers
+ * take them at run time (Optimizers/__init__.py:52-63) from the predictor (controller_mpc.py:87-88).
  * Every function that returns int returns 0 on success and a ctk_status otherwise;
  * ctk_last_error() gives the message.  A handle is NOT thread-safe (the reference caller is a
  * single-threaded loop, controller_server/controller_server.py:55-86); all work of a handle
@@ -29,7 +31,9 @@
 extern "C" {
 #endif
 
-#define CTK_ABI_VERSION 2
+#define CTK_ABI_VERSION 3
+#define CTK_MAX_STATES 8   /* S <= 8 */
+#define CTK_MAX_INPUTS 4   /* C <= 4 */
 
 typedef struct ctk_handle ctk_handle;
 
@@ -58,6 +62,19 @@ typedef enum ctk_optimizer {
                                   adam_*, gradmax_clip, warmup*                                                    */
 } ctk_optimizer;
 
+/* The plant + its concrete cost: what the reference selects by `environment_name` (Controllers/__init__.py:32-37),
+ * `predictor_specification` (controller_mpc.py:67-73: which model of that plant) and `cost_function_specification`
+ * (cost_function_wrapper.py:59-66: Control_Toolkit_ASF.Cost_Functions.<environment>.<name>).  Both are external to
+ * the reference; this build defines two, written against ONE device interface (csrc/ctk_env.h: step, stage /
+ * terminal cost and their adjoints), so that the optimizer kernels are environment-agnostic templates.        */
+typedef enum ctk_environment {
+    CTK_ENV_CARTPOLE = 0, /* S 4 (position, positionD, angle, angleD), C 1 (normalised motor force);
+                             parameters: enum ctk_param.  Also has hand-tuned kernels (ctk_mppi.hip ...).      */
+    CTK_ENV_QUAD2D = 1,   /* planar quadrotor: S 6 (x, vx, z, vz, theta, omega), C 2 (normalised rotor commands);
+                             parameters: enum ctk_param_quad2d                                                  */
+    CTK_ENV_COUNT
+} ctk_environment;
+
 /* reference: predictor_specification passed to PredictorWrapper.configure
  * (Controllers/controller_mpc.py:67-73): "ODE" or a network name                              */
 typedef enum ctk_predictor {
@@ -80,6 +97,16 @@ typedef enum ctk_param {
     CTK_P_R, CTK_P_X_SCALE, CTK_P_TERMINAL_WEIGHT,
     CTK_P_COUNT
 } ctk_param;
+
+/* parameters of CTK_ENV_QUAD2D (same role; ids are per environment, names via ctk_param_name) */
+typedef enum ctk_param_quad2d {
+    CTK_Q_G = 0, CTK_Q_MASS, CTK_Q_INERTIA, CTK_Q_ARM, CTK_Q_THRUST_GAIN, CTK_Q_DRAG_LIN, CTK_Q_DRAG_ANG,
+    CTK_Q_TARGET_X, CTK_Q_TARGET_Z,
+    CTK_Q_POS_WEIGHT, CTK_Q_ANG_WEIGHT, CTK_Q_VEL_WEIGHT, CTK_Q_ANGVEL_WEIGHT, CTK_Q_CC_WEIGHT, CTK_Q_CCRC_WEIGHT,
+    CTK_Q_R, CTK_Q_POS_SCALE, CTK_Q_TERMINAL_WEIGHT,
+    CTK_Q_COUNT
+} ctk_param_quad2d;
+#define CTK_MAX_PARAMS 32
 
 /* Device-resident tensors readable with ctk_read(); replaces the to_numpy() calls that fill
  * `logging_values` (optimizer_mppi.py:214-220, optimizer_cem_tf.py:96,104-108,
@@ -116,15 +143,18 @@ typedef struct ctk_config {
     int32_t device;       /* HIP device ordinal                                                */
     int32_t num_rollouts; /* N — rollouts owned by THIS handle (the local shard)               */
     int32_t mpc_horizon;  /* H                                                                 */
-    int32_t num_states;   /* S, must be 4                                                      */
-    int32_t num_control_inputs; /* C, must be 1                                                */
+    int32_t num_states;   /* S, must equal the environment's (ctk_env_info)                    */
+    int32_t num_control_inputs; /* C, must equal the environment's                             */
     int32_t period_interpolation_inducing_points;
     int32_t intermediate_steps; /* Euler sub-steps per dt (ODE predictor), >= 1               */
     int32_t materialize_trajectories; /* optimizer_logging / calculate_optimal_trajectory      */
     int32_t global_rollout_offset;    /* first global rollout index of this shard (Philox)     */
     uint64_t seed;
     float dt;
-    float action_low, action_high;
+    int32_t environment;     /* ctk_environment                                                */
+    int32_t generic_kernels; /* 1: run the environment-agnostic template kernels (csrc/ctk_generic.hip) even where
+                                a hand-tuned kernel exists (CartPole); 0: fastest available                      */
+    float action_low[CTK_MAX_INPUTS], action_high[CTK_MAX_INPUTS]; /* control_limits, one pair per input       */
     /* MPPI */
     float cc_weight, R, LBD, NU, SQRTRHOINV;
     /* CEM */
@@ -133,6 +163,8 @@ typedef struct ctk_config {
     /* RPGD */
     int32_t outer_its, resamp_per, shift_previous, opt_keep_k;
     int32_t sampling_distribution; /* 0 = uniform, 1 = normal                                 */
+    int32_t sample_whole_control_space; /* 1: uniform samples span [action_low[c], action_high[c]] per input
+                                           (optimizer_rpgd.py:200-203); 0: [sample_min, sample_max] for every input  */
     float sample_stdev, sample_mean, sample_min, sample_max;
     float learning_rate, gradmax_clip, adam_beta_1, adam_beta_2, adam_epsilon;
 } ctk_config;
@@ -163,16 +195,22 @@ int ctk_set_stream(ctk_handle* h, void* hip_stream);
  * ----------------------------------------------------------------------------------------- */
 int ctk_set_param(ctk_handle* h, int id, float value);
 int ctk_get_param(const ctk_handle* h, int id, float* value);
-/* Network weights, flat fp32.
- *   MLP: W1[32,5] b1[32] W2[32,32] b2[32] W3[4,32] b3[4]                       (1380 floats)
- *   GRU: per layer W_i[96,I] W_h[96,32] b_i[96] b_h[96] (rows r|z|n, I = 5 then 32), then
- *        W_o[4,32] b_o[4]                                                        (10212 floats)
+/* What an environment is made of: S, C and its parameter list (ids 0 .. n_params-1, names as in the cost YAML /
+ * the dynamics section).  Any output pointer may be NULL.                                                      */
+int ctk_env_info(int environment, int* num_states, int* num_control_inputs, int* n_params);
+const char* ctk_param_name(int environment, int id);       /* NULL if out of range */
+const char* ctk_environment_name(int environment);         /* "CartPole", "Quad2D"; NULL if unknown */
+/* Network weights, flat fp32, I = S + C inputs, S outputs (CartPole: I 5, S 4):
+ *   MLP: W1[32,I] b1[32] W2[32,32] b2[32] W3[S,32] b3[S]                       (CartPole 1380 floats)
+ *   GRU: per layer W_i[96,I'] W_h[96,32] b_i[96] b_h[96] (rows r|z|n, I' = I then 32), then
+ *        W_o[S,32] b_o[S]                                                        (CartPole 10212 floats)
  * Uploading GRU weights also zeroes the carried hidden state.                                 */
+size_t ctk_predictor_weight_count(const ctk_handle* h);    /* floats ctk_set_predictor_weights expects (0: ODE) */
 int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n);
 
 /* Recurrent predictor state (GRU): [2,32] fp32, the state every rollout starts from.
  * ctk_predictor_update = predictor.update(s, Q0) (optimizer_mppi.py:195-197): advance it by the measured
- * state s[4] and the applied input u[1] (NULL: the optimizer's last output, still on the device).
+ * state s[S] and the applied input u[C] (NULL: the optimizer's last output, still on the device).
  * ctk_step of an MPPI handle does this itself after the nominal-plan update (optimizer_mppi.py:192),
  * CEM / random-action never do (optimizer_cem_tf.py, optimizer_random_action_tf.py have no such call).
  * Non-recurrent predictors: size 0, update is a no-op, get/set reject.                          */

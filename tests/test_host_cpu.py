@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libctk_hip.so does not export {n}"
     assert set(names) == set(SYMBOLS), "ctypes binding and header disagree"
-    assert lib.ctk_abi_version() == 2
+    assert lib.ctk_abi_version() == 3
     assert os.path.dirname(library_path()).endswith("control_toolkit_amd")   # in-tree, not site-packages
 
 
@@ -174,8 +174,10 @@ def test_cost_yaml_hot_reload_and_declarative_predictor(tmp_path):
     with pytest.raises(ValueError, match="unknown cost parameters"):
         bad = tmp_path / "bad.yml"; bad.write_text("CartPole:\n  default:\n    not_a_term: 1.0\n")
         CostFunctionWrapper(config_path=str(bad), watch=False).configure(8, 5, environment_name="CartPole")
-    with pytest.raises(KeyError):
+    with pytest.raises(NotImplementedError, match="not built"):
         CostFunctionWrapper(config_path=str(y), watch=False).configure(8, 5, environment_name="Acrobot")
+    with pytest.raises(KeyError):      # a built environment the file has no section for
+        CostFunctionWrapper(config_path=str(y), watch=False).configure(8, 5, environment_name="Quad2D")
     with pytest.raises(FileNotFoundError):
         CostFunctionWrapper(config_path=str(tmp_path / "missing.yml"), watch=False).configure(8, 5, environment_name="CartPole")
     # declarative predictor: YAML -> dynamics constants + weights file
@@ -189,3 +191,24 @@ def test_cost_yaml_hot_reload_and_declarative_predictor(tmp_path):
     with pytest.raises(ValueError):
         q = tmp_path / "q.yml"; q.write_text("dynamics: {}\nfoo: 1\n")
         PredictorWrapper.from_yaml(str(q))
+
+
+def test_environment_tables_agree_between_library_host_mirror_and_oracle():
+    """ctk_env_info / ctk_param_name (no GPU needed) == the static host tables == the oracle's parameter lists."""
+    from control_toolkit_amd._capi import environment_info, ENVIRONMENTS
+    from control_toolkit_amd.Predictors import ENVIRONMENT_DIMS, DEFAULT_DYNAMICS_BY_ENV, network_weight_count
+    from control_toolkit_amd.Cost_Functions import DEFAULT_COST_BY_ENV, DEFAULT_ATTRIBUTES_BY_ENV
+    from oracle import ctk_oracle as O
+    assert set(ENVIRONMENTS) == set(ENVIRONMENT_DIMS) == set(O.ENVIRONMENTS)
+    for name, cls in O.ENVIRONMENTS.items():
+        S, C, params = environment_info(name)
+        assert (S, C) == ENVIRONMENT_DIMS[name] == (cls.S, cls.C)
+        assert params == cls().param_names()
+        host = dict(DEFAULT_DYNAMICS_BY_ENV[name], **DEFAULT_ATTRIBUTES_BY_ENV[name], **DEFAULT_COST_BY_ENV[name])
+        assert set(host) == set(params)
+        for k in params:
+            assert host[k] == getattr(cls(), k), (name, k)
+    assert network_weight_count("MLP", 4, 1) == 1380 == O.mlp_num_weights() and network_weight_count("GRU", 4, 1) == 10212 == O.gru_num_weights()
+    assert network_weight_count("MLP", 6, 2) == O.mlp_num_weights(8, 6)
+    with pytest.raises(NotImplementedError):
+        environment_info("Acrobot")
