@@ -86,8 +86,19 @@ def inject_constants(env: O.EnvParams, dt: float, mlp_weights):
         cf.CONSTANTS[name] = float(np.float32(getattr(env, name)))
 
 
+def inject_quad(env: O.Quad2DParams, dt: float):
+    """constants of the second environment (planar quadrotor, 6 states / 2 inputs) into its torch stand-ins"""
+    import SI_Toolkit.Predictors.predictor_wrapper as pw
+    import Control_Toolkit_ASF.Cost_Functions.Quad2D.default as cf
+    k = {kk: float(v) for kk, v in O.quad2d_constants(env, dt, 1).items()}
+    pw.CONSTANTS.clear(); pw.CONSTANTS.update(k)
+    cf.CONSTANTS.clear(); cf.CONSTANTS.update(k)
+    for name in ("target_x", "target_z", "ang_weight", "vel_weight", "angvel_weight", "ccrc_weight", "terminal_weight"):
+        cf.CONSTANTS[name] = float(np.float32(getattr(env, name)))
+
+
 def plant_step(pred: O.Predictor, s, u):
-    return pred.step(np.asarray(s, np.float32).reshape(1, 4), np.asarray(u, np.float32).reshape(1))[0]
+    return pred.step(np.asarray(s, np.float32).reshape(1, pred.S), np.asarray(u, np.float32).reshape(1, pred.C))[0]
 
 
 def initial_state(seed):
@@ -155,9 +166,9 @@ def main():
     # ---- controller_mpc helper ----------------------------------------------------------------
     low, high = np.array([-1.0], np.float32), np.array([1.0], np.float32)
 
-    def make_controller(opt_name, opt_cfg, predictor_spec):
+    def make_controller(opt_name, opt_cfg, predictor_spec, environment="CartPole", limits=None):
         cm.config_optimizers[opt_name] = dict(opt_cfg)
-        ctrl = cm.controller_mpc("CartPole", (low, high), {})
+        ctrl = cm.controller_mpc(environment, limits if limits is not None else (low, high), {})
         ctrl.configure(optimizer_name=opt_name, predictor_specification=predictor_spec)
         return ctrl
 
@@ -271,6 +282,92 @@ def main():
             s = plant_step(plant, s, u)
         d["steps"] = np.int32(c["steps"])
         np.savez_compressed(os.path.join(out_dir, f"rpgd_{name}.npz"), **d)
+
+    # ---- second environment, C = 2: the SAME unmodified reference optimizers on the planar quadrotor ---------------
+    # pins the [N,P,C] / [N,H,C] logic of optimizer_mppi.py / optimizer_rpgd.py / Interpolator.py for C > 1: per-channel
+    # interpolation and limits, sums over axes [1,2] (:154-155), clip_by_norm over [1,2] (:315,:334), [C]-shaped u
+    import SI_Toolkit.Predictors.predictor_wrapper as pw
+    qenv = O.Quad2DParams(terminal_weight=0.4, target_x=0.1)
+    inject_quad(qenv, dt)
+    pw.ENVIRONMENT = "Quad2D"
+    qlow, qhigh = np.array([-1.0, -0.8], np.float32), np.array([1.0, 0.9], np.float32)
+    qcommon = dict(environment=np.array("Quad2D"), env_params=qenv.as_array(), env_param_names=np.array(O.QUAD2D_PARAM_NAMES),
+                   dt=np.float32(dt), low=qlow, high=qhigh, predictor=np.array("ODE"))
+
+    def quad_state(seed):
+        r = np.random.default_rng(seed)
+        return np.array([r.uniform(-0.3, 0.3), r.uniform(-0.5, 0.5), r.uniform(0.6, 1.4), r.uniform(-0.5, 0.5),
+                         r.uniform(-0.5, 0.5), r.uniform(-1, 1)], np.float32)
+
+    for name, c in {"quad2d": dict(N=128, H=30, p=5, steps=3, seed=21), "quad2d_p1": dict(N=64, H=12, p=1, steps=2, seed=22)}.items():
+        cfg = dict(seed=1, mpc_horizon=c["H"], num_rollouts=c["N"], cc_weight=1.0, R=1.0, LBD=100.0, NU=1000.0,
+                   SQRTRHOINV=0.03, period_interpolation_inducing_points=c["p"], mpc_timestep=dt)
+        ctrl = make_controller("mppi", cfg, "ODE", "Quad2D", (qlow, qhigh))
+        ctrl.controller_logging = True
+        ctrl.optimizer.optimizer_logging = True
+        opt = ctrl.optimizer
+        rec = RecordingRng(opt.rng); opt.rng = rec
+        plant = O.Predictor(kind="ODE", dt=dt, env=qenv)
+        s = quad_state(c["seed"])
+        d = dict(qcommon, **{k: np.float32(v) if isinstance(v, float) else np.array(v) for k, v in cfg.items()})
+        d["u_nom_init"] = opt.u_nom.numpy().copy()
+        for t in range(c["steps"]):
+            u_prev = np.asarray(opt.u, np.float32).reshape(-1)
+            u_prev = np.broadcast_to(u_prev, (2,)).copy()
+            u = ctrl.step(s.copy())
+            lv = opt.logging_values
+            d[f"s_{t}"] = s.copy(); d[f"u_prev_{t}"] = u_prev
+            d[f"noise_{t}"] = rec.raw[-1]
+            d[f"u_{t}"] = np.asarray(u, np.float32).reshape(-1)
+            d[f"u_nom_{t}"] = opt.u_nom.numpy().copy()
+            d[f"J_{t}"] = lv["J_logged"].copy(); d[f"u_run_{t}"] = lv["Q_logged"].copy()
+            d[f"traj_{t}"] = lv["rollout_trajectories_logged"].copy()
+            s = plant_step(plant, s, u)
+        d["steps"] = np.int32(c["steps"])
+        np.savez_compressed(os.path.join(out_dir, f"mppi_{name}.npz"), **d)
+
+    for name, c in {"quad2d": dict(N=32, H=20, p=5, its=3, steps=4, resamp=2, dist="uniform", seed=23, shift=1),
+                    "quad2d_its20": dict(N=64, H=30, p=10, its=20, steps=2, resamp=10, dist="normal", seed=24, shift=1)}.items():
+        cfg = dict(seed=1, mpc_horizon=c["H"], num_rollouts=c["N"], outer_its=c["its"], sample_stdev=0.5,
+                   sample_mean=0.0, sample_whole_control_space=True, uniform_dist_min=-1.0, uniform_dist_max=1.0,
+                   resamp_per=c["resamp"], period_interpolation_inducing_points=c["p"],
+                   SAMPLING_DISTRIBUTION=c["dist"], shift_previous=c["shift"], warmup=False, warmup_iterations=250,
+                   learning_rate=0.05, opt_keep_k_ratio=0.25, gradmax_clip=5.0, rtol=1e-3, adam_beta_1=0.9,
+                   adam_beta_2=0.999, adam_epsilon=1e-8, mpc_timestep=dt)
+        import Control_Toolkit.Optimizers as tmpl
+        orig_create = tmpl.create_rng
+        holder = {}
+        def recording_create(id, seed, computation_library=None):
+            holder["rec"] = RecordingRng(orig_create(id, seed, computation_library=computation_library))
+            return holder["rec"]
+        tmpl.create_rng = recording_create
+        try:
+            ctrl = make_controller("rpgd", cfg, "ODE", "Quad2D", (qlow, qhigh))
+        finally:
+            tmpl.create_rng = orig_create
+        opt, rec = ctrl.optimizer, holder["rec"]
+        d = dict(qcommon, **{k: (np.float32(v) if isinstance(v, float) else np.array(v)) for k, v in cfg.items()})
+        d["reset_draws"] = rec.raw[0]
+        d["Q_init"] = opt.Q_tf.detach().numpy().copy()
+        plant = O.Predictor(kind="ODE", dt=dt, env=qenv)
+        s = quad_state(c["seed"])
+        for t in range(c["steps"]):
+            ndraw = len(rec.raw)
+            u_prev = np.broadcast_to(np.asarray(opt.u, np.float32).reshape(-1), (2,)).copy()
+            u = ctrl.step(s.copy())
+            d[f"s_{t}"] = s.copy(); d[f"u_prev_{t}"] = u_prev
+            d[f"u_{t}"] = np.asarray(u, np.float32).reshape(-1)
+            if len(rec.raw) > ndraw:
+                d[f"resample_draws_{t}"] = rec.raw[-1]
+            d[f"Q_{t}"] = opt.Q_tf.detach().numpy().copy()
+            d[f"u_nom_{t}"] = opt.u_nom.detach().numpy().copy()
+            stp, m_arr, v_arr = opt.opt.get_weights()
+            d[f"adam_step_{t}"] = np.int32(stp); d[f"m_{t}"] = m_arr.copy(); d[f"v_{t}"] = v_arr.copy()
+            d[f"ages_{t}"] = opt.trajectory_ages.numpy().copy()
+            s = plant_step(plant, s, u)
+        d["steps"] = np.int32(c["steps"])
+        np.savez_compressed(os.path.join(out_dir, f"rpgd_{name}.npz"), **d)
+    pw.ENVIRONMENT = "CartPole"
 
     print("golden fixtures written to", out_dir)
     for f in sorted(os.listdir(out_dir)):

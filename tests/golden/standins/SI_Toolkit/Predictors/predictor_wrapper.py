@@ -1,17 +1,18 @@
-"""Stand-in PredictorWrapper: the build's own cart-pole ODE / 5-32-32-4 tanh MLP in torch fp32
-(differentiable, so the reference's RPGD can backpropagate through it).  Same formulas as
-oracle/ctk_oracle.py:Predictor; constants are injected by tests/golden/make_golden.py."""
+"""Stand-in PredictorWrapper: the build's own plants in torch fp32 (differentiable, so the reference's RPGD can
+backpropagate through them) — cart-pole ODE / 5-32-32-4 tanh MLP, and the planar quadrotor ODE (6 states, 2 inputs).
+Same formulas as oracle/ctk_oracle.py:Predictor; constants are injected by tests/golden/make_golden.py."""
 import torch
 
 # injected by make_golden.py ------------------------------------------------------------------
+ENVIRONMENT = "CartPole"   # which plant the next PredictorWrapper() models
 CONSTANTS = {}      # derived fp32 constants (oracle.derived_constants)
 MLP_WEIGHTS = None  # tuple of torch tensors (W1,b1,W2,b2,W3,b3)
 
 
 class PredictorWrapper:
     def __init__(self):
-        self.num_states = 4
-        self.num_control_inputs = 1
+        self.environment = ENVIRONMENT
+        self.num_states, self.num_control_inputs = (6, 2) if ENVIRONMENT == "Quad2D" else (4, 1)
         self.kind = None
         self.batch_size = None
 
@@ -27,7 +28,22 @@ class PredictorWrapper:
     def update(self, s=None, Q0=None):
         pass   # no recurrent state
 
+    def _quad_step(self, s, q):
+        k = CONSTANTS
+        x, vx, z, vz, th, om = s.unbind(1)
+        aF = k["g"] + k["kF"] * (q[:, 0] + q[:, 1])
+        aM = k["kM"] * (q[:, 0] - q[:, 1])
+        sn, cs = torch.sin(th), torch.cos(th)
+        ax = -aF * sn - k["c_v"] * vx
+        az = aF * cs - k["g"] - k["c_v"] * vz
+        al = aM - k["c_w"] * om
+        dt = k["dt"]
+        return torch.stack([x + dt * vx, vx + dt * ax, z + dt * vz, vz + dt * az, th + dt * om, om + dt * al], 1)
+
     def _step(self, s, q):
+        if self.environment == "Quad2D":
+            return self._quad_step(s, q)
+        q = q[:, 0]
         if self.kind == "ODE":
             k = CONSTANTS
             x, v, th, om = s.unbind(1)
@@ -49,6 +65,6 @@ class PredictorWrapper:
         states = [s]
         cur = s
         for h in range(Q.shape[1]):
-            cur = self._step(cur, Q[:, h, 0])
+            cur = self._step(cur, Q[:, h, :])
             states.append(cur)
         return torch.stack(states, 1)

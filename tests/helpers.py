@@ -12,18 +12,20 @@ def load(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
 
-def env_from(d) -> O.EnvParams:
+def env_from(d):
+    """the environment a fixture was recorded on (CartPole unless the file says otherwise)"""
     names = [str(x) for x in d["env_param_names"]]
-    return O.EnvParams(**{n: float(v) for n, v in zip(names, d["env_params"])})
+    cls = O.ENVIRONMENTS[str(d["environment"])] if "environment" in d.files else O.EnvParams
+    return cls(**{n: float(v) for n, v in zip(names, d["env_params"])})
 
 
 def predictor_from(d) -> O.Predictor:
-    return O.Predictor(kind=str(d["predictor"]), dt=float(d["dt"]), env=env_from(d), weights=d["mlp_weights"])
+    return O.Predictor(kind=str(d["predictor"]), dt=float(d["dt"]), env=env_from(d), weights=d["mlp_weights"] if "mlp_weights" in d.files else None)
 
 
 def mppi_oracle_from(d) -> O.MPPI:
     pred = predictor_from(d)
-    return O.MPPI(pred, O.Cost(pred.env, pred.dt), float(d["low"][0]), float(d["high"][0]),
+    return O.MPPI(pred, O.Cost(pred.env, pred.dt), d["low"], d["high"],
                   num_rollouts=int(d["num_rollouts"]), mpc_horizon=int(d["mpc_horizon"]),
                   cc_weight=float(d["cc_weight"]), R=float(d["R"]), LBD=float(d["LBD"]), NU=float(d["NU"]),
                   SQRTRHOINV=float(d["SQRTRHOINV"]),
@@ -53,9 +55,12 @@ def rpgd_kwargs_from(d) -> dict:
 
 def rpgd_oracle_from(d) -> O.RPGD:
     pred = predictor_from(d)
-    return O.RPGD(pred, O.Cost(pred.env, pred.dt), float(d["low"][0]), float(d["high"][0]),
+    return O.RPGD(pred, O.Cost(pred.env, pred.dt), d["low"], d["high"],
                   num_rollouts=int(d["num_rollouts"]), mpc_horizon=int(d["mpc_horizon"]), **rpgd_kwargs_from(d))
 
 
 MPPI_CASES = ["tiny_ode", "interp_ode", "cfg2_ode", "quirk_ode", "mlp"]
 RPGD_CASES = ["ode_small", "ode_its20", "mlp_cfg4", "ode_normal"]
+# recorded from the same unmodified reference optimizers on the second environment (6 states, 2 control inputs)
+MPPI_QUAD_CASES = ["quad2d", "quad2d_p1"]
+RPGD_QUAD_CASES = ["quad2d", "quad2d_its20"]

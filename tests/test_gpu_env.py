@@ -198,8 +198,8 @@ def test_quad2d_rpgd_matches_oracle(N, H, p, its, dist):
         assert (e.samples_needed() > 0) == (dr is not None)
         uo, ug = o.step(s, dr), e.step(s, dr)
         np.testing.assert_allclose(e.read("J"), o.J, rtol=2e-3, atol=1e-3)
-        assert_close_mostly(e.read("PLAN"), o.Q, max_outliers=max(2, o.Q.size // 2000), **tol)
-        assert_close_mostly(e.read("ADAM_M"), o.opt.m, max_outliers=max(2, o.Q.size // 2000), **tol)
+        assert_close_mostly(e.read("PLAN"), o.Q, max_outliers=max(4, o.Q.size // 400), **tol)
+        assert_close_mostly(e.read("ADAM_M"), o.opt.m, max_outliers=max(4, o.Q.size // 400), **tol)
         np.testing.assert_array_equal(e.read("AGES"), o.trajectory_ages)
         np.testing.assert_allclose(ug, np.asarray(uo).reshape(-1), **tol)
         e.set_state(rpgd_state(o))
@@ -276,3 +276,64 @@ def test_controller_mpc_flies_the_quadrotor_to_its_target(name, cfg):
     assert abs(s[0] - 0.4) < 0.12 and abs(s[2] - 1.2) < 0.12 and abs(s[4]) < 0.3, f"did not reach the target: {s}"
     c.step(s, updated_attributes={"target_x": -0.2})          # per-step attribute reaches the kernels (Controllers/__init__.py:106-107)
     assert c.optimizer.engine.get_param("target_x") == np.float32(-0.2)
+
+
+# ---- reference-recorded fixtures on the second environment (tests/golden/make_golden.py: the UNMODIFIED optimizer_mppi.py /
+#      optimizer_rpgd.py driven through controller_mpc with a 6-state, 2-input plant) -------------------------------------------
+def quad_engine_from(d, opt, **kw):
+    from helpers import env_from
+    e = CtkEngine(opt, "ODE", environment="Quad2D", num_rollouts=int(d["num_rollouts"]), mpc_horizon=int(d["mpc_horizon"]), dt=float(d["dt"]),
+                  action_low=d["low"], action_high=d["high"], period_interpolation_inducing_points=int(d["period_interpolation_inducing_points"]), **kw)
+    apply_params(e, env_from(d))
+    return e
+
+
+@pytest.mark.parametrize("materialize", [True, False])
+@pytest.mark.parametrize("case", ["quad2d", "quad2d_p1"])
+def test_quad2d_mppi_matches_reference_golden(case, materialize):
+    d = load(f"mppi_{case}.npz")
+    e = quad_engine_from(d, "mppi", materialize_trajectories=materialize, cc_weight=float(d["cc_weight"]), R=float(d["R"]), LBD=float(d["LBD"]),
+                         NU=float(d["NU"]), SQRTRHOINV=float(d["SQRTRHOINV"]))
+    H = int(d["mpc_horizon"])
+    np.testing.assert_array_equal(e.read("U_NOM"), d["u_nom_init"])
+    for t in range(int(d["steps"])):
+        u = e.step(d[f"s_{t}"], d[f"noise_{t}"], u_prev=d[f"u_prev_{t}"])
+        if materialize:
+            np.testing.assert_allclose(e.read("Q"), d[f"u_run_{t}"], rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(e.read("TRAJ"), d[f"traj_{t}"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(e.read("J"), d[f"J_{t}"], rtol=3e-5)
+        np.testing.assert_allclose(e.read("U_NOM"), d[f"u_nom_{t}"], **U_TOL)
+        np.testing.assert_allclose(u, d[f"u_{t}"], **U_TOL)
+        e.set_state(np.concatenate([d[f"u_nom_{t}"].reshape(H * 2), d[f"u_{t}"].reshape(2)]))
+    e.close()
+
+
+@pytest.mark.parametrize("case", ["quad2d", "quad2d_its20"])
+def test_quad2d_rpgd_matches_reference_golden(case):
+    from helpers import rpgd_kwargs_from
+    d = load(f"rpgd_{case}.npz")
+    k = rpgd_kwargs_from(d)
+    N = int(d["num_rollouts"])
+    e = quad_engine_from(d, "rpgd", outer_its=k["outer_its"], resamp_per=k["resamp_per"], shift_previous=k["shift_previous"],
+                         opt_keep_k=int(max(int(N * k["opt_keep_k_ratio"]), 1)), sampling_distribution=0 if k["SAMPLING_DISTRIBUTION"] == "uniform" else 1,
+                         sample_whole_control_space=int(k["sample_whole_control_space"]), sample_stdev=k["sample_stdev"], sample_mean=k["sample_mean"],
+                         sample_min=k["uniform_dist_min"], sample_max=k["uniform_dist_max"], learning_rate=k["learning_rate"],
+                         gradmax_clip=k["gradmax_clip"], adam_beta_1=k["adam_beta_1"], adam_beta_2=k["adam_beta_2"], adam_epsilon=k["adam_epsilon"])
+    e.reset(d["reset_draws"])
+    np.testing.assert_allclose(e.read("PLAN"), d["Q_init"], rtol=1e-6, atol=1e-7)
+    tol = dict(rtol=1e-3, atol=3e-3) if k["outer_its"] >= 20 else dict(rtol=2e-4, atol=2e-4)
+    count = 0
+    for t in range(int(d["steps"])):
+        key = f"resample_draws_{t}"
+        assert (e.samples_needed() > 0) == (key in d.files)
+        u = e.step(d[f"s_{t}"], d[key] if key in d.files else None, u_prev=d[f"u_prev_{t}"])
+        count += 1
+        np.testing.assert_allclose(e.read("U_NOM"), d[f"u_nom_{t}"], **tol)
+        np.testing.assert_allclose(u, d[f"u_{t}"], **tol)
+        np.testing.assert_allclose(e.read("PLAN"), d[f"Q_{t}"], **tol)
+        np.testing.assert_allclose(e.read("ADAM_M"), d[f"m_{t}"], **tol)
+        np.testing.assert_allclose(e.read("ADAM_V"), d[f"v_{t}"], **tol)
+        np.testing.assert_array_equal(e.read("AGES"), d[f"ages_{t}"])
+        e.set_state(np.concatenate([d[f"Q_{t}"].ravel(), d[f"m_{t}"].ravel(), d[f"v_{t}"].ravel(), d[f"ages_{t}"].ravel(), d[f"u_{t}"].ravel(),
+                                    [int(d[f"adam_step_{t}"])], [count]]).astype(np.float32))
+    e.close()

@@ -153,8 +153,10 @@ def test_errors_are_loud():
     from control_toolkit_amd import CtkEngine
     with pytest.raises(ValueError):
         CtkEngine("mppi", "ODE", num_rollouts=0, mpc_horizon=10, dt=0.02)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="num_states == 4"):     # S / C are the environment's (Optimizers/__init__.py:52-63 take the predictor's)
         CtkEngine("mppi", "ODE", num_rollouts=8, mpc_horizon=10, dt=0.02, num_states=6)
+    with pytest.raises(NotImplementedError, match="not built"):
+        CtkEngine("mppi", "ODE", num_rollouts=8, mpc_horizon=10, dt=0.02, environment="Acrobot")
     e = CtkEngine("mppi", "ODE", num_rollouts=8, mpc_horizon=10, dt=0.02)
     with pytest.raises(ValueError):
         e.step(np.zeros(4, np.float32), np.zeros((3, 10, 1), np.float32))

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import ctk_oracle as O
-from helpers import load, env_from, mppi_oracle_from, rpgd_oracle_from, MPPI_CASES, RPGD_CASES
+from helpers import load, env_from, mppi_oracle_from, rpgd_oracle_from, MPPI_CASES, RPGD_CASES, MPPI_QUAD_CASES, RPGD_QUAD_CASES
 
 
 def test_interpolator_matches_reference():
@@ -216,3 +216,41 @@ def test_torch_cpu_restatement_matches_the_numpy_oracle():
             np.testing.assert_allclose(t.J.numpy(), o.J, rtol=2e-5)
             np.testing.assert_allclose(t.u_nom.numpy(), o.u_nom.reshape(-1), rtol=1e-4, atol=2e-5)
             assert abs(uo - ut) < 2e-5
+
+
+# ---- second environment (Quad2D, C = 2): the same reference optimizers, recorded by tests/golden/make_golden.py -------------
+@pytest.mark.parametrize("case", MPPI_QUAD_CASES)
+def test_mppi_two_inputs_matches_reference(case):
+    d = load(f"mppi_{case}.npz")
+    o = mppi_oracle_from(d)
+    assert (o.S, o.C) == (6, 2)
+    np.testing.assert_array_equal(o.u_nom, d["u_nom_init"])
+    for t in range(int(d["steps"])):
+        np.testing.assert_array_equal(np.broadcast_to(np.asarray(o.u, np.float32).reshape(-1), (2,)), d[f"u_prev_{t}"])
+        u = o.step(d[f"s_{t}"], d[f"noise_{t}"])
+        np.testing.assert_allclose(o.u_run, d[f"u_run_{t}"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(o.J, d[f"J_{t}"], rtol=2e-5)
+        np.testing.assert_allclose(o.rollout_trajectories, d[f"traj_{t}"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(o.u_nom, d[f"u_nom_{t}"], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(u, d[f"u_{t}"], rtol=1e-5, atol=2e-6)
+        o.u_nom = d[f"u_nom_{t}"].copy(); o.u = d[f"u_{t}"].copy()
+
+
+@pytest.mark.parametrize("case", RPGD_QUAD_CASES)
+def test_rpgd_two_inputs_matches_reference(case):
+    d = load(f"rpgd_{case}.npz")
+    o = rpgd_oracle_from(d)
+    o.optimizer_reset(d["reset_draws"])
+    np.testing.assert_allclose(o.Q, d["Q_init"], rtol=1e-6, atol=1e-7)
+    tol = dict(rtol=1e-3, atol=2e-3) if int(d["outer_its"]) >= 20 else dict(rtol=1e-4, atol=1e-4)
+    for t in range(int(d["steps"])):
+        key = f"resample_draws_{t}"
+        u = o.step(d[f"s_{t}"], d[key] if key in d.files else None)
+        np.testing.assert_allclose(o.u_nom, d[f"u_nom_{t}"], **tol)
+        np.testing.assert_allclose(o.Q, d[f"Q_{t}"], **tol)
+        np.testing.assert_allclose(o.opt.m, d[f"m_{t}"], **tol)
+        np.testing.assert_allclose(o.opt.v, d[f"v_{t}"], **tol)
+        np.testing.assert_array_equal(o.trajectory_ages, d[f"ages_{t}"])
+        assert o.opt.step_count == int(d[f"adam_step_{t}"])
+        np.testing.assert_allclose(u, d[f"u_{t}"], **tol)
+        o.Q = d[f"Q_{t}"].copy(); o.opt.m = d[f"m_{t}"].copy(); o.opt.v = d[f"v_{t}"].copy(); o.u = d[f"u_{t}"].copy()
