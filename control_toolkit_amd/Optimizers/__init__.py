@@ -247,6 +247,7 @@ class template_optimizer:
                 v = getattr(inner, n, None)
                 if isinstance(v, (int, float, np.floating, np.integer)):
                     vals[n] = float(v)
+            vals.update(self._reference_cost_yaml(cf))
             cfgd = getattr(inner, "config", None)
             if isinstance(cfgd, dict):
                 vals.update({k: v for k, v in cfgd.items() if isinstance(v, (int, float))})
@@ -260,6 +261,26 @@ class template_optimizer:
                     except (TypeError, ValueError):
                         pass
         return {k: float(v) for k, v in vals.items() if k in names}
+
+    def _reference_cost_yaml(self, cf) -> dict:
+        """Control_Toolkit_ASF/config_cost_function.yml[<environment>][<cost function name>] — the file the reference's
+        cost functions take their weights from (cost_function_wrapper.py:14; CWD-relative like there), re-read when it changes."""
+        import os
+        path = os.path.join("Control_Toolkit_ASF", "config_cost_function.yml")
+        env, name = getattr(cf, "environment_name", None), getattr(cf, "cost_function_name", None)
+        if env is None or name is None or not os.path.isfile(path):
+            return {}
+        st = os.stat(path)
+        key = (st.st_mtime_ns, st.st_size, env, name)
+        if getattr(self, "_cost_yaml_key", None) != key:
+            from yaml import safe_load
+            try:
+                section = (safe_load(open(path, "r")) or {}).get(env, {}).get(name, {}) or {}
+            except Exception:   # noqa: BLE001 — a half-written file: keep what was read last
+                return getattr(self, "_cost_yaml_vals", {})
+            self._cost_yaml_key = key
+            self._cost_yaml_vals = {k: v for k, v in section.items() if isinstance(v, (int, float))}
+        return self._cost_yaml_vals
 
     def _sync_parameters(self, force=False):
         """Upload changed dynamics / cost / per-step attributes (reference: variable_parameters

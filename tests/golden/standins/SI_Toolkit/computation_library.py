@@ -13,7 +13,28 @@ class ComputationLibrary:
 
 
 class NumpyLibrary(ComputationLibrary):
+    """caller-side members only (Controllers/__init__.py:72-82, Optimizers/__init__.py:42-44, controller_mpc.py:93-96):
+    enough for the reference's controller_mpc to drive an optimizer that computes elsewhere (tests/ref_plugin_probe.py)"""
     lib = "Numpy"
+    float32 = np.float32
+
+    @staticmethod
+    def set_device(device_name):
+        def deco(fn):
+            return fn
+        return deco
+
+    @staticmethod
+    def to_tensor(x, dtype):
+        return np.asarray(x, dtype=dtype)
+
+    @staticmethod
+    def to_variable(x, dtype):
+        return np.array(x, dtype=dtype)
+
+    @staticmethod
+    def to_numpy(x):
+        return np.asarray(x)
 
 
 class TensorFlowLibrary(ComputationLibrary):
