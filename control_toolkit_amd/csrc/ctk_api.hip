@@ -166,37 +166,44 @@ void refresh_constants(ctk_handle* h) {
     h->mk = m;
 }
 
-// Per-lane MFMA operand layout of the MLP weights (ctk_mlp.h header comment).
-// raw: W1[32,5] b1[32] W2[32,32] b2[32] W3[4,32] b3[4].  out: fwd [64][48] | bwd [64][28].
-std::vector<float> permute_mlp_weights(const float* raw) {
-    const float* W1 = raw;                 const float* b1 = W1 + 32 * 5;
+// Per-lane MFMA operand layout of the MLP weights (ctk_mlp.h header comment), for a network with I = S + C <= 8 inputs and
+// S <= 8 outputs.  Network input / output index k lives in lane group k % 4, k-step (inputs) or register (outputs) k / 4,
+// i.e. at row 4*(k%4) + k/4 of a 16-row tile — inputs are the S state components followed by the C control inputs.
+// raw: W1[32,I] b1[32] W2[32,32] b2[32] W3[S,32] b3[S].  out: fwd [64][48] | bwd [64][28].
+std::vector<float> permute_mlp_weights(const float* raw, int S = CTK_S, int C = CTK_C) {
+    const int I = S + C;
+    const float* W1 = raw;                 const float* b1 = W1 + 32 * I;
     const float* W2 = b1 + 32;             const float* b2 = W2 + 32 * 32;
-    const float* W3 = b2 + 32;             const float* b3 = W3 + 4 * 32;
+    const float* W3 = b2 + 32;             const float* b3 = W3 + S * 32;
     std::vector<float> out((size_t)64 * (MLP_FWD_PER_LANE + MLP_BWD_PER_LANE), 0.0f);
+    auto io_of_row = [](int row) { return 4 * (row % 4) + row / 4; };   // network input / output index held at tile row `row`
     for (int l = 0; l < 64; ++l) {
         const int i = l & 15, g = l >> 4;
         float* f = out.data() + (size_t)l * MLP_FWD_PER_LANE;
         for (int m = 0; m < 2; ++m)
             for (int ks = 0; ks < 2; ++ks) {
                 const int kk = 4 * ks + g;
-                f[m * 2 + ks] = kk < 5 ? W1[(16 * m + i) * 5 + kk] : 0.0f;
+                f[m * 2 + ks] = kk < I ? W1[(16 * m + i) * I + kk] : 0.0f;
             }
         for (int mo = 0; mo < 2; ++mo)
             for (int j = 0; j < 8; ++j) f[4 + mo * 8 + j] = W2[(16 * mo + i) * 32 + mlp_hid(j, g)];
-        for (int j = 0; j < 8; ++j) f[20 + j] = (i % 4 == 0) ? W3[(i / 4) * 32 + mlp_hid(j, g)] : 0.0f;
+        const int out_i = (i % 4 < 2 && io_of_row(i) < S) ? io_of_row(i) : -1;     // rows r = 0, 1 of every lane group carry outputs
+        for (int j = 0; j < 8; ++j) f[20 + j] = out_i >= 0 ? W3[out_i * 32 + mlp_hid(j, g)] : 0.0f;
         for (int m = 0; m < 2; ++m)
             for (int r = 0; r < 4; ++r) {
                 f[28 + m * 4 + r] = b1[16 * m + 4 * g + r];
                 f[36 + m * 4 + r] = b2[16 * m + 4 * g + r];
             }
-        for (int r = 0; r < 4; ++r) f[44 + r] = (r == 0) ? b3[g] : 0.0f;
-        // backward (vector-Jacobian products, used by RPGD): A operands of W3^T, W2^T, W1^T
+        for (int r = 0; r < 4; ++r) f[44 + r] = (r < 2 && 4 * r + g < S) ? b3[4 * r + g] : 0.0f;
+        // backward (vector-Jacobian products): A operands of W3^T, W2^T, W1^T
         float* b = out.data() + (size_t)64 * MLP_FWD_PER_LANE + (size_t)l * MLP_BWD_PER_LANE;
-        for (int m = 0; m < 2; ++m) b[m] = W3[g * 32 + 16 * m + i];                       // rows: hidden, k: output comp g
+        for (int m = 0; m < 2; ++m)
+            for (int ks = 0; ks < 2; ++ks)
+                b[2 * m + ks] = (4 * ks + g < S) ? W3[(4 * ks + g) * 32 + 16 * m + i] : 0.0f;           // rows: hidden, k: output component 4ks+g
         for (int mi = 0; mi < 2; ++mi)
-            for (int j = 0; j < 8; ++j) b[2 + mi * 8 + j] = W2[mlp_hid(j, g) * 32 + 16 * mi + i];   // rows: hidden_in, k: hidden_out
-        const int inp = (i % 4 == 0) ? i / 4 : (i == 1 ? 4 : -1);                          // rows 0,4,8,12 -> state 0..3; row 1 -> input
-        for (int j = 0; j < 8; ++j) b[18 + j] = inp >= 0 ? W1[mlp_hid(j, g) * 5 + inp] : 0.0f;
+            for (int j = 0; j < 8; ++j) b[4 + mi * 8 + j] = W2[mlp_hid(j, g) * 32 + 16 * mi + i];       // rows: hidden_in, k: hidden_out
+        const int inp = (i % 4 < 2 && io_of_row(i) < I) ? io_of_row(i) : -1;                            // rows: network inputs
+        for (int j = 0; j < 8; ++j) b[20 + j] = inp >= 0 ? W1[mlp_hid(j, g) * I + inp] : 0.0f;
     }
     return out;
 }
@@ -1064,7 +1071,7 @@ int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n) {
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipMemcpyAsync(h->d_weights, w, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
     if (gru) HIP_TRY(h, hipMemsetAsync(h->d_wperm + GRU_TABLE_FLOATS, 0, GRU_HIDDEN_FLOATS * sizeof(float), h->stream));
-    const std::vector<float> perm = gru ? permute_gru_weights(w) : permute_mlp_weights(w);
+    const std::vector<float> perm = gru ? permute_gru_weights(w) : permute_mlp_weights(w, h->S, h->C);
     if (gru) {   // |h2| <= 1 (convex mix of tanh values and the previous state, which starts at 0 or at what the caller set)
         const float* Wo = w + GRU_NW_RAW - 4 * 32 - 4; const float* bo = Wo + 4 * 32;
         float bound = 0.0f;

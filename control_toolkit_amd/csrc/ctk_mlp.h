@@ -20,7 +20,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MLP_FWD_PER_LANE = 48;   // floats per lane, forward  (12 x float4)
-constexpr int MLP_BWD_PER_LANE = 28;   // floats per lane, backward ( 7 x float4; 26 used)
+constexpr int MLP_BWD_PER_LANE = 28;   // floats per lane, backward ( 7 x float4)
 
 __host__ __device__ inline int mlp_hid(int j, int g) { return 16 * (j >> 2) + 4 * g + (j & 3); }
 
@@ -235,10 +235,12 @@ CTK_DEV MlpBwdW mlp_load_bwd(const float* __restrict__ wperm) {
     const float f[28] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w,
                          v[3].x, v[3].y, v[3].z, v[3].w, v[4].x, v[4].y, v[4].z, v[4].w, v[5].x, v[5].y, v[5].z, v[5].w,
                          v[6].x, v[6].y, v[6].z, v[6].w};
+    // table: [0..3] w3t[tile][k-step] | [4..19] w2t[tile][k-step] | [20..27] w1t[k-step]   (ctk_api.hip:permute_mlp_weights);
+    // CartPole has 4 outputs: only k-step 0 of W3^T is non-zero
     MlpBwdW w;
-    w.w3t[0] = f[0]; w.w3t[1] = f[1];
+    w.w3t[0] = f[0]; w.w3t[1] = f[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { w.w2t[0][j] = f[2 + j]; w.w2t[1][j] = f[10 + j]; w.w1t[j] = f[18 + j]; }
+    for (int j = 0; j < 8; ++j) { w.w2t[0][j] = f[4 + j]; w.w2t[1][j] = f[12 + j]; w.w1t[j] = f[20 + j]; }
     return w;
 }
 
