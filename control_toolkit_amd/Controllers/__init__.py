@@ -123,8 +123,8 @@ class template_controller(ABC):
         # reference :170-178 (logged arrays are copies).  Entries that live in the engine's HBM log ring
         # (optimizer option logging_on_device) stay there: the handle is kept and the data moves in get_outputs();
         # when the ring is about to wrap, what it holds is brought to the host first.
-        from ..Optimizers import DeviceLogEntry
         if self.controller_logging:
+            from ..Optimizers import DeviceLogEntry
             for name in self.save_vars:
                 var = logging_values.get(name, None)
                 if var is None:

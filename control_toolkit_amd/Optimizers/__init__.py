@@ -112,6 +112,8 @@ class template_optimizer:
         self._param_cache = {}
         self._cost_version = None
         self._sync_key = None
+        self._vp_names, self._vp_len = None, -1
+        self._u_public, self._u_vec = None, None
         self.optimal_trajectory = None
         self.rollout_trajectories = None
         self._lazy = {}   # device buffers fetched on first access after a step (u_nom: no D2H copy on the step path)
@@ -286,11 +288,24 @@ class template_optimizer:
         """Upload changed dynamics / cost / per-step attributes (reference: variable_parameters
         updated by template_controller.update_attributes, Controllers/__init__.py:106-107; cost
         YAML hot reload, cost_function_wrapper.py:71-74).  Only between steps."""
-        vals = self._parameter_values()
-        key = tuple(vals.values())
+        cf, vals = self.cost_function, None
+        if hasattr(cf, "version") and isinstance(getattr(cf, "parameters", None), dict):
+            # fast per-step check for the build's own wrappers: the cost parameters carry a version counter, the dynamics are a
+            # small dict, and of variable_parameters only the attributes that name engine parameters matter
+            vp = getattr(cf, "variable_parameters", None) or getattr(self.predictor, "variable_parameters", None)
+            vpd = getattr(vp, "__dict__", {}) if vp is not None else {}
+            if self._vp_names is None or len(vpd) != self._vp_len:
+                self._vp_names, self._vp_len = [n for n in self.engine.param_names if n in vpd], len(vpd)
+            key = (cf.version, tuple(cf.parameters.values()), tuple((getattr(self.predictor, "parameters", None) or {}).values()),
+                   tuple([vpd[n].item() if hasattr(vpd[n], "item") else float(vpd[n]) for n in self._vp_names]))
+        else:
+            vals = self._parameter_values()
+            key = tuple(vals.values())
         if not force and key == self._sync_key:
             return
         self._sync_key = key
+        if vals is None:
+            vals = self._parameter_values()
         for name, v in vals.items():
             if force or self._param_cache.get(name) != v:
                 self.engine.set_param(name, v)
@@ -311,9 +326,19 @@ class template_optimizer:
         return s
 
     def _u_prev(self):
-        """the previous output as [C] (self.u starts as the scalar 0.0, reference Optimizers/__init__.py:34)"""
-        return np.broadcast_to(np.asarray(self.u, np.float32).reshape(-1), (self.num_control_inputs,)) \
-            if np.size(self.u) == 1 else np.asarray(self.u, np.float32).reshape(-1)
+        """the previous output as [C] (self.u starts as the scalar 0.0, reference Optimizers/__init__.py:34).  Fast path: self.u
+        is still the object _publish_u() put there, so the engine's own [C] array is the answer; otherwise (a caller assigned
+        self.u) convert."""
+        if self.u is self._u_public:
+            return self._u_vec
+        u = np.asarray(self.u, np.float32).reshape(-1)
+        return np.broadcast_to(u, (self.num_control_inputs,)) if u.size == 1 else u
+
+    def _publish_u(self, u_vec):
+        """self.u as the reference exposes it (squeezed: a scalar for one control input, optimizer_mppi.py:212) + its [C] form"""
+        self._u_vec = u_vec
+        self.u = self._u_public = u_vec[0] if u_vec.size == 1 else u_vec
+        return self.u
 
     def _logged(self, name: str):
         """the tensor `name` of the step just completed: a host array, or its handle in the device log"""

@@ -45,7 +45,7 @@ class optimizer_cem_hip(template_optimizer):
         self._sync_parameters()
         iterations = self.warmup_iterations if self.warmup and self.count == 0 else self.cem_outer_it   # :92
         noise = self._draws("normal", [iterations, self.num_rollouts, self.mpc_horizon, self.num_control_inputs])   # :64-65
-        self.u = np.squeeze(self.engine.step(s, noise, u_prev=self._u_prev()))
+        self._publish_u(self.engine.step(s, noise, u_prev=self._u_prev()))
         if self.optimizer_logging:
             self._fill_logging(s, self.u)
         self.count += 1

@@ -41,7 +41,7 @@ class optimizer_mppi_hip(template_optimizer):
         s = self._prepare_state(s)
         self._sync_parameters()
         noise = self._draws("normal", [self.num_rollouts, self.number_of_interpolation_inducing_points, self.num_control_inputs])   # :173-175
-        self.u = np.squeeze(self.engine.step(s, noise, u_prev=self._u_prev()))  # :211-212
+        self._publish_u(self.engine.step(s, noise, u_prev=self._u_prev()))      # :211-212
         self._lazy.clear()                                                        # u_nom / optimal_control_sequence (:220): read on demand
         if self.optimizer_logging:
             self._fill_logging(s, self.u)

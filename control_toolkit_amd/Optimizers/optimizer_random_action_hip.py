@@ -34,7 +34,7 @@ class optimizer_random_action_hip(template_optimizer):
         s = self._prepare_state(s)
         self._sync_parameters()
         u01 = self._draws("uniform", [self.num_rollouts, self.mpc_horizon, self.num_control_inputs])   # :56-61
-        self.u = np.squeeze(self.engine.step(s, u01, u_prev=self._u_prev()))
+        self._publish_u(self.engine.step(s, u01, u_prev=self._u_prev()))
         if self.optimizer_logging:
             self._fill_logging(s, self.u)
         return self.u
