@@ -487,8 +487,12 @@ int mppi_rollout(ctk_handle* h, const float* s, const float* u_prev, const float
     if (int rc = check_predictor(h)) return rc;
     if (h->generic) {   // template kernel: block records only (merged by the launches that follow)
         ProfSlot ps(h);
-        HIP_TRY(h, ctk_launch_g_rollout(h->stream, h->env, CTK_G_MODE_MPPI, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s,
-                                        h->d_unom[h->cur], nullptr, 0, h->d_parts, log, ps.a, ps.b));
+        if (h->cfg.predictor == CTK_PRED_MLP)
+            HIP_TRY(h, ctk_launch_g_rollout_mlp(h->stream, h->env, CTK_G_MODE_MPPI, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s,
+                                                h->d_unom[h->cur], nullptr, 0, h->d_wperm, h->d_parts, log, ps.a, ps.b));
+        else
+            HIP_TRY(h, ctk_launch_g_rollout(h->stream, h->env, CTK_G_MODE_MPPI, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s,
+                                            h->d_unom[h->cur], nullptr, 0, h->d_parts, log, ps.a, ps.b));
         return CTK_OK;
     }
     MppiFuse fz;
@@ -555,7 +559,10 @@ int mppi_update(ctk_handle* h, const float* parts, int n_parts, float* u_out) {
 int launch_affine(ctk_handle* h, const RolloutArgs& a, const float* d_s, int rng_kind, const float* base, const float* scale, bool log,
                   const AffineBest* bst = nullptr) {
     ProfSlot ps(h);
-    if (h->generic)
+    if (h->generic && h->cfg.predictor == CTK_PRED_MLP)
+        HIP_TRY(h, ctk_launch_g_rollout_mlp(h->stream, h->env, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s,
+                                            base, scale, rng_kind, h->d_wperm, nullptr, log, ps.a, ps.b));
+    else if (h->generic)
         HIP_TRY(h, ctk_launch_g_rollout(h->stream, h->env, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s, base,
                                         scale, rng_kind, nullptr, log, ps.a, ps.b));
     else
@@ -568,7 +575,10 @@ int launch_descent(ctk_handle* h, const RolloutArgs& a, float lr, float b1, floa
                    const float* bc, int bc_len, int t0, int iters, int rule, const RpgdFusedWarm* fused = nullptr) {
     const ctk_config& c = h->cfg;
     ProfSlot ps(h);
-    if (h->generic)
+    if (h->generic && c.predictor == CTK_PRED_MLP)
+        HIP_TRY(h, ctk_launch_g_rpgd_descent_mlp(h->stream, h->env, a, h->params, c.dt, c.intermediate_steps, lr, b1, b2, eps, c.gradmax_clip, Q, m,
+                                                 v, bc, bc_len, t0, iters, h->d_wperm, h->d_scratch, ps.a, ps.b, rule));
+    else if (h->generic)
         HIP_TRY(h, ctk_launch_g_rpgd_descent(h->stream, h->env, a, h->params, c.dt, c.intermediate_steps, lr, b1, b2, eps, c.gradmax_clip, Q, m, v,
                                              bc, bc_len, t0, iters, h->d_scratch, ps.a, ps.b, rule));
     else
@@ -852,8 +862,8 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: unknown predictor");
     // the template kernels roll the analytic model out; the network predictors have (so far) CartPole-shaped MFMA kernels only
     const bool generic = cfg->environment != CTK_ENV_CARTPOLE || cfg->generic_kernels != 0;
-    if (generic && cfg->predictor != CTK_PRED_ODE)
-        return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: the MLP / GRU predictors are built for the CartPole kernels (environment CartPole, generic_kernels 0)");
+    if (generic && cfg->predictor == CTK_PRED_GRU)
+        return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: the GRU predictor is built for the CartPole kernels (environment CartPole, generic_kernels 0)");
     if (cfg->predictor == CTK_PRED_GRU && (cfg->optimizer == CTK_OPT_RPGD || variant != cfg->optimizer))
         return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: the GRU predictor is built forward-only (MPPI, CEM, random-action); no reverse mode for the gradient-based optimizers");
     if (cfg->optimizer == CTK_OPT_CEM && (cfg->cem_best_k < 1 || cfg->cem_best_k > cfg->num_rollouts || cfg->cem_outer_it < 1))
@@ -902,7 +912,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     // LDS budget of the rollout tiles (one wave per block): 64 * stride * 4 B <= 160 KiB
     {
         size_t lds;
-        if (generic) lds = descends ? ctk_g_rpgd_descent_lds(h->env, (int)H, nullptr)
+        if (generic) lds = descends ? (cfg->predictor == CTK_PRED_MLP ? ctk_g_rpgd_descent_mlp_lds(h->env, (int)H) : ctk_g_rpgd_descent_lds(h->env, (int)H, nullptr))
                                     : ctk_g_rollout_lds((int)(cfg->optimizer == CTK_OPT_MPPI ? PC : HC), (int)H, h->C);
         else lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_lds((int)P, (int)H, cfg->predictor)
                  : descends ? ctk_rpgd_descent_lds(cfg->predictor, (int)H, nullptr) : ctk_affine_rollout_lds((int)H, cfg->predictor);
@@ -932,7 +942,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     TRY_CREATE(dev_alloc(h, &h->d_scale, HC));
     TRY_CREATE(dev_alloc(h, &h->d_idx, N));
     TRY_CREATE(dev_alloc(h, &h->d_u, CTK_MAX_INPUTS));
-    TRY_CREATE(dev_alloc(h, &h->d_weights, cfg->predictor == CTK_PRED_GRU ? GRU_NW_RAW : CTK_MLP_NW));
+    TRY_CREATE(dev_alloc(h, &h->d_weights, std::max<size_t>(1, weight_count(cfg->predictor, h->S, h->C))));
     TRY_CREATE(dev_alloc(h, &h->d_wperm, cfg->predictor == CTK_PRED_GRU ? (size_t)GRU_TABLE_FLOATS + GRU_HIDDEN_FLOATS
                                                                           : (size_t)64 * (MLP_FWD_PER_LANE + MLP_BWD_PER_LANE)));
     HIP_CREATE(hipHostMalloc((void**)&h->h_u, 64, hipHostMallocMapped | hipHostMallocCoherent));
@@ -957,14 +967,19 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
         TRY_CREATE(dev_alloc(h, &h->d_bc, bc.size()));
         HIP_CREATE(hipMemcpyAsync(h->d_bc, bc.data(), bc.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
         HIP_CREATE(hipStreamSynchronize(h->stream));
-        TRY_CREATE(dev_alloc(h, &h->d_scratch, generic ? ctk_g_rpgd_scratch_floats(h->env, (int)N, (int)H)
-                                                       : ctk_rpgd_scratch_floats(cfg->predictor, (int)N, (int)H)));
+        TRY_CREATE(dev_alloc(h, &h->d_scratch, !generic ? ctk_rpgd_scratch_floats(cfg->predictor, (int)N, (int)H)
+                                               : cfg->predictor == CTK_PRED_MLP ? ctk_g_rpgd_scratch_floats_mlp((int)N, (int)H)
+                                                                                : ctk_g_rpgd_scratch_floats(h->env, (int)N, (int)H)));
     }
     const bool mat = cfg->materialize_trajectories != 0;
-    if (descends) h->dominant = generic ? ctk_g_rpgd_descent_name(h->env) : ctk_rpgd_descent_name(cfg->predictor);
-    else if (cfg->optimizer == CTK_OPT_MPPI)
-        h->dominant = generic ? ctk_g_rollout_name(h->env, CTK_G_MODE_MPPI, mat) : ctk_mppi_rollout_name(cfg->predictor, mat, cfg->num_rollouts);
-    else h->dominant = generic ? ctk_g_rollout_name(h->env, CTK_G_MODE_AFFINE, mat) : ctk_affine_rollout_name(cfg->predictor, mat);
+    const bool gnet = generic && cfg->predictor == CTK_PRED_MLP;
+    if (descends) h->dominant = gnet ? ctk_g_rpgd_descent_mlp_name(h->env) : generic ? ctk_g_rpgd_descent_name(h->env) : ctk_rpgd_descent_name(cfg->predictor);
+    else {
+        const int mode = cfg->optimizer == CTK_OPT_MPPI ? CTK_G_MODE_MPPI : CTK_G_MODE_AFFINE;
+        h->dominant = gnet ? ctk_g_rollout_mlp_name(h->env, mode, mat) : generic ? ctk_g_rollout_name(h->env, mode, mat)
+                    : cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_name(cfg->predictor, mat, cfg->num_rollouts)
+                                                     : ctk_affine_rollout_name(cfg->predictor, mat);
+    }
     if (cfg->optimizer != CTK_OPT_RPGD) TRY_CREATE(ctk_reset(h, nullptr, CTK_LOC_NONE));
     HIP_CREATE(hipStreamSynchronize(h->stream));
     *out = h;
@@ -1067,7 +1082,8 @@ int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n) {
     if (h->cfg.predictor == CTK_PRED_ODE) return fail(h, CTK_ERR_STATE, "ctk_set_predictor_weights: the ODE predictor has no weights");
     const bool gru = h->cfg.predictor == CTK_PRED_GRU;
     if (n != weight_count(h->cfg.predictor, h->S, h->C))
-        return fail(h, CTK_ERR_INVALID_ARGUMENT, gru ? "ctk_set_predictor_weights: expected 10212 floats (GRU)" : "ctk_set_predictor_weights: expected 1380 floats (MLP)");
+        return fail(h, CTK_ERR_INVALID_ARGUMENT, std::string("ctk_set_predictor_weights: expected ") +
+                    std::to_string(weight_count(h->cfg.predictor, h->S, h->C)) + " floats for this predictor and environment (ctk_predictor_weight_count)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipMemcpyAsync(h->d_weights, w, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
     if (gru) HIP_TRY(h, hipMemsetAsync(h->d_wperm + GRU_TABLE_FLOATS, 0, GRU_HIDDEN_FLOATS * sizeof(float), h->stream));
@@ -1365,7 +1381,10 @@ int ctk_rollout(ctk_handle* h, const float* s, const float* u_prev, const float*
     RolloutArgs a = make_args(h, s, u_prev, n, h->H);
     for (int c = 0; c < h->C; ++c) { a.lo[c] = -INFINITY; a.hi[c] = INFINITY; }
     a.traj_out = traj_out ? d_traj : nullptr;
-    hipError_t e = h->generic
+    hipError_t e = (h->generic && h->cfg.predictor == CTK_PRED_MLP)
+        ? ctk_launch_g_rollout_mlp(h->stream, h->env, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s, d_zero,
+                                   d_one, 0, h->d_wperm, nullptr, traj_out != nullptr)
+        : h->generic
         ? ctk_launch_g_rollout(h->stream, h->env, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s, d_zero, d_one,
                                0, nullptr, traj_out != nullptr)
         : ctk_launch_affine_rollout(h->stream, h->cfg.predictor, a, h->k, d_s, 0, d_zero, d_one, h->d_wperm, traj_out != nullptr);

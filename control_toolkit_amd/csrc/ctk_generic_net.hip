@@ -1,0 +1,362 @@
+// ctk_generic_net.hip — the environment-agnostic template kernels with the MLP predictor ((S+C)-32-32-S tanh network on the
+// fp32 matrix cores, ctk_mlp.h) in place of the analytic model: same structure as ctk_generic.hip (Env<> supplies S, C and the
+// cost terms; the network replaces Env::step), one wave = one 16-trajectory MFMA tile, four tiles per workgroup.
+// State layout of a tile: lane (c, g) holds components g and 4+g of trajectory c — layer 1's B operands as they stand; the
+// cost terms need the whole state, gathered per step with cross-lane reads (every lane group evaluates the same cost).
+#include "ctk_rollout.h"
+#include "ctk_env.h"
+#include "ctk_mlp.h"
+#include "ctk_adam.h"
+#include "ctk_launch.h"
+
+constexpr int GN_TRAJ = 64, GN_BLOCK = 256, GN_LD = GN_TRAJ + 1;
+
+template <int N>
+CTK_DEV float pick(const float (&v)[N], int idx) {      // v[idx] for a lane-dependent idx without scratch memory
+    float r = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r = (i == idx) ? v[i] : r;
+    return r;
+}
+
+// the whole state of the lane's trajectory from the (component g, component 4+g) layout
+template <int S>
+CTK_DEV void gather_state(float sv0, float sv1, int c, float (&s)[S]) {
+#pragma unroll
+    for (int j = 0; j < S; ++j) s[j] = __shfl(j < 4 ? sv0 : sv1, c + 16 * (j & 3), 64);
+}
+
+// layer-1 B operand of k-step 1 for lane group g: state component 4+g, or control input 4+g-S, or padding
+template <int S, int C>
+CTK_DEV float second_operand(float sv1, const float (&u)[C], int g) {
+    float x1 = (4 + g < S) ? sv1 : 0.0f;
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) x1 = (4 + g == S + cc) ? u[cc] : x1;
+    return x1;
+}
+template <int S, int C>
+CTK_DEV float first_operand(float sv0, const float (&u)[C], int g) {   // S < 4 environments: inputs may already start in k-step 0
+    float x0 = (g < S) ? sv0 : 0.0f;
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) x0 = (g == S + cc) ? u[cc] : x0;
+    return x0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// rollout + cost (MPPI / affine modes of ctk_generic.hip)
+// ---------------------------------------------------------------------------------------------------------------
+template <int ENV, int MODE, bool LOG>
+__global__ __launch_bounds__(GN_BLOCK) void ctk_g_rollout_mlp(RolloutArgs a, typename Env<ENV>::K k, MppiK m, const float* __restrict__ samples,
+                                                             const float* __restrict__ base, const float* __restrict__ scale, int rng_kind,
+                                                             const float* __restrict__ wperm, float* __restrict__ parts) {
+    using E = Env<ENV>;
+    constexpr int S = E::S, C = E::C;
+    extern __shared__ float lds[];
+    __shared__ float red_s[8];
+    const int H = a.H, HC = H * C, cols = a.P, ts = tile_stride(cols);
+    float* tile = lds;
+    float* e_s = tile + GN_TRAJ * ts;
+    float* base_s = e_s + GN_TRAJ;
+    float* scale_s = base_s + HC;
+    float* w0_s = scale_s + HC;
+    float* w1_s = w0_s + H;
+    int* i0_s = reinterpret_cast<int*>(w1_s + H);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * GN_TRAJ;
+    const int tr = wave * 16 + c, n = row0 + tr;
+    const bool valid = n < a.N;
+
+    load_tile_early<GN_TRAJ, GN_BLOCK>(tile, samples, a, row0, MODE == CTK_G_MODE_MPPI ? m.stdev : 1.0f, rng_kind, [&] {
+        if constexpr (MODE == CTK_G_MODE_MPPI) {
+            for (int h = t; h < H; h += GN_BLOCK) {
+                const InterpEntry e = a.interp[h];
+                i0_s[h] = e.i0; w0_s[h] = e.w0; w1_s[h] = e.w1;
+            }
+            for (int hc = t; hc < HC; hc += GN_BLOCK) {
+                const int h = hc / C, cc = hc - h * C;
+                base_s[hc] = base[min(h + 1, H - 1) * C + cc];
+            }
+        } else {
+            for (int hc = t; hc < HC; hc += GN_BLOCK) { base_s[hc] = base[hc]; scale_s[hc] = scale[hc]; }
+        }
+    });
+    __syncthreads();
+
+    const MlpFwdW w = mlp_load_fwd(wperm);
+    const float* my = tile + tr * ts;
+    float sv0 = g < S ? a.s0[g] : 0.0f, sv1 = 4 + g < S ? a.s0[(4 + g) & (CTK_MAX_STATES - 1)] : 0.0f;
+    float up[C];
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) up[cc] = a.u_prev_dev ? a.u_prev_dev[cc] : a.u_prev[cc];
+    float csum = 0.0f, corr = 0.0f;
+    const int Pm1 = cols / C - 1;
+    for (int h = 0; h < H; ++h) {
+        float u[C];
+        if constexpr (MODE == CTK_G_MODE_MPPI) {
+            const int i0 = i0_s[h], i1 = min(i0 + 1, Pm1);
+            const float w0 = w0_s[h], w1 = w1_s[h];
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) {
+                const float du = my[i0 * C + cc] * w0 + my[i1 * C + cc] * w1;
+                u[cc] = fminf(fmaxf(base_s[h * C + cc] + du, a.lo[cc]), a.hi[cc]);
+                corr += m.cc * (m.k_dd * (du * du) + m.R * u[cc] * du + m.k_uu * (u[cc] * u[cc]));
+            }
+        } else {
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc)
+                u[cc] = fminf(fmaxf(base_s[h * C + cc] + my[h * C + cc] * scale_s[h * C + cc], a.lo[cc]), a.hi[cc]);
+        }
+        if constexpr (LOG || MODE == CTK_G_MODE_AFFINE) {
+            if (valid && g == 0 && a.Q_out) {
+#pragma unroll
+                for (int cc = 0; cc < C; ++cc) a.Q_out[(size_t)n * HC + h * C + cc] = u[cc];
+            }
+        }
+        float s[S];
+        gather_state<S>(sv0, sv1, c, s);
+        csum += E::stage_cost(k, s, u, up);
+        if constexpr (LOG) {
+            if (valid && g == 0 && a.traj_out) {
+#pragma unroll
+                for (int i = 0; i < S; ++i) a.traj_out[((size_t)n * (H + 1) + h) * S + i] = s[i];
+            }
+        }
+        const MlpPair o = mlp_step2(w, first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g));
+        sv0 = o.lo; sv1 = o.hi;
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) up[cc] = u[cc];
+    }
+    float sT[S];
+    gather_state<S>(sv0, sv1, c, sT);
+    if constexpr (LOG) {
+        if (valid && g == 0 && a.traj_out) {
+#pragma unroll
+            for (int i = 0; i < S; ++i) a.traj_out[((size_t)n * (H + 1) + H) * S + i] = sT[i];
+        }
+    }
+    const float J = (csum + E::terminal_cost(k, sT)) * a.inv_Hp1 + corr;
+    if (valid && g == 0) a.J[n] = J;
+
+    if constexpr (MODE == CTK_G_MODE_MPPI) {
+        const float rw = wave_min(valid ? J : INFINITY);           // every trajectory appears in all four lane groups: min unaffected
+        if (lane == 0) red_s[wave] = rw;
+        __syncthreads();
+        const float rho = fminf(fminf(red_s[0], red_s[1]), fminf(red_s[2], red_s[3]));
+        const float e = valid ? expf(m.neg_inv_lbd * (J - rho)) : 0.0f;
+        const float aw = wave_sum(g == 0 ? e : 0.0f);
+        if (g == 0) e_s[tr] = e;
+        if (lane == 0) red_s[4 + wave] = aw;
+        __syncthreads();
+        float* rec = parts + (size_t)blockIdx.x * (2 + cols);
+        if (t == 0) { rec[0] = rho; rec[1] = (red_s[4] + red_s[5]) + (red_s[6] + red_s[7]); }
+        for (int p = t; p < cols; p += GN_BLOCK) {
+            float acc = 0.0f;
+#pragma unroll 8
+            for (int r = 0; r < GN_TRAJ; ++r) acc += e_s[r] * tile[r * ts + p];
+            rec[2 + p] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RPGD descent with the network predictor: forward with the activations taped to an L2-resident global scratch
+// ([h][lane][20] floats per wave: {sv0, sv1, -, -}, h1[8], h2[8]), reverse sweep on MFMA (mlp_step_vjp2), cost gradients from
+// Env<>, per-plan clip_by_norm, Adam, clip, final cost pass.  64 plans per workgroup, 16 per wave.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int GN_TAPE = 20;
+
+template <int ENV>
+__global__ __launch_bounds__(GN_BLOCK) void ctk_g_rpgd_descent_mlp(RolloutArgs a, typename Env<ENV>::K k, AdamK ad, float* __restrict__ Q,
+                                                                  float* __restrict__ m, float* __restrict__ v,
+                                                                  const float* __restrict__ bc_table, int bc_len, int t0, int iters,
+                                                                  const float* __restrict__ wperm, float* __restrict__ scratch) {
+    using E = Env<ENV>;
+    constexpr int S = E::S, C = E::C;
+    extern __shared__ float lds[];
+    const int H = a.H, HC = H * C;
+    float* q_s = lds;
+    float* g_s = q_s + HC * GN_LD;
+    float* sc_s = g_s + HC * GN_LD;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 15, g = lane >> 4;
+    const int col = wave * 16 + c;
+    const int row0 = blockIdx.x * GN_TRAJ;
+    const int rows = min(GN_TRAJ, a.N - row0);
+    const int total = rows * HC;
+    const size_t gbase = (size_t)row0 * HC;
+    float* tape = scratch + (size_t)(blockIdx.x * 4 + wave) * H * 64 * GN_TAPE;
+
+    for (int i = t; i < GN_TRAJ * HC; i += GN_BLOCK) {
+        const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, hc = i - r * HC;
+        q_s[hc * GN_LD + r] = i < total ? Q[gbase + i] : 0.0f;
+    }
+    __syncthreads();
+
+    const MlpFwdW wf = mlp_load_fwd(wperm);
+    const MlpBwdW2 wb = mlp_load_bwd2(wperm);
+    float up0[C];
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) up0[cc] = a.u_prev_dev ? a.u_prev_dev[cc] : a.u_prev[cc];
+    const float inv = a.inv_Hp1;
+    const float s00 = g < S ? a.s0[g] : 0.0f, s01 = 4 + g < S ? a.s0[(4 + g) & (CTK_MAX_STATES - 1)] : 0.0f;
+
+    for (int it = 0; it < iters; ++it) {
+        // ---- forward, taping the step inputs and activations
+        float sv0 = s00, sv1 = s01;
+        for (int h = 0; h < H; ++h) {
+            float u[C];
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) u[cc] = q_s[(h * C + cc) * GN_LD + col];
+            MlpAct act;
+            const MlpPair o = mlp_step2(wf, first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g), &act);
+            float4* tp = reinterpret_cast<float4*>(tape + ((size_t)h * 64 + lane) * GN_TAPE);
+            tp[0] = make_float4(sv0, sv1, 0.f, 0.f);
+            tp[1] = make_float4(act.h1[0][0], act.h1[0][1], act.h1[0][2], act.h1[0][3]);
+            tp[2] = make_float4(act.h1[1][0], act.h1[1][1], act.h1[1][2], act.h1[1][3]);
+            tp[3] = make_float4(act.h2[0][0], act.h2[0][1], act.h2[0][2], act.h2[0][3]);
+            tp[4] = make_float4(act.h2[1][0], act.h2[1][1], act.h2[1][2], act.h2[1][3]);
+            sv0 = o.lo; sv1 = o.hi;
+        }
+        // ---- reverse sweep
+        float sH[S], gT[S];
+        gather_state<S>(sv0, sv1, c, sH);
+        E::terminal_grad(k, sH, gT);
+        float lam0 = g < S ? pick<S>(gT, g) * inv : 0.0f, lam1 = 4 + g < S ? pick<S>(gT, 4 + g) * inv : 0.0f;
+        float nrm2 = 0.0f;
+        float gp_next[C];
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) gp_next[cc] = 0.0f;
+        const float4* tq = reinterpret_cast<const float4*>(tape + ((size_t)(H - 1) * 64 + lane) * GN_TAPE);
+        float4 r0 = tq[0], r1 = tq[1], r2 = tq[2], r3 = tq[3], r4 = tq[4];
+        for (int h = H - 1; h >= 0; --h) {
+            MlpAct act;
+            act.h1[0] = f32x4{r1.x, r1.y, r1.z, r1.w}; act.h1[1] = f32x4{r2.x, r2.y, r2.z, r2.w};
+            act.h2[0] = f32x4{r3.x, r3.y, r3.z, r3.w}; act.h2[1] = f32x4{r4.x, r4.y, r4.z, r4.w};
+            const float p0 = r0.x, p1 = r0.y;                 // state components g, 4+g entering step h
+            if (h > 0) {                                       // prefetch the previous step's tape under this step's MFMAs
+                const float4* tn = reinterpret_cast<const float4*>(tape + ((size_t)(h - 1) * 64 + lane) * GN_TAPE);
+                r0 = tn[0]; r1 = tn[1]; r2 = tn[2]; r3 = tn[3]; r4 = tn[4];
+            }
+            const MlpPair d = mlp_step_vjp2(wb, act, lam0, lam1);
+            float s[S], gs[S], u[C], upv[C], gu[C], gp[C];
+            gather_state<S>(p0, p1, c, s);
+            E::stage_grad_state(k, s, gs);
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) {
+                u[cc] = q_s[(h * C + cc) * GN_LD + col];
+                upv[cc] = h > 0 ? q_s[((h - 1) * C + cc) * GN_LD + col] : up0[cc];
+            }
+            E::input_grad(k, u, upv, gu, gp);
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) {
+                const int kk = S + cc;                         // network input index of control input cc: lane group kk % 4, half kk / 4
+                if (g == (kk & 3)) {
+                    const float gq = (gu[cc] + gp_next[cc]) * inv + (kk >= 4 ? d.hi : d.lo);
+                    g_s[(h * C + cc) * GN_LD + col] = gq;
+                    nrm2 += gq * gq;
+                }
+                gp_next[cc] = gp[cc];
+            }
+            lam0 = g < S ? pick<S>(gs, g) * inv + d.lo : 0.0f;
+            lam1 = 4 + g < S ? pick<S>(gs, 4 + g) * inv + d.hi : 0.0f;
+        }
+        nrm2 = sum_over_groups(nrm2);
+        if (g == 0) sc_s[col] = ad.clip / fmaxf(sqrtf(nrm2), ad.clip);
+        __syncthreads();
+        const int ti = t0 + it + 1;
+        const float bc1 = ti <= bc_len ? bc_table[2 * (ti - 1)] : 1.0f;
+        const float bc2 = ti <= bc_len ? bc_table[2 * (ti - 1) + 1] : 1.0f;
+        for (int i = t; i < total; i += GN_BLOCK) {
+            const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, hc = i - r * HC, cc = hc % C;
+            float mm = 0.0f, vv = 0.0f;
+            if (ad.rule != 2) { mm = m[gbase + i]; vv = v[gbase + i]; }
+            const float gg = g_s[hc * GN_LD + r] * sc_s[r];
+            q_s[hc * GN_LD + r] = adam_update(ad, q_s[hc * GN_LD + r], gg, mm, vv, bc1, bc2, a.lo[cc], a.hi[cc]);
+            if (ad.rule != 2) { m[gbase + i] = mm; v[gbase + i] = vv; }
+        }
+        __syncthreads();
+    }
+    {   // get_action's forward pass (optimizer_rpgd.py:342): costs of the refined plans
+        float sv0 = s00, sv1 = s01, csum = 0.0f, up[C];
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) up[cc] = up0[cc];
+        for (int h = 0; h < H; ++h) {
+            float u[C], s[S];
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) u[cc] = q_s[(h * C + cc) * GN_LD + col];
+            gather_state<S>(sv0, sv1, c, s);
+            csum += E::stage_cost(k, s, u, up);
+            const MlpPair o = mlp_step2(wf, first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g));
+            sv0 = o.lo; sv1 = o.hi;
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) up[cc] = u[cc];
+        }
+        float sT[S];
+        gather_state<S>(sv0, sv1, c, sT);
+        const float J = (csum + E::terminal_cost(k, sT)) * inv;
+        if (g == 0 && row0 + col < a.N) a.J[row0 + col] = J;
+    }
+    __syncthreads();
+    for (int i = t; i < total; i += GN_BLOCK) {
+        const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, hc = i - r * HC;
+        Q[gbase + i] = q_s[hc * GN_LD + r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static uint32_t magic_of(int d) { return d >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d) : 0u; }
+
+const char* ctk_g_rollout_mlp_name(int env, int mode, bool log) {
+    static const char* names[2][2][2] = {
+        {{"ctk_g_rollout_mlp<0, 0, false>", "ctk_g_rollout_mlp<0, 0, true>"}, {"ctk_g_rollout_mlp<0, 1, false>", "ctk_g_rollout_mlp<0, 1, true>"}},
+        {{"ctk_g_rollout_mlp<1, 0, false>", "ctk_g_rollout_mlp<1, 0, true>"}, {"ctk_g_rollout_mlp<1, 1, false>", "ctk_g_rollout_mlp<1, 1, true>"}}};
+    return names[env == CTK_ENV_CARTPOLE ? 0 : 1][mode == CTK_G_MODE_MPPI ? 0 : 1][log ? 1 : 0];
+}
+
+hipError_t ctk_launch_g_rollout_mlp(hipStream_t st, int env, int mode, const RolloutArgs& a_in, const float* params, float dt, int isteps,
+                                    const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
+                                    const float* wperm, float* parts, bool log, hipEvent_t e0, hipEvent_t e1) {
+    CTK_FOR_ENV(env, EV, {
+        using E = Env<EV>;
+        RolloutArgs a = a_in;
+        const int cols = (mode == CTK_G_MODE_MPPI ? a_in.P : a_in.H) * E::C;
+        a.P = cols; a.p_magic = magic_of(cols); a.C = E::C;
+        const typename E::K k = E::derive(params, dt, isteps);
+        const dim3 grid(ctk_g_rollout_blocks(a.N)), block(GN_BLOCK);
+        const size_t lds = ctk_g_rollout_lds(cols, a.H, E::C);
+        if (mode == CTK_G_MODE_MPPI) {
+            if (log) CTK_LAUNCH((ctk_g_rollout_mlp<EV, CTK_G_MODE_MPPI, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, parts);
+            else CTK_LAUNCH((ctk_g_rollout_mlp<EV, CTK_G_MODE_MPPI, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, parts);
+        } else {
+            if (log) CTK_LAUNCH((ctk_g_rollout_mlp<EV, CTK_G_MODE_AFFINE, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, parts);
+            else CTK_LAUNCH((ctk_g_rollout_mlp<EV, CTK_G_MODE_AFFINE, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, parts);
+        }
+    });
+    return hipGetLastError();
+}
+
+size_t ctk_g_rpgd_descent_mlp_lds(int env, int H) {
+    int C = 0;
+    CTK_FOR_ENV(env, EV, { C = Env<EV>::C; });
+    return (size_t)(2 * H * C * GN_LD + GN_TRAJ) * sizeof(float);
+}
+
+size_t ctk_g_rpgd_scratch_floats_mlp(int N, int H) { return (size_t)((N + GN_TRAJ - 1) / GN_TRAJ) * 4 * H * 64 * GN_TAPE; }
+
+const char* ctk_g_rpgd_descent_mlp_name(int env) { return env == CTK_ENV_CARTPOLE ? "ctk_g_rpgd_descent_mlp<0>" : "ctk_g_rpgd_descent_mlp<1>"; }
+
+hipError_t ctk_launch_g_rpgd_descent_mlp(hipStream_t st, int env, const RolloutArgs& a_in, const float* params, float dt, int isteps, float lr,
+                                         float b1, float b2, float eps, float clip, float* Q, float* m, float* v, const float* bc_table,
+                                         int bc_len, int t0, int iters, const float* wperm, float* scratch, hipEvent_t e0, hipEvent_t e1,
+                                         int rule) {
+    AdamK ad{lr, b1, b2, (float)(1.0 - (double)b1), (float)(1.0 - (double)b2), eps, clip, rule};
+    CTK_FOR_ENV(env, EV, {
+        using E = Env<EV>;
+        RolloutArgs a = a_in;
+        a.C = E::C; a.p_magic = magic_of(a.H * E::C);
+        const typename E::K k = E::derive(params, dt, isteps);
+        const dim3 grid((a.N + GN_TRAJ - 1) / GN_TRAJ), block(GN_BLOCK);
+        CTK_LAUNCH((ctk_g_rpgd_descent_mlp<EV>), grid, block, ctk_g_rpgd_descent_mlp_lds(env, a.H), st, e0, e1, a, k, ad, Q, m, v, bc_table,
+                   bc_len, t0, iters, wperm, scratch);
+    });
+    return hipGetLastError();
+}

@@ -149,3 +149,16 @@ hipError_t ctk_launch_g_rpgd_descent(hipStream_t st, int env, const RolloutArgs&
                                      float b1, float b2, float eps, float clip, float* Q, float* m, float* v, const float* bc_table,
                                      int bc_len, int t0, int iters, float* scratch, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
                                      int rule = 0);
+
+// ---- ctk_generic_net.hip : the template kernels with the MLP predictor ((S+C)-32-32-S, fp32 MFMA) ---------------
+const char* ctk_g_rollout_mlp_name(int env, int mode, bool log);
+hipError_t ctk_launch_g_rollout_mlp(hipStream_t st, int env, int mode, const RolloutArgs& a, const float* params, float dt, int isteps,
+                                    const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
+                                    const float* wperm, float* parts, bool log, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+size_t ctk_g_rpgd_descent_mlp_lds(int env, int H);
+size_t ctk_g_rpgd_scratch_floats_mlp(int N, int H);
+const char* ctk_g_rpgd_descent_mlp_name(int env);
+hipError_t ctk_launch_g_rpgd_descent_mlp(hipStream_t st, int env, const RolloutArgs& a, const float* params, float dt, int isteps, float lr,
+                                         float b1, float b2, float eps, float clip, float* Q, float* m, float* v, const float* bc_table,
+                                         int bc_len, int t0, int iters, const float* wperm, float* scratch, hipEvent_t e0 = nullptr,
+                                         hipEvent_t e1 = nullptr, int rule = 0);

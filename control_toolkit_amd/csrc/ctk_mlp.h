@@ -278,3 +278,90 @@ CTK_DEV float mlp_step_vjp(const MlpBwdW& w, const MlpAct& act, float lam, float
     *du = o0[1] + o1[1];
     return o0[0] + o1[0];
 }
+
+// ---------------------------------------------------------------------------------------------
+// The same network for any environment with I = S + C <= 8 inputs and S <= 8 outputs (ctk_generic.hip): network input /
+// output index k lives in lane group k % 4, k-step (inputs) or register (outputs) k / 4 — the per-lane tables are built for
+// (S, C) by ctk_api.hip:permute_mlp_weights.  CartPole's own entry points above are the I = 5, S = 4 case with the second
+// half unused.
+// ---------------------------------------------------------------------------------------------
+struct MlpPair {
+    float lo, hi;      // network input / output (or adjoint) index g and 4+g of the lane's trajectory
+};
+
+// x0 / x1: values of network inputs g and 4+g (0 where 4+g >= I).  Returns outputs g and 4+g.
+CTK_DEV MlpPair mlp_step2(const MlpFwdW& w, float x0, float x1, MlpAct* keep = nullptr) {
+    f32x4 a0 = w.b1[0], a1 = w.b1[1];
+    a0 = CTK_MFMA(w.w1[0][0], x0, a0);
+    a1 = CTK_MFMA(w.w1[1][0], x0, a1);
+    a0 = CTK_MFMA(w.w1[0][1], x1, a0);
+    a1 = CTK_MFMA(w.w1[1][1], x1, a1);
+    f32x4 h1[2];
+    h1[0] = ctk_tanhf4(a0); h1[1] = ctk_tanhf4(a1);
+    f32x4 c0 = w.b2[0], c1 = w.b2[1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float b = h1[j >> 2][j & 3];
+        c0 = CTK_MFMA(w.w2[0][j], b, c0);
+        c1 = CTK_MFMA(w.w2[1][j], b, c1);
+    }
+    f32x4 h2[2];
+    h2[0] = ctk_tanhf4(c0); h2[1] = ctk_tanhf4(c1);
+    f32x4 o0 = w.b3, o1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        o0 = CTK_MFMA(w.w3[j], h2[j >> 2][j & 3], o0);
+        o1 = CTK_MFMA(w.w3[j + 1], h2[(j + 1) >> 2][(j + 1) & 3], o1);
+    }
+    if (keep) { keep->h1[0] = h1[0]; keep->h1[1] = h1[1]; keep->h2[0] = h2[0]; keep->h2[1] = h2[1]; }
+    return MlpPair{o0[0] + o1[0], o0[1] + o1[1]};
+}
+
+struct MlpBwdW2 {
+    float w3t[2][2];   // [hidden tile][k-step]   A = W3^T (rows hidden, k = output component 4*ks + g)
+    float w2t[2][8];
+    float w1t[8];
+};
+
+CTK_DEV MlpBwdW2 mlp_load_bwd2(const float* __restrict__ wperm) {
+    const float* p = wperm + 64 * MLP_FWD_PER_LANE + (threadIdx.x & 63) * MLP_BWD_PER_LANE;
+    MlpBwdW2 w;
+    w.w3t[0][0] = p[0]; w.w3t[0][1] = p[1]; w.w3t[1][0] = p[2]; w.w3t[1][1] = p[3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { w.w2t[0][j] = p[4 + j]; w.w2t[1][j] = p[12 + j]; w.w1t[j] = p[20 + j]; }
+    return w;
+}
+
+// lam0 / lam1: adjoints of the NEXT state's components g / 4+g.  Returns the adjoints w.r.t. network inputs g and 4+g.
+CTK_DEV MlpPair mlp_step_vjp2(const MlpBwdW2& w, const MlpAct& act, float lam0, float lam1) {
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 t0 = CTK_MFMA(w.w3t[0][0], lam0, z), t1 = CTK_MFMA(w.w3t[1][0], lam0, z);
+    t0 = CTK_MFMA(w.w3t[0][1], lam1, t0);
+    t1 = CTK_MFMA(w.w3t[1][1], lam1, t1);
+    f32x4 d2[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        d2[0][r] = t0[r] * (1.0f - act.h2[0][r] * act.h2[0][r]);
+        d2[1][r] = t1[r] * (1.0f - act.h2[1][r] * act.h2[1][r]);
+    }
+    f32x4 s0 = z, s1 = z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float b = d2[j >> 2][j & 3];
+        s0 = CTK_MFMA(w.w2t[0][j], b, s0);
+        s1 = CTK_MFMA(w.w2t[1][j], b, s1);
+    }
+    f32x4 d1[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        d1[0][r] = s0[r] * (1.0f - act.h1[0][r] * act.h1[0][r]);
+        d1[1][r] = s1[r] * (1.0f - act.h1[1][r] * act.h1[1][r]);
+    }
+    f32x4 o0 = z, o1 = z;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        o0 = CTK_MFMA(w.w1t[j], d1[j >> 2][j & 3], o0);
+        o1 = CTK_MFMA(w.w1t[j + 1], d1[(j + 1) >> 2][(j + 1) & 3], o1);
+    }
+    return MlpPair{o0[0] + o1[0], o0[1] + o1[1]};
+}

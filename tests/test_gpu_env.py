@@ -71,7 +71,12 @@ def test_quad2d_env_info_and_errors():
     with pytest.raises(ValueError, match="num_states"):
         CtkEngine("mppi", "ODE", environment="Quad2D", num_states=4, num_control_inputs=1, num_rollouts=8, mpc_horizon=5, dt=0.02)
     with pytest.raises(NotImplementedError, match="CartPole kernels"):
-        CtkEngine("mppi", "MLP", environment="Quad2D", num_rollouts=8, mpc_horizon=5, dt=0.02)
+        CtkEngine("mppi", "GRU", environment="Quad2D", num_rollouts=8, mpc_horizon=5, dt=0.02)
+    em = CtkEngine("mppi", "MLP", environment="Quad2D", num_rollouts=8, mpc_horizon=5, dt=0.02)
+    assert em.predictor_weight_count() == O.mlp_num_weights(8, 6)
+    with pytest.raises(ValueError, match="expected 1542"):
+        em.set_predictor_weights(np.zeros(1380, np.float32))
+    em.close()
     with pytest.raises(ValueError):
         CtkEngine("mppi", "ODE", environment="Quad2D", num_rollouts=8, mpc_horizon=5, dt=0.02, action_low=[-1, -1, -1])
 
@@ -336,4 +341,123 @@ def test_quad2d_rpgd_matches_reference_golden(case):
         np.testing.assert_array_equal(e.read("AGES"), d[f"ages_{t}"])
         e.set_state(np.concatenate([d[f"Q_{t}"].ravel(), d[f"m_{t}"].ravel(), d[f"v_{t}"].ravel(), d[f"ages_{t}"].ravel(), d[f"u_{t}"].ravel(),
                                     [int(d[f"adam_step_{t}"])], [count]]).astype(np.float32))
+    e.close()
+
+
+# ---- the MLP predictor ((S+C)-32-32-S tanh network on the fp32 matrix cores) under the template kernels ------------------------
+@pytest.mark.parametrize("opt", ["mppi", "cem", "random_action", "rpgd"])
+def test_cartpole_generic_mlp_kernels_match_tuned_mlp_kernels(opt):
+    N, H, p = 160, 20, (5 if opt in ("mppi", "rpgd") else 1)
+    kw = dict(num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p, seed=9, materialize_trajectories=True)
+    if opt == "cem":
+        kw.update(cem_outer_it=2, cem_best_k=16)
+    if opt == "rpgd":
+        kw.update(outer_its=3, resamp_per=2, opt_keep_k=40, sample_whole_control_space=1)
+    w = O.mlp_default_weights(2)
+    a, b = CtkEngine(opt, "MLP", **kw), CtkEngine(opt, "MLP", generic_kernels=True, **kw)
+    assert "ctk_g_" in b.dominant_kernel() and "mlp" in b.dominant_kernel()
+    a.set_predictor_weights(w); b.set_predictor_weights(w)
+    if opt == "rpgd":
+        a.reset(); b.reset()
+    s = np.array([0.05, -0.1, 2.8, 0.4], np.float32)
+    for t in range(3):
+        ua, ub = a.step(s), b.step(s)
+        np.testing.assert_allclose(b.read("J"), a.read("J"), rtol=5e-5, atol=1e-3)
+        if opt != "rpgd":
+            np.testing.assert_allclose(b.read("Q"), a.read("Q"), rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(b.read("TRAJ"), a.read("TRAJ"), rtol=1e-4, atol=2e-5)
+        else:
+            assert_close_mostly(b.read("PLAN"), a.read("PLAN"), rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(ub, ua, rtol=2e-4, atol=2e-4)
+        b.set_state(a.get_state())
+        s = s + np.array([0.01, 0.0, -0.02, 0.01], np.float32)
+    a.close(); b.close()
+
+
+def quad_mlp(seed=3):
+    env = quad_env()
+    w = O.mlp_default_weights(seed, 8, 6)
+    return env, w, O.Predictor("MLP", env=env, weights=w)
+
+
+def test_quad2d_mlp_plain_rollout_and_mppi_match_oracle():
+    env, w, pred = quad_mlp()
+    cost = O.Cost(env)
+    e = CtkEngine("mppi", "MLP", environment="Quad2D", num_rollouts=200, mpc_horizon=30, dt=0.02, period_interpolation_inducing_points=5,
+                  action_low=QLO, action_high=QHI, materialize_trajectories=True)
+    apply_params(e, env); e.set_predictor_weights(w)
+    Q = np.random.default_rng(0).uniform(-1, 1, (37, 30, 2)).astype(np.float32)
+    up = np.array([0.2, -0.3], np.float32)
+    traj, J = e.rollout(S0, Q, u_prev=up)
+    to = pred.predict_core(np.tile(S0, (37, 1)), Q)
+    np.testing.assert_allclose(traj, to, rtol=1e-4, atol=3e-5)        # tanh via v_exp/v_rcp, MFMA summation order
+    np.testing.assert_allclose(J, cost.get_trajectory_cost(to, Q, up), rtol=5e-5, atol=1e-3)
+    o = O.MPPI(pred, cost, QLO, QHI, num_rollouts=200, mpc_horizon=30, period_interpolation_inducing_points=5)
+    rng = np.random.default_rng(1)
+    s = S0.copy()
+    for t in range(3):
+        noise = rng.standard_normal((200, o.P, 2)).astype(np.float32)
+        uo, ug = o.step(s, noise), e.step(s, noise)
+        np.testing.assert_allclose(e.read("Q"), o.u_run, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(e.read("J"), o.J, rtol=5e-5, atol=1e-3)
+        np.testing.assert_allclose(e.read("TRAJ"), o.rollout_trajectories, rtol=1e-4, atol=3e-5)
+        np.testing.assert_allclose(e.read("U_NOM"), o.u_nom, **U_TOL)
+        np.testing.assert_allclose(ug, np.asarray(uo).reshape(-1), **U_TOL)
+        s = pred.step(s.reshape(1, 6), np.asarray(uo, np.float32).reshape(1, 2))[0]
+    e.close()
+
+
+def test_quad2d_mlp_cem_matches_oracle():
+    env, w, pred = quad_mlp(4)
+    N, H, K = 256, 20, 25
+    o = O.CEM(pred, O.Cost(env), QLO, QHI, num_rollouts=N, mpc_horizon=H, cem_outer_it=2, cem_best_k=K)
+    e = CtkEngine("cem", "MLP", environment="Quad2D", num_rollouts=N, mpc_horizon=H, dt=0.02, cem_outer_it=2, cem_best_k=K,
+                  action_low=QLO, action_high=QHI)
+    apply_params(e, env); e.set_predictor_weights(w)
+    rng = np.random.default_rng(2)
+    for t in range(2):
+        noise = rng.standard_normal((2, N, H, 2)).astype(np.float32)
+        uo, ug = o.step(S0, noise), e.step(S0, noise)
+        np.testing.assert_allclose(e.read("J"), o.J, rtol=5e-5, atol=1e-3)
+        np.testing.assert_allclose(e.read("U_NOM"), o.dist_mue, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(ug, np.asarray(uo).reshape(-1), rtol=1e-5, atol=1e-6)
+    e.close()
+
+
+def test_quad2d_mlp_gradient_and_rpgd_match_oracle():
+    env, w, pred = quad_mlp(5)
+    cost = O.Cost(env)
+    N, H = 64, 20
+    # one Adam iteration from zero moments: m = (1 - beta1) * dJ/dQ — isolates the MFMA reverse sweep (mlp_step_vjp2) for S = 6, C = 2
+    e = CtkEngine("rpgd", "MLP", environment="Quad2D", num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=1,
+                  outer_its=1, resamp_per=1000, opt_keep_k=16, sampling_distribution=0, sample_whole_control_space=1, gradmax_clip=1e9,
+                  action_low=QLO, action_high=QHI)
+    apply_params(e, env); e.set_predictor_weights(w)
+    e.reset(np.random.default_rng(3).random((N, H, 2), dtype=np.float32))
+    Q0 = e.read("PLAN")
+    up = np.array([0.05, -0.02], np.float32)
+    e.set_state(np.concatenate([Q0.ravel(), np.zeros(2 * N * H * 2 + N, np.float32), up, [0], [1]]).astype(np.float32))
+    e.step(S0, None, u_prev=up)
+    _, _, g = O.rollout_cost_and_grad(pred, cost, np.tile(S0, (N, 1)), Q0, up)
+    np.testing.assert_allclose(e.read("ADAM_M")[:, :-1, :], 0.1 * g[:, 1:, :], rtol=2e-3, atol=2e-4 * np.abs(g).max())
+    e.close()
+    # the full step, several iterations
+    o = O.RPGD(pred, cost, QLO, QHI, num_rollouts=N, mpc_horizon=H, outer_its=4, resamp_per=2, period_interpolation_inducing_points=5,
+               SAMPLING_DISTRIBUTION="uniform", opt_keep_k_ratio=0.25)
+    e = CtkEngine("rpgd", "MLP", environment="Quad2D", num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=5,
+                  outer_its=4, resamp_per=2, opt_keep_k=o.k, sampling_distribution=0, sample_whole_control_space=1, action_low=QLO, action_high=QHI)
+    apply_params(e, env); e.set_predictor_weights(w)
+    rng = np.random.default_rng(6)
+    d0 = rng.random((N, o.P, 2), dtype=np.float32)
+    o.optimizer_reset(d0); e.reset(d0)
+    tol = dict(rtol=2e-4, atol=3e-4)
+    s = S0.copy()
+    for t in range(3):
+        dr = rng.random((N - o.k, o.P, 2), dtype=np.float32) if t % 2 == 0 else None
+        uo, ug = o.step(s, dr), e.step(s, dr)
+        assert_close_mostly(e.read("PLAN"), o.Q, max_outliers=max(4, o.Q.size // 400), **tol)
+        assert_close_mostly(e.read("ADAM_M"), o.opt.m, max_outliers=max(4, o.Q.size // 400), **tol)
+        np.testing.assert_allclose(ug, np.asarray(uo).reshape(-1), **tol)
+        e.set_state(rpgd_state(o))
+        s = pred.step(s.reshape(1, 6), np.asarray(uo, np.float32).reshape(1, 2))[0]
     e.close()

@@ -17,10 +17,6 @@
 // any environment with S + C <= 8 inputs and S <= 8 outputs fits; outputs come back as (component g, component 4+g).
 // Both waves end a step with bit-identical outputs (same instructions on the same data in the same order).
 // =============================================================================================
-struct MlpPair {
-    float lo, hi;      // network input / output (or adjoint) index g and 4+g of the lane's trajectory
-};
-
 struct MlpFwdWS {      // wave m's share of the forward operands (same per-lane table as MlpFwdW)
     float w1[2];       // [k-step]
     float w2[8];       // [k-step]   output tile m
