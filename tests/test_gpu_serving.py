@@ -16,8 +16,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.timeout(120)
 def test_router_loop_serves_mppi_hip_within_the_reference_deadline():
-    ctrl = build_controller("mppi-hip", "ODE", dict(num_rollouts=1024, mpc_horizon=50, seed=5))
-    local = build_controller("mppi-hip", "ODE", dict(num_rollouts=1024, mpc_horizon=50, seed=5))   # same seed, stepped in-process
+    cfg = dict(num_rollouts=3500, mpc_horizon=35, period_interpolation_inducing_points=10, seed=5)   # the reference's default MPPI size
+    ctrl = build_controller("mppi-hip", "ODE", cfg)
+    local = build_controller("mppi-hip", "ODE", cfg)            # same seed (same device draws), stepped in-process
     port_box, done = [], threading.Event()
     th = threading.Thread(target=lambda: (serve(ctrl, "127.0.0.1", 0, on_ready=port_box.append, prefer_zmq=False), done.set()), daemon=True)
     th.start()
