@@ -12,6 +12,7 @@
 #include "ctk_mlp.h"      // mlp_hid, per-lane weight layout
 #include "ctk_gru.h"      // GRU per-lane table layout
 #include "ctk_env.h"      // Env<>: S, C of every environment
+#include "ctk_net.h"      // GRUG_*: per-lane table layout of the GRU under the template kernels
 #include <algorithm>
 #include <cstdlib>
 
@@ -262,6 +263,67 @@ const EnvInfo kEnvs[CTK_ENV_COUNT] = {
 };
 const EnvInfo* env_info(int env) { return (env >= 0 && env < CTK_ENV_COUNT) ? &kEnvs[env] : nullptr; }
 
+// Per-lane operand tables of the GRU under the template kernels (ctk_net.h: NetGru — one wave per 16-trajectory tile, operands
+// staged in LDS): forward [232][64] then reverse [172][64], for a network with I = S + C <= 8 inputs and S <= 8 outputs.
+// raw: per layer W_i[96,I'] W_h[96,32] b_i[96] b_h[96] (rows r|z|n, I' = I then 32), then W_o[S,32] b_o[S].
+std::vector<float> permute_gru_weights_g(const float* raw, int S, int C) {
+    const int I = S + C;
+    std::vector<float> out((size_t)(GRUG_FWD + GRUG_BWD) * 64, 0.0f);
+    float* F = out.data();
+    float* B = F + (size_t)GRUG_FWD * 64;
+    const float *Wi[2], *Wh[2], *bi[2], *bh[2];
+    const float* p = raw;
+    for (int L = 0; L < 2; ++L) {
+        const int In = L == 0 ? I : 32;
+        Wi[L] = p; Wh[L] = Wi[L] + 96 * In; bi[L] = Wh[L] + 96 * 32; bh[L] = bi[L] + 96;
+        p = bh[L] + 96;
+    }
+    const float* Wo = p; const float* bo = Wo + S * 32;
+    auto io_of_row = [](int row) { return 4 * (row % 4) + row / 4; };
+    for (int l = 0; l < 64; ++l) {
+        const int i = l & 15, g = l >> 4;
+        for (int L = 0; L < 2; ++L) {
+            const int KS = L == 0 ? 2 : 8, In = L == 0 ? I : 32, base = L == 0 ? 0 : GRUG_L1;
+            for (int G = 0; G < 3; ++G)
+                for (int m = 0; m < 2; ++m) {
+                    const int row = G * 32 + 16 * m + i;
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const int kk = L == 0 ? 4 * ks + g : mlp_hid(ks, g);
+                        F[(size_t)(base + (G * 2 + m) * KS + ks) * 64 + l] = (L == 0 && kk >= I) ? 0.0f : Wi[L][row * In + kk];
+                    }
+                    for (int j = 0; j < 8; ++j) F[(size_t)(base + 6 * KS + (G * 2 + m) * 8 + j) * 64 + l] = Wh[L][row * 32 + mlp_hid(j, g)];
+                }
+            const int bb = base + 6 * KS + 48;
+            for (int m = 0; m < 2; ++m)
+                for (int r = 0; r < 4; ++r) {
+                    const int unit = 16 * m + 4 * g + r;
+                    F[(size_t)(bb + 0 + m * 4 + r) * 64 + l] = bi[L][unit] + bh[L][unit];
+                    F[(size_t)(bb + 8 + m * 4 + r) * 64 + l] = bi[L][32 + unit] + bh[L][32 + unit];
+                    F[(size_t)(bb + 16 + m * 4 + r) * 64 + l] = bi[L][64 + unit];
+                    F[(size_t)(bb + 24 + m * 4 + r) * 64 + l] = bh[L][64 + unit];
+                }
+        }
+        const int ob = GRUG_L1 + GRUG_L2;
+        const int out_i = (i % 4 < 2 && io_of_row(i) < S) ? io_of_row(i) : -1;
+        for (int j = 0; j < 8; ++j) F[(size_t)(ob + j) * 64 + l] = out_i >= 0 ? Wo[out_i * 32 + mlp_hid(j, g)] : 0.0f;
+        for (int r = 0; r < 4; ++r) F[(size_t)(ob + 8 + r) * 64 + l] = (r < 2 && 4 * r + g < S) ? bo[4 * r + g] : 0.0f;
+        // reverse: A operands of the transposed products; k-step (G, m, r) has k-slot g = gate neuron G*32 + 16m + 4g + r
+        for (int m = 0; m < 2; ++m)
+            for (int ks = 0; ks < 2; ++ks) B[(size_t)(m * 2 + ks) * 64 + l] = (4 * ks + g < S) ? Wo[(4 * ks + g) * 32 + 16 * m + i] : 0.0f;
+        const int inp = (i % 4 < 2 && io_of_row(i) < I) ? io_of_row(i) : -1;
+        for (int G = 0; G < 3; ++G)
+            for (int m = 0; m < 2; ++m)
+                for (int r = 0; r < 4; ++r) {
+                    const int ks = G * 8 + m * 4 + r, neuron = G * 32 + 16 * m + 4 * g + r;
+                    for (int mi = 0; mi < 2; ++mi) B[(size_t)(4 + mi * 24 + ks) * 64 + l] = Wi[1][neuron * 32 + 16 * mi + i];
+                    for (int mh = 0; mh < 2; ++mh) B[(size_t)(4 + 48 + mh * 24 + ks) * 64 + l] = Wh[1][neuron * 32 + 16 * mh + i];
+                    B[(size_t)(4 + 96 + ks) * 64 + l] = inp >= 0 ? Wi[0][neuron * I + inp] : 0.0f;
+                    for (int mh = 0; mh < 2; ++mh) B[(size_t)(4 + 96 + 24 + mh * 24 + ks) * 64 + l] = Wh[0][neuron * 32 + 16 * mh + i];
+                }
+    }
+    return out;
+}
+
 void default_params(int env, float* p) {
     const EnvInfo* e = env_info(env);
     for (int i = 0; i < e->n_params; ++i) p[i] = e->param_defaults[i];
@@ -487,9 +549,9 @@ int mppi_rollout(ctk_handle* h, const float* s, const float* u_prev, const float
     if (int rc = check_predictor(h)) return rc;
     if (h->generic) {   // template kernel: block records only (merged by the launches that follow)
         ProfSlot ps(h);
-        if (h->cfg.predictor == CTK_PRED_MLP)
-            HIP_TRY(h, ctk_launch_g_rollout_mlp(h->stream, h->env, CTK_G_MODE_MPPI, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s,
-                                                h->d_unom[h->cur], nullptr, 0, h->d_wperm, h->d_parts, log, ps.a, ps.b));
+        if (h->cfg.predictor != CTK_PRED_ODE)
+            HIP_TRY(h, ctk_launch_g_rollout_net(h->stream, h->env, h->cfg.predictor, CTK_G_MODE_MPPI, a, h->params, h->cfg.dt, h->cfg.intermediate_steps,
+                                                h->mk, d_s, h->d_unom[h->cur], nullptr, 0, h->d_wperm, h->d_parts, log, ps.a, ps.b));
         else
             HIP_TRY(h, ctk_launch_g_rollout(h->stream, h->env, CTK_G_MODE_MPPI, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s,
                                             h->d_unom[h->cur], nullptr, 0, h->d_parts, log, ps.a, ps.b));
@@ -525,10 +587,23 @@ int mppi_reduce_blocks(ctk_handle* h, const float** parts, int* n_parts) {
 
 // optimizer_mppi.py:192,195-197: predictor.update(s, u_nom[:, :1]) — behind the update on the stream, off the
 // caller's latency path (the step's result is already published when this runs)
+// where the GRU's carried hidden state [2,32] lives: behind the per-lane tables of whichever kernel family the handle runs
+float* gru_hidden(ctk_handle* h) { return h->d_wperm + (h->generic ? ctk_g_net_table_floats(CTK_PRED_GRU) : (size_t)GRU_TABLE_FLOATS); }
+
+int gru_advance(ctk_handle* h, const float* s, const float* u_host) {   // u_host NULL: the optimizer's last output on the device
+    if (h->generic) {
+        float zero_u[CTK_MAX_INPUTS] = {};
+        const RolloutArgs a = make_args(h, s, u_host ? u_host : zero_u, 1, 1);
+        HIP_TRY(h, ctk_launch_g_gru_advance(h->stream, h->env, a, u_host ? nullptr : h->d_u, h->d_wperm));
+    } else {
+        HIP_TRY(h, ctk_launch_gru_advance(h->stream, s, u_host ? nullptr : h->d_u, u_host ? u_host[0] : 0.0f, h->d_wperm));
+    }
+    return CTK_OK;
+}
+
 int mppi_advance_hidden(ctk_handle* h) {
     if (h->cfg.predictor != CTK_PRED_GRU) return CTK_OK;
-    HIP_TRY(h, ctk_launch_gru_advance(h->stream, h->mppi_s, h->d_u, 0.0f, h->d_wperm));
-    return CTK_OK;
+    return gru_advance(h, h->mppi_s, nullptr);
 }
 
 int mppi_update(ctk_handle* h, const float* parts, int n_parts, float* u_out) {
@@ -559,9 +634,9 @@ int mppi_update(ctk_handle* h, const float* parts, int n_parts, float* u_out) {
 int launch_affine(ctk_handle* h, const RolloutArgs& a, const float* d_s, int rng_kind, const float* base, const float* scale, bool log,
                   const AffineBest* bst = nullptr) {
     ProfSlot ps(h);
-    if (h->generic && h->cfg.predictor == CTK_PRED_MLP)
-        HIP_TRY(h, ctk_launch_g_rollout_mlp(h->stream, h->env, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s,
-                                            base, scale, rng_kind, h->d_wperm, nullptr, log, ps.a, ps.b));
+    if (h->generic && h->cfg.predictor != CTK_PRED_ODE)
+        HIP_TRY(h, ctk_launch_g_rollout_net(h->stream, h->env, h->cfg.predictor, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps,
+                                            h->mk, d_s, base, scale, rng_kind, h->d_wperm, nullptr, log, ps.a, ps.b));
     else if (h->generic)
         HIP_TRY(h, ctk_launch_g_rollout(h->stream, h->env, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s, base,
                                         scale, rng_kind, nullptr, log, ps.a, ps.b));
@@ -575,9 +650,9 @@ int launch_descent(ctk_handle* h, const RolloutArgs& a, float lr, float b1, floa
                    const float* bc, int bc_len, int t0, int iters, int rule, const RpgdFusedWarm* fused = nullptr) {
     const ctk_config& c = h->cfg;
     ProfSlot ps(h);
-    if (h->generic && c.predictor == CTK_PRED_MLP)
-        HIP_TRY(h, ctk_launch_g_rpgd_descent_mlp(h->stream, h->env, a, h->params, c.dt, c.intermediate_steps, lr, b1, b2, eps, c.gradmax_clip, Q, m,
-                                                 v, bc, bc_len, t0, iters, h->d_wperm, h->d_scratch, ps.a, ps.b, rule));
+    if (h->generic && c.predictor != CTK_PRED_ODE)
+        HIP_TRY(h, ctk_launch_g_rpgd_descent_net(h->stream, h->env, c.predictor, a, h->params, c.dt, c.intermediate_steps, lr, b1, b2, eps,
+                                                 c.gradmax_clip, Q, m, v, bc, bc_len, t0, iters, h->d_wperm, h->d_scratch, ps.a, ps.b, rule));
     else if (h->generic)
         HIP_TRY(h, ctk_launch_g_rpgd_descent(h->stream, h->env, a, h->params, c.dt, c.intermediate_steps, lr, b1, b2, eps, c.gradmax_clip, Q, m, v,
                                              bc, bc_len, t0, iters, h->d_scratch, ps.a, ps.b, rule));
@@ -861,11 +936,10 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     if (cfg->predictor != CTK_PRED_ODE && cfg->predictor != CTK_PRED_MLP && cfg->predictor != CTK_PRED_GRU)
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: unknown predictor");
     // the template kernels roll the analytic model out; the network predictors have (so far) CartPole-shaped MFMA kernels only
-    const bool generic = cfg->environment != CTK_ENV_CARTPOLE || cfg->generic_kernels != 0;
-    if (generic && cfg->predictor == CTK_PRED_GRU)
-        return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: the GRU predictor is built for the CartPole kernels (environment CartPole, generic_kernels 0)");
-    if (cfg->predictor == CTK_PRED_GRU && (cfg->optimizer == CTK_OPT_RPGD || variant != cfg->optimizer))
-        return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: the GRU predictor is built forward-only (MPPI, CEM, random-action); no reverse mode for the gradient-based optimizers");
+    // template kernels: every environment but CartPole; CartPole on request; and the gradient-based optimizers with the
+    // recurrent predictor (reverse mode through the GRU = NetGru::Bwd of ctk_net.h; CartPole's 4-wave GRU kernels are forward only)
+    const bool grad_family = cfg->optimizer == CTK_OPT_RPGD || variant != cfg->optimizer;
+    const bool generic = cfg->environment != CTK_ENV_CARTPOLE || cfg->generic_kernels != 0 || (cfg->predictor == CTK_PRED_GRU && grad_family);
     if (cfg->optimizer == CTK_OPT_CEM && (cfg->cem_best_k < 1 || cfg->cem_best_k > cfg->num_rollouts || cfg->cem_outer_it < 1))
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: need 1 <= cem_best_k <= num_rollouts and cem_outer_it >= 1");
     if (cfg->optimizer == CTK_OPT_RPGD) {
@@ -912,8 +986,10 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     // LDS budget of the rollout tiles (one wave per block): 64 * stride * 4 B <= 160 KiB
     {
         size_t lds;
-        if (generic) lds = descends ? (cfg->predictor == CTK_PRED_MLP ? ctk_g_rpgd_descent_mlp_lds(h->env, (int)H) : ctk_g_rpgd_descent_lds(h->env, (int)H, nullptr))
-                                    : ctk_g_rollout_lds((int)(cfg->optimizer == CTK_OPT_MPPI ? PC : HC), (int)H, h->C);
+        const int cols = (int)(cfg->optimizer == CTK_OPT_MPPI ? PC : HC);
+        if (generic && cfg->predictor != CTK_PRED_ODE)
+            lds = descends ? ctk_g_rpgd_descent_net_lds(h->env, cfg->predictor, (int)H) : ctk_g_rollout_net_lds(cfg->predictor, cols, (int)H, h->C);
+        else if (generic) lds = descends ? ctk_g_rpgd_descent_lds(h->env, (int)H, nullptr) : ctk_g_rollout_lds(cols, (int)H, h->C);
         else lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_lds((int)P, (int)H, cfg->predictor)
                  : descends ? ctk_rpgd_descent_lds(cfg->predictor, (int)H, nullptr) : ctk_affine_rollout_lds((int)H, cfg->predictor);
         if (lds > 160 * 1024) { h->err = "horizon too long for the LDS sample tiles (160 KiB per CU)"; return bail(CTK_ERR_UNSUPPORTED); }
@@ -943,7 +1019,8 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     TRY_CREATE(dev_alloc(h, &h->d_idx, N));
     TRY_CREATE(dev_alloc(h, &h->d_u, CTK_MAX_INPUTS));
     TRY_CREATE(dev_alloc(h, &h->d_weights, std::max<size_t>(1, weight_count(cfg->predictor, h->S, h->C))));
-    TRY_CREATE(dev_alloc(h, &h->d_wperm, cfg->predictor == CTK_PRED_GRU ? (size_t)GRU_TABLE_FLOATS + GRU_HIDDEN_FLOATS
+    TRY_CREATE(dev_alloc(h, &h->d_wperm, generic ? ctk_g_net_table_floats(cfg->predictor == CTK_PRED_GRU ? CTK_PRED_GRU : CTK_PRED_MLP) + GRU_HIDDEN_FLOATS
+                                         : cfg->predictor == CTK_PRED_GRU ? (size_t)GRU_TABLE_FLOATS + GRU_HIDDEN_FLOATS
                                                                           : (size_t)64 * (MLP_FWD_PER_LANE + MLP_BWD_PER_LANE)));
     HIP_CREATE(hipHostMalloc((void**)&h->h_u, 64, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(h->h_u, 0, 64);
@@ -968,15 +1045,15 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
         HIP_CREATE(hipMemcpyAsync(h->d_bc, bc.data(), bc.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
         HIP_CREATE(hipStreamSynchronize(h->stream));
         TRY_CREATE(dev_alloc(h, &h->d_scratch, !generic ? ctk_rpgd_scratch_floats(cfg->predictor, (int)N, (int)H)
-                                               : cfg->predictor == CTK_PRED_MLP ? ctk_g_rpgd_scratch_floats_mlp((int)N, (int)H)
+                                               : cfg->predictor != CTK_PRED_ODE ? ctk_g_rpgd_scratch_floats_net(cfg->predictor, (int)N, (int)H)
                                                                                 : ctk_g_rpgd_scratch_floats(h->env, (int)N, (int)H)));
     }
     const bool mat = cfg->materialize_trajectories != 0;
-    const bool gnet = generic && cfg->predictor == CTK_PRED_MLP;
-    if (descends) h->dominant = gnet ? ctk_g_rpgd_descent_mlp_name(h->env) : generic ? ctk_g_rpgd_descent_name(h->env) : ctk_rpgd_descent_name(cfg->predictor);
+    const bool gnet = generic && cfg->predictor != CTK_PRED_ODE;
+    if (descends) h->dominant = gnet ? ctk_g_rpgd_descent_net_name(h->env, cfg->predictor) : generic ? ctk_g_rpgd_descent_name(h->env) : ctk_rpgd_descent_name(cfg->predictor);
     else {
         const int mode = cfg->optimizer == CTK_OPT_MPPI ? CTK_G_MODE_MPPI : CTK_G_MODE_AFFINE;
-        h->dominant = gnet ? ctk_g_rollout_mlp_name(h->env, mode, mat) : generic ? ctk_g_rollout_name(h->env, mode, mat)
+        h->dominant = gnet ? ctk_g_rollout_net_name(h->env, cfg->predictor, mode, mat) : generic ? ctk_g_rollout_name(h->env, mode, mat)
                     : cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_name(cfg->predictor, mat, cfg->num_rollouts)
                                                      : ctk_affine_rollout_name(cfg->predictor, mat);
     }
@@ -1086,9 +1163,10 @@ int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n) {
                     std::to_string(weight_count(h->cfg.predictor, h->S, h->C)) + " floats for this predictor and environment (ctk_predictor_weight_count)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipMemcpyAsync(h->d_weights, w, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    if (gru) HIP_TRY(h, hipMemsetAsync(h->d_wperm + GRU_TABLE_FLOATS, 0, GRU_HIDDEN_FLOATS * sizeof(float), h->stream));
-    const std::vector<float> perm = gru ? permute_gru_weights(w) : permute_mlp_weights(w, h->S, h->C);
-    if (gru) {   // |h2| <= 1 (convex mix of tanh values and the previous state, which starts at 0 or at what the caller set)
+    if (gru) HIP_TRY(h, hipMemsetAsync(gru_hidden(h), 0, GRU_HIDDEN_FLOATS * sizeof(float), h->stream));
+    const std::vector<float> perm = !gru ? permute_mlp_weights(w, h->S, h->C)
+                                  : h->generic ? permute_gru_weights_g(w, h->S, h->C) : permute_gru_weights(w);
+    if (gru && !h->generic) {   // |h2| <= 1 (convex mix of tanh values and the previous state, which starts at 0 or at what the caller set)
         const float* Wo = w + GRU_NW_RAW - 4 * 32 - 4; const float* bo = Wo + 4 * 32;
         float bound = 0.0f;
         for (int g = 0; g < 4; ++g) { float r = std::fabs(bo[g]); for (int j = 0; j < 32; ++j) r += std::fabs(Wo[g * 32 + j]); bound = std::max(bound, r); }
@@ -1107,8 +1185,7 @@ int ctk_predictor_update(ctk_handle* h, const float* s, const float* u) {
     if (h->cfg.predictor != CTK_PRED_GRU) return CTK_OK;   // predictor.update is a no-op for stateless predictors
     if (int rc = check_predictor(h)) return rc;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    HIP_TRY(h, ctk_launch_gru_advance(h->stream, s, u ? nullptr : h->d_u, u ? u[0] : 0.0f, h->d_wperm));
-    return CTK_OK;
+    return gru_advance(h, s, u);
 }
 
 int ctk_predictor_get_hidden(ctk_handle* h, float* dst, size_t cap) {
@@ -1116,7 +1193,7 @@ int ctk_predictor_get_hidden(ctk_handle* h, float* dst, size_t cap) {
     if (h->cfg.predictor != CTK_PRED_GRU) return fail(h, CTK_ERR_STATE, "ctk_predictor_get_hidden: predictor has no hidden state");
     if (cap < (size_t)GRU_HIDDEN_FLOATS) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_predictor_get_hidden: need room for 64 floats");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    HIP_TRY(h, hipMemcpyAsync(dst, h->d_wperm + GRU_TABLE_FLOATS, GRU_HIDDEN_FLOATS * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(dst, gru_hidden(h), GRU_HIDDEN_FLOATS * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CTK_OK;
 }
@@ -1128,8 +1205,8 @@ int ctk_predictor_set_hidden(ctk_handle* h, const float* src, size_t n) {
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     h->hidden_scale = 1.0f;
     if (src) for (int i = 0; i < GRU_HIDDEN_FLOATS; ++i) h->hidden_scale = std::max(h->hidden_scale, std::fabs(src[i]));
-    if (src) HIP_TRY(h, hipMemcpyAsync(h->d_wperm + GRU_TABLE_FLOATS, src, GRU_HIDDEN_FLOATS * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    else HIP_TRY(h, hipMemsetAsync(h->d_wperm + GRU_TABLE_FLOATS, 0, GRU_HIDDEN_FLOATS * sizeof(float), h->stream));
+    if (src) HIP_TRY(h, hipMemcpyAsync(gru_hidden(h), src, GRU_HIDDEN_FLOATS * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    else HIP_TRY(h, hipMemsetAsync(gru_hidden(h), 0, GRU_HIDDEN_FLOATS * sizeof(float), h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CTK_OK;
 }
@@ -1381,9 +1458,9 @@ int ctk_rollout(ctk_handle* h, const float* s, const float* u_prev, const float*
     RolloutArgs a = make_args(h, s, u_prev, n, h->H);
     for (int c = 0; c < h->C; ++c) { a.lo[c] = -INFINITY; a.hi[c] = INFINITY; }
     a.traj_out = traj_out ? d_traj : nullptr;
-    hipError_t e = (h->generic && h->cfg.predictor == CTK_PRED_MLP)
-        ? ctk_launch_g_rollout_mlp(h->stream, h->env, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s, d_zero,
-                                   d_one, 0, h->d_wperm, nullptr, traj_out != nullptr)
+    hipError_t e = (h->generic && h->cfg.predictor != CTK_PRED_ODE)
+        ? ctk_launch_g_rollout_net(h->stream, h->env, h->cfg.predictor, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk,
+                                   d_s, d_zero, d_one, 0, h->d_wperm, nullptr, traj_out != nullptr)
         : h->generic
         ? ctk_launch_g_rollout(h->stream, h->env, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s, d_zero, d_one,
                                0, nullptr, traj_out != nullptr)

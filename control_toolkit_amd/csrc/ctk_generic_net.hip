@@ -1,11 +1,12 @@
-// ctk_generic_net.hip — the environment-agnostic template kernels with the MLP predictor ((S+C)-32-32-S tanh network on the
-// fp32 matrix cores, ctk_mlp.h) in place of the analytic model: same structure as ctk_generic.hip (Env<> supplies S, C and the
-// cost terms; the network replaces Env::step), one wave = one 16-trajectory MFMA tile, four tiles per workgroup.
+// ctk_generic_net.hip — the environment-agnostic template kernels with a NETWORK predictor in place of the analytic model:
+// (S+C)-32-32-S tanh MLP or 2 x 32 GRU + dense (policies NetMlp / NetGru of ctk_net.h, fp32 matrix cores both directions).
+// Same structure as ctk_generic.hip (Env<> supplies S, C and the cost terms; the network replaces Env::step), one wave = one
+// 16-trajectory MFMA tile, four tiles per workgroup.
 // State layout of a tile: lane (c, g) holds components g and 4+g of trajectory c — layer 1's B operands as they stand; the
 // cost terms need the whole state, gathered per step with cross-lane reads (every lane group evaluates the same cost).
 #include "ctk_rollout.h"
 #include "ctk_env.h"
-#include "ctk_mlp.h"
+#include "ctk_net.h"
 #include "ctk_adam.h"
 #include "ctk_launch.h"
 
@@ -45,10 +46,11 @@ CTK_DEV float first_operand(float sv0, const float (&u)[C], int g) {   // S < 4 
 // ---------------------------------------------------------------------------------------------------------------
 // rollout + cost (MPPI / affine modes of ctk_generic.hip)
 // ---------------------------------------------------------------------------------------------------------------
-template <int ENV, int MODE, bool LOG>
-__global__ __launch_bounds__(GN_BLOCK) void ctk_g_rollout_mlp(RolloutArgs a, typename Env<ENV>::K k, MppiK m, const float* __restrict__ samples,
+template <int ENV, class NET, int MODE, bool LOG>
+__global__ __launch_bounds__(GN_BLOCK) void ctk_g_rollout_net(RolloutArgs a, typename Env<ENV>::K k, MppiK m, const float* __restrict__ samples,
                                                              const float* __restrict__ base, const float* __restrict__ scale, int rng_kind,
-                                                             const float* __restrict__ wperm, float* __restrict__ parts) {
+                                                             const float* __restrict__ wperm, const float* __restrict__ hidden,
+                                                             int net_lds_off, float* __restrict__ parts) {
     using E = Env<ENV>;
     constexpr int S = E::S, C = E::C;
     extern __shared__ float lds[];
@@ -82,7 +84,10 @@ __global__ __launch_bounds__(GN_BLOCK) void ctk_g_rollout_mlp(RolloutArgs a, typ
     });
     __syncthreads();
 
-    const MlpFwdW w = mlp_load_fwd(wperm);
+    typename NET::Fwd net;
+    net.load(wperm, lds + net_lds_off);
+    if constexpr (NET::LDS_FWD > 0) __syncthreads();
+    net.begin(hidden);
     const float* my = tile + tr * ts;
     float sv0 = g < S ? a.s0[g] : 0.0f, sv1 = 4 + g < S ? a.s0[(4 + g) & (CTK_MAX_STATES - 1)] : 0.0f;
     float up[C];
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(GN_BLOCK) void ctk_g_rollout_mlp(RolloutArgs a, typ
                 for (int i = 0; i < S; ++i) a.traj_out[((size_t)n * (H + 1) + h) * S + i] = s[i];
             }
         }
-        const MlpPair o = mlp_step2(w, first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g));
+        const MlpPair o = net.step(first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g), nullptr);
         sv0 = o.lo; sv1 = o.hi;
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) up[cc] = u[cc];
@@ -159,17 +164,18 @@ __global__ __launch_bounds__(GN_BLOCK) void ctk_g_rollout_mlp(RolloutArgs a, typ
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// RPGD descent with the network predictor: forward with the activations taped to an L2-resident global scratch
-// ([h][lane][20] floats per wave: {sv0, sv1, -, -}, h1[8], h2[8]), reverse sweep on MFMA (mlp_step_vjp2), cost gradients from
-// Env<>, per-plan clip_by_norm, Adam, clip, final cost pass.  64 plans per workgroup, 16 per wave.
+// RPGD descent with a network predictor: forward with what the adjoint needs taped to an L2-resident global scratch
+// ([h][lane][NET::TAPE] floats per wave: the step's inputs and the activations / gates), reverse sweep on MFMA (NET::Bwd::vjp;
+// for the GRU back-propagation through time with the hidden-state adjoints carried), cost gradients from Env<>, per-plan
+// clip_by_norm, Adam, clip, final cost pass.  64 plans per workgroup, 16 per wave.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int GN_TAPE = 20;
-
-template <int ENV>
-__global__ __launch_bounds__(GN_BLOCK) void ctk_g_rpgd_descent_mlp(RolloutArgs a, typename Env<ENV>::K k, AdamK ad, float* __restrict__ Q,
+template <int ENV, class NET>
+__global__ __launch_bounds__(GN_BLOCK) void ctk_g_rpgd_descent_net(RolloutArgs a, typename Env<ENV>::K k, AdamK ad, float* __restrict__ Q,
                                                                   float* __restrict__ m, float* __restrict__ v,
                                                                   const float* __restrict__ bc_table, int bc_len, int t0, int iters,
-                                                                  const float* __restrict__ wperm, float* __restrict__ scratch) {
+                                                                  const float* __restrict__ wperm, const float* __restrict__ wperm_bwd,
+                                                                  const float* __restrict__ hidden, float* __restrict__ scratch) {
+    constexpr int GN_TAPE = NET::TAPE;
     using E = Env<ENV>;
     constexpr int S = E::S, C = E::C;
     extern __shared__ float lds[];
@@ -191,8 +197,11 @@ __global__ __launch_bounds__(GN_BLOCK) void ctk_g_rpgd_descent_mlp(RolloutArgs a
     }
     __syncthreads();
 
-    const MlpFwdW wf = mlp_load_fwd(wperm);
-    const MlpBwdW2 wb = mlp_load_bwd2(wperm);
+    typename NET::Fwd nf;
+    typename NET::Bwd nb;
+    nf.load(wperm, sc_s + GN_TRAJ);
+    nb.load(wperm_bwd, sc_s + GN_TRAJ + NET::LDS_FWD);
+    if constexpr (NET::LDS_FWD + NET::LDS_BWD > 0) __syncthreads();
     float up0[C];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) up0[cc] = a.u_prev_dev ? a.u_prev_dev[cc] : a.u_prev[cc];
@@ -202,18 +211,13 @@ __global__ __launch_bounds__(GN_BLOCK) void ctk_g_rpgd_descent_mlp(RolloutArgs a
     for (int it = 0; it < iters; ++it) {
         // ---- forward, taping the step inputs and activations
         float sv0 = s00, sv1 = s01;
+        nf.begin(hidden);
         for (int h = 0; h < H; ++h) {
             float u[C];
 #pragma unroll
             for (int cc = 0; cc < C; ++cc) u[cc] = q_s[(h * C + cc) * GN_LD + col];
-            MlpAct act;
-            const MlpPair o = mlp_step2(wf, first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g), &act);
-            float4* tp = reinterpret_cast<float4*>(tape + ((size_t)h * 64 + lane) * GN_TAPE);
-            tp[0] = make_float4(sv0, sv1, 0.f, 0.f);
-            tp[1] = make_float4(act.h1[0][0], act.h1[0][1], act.h1[0][2], act.h1[0][3]);
-            tp[2] = make_float4(act.h1[1][0], act.h1[1][1], act.h1[1][2], act.h1[1][3]);
-            tp[3] = make_float4(act.h2[0][0], act.h2[0][1], act.h2[0][2], act.h2[0][3]);
-            tp[4] = make_float4(act.h2[1][0], act.h2[1][1], act.h2[1][2], act.h2[1][3]);
+            const MlpPair o = nf.step(first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g),
+                                      reinterpret_cast<float4*>(tape + ((size_t)h * 64 + lane) * GN_TAPE));   // tape[0] = the step's (x0, x1)
             sv0 = o.lo; sv1 = o.hi;
         }
         // ---- reverse sweep
@@ -225,18 +229,12 @@ __global__ __launch_bounds__(GN_BLOCK) void ctk_g_rpgd_descent_mlp(RolloutArgs a
         float gp_next[C];
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) gp_next[cc] = 0.0f;
-        const float4* tq = reinterpret_cast<const float4*>(tape + ((size_t)(H - 1) * 64 + lane) * GN_TAPE);
-        float4 r0 = tq[0], r1 = tq[1], r2 = tq[2], r3 = tq[3], r4 = tq[4];
+        nb.begin();
         for (int h = H - 1; h >= 0; --h) {
-            MlpAct act;
-            act.h1[0] = f32x4{r1.x, r1.y, r1.z, r1.w}; act.h1[1] = f32x4{r2.x, r2.y, r2.z, r2.w};
-            act.h2[0] = f32x4{r3.x, r3.y, r3.z, r3.w}; act.h2[1] = f32x4{r4.x, r4.y, r4.z, r4.w};
-            const float p0 = r0.x, p1 = r0.y;                 // state components g, 4+g entering step h
-            if (h > 0) {                                       // prefetch the previous step's tape under this step's MFMAs
-                const float4* tn = reinterpret_cast<const float4*>(tape + ((size_t)(h - 1) * 64 + lane) * GN_TAPE);
-                r0 = tn[0]; r1 = tn[1]; r2 = tn[2]; r3 = tn[3]; r4 = tn[4];
-            }
-            const MlpPair d = mlp_step_vjp2(wb, act, lam0, lam1);
+            const float4* tq = reinterpret_cast<const float4*>(tape + ((size_t)h * 64 + lane) * GN_TAPE);
+            const float4 in01 = tq[0];
+            const float p0 = in01.x, p1 = in01.y;              // network inputs g, 4+g of step h: the state components where < S
+            const MlpPair d = nb.vjp(tq, lam0, lam1);
             float s[S], gs[S], u[C], upv[C], gu[C], gp[C];
             gather_state<S>(p0, p1, c, s);
             E::stage_grad_state(k, s, gs);
@@ -276,6 +274,7 @@ __global__ __launch_bounds__(GN_BLOCK) void ctk_g_rpgd_descent_mlp(RolloutArgs a
         __syncthreads();
     }
     {   // get_action's forward pass (optimizer_rpgd.py:342): costs of the refined plans
+        nf.begin(hidden);
         float sv0 = s00, sv1 = s01, csum = 0.0f, up[C];
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) up[cc] = up0[cc];
@@ -285,7 +284,7 @@ __global__ __launch_bounds__(GN_BLOCK) void ctk_g_rpgd_descent_mlp(RolloutArgs a
             for (int cc = 0; cc < C; ++cc) u[cc] = q_s[(h * C + cc) * GN_LD + col];
             gather_state<S>(sv0, sv1, c, s);
             csum += E::stage_cost(k, s, u, up);
-            const MlpPair o = mlp_step2(wf, first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g));
+            const MlpPair o = nf.step(first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g), nullptr);
             sv0 = o.lo; sv1 = o.hi;
 #pragma unroll
             for (int cc = 0; cc < C; ++cc) up[cc] = u[cc];
@@ -303,60 +302,126 @@ __global__ __launch_bounds__(GN_BLOCK) void ctk_g_rpgd_descent_mlp(RolloutArgs a
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-static uint32_t magic_of(int d) { return d >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d) : 0u; }
-
-const char* ctk_g_rollout_mlp_name(int env, int mode, bool log) {
-    static const char* names[2][2][2] = {
-        {{"ctk_g_rollout_mlp<0, 0, false>", "ctk_g_rollout_mlp<0, 0, true>"}, {"ctk_g_rollout_mlp<0, 1, false>", "ctk_g_rollout_mlp<0, 1, true>"}},
-        {{"ctk_g_rollout_mlp<1, 0, false>", "ctk_g_rollout_mlp<1, 0, true>"}, {"ctk_g_rollout_mlp<1, 1, false>", "ctk_g_rollout_mlp<1, 1, true>"}}};
-    return names[env == CTK_ENV_CARTPOLE ? 0 : 1][mode == CTK_G_MODE_MPPI ? 0 : 1][log ? 1 : 0];
+// predictor.update(s, Q0) for the GRU (optimizer_mppi.py:195-197): one wave advances the carried hidden state by the measured
+// state and the applied input (all 16 MFMA columns carry the same values; column 0 writes back).  hidden = [h1[32] | h2[32]].
+template <int ENV>
+__global__ __launch_bounds__(64) void ctk_g_gru_advance(RolloutArgs a, const float* __restrict__ u_dev, const float* __restrict__ wperm,
+                                                       float* __restrict__ hidden) {
+    using E = Env<ENV>;
+    constexpr int S = E::S, C = E::C;
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    NetGru::Fwd net;
+    net.load(wperm, lds);
+    __syncthreads();
+    net.begin(hidden);
+    float u[C];
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) u[cc] = u_dev ? u_dev[cc] : a.u_prev[cc];
+    const float sv0 = g < S ? a.s0[g] : 0.0f, sv1 = 4 + g < S ? a.s0[(4 + g) & (CTK_MAX_STATES - 1)] : 0.0f;
+    (void)net.step(first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g), nullptr);
+    __syncthreads();                       // every lane has read `hidden` (begin) before column 0 overwrites it
+    if (c == 0) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { hidden[16 * m + 4 * g + r] = net.h1[m][r]; hidden[32 + 16 * m + 4 * g + r] = net.h2[m][r]; }
+    }
 }
 
-hipError_t ctk_launch_g_rollout_mlp(hipStream_t st, int env, int mode, const RolloutArgs& a_in, const float* params, float dt, int isteps,
+// ---------------------------------------------------------------------------------------------------------------
+static uint32_t magic_of(int d) { return d >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d) : 0u; }
+
+size_t ctk_g_net_table_floats(int net) { return net == NET_GRU ? (size_t)(GRUG_FWD + GRUG_BWD) * 64 : (size_t)64 * (MLP_FWD_PER_LANE + MLP_BWD_PER_LANE); }
+size_t ctk_g_net_hidden_floats(int net) { return net == NET_GRU ? NetGru::HIDDEN : 0; }
+static const float* bwd_table(int net, const float* wperm) { return net == NET_GRU ? wperm + (size_t)GRUG_FWD * 64 : wperm; }
+static size_t net_lds_fwd(int net) { return net == NET_GRU ? NetGru::LDS_FWD : 0; }
+static size_t net_lds_bwd(int net) { return net == NET_GRU ? NetGru::LDS_BWD : 0; }
+
+const char* ctk_g_rollout_net_name(int env, int net, int mode, bool log) {
+    static char buf[2][2][2][2][64];
+    char* b = buf[env == CTK_ENV_CARTPOLE ? 0 : 1][net == NET_GRU ? 1 : 0][mode == CTK_G_MODE_MPPI ? 0 : 1][log ? 1 : 0];
+    snprintf(b, 64, "ctk_g_rollout_net<%d, %s, %d, %s>", env, net == NET_GRU ? "NetGru" : "NetMlp", mode, log ? "true" : "false");
+    return b;
+}
+
+size_t ctk_g_rollout_net_lds(int net, int cols, int H, int C) { return ctk_g_rollout_lds(cols, H, C) + net_lds_fwd(net) * sizeof(float); }
+
+template <int EV, class NETT>
+static void launch_rollout_net(hipStream_t st, int mode, const RolloutArgs& a_in, const float* params, float dt, int isteps, const MppiK& mk,
+                               const float* samples, const float* base, const float* scale, int rng_kind, const float* wperm,
+                               const float* hidden, float* parts, bool log, hipEvent_t e0, hipEvent_t e1) {
+    using E = Env<EV>;
+    RolloutArgs a = a_in;
+    const int cols = (mode == CTK_G_MODE_MPPI ? a_in.P : a_in.H) * E::C;
+    a.P = cols; a.p_magic = magic_of(cols); a.C = E::C;
+    const typename E::K k = E::derive(params, dt, isteps);
+    const dim3 grid(ctk_g_rollout_blocks(a.N)), block(GN_BLOCK);
+    const size_t lds0 = ctk_g_rollout_lds(cols, a.H, E::C), lds = lds0 + NETT::LDS_FWD * sizeof(float);
+    const int off = (int)(lds0 / sizeof(float));
+    if (mode == CTK_G_MODE_MPPI) {
+        if (log) CTK_LAUNCH((ctk_g_rollout_net<EV, NETT, CTK_G_MODE_MPPI, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, off, parts);
+        else CTK_LAUNCH((ctk_g_rollout_net<EV, NETT, CTK_G_MODE_MPPI, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, off, parts);
+    } else {
+        if (log) CTK_LAUNCH((ctk_g_rollout_net<EV, NETT, CTK_G_MODE_AFFINE, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, off, parts);
+        else CTK_LAUNCH((ctk_g_rollout_net<EV, NETT, CTK_G_MODE_AFFINE, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, off, parts);
+    }
+}
+
+hipError_t ctk_launch_g_rollout_net(hipStream_t st, int env, int net, int mode, const RolloutArgs& a, const float* params, float dt, int isteps,
                                     const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
                                     const float* wperm, float* parts, bool log, hipEvent_t e0, hipEvent_t e1) {
+    const float* hidden = wperm + ctk_g_net_table_floats(net);
     CTK_FOR_ENV(env, EV, {
-        using E = Env<EV>;
-        RolloutArgs a = a_in;
-        const int cols = (mode == CTK_G_MODE_MPPI ? a_in.P : a_in.H) * E::C;
-        a.P = cols; a.p_magic = magic_of(cols); a.C = E::C;
-        const typename E::K k = E::derive(params, dt, isteps);
-        const dim3 grid(ctk_g_rollout_blocks(a.N)), block(GN_BLOCK);
-        const size_t lds = ctk_g_rollout_lds(cols, a.H, E::C);
-        if (mode == CTK_G_MODE_MPPI) {
-            if (log) CTK_LAUNCH((ctk_g_rollout_mlp<EV, CTK_G_MODE_MPPI, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, parts);
-            else CTK_LAUNCH((ctk_g_rollout_mlp<EV, CTK_G_MODE_MPPI, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, parts);
-        } else {
-            if (log) CTK_LAUNCH((ctk_g_rollout_mlp<EV, CTK_G_MODE_AFFINE, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, parts);
-            else CTK_LAUNCH((ctk_g_rollout_mlp<EV, CTK_G_MODE_AFFINE, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, parts);
-        }
+        if (net == NET_GRU) launch_rollout_net<EV, NetGru>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1);
+        else launch_rollout_net<EV, NetMlp>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1);
     });
     return hipGetLastError();
 }
 
-size_t ctk_g_rpgd_descent_mlp_lds(int env, int H) {
+size_t ctk_g_rpgd_descent_net_lds(int env, int net, int H) {
     int C = 0;
     CTK_FOR_ENV(env, EV, { C = Env<EV>::C; });
-    return (size_t)(2 * H * C * GN_LD + GN_TRAJ) * sizeof(float);
+    return (size_t)(2 * H * C * GN_LD + GN_TRAJ + net_lds_fwd(net) + net_lds_bwd(net)) * sizeof(float);
 }
 
-size_t ctk_g_rpgd_scratch_floats_mlp(int N, int H) { return (size_t)((N + GN_TRAJ - 1) / GN_TRAJ) * 4 * H * 64 * GN_TAPE; }
+size_t ctk_g_rpgd_scratch_floats_net(int net, int N, int H) {
+    return (size_t)((N + GN_TRAJ - 1) / GN_TRAJ) * 4 * H * 64 * (net == NET_GRU ? NetGru::TAPE : NetMlp::TAPE);
+}
 
-const char* ctk_g_rpgd_descent_mlp_name(int env) { return env == CTK_ENV_CARTPOLE ? "ctk_g_rpgd_descent_mlp<0>" : "ctk_g_rpgd_descent_mlp<1>"; }
+const char* ctk_g_rpgd_descent_net_name(int env, int net) {
+    static char buf[2][2][64];
+    char* b = buf[env == CTK_ENV_CARTPOLE ? 0 : 1][net == NET_GRU ? 1 : 0];
+    snprintf(b, 64, "ctk_g_rpgd_descent_net<%d, %s>", env, net == NET_GRU ? "NetGru" : "NetMlp");
+    return b;
+}
 
-hipError_t ctk_launch_g_rpgd_descent_mlp(hipStream_t st, int env, const RolloutArgs& a_in, const float* params, float dt, int isteps, float lr,
-                                         float b1, float b2, float eps, float clip, float* Q, float* m, float* v, const float* bc_table,
-                                         int bc_len, int t0, int iters, const float* wperm, float* scratch, hipEvent_t e0, hipEvent_t e1,
-                                         int rule) {
+hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const RolloutArgs& a_in, const float* params, float dt, int isteps,
+                                         float lr, float b1, float b2, float eps, float clip, float* Q, float* m, float* v,
+                                         const float* bc_table, int bc_len, int t0, int iters, const float* wperm, float* scratch,
+                                         hipEvent_t e0, hipEvent_t e1, int rule) {
     AdamK ad{lr, b1, b2, (float)(1.0 - (double)b1), (float)(1.0 - (double)b2), eps, clip, rule};
+    const float* hidden = wperm + ctk_g_net_table_floats(net);
+    const float* wb = bwd_table(net, wperm);
     CTK_FOR_ENV(env, EV, {
         using E = Env<EV>;
         RolloutArgs a = a_in;
         a.C = E::C; a.p_magic = magic_of(a.H * E::C);
         const typename E::K k = E::derive(params, dt, isteps);
         const dim3 grid((a.N + GN_TRAJ - 1) / GN_TRAJ), block(GN_BLOCK);
-        CTK_LAUNCH((ctk_g_rpgd_descent_mlp<EV>), grid, block, ctk_g_rpgd_descent_mlp_lds(env, a.H), st, e0, e1, a, k, ad, Q, m, v, bc_table,
-                   bc_len, t0, iters, wperm, scratch);
+        const size_t lds = ctk_g_rpgd_descent_net_lds(env, net, a.H);
+        if (net == NET_GRU)
+            CTK_LAUNCH((ctk_g_rpgd_descent_net<EV, NetGru>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wb, hidden, scratch);
+        else
+            CTK_LAUNCH((ctk_g_rpgd_descent_net<EV, NetMlp>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wb, hidden, scratch);
+    });
+    return hipGetLastError();
+}
+
+hipError_t ctk_launch_g_gru_advance(hipStream_t st, int env, const RolloutArgs& a, const float* u_dev, float* wperm) {
+    float* hidden = wperm + ctk_g_net_table_floats(NET_GRU);
+    CTK_FOR_ENV(env, EV, {
+        hipLaunchKernelGGL((ctk_g_gru_advance<EV>), dim3(1), dim3(64), NetGru::LDS_FWD * sizeof(float), st, a, u_dev, wperm, hidden);
     });
     return hipGetLastError();
 }

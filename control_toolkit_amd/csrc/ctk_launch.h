@@ -150,15 +150,21 @@ hipError_t ctk_launch_g_rpgd_descent(hipStream_t st, int env, const RolloutArgs&
                                      int bc_len, int t0, int iters, float* scratch, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
                                      int rule = 0);
 
-// ---- ctk_generic_net.hip : the template kernels with the MLP predictor ((S+C)-32-32-S, fp32 MFMA) ---------------
-const char* ctk_g_rollout_mlp_name(int env, int mode, bool log);
-hipError_t ctk_launch_g_rollout_mlp(hipStream_t st, int env, int mode, const RolloutArgs& a, const float* params, float dt, int isteps,
+// ---- ctk_generic_net.hip : the template kernels with a network predictor (net = CTK_PRED_MLP | CTK_PRED_GRU; ctk_net.h) -----
+// wperm: the policy's per-lane operand tables (forward | reverse), followed by the GRU's carried hidden state [64]
+size_t ctk_g_net_table_floats(int net);
+size_t ctk_g_net_hidden_floats(int net);
+const char* ctk_g_rollout_net_name(int env, int net, int mode, bool log);
+size_t ctk_g_rollout_net_lds(int net, int cols, int H, int C);
+hipError_t ctk_launch_g_rollout_net(hipStream_t st, int env, int net, int mode, const RolloutArgs& a, const float* params, float dt, int isteps,
                                     const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
                                     const float* wperm, float* parts, bool log, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
-size_t ctk_g_rpgd_descent_mlp_lds(int env, int H);
-size_t ctk_g_rpgd_scratch_floats_mlp(int N, int H);
-const char* ctk_g_rpgd_descent_mlp_name(int env);
-hipError_t ctk_launch_g_rpgd_descent_mlp(hipStream_t st, int env, const RolloutArgs& a, const float* params, float dt, int isteps, float lr,
-                                         float b1, float b2, float eps, float clip, float* Q, float* m, float* v, const float* bc_table,
-                                         int bc_len, int t0, int iters, const float* wperm, float* scratch, hipEvent_t e0 = nullptr,
-                                         hipEvent_t e1 = nullptr, int rule = 0);
+size_t ctk_g_rpgd_descent_net_lds(int env, int net, int H);
+size_t ctk_g_rpgd_scratch_floats_net(int net, int N, int H);
+const char* ctk_g_rpgd_descent_net_name(int env, int net);
+hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const RolloutArgs& a, const float* params, float dt, int isteps,
+                                         float lr, float b1, float b2, float eps, float clip, float* Q, float* m, float* v,
+                                         const float* bc_table, int bc_len, int t0, int iters, const float* wperm, float* scratch,
+                                         hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int rule = 0);
+// predictor.update(s, Q0) for the GRU under the template kernels: a.s0 = measured state, a.u_prev = applied input (u_dev overrides)
+hipError_t ctk_launch_g_gru_advance(hipStream_t st, int env, const RolloutArgs& a, const float* u_dev, float* wperm);

@@ -78,13 +78,15 @@ typedef enum ctk_environment {
 /* reference: predictor_specification passed to PredictorWrapper.configure
  * (Controllers/controller_mpc.py:67-73): "ODE" or a network name                              */
 typedef enum ctk_predictor {
-    CTK_PRED_ODE = 0, /* analytic cart-pole, explicit Euler, VALU, one thread per trajectory   */
-    CTK_PRED_MLP = 1, /* 5-32-32-4 tanh MLP, fp32 MFMA (v_mfma_f32_16x16x4_f32), 16 traj./wave */
-    CTK_PRED_GRU = 2  /* 2x32 GRU + dense 32->4 (network-name convention 'GRU-..-32H1-32H2-..',
-                         Control_Toolkit_ASF_Template/config_controllers.yml:8), fp32 MFMA, weights in LDS;
-                         carries a hidden state across MPC steps (ctk_predictor_update).  Forward path only:
-                         the sampling optimizers (MPPI, CEM, random-action) and ctk_rollout; the
-                         gradient-based optimizers reject it with CTK_ERR_UNSUPPORTED.                   */
+    CTK_PRED_ODE = 0, /* the environment's analytic model (explicit Euler), VALU, one thread per trajectory  */
+    CTK_PRED_MLP = 1, /* (S+C)-32-32-S tanh MLP (CartPole 5-32-32-4), fp32 MFMA (v_mfma_f32_16x16x4_f32), 16
+                         trajectories per wave, forward and reverse mode                                       */
+    CTK_PRED_GRU = 2  /* 2x32 GRU + dense 32->S (network-name convention 'GRU-..-32H1-32H2-..',
+                         Control_Toolkit_ASF_Template/config_controllers.yml:8), fp32 MFMA; carries a hidden state
+                         across MPC steps (ctk_predictor_update).  Forward AND reverse mode (back-propagation through
+                         time over the horizon): every optimizer takes it.  CartPole's sampling optimizers run the
+                         4-wave forward kernels of ctk_gru.h; the gradient-based optimizers and the other
+                         environments run csrc/ctk_net.h:NetGru under the template kernels.                     */
 } ctk_predictor;
 
 /* Environment / cost parameters.  Replaces template_controller.update_attributes

@@ -254,6 +254,33 @@ def gru_cell(x, h, Wi, Wh, bi, bh):
     return ((f32(1.0) - z) * n + z * h).astype(np.float32)
 
 
+def gru_cell_fwd(x, h, Wi, Wh, bi, bh):
+    """gru_cell + what its adjoint needs"""
+    gi = (x @ Wi.T + bi).astype(np.float32)
+    gh = (h @ Wh.T + bh).astype(np.float32)
+    r = _sigmoid(gi[:, :32] + gh[:, :32])
+    z = _sigmoid(gi[:, 32:64] + gh[:, 32:64])
+    ghn = gh[:, 64:]
+    n = np.tanh(gi[:, 64:] + r * ghn).astype(np.float32)
+    return ((f32(1.0) - z) * n + z * h).astype(np.float32), (x, h, r, z, n, ghn)
+
+
+def gru_cell_bwd(dh_new, cache, Wi, Wh):
+    """vector-Jacobian product of one GRU cell: adjoint of h' -> (adjoint of x, adjoint of h)"""
+    x, h, r, z, n, ghn = cache
+    dn = dh_new * (f32(1.0) - z)
+    dz = dh_new * (h - n)
+    dh = dh_new * z
+    dan = dn * (f32(1.0) - n * n)            # pre-activation of n: gi_n + r * gh_n
+    dr = dan * ghn
+    dghn = dan * r
+    daz = dz * z * (f32(1.0) - z)
+    dar = dr * r * (f32(1.0) - r)
+    dgi = np.concatenate([dar, daz, dan], 1).astype(np.float32)
+    dgh = np.concatenate([dar, daz, dghn], 1).astype(np.float32)
+    return (dgi @ Wi).astype(np.float32), (dh + dgh @ Wh).astype(np.float32)
+
+
 @dataclass
 class Predictor:
     """kind = "ODE" (analytic cart-pole, explicit Euler), "MLP" (direct next-state net) or "GRU"
@@ -805,6 +832,8 @@ def rollout_cost_and_grad(predictor: Predictor, cost: Cost, s_t, Q, u_prev):
     """Forward rollout + hand-written reverse-mode of J.sum() w.r.t. Q (what autograd does at
     optimizer_rpgd.py:310-314 / :329-333).  Returns (J[N], traj[N,H+1,S], dJ/dQ[N,H,C])."""
     N, H, C = Q.shape
+    if predictor.kind == "GRU":
+        return _rollout_cost_and_grad_gru(predictor, cost, s_t, Q, u_prev)
     traj = predictor.predict_core(s_t, Q)
     J = cost.get_trajectory_cost(traj, Q, u_prev)
     inv = f32(1.0 / (H + 1))   # mean over H+1, Cost_Functions/__init__.py:92
@@ -815,6 +844,40 @@ def rollout_cost_and_grad(predictor: Predictor, cost: Cost, s_t, Q, u_prev):
         ls, gq = predictor.step_vjp(traj[:, h], Q[:, h, :], lam)
         g[:, h, :] = gu[:, h, :] * inv + gq
         lam = cost.state_grad(traj[:, h], terminal=False) * inv + ls
+    return J, traj, g.astype(np.float32)
+
+
+def _rollout_cost_and_grad_gru(predictor: Predictor, cost: Cost, s_t, Q, u_prev):
+    """the same for the recurrent predictor: the hidden states of both GRU layers are part of the differentiated path
+    (back-propagation through time over the horizon, as autograd does for the reference at optimizer_rpgd.py:329-333);
+    every rollout starts from the carried hidden state, which does not depend on Q"""
+    N, H, C = Q.shape
+    S = predictor.S
+    layers, Wo, bo = gru_unpack(predictor.weights, S + C, S)
+    h1 = np.tile(predictor.hidden[0:1], (N, 1)); h2 = np.tile(predictor.hidden[1:2], (N, 1))
+    traj = np.empty((N, H + 1, S), np.float32)
+    traj[:, 0] = s_t
+    caches = []
+    cur = np.asarray(s_t, np.float32)
+    for h in range(H):
+        xin = np.concatenate([cur, Q[:, h, :]], axis=1).astype(np.float32)
+        h1, c1 = gru_cell_fwd(xin, h1, *layers[0])
+        h2, c2 = gru_cell_fwd(h1, h2, *layers[1])
+        cur = (h2 @ Wo.T + bo).astype(np.float32)
+        traj[:, h + 1] = cur
+        caches.append((c1, c2))
+    J = cost.get_trajectory_cost(traj, Q, u_prev)
+    inv = f32(1.0 / (H + 1))
+    gu = input_cost_grad(cost, Q, u_prev)
+    g = np.zeros((N, H, C), np.float32)
+    lam = cost.state_grad(traj[:, H], terminal=True) * inv
+    dh1 = np.zeros((N, GRU_H), np.float32); dh2 = np.zeros((N, GRU_H), np.float32)
+    for h in range(H - 1, -1, -1):
+        c1, c2 = caches[h]
+        dx2, dh2 = gru_cell_bwd((lam @ Wo + dh2).astype(np.float32), c2, layers[1][0], layers[1][1])
+        dx1, dh1 = gru_cell_bwd((dx2 + dh1).astype(np.float32), c1, layers[0][0], layers[0][1])
+        g[:, h, :] = gu[:, h, :] * inv + dx1[:, S:]
+        lam = cost.state_grad(traj[:, h], terminal=False) * inv + dx1[:, :S]
     return J, traj, g.astype(np.float32)
 
 

@@ -117,10 +117,17 @@ def test_cem_and_random_gru_match_oracle_and_leave_hidden_alone():
     e.close()
 
 
-def test_gru_rejected_by_gradient_optimizers_and_device_rng_runs():
+def test_gru_accepted_by_every_optimizer_and_device_rng_runs():
+    # the gradient-based optimizers take the recurrent predictor too (reverse mode: ctk_net.h:NetGru::Bwd; parity: test_gpu_gru_grad.py)
     for opt in ("rpgd", "gradient", "cem_naive_grad", "cem_grad_bharadhwaj"):
-        with pytest.raises(NotImplementedError):
-            CtkEngine(opt, "GRU", num_rollouts=64, mpc_horizon=10, dt=0.02)
+        e = CtkEngine(opt, "GRU", num_rollouts=64, mpc_horizon=10, dt=0.02, cem_best_k=8)
+        assert "NetGru" in e.dominant_kernel()
+        e.set_predictor_weights(O.gru_default_weights(0))
+        if opt in ("rpgd", "gradient"):
+            e.reset()
+        u = e.step(np.array([0.0, 0.0, 0.3, 0.0], np.float32))
+        assert np.isfinite(u).all() and abs(u[0]) <= 1.0
+        e.close()
     # device sampler path (no host samples): deterministic for a seed, finite, inside the limits
     outs = []
     for rep in range(2):

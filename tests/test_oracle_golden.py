@@ -254,3 +254,76 @@ def test_rpgd_two_inputs_matches_reference(case):
         assert o.opt.step_count == int(d[f"adam_step_{t}"])
         np.testing.assert_allclose(u, d[f"u_{t}"], **tol)
         o.Q = d[f"Q_{t}"].copy(); o.opt.m = d[f"m_{t}"].copy(); o.opt.v = d[f"v_{t}"].copy(); o.u = d[f"u_{t}"].copy()
+
+
+# ---- the oracle's hand-written reverse modes against torch autograd in fp64 (build container and GPU box: torch-CPU) ------------
+@pytest.mark.parametrize("kind,envname", [("GRU", "CartPole"), ("GRU", "Quad2D"), ("MLP", "Quad2D"), ("ODE", "Quad2D")])
+def test_oracle_adjoints_match_torch_autograd_fp64(kind, envname):
+    """d(sum_n J_n)/dQ from rollout_cost_and_grad (what the HIP reverse sweeps are tested against) == autograd through a
+    float64 torch restatement of the same rollout and cost (what the reference does at optimizer_rpgd.py:329-333)."""
+    import torch
+    env = O.ENVIRONMENTS[envname](terminal_weight=0.3)
+    S, C = env.S, env.C
+    weights = None if kind == "ODE" else (O.gru_default_weights(4, S + C, S) if kind == "GRU" else O.mlp_default_weights(4, S + C, S))
+    pred = O.Predictor(kind, env=env, weights=weights)
+    cost = O.Cost(env)
+    rng = np.random.default_rng(0)
+    N, H = 6, 9
+    if kind == "GRU":
+        pred.hidden = (0.3 * rng.standard_normal((2, 32))).astype(np.float32)
+    Q = rng.uniform(-1, 1, (N, H, C)).astype(np.float32)
+    s0 = (rng.standard_normal(S) * 0.3).astype(np.float32)
+    up = rng.uniform(-0.5, 0.5, C).astype(np.float32)
+    J, traj, g = O.rollout_cost_and_grad(pred, cost, np.tile(s0, (N, 1)), Q, up)
+
+    T = lambda a: torch.tensor(np.asarray(a, np.float64))
+    Qt = T(Q).requires_grad_(True)
+    k = {kk: float(v) for kk, v in O.derived_constants(env, 0.02, 1).items()}
+
+    def step(s, u, hid):
+        if kind == "MLP":
+            W1, b1, W2, b2, W3, b3 = (T(a) for a in O.mlp_unpack(weights, S + C, S))
+            x = torch.cat([s, u], 1)
+            return torch.tanh(torch.tanh(x @ W1.T + b1) @ W2.T + b2) @ W3.T + b3, hid
+        if kind == "GRU":
+            layers, Wo, bo = O.gru_unpack(weights, S + C, S)
+            x = torch.cat([s, u], 1)
+            new = []
+            for (Wi, Wh, bi, bh), hprev in zip(layers, hid):
+                gi, gh = x @ T(Wi).T + T(bi), hprev @ T(Wh).T + T(bh)
+                r, z = torch.sigmoid(gi[:, :32] + gh[:, :32]), torch.sigmoid(gi[:, 32:64] + gh[:, 32:64])
+                n = torch.tanh(gi[:, 64:] + r * gh[:, 64:])
+                x = (1 - z) * n + z * hprev
+                new.append(x)
+            return x @ T(Wo).T + T(bo), new
+        x_, vx, z_, vz, th, om = s.unbind(1)                              # Quad2D ODE
+        aF, aM = k["g"] + k["kF"] * (u[:, 0] + u[:, 1]), k["kM"] * (u[:, 0] - u[:, 1])
+        ax, az, al = -aF * torch.sin(th) - k["c_v"] * vx, aF * torch.cos(th) - k["g"] - k["c_v"] * vz, aM - k["c_w"] * om
+        dt = k["dt"]
+        return torch.stack([x_ + dt * vx, vx + dt * ax, z_ + dt * vz, vz + dt * az, th + dt * om, om + dt * al], 1), hid
+
+    def stage(s, u, upv):
+        e = env
+        if envname == "Quad2D":
+            pos = k["pos_c"] * ((s[:, 0] - e.target_x) ** 2 + (s[:, 2] - e.target_z) ** 2) + e.ang_weight * (1 - torch.cos(s[:, 4]))
+            return (pos + e.vel_weight * (s[:, 1] ** 2 + s[:, 3] ** 2) + e.angvel_weight * s[:, 5] ** 2
+                    + k["ccR"] * (u ** 2).sum(1) + e.ccrc_weight * ((u - upv) ** 2).sum(1)), pos
+        dd = e.dd_weight * ((s[:, 0] - e.target_position) * k["inv_xs"]) ** 2
+        ep = k["ep_c"] * (1 - torch.cos(s[:, 2])) ** 2
+        return dd + ep + e.ekp_weight * s[:, 3] ** 2 + k["ccR"] * u[:, 0] ** 2 + e.ccrc_weight * (u[:, 0] - upv[:, 0]) ** 2, dd + ep
+
+    s = T(np.tile(s0, (N, 1)))
+    hid = [T(np.tile(pred.hidden[i:i + 1], (N, 1))) for i in range(2)] if kind == "GRU" else None
+    upv = T(np.tile(up, (N, 1)))
+    tot = 0.0
+    for h in range(H):
+        c, _ = stage(s, Qt[:, h, :], upv)
+        tot = tot + c
+        s, hid = step(s, Qt[:, h, :], hid)
+        upv = Qt[:, h, :]
+    _, term = stage(s, Qt[:, 0, :] * 0, upv * 0)
+    Jt = (tot + env.terminal_weight * term) / (H + 1)
+    Jt.sum().backward()
+    np.testing.assert_allclose(J, Jt.detach().numpy(), rtol=2e-5)
+    scale = np.abs(Qt.grad.numpy()).max()
+    np.testing.assert_allclose(g, Qt.grad.numpy(), rtol=2e-4, atol=2e-6 * max(1.0, scale))
