@@ -621,6 +621,7 @@ int mppi_update(ctk_handle* h, const float* parts, int n_parts, float* u_out) {
         HIP_TRY(h, ctk_launch_g_mppi_update(h->stream, rec, h->P, h->C, h->H, h->d_interp, h->d_unom[h->cur], h->d_unom[nxt], a, h->d_u,
                                             h->h_u_dev, h->seq));
         h->cur = nxt;
+        if (int rc = mppi_advance_hidden(h)) return rc;   // optimizer_mppi.py:192 (RNN hidden state), behind the update on the stream
         return finish_step(h, u_out);
     }
     HIP_TRY(h, ctk_launch_mppi_update(h->stream, parts, n_parts, h->P, h->mk.neg_inv_lbd, h->H, h->d_interp, h->d_unom[h->cur],
