@@ -413,6 +413,8 @@ def main():
             return (lambda s, i: eng.step(s, ptrs[i & 15] if eng.samples_needed() else None)) if samples == "buffer" else (lambda s, i: eng.step(s, None))
         return (lambda s, i: eng.step(s, ptrs[i & 15])) if samples == "buffer" else (lambda s, i: eng.step(s, None))
 
+    bracket = {}
+
     def run_region(step_fn, steps, warmup, timed_region):
         """W warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
         s = s0.copy()
@@ -428,10 +430,12 @@ def main():
         for i in range(steps):
             plant_step(s, np.asarray(step_fn(s, i)).reshape(-1)[0])   # controller.step, then the plant: closed loop
             tb = time.perf_counter(); per_step[i] = tb - ta; ta = tb
+        t_sync = time.perf_counter()
         torch.cuda.synchronize()
         if use_pg:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        bracket["close_ms"] = (time.perf_counter() - t_sync) * 1e3     # the closing synchronize (+ barrier): inside the bracket by contract
         if use_pg:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -441,6 +445,7 @@ def main():
     boundary = "sharded" if sharded is not None else args.boundary
     samples = args.samples
     elapsed, per_step = run_region(make_step(boundary, samples), args.steps, args.warmup, True)
+    bracket_close_ms = bracket.get("close_ms")
 
     # ---- the other boundary x sample-mode combinations, same protocol, outside the timed region ------------------
     modes = {}
@@ -503,6 +508,10 @@ def main():
             "step_ms_median": float(np.median(ps)),
             "roofline": roof,
         }
+        # what the barrier + synchronize bracket itself contributes to `ms_per_step` (fixed per region, so 1/K of it per step: a K = 20
+        # run reads ~2 us per step higher than a K = 200 run of the same steady state; the median does not move)
+        out["timed_region"] = {"first_step_ms": float(ps[0]), "closing_synchronize_ms": bracket_close_ms,
+                               "ms_per_step_without_first_and_close": float((elapsed * 1e3 - ps[0] - (bracket_close_ms or 0.0)) / max(1, args.steps - 1))}
         if args.steps >= 100:
             out["step_ms_p95"] = float(np.percentile(ps, 95))
         if modes:
