@@ -196,6 +196,12 @@ std::vector<float> permute_mlp_weights(const float* raw, int S = CTK_S, int C = 
                 f[36 + m * 4 + r] = b2[16 * m + 4 * g + r];
             }
         for (int r = 0; r < 4; ++r) f[44 + r] = (r < 2 && 4 * r + g < S) ? b3[4 * r + g] : 0.0f;
+        if (S == CTK_S && C == CTK_C) {   // thin-layer form of the CartPole kernels (ctk_mlp.h: MlpFwdT)
+            for (int j = 0; j < 8; ++j) f[48 + j] = W3[(l & 3) * 32 + mlp_hid(j, g)];                  // A of the 4x4x1 blocks: output row lane % 4
+            for (int m = 0; m < 2; ++m)
+                for (int r = 0; r < 4; ++r) f[56 + m * 4 + r] = W1[(16 * m + 4 * g + r) * I + S];     // the input's column at this lane's accumulator rows
+            f[64] = b3[g];
+        }
         // backward (vector-Jacobian products): A operands of W3^T, W2^T, W1^T
         float* b = out.data() + (size_t)64 * MLP_FWD_PER_LANE + (size_t)l * MLP_BWD_PER_LANE;
         for (int m = 0; m < 2; ++m)

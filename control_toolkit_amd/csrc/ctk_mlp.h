@@ -19,7 +19,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MLP_FWD_PER_LANE = 48;   // floats per lane, forward  (12 x float4)
+constexpr int MLP_FWD_PER_LANE = 68;   // floats per lane, forward  (12 x float4 general + 5 x float4 thin-layer form, S = 4 / C = 1)
 constexpr int MLP_BWD_PER_LANE = 28;   // floats per lane, backward ( 7 x float4)
 
 __host__ __device__ inline int mlp_hid(int j, int g) { return 16 * (j >> 2) + 4 * g + (j & 3); }
@@ -83,15 +83,71 @@ struct MlpAct {
     f32x4 h1[2], h2[2];
 };
 
+// ---------------------------------------------------------------------------------------------
+// The CartPole network (4 states + 1 input -> 32 -> 32 -> 4) with its two THIN layers taken off the 16x16x4 tiles
+// (tools/diag_mlp_l3.hip: 725 -> 630 ns per step of a lone wave, 4860 -> 4130 ns with the SIMDs four waves deep):
+//   layer 1: the input's column enters the accumulator on the VALU (b1 + w1u * u, two v_pk_fma per tile), so the
+//            matrix part is ONE k-step (the four state components) instead of two with 3 of 4 k-slots padding;
+//   layer 3: 32 -> 4 as eight v_mfma_f32_4x4x1 (16 blocks of 4 lanes, 2 passes each instead of 8): block b = lane / 4
+//            multiplies A[i] = W3[i][unit] (held by lane 4b + i) with B = the lane's own h2 value, so reg i of lane
+//            (c, g) accumulates output i over the 8 hidden units lane group g holds.  The four lane groups' partial
+//            sums meet in a reduce-scatter — v_permlane32_swap pairs (g, g+2), v_permlane16_swap pairs (g, g+1) —
+//            that leaves component g in lane (c, g): the state layout layer 1 consumes.  12 of the 16 rows of the
+//            16x16x4 form were padding.
+// Same products; other summation order than the k-ordered chain (|diff| ~ 2e-6 over 20 steps, tools/diag_mlp_l3.hip).
+// ---------------------------------------------------------------------------------------------
+struct MlpFwdT {
+    float w1s[2];     // [out tile]: k-step 0 of layer 1 (state components)
+    float w2[2][8];   // [out tile][k-step]
+    float w3n[8];     // [k-step]: A operand of the 4x4x1 blocks, output row lane % 4
+    f32x4 b1[2], w1u[2], b2[2];
+    float b3g;        // bias of output component g
+};
+
+CTK_DEV MlpFwdT mlp_load_fwd_thin(const float* __restrict__ wperm) {
+    const float4* p = reinterpret_cast<const float4*>(wperm) + (threadIdx.x & 63) * (MLP_FWD_PER_LANE / 4);
+    float4 v[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) v[i] = p[i];
+    MlpFwdT w;
+    w.w1s[0] = v[0].x; w.w1s[1] = v[0].z;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int mo = i >> 1, j0 = (i & 1) * 4;
+        w.w2[mo][j0] = v[1 + i].x; w.w2[mo][j0 + 1] = v[1 + i].y; w.w2[mo][j0 + 2] = v[1 + i].z; w.w2[mo][j0 + 3] = v[1 + i].w;
+    }
+    w.b1[0] = f32x4{v[7].x, v[7].y, v[7].z, v[7].w};
+    w.b1[1] = f32x4{v[8].x, v[8].y, v[8].z, v[8].w};
+    w.b2[0] = f32x4{v[9].x, v[9].y, v[9].z, v[9].w};
+    w.b2[1] = f32x4{v[10].x, v[10].y, v[10].z, v[10].w};
+    w.w3n[0] = v[12].x; w.w3n[1] = v[12].y; w.w3n[2] = v[12].z; w.w3n[3] = v[12].w;
+    w.w3n[4] = v[13].x; w.w3n[5] = v[13].y; w.w3n[6] = v[13].z; w.w3n[7] = v[13].w;
+    w.w1u[0] = f32x4{v[14].x, v[14].y, v[14].z, v[14].w};
+    w.w1u[1] = f32x4{v[15].x, v[15].y, v[15].z, v[15].w};
+    w.b3g = v[16].x;
+    return w;
+}
+
+// a + b after exchanging halves: returns a[l] + a[l ^ 32] in the lower 32 lanes, b[l ^ 32] + b[l] in the upper 32.
+// Written as asm: this compiler's __builtin_amdgcn_permlane32_swap / permlane16_swap fold r[0] + r[1] into
+// 2 * r[0] (seen in the ISA, tools/diag_mlp_l3.hip); the s_nop is the two wait states the hazard recogniser puts
+// between a VALU write of an operand and the swap, which it cannot see inside an asm statement.
+CTK_DEV float swap_sum32(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+// rows of 16 lanes: a[row] + a[row ^ 1] in the even rows, b[row ^ 1] + b[row] in the odd rows
+CTK_DEV float swap_sum16(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 // One predictor step for the wave's 16 trajectories.  sv: state component g of trajectory c;
-// u: input of trajectory c (any lane group).  Returns the next state component.
-CTK_DEV float mlp_step(const MlpFwdW& w, float sv, float u, int g, MlpAct* keep = nullptr) {
-    const float x1 = (g == 0) ? u : 0.0f;   // k-step 1 of layer 1: k = 4 is the input, k = 5..7 padding
-    f32x4 a0 = w.b1[0], a1 = w.b1[1];
-    a0 = CTK_MFMA(w.w1[0][0], sv, a0);
-    a1 = CTK_MFMA(w.w1[1][0], sv, a1);
-    a0 = CTK_MFMA(w.w1[0][1], x1, a0);
-    a1 = CTK_MFMA(w.w1[1][1], x1, a1);
+// u: input of trajectory c (every lane group).  Returns the next state component.
+CTK_DEV float mlp_step(const MlpFwdT& w, float sv, float u, int /*g*/, MlpAct* keep = nullptr) {
+    f32x4 a0 = w.w1u[0] * u + w.b1[0], a1 = w.w1u[1] * u + w.b1[1];
+    a0 = CTK_MFMA(w.w1s[0], sv, a0);
+    a1 = CTK_MFMA(w.w1s[1], sv, a1);
     f32x4 h1[2];
     h1[0] = ctk_tanhf4(a0); h1[1] = ctk_tanhf4(a1);
     f32x4 c0 = w.b2[0], c1 = w.b2[1];
@@ -103,15 +159,17 @@ CTK_DEV float mlp_step(const MlpFwdW& w, float sv, float u, int g, MlpAct* keep 
     }
     f32x4 h2[2];
     h2[0] = ctk_tanhf4(c0); h2[1] = ctk_tanhf4(c1);
-    // layer 3: two interleaved accumulation chains (dependent MFMA latency 40 > issue 32 cycles)
-    f32x4 o0 = w.b3, o1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    // layer 3: two interleaved accumulation chains of 4x4x1 blocks, then the reduce-scatter over the lane groups
+    f32x4 p0 = f32x4{0.f, 0.f, 0.f, 0.f}, p1 = p0;
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
-        o0 = CTK_MFMA(w.w3[j], h2[j >> 2][j & 3], o0);
-        o1 = CTK_MFMA(w.w3[j + 1], h2[(j + 1) >> 2][(j + 1) & 3], o1);
+        p0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[j], h2[j >> 2][j & 3], p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[j + 1], h2[(j + 1) >> 2][(j + 1) & 3], p1, 0, 0, 0);
     }
+    const f32x4 p = p0 + p1;
+    const float s02 = swap_sum32(p[0], p[2]), s13 = swap_sum32(p[1], p[3]);
     if (keep) { keep->h1[0] = h1[0]; keep->h1[1] = h1[1]; keep->h2[0] = h2[0]; keep->h2[1] = h2[1]; }
-    return o0[0] + o1[0];
+    return swap_sum16(s02, s13) + w.b3g;
 }
 
 // Stage-cost share of lane group g (oracle Cost._get_stage_cost split by state component):
@@ -176,7 +234,7 @@ CTK_DEV float sum_over_groups(float v) {
 // Returns J of trajectory c in every lane.  INPUT_COST: include cc + ccrc (callers that sum the
 // input-only terms off the recurrence pass false and add them themselves).
 template <bool WRITE_Q, bool WRITE_TRAJ, bool INPUT_COST, bool CHECKED, class UFn>
-CTK_DEV float rollout_mlp_impl(const RolloutArgs& a, const EnvK& k, const MlpFwdW& w, int traj0, UFn&& ufn, float* amax) {
+CTK_DEV float rollout_mlp_impl(const RolloutArgs& a, const EnvK& k, const MlpFwdT& w, int traj0, UFn&& ufn, float* amax) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const int n = traj0 + c;
     const bool valid = n < a.N;
@@ -209,7 +267,7 @@ CTK_DEV float rollout_mlp_impl(const RolloutArgs& a, const EnvK& k, const MlpFwd
 }
 
 template <bool WRITE_Q, bool WRITE_TRAJ, bool INPUT_COST = true, class UFn>
-CTK_DEV float rollout_mlp(const RolloutArgs& a, const EnvK& k, const MlpFwdW& w, int traj0, UFn&& ufn) {
+CTK_DEV float rollout_mlp(const RolloutArgs& a, const EnvK& k, const MlpFwdT& w, int traj0, UFn&& ufn) {
     float amax;
     float J = rollout_mlp_impl<WRITE_Q, WRITE_TRAJ, INPUT_COST, false>(a, k, w, traj0, ufn, &amax);
     // angle beyond the unchecked cos's range somewhere in the wave (never in practice): redo, checked

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
         // all four waves: 16 trajectories each on the fp32 matrix cores (ctk_mlp.h)
         const int tr = wave * CTK_MLP_TRAJ_PER_WAVE + (lane & 15);
         const float* myu = ubuf + tr * us;
-        const MlpFwdW w = mlp_load_fwd(wperm);
+        const MlpFwdT w = mlp_load_fwd_thin(wperm);
         const float Jw = rollout_mlp<false, LOG, false>(a, k, w, row0 + wave * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return myu[h]; });
         if (lane < 16) e_s[tr] = Jw;          // hand the 64 costs to wave 0 (e_s doubles as J scratch)
         __syncthreads();

@@ -113,7 +113,7 @@ CTK_DEV float rpgd_backward_ode(const RolloutArgs& a, const EnvK& k, const float
 // ---------------------------------------------------------------------------------------------
 constexpr int RP_MLP_TAPE = 20;
 
-CTK_DEV float rpgd_forward_mlp_tape(const RolloutArgs& a, const MlpFwdW& w, const float* q_s, float* tape, int col, int g) {
+CTK_DEV float rpgd_forward_mlp_tape(const RolloutArgs& a, const MlpFwdT& w, const float* q_s, float* tape, int col, int g) {
     const int lane = threadIdx.x & 63;
     float sv = a.s0[g];
     const int H = a.H;
@@ -361,13 +361,22 @@ __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_descent(RolloutArgs a, EnvK
         }
     }
     else {
-        const MlpFwdW wf = mlp_load_fwd(wperm);
+        const MlpFwdT wf = mlp_load_fwd_thin(wperm);
         const MlpBwdW wb = mlp_load_bwd(wperm);
         const int g = lane >> 4, col = wave * CTK_MLP_TRAJ_PER_WAVE + (lane & 15);
         float* tape = scratch + (size_t)(blockIdx.x * RP_WAVES + wave) * H * 64 * RP_MLP_TAPE;
         for (int it = 0; it < iters; ++it) {
+#if defined(CTK_DIAG_RPGD_NO_FWD)   // timing experiments only (tools/rpgd_split.sh): the sweeps in isolation, results meaningless
+            const float svH = it == 0 ? rpgd_forward_mlp_tape(a, wf, q_s, tape, col, g) : 0.1f * g;
+#else
             const float svH = rpgd_forward_mlp_tape(a, wf, q_s, tape, col, g);
+#endif
+#if defined(CTK_DIAG_RPGD_NO_BWD)
+            const float nrm2 = svH * svH;
+            if (g == 0) for (int h = 0; h < H; ++h) g_s[h * RP_LD + col] = 0.01f * svH;
+#else
             const float nrm2 = rpgd_backward_mlp(a, k, wb, q_s, tape, g_s, col, g, svH, uprev0);
+#endif
             if (g == 0) sc_s[col] = ad.clip / fmaxf(sqrtf(nrm2), ad.clip);
             __syncthreads();
             const int ti = t0 + it + 1;

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(const float* __
     if constexpr (PRED == CTK_PRED_MLP) {
         const int tr = wave * CTK_MLP_TRAJ_PER_WAVE + (lane & 15);
         const float* myu = ubuf + tr * us;
-        const MlpFwdW w = mlp_load_fwd(wperm);
+        const MlpFwdT w = mlp_load_fwd_thin(wperm);
         float J = rollout_mlp<false, WTRAJ, false>(a, k, w, row0 + wave * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return myu[h]; });
         J += ((cin_s[tr] + cin_s[SAMP_TRAJ + tr]) + (cin_s[2 * SAMP_TRAJ + tr] + cin_s[3 * SAMP_TRAJ + tr])) * a.inv_Hp1;
         if (lane < 16 && row0 + tr < a.N) a.J[row0 + tr] = J;

@@ -1,6 +1,6 @@
 // diag_mlp_step.hip — where does a wave's MLP step go?  Times H steps of the 5-32-32-4 tanh MLP step of ctk_mlp.h in
 // isolation (no cost, no inputs from LDS), one wave per SIMD-ish launch shapes, in several variants:
-//   full      mlp_step as the rollout kernels run it (28 MFMA + 16 tanh)
+//   full      mlp_step as the rollout kernels run it (round 2 start: 28 MFMA + 16 tanh; now the thin-layer form, see diag_mlp_l3.hip)
 //   mfma      the same 28 MFMAs with the tanh replaced by a copy (dependent chain kept)
 //   tanh      the 16 tanh alone (dependent chain kept)
 //   split     two-wave form (14 MFMA + 8 tanh + 2 LDS exchanges with barriers)
@@ -14,10 +14,11 @@
 template <int MODE>
 __global__ __launch_bounds__(256) void k_unsplit(const float* wperm, float* out, int H) {
     const MlpFwdW w = mlp_load_fwd(wperm);
+    const MlpFwdT wt = mlp_load_fwd_thin(wperm);
     const int g = (threadIdx.x & 63) >> 4;
     float sv = 0.01f * (threadIdx.x & 15);
     for (int h = 0; h < H; ++h) {
-        if constexpr (MODE == 0) sv = mlp_step(w, sv, 0.1f, g);
+        if constexpr (MODE == 0) sv = mlp_step(wt, sv, 0.1f, g);
         else if constexpr (MODE == 1) {   // MFMAs only
             const float x1 = (g == 0) ? 0.1f : 0.0f;
             f32x4 a0 = w.b1[0], a1 = w.b1[1];

@@ -1,0 +1,11 @@
+#!/bin/bash
+# timing experiment: ctk_rpgd_descent<1> (cfg4) with one of its sweeps removed (variant libraries built with
+# -DCTK_DIAG_RPGD_NO_FWD / -DCTK_DIAG_RPGD_NO_BWD into tools/_variants/; results of those runs are meaningless, only the time counts)
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/split; mkdir -p $O
+L=control_toolkit_amd/libctk_hip.so
+cp $L /tmp/libctk_orig.so
+run() { python bench.py --workload rpgd_cfg4 --steps 60 --warmup 10 --no-cpu-baseline --no-modes 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', 'ms_per_step', round(d['ms_per_step'],4), 'kernel_us', d['roofline'].get('kernel_us'))"; }
+run full | tee $O/split.txt
+for v in "$@"; do cp tools/_variants/libctk_hip_$v.so $L && run $v | tee -a $O/split.txt; done
+cp /tmp/libctk_orig.so $L
