@@ -830,7 +830,7 @@ RpgdFusedWarm rpgd_fused(ctk_handle* h, int K, int n_new, int gather, const floa
 }
 bool rpgd_can_fuse(const ctk_handle* h) {
     static const bool off = std::getenv("CTK_NO_RPGD_FUSED") != nullptr;   // A/B switch
-    return !off && !h->generic && h->N <= CTK_RPGD_FUSED_MAX_N;
+    return !off && !h->generic && h->N <= ctk_rpgd_fused_max_n(h->cfg.predictor, h->N);
 }
 
 int rpgd_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc, float* u_out) {
@@ -1057,7 +1057,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     }
     const bool mat = cfg->materialize_trajectories != 0;
     const bool gnet = generic && cfg->predictor != CTK_PRED_ODE;
-    if (descends) h->dominant = gnet ? ctk_g_rpgd_descent_net_name(h->env, cfg->predictor) : generic ? ctk_g_rpgd_descent_name(h->env) : ctk_rpgd_descent_name(cfg->predictor);
+    if (descends) h->dominant = gnet ? ctk_g_rpgd_descent_net_name(h->env, cfg->predictor) : generic ? ctk_g_rpgd_descent_name(h->env) : ctk_rpgd_descent_name(cfg->predictor, (int)N);
     else {
         const int mode = cfg->optimizer == CTK_OPT_MPPI ? CTK_G_MODE_MPPI : CTK_G_MODE_AFFINE;
         h->dominant = gnet ? ctk_g_rollout_net_name(h->env, cfg->predictor, mode, mat) : generic ? ctk_g_rollout_name(h->env, mode, mat)

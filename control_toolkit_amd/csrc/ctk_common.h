@@ -86,3 +86,18 @@ struct RolloutArgs {
     int fast_cos_ok;         // network predictors: every angle the cost will see is inside the unchecked cos range (host-side bound)
     unsigned long long* stamps;   // diagnostic builds only (-DCTK_STAMPS): 8 s_memtime stamps per block
 };
+
+// The caller-supplied previous input (wave-uniform), through an SGPR: u_prev_dev is read with a vector load, and a loop
+// that first uses the value inherits the load's s_waitcnt vmcnt(0) — which then also waits for the loop's own stores.
+__device__ __forceinline__ float uniform_u_prev0(const RolloutArgs& a) {
+    const float v = a.u_prev_dev ? *a.u_prev_dev : a.u_prev[0];
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// s0[g] for a per-lane g in 0..3 by selects: a dynamically indexed kernarg array is read with a VECTOR load (through a
+// scratch copy), and the s_waitcnt vmcnt(0) guarding that one load lands INSIDE the consumer's loop, where it also waits
+// for every store the loop issued (seen in ctk_rpgd_mlp_wide: each step stalled on its tape stores, 900 vs 600 ns).
+__device__ __forceinline__ float lane_state4(const RolloutArgs& a, int g, int base = 0) {
+    const float lo = g == 0 ? a.s0[base] : a.s0[base + 1], hi = g == 2 ? a.s0[base + 2] : a.s0[base + 3];
+    return g < 2 ? lo : hi;
+}

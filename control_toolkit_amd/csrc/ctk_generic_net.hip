@@ -89,7 +89,7 @@ __global__ __launch_bounds__(GN_BLOCK) void ctk_g_rollout_net(RolloutArgs a, typ
     if constexpr (NET::LDS_FWD > 0) __syncthreads();
     net.begin(hidden);
     const float* my = tile + tr * ts;
-    float sv0 = g < S ? a.s0[g] : 0.0f, sv1 = 4 + g < S ? a.s0[(4 + g) & (CTK_MAX_STATES - 1)] : 0.0f;
+    float sv0 = g < S ? lane_state4(a, g) : 0.0f, sv1 = 4 + g < S ? lane_state4(a, g, 4) : 0.0f;
     float up[C];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) up[cc] = a.u_prev_dev ? a.u_prev_dev[cc] : a.u_prev[cc];
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(GN_BLOCK) void ctk_g_rpgd_descent_net(RolloutArgs a
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) up0[cc] = a.u_prev_dev ? a.u_prev_dev[cc] : a.u_prev[cc];
     const float inv = a.inv_Hp1;
-    const float s00 = g < S ? a.s0[g] : 0.0f, s01 = 4 + g < S ? a.s0[(4 + g) & (CTK_MAX_STATES - 1)] : 0.0f;
+    const float s00 = g < S ? lane_state4(a, g) : 0.0f, s01 = 4 + g < S ? lane_state4(a, g, 4) : 0.0f;
 
     for (int it = 0; it < iters; ++it) {
         // ---- forward, taping the step inputs and activations
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64) void ctk_g_gru_advance(RolloutArgs a, const flo
     float u[C];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) u[cc] = u_dev ? u_dev[cc] : a.u_prev[cc];
-    const float sv0 = g < S ? a.s0[g] : 0.0f, sv1 = 4 + g < S ? a.s0[(4 + g) & (CTK_MAX_STATES - 1)] : 0.0f;
+    const float sv0 = g < S ? lane_state4(a, g) : 0.0f, sv1 = 4 + g < S ? lane_state4(a, g, 4) : 0.0f;
     (void)net.step(first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g), nullptr);
     __syncthreads();                       // every lane has read `hidden` (begin) before column 0 overwrites it
     if (c == 0) {

@@ -161,8 +161,8 @@ CTK_DEV float rollout_gru_impl(const RolloutArgs& a, const EnvK& k, const GruW& 
     const bool valid = n < a.N;
     const MlpCostK ck = mlp_cost_coeffs(k, g, INPUT_COST);
     GruState st = gru_load_state(h0, g);
-    float sv = a.s0[g];
-    float uprev = a.u_prev_dev ? *a.u_prev_dev : a.u_prev[0];
+    float sv = lane_state4(a, g);
+    float uprev = uniform_u_prev0(a);
     float csum = 0.0f;
     const int H = a.H;
     float u_next = ufn(0);

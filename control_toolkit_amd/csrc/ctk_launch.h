@@ -95,7 +95,10 @@ hipError_t ctk_launch_pick_best_first(hipStream_t st, const float* Q, const int*
                                       int ldq);
 
 // ---- ctk_rpgd.hip ---------------------------------------------------------------------------
-const char* ctk_rpgd_descent_name(int pred);
+const char* ctk_rpgd_descent_name(int pred, int N);
+constexpr int CTK_RPGD_WIDE_MAX_N = 4096;
+bool ctk_rpgd_uses_wide(int pred, int N);
+int ctk_rpgd_fused_max_n(int pred, int N);   // one-launch step (keep-k / warm start as the descent's tail) up to this population   // MLP, small populations: phase launches + grid-wide step Jacobians (ctk_rpgd.hip)
 size_t ctk_rpgd_descent_lds(int pred, int H, bool* tape_in_lds);
 size_t ctk_rpgd_scratch_floats(int pred, int N, int H);
 // All `iters` clipped-gradient Adam iterations + the final cost pass; bc_table[2*(t-1)] = 1-b1^t, [..+1] = 1-b2^t

@@ -597,7 +597,7 @@ __global__ __launch_bounds__(64) void ctk_mppi_rollout_tp(RolloutArgs a, EnvK k,
     const float* my = tile + lane * ts;
     const bool ident = a.identity_interp != 0;
     float corr = 0.0f, cin = 0.0f;
-    float uprev = a.u_prev_dev ? *a.u_prev_dev : a.u_prev[0];
+    float uprev = uniform_u_prev0(a);
     float amax = 0.0f;
     auto F_at = [&](int h) {
         float du;
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(64) void ctk_mppi_rollout_tp(RolloutArgs a, EnvK k,
     if (k.intermediate_steps == 1) J = recur_ode_state_cost<LOG, false, true>(a, k, n, valid, F_at, &amax);
     else J = recur_ode_state_cost<LOG, true, false>(a, k, n, valid, F_at, &amax);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0)) {
-        corr = 0.0f; cin = 0.0f; uprev = a.u_prev_dev ? *a.u_prev_dev : a.u_prev[0];
+        corr = 0.0f; cin = 0.0f; uprev = uniform_u_prev0(a);
         J = recur_ode_state_cost<LOG, true, false>(a, k, n, valid, F_at, &amax);
     }
     J = (J + cin) * a.inv_Hp1 + corr;

@@ -95,7 +95,7 @@ CTK_DEV void load_tile(float* tile, const float* __restrict__ samples, const Rol
 template <bool WRITE_Q, bool WRITE_TRAJ, class UFn>
 CTK_DEV float rollout_ode(const RolloutArgs& a, const EnvK& k, int n, bool valid, UFn&& ufn) {
     State4 s{a.s0[0], a.s0[1], a.s0[2], a.s0[3]};
-    float uprev = a.u_prev_dev ? *a.u_prev_dev : a.u_prev[0];
+    float uprev = uniform_u_prev0(a);
     float csum = 0.0f;
     const int H = a.H;
     float4* traj = nullptr;

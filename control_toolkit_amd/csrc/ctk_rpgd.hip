@@ -115,10 +115,12 @@ constexpr int RP_MLP_TAPE = 20;
 
 CTK_DEV float rpgd_forward_mlp_tape(const RolloutArgs& a, const MlpFwdT& w, const float* q_s, float* tape, int col, int g) {
     const int lane = threadIdx.x & 63;
-    float sv = a.s0[g];
+    float sv = lane_state4(a, g);
     const int H = a.H;
+    float u_next = q_s[col];
     for (int h = 0; h < H; ++h) {
-        const float u = q_s[h * RP_LD + col];
+        const float u = u_next;
+        if (h + 1 < H) u_next = q_s[(h + 1) * RP_LD + col];   // a step ahead: the input opens the step (b1 + w1u * u)
         MlpAct act;
         const float nsv = mlp_step(w, sv, u, g, &act);
         float4* tp = reinterpret_cast<float4*>(tape + ((size_t)h * 64 + lane) * RP_MLP_TAPE);
@@ -132,6 +134,91 @@ CTK_DEV float rpgd_forward_mlp_tape(const RolloutArgs& a, const MlpFwdT& w, cons
     return sv;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same forward pass with a tile's step SHARED BY TWO WAVES (wide form: the chip is empty, a wave's matrix and vector
+// time add up — profiles/r02_mlp_step_microbench.txt — so halving both per wave shortens the recurrence).  Wave m of the
+// pair owns hidden units 16m .. 16m+15 of both layers: layer 1 is its own MFMA, it publishes its 4 tanh values per lane
+// (LDS, one barrier) and starts layer 2 with its OWN half of the k-steps while the other half arrives; layer 3 is the four
+// 4x4x1 blocks of its own units, reduce-scattered like mlp_step, and the two partial outputs meet through LDS (second barrier).
+// Both waves end with the same next state.  ex: [2][64] float4 (h1 halves) + [2][64] float (partial outputs) per pair.
+// ---------------------------------------------------------------------------------------------
+constexpr int RP_PAIR_EX = 2 * 64 * 4 + 2 * 64;
+
+struct MlpFwdHalf {
+    float w1s;          // layer 1, state k-step, own row tile
+    float w2o[4], w2x[4];   // layer 2, own row tile: k-steps of the OWN / the OTHER wave's hidden units
+    float w3n[4];       // layer 3 blocks, own hidden units
+    f32x4 b1, w1u, b2;
+    float b3g;
+};
+
+CTK_DEV MlpFwdHalf mlp_half_of(const MlpFwdT& w, int m) {
+    MlpFwdHalf x;
+    x.w1s = m ? w.w1s[1] : w.w1s[0];
+    x.b1 = m ? w.b1[1] : w.b1[0]; x.w1u = m ? w.w1u[1] : w.w1u[0]; x.b2 = m ? w.b2[1] : w.b2[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        x.w2o[j] = m ? w.w2[1][4 + j] : w.w2[0][j];
+        x.w2x[j] = m ? w.w2[1][j] : w.w2[0][4 + j];
+        x.w3n[j] = m ? w.w3n[4 + j] : w.w3n[j];
+    }
+    x.b3g = w.b3g;
+    return x;
+}
+
+// every wave of the workgroup must call this H times (two workgroup barriers per step)
+CTK_DEV float rpgd_forward_mlp_tape_pair(const RolloutArgs& a, const MlpFwdHalf& w, const float* q_s, int ld, float* tape, int col, int g, int m,
+                                         float* ex) {
+    const int lane = threadIdx.x & 63;
+    float4* ex_h = reinterpret_cast<float4*>(ex);          // [2][64]
+    float* ex_o = ex + 2 * 64 * 4;                         // [2][64]
+    float sv = lane_state4(a, g);
+    const int H = a.H;
+    float u_next = q_s[col];
+    for (int h = 0; h < H; ++h) {
+        const float u = u_next;
+        if (h + 1 < H) u_next = q_s[(h + 1) * ld + col];
+        f32x4 a1 = w.w1u * u + w.b1;
+        a1 = CTK_MFMA(w.w1s, sv, a1);
+        const f32x4 h1m = ctk_tanhf4(a1);
+        ex_h[m * 64 + lane] = make_float4(h1m[0], h1m[1], h1m[2], h1m[3]);
+        __syncthreads();
+        f32x4 c = w.b2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = CTK_MFMA(w.w2o[j], h1m[j], c);
+        const float4 o4 = ex_h[(m ^ 1) * 64 + lane];
+        const f32x4 h1x = f32x4{o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = CTK_MFMA(w.w2x[j], h1x[j], c);
+        const f32x4 h2m = ctk_tanhf4(c);
+        f32x4 p0 = f32x4{0.f, 0.f, 0.f, 0.f}, p1 = p0;
+        p0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[0], h2m[0], p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[1], h2m[1], p1, 0, 0, 0);
+        p0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[2], h2m[2], p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[3], h2m[3], p1, 0, 0, 0);
+        const f32x4 p = p0 + p1;
+        const float part = swap_sum16(swap_sum32(p[0], p[2]), swap_sum32(p[1], p[3]));
+        ex_o[m * 64 + lane] = part;
+        // the tape row of (tile, h): {state}, h1[tile 0], h1[tile 1], h2[tile 0], h2[tile 1] — each wave its own halves
+        float4* tp = reinterpret_cast<float4*>(tape + ((size_t)h * 64 + lane) * RP_MLP_TAPE);
+        if (m == 0) tp[0] = make_float4(sv, 0.f, 0.f, 0.f);
+        tp[1 + m] = make_float4(h1m[0], h1m[1], h1m[2], h1m[3]);
+        tp[3 + m] = make_float4(h2m[0], h2m[1], h2m[2], h2m[3]);
+        __syncthreads();
+        const float other = ex_o[(m ^ 1) * 64 + lane];
+        sv = (m == 0 ? part + other : other + part) + w.b3g;     // the same association in both waves
+    }
+    return sv;
+}
+
+// terminal adjoint share of lane group g (terminal_weight * (dd + ep) at s_H), scaled like the stage terms
+CTK_DEV float rpgd_mlp_terminal_adjoint(const RolloutArgs& a, const EnvK& k, int g, float svH) {
+    const float two_dd = 2.0f * k.dd_weight * k.inv_xs * k.inv_xs;
+    float snT, csT;
+    ctk_sincosf(svH, &snT, &csT);
+    return k.terminal_weight * a.inv_Hp1 * (g == 0 ? two_dd * (svH - k.target_position) : (g == 2 ? 2.0f * k.ep_c * (1.0f - csT) * snT : 0.0f));
+}
+
 // reverse sweep for the wave's 16 plans; lanes of group 0 write g_s[h][col] and return sum_h g^2
 CTK_DEV float rpgd_backward_mlp(const RolloutArgs& a, const EnvK& k, const MlpBwdW& w, const float* q_s, const float* tape,
                                 float* g_s, int col, int g, float svH, float uprev0) {
@@ -139,10 +226,7 @@ CTK_DEV float rpgd_backward_mlp(const RolloutArgs& a, const EnvK& k, const MlpBw
     const int H = a.H;
     const float inv = a.inv_Hp1;
     const float two_dd = 2.0f * k.dd_weight * k.inv_xs * k.inv_xs;
-    // terminal adjoint share of lane group g
-    float snT, csT;
-    ctk_sincosf(svH, &snT, &csT);
-    float lam = k.terminal_weight * inv * (g == 0 ? two_dd * (svH - k.target_position) : (g == 2 ? 2.0f * k.ep_c * (1.0f - csT) * snT : 0.0f));
+    float lam = rpgd_mlp_terminal_adjoint(a, k, g, svH);
     float nrm2 = 0.0f;
     float u_hp1 = 0.0f, u_h = q_s[(H - 1) * RP_LD + col];
     const float4* tp = reinterpret_cast<const float4*>(tape + ((size_t)(H - 1) * 64 + lane) * RP_MLP_TAPE);
@@ -172,6 +256,148 @@ CTK_DEV float rpgd_backward_mlp(const RolloutArgs& a, const EnvK& k, const MlpBw
     }
     return nrm2;
 }
+
+// ---------------------------------------------------------------------------------------------
+// MLP, wide form (small populations): the reverse sweep above is a chain of H dependent network products per wave
+// while the chip idles (cfg4: 16 waves on 1024 SIMDs, 1.05 us per step).  But lam_h = c_h + J_h^T lam_{h+1} is LINEAR
+// in lam once the step Jacobians J_h = d s_{h+1} / d (s_h, u_h) (4 x 5) are known, and those depend on the taped
+// activations only: all N x H of them are formed at once by a grid-wide launch (ctk_rpgd_mlp_jacobians, one wave per
+// (16-plan tile, step), five tangent passes through the network on the matrix cores), and the sequential part shrinks to
+// a 4 x 5 product per step (rpgd_chain_mlp).  Same gradient (optimizer_rpgd.py:310-315), other association of the
+// products.
+// Forward-mode tangents land component-wise in lane group g (the state layout): lane (c, i) of the Jacobian wave ends with
+// ROW i of plan c's Jacobian.  The chain wants a plan in ONE quad of lanes (its products then need only quad-local DPP
+// broadcasts): record slot 4c + j of (tile, step) holds {J[0..3][j]}, {J[j][4], c_h[j], 0, 0} — COLUMN j and the stage-cost
+// adjoint share — so the Jacobian wave scatters its row into the four slots of its plan.
+// ---------------------------------------------------------------------------------------------
+constexpr int RP_JAC = 8;
+
+CTK_DEV void rpgd_mlp_jacobian_record(const RolloutArgs& a, const EnvK& k, const MlpFwdT& w, const float* __restrict__ tape_row,
+                                      float* __restrict__ jac_step, int c, int g) {
+    const float4* tp = reinterpret_cast<const float4*>(tape_row);
+    const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2], r3 = tp[3], r4 = tp[4];
+    const f32x4 one = f32x4{1.f, 1.f, 1.f, 1.f};
+    const f32x4 h10 = f32x4{r1.x, r1.y, r1.z, r1.w}, h11 = f32x4{r2.x, r2.y, r2.z, r2.w};
+    const f32x4 h20 = f32x4{r3.x, r3.y, r3.z, r3.w}, h21 = f32x4{r4.x, r4.y, r4.z, r4.w};
+    const f32x4 D10 = one - h10 * h10, D11 = one - h11 * h11, D20 = one - h20 * h20, D21 = one - h21 * h21;   // tanh'
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    float Jrow[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        // tangent of layer 1's pre-activation for input basis vector e_j: column j of W1 at this lane's accumulator rows
+        f32x4 a0, a1;
+        if (j < 4) {
+            const float ind = g == j ? 1.0f : 0.0f;
+            a0 = CTK_MFMA(w.w1s[0], ind, z); a1 = CTK_MFMA(w.w1s[1], ind, z);
+        } else { a0 = w.w1u[0]; a1 = w.w1u[1]; }
+        f32x4 d1[2];
+        d1[0] = a0 * D10; d1[1] = a1 * D11;
+        f32x4 c0 = z, c1 = z;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const float b = d1[jj >> 2][jj & 3];
+            c0 = CTK_MFMA(w.w2[0][jj], b, c0);
+            c1 = CTK_MFMA(w.w2[1][jj], b, c1);
+        }
+        f32x4 d2[2];
+        d2[0] = c0 * D20; d2[1] = c1 * D21;
+        f32x4 p0 = z, p1 = z;
+#pragma unroll
+        for (int jj = 0; jj < 8; jj += 2) {
+            p0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[jj], d2[jj >> 2][jj & 3], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[jj + 1], d2[(jj + 1) >> 2][(jj + 1) & 3], p1, 0, 0, 0);
+        }
+        const f32x4 pp = p0 + p1;
+        Jrow[j] = swap_sum16(swap_sum32(pp[0], pp[2]), swap_sum32(pp[1], pp[3]));
+    }
+    // stage-cost adjoint share of lane group g at s_h (the `share` of rpgd_backward_mlp), branch-free
+    const float sv = r0.x;
+    float sn, cs;
+    ctk_sincosf(sv, &sn, &cs);
+    const float two_dd = 2.0f * k.dd_weight * k.inv_xs * k.inv_xs;
+    const float A2 = g == 0 ? two_dd : (g == 3 ? 2.0f * k.ekp_weight : 0.0f);
+    const float B = g == 0 ? k.target_position : 0.0f;
+    const float E2 = g == 2 ? 2.0f * k.ep_c : 0.0f;
+    const float share = (A2 * (sv - B) + E2 * (1.0f - cs) * sn) * a.inv_Hp1;
+    // jac_step: the 64 x RP_JAC floats of this (tile, step); this lane is row g of plan c
+    float* slot = jac_step + (size_t)(4 * c) * RP_JAC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) slot[j * RP_JAC + g] = Jrow[j];
+    slot[g * RP_JAC + 4] = Jrow[4];
+    slot[g * RP_JAC + 5] = share;
+}
+
+// The sequential part of the reverse sweep for the wave's 16 plans, from the Jacobian records of its tile.  Lane 4b + j is
+// component j of plan b (QUAD layout):  lam_h[j] = c_h[j] + sum_i lam_{h+1}[i] J_h[i][j]  is four FMAs whose lam operand is a
+// quad-local DPP broadcast, and  dJ/du_h = sum_i lam_{h+1}[i] J_h[i][4]  a two-step DPP sum over the quad, + the input-cost
+// terms.  Lanes j == 0 write g_s[h][plan] and return sum_h g^2 (as rpgd_backward_mlp); lamH comes in quad layout.
+struct RpgdChainMlp {
+    // a step is ~20 instructions; the records were written by waves all over the chip (other XCDs' L2s), a round trip to them
+    // costs >10 steps' worth: two register chunks of RP_CH steps, one being consumed while the other is in flight
+    static constexpr int RP_CH = 8;
+    float4 bufA[RP_CH][2], bufB[RP_CH][2];
+    const float* jac;
+    float lamH;
+
+    CTK_DEV void fetch(float4 (&dst)[RP_CH][2], int top) const {     // steps top, top-1, ..., top-RP_CH+1 (those >= 0)
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int i = 0; i < RP_CH; ++i) {
+            const int h = max(top - i, 0);                   // unconditional (clamped): straight-line loads keep the wait counts exact
+            const float4* jq = reinterpret_cast<const float4*>(jac + ((size_t)h * 64 + lane) * RP_JAC);
+            dst[i][0] = jq[0]; dst[i][1] = jq[1];
+        }
+    }
+    // issue the first loads (the launch does this before anything waits on memory)
+    CTK_DEV void begin(const float* jac_tile, const float* term, int H) {
+        jac = jac_tile;
+        lamH = term[threadIdx.x & 63];
+        fetch(bufA, H - 1);
+    }
+    // Writes du_h = sum_i lam_{h+1}[i] J_h[i][4] to g_s[h][plan] (lanes j == 0, a chunk at a time); the input-cost terms, which do not
+    // depend on lam, are added afterwards by rpgd_finish_gradient with the whole workgroup.
+    template <bool PARTIAL>
+    CTK_DEV void consume(const float4 (&src)[RP_CH][2], int top, float& lam, float* g_col, int ld) const {
+        float du[RP_CH];
+#pragma unroll
+        for (int i = 0; i < RP_CH; ++i) {
+            if (PARTIAL && top - i < 0) break;
+            const float4 c0 = src[i][0], c1 = src[i][1];
+            float pu = lam * c1.x;
+            pu += dpp_mov<DPP_QUAD_XOR1>(pu);
+            du[i] = pu + dpp_mov<DPP_QUAD_XOR2>(pu);
+            // quad_perm broadcasts of lanes 0..3 of the quad; two short accumulation chains
+            const float e = fmaf(dpp_mov<0x00>(lam), c0.x, c1.y), o = dpp_mov<0x55>(lam) * c0.y;
+            lam = fmaf(dpp_mov<0xAA>(lam), c0.z, e) + fmaf(dpp_mov<0xFF>(lam), c0.w, o);
+        }
+        if ((threadIdx.x & 3) == 0) {
+#pragma unroll
+            for (int i = 0; i < RP_CH; ++i) {
+                if (PARTIAL && top - i < 0) break;
+                g_col[(top - i) * ld] = du[i];
+            }
+        }
+    }
+    // g_tile: &g_s[0][first plan of the tile], ld: row stride of g_s
+    CTK_DEV void run(const RolloutArgs& a, float* g_tile, int ld) {
+        const int lane = threadIdx.x & 63;
+        const int H = a.H;
+        float lam = lamH;
+        float* g_col = g_tile + (lane >> 2);
+        int top = H - 1;
+        for (; top >= 2 * RP_CH - 1; top -= 2 * RP_CH) {      // two full chunks per round
+            fetch(bufB, top - RP_CH);
+            consume<false>(bufA, top, lam, g_col, ld);
+            fetch(bufA, top - 2 * RP_CH);
+            consume<false>(bufB, top - RP_CH, lam, g_col, ld);
+        }
+        if (top >= 0) {                                        // the last 1 .. 2 RP_CH - 1 steps
+            fetch(bufB, top - RP_CH);
+            consume<true>(bufA, top, lam, g_col, ld);
+            if (top - RP_CH >= 0) consume<true>(bufB, top - RP_CH, lam, g_col, ld);
+        }
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // warm start / resampling / reset.  One thread per (row, h) of the NEW population.
@@ -302,6 +528,30 @@ struct FusedWarm {
     WarmPtrs p;            // p.idx is ignored (the tail's own selection is used)
 };
 
+// keep-k selection + warm start as the tail of a descent launch whose ONE workgroup holds the whole population
+CTK_DEV void rpgd_fused_tail(const RolloutArgs& a, const FusedWarm& fw, float* g_s, int t, int H) {
+    __threadfence();
+    __syncthreads();                                   // Q, m, v, J of this launch are visible to every thread of the block
+    uint32_t* key_s = reinterpret_cast<uint32_t*>(g_s);   // g_s is dead: [64] keys, then [64] indices
+    int* idx_s = reinterpret_cast<int*>(g_s) + 64;
+    if (t < 64) {
+        const float Jt = t < a.N ? __hip_atomic_load(a.J + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INFINITY;
+        const uint32_t u = __builtin_bit_cast(uint32_t, Jt);
+        key_s[t] = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);   // order-preserving map (ctk_sampled.hip:f32_sortable)
+    }
+    __syncthreads();
+    if (t < a.N) {                                      // rank under the total order (J, index): ctk_select_topk
+        const uint32_t ki = key_s[t];
+        int rk = 0;
+        for (int j = 0; j < a.N; ++j) { const uint32_t kj = key_s[j]; rk += (kj < ki) | ((kj == ki) & (j < t)); }
+        if (rk < fw.K) { idx_s[rk] = t; fw.idx_out[rk] = t; }
+    }
+    __syncthreads();
+    WarmPtrs p = fw.p;
+    p.idx = idx_s;
+    for (int gid = t; gid < max(fw.w.N * H, H); gid += RP_BLOCK) rpgd_warm_element(fw.w, a, p, gid);   // CartPole: C == 1
+}
+
 template <int PRED>
 __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_descent(RolloutArgs a, EnvK k, AdamK ad, float* __restrict__ Q,
                                                              float* __restrict__ m, float* __restrict__ v,
@@ -319,7 +569,7 @@ __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_descent(RolloutArgs a, EnvK
     const int rows = min(RP_TRAJ, a.N - row0);
     const int total = rows * H;
     const size_t gbase = (size_t)row0 * H;
-    const float uprev0 = a.u_prev_dev ? *a.u_prev_dev : a.u_prev[0];
+    const float uprev0 = uniform_u_prev0(a);
 
     // plans of this block -> LDS, transposed to [h][plan] (coalesced global read)
     for (int i = t; i < RP_TRAJ * H; i += RP_BLOCK) {
@@ -400,27 +650,171 @@ __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_descent(RolloutArgs a, EnvK
         const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;
         Q[gbase + i] = q_s[h * RP_LD + r];
     }
-    if (fw.enabled) {   // one workgroup holds the whole population (host guarantees gridDim.x == 1)
-        __threadfence();
-        __syncthreads();                                   // Q, m, v, J of this launch are visible to every thread of the block
-        uint32_t* key_s = reinterpret_cast<uint32_t*>(g_s);   // g_s is dead: [64] keys, then [64] indices
-        int* idx_s = reinterpret_cast<int*>(g_s) + 64;
-        if (t < 64) {
-            const float Jt = t < a.N ? __hip_atomic_load(a.J + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INFINITY;
-            const uint32_t u = __builtin_bit_cast(uint32_t, Jt);
-            key_s[t] = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);   // order-preserving map (ctk_sampled.hip:f32_sortable)
+    if (fw.enabled) rpgd_fused_tail(a, fw, g_s, t, H);   // one workgroup holds the whole population (host guarantees gridDim.x == 1)
+}
+
+// ---- MLP, wide form: one launch per phase --------------------------------------------------------------------------
+// scratch: [tiles][H][64][RP_MLP_TAPE] tape | [tiles][H][64][RP_JAC] Jacobian records | [tiles][64] terminal adjoints
+CTK_DEV size_t rp_wide_jac_off(int tiles, int H) { return (size_t)tiles * H * 64 * RP_MLP_TAPE; }
+CTK_DEV size_t rp_wide_term_off(int tiles, int H) { return (size_t)tiles * H * 64 * (RP_MLP_TAPE + RP_JAC); }
+
+// one wave per (tile, step): jobs = live_tiles * H
+__global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_mlp_jacobians(RolloutArgs a, EnvK k, const float* __restrict__ wperm,
+                                                                  float* __restrict__ scratch, int tiles, int jobs) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int job = blockIdx.x * RP_WAVES + wave;       // = tile * H + step (wave-uniform)
+    if (job >= jobs) return;
+    const MlpFwdT w = mlp_load_fwd_thin(wperm);
+    const float* tape_row = scratch + ((size_t)job * 64 + lane) * RP_MLP_TAPE;
+    float* jac_step = scratch + rp_wide_jac_off(tiles, a.H) + (size_t)job * 64 * RP_JAC;
+    rpgd_mlp_jacobian_record(a, k, w, tape_row, jac_step, lane & 15, g);
+}
+
+// phase launch of the descent: [update from the previous launch's tape + Jacobians] then [forward with tape | final costs]
+//   update: reverse chain -> dJ/dQ, clip_by_norm, Adam step `ti` (1-based), as one iteration of ctk_rpgd_descent
+//   final : get_action's cost pass (:342) (+ the fused keep-k / warm-start tail when one workgroup holds the population)
+// A workgroup holds RP_WTRAJ = 32 plans = 2 tiles; waves (2p, 2p+1) share tile p in the forward pass
+// (rpgd_forward_mlp_tape_pair), wave 2p runs its chain.  LDS: q_s[H][33] | g_s[max(H*33, 128)] | sc_s[32] | ex[2][RP_PAIR_EX]
+constexpr int RP_WTRAJ = 32, RP_WLD = RP_WTRAJ + 1, RP_WTILES = 2;
+
+CTK_DEV void rpgd_finish_gradient_w(const RolloutArgs& a, const EnvK& k, const AdamK& ad, const float* q_s, float* g_s, float* sc_s, float uprev0) {
+    // g_s[h][r] holds du (network part of dJ/du); add the input-cost terms (cc + ccrc towards both neighbours, as
+    // rpgd_backward_mlp) and form the per-plan clip scale: 8 threads per plan, each an eighth of the horizon
+    const int t = threadIdx.x, r = t >> 3, part = t & 7, H = a.H;
+    const float inv = a.inv_Hp1;
+    float nrm2 = 0.0f;
+    for (int h = part; h < H; h += 8) {
+        const float u_h = q_s[h * RP_WLD + r], u_hm1 = h > 0 ? q_s[(h - 1) * RP_WLD + r] : uprev0;
+        float gu = 2.0f * k.ccR * u_h + 2.0f * k.ccrc_weight * (u_h - u_hm1);
+        if (h + 1 < H) gu -= 2.0f * k.ccrc_weight * (q_s[(h + 1) * RP_WLD + r] - u_h);
+        const float gq = gu * inv + g_s[h * RP_WLD + r];
+        g_s[h * RP_WLD + r] = gq;
+        nrm2 += gq * gq;
+    }
+    nrm2 += dpp_mov<DPP_QUAD_XOR1>(nrm2);
+    nrm2 += dpp_mov<DPP_QUAD_XOR2>(nrm2);
+    nrm2 += dpp_mov<DPP_ROW_HALF_MIRROR>(nrm2);           // lanes 0..7 of each half row: the 8 parts of one plan
+    if (part == 0) sc_s[r] = ad.clip / fmaxf(sqrtf(nrm2), ad.clip);   // lib.clip_by_norm(g, clip, [1,2]) (:315,:334)
+}
+
+__global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_mlp_wide(RolloutArgs a, EnvK k, AdamK ad, float* __restrict__ Q, float* __restrict__ m,
+                                                             float* __restrict__ v, const float* __restrict__ bc_table, int bc_len, int ti,
+                                                             const float* __restrict__ wperm, float* __restrict__ scratch, int tiles,
+                                                             int update, int final_pass, FusedWarm fw) {
+    extern __shared__ float lds[];
+    const int H = a.H;
+    float* q_s = lds;                                   // [H][33]
+    float* g_s = q_s + H * RP_WLD;                      // [H][33] (>= 128 words: the fused tail's keys + indices)
+    float* sc_s = g_s + max(H * RP_WLD, 128);           // [32]
+    float* ex_s = sc_s + RP_WTRAJ;                      // [2 pairs][RP_PAIR_EX]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, pair = wave >> 1, half = wave & 1;
+    const int row0 = blockIdx.x * RP_WTRAJ;
+    const int rows = min(RP_WTRAJ, a.N - row0);
+    const int total = rows * H;
+    const size_t gbase = (size_t)row0 * H;
+    const int g = lane >> 4;
+    const int tile = blockIdx.x * RP_WTILES + pair;
+    const bool live = row0 + pair * CTK_MLP_TRAJ_PER_WAVE < a.N;     // wave-uniform: the tile holds at least one plan
+    float* tape = scratch + (size_t)tile * H * 64 * RP_MLP_TAPE;
+    float* term = scratch + rp_wide_term_off(tiles, H) + (size_t)tile * 64;
+#if defined(CTK_DIAG_WIDE_STAMPS)
+    unsigned long long st_[8]; int sn_ = 0;
+#define WSTAMP() do { st_[sn_++] = wall_clock64(); } while (0)
+#else
+#define WSTAMP() do {} while (0)
+#endif
+    WSTAMP();
+    // Everything this launch reads from memory was written by OTHER launches (the Jacobian waves ran on every XCD): each
+    // dependent round trip costs ~2 us here, so all independent loads are issued before the first wait —
+    // weights, previous input, the chain's first records, the Adam moments of this thread's elements, the plans.
+    const MlpFwdT wf = mlp_load_fwd_thin(wperm);
+    const float uprev0 = uniform_u_prev0(a);
+    RpgdChainMlp chain;
+    constexpr int AB = 8;                   // Adam elements per thread and pass (H <= 64: one pass)
+    float mm0[AB], vv0[AB];
+    float bc1 = 1.0f, bc2 = 1.0f;
+    const bool chains = update && live && half == 0;
+    if (update) {
+        if (chains) chain.begin(scratch + rp_wide_jac_off(tiles, H) + (size_t)tile * H * 64 * RP_JAC, term, H);
+#pragma unroll
+        for (int j = 0; j < AB; ++j) {
+            const int i = t + j * RP_BLOCK;
+            mm0[j] = 0.0f; vv0[j] = 0.0f;
+            if (i < total && ad.rule != 2) { mm0[j] = m[gbase + i]; vv0[j] = v[gbase + i]; }
         }
-        __syncthreads();
-        if (t < a.N) {                                      // rank under the total order (J, index): ctk_select_topk
-            const uint32_t ki = key_s[t];
-            int rk = 0;
-            for (int j = 0; j < a.N; ++j) { const uint32_t kj = key_s[j]; rk += (kj < ki) | ((kj == ki) & (j < t)); }
-            if (rk < fw.K) { idx_s[rk] = t; fw.idx_out[rk] = t; }
+        if (ti <= bc_len) { bc1 = bc_table[2 * (ti - 1)]; bc2 = bc_table[2 * (ti - 1) + 1]; }
+    }
+    {   // the plans -> LDS, transposed to [h][plan]; the first AB elements per thread as one batch of loads
+        float q0[AB];
+#pragma unroll
+        for (int j = 0; j < AB; ++j) { const int i = t + j * RP_BLOCK; q0[j] = i < total ? Q[gbase + i] : 0.0f; }
+#pragma unroll
+        for (int j = 0; j < AB; ++j) {
+            const int i = t + j * RP_BLOCK;
+            if (i < RP_WTRAJ * H) { const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H; q_s[h * RP_WLD + r] = q0[j]; }
         }
+        for (int i = t + AB * RP_BLOCK; i < RP_WTRAJ * H; i += RP_BLOCK) {
+            const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;
+            q_s[h * RP_WLD + r] = i < total ? Q[gbase + i] : 0.0f;
+        }
+    }
+    __syncthreads();
+    WSTAMP();
+    if (update) {
+#if defined(CTK_DIAG_WIDE_NO_CHAIN)   // timing experiments only (tools/rpgd_split.sh)
+        for (int i = t; i < RP_WTRAJ * H; i += RP_BLOCK) g_s[(i >> 5) * RP_WLD + (i & 31)] = 0.01f * uprev0;
+#else
+        if (chains) chain.run(a, g_s + pair * CTK_MLP_TRAJ_PER_WAVE, RP_WLD);
+        else if (half == 0) for (int h = lane >> 4; h < H; h += 4) g_s[h * RP_WLD + pair * CTK_MLP_TRAJ_PER_WAVE + (lane & 15)] = 0.0f;   // plans beyond N
+#endif
+        WSTAMP();
         __syncthreads();
-        WarmPtrs p = fw.p;
-        p.idx = idx_s;
-        for (int gid = t; gid < max(fw.w.N * H, H); gid += RP_BLOCK) rpgd_warm_element(fw.w, a, p, gid);   // CartPole: C == 1
+        rpgd_finish_gradient_w(a, k, ad, q_s, g_s, sc_s, uprev0);
+        __syncthreads();
+        WSTAMP();
+        auto adam_element = [&](int i, float mmv, float vvv) {
+            const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;
+            const float gg = g_s[h * RP_WLD + r] * sc_s[r];
+            const float qn = adam_update(ad, q_s[h * RP_WLD + r], gg, mmv, vvv, bc1, bc2, a.lo[0], a.hi[0]);
+            q_s[h * RP_WLD + r] = qn;
+            Q[gbase + i] = qn;
+            if (ad.rule != 2) { m[gbase + i] = mmv; v[gbase + i] = vvv; }
+        };
+#if !defined(CTK_DIAG_WIDE_NO_ADAM)
+#pragma unroll
+        for (int j = 0; j < AB; ++j) {
+            const int i = t + j * RP_BLOCK;
+            if (i < total) adam_element(i, mm0[j], vv0[j]);
+        }
+        for (int i = t + AB * RP_BLOCK; i < total; i += RP_BLOCK) {       // H > 64: the rest, one element at a time
+            float mmv = 0.0f, vvv = 0.0f;
+            if (ad.rule != 2) { mmv = m[gbase + i]; vvv = v[gbase + i]; }
+            adam_element(i, mmv, vvv);
+        }
+#endif
+        __syncthreads();
+    }
+    WSTAMP();
+    const int col = pair * CTK_MLP_TRAJ_PER_WAVE + (lane & 15);
+    if (!final_pass) {
+        // every wave takes part (workgroup barriers inside), also for a tile beyond N (its tape is never read)
+        const MlpFwdHalf wh = mlp_half_of(wf, half);
+        const float svH = rpgd_forward_mlp_tape_pair(a, wh, q_s, RP_WLD, tape, col, g, half, ex_s + pair * RP_PAIR_EX);
+        if (half == 0) term[4 * (lane & 15) + g] = rpgd_mlp_terminal_adjoint(a, k, g, svH);   // quad layout for the chain
+        WSTAMP();
+#if defined(CTK_DIAG_WIDE_STAMPS)
+        if (blockIdx.x == 0 && t == 0 && ti == 7) {
+            printf("wide stamps (10 ns ticks since start): n=%d", sn_);
+            for (int q = 1; q < sn_; ++q) printf(" %llu", st_[q] - st_[0]);
+            printf("\n");
+        }
+#endif
+    } else {
+        if (half == 0) {   // one wave per tile for the cost pass (1 of iters + 1 passes)
+            const float J = rollout_mlp<false, false>(a, k, wf, row0 + pair * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return q_s[h * RP_WLD + col]; });
+            if (lane < 16 && row0 + col < a.N) a.J[row0 + col] = J;
+        }
+        if (fw.enabled) rpgd_fused_tail(a, fw, g_s, t, H);
     }
 }
 
@@ -451,7 +845,17 @@ hipError_t ctk_launch_rpgd_pack_keepers(hipStream_t st, const float* J, const fl
 }
 
 // ---------------------------------------------------------------------------------------------
-const char* ctk_rpgd_descent_name(int pred) { return pred == CTK_PRED_ODE ? "ctk_rpgd_descent<0>" : "ctk_rpgd_descent<1>"; }
+// MLP populations up to this size take the wide form (phase launches + grid-wide Jacobians): per iteration
+// ~45 us + 6.5 ns per plan against ~87 us of the single-launch form (both measured at cfg4, tools/rpgd_split.sh)
+bool ctk_rpgd_uses_wide(int pred, int N) {
+    static const bool narrow = getenv("CTK_RPGD_NARROW") != nullptr;   // diagnostic switch: A/B the two forms
+    return pred == CTK_PRED_MLP && N <= CTK_RPGD_WIDE_MAX_N && !narrow;
+}
+
+const char* ctk_rpgd_descent_name(int pred, int N) {
+    if (ctk_rpgd_uses_wide(pred, N)) return "ctk_rpgd_mlp_wide + ctk_rpgd_mlp_jacobians";
+    return pred == CTK_PRED_ODE ? "ctk_rpgd_descent<0>" : "ctk_rpgd_descent<1>";
+}
 
 size_t ctk_rpgd_descent_lds(int pred, int H, bool* tape_in_lds) {
     const size_t base = (size_t)(2 * H * RP_LD + RP_TRAJ) * sizeof(float);
@@ -461,9 +865,25 @@ size_t ctk_rpgd_descent_lds(int pred, int H, bool* tape_in_lds) {
     return fits ? base + tape : base;
 }
 
+static int wide_blocks(int N) { return (N + RP_WTRAJ - 1) / RP_WTRAJ; }
+
 size_t ctk_rpgd_scratch_floats(int pred, int N, int H) {
     const size_t blocks = (N + RP_TRAJ - 1) / RP_TRAJ;
-    return pred == CTK_PRED_ODE ? blocks * H * RP_NS * 64 : blocks * RP_WAVES * (size_t)H * 64 * RP_MLP_TAPE;
+    if (pred == CTK_PRED_ODE) return blocks * H * RP_NS * 64;
+    // single-launch form: tape per 16-plan tile; wide form: tape | Jacobian records | terminal adjoints per tile
+    const size_t tiles = std::max(blocks * RP_WAVES, (size_t)wide_blocks(N) * RP_WTILES);
+    return tiles * (size_t)H * 64 * (RP_MLP_TAPE + RP_JAC) + tiles * 64;
+}
+
+// largest population whose step runs as ONE launch with the keep-k / warm-start tail (one workgroup holds it)
+int ctk_rpgd_fused_max_n(int pred, int N) { return ctk_rpgd_uses_wide(pred, N) ? RP_WTRAJ : CTK_RPGD_FUSED_MAX_N; }
+
+static size_t wide_lds(int H) { return (size_t)(H * RP_WLD + std::max(H * RP_WLD, 128) + RP_WTRAJ + 2 * RP_PAIR_EX) * sizeof(float); }
+
+template <class K, class... Args>
+static void launch_timed(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, hipEvent_t e0, hipEvent_t e1, Args... args) {
+    if (e0 || e1) hipExtLaunchKernelGGL(kernel, grid, block, lds, st, e0, e1, 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
 }
 
 hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, float lr, float b1, float b2,
@@ -474,13 +894,32 @@ hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& 
     bool tape_in_lds = false;
     const size_t lds = ctk_rpgd_descent_lds(pred, a.H, &tape_in_lds);
     const dim3 grid((a.N + RP_TRAJ - 1) / RP_TRAJ), block(RP_BLOCK);
+    auto fw_of = [&](const RpgdFusedWarm* f) {
+        FusedWarm x{};
+        x.enabled = 1; x.K = f->K; x.idx_out = f->idx_out;
+        x.w = WarmArgs{a.N, a.H, f->P, f->n_new, f->gather, f->shift_previous, f->sampling_distribution, 0,
+                       f->sample_stdev, f->sample_mean, f->sample_min, f->sample_max, 0, nullptr, 3 + 3 * a.H, 0, f->fresh_tail};
+        x.p = WarmPtrs{f->draws, nullptr, Q, m, v, f->ages_old, f->Q_new, f->m_new, f->v_new, f->ages_new,
+                       f->interp, f->u_nom, f->u_dev, f->u_host, f->seq};
+        return x;
+    };
     FusedWarm fw{};
-    if (fused && grid.x == 1) {
-        fw.enabled = 1; fw.K = fused->K; fw.idx_out = fused->idx_out;
-        fw.w = WarmArgs{a.N, a.H, fused->P, fused->n_new, fused->gather, fused->shift_previous, fused->sampling_distribution, 0,
-                        fused->sample_stdev, fused->sample_mean, fused->sample_min, fused->sample_max, 0, nullptr, 3 + 3 * a.H, 0, fused->fresh_tail};
-        fw.p = WarmPtrs{fused->draws, nullptr, Q, m, v, fused->ages_old, fused->Q_new, fused->m_new, fused->v_new, fused->ages_new,
-                        fused->interp, fused->u_nom, fused->u_dev, fused->u_host, fused->seq};
+    if (fused && grid.x == 1) fw = fw_of(fused);
+    if (ctk_rpgd_uses_wide(pred, a.N)) {
+        // phase launches: [tape] J [update+tape] J ... [update+final]; the event pair brackets the whole sequence
+        const dim3 wgrid(wide_blocks(a.N));
+        const int tiles = (int)wgrid.x * RP_WTILES, live = (a.N + CTK_MLP_TRAJ_PER_WAVE - 1) / CTK_MLP_TRAJ_PER_WAVE, jobs = live * a.H;
+        FusedWarm wfw{};
+        if (fused && wgrid.x == 1) wfw = fw_of(fused);
+        const FusedWarm none{};
+        for (int it = 0; it <= iters; ++it) {
+            const bool last = it == iters;
+            launch_timed(ctk_rpgd_mlp_wide, wgrid, block, wide_lds(a.H), st, it == 0 ? e0 : nullptr, last ? e1 : nullptr, a, k, ad, Q, m, v, bc_table,
+                         bc_len, t0 + it, wperm, scratch, tiles, it > 0 ? 1 : 0, last ? 1 : 0, last ? wfw : none);
+            if (!last)
+                hipLaunchKernelGGL(ctk_rpgd_mlp_jacobians, dim3((jobs + RP_WAVES - 1) / RP_WAVES), block, 0, st, a, k, wperm, scratch, tiles, jobs);
+        }
+        return hipGetLastError();
     }
     if (pred == CTK_PRED_ODE)
         CTK_LAUNCH((ctk_rpgd_descent<CTK_PRED_ODE>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm,
