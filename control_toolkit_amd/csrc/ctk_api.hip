@@ -997,7 +997,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
         if (generic && cfg->predictor != CTK_PRED_ODE)
             lds = descends ? ctk_g_rpgd_descent_net_lds(h->env, cfg->predictor, (int)H) : ctk_g_rollout_net_lds(cfg->predictor, cols, (int)H, h->C);
         else if (generic) lds = descends ? ctk_g_rpgd_descent_lds(h->env, (int)H, nullptr) : ctk_g_rollout_lds(cols, (int)H, h->C);
-        else lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_lds((int)P, (int)H, cfg->predictor)
+        else lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_lds((int)P, (int)H, cfg->predictor, (int)N)
                  : descends ? ctk_rpgd_descent_lds(cfg->predictor, (int)H, nullptr) : ctk_affine_rollout_lds((int)H, cfg->predictor);
         if (lds > 160 * 1024) { h->err = "horizon too long for the LDS sample tiles (160 KiB per CU)"; return bail(CTK_ERR_UNSUPPORTED); }
     }

@@ -15,7 +15,11 @@
 const char* ctk_mppi_rollout_name(int pred, bool log, int N);
 int ctk_mppi_num_blocks(int N, int pred);   // workgroups = block records of one rollout launch (64 trajectories each; GRU: 16)
 bool ctk_mppi_uses_throughput_kernel(int pred, int N);
-size_t ctk_mppi_rollout_lds(int P, int H, int pred = 0);
+size_t ctk_mppi_rollout_lds(int P, int H, int pred = 0, int N = 1 << 30);
+// MLP, N <= CTK_MPPI_PAIR_MAX_N: workgroups of 32 trajectories with a tile's network step shared by two waves (ctk_mlp.h:
+// mlp_step_pair) — at these sizes 16 trajectories per wave leave half of the chip's SIMDs idle.
+constexpr int CTK_MPPI_PAIR_MAX_N = 8192;
+constexpr int CTK_PRED_MLP_PAIR = 3;   // kernel-variant id (internal to the launchers, not a ctk_predictor value)
 // wperm: per-lane permuted MLP weights (ctk_api.hip: permute_mlp_weights), nullptr for the ODE predictor
 // In-launch merge by the last block to finish (<= CTK_MPPI_FUSE_MAX_BLOCKS blocks).
 constexpr int CTK_MPPI_FUSE_MAX_BLOCKS = 64;     // ticket form: beyond this the last block's serial record fetch costs more than a launch

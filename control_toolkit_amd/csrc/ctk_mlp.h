@@ -172,6 +172,75 @@ CTK_DEV float mlp_step(const MlpFwdT& w, float sv, float u, int /*g*/, MlpAct* k
     return swap_sum16(s02, s13) + w.b3g;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The step SHARED BY TWO WAVES (where a launch leaves SIMDs idle: a wave's matrix and vector time add up —
+// profiles/r02_mlp_step_microbench.txt — so halving both per wave shortens the recurrence).  Wave m of the pair owns hidden
+// units 16m .. 16m+15 of both layers: layer 1 is its own MFMA, it publishes its 4 tanh values per lane (LDS, one barrier) and
+// starts layer 2 with its OWN half of the k-steps while the other half arrives; layer 3 is the four 4x4x1 blocks of its own
+// units, reduce-scattered like mlp_step, and the two partial outputs meet through LDS (second barrier).  Both waves end
+// with the same next state (same association of the two partial sums).
+// ex: [2][64] float4 (h1 halves) + [2][64] float (partial outputs) per pair.  Two WORKGROUP barriers per step: every wave of
+// the workgroup must take every step.
+// ---------------------------------------------------------------------------------------------
+constexpr int MLP_PAIR_EX = 2 * 64 * 4 + 2 * 64;
+
+struct MlpFwdHalf {
+    float w1s;              // layer 1, state k-step, own row tile
+    float w2o[4], w2x[4];   // layer 2, own row tile: k-steps of the OWN / the OTHER wave's hidden units
+    float w3n[4];           // layer 3 blocks, own hidden units
+    f32x4 b1, w1u, b2;
+    float b3g;
+};
+
+CTK_DEV MlpFwdHalf mlp_half_of(const MlpFwdT& w, int m) {
+    MlpFwdHalf x;
+    x.w1s = m ? w.w1s[1] : w.w1s[0];
+    x.b1 = m ? w.b1[1] : w.b1[0]; x.w1u = m ? w.w1u[1] : w.w1u[0]; x.b2 = m ? w.b2[1] : w.b2[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        x.w2o[j] = m ? w.w2[1][4 + j] : w.w2[0][j];
+        x.w2x[j] = m ? w.w2[1][j] : w.w2[0][4 + j];
+        x.w3n[j] = m ? w.w3n[4 + j] : w.w3n[j];
+    }
+    x.b3g = w.b3g;
+    return x;
+}
+
+struct MlpHalfAct {
+    f32x4 h1m, h2m;         // this wave's halves of the activations
+};
+
+CTK_DEV float mlp_step_pair(const MlpFwdHalf& w, float sv, float u, int m, float* ex, MlpHalfAct* keep = nullptr) {
+    const int lane = threadIdx.x & 63;
+    float4* ex_h = reinterpret_cast<float4*>(ex);          // [2][64]
+    float* ex_o = ex + 2 * 64 * 4;                         // [2][64]
+    f32x4 a1 = w.w1u * u + w.b1;
+    a1 = CTK_MFMA(w.w1s, sv, a1);
+    const f32x4 h1m = ctk_tanhf4(a1);
+    ex_h[m * 64 + lane] = make_float4(h1m[0], h1m[1], h1m[2], h1m[3]);
+    __syncthreads();
+    f32x4 c = w.b2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = CTK_MFMA(w.w2o[j], h1m[j], c);
+    const float4 o4 = ex_h[(m ^ 1) * 64 + lane];
+    const f32x4 h1x = f32x4{o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = CTK_MFMA(w.w2x[j], h1x[j], c);
+    const f32x4 h2m = ctk_tanhf4(c);
+    f32x4 p0 = f32x4{0.f, 0.f, 0.f, 0.f}, p1 = p0;
+    p0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[0], h2m[0], p0, 0, 0, 0);
+    p1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[1], h2m[1], p1, 0, 0, 0);
+    p0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[2], h2m[2], p0, 0, 0, 0);
+    p1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[3], h2m[3], p1, 0, 0, 0);
+    const f32x4 p = p0 + p1;
+    const float part = swap_sum16(swap_sum32(p[0], p[2]), swap_sum32(p[1], p[3]));
+    ex_o[m * 64 + lane] = part;
+    if (keep) { keep->h1m = h1m; keep->h2m = h2m; }
+    __syncthreads();
+    const float other = ex_o[(m ^ 1) * 64 + lane];
+    return (m == 0 ? part + other : other + part) + w.b3g;     // the same association in both waves
+}
+
 // Stage-cost share of lane group g (oracle Cost._get_stage_cost split by state component):
 //   g = 0: dd(x)   g = 1: cc(u) + ccrc(u - u_prev)   g = 2: ep(angle)   g = 3: ekp(angleD)
 // as per-lane coefficients, so every lane runs the same few instructions:
@@ -274,6 +343,61 @@ CTK_DEV float rollout_mlp(const RolloutArgs& a, const EnvK& k, const MlpFwdT& w,
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0))
         J = rollout_mlp_impl<WRITE_Q, WRITE_TRAJ, INPUT_COST, true>(a, k, w, traj0, ufn, &amax);
     return J;
+}
+
+// The same with a tile shared by two waves (mlp_step_pair): wave 0 of the pair carries the angle term of the cost (the cos) and
+// the range check, wave 1 the quadratic and the input terms; the two partial costs meet through `ex` at the end.
+// Every wave of the workgroup must call this (workgroup barriers per step and one at the end).  *amax: the pair's max |angle|.
+template <bool WRITE_Q, bool WRITE_TRAJ, bool INPUT_COST, bool CHECKED, class UFn>
+CTK_DEV float rollout_mlp_pair_impl(const RolloutArgs& a, const EnvK& k, const MlpFwdHalf& w, int traj0, int m, float* ex, UFn&& ufn, float* amax) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int n = traj0 + c;
+    const bool valid = n < a.N;
+    const MlpCostK ck = mlp_cost_coeffs(k, g, INPUT_COST);
+    float sv = lane_state4(a, g);
+    float uprev = uniform_u_prev0(a);
+    float csum = 0.0f, am = 0.0f;
+    const int H = a.H;
+    float u_next = ufn(0);
+    for (int h = 0; h < H; ++h) {
+        const float u = u_next;
+        if (h + 1 < H) u_next = ufn(h + 1);
+        if (m == 0) {
+            const float omc = 1.0f - (CHECKED ? cosf(sv) : ctk_cosf_fast(sv));
+            csum += ck.E * omc * omc;
+            if constexpr (!CHECKED) am = fmaxf(am, fabsf(sv));
+            if constexpr (WRITE_TRAJ) {
+                if (valid && a.traj_out) a.traj_out[((size_t)n * (H + 1) + h) * CTK_S + g] = sv;
+            }
+        } else {
+            const float d = sv - ck.B, du = u - uprev;
+            csum += ck.A * d * d + ck.I * (k.ccR * u * u + k.ccrc_weight * du * du);
+            if constexpr (WRITE_Q) {
+                if (valid && g == 0) a.Q_out[(size_t)n * H + h] = u;
+            }
+        }
+        sv = mlp_step_pair(w, sv, u, m, ex);
+        uprev = u;
+    }
+    if (m == 0) {
+        if constexpr (WRITE_TRAJ) {
+            if (valid && a.traj_out) a.traj_out[((size_t)n * (H + 1) + H) * CTK_S + g] = sv;
+        }
+        const float omc = 1.0f - cosf(sv);
+        csum += k.terminal_weight * ck.E * omc * omc;
+    } else {
+        const float d = sv - ck.B;
+        csum += g == 0 ? k.terminal_weight * ck.A * d * d : 0.0f;
+    }
+    const float part = sum_over_groups(csum);
+    float* ex_j = ex;                      // [2][64] partial costs, [2][64] max |angle| (the step's exchange slots are free now)
+    ex_j[m * 64 + lane] = part;
+    ex_j[128 + m * 64 + lane] = am;
+    __syncthreads();
+    const float other = ex_j[(m ^ 1) * 64 + lane];
+    *amax = fmaxf(am, ex_j[128 + (m ^ 1) * 64 + lane]);
+    __syncthreads();                       // the slots are reused by a caller's next pass
+    return (m == 0 ? part + other : other + part) * a.inv_Hp1;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -254,7 +254,8 @@ __host__ __device__ inline int mppi_carve_floats(int P, int H, int traj) {
     const int f = traj * tile_stride(P) + traj * ubuf_stride(H) + MPPI_BLOCK + traj + MPPI_WAVES * P + 4 * H;
     return (f + 3) & ~3;
 }
-__host__ __device__ inline int mppi_traj(int pred) { return pred == CTK_PRED_GRU ? GRU_TRAJ : MPPI_TRAJ; }
+constexpr int MPPI_PAIR_TRAJ = 32;   // MLP pair form: two tiles per workgroup, two waves per tile
+__host__ __device__ inline int mppi_traj(int pred) { return pred == CTK_PRED_GRU ? GRU_TRAJ : pred == CTK_PRED_MLP_PAIR ? MPPI_PAIR_TRAJ : MPPI_TRAJ; }
 
 // In-launch tail of the rollout kernel (single-GPU, <= 256 blocks): the block whose ticket is last
 // merges all block records and applies the update, saving the second launch and its boundary.
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
     extern __shared__ float lds[];
     RolloutArgs a = a_in;
     a.N = N_; a.H = H_; a.P = P_; a.p_magic = pmagic_;
-    constexpr int TRAJ = (PRED == CTK_PRED_GRU) ? GRU_TRAJ : MPPI_TRAJ;   // trajectories of this workgroup
+    constexpr int TRAJ = (PRED == CTK_PRED_GRU) ? GRU_TRAJ : (PRED == CTK_PRED_MLP_PAIR) ? MPPI_PAIR_TRAJ : MPPI_TRAJ;   // trajectories of this workgroup
     constexpr int CHUNKS = MPPI_BLOCK / TRAJ;                             // horizon chunks of prologue 2 (4 / 16)
     constexpr int RPW = TRAJ / MPPI_WAVES;                                // tile rows per wave in the epilogue
     const int P = a.P, H = a.H, ts = tile_stride(P), us = ubuf_stride(H);
@@ -421,6 +422,22 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
         if (lane < 16) e_s[tr] = Jw;          // hand the 64 costs to wave 0 (e_s doubles as J scratch)
         __syncthreads();
         if (wave == 0) J = e_s[lane];
+        __syncthreads();
+    } else if constexpr (PRED == CTK_PRED_MLP_PAIR) {
+        // waves (2p, 2p+1) share tile p of the workgroup's two (ctk_mlp.h: mlp_step_pair)
+        const int pair = wave >> 1, half = wave & 1;
+        const int tr = pair * CTK_MLP_TRAJ_PER_WAVE + (lane & 15);
+        const float* myu = ubuf + tr * us;
+        const MlpFwdHalf w = mlp_half_of(mlp_load_fwd_thin(wperm), half);
+        float* ex = gru_ex + pair * MLP_PAIR_EX;           // the exchange slots follow the rollout carve
+        float amax;
+        float Jw = rollout_mlp_pair_impl<false, LOG, false, false>(a, k, w, row0 + pair * CTK_MLP_TRAJ_PER_WAVE, half, ex, [&](int h) { return myu[h]; }, &amax);
+        // an angle beyond the unchecked cos's range anywhere in the WORKGROUP (never in practice): all waves redo, checked
+        if (__builtin_expect(__syncthreads_or(!(amax <= CTK_SINCOS_FAST_LIMIT)), 0))
+            Jw = rollout_mlp_pair_impl<false, LOG, false, true>(a, k, w, row0 + pair * CTK_MLP_TRAJ_PER_WAVE, half, ex, [&](int h) { return myu[h]; }, &amax);
+        if (half == 0 && lane < 16) e_s[tr] = Jw;
+        __syncthreads();
+        if (wave == 0) J = e_s[lane & (TRAJ - 1)];
         __syncthreads();
     } else {
         // the four waves share the workgroup's 16 trajectories (ctk_gru.h); wave 0 ends with J of trajectory
@@ -642,29 +659,37 @@ __global__ __launch_bounds__(64) void ctk_mppi_rollout_tp(RolloutArgs a, EnvK k,
 // ---------------------------------------------------------------------------------------------
 bool ctk_mppi_uses_throughput_kernel(int pred, int N) { return pred == CTK_PRED_ODE && N >= CTK_MPPI_THROUGHPUT_MIN_N; }
 
+// MLP at sizes that leave SIMDs idle -> the pair form
+static int kernel_pred(int pred, int N) {
+    static const bool off = getenv("CTK_MPPI_NO_PAIR") != nullptr;   // diagnostic switch: A/B the two forms
+    return (pred == CTK_PRED_MLP && N <= CTK_MPPI_PAIR_MAX_N && !off) ? CTK_PRED_MLP_PAIR : pred;
+}
+
 const char* ctk_mppi_rollout_name(int pred, bool log, int N) {
     if (ctk_mppi_uses_throughput_kernel(pred, N)) return log ? "ctk_mppi_rollout_tp<true>" : "ctk_mppi_rollout_tp<false>";
     if (pred == CTK_PRED_ODE) return log ? "ctk_mppi_rollout<0, true>" : "ctk_mppi_rollout<0, false>";
     if (pred == CTK_PRED_GRU) return log ? "ctk_mppi_rollout<2, true>" : "ctk_mppi_rollout<2, false>";
+    if (kernel_pred(pred, N) == CTK_PRED_MLP_PAIR) return log ? "ctk_mppi_rollout<3, true>" : "ctk_mppi_rollout<3, false>";
     return log ? "ctk_mppi_rollout<1, true>" : "ctk_mppi_rollout<1, false>";
 }
 
-int ctk_mppi_num_blocks(int N, int pred) { const int tr = mppi_traj(pred); return (N + tr - 1) / tr; }
+int ctk_mppi_num_blocks(int N, int pred) { const int tr = mppi_traj(kernel_pred(pred, N)); return (N + tr - 1) / tr; }
 
 static size_t merge_lds(int P, int cnt) { return (size_t)(8 + P + 1 + (cnt < MERGE_CHUNK ? cnt : MERGE_CHUNK)) * sizeof(float); }
 // with all records staged in LDS (used when it stays <= 64 KiB)
 static size_t merge_lds_staged(int P, int cnt) { return merge_lds(P, cnt) + (size_t)cnt * (2 + P) * sizeof(float); }
 static bool merge_can_stage(int P, int cnt) { return merge_lds_staged(P, cnt) <= 64 * 1024; }
 
-size_t ctk_mppi_rollout_lds(int P, int H, int pred) {
-    const size_t roll = (size_t)(mppi_carve_floats(P, H, mppi_traj(pred)) + (pred == CTK_PRED_GRU ? GRU_EX_FLOATS : 0)) * sizeof(float);
+size_t ctk_mppi_rollout_lds(int P, int H, int pred, int N) {
+    const int kp = kernel_pred(pred, N);
+    const size_t roll = (size_t)(mppi_carve_floats(P, H, mppi_traj(kp)) + (kp == CTK_PRED_GRU ? GRU_EX_FLOATS : kp == CTK_PRED_MLP_PAIR ? 2 * MLP_PAIR_EX : 0)) * sizeof(float);
     const size_t tail = merge_lds(P, CTK_MPPI_FUSE_MAX_BLOCKS);
     return roll > tail ? roll : tail;
 }
 
 // LDS of one launch: the rollout carve, or the fused tail's (staged) merge scratch if larger
-static size_t rollout_launch_lds(int P, int H, int pred, int blocks, int* stage_ok) {
-    size_t lds = ctk_mppi_rollout_lds(P, H, pred);
+static size_t rollout_launch_lds(int P, int H, int pred, int N, int blocks, int* stage_ok) {
+    size_t lds = ctk_mppi_rollout_lds(P, H, pred, N);
     *stage_ok = 0;
     if (blocks <= CTK_MPPI_FUSE_MAX_BLOCKS_LL && merge_can_stage(P, blocks)) {
         const size_t st = merge_lds_staged(P, blocks);
@@ -685,7 +710,7 @@ hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& 
         return hipGetLastError();
     }
     FuseArgs fz{};
-    size_t lds = rollout_launch_lds(a.P, a.H, pred, (int)grid.x, &fz.stage_ok);
+    size_t lds = rollout_launch_lds(a.P, a.H, pred, a.N, (int)grid.x, &fz.stage_ok);
     if (fuse.mode == 3) {   // the tail also stages the `world` records of the exchange
         const size_t need = merge_lds_staged(a.P, fuse.p2p_world);
         if (need > lds) lds = need;
@@ -701,6 +726,7 @@ hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& 
         else { if (log) CTK_MPPI_LAUNCH(PREDV, true, false); else CTK_MPPI_LAUNCH(PREDV, false, false); }             \
     } while (0)
     if (pred == CTK_PRED_ODE) CTK_MPPI_LAUNCH_PRED(CTK_PRED_ODE);
+    else if (kernel_pred(pred, a.N) == CTK_PRED_MLP_PAIR) CTK_MPPI_LAUNCH_PRED(CTK_PRED_MLP_PAIR);
     else if (pred == CTK_PRED_MLP) CTK_MPPI_LAUNCH_PRED(CTK_PRED_MLP);
     else CTK_MPPI_LAUNCH_PRED(CTK_PRED_GRU);
 #undef CTK_MPPI_LAUNCH_PRED

@@ -134,79 +134,27 @@ CTK_DEV float rpgd_forward_mlp_tape(const RolloutArgs& a, const MlpFwdT& w, cons
     return sv;
 }
 
-// ---------------------------------------------------------------------------------------------
-// The same forward pass with a tile's step SHARED BY TWO WAVES (wide form: the chip is empty, a wave's matrix and vector
-// time add up — profiles/r02_mlp_step_microbench.txt — so halving both per wave shortens the recurrence).  Wave m of the
-// pair owns hidden units 16m .. 16m+15 of both layers: layer 1 is its own MFMA, it publishes its 4 tanh values per lane
-// (LDS, one barrier) and starts layer 2 with its OWN half of the k-steps while the other half arrives; layer 3 is the four
-// 4x4x1 blocks of its own units, reduce-scattered like mlp_step, and the two partial outputs meet through LDS (second barrier).
-// Both waves end with the same next state.  ex: [2][64] float4 (h1 halves) + [2][64] float (partial outputs) per pair.
-// ---------------------------------------------------------------------------------------------
-constexpr int RP_PAIR_EX = 2 * 64 * 4 + 2 * 64;
+// The same forward pass with a tile's step shared by two waves (ctk_mlp.h: mlp_step_pair) — the wide form, where the chip is
+// empty and the recurrence's latency is what counts.  Every wave of the workgroup must call this (workgroup barriers inside).
+constexpr int RP_PAIR_EX = MLP_PAIR_EX;
 
-struct MlpFwdHalf {
-    float w1s;          // layer 1, state k-step, own row tile
-    float w2o[4], w2x[4];   // layer 2, own row tile: k-steps of the OWN / the OTHER wave's hidden units
-    float w3n[4];       // layer 3 blocks, own hidden units
-    f32x4 b1, w1u, b2;
-    float b3g;
-};
-
-CTK_DEV MlpFwdHalf mlp_half_of(const MlpFwdT& w, int m) {
-    MlpFwdHalf x;
-    x.w1s = m ? w.w1s[1] : w.w1s[0];
-    x.b1 = m ? w.b1[1] : w.b1[0]; x.w1u = m ? w.w1u[1] : w.w1u[0]; x.b2 = m ? w.b2[1] : w.b2[0];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        x.w2o[j] = m ? w.w2[1][4 + j] : w.w2[0][j];
-        x.w2x[j] = m ? w.w2[1][j] : w.w2[0][4 + j];
-        x.w3n[j] = m ? w.w3n[4 + j] : w.w3n[j];
-    }
-    x.b3g = w.b3g;
-    return x;
-}
-
-// every wave of the workgroup must call this H times (two workgroup barriers per step)
 CTK_DEV float rpgd_forward_mlp_tape_pair(const RolloutArgs& a, const MlpFwdHalf& w, const float* q_s, int ld, float* tape, int col, int g, int m,
                                          float* ex) {
     const int lane = threadIdx.x & 63;
-    float4* ex_h = reinterpret_cast<float4*>(ex);          // [2][64]
-    float* ex_o = ex + 2 * 64 * 4;                         // [2][64]
     float sv = lane_state4(a, g);
     const int H = a.H;
     float u_next = q_s[col];
     for (int h = 0; h < H; ++h) {
         const float u = u_next;
         if (h + 1 < H) u_next = q_s[(h + 1) * ld + col];
-        f32x4 a1 = w.w1u * u + w.b1;
-        a1 = CTK_MFMA(w.w1s, sv, a1);
-        const f32x4 h1m = ctk_tanhf4(a1);
-        ex_h[m * 64 + lane] = make_float4(h1m[0], h1m[1], h1m[2], h1m[3]);
-        __syncthreads();
-        f32x4 c = w.b2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c = CTK_MFMA(w.w2o[j], h1m[j], c);
-        const float4 o4 = ex_h[(m ^ 1) * 64 + lane];
-        const f32x4 h1x = f32x4{o4.x, o4.y, o4.z, o4.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c = CTK_MFMA(w.w2x[j], h1x[j], c);
-        const f32x4 h2m = ctk_tanhf4(c);
-        f32x4 p0 = f32x4{0.f, 0.f, 0.f, 0.f}, p1 = p0;
-        p0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[0], h2m[0], p0, 0, 0, 0);
-        p1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[1], h2m[1], p1, 0, 0, 0);
-        p0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[2], h2m[2], p0, 0, 0, 0);
-        p1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[3], h2m[3], p1, 0, 0, 0);
-        const f32x4 p = p0 + p1;
-        const float part = swap_sum16(swap_sum32(p[0], p[2]), swap_sum32(p[1], p[3]));
-        ex_o[m * 64 + lane] = part;
+        MlpHalfAct act;
+        const float nsv = mlp_step_pair(w, sv, u, m, ex, &act);
         // the tape row of (tile, h): {state}, h1[tile 0], h1[tile 1], h2[tile 0], h2[tile 1] — each wave its own halves
         float4* tp = reinterpret_cast<float4*>(tape + ((size_t)h * 64 + lane) * RP_MLP_TAPE);
         if (m == 0) tp[0] = make_float4(sv, 0.f, 0.f, 0.f);
-        tp[1 + m] = make_float4(h1m[0], h1m[1], h1m[2], h1m[3]);
-        tp[3 + m] = make_float4(h2m[0], h2m[1], h2m[2], h2m[3]);
-        __syncthreads();
-        const float other = ex_o[(m ^ 1) * 64 + lane];
-        sv = (m == 0 ? part + other : other + part) + w.b3g;     // the same association in both waves
+        tp[1 + m] = make_float4(act.h1m[0], act.h1m[1], act.h1m[2], act.h1m[3]);
+        tp[3 + m] = make_float4(act.h2m[0], act.h2m[1], act.h2m[2], act.h2m[3]);
+        sv = nsv;
     }
     return sv;
 }
