@@ -1061,7 +1061,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     else {
         const int mode = cfg->optimizer == CTK_OPT_MPPI ? CTK_G_MODE_MPPI : CTK_G_MODE_AFFINE;
         h->dominant = gnet ? ctk_g_rollout_net_name(h->env, cfg->predictor, mode, mat) : generic ? ctk_g_rollout_name(h->env, mode, mat)
-                    : cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_name(cfg->predictor, mat, cfg->num_rollouts)
+                    : cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_name(cfg->predictor, mat, cfg->num_rollouts, cfg->period_interpolation_inducing_points == 1)
                                                      : ctk_affine_rollout_name(cfg->predictor, mat);
     }
     if (cfg->optimizer != CTK_OPT_RPGD) TRY_CREATE(ctk_reset(h, nullptr, CTK_LOC_NONE));

@@ -613,7 +613,10 @@ __global__ __launch_bounds__(64) void ctk_mppi_rollout_tp(RolloutArgs a, EnvK k,
 
     const float* my = tile + lane * ts;
     const bool ident = a.identity_interp != 0;
-    float corr = 0.0f, cin = 0.0f;
+    // The input-only cost terms are quadratic forms of (du, u, u - u_prev): four running sums in the recurrence,
+    //   correction (:154-155)  cc * (k_dd S(du^2) + R S(u du) + k_uu S(u^2)),   stage cost  ccR S(u^2) + ccrc S((u - u_prev)^2),
+    // scaled once after the loop — 5 instructions per step instead of 13 (this kernel is VALU-bound: profiles/r01_mppi_largeN_pmc.txt).
+    float s_dd = 0.0f, s_ud = 0.0f, s_uu = 0.0f, s_rc = 0.0f;
     float uprev = uniform_u_prev0(a);
     float amax = 0.0f;
     auto F_at = [&](int h) {
@@ -621,8 +624,8 @@ __global__ __launch_bounds__(64) void ctk_mppi_rollout_tp(RolloutArgs a, EnvK k,
         if (ident) du = my[h];
         else { const int i0 = i0_s[h]; du = my[i0] * w0_s[h] + my[i0 + 1] * w1_s[h]; }
         const float u = fminf(fmaxf(un_s[h] + du, a.lo[0]), a.hi[0]);
-        corr += m.cc * (m.k_dd * (du * du) + m.R * u * du + m.k_uu * (u * u));
-        cin += stage_cost_input(k, u, uprev);
+        const float dr = u - uprev;
+        s_dd = fmaf(du, du, s_dd); s_ud = fmaf(u, du, s_ud); s_uu = fmaf(u, u, s_uu); s_rc = fmaf(dr, dr, s_rc);
         uprev = u;
         if constexpr (LOG) {
             if (valid) a.Q_out[(size_t)n * H + h] = u;
@@ -633,9 +636,11 @@ __global__ __launch_bounds__(64) void ctk_mppi_rollout_tp(RolloutArgs a, EnvK k,
     if (k.intermediate_steps == 1) J = recur_ode_state_cost<LOG, false, true>(a, k, n, valid, F_at, &amax);
     else J = recur_ode_state_cost<LOG, true, false>(a, k, n, valid, F_at, &amax);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0)) {
-        corr = 0.0f; cin = 0.0f; uprev = uniform_u_prev0(a);
+        s_dd = 0.0f; s_ud = 0.0f; s_uu = 0.0f; s_rc = 0.0f; uprev = uniform_u_prev0(a);
         J = recur_ode_state_cost<LOG, true, false>(a, k, n, valid, F_at, &amax);
     }
+    const float corr = m.cc * (m.k_dd * s_dd + m.R * s_ud + m.k_uu * s_uu);
+    const float cin = k.ccR * s_uu + k.ccrc_weight * s_rc;
     J = (J + cin) * a.inv_Hp1 + corr;
     if (valid) a.J[n] = J;
 
@@ -655,6 +660,128 @@ __global__ __launch_bounds__(64) void ctk_mppi_rollout_tp(RolloutArgs a, EnvK k,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Throughput variant that STREAMS the samples (identity interpolation, samples in a buffer).  With P = H the whole-horizon LDS
+// tile is what limits residency (13.5 KiB per wave -> ~8 waves per CU, profiles/r01_mppi_largeN_pmc.txt), and at ~2 waves per
+// SIMD the recurrence is bound by its own dependent-issue latency, not by VALU throughput (a wave64 VALU op issues in 2 cycles
+// when enough waves share the SIMD; measured: tools/diag_pk_rate.hip).  Here the wave moves TPS_CK = 16 steps at a time:
+// 64 rows x 16 steps are read as 64-byte row segments (16 lanes per row: every fetched line is used once), transposed through
+// a 4.3 KiB wave-private LDS patch into 16 registers per lane, and the next chunk's loads are in flight while the current
+// 16 steps run.  The epilogue's weighted column sums re-read the block's rows (row-coalesced; they are still in L2 / MALL).
+// (Reading each lane's row directly, a dword per step, was tried first: 16x amplification of the L2->L1 traffic, no gain.)
+// ---------------------------------------------------------------------------------------------
+constexpr int TPS_CK = 16, TPS_LD = TPS_CK + 1;
+
+template <bool LOG>
+__global__ __launch_bounds__(64) void ctk_mppi_rollout_tps(RolloutArgs a, EnvK k, MppiK m, const float* __restrict__ samples,
+                                                           const float* __restrict__ u_nom, float* __restrict__ parts) {
+    extern __shared__ float lds[];
+    const int P = a.P, H = a.H;               // P == H (identity interpolation)
+    float* xs = lds;                          // [64][TPS_LD] transposition patch
+    float* e_s = xs + 64 * TPS_LD;            // [64]
+    float* un_s = e_s + 64;                   // [H] shifted nominal input
+    const int lane = threadIdx.x;
+    const int row0 = blockIdx.x * 64;
+    const int n = row0 + lane;
+    const bool valid = n < a.N;
+    const int last = a.N - 1 - row0;          // last valid row of the block (rows beyond N re-read it; their weight is 0)
+    // element e = lane + 64 i of a chunk: row e / 16, column e % 16 -> lanes 16j .. 16j+15 read one 64-byte row segment
+    const int crow = lane >> 4, ccol = lane & 15;
+    const float* cbase = samples + (size_t)row0 * P;
+    float nxt[TPS_CK], cur[TPS_CK];
+    auto fetch = [&](int h0) {
+        const int c = min(h0 + ccol, H - 1);
+#pragma unroll
+        for (int i = 0; i < TPS_CK; ++i) nxt[i] = cbase[(size_t)min(crow + 4 * i, last) * P + c];
+    };
+    auto transpose = [&]() {                  // nxt (chunk layout) -> cur (this lane's 16 steps); the patch is the wave's own
+#pragma unroll
+        for (int i = 0; i < TPS_CK; ++i) xs[(crow + 4 * i) * TPS_LD + ccol] = nxt[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < TPS_CK; ++i) cur[i] = xs[lane * TPS_LD + i];
+    };
+    fetch(0);
+    for (int h = lane; h < H; h += 64) un_s[h] = u_nom[min(h + 1, H - 1)];   // optimizer_mppi.py:184 (shift)
+    __syncthreads();
+
+    const float up0 = uniform_u_prev0(a);
+    float s_dd = 0.0f, s_ud = 0.0f, s_uu = 0.0f, s_rc = 0.0f, uprev = up0;   // quadratic-form sums, as in ctk_mppi_rollout_tp
+    float J;
+    bool redo = k.intermediate_steps != 1;
+    if (!redo) {
+        State4 s{a.s0[0], a.s0[1], a.s0[2], a.s0[3]};
+        float csum = 0.0f, am = 0.0f;
+        float4* traj = nullptr;
+        if constexpr (LOG) {
+            if (a.traj_out) traj = reinterpret_cast<float4*>(a.traj_out) + (size_t)n * (H + 1);
+        }
+        for (int h0 = 0; h0 < H; h0 += TPS_CK) {
+            transpose();
+            if (h0 + TPS_CK < H) fetch(h0 + TPS_CK);
+#pragma unroll
+            for (int i = 0; i < TPS_CK; ++i) {
+                const int h = h0 + i;
+                if (h < H) {
+                    const float du = cur[i] * m.stdev;
+                    const float u = fminf(fmaxf(un_s[h] + du, a.lo[0]), a.hi[0]);
+                    const float dr = u - uprev;
+                    s_dd = fmaf(du, du, s_dd); s_ud = fmaf(u, du, s_ud); s_uu = fmaf(u, u, s_uu); s_rc = fmaf(dr, dr, s_rc);
+                    uprev = u;
+                    float sn, cs;
+                    ctk_sincosf_fast(s.th, &sn, &cs);
+                    am = fmaxf(am, fabsf(s.th));
+                    csum += stage_cost_state(k, s, cs);
+                    if constexpr (LOG) {
+                        if (valid) a.Q_out[(size_t)n * H + h] = u;
+                        if (valid && traj) traj[h] = make_float4(s.x, s.v, s.th, s.om);
+                    }
+                    ode_substep(k, s, k.u_max * u, sn, cs);
+                }
+            }
+        }
+        if constexpr (LOG) {
+            if (valid && traj) traj[H] = make_float4(s.x, s.v, s.th, s.om);
+        }
+        J = csum + terminal_cost(k, s);
+        redo = __builtin_amdgcn_ballot_w64(!(am <= CTK_SINCOS_FAST_LIMIT)) != 0;
+    }
+    if (__builtin_expect(redo, 0)) {   // Euler sub-steps, or an angle beyond the fast sincos range somewhere in the wave: checked recurrence
+        s_dd = 0.0f; s_ud = 0.0f; s_uu = 0.0f; s_rc = 0.0f; uprev = up0;
+        const float* my = samples + (size_t)min(n, a.N - 1) * P;
+        float amax;
+        auto F_at = [&](int h) {
+            const float du = my[h] * m.stdev;
+            const float u = fminf(fmaxf(un_s[h] + du, a.lo[0]), a.hi[0]);
+            const float dr = u - uprev;
+            s_dd = fmaf(du, du, s_dd); s_ud = fmaf(u, du, s_ud); s_uu = fmaf(u, u, s_uu); s_rc = fmaf(dr, dr, s_rc);
+            uprev = u;
+            if constexpr (LOG) {
+                if (valid) a.Q_out[(size_t)n * H + h] = u;
+            }
+            return k.u_max * u;
+        };
+        J = recur_ode_state_cost<LOG, true, false>(a, k, n, valid, F_at, &amax);
+    }
+    J = (J + k.ccR * s_uu + k.ccrc_weight * s_rc) * a.inv_Hp1 + m.cc * (m.k_dd * s_dd + m.R * s_ud + m.k_uu * s_uu);
+    if (valid) a.J[n] = J;
+
+    const float rho = wave_min(valid ? J : INFINITY);
+    const float e = valid ? expf(m.neg_inv_lbd * (J - rho)) : 0.0f;
+    const float asum = wave_sum(e);
+    e_s[lane] = e;
+    __syncthreads();
+    float* rec = parts + (size_t)blockIdx.x * (2 + P);
+    if (lane == 0) { rec[0] = rho; rec[1] = asum; }
+    for (int p = lane; p < P; p += 64) {
+        const float* colp = cbase + p;
+        float acc = 0.0f;
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) acc = fmaf(e_s[r], colp[(size_t)min(r, last) * P], acc);
+        rec[2 + p] = acc * m.stdev;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 bool ctk_mppi_uses_throughput_kernel(int pred, int N) { return pred == CTK_PRED_ODE && N >= CTK_MPPI_THROUGHPUT_MIN_N; }
@@ -665,15 +792,22 @@ static int kernel_pred(int pred, int N) {
     return (pred == CTK_PRED_MLP && N <= CTK_MPPI_PAIR_MAX_N && !off) ? CTK_PRED_MLP_PAIR : pred;
 }
 
-const char* ctk_mppi_rollout_name(int pred, bool log, int N) {
-    if (ctk_mppi_uses_throughput_kernel(pred, N)) return log ? "ctk_mppi_rollout_tp<true>" : "ctk_mppi_rollout_tp<false>";
+const char* ctk_mppi_rollout_name(int pred, bool log, int N, bool identity_interp) {
+    if (ctk_mppi_uses_throughput_kernel(pred, N)) {
+        // period 1: sample buffers take the streaming form (the in-kernel sampler keeps the tile form, ctk_mppi_rollout_tp)
+        if (identity_interp) return log ? "ctk_mppi_rollout_tps<true>" : "ctk_mppi_rollout_tps<false>";
+        return log ? "ctk_mppi_rollout_tp<true>" : "ctk_mppi_rollout_tp<false>";
+    }
     if (pred == CTK_PRED_ODE) return log ? "ctk_mppi_rollout<0, true>" : "ctk_mppi_rollout<0, false>";
     if (pred == CTK_PRED_GRU) return log ? "ctk_mppi_rollout<2, true>" : "ctk_mppi_rollout<2, false>";
     if (kernel_pred(pred, N) == CTK_PRED_MLP_PAIR) return log ? "ctk_mppi_rollout<3, true>" : "ctk_mppi_rollout<3, false>";
     return log ? "ctk_mppi_rollout<1, true>" : "ctk_mppi_rollout<1, false>";
 }
 
-int ctk_mppi_num_blocks(int N, int pred) { const int tr = mppi_traj(kernel_pred(pred, N)); return (N + tr - 1) / tr; }
+int ctk_mppi_num_blocks(int N, int pred) {
+    const int tr = mppi_traj(kernel_pred(pred, N));
+    return (N + tr - 1) / tr;
+}
 
 static size_t merge_lds(int P, int cnt) { return (size_t)(8 + P + 1 + (cnt < MERGE_CHUNK ? cnt : MERGE_CHUNK)) * sizeof(float); }
 // with all records staged in LDS (used when it stays <= 64 KiB)
@@ -704,6 +838,13 @@ hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& 
                                    const MppiFuse& fuse, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid(ctk_mppi_num_blocks(a.N, pred)), block(MPPI_BLOCK);
     if (ctk_mppi_uses_throughput_kernel(pred, a.N)) {
+        static const bool no_direct = getenv("CTK_MPPI_TP_TILE") != nullptr;   // diagnostic switch: A/B the two throughput forms
+        if (samples != nullptr && a.identity_interp && !no_direct) {
+            const size_t lds_d = (size_t)(64 * TPS_LD + 64 + a.H) * sizeof(float);
+            if (log) CTK_LAUNCH((ctk_mppi_rollout_tps<true>), grid, dim3(64), lds_d, st, e0, e1, a, k, m, samples, u_nom, parts);
+            else CTK_LAUNCH((ctk_mppi_rollout_tps<false>), grid, dim3(64), lds_d, st, e0, e1, a, k, m, samples, u_nom, parts);
+            return hipGetLastError();
+        }
         const size_t lds_tp = (size_t)(64 * tile_stride(a.P) + 64 + 4 * a.H) * sizeof(float);
         if (log) CTK_LAUNCH((ctk_mppi_rollout_tp<true>), grid, dim3(64), lds_tp, st, e0, e1, a, k, m, samples, u_nom, a.interp, parts);
         else CTK_LAUNCH((ctk_mppi_rollout_tp<false>), grid, dim3(64), lds_tp, st, e0, e1, a, k, m, samples, u_nom, a.interp, parts);
