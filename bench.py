@@ -253,9 +253,9 @@ def large_n_point(torch, CtkEngine, dev, H, p, N=1 << 20, steps=12):
     eng.close()
     alg = 4 * N * P + 4 * N + 8 * H + 16
     ach = alg / (k_ms * 1e-3) / 1e9
-    return {"N": N, "kernel": name, "kernel_us": k_ms * 1e3, "bound": "valu", "achieved": ach, "peak": HBM_PEAK_GBS,
+    return {"N": N, "kernel": name, "kernel_us": k_ms * 1e3, "bound": "valu-issue", "achieved": ach, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "trajectory_steps_per_s_kernel": N * H / (k_ms * 1e-3),
-            "note": "VALU-bound before it is HBM-bound (DESIGN.md 5: instructions per trajectory-step vs 4 compulsory bytes)"}
+            "note": "issue/latency-bound before it is HBM-bound (DESIGN.md 5: ~75 instructions per trajectory-step vs 4 compulsory bytes)"}
 
 
 def build_controller(w, N_local, local_rank, rank, rng_mode):
