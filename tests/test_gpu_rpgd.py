@@ -145,7 +145,7 @@ def test_rpgd_device_rng_reset_and_step_run():
     e.close()
 
 
-@pytest.mark.parametrize("N,H,p,its", [(256, 50, 10, 20), (48, 12, 4, 3)])
+@pytest.mark.parametrize("N,H,p,its", [(256, 50, 10, 20), (48, 12, 4, 3), (24, 10, 5, 3), (40, 70, 7, 2)])
 def test_rpgd_mlp_matches_oracle(N, H, p, its):
     # (256, 50, 10, 20) is BASELINE config 4: RPGD, N=256 x 20 Adam iterations, H=50, MLP predictor (MFMA path)
     env = O.EnvParams(terminal_weight=0.3)
