@@ -154,3 +154,24 @@ def test_single_wave_forms_also_match_oracle():
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.parametrize("materialize", [False, True])
+def test_mppi_mlp_angle_beyond_the_fast_cos_range_takes_the_checked_pass(materialize):
+    """A state angle beyond the unchecked cos's range (|x| > 32768 rad) in ONE tile of a workgroup: every wave of the workgroup
+    must take the checked second pass together (workgroup barriers inside the pair step) — and the costs still match the oracle."""
+    env = O.EnvParams(terminal_weight=0.25)
+    w = O.mlp_default_weights(1)
+    pred = O.Predictor("MLP", dt=0.02, env=env, weights=w)
+    N, H, p = 96, 9, 3
+    o = O.MPPI(pred, O.Cost(env), num_rollouts=N, mpc_horizon=H, period_interpolation_inducing_points=p)
+    e = CtkEngine("mppi", "MLP", num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p,
+                  materialize_trajectories=materialize)
+    apply_env(e, env); e.set_predictor_weights(w)
+    rng = np.random.default_rng(3)
+    s = np.array([0.1, -0.2, 40000.25, 0.7], np.float32)         # the initial angle itself is out of range: every trajectory sees it
+    noise = rng.standard_normal((N, o.P, 1)).astype(np.float32)
+    uo, ug = o.step(s, noise), e.step(s, noise)
+    np.testing.assert_allclose(e.read("J"), o.J, rtol=2e-4, atol=1e-3)
+    np.testing.assert_allclose(ug[0], uo, rtol=2e-3, atol=2e-4)
+    e.close()
