@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Closed-loop soak (GPU box): 3000 steps of MPPI / MPPI+logging / CEM / RPGD / random-action against a host plant with
+"""Closed-loop soak (GPU box): 3000 steps of MPPI / MPPI+logging / CEM / RPGD / random-action (+ MPPI and RPGD with the MLP predictor) against a host plant with
 API calls interleaved (parameters, reset, state round trip, log reads); every output must stay finite and inside the limits.
 usage: python tools/soak.py"""
 import numpy as np, sys, time
@@ -13,8 +13,13 @@ engs = {
  "cem": CtkEngine("cem", "ODE", num_rollouts=500, mpc_horizon=25, dt=0.02, seed=3, cem_outer_it=3, cem_best_k=50, cem_initial_action_stdev=0.5, cem_stdev_min=0.01),
  "rpgd": CtkEngine("rpgd", "ODE", num_rollouts=64, mpc_horizon=30, dt=0.02, seed=4, outer_its=3, resamp_per=5, shift_previous=1, opt_keep_k=16, sampling_distribution=0, sample_min=-1.0, sample_max=1.0, learning_rate=0.05, gradmax_clip=5.0, period_interpolation_inducing_points=5),
  "rand": CtkEngine("random_action", "ODE", num_rollouts=320, mpc_horizon=35, dt=0.02, seed=5),
+ # the MLP predictor: pair form of the MPPI kernel (N <= 8192), wide form of the RPGD descent (phase + Jacobian launches)
+ "mppi_mlp": CtkEngine("mppi", "MLP", num_rollouts=1000, mpc_horizon=30, dt=0.02, seed=6, period_interpolation_inducing_points=5),
+ "rpgd_mlp": CtkEngine("rpgd", "MLP", num_rollouts=72, mpc_horizon=25, dt=0.02, seed=7, outer_its=3, resamp_per=5, shift_previous=1, opt_keep_k=18, sampling_distribution=0, sample_min=-1.0, sample_max=1.0, learning_rate=0.05, gradmax_clip=5.0, period_interpolation_inducing_points=5),
 }
-engs["rpgd"].reset()
+_w = (np.random.default_rng(11).standard_normal(engs["mppi_mlp"].predictor_weight_count()) * 0.15).astype(np.float32)
+engs["mppi_mlp"].set_predictor_weights(_w); engs["rpgd_mlp"].set_predictor_weights(_w)
+engs["rpgd"].reset(); engs["rpgd_mlp"].reset()
 engs["mppi_log"].log_enable(64)
 states = {k: np.array([0.0, 0.0, 3.0, 0.0], np.float32) for k in engs}
 t0 = time.time()
