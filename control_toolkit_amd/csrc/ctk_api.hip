@@ -618,14 +618,14 @@ int mppi_update(ctk_handle* h, const float* parts, int n_parts, float* u_out) {
         // merge the records into ONE (the same merge kernel the CartPole path uses; it only sees P*C columns), then the
         // per-channel update u_nom <- clip(shift(u_nom) + interp(b)/a)
         const float* rec = parts;
-        if (n_parts > 1) {
+        if (n_parts > ctk_g_mppi_update_max_parts()) {   // (mppi_reduce_blocks leaves <= 64: not reached today)
             HIP_TRY(h, ctk_launch_mppi_merge_partial(h->stream, parts, n_parts, n_parts, h->PC, h->mk.neg_inv_lbd, h->d_rec));
-            rec = h->d_rec;
+            rec = h->d_rec; n_parts = 1;
         }
         float zero_s[CTK_MAX_STATES] = {};
         const RolloutArgs a = make_args(h, zero_s, nullptr, h->N, h->P);   // limits per input
-        HIP_TRY(h, ctk_launch_g_mppi_update(h->stream, rec, h->P, h->C, h->H, h->d_interp, h->d_unom[h->cur], h->d_unom[nxt], a, h->d_u,
-                                            h->h_u_dev, h->seq));
+        HIP_TRY(h, ctk_launch_g_mppi_update(h->stream, rec, n_parts, h->mk.neg_inv_lbd, h->P, h->C, h->H, h->d_interp, h->d_unom[h->cur],
+                                            h->d_unom[nxt], a, h->d_u, h->h_u_dev, h->seq));
         h->cur = nxt;
         if (int rc = mppi_advance_hidden(h)) return rc;   // optimizer_mppi.py:192 (RNN hidden state), behind the update on the stream
         return finish_step(h, u_out);

@@ -145,26 +145,57 @@ __global__ __launch_bounds__(G_TRAJ) void ctk_g_rollout(RolloutArgs a, typename 
     }
 }
 
-// u_nom <- clip(shift(u_nom) + interp(b) / a)  (optimizer_mppi.py:190), u = u_nom[0, :] (:191); rec = ONE merged record
+// u_nom <- clip(shift(u_nom) + interp(b) / a)  (optimizer_mppi.py:190), u = u_nom[0, :] (:191).
+// parts: n_parts <= G_UPD_MAX_PARTS block (or shard) records {rho, a, b[P*C]}, merged here first — rho = min rho_r,
+// a = sum a_r e^{-(rho_r - rho)/lambda}, b likewise (optimizer_mppi.py:163-168 re-associated, as ctk_mppi_merge) — so that the
+// template path's MPPI step is two launches (rollout, this) instead of three.  LDS: w[n_parts] | b[P*C]
+constexpr int G_UPD_MAX_PARTS = 1024;
+
 template <int DUMMY>
-__global__ __launch_bounds__(256) void ctk_g_mppi_update(const float* __restrict__ rec, int P, int C, int H,
+__global__ __launch_bounds__(256) void ctk_g_mppi_update(const float* __restrict__ parts, int n_parts, float neg_inv_lbd, int P, int C, int H,
                                                         const InterpEntry* __restrict__ interp, const float* __restrict__ u_nom_in,
                                                         float* __restrict__ u_nom_out, RolloutArgs a, float* __restrict__ u_dev,
                                                         float* __restrict__ u_host, uint32_t seq) {
+    extern __shared__ float lds[];
     __shared__ float u_s[CTK_MAX_INPUTS];
-    const float a_tot = rec[1];
-    const float* b = rec + 2;
-    for (int hc = threadIdx.x; hc < H * C; hc += 256) {
+    __shared__ float red_s[4];
+    const int PC = P * C, rs = 2 + PC, t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    float* w_s = lds;                 // [n_parts]
+    float* b_s = w_s + n_parts;       // [PC]
+    float rho = INFINITY;
+    for (int r = t; r < n_parts; r += 256) rho = fminf(rho, parts[(size_t)r * rs]);
+    rho = wave_min(rho);
+    if (lane == 0) red_s[wave] = rho;
+    __syncthreads();
+    rho = fminf(fminf(red_s[0], red_s[1]), fminf(red_s[2], red_s[3]));
+    __syncthreads();
+    float asum = 0.0f;
+    for (int r = t; r < n_parts; r += 256) {
+        const float w = expf(neg_inv_lbd * (parts[(size_t)r * rs] - rho));
+        w_s[r] = w;
+        asum += parts[(size_t)r * rs + 1] * w;
+    }
+    asum = wave_sum(asum);
+    if (lane == 0) red_s[wave] = asum;
+    __syncthreads();
+    const float a_tot = (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]);
+    for (int pc = t; pc < PC; pc += 256) {
+        float acc = 0.0f;
+        for (int r = 0; r < n_parts; ++r) acc += parts[(size_t)r * rs + 2 + pc] * w_s[r];
+        b_s[pc] = acc;
+    }
+    __syncthreads();
+    for (int hc = t; hc < H * C; hc += 256) {
         const int h = hc / C, c = hc - h * C;
         const InterpEntry e = interp[h];
         const int i1 = min(e.i0 + 1, P - 1);
-        const float w = (b[e.i0 * C + c] * e.w0 + b[i1 * C + c] * e.w1) / a_tot;
+        const float w = (b_s[e.i0 * C + c] * e.w0 + b_s[i1 * C + c] * e.w1) / a_tot;
         const float o = fminf(fmaxf(u_nom_in[min(h + 1, H - 1) * C + c] + w, a.lo[c]), a.hi[c]);
         u_nom_out[hc] = o;
         if (h == 0) u_s[c] = o;
     }
     __syncthreads();
-    if (threadIdx.x == 0) publish_u_vec(u_dev, u_host, u_s, C, seq);
+    if (t == 0) publish_u_vec(u_dev, u_host, u_s, C, seq);
 }
 
 // optimizer_cem_tf.py:99-102 with C channels: clip std, shift mean and std by one STEP (C floats), refill the tail with
@@ -368,9 +399,13 @@ hipError_t ctk_launch_g_rollout(hipStream_t st, int env, int mode, const Rollout
     return hipGetLastError();
 }
 
-hipError_t ctk_launch_g_mppi_update(hipStream_t st, const float* rec, int P, int C, int H, const InterpEntry* interp, const float* u_nom_in,
-                                    float* u_nom_out, const RolloutArgs& a, float* u_dev, float* u_host, uint32_t seq) {
-    hipLaunchKernelGGL(ctk_g_mppi_update<0>, dim3(1), dim3(256), 0, st, rec, P, C, H, interp, u_nom_in, u_nom_out, a, u_dev, u_host, seq);
+int ctk_g_mppi_update_max_parts() { return G_UPD_MAX_PARTS; }
+
+hipError_t ctk_launch_g_mppi_update(hipStream_t st, const float* parts, int n_parts, float neg_inv_lbd, int P, int C, int H,
+                                    const InterpEntry* interp, const float* u_nom_in, float* u_nom_out, const RolloutArgs& a, float* u_dev,
+                                    float* u_host, uint32_t seq) {
+    hipLaunchKernelGGL(ctk_g_mppi_update<0>, dim3(1), dim3(256), (size_t)(n_parts + P * C) * sizeof(float), st, parts, n_parts, neg_inv_lbd, P, C, H,
+                       interp, u_nom_in, u_nom_out, a, u_dev, u_host, seq);
     return hipGetLastError();
 }
 

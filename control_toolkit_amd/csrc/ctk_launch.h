@@ -142,8 +142,10 @@ const char* ctk_g_rollout_name(int env, int mode, bool log);
 hipError_t ctk_launch_g_rollout(hipStream_t st, int env, int mode, const RolloutArgs& a, const float* params, float dt, int isteps,
                                 const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
                                 float* parts, bool log, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
-hipError_t ctk_launch_g_mppi_update(hipStream_t st, const float* rec, int P, int C, int H, const InterpEntry* interp, const float* u_nom_in,
-                                    float* u_nom_out, const RolloutArgs& a, float* u_dev, float* u_host, uint32_t seq);
+int ctk_g_mppi_update_max_parts();   // records the update launch merges itself
+hipError_t ctk_launch_g_mppi_update(hipStream_t st, const float* parts, int n_parts, float neg_inv_lbd, int P, int C, int H,
+                                    const InterpEntry* interp, const float* u_nom_in, float* u_nom_out, const RolloutArgs& a, float* u_dev,
+                                    float* u_host, uint32_t seq);
 hipError_t ctk_launch_g_cem_finish(hipStream_t st, const float* Q, const int* idx, int H, int C, float* mu, float* sd, float std_min,
                                    float init_std, const RolloutArgs& a, float* u_dev, float* u_host, uint32_t seq, int ldq,
                                    float std_max = 1.0e8f, int u_from_mu = 0);
