@@ -118,3 +118,13 @@ def test_p2p_single_rank_and_error_paths():
         c.p2p_alloc(0, 1)
     for x in (e, f, c):
         x.close()
+    # the network predictor: N <= 8192 runs the pair form of the rollout kernel, whose exchanging instantiation is its own
+    from oracle import ctk_oracle as O
+    w = O.mlp_default_weights(4)
+    e = CtkEngine("mppi", "MLP", num_rollouts=1024, mpc_horizon=15, dt=0.02, seed=3, period_interpolation_inducing_points=5)
+    f = CtkEngine("mppi", "MLP", num_rollouts=1024, mpc_horizon=15, dt=0.02, seed=3, period_interpolation_inducing_points=5)
+    e.set_predictor_weights(w); f.set_predictor_weights(w)
+    e.p2p_connect([e.p2p_alloc(0, 1)])
+    for t in range(3):
+        np.testing.assert_allclose(e.p2p_step(s), f.step(s), rtol=1e-5, atol=1e-6)
+    e.close(); f.close()
