@@ -53,6 +53,14 @@ class CtkConfig(C.Structure):
 
 
 def library_path() -> str:
+    """The in-tree product library.  CTK_HIP_LIBRARY points a diagnostic run (tools/rpgd_split.sh: timing variants whose
+    results are meaningless) at another build WITHOUT touching the product file; it is announced on stderr so that a test or
+    bench line can never be attributed to the product library by mistake."""
+    override = os.environ.get("CTK_HIP_LIBRARY")
+    if override:
+        import sys
+        print(f"[ctk] CTK_HIP_LIBRARY override: loading {override} instead of the product library", file=sys.stderr)
+        return override
     return os.path.join(_HERE, _LIB_NAME)
 
 

@@ -103,6 +103,7 @@ struct ctk_handle {
     size_t ev_used = 0;
     std::string err;
     std::string dominant;
+    const char* dominant_ran = nullptr;   // name the MPPI launcher reported last (kernel choice depends on the sample mode)
 };
 
 namespace {
@@ -568,8 +569,10 @@ int mppi_rollout(ctk_handle* h, const float* s, const float* u_prev, const float
     if (fuse_mode == 3) { fz.p2p = h->d_p2p_args; fz.p2p_seq = h->p2p_seq; fz.p2p_world = h->p2p_world; }
     fz.u_nom_out = h->d_unom[h->cur ^ 1]; fz.u_dev = h->d_u; fz.u_host = h->h_u_dev; fz.seq = h->seq;
     ProfSlot ps(h);
+    const char* ran = nullptr;
     HIP_TRY(h, ctk_launch_mppi_rollout(h->stream, h->cfg.predictor, a, h->k, h->mk, d_s, h->d_unom[h->cur], h->d_wperm,
-                                       h->d_parts, log, fz, ps.a, ps.b));
+                                       h->d_parts, log, fz, ps.a, ps.b, &ran));
+    if (ran != h->dominant_ran) { h->dominant_ran = ran; h->dominant = ran; }   // string literals: pointer compare
     return CTK_OK;
 }
 
@@ -825,7 +828,7 @@ int rpgd_reset(ctk_handle* h, const float* draws, int loc) {
 RpgdFusedWarm rpgd_fused(ctk_handle* h, int K, int n_new, int gather, const float* d_draws, int from, int to, int fresh_tail) {
     const ctk_config& c = h->cfg;
     return RpgdFusedWarm{K, h->d_idx, h->P, n_new, gather, c.shift_previous, c.sampling_distribution, fresh_tail,
-                         c.sample_stdev, c.sample_mean, c.sample_min, c.sample_max, d_draws, h->d_ages[from],
+                         c.sample_whole_control_space, c.sample_stdev, c.sample_mean, c.sample_min, c.sample_max, d_draws, h->d_ages[from],
                          h->d_pop[to], h->d_m[to], h->d_v[to], h->d_ages[to], h->d_interp, h->d_unom[0], h->d_u, h->h_u_dev, h->seq};
 }
 bool rpgd_can_fuse(const ctk_handle* h) {
@@ -1061,7 +1064,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     else {
         const int mode = cfg->optimizer == CTK_OPT_MPPI ? CTK_G_MODE_MPPI : CTK_G_MODE_AFFINE;
         h->dominant = gnet ? ctk_g_rollout_net_name(h->env, cfg->predictor, mode, mat) : generic ? ctk_g_rollout_name(h->env, mode, mat)
-                    : cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_name(cfg->predictor, mat, cfg->num_rollouts, cfg->period_interpolation_inducing_points == 1)
+                    : cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_name(cfg->predictor, mat, cfg->num_rollouts, cfg->period_interpolation_inducing_points == 1 && h->P == (int)H, false)
                                                      : ctk_affine_rollout_name(cfg->predictor, mat);
     }
     if (cfg->optimizer != CTK_OPT_RPGD) TRY_CREATE(ctk_reset(h, nullptr, CTK_LOC_NONE));

@@ -12,7 +12,7 @@
     } while (0)
 
 // ---- ctk_mppi.hip ---------------------------------------------------------------------------
-const char* ctk_mppi_rollout_name(int pred, bool log, int N, bool identity_interp = false);
+const char* ctk_mppi_rollout_name(int pred, bool log, int N, bool identity_interp = false, bool have_samples = true);
 int ctk_mppi_num_blocks(int N, int pred);   // workgroups = block records of one rollout launch (64 trajectories each; GRU: 16)
 bool ctk_mppi_uses_throughput_kernel(int pred, int N);
 size_t ctk_mppi_rollout_lds(int P, int H, int pred = 0, int N = 1 << 30);
@@ -43,7 +43,8 @@ struct MppiFuse {
 };
 hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const MppiK& m,
                                    const float* samples, const float* u_nom, const float* wperm, float* parts, bool log,
-                                   const MppiFuse& fuse, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                                   const MppiFuse& fuse, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+                                   const char** ran = nullptr);   // *ran: name of the kernel this call launched
 hipError_t ctk_launch_mppi_merge_partial(hipStream_t st, const float* parts, int n_parts, int per_block, int P,
                                          float neg_inv_lbd, float* out_rec);
 // direct peer-to-peer record exchange + merge + update (ctk_mppi.hip: ctk_mppi_p2p_exchange)
@@ -111,6 +112,7 @@ size_t ctk_rpgd_scratch_floats(int pred, int N, int H);
 struct RpgdFusedWarm {
     int K; int* idx_out;
     int P, n_new, gather, shift_previous, sampling_distribution, fresh_tail;
+    int whole_space;      // sample_whole_control_space: uniform draws span the per-input limits (optimizer_rpgd.py:200-203)
     float sample_stdev, sample_mean, sample_min, sample_max;
     const float* draws; const float* ages_old;
     float* Q_new; float* m_new; float* v_new; float* ages_new;

@@ -792,12 +792,19 @@ static int kernel_pred(int pred, int N) {
     return (pred == CTK_PRED_MLP && N <= CTK_MPPI_PAIR_MAX_N && !off) ? CTK_PRED_MLP_PAIR : pred;
 }
 
-const char* ctk_mppi_rollout_name(int pred, bool log, int N, bool identity_interp) {
-    if (ctk_mppi_uses_throughput_kernel(pred, N)) {
-        // period 1: sample buffers take the streaming form (the in-kernel sampler keeps the tile form, ctk_mppi_rollout_tp)
-        if (identity_interp) return log ? "ctk_mppi_rollout_tps<true>" : "ctk_mppi_rollout_tps<false>";
-        return log ? "ctk_mppi_rollout_tp<true>" : "ctk_mppi_rollout_tp<false>";
-    }
+// which throughput form a launch takes: 2 = streaming (ctk_mppi_rollout_tps: sample buffer + identity interpolation), 1 = whole-horizon
+// tile (ctk_mppi_rollout_tp: in-kernel sampler, or P < H), 0 = not a throughput launch.  ONE predicate for the launcher and the name.
+static int throughput_form(int pred, int N, bool have_samples, bool identity_interp) {
+    if (!ctk_mppi_uses_throughput_kernel(pred, N)) return 0;
+    static const bool no_direct = getenv("CTK_MPPI_TP_TILE") != nullptr;   // diagnostic switch: A/B the two throughput forms
+    return (have_samples && identity_interp && !no_direct) ? 2 : 1;
+}
+
+// name of the kernel ctk_launch_mppi_rollout runs for these arguments (identity_interp as RolloutArgs carries it: period 1 AND P == H)
+const char* ctk_mppi_rollout_name(int pred, bool log, int N, bool identity_interp, bool have_samples) {
+    const int tf = throughput_form(pred, N, have_samples, identity_interp);
+    if (tf == 2) return log ? "ctk_mppi_rollout_tps<true>" : "ctk_mppi_rollout_tps<false>";
+    if (tf == 1) return log ? "ctk_mppi_rollout_tp<true>" : "ctk_mppi_rollout_tp<false>";
     if (pred == CTK_PRED_ODE) return log ? "ctk_mppi_rollout<0, true>" : "ctk_mppi_rollout<0, false>";
     if (pred == CTK_PRED_GRU) return log ? "ctk_mppi_rollout<2, true>" : "ctk_mppi_rollout<2, false>";
     if (kernel_pred(pred, N) == CTK_PRED_MLP_PAIR) return log ? "ctk_mppi_rollout<3, true>" : "ctk_mppi_rollout<3, false>";
@@ -835,11 +842,11 @@ static size_t rollout_launch_lds(int P, int H, int pred, int N, int blocks, int*
 
 hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const MppiK& m,
                                    const float* samples, const float* u_nom, const float* wperm, float* parts, bool log,
-                                   const MppiFuse& fuse, hipEvent_t e0, hipEvent_t e1) {
+                                   const MppiFuse& fuse, hipEvent_t e0, hipEvent_t e1, const char** ran) {
     const dim3 grid(ctk_mppi_num_blocks(a.N, pred)), block(MPPI_BLOCK);
-    if (ctk_mppi_uses_throughput_kernel(pred, a.N)) {
-        static const bool no_direct = getenv("CTK_MPPI_TP_TILE") != nullptr;   // diagnostic switch: A/B the two throughput forms
-        if (samples != nullptr && a.identity_interp && !no_direct) {
+    if (ran) *ran = ctk_mppi_rollout_name(pred, log, a.N, a.identity_interp != 0, samples != nullptr);
+    if (const int tf = throughput_form(pred, a.N, samples != nullptr, a.identity_interp != 0)) {
+        if (tf == 2) {
             const size_t lds_d = (size_t)(64 * TPS_LD + 64 + a.H) * sizeof(float);
             if (log) CTK_LAUNCH((ctk_mppi_rollout_tps<true>), grid, dim3(64), lds_d, st, e0, e1, a, k, m, samples, u_nom, parts);
             else CTK_LAUNCH((ctk_mppi_rollout_tps<false>), grid, dim3(64), lds_d, st, e0, e1, a, k, m, samples, u_nom, parts);

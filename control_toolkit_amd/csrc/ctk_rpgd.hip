@@ -846,7 +846,7 @@ hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& 
         FusedWarm x{};
         x.enabled = 1; x.K = f->K; x.idx_out = f->idx_out;
         x.w = WarmArgs{a.N, a.H, f->P, f->n_new, f->gather, f->shift_previous, f->sampling_distribution, 0,
-                       f->sample_stdev, f->sample_mean, f->sample_min, f->sample_max, 0, nullptr, 3 + 3 * a.H, 0, f->fresh_tail};
+                       f->sample_stdev, f->sample_mean, f->sample_min, f->sample_max, f->whole_space, nullptr, 3 + 3 * a.H, 0, f->fresh_tail};
         x.p = WarmPtrs{f->draws, nullptr, Q, m, v, f->ages_old, f->Q_new, f->m_new, f->v_new, f->ages_new,
                        f->interp, f->u_nom, f->u_dev, f->u_host, f->seq};
         return x;

@@ -16,7 +16,28 @@ def _bind_stream(engine, torch, device):
     the exchanged records, so they must be ordered with it: put the engine on the same stream (include/ctk_hip.h:
     ctk_set_stream).  CPU tensors (gloo tests with a stand-in engine): nothing to order."""
     if device is not None and getattr(device, "type", "cpu") == "cuda" and hasattr(engine, "set_stream"):
-        engine.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        handle = torch.cuda.current_stream(device).cuda_stream
+        engine.set_stream(handle)
+        return handle
+    return None
+
+
+class _StreamBound:
+    """begin -> collective -> end must run on ONE stream (they hand the `mine` / `all` record buffers to each other).  The
+    collective runs on whatever torch stream is current when step() is called, so step() re-binds the engine whenever
+    that stream is not the one bound last (a caller stepping under `with torch.cuda.stream(...)`): ctk_set_stream orders
+    the engine's earlier work before the new stream's (include/ctk_hip.h)."""
+
+    _bound = None
+
+    def _bind(self):
+        self._bound = _bind_stream(self.engine, self.torch, self.device)
+
+    def _rebind_if_stream_changed(self):
+        if self._bound is None:
+            return
+        if self.torch.cuda.current_stream(self.device).cuda_stream != self._bound:
+            self._bind()
 
 
 class _EngineSnapshot:
@@ -37,7 +58,7 @@ class _EngineSnapshot:
             self.engine.set_rng_position(self.call)
 
 
-class ShardedMPPI:
+class ShardedMPPI(_StreamBound):
     """exchange = "rccl": ctk_mppi_step_begin -> all_gather_into_tensor -> ctk_mppi_step_end.
     exchange = "p2p" : the ranks' exchange kernels store their records straight into each other's HBM over xGMI
     (ctk_p2p_*, HIP IPC mappings set up once through the process group): no collective launch and no host
@@ -59,7 +80,7 @@ class ShardedMPPI:
         self.all = torch.zeros(self.rec * world_size, dtype=torch.float32, device=self.device)
         self.exchange = "rccl"
         self.p2p_error = None
-        _bind_stream(engine, torch, self.device)
+        self._bind()
         if exchange == "p2p" and world_size > 1:
             self._try_p2p(device)
         elif exchange not in ("rccl", "p2p"):
@@ -122,6 +143,7 @@ class ShardedMPPI:
     def step(self, s, samples=None, u_prev=None) -> np.ndarray:
         """samples: this rank's slice of the draws (host array / device pointer) or None (device
         Philox addressed by GLOBAL rollout index, so the result does not depend on world_size)."""
+        self._rebind_if_stream_changed()
         if self.exchange == "p2p":
             return self.engine.p2p_step(s, samples, u_prev=u_prev)
         self.engine.mppi_step_begin(s, self.mine.data_ptr(), samples, u_prev=u_prev)
@@ -133,7 +155,7 @@ class ShardedMPPI:
         return self.engine.mppi_step_end(parts.data_ptr(), self.world_size)
 
 
-class ShardedTopK:
+class ShardedTopK(_StreamBound):
     """Sharded CEM / random-action: per outer iteration every rank rolls out its shard
     and contributes its best K plans as records {J, global index, Q[H]}; ONE all-gather of those records
     per iteration; every rank then selects the global best K from the union and (CEM) refits the same
@@ -146,12 +168,13 @@ class ShardedTopK:
         self.engine, self.rank, self.world_size, self.group = engine, rank, world_size, group
         self.rec = int(engine.shard_candidates_size())
         self.device = device if device is not None else torch.device("cpu")
-        _bind_stream(engine, torch, self.device)
+        self._bind()
         self.mine = torch.zeros(self.rec, dtype=torch.float32, device=self.device)
         self.all = torch.zeros(self.rec * world_size, dtype=torch.float32, device=self.device)
 
     def step(self, s, samples=None, u_prev=None) -> np.ndarray:
         """samples: None (device Philox by global rollout index) or this rank's draws [iterations, N_local, H, 1]."""
+        self._rebind_if_stream_changed()
         its = self.engine.shard_iterations()
         for it in range(its):
             smp = None if samples is None else samples[it]
@@ -165,7 +188,7 @@ class ShardedTopK:
         return self.engine.shard_finish()
 
 
-class ShardedRPGD:
+class ShardedRPGD(_StreamBound):
     """Sharded RPGD: the Adam descent is local; one all-gather per step of the shards'
     best plans WITH their optimizer state, after which every rank rebuilds its rows of the global
     population [fresh | keepers sorted by cost] exactly as one big optimizer would."""
@@ -177,7 +200,7 @@ class ShardedRPGD:
         self.engine, self.rank, self.world_size, self.group = engine, rank, world_size, group
         self.rec = int(engine.rpgd_keepers_size())
         self.device = device if device is not None else torch.device("cpu")
-        _bind_stream(engine, torch, self.device)
+        self._bind()
         self.mine = torch.zeros(self.rec, dtype=torch.float32, device=self.device)
         self.all = torch.zeros(self.rec * world_size, dtype=torch.float32, device=self.device)
 
@@ -186,6 +209,7 @@ class ShardedRPGD:
 
     def step(self, s, draws=None, u_prev=None) -> np.ndarray:
         """draws: None (device Philox by global row) or raw draws [fresh_rows(), P, 1] for this shard."""
+        self._rebind_if_stream_changed()
         self.engine.rpgd_step_begin(s, self.mine.data_ptr(), u_prev=u_prev)
         if self.world_size > 1:
             self.dist.all_gather_into_tensor(self.all, self.mine, group=self.group)

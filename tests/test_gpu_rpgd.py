@@ -227,3 +227,44 @@ def test_sharded_rpgd_two_shards_equal_one_handle(pred, host_draws):
             np.testing.assert_allclose(got, full.read(name), rtol=1e-6, atol=1e-7, err_msg=name)
     for e in sh + [full]:
         e.close()
+
+
+@pytest.mark.parametrize("pred_name,N", [("ODE", 64), ("ODE", 40), ("MLP", 32), ("ODE", 128)])
+def test_rpgd_whole_control_space_on_fused_and_unfused_steps(pred_name, N):
+    """optimizer_rpgd.py:200-203: with sample_whole_control_space the uniform draws span the control limits, not
+    [uniform_dist_min, uniform_dist_max].  The one-launch step (population within one workgroup: N <= 64 ODE, <= 32 MLP wide
+    form) must honour the flag like the separate warm-start launch (N = 128) does: limits +-0.6, sample range +-1."""
+    from control_toolkit_amd import CtkEngine
+    from gpu_helpers import apply_env
+    H, p, its = 12, 4, 2
+    env = O.EnvParams(terminal_weight=0.3)
+    w = O.mlp_default_weights(2) if pred_name == "MLP" else None
+    pred = O.Predictor(pred_name, dt=0.02, env=env, weights=w)
+    o = O.RPGD(pred, O.Cost(env), -0.6, 0.6, num_rollouts=N, mpc_horizon=H, outer_its=its, resamp_per=1,
+               period_interpolation_inducing_points=p, SAMPLING_DISTRIBUTION="uniform", shift_previous=1, learning_rate=0.05,
+               opt_keep_k_ratio=0.25, gradmax_clip=5.0, sample_whole_control_space=True, uniform_dist_min=-1.0, uniform_dist_max=1.0)
+    e = CtkEngine("rpgd", pred_name, num_rollouts=N, mpc_horizon=H, dt=0.02, action_low=-0.6, action_high=0.6,
+                  period_interpolation_inducing_points=p, outer_its=its, resamp_per=1, shift_previous=1, opt_keep_k=o.k,
+                  sampling_distribution=0, sample_whole_control_space=1, sample_min=-1.0, sample_max=1.0, learning_rate=0.05,
+                  gradmax_clip=5.0)
+    apply_env(e, env)
+    if w is not None:
+        e.set_predictor_weights(w)
+    rng = np.random.default_rng(N)
+    d0 = rng.random((N, o.P, 1), dtype=np.float32)
+    o.optimizer_reset(d0); e.reset(d0)
+    np.testing.assert_allclose(e.read("PLAN"), o.Q, rtol=1e-6, atol=1e-7)
+    s = np.array([0.05, 0.0, 2.9, 0.3], np.float32)
+    for t in range(2):                      # resamp_per = 1: every step resamples N - k plans
+        dr = rng.random((N - o.k, o.P, 1), dtype=np.float32)
+        uo = o.step(s, dr)
+        ug = e.step(s, dr)
+        fresh = e.read("PLAN")[: N - o.k]
+        # the fresh plans ARE the draws mapped to the limits: a sample range of +-1 clipped to +-0.6 would pile up at the limits
+        np.testing.assert_allclose(fresh, o.Q[: N - o.k], rtol=1e-6, atol=1e-7)
+        assert np.abs(fresh).max() <= 0.6 + 1e-6 and (np.abs(fresh) >= 0.6 - 1e-6).mean() < 0.02
+        np.testing.assert_allclose(e.read("PLAN"), o.Q, rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(ug[0], uo, rtol=2e-4, atol=2e-4)
+        e.set_state(state_vec(o.Q, o.opt.m, o.opt.v, o.trajectory_ages, float(o.u), o.opt.step_count, o.count))
+        s = pred.step(s.reshape(1, 4), np.array([uo], np.float32))[0]
+    e.close()

@@ -1,9 +1,6 @@
 #!/bin/bash
-# in-kernel wall-clock stamps of ctk_rpgd_mlp_wide (variant library built with -DCTK_DIAG_WIDE_STAMPS into tools/_variants/)
+# in-kernel wall-clock stamps of ctk_rpgd_mlp_wide (variant library built with -DCTK_DIAG_WIDE_STAMPS into tools/_variants/),
+# loaded through CTK_HIP_LIBRARY: the product library is never overwritten
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/split
-L=control_toolkit_amd/libctk_hip.so
-cp $L /tmp/libctk_orig.so
-cp tools/_variants/libctk_hip_WIDE_STAMPS.so $L
-python bench.py --workload rpgd_cfg4 --steps 6 --warmup 2 --no-cpu-baseline --no-modes --no-large-n 2>&1 | grep "wide stamps" | tail -5 | tee gpurun_out/split/stamps.txt
-cp /tmp/libctk_orig.so $L
+CTK_HIP_LIBRARY=$PWD/tools/_variants/libctk_hip_WIDE_STAMPS.so python bench.py --workload rpgd_cfg4 --steps 6 --warmup 2 --no-cpu-baseline --no-modes --no-large-n 2>&1 | grep "wide stamps" | tail -5 | tee gpurun_out/split/stamps.txt
