@@ -99,7 +99,7 @@ def gru_weights(seed=0):
     return np.concatenate([a.ravel() for a in parts]).astype(np.float32)
 
 
-def algorithmic(w, N, P, samples_in_hbm):
+def algorithmic(w, N, P, samples_in_hbm, kernel=""):
     """compulsory bytes (and network flops) of ONE launch of the dominant kernel over N rollouts."""
     H, C, S = w["H"], 1, 4
     flops = None
@@ -109,9 +109,11 @@ def algorithmic(w, N, P, samples_in_hbm):
             flops = 2624 * N * H
         elif w["pred"] == "GRU":   # 2 * (96*5 + 96*32 + 2*96*32 + 4*32) multiply-adds per trajectory step
             flops = 19648 * N * H
-    elif w["opt"] == "cem":      # one outer iteration = one rollout launch
+    elif w["opt"] == "cem":      # one outer iteration = one rollout launch; the one-launch step (ctk_cem_fused) runs all of them
         K = w["kw"]["cem_best_k"]
         b = (4 * N * H * C if samples_in_hbm else 0) + 4 * N + 4 * K * H * C + 8 * H * C
+        if kernel.startswith("ctk_cem_fused"):
+            b *= w["kw"]["cem_outer_it"]
     elif w["opt"] == "rpgd":     # one descent launch = outer_its Adam iterations + the final cost pass
         its = w["kw"]["outer_its"]
         b = its * (24 * N * H * C + 4 * N) + 4 * N * H * C + 4 * N
@@ -476,9 +478,9 @@ def main():
         total_units = Ng * H * args.steps
         kms = float(np.mean(kern_ms)) if len(kern_ms) else float("nan")
         samples_in_hbm = samples == "buffer" and w["opt"] in ("mppi", "cem", "random_action")
-        alg_bytes, alg_flops = algorithmic(w, N, P, samples_in_hbm)
-        ok = kms == kms and kms > 0
         kname = eng.dominant_kernel()
+        alg_bytes, alg_flops = algorithmic(w, N, P, samples_in_hbm, kname)
+        ok = kms == kms and kms > 0
         if alg_flops is not None:
             ach = alg_flops / (kms * 1e-3) / 1e12 if ok else None
             roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",

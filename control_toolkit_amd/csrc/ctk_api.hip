@@ -48,6 +48,9 @@ struct ctk_handle {
     float* d_parts3 = nullptr;
     unsigned* d_counter = nullptr;   // ticket counter of the fused in-launch merge
     unsigned long long* d_ll = nullptr;   // {value, seq} record words of the low-latency in-launch hand-off
+    unsigned long long* d_cem_ll = nullptr;   // hand-off words of the one-launch CEM step (ctk_cem_fused.hip); nullptr: not fusable
+    uint32_t cem_tag = 1;                 // next hand-off tag (one per outer iteration, consecutive across launches)
+    bool idx_stale = false;               // the one-launch CEM step leaves only idx[0]; BEST_IDX is rebuilt from J on demand
     float* d_unom[2] = {nullptr, nullptr};   // MPPI u_nom ping-pong / CEM mu in [0]
     int cur = 0;
     float* d_std = nullptr;     // CEM
@@ -449,6 +452,10 @@ int locate_buffer(ctk_handle* h, int which, const float** src_out, size_t* n_out
         case CTK_BUF_U_NOM: src = h->d_unom[h->cfg.optimizer == CTK_OPT_MPPI ? h->cur : 0]; n = H; break;
         case CTK_BUF_STD: src = h->d_std; n = H; break;
         case CTK_BUF_BEST_IDX:
+            if (h->idx_stale) {   // one-launch CEM step: the sorted elite indices are materialised from the last iteration's costs
+                HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, h->cfg.cem_best_k, h->d_idx));
+                h->idx_stale = false;
+            }
             src = (const float*)h->d_idx; is_int = true;
             n = h->cfg.optimizer == CTK_OPT_CEM ? (size_t)h->cfg.cem_best_k : (h->cfg.optimizer == CTK_OPT_RPGD ? (size_t)h->cfg.opt_keep_k : 1);
             break;
@@ -752,6 +759,20 @@ int cem_step(ctk_handle* h, const float* s, const float* u_prev, const float* sa
         ++h->count;
         return finish_step(h, u_out);
     }
+    if (h->d_cem_ll && h->variant == CTK_OPT_CEM && h->cfg.cem_best_k <= h->N) {
+        // ONE launch: all outer iterations, selection and refit between workgroups inside it (ctk_cem_fused.hip)
+        RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);
+        const ctk_config& c = h->cfg;
+        if ((uint32_t)(h->cem_tag + (uint32_t)its) < h->cem_tag) h->cem_tag = 1;   // wrapped: tag 0 is the never-written value
+        const CemFusedLaunch cl{its, c.cem_best_k, h->d_cem_ll, h->cem_tag, c.cem_stdev_min, 1.0e8f, c.cem_initial_action_stdev,
+                                (c.action_low[0] + c.action_high[0]) * 0.5f, mu, h->d_std, h->d_u, h->h_u_dev, h->d_idx, h->seq, 0.5};
+        h->cem_tag += (uint32_t)its;
+        ProfSlot ps(h);
+        HIP_TRY(h, ctk_launch_cem_fused(h->stream, a, h->k, d_s, cl, log, ps.a, ps.b));
+        h->idx_stale = true;
+        ++h->count;
+        return finish_step(h, u_out);
+    }
     for (int it = 0; it < its; ++it) {
         RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);
         a.stream_id = (uint32_t)it;
@@ -1021,6 +1042,8 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     TRY_CREATE(dev_alloc(h, &h->d_rec, 2 + PC));
     TRY_CREATE(dev_alloc(h, &h->d_counter, 1));
     if (!generic && nblk <= (size_t)CTK_MPPI_FUSE_MAX_BLOCKS_LL && !std::getenv("CTK_NO_LL")) TRY_CREATE(dev_alloc(h, &h->d_ll, nblk * (2 + P)));
+    if (!generic && cfg->optimizer == CTK_OPT_CEM && ctk_cem_fusable(cfg->predictor, (int)N, (int)H) && !std::getenv("CTK_NO_CEM_FUSED"))
+        TRY_CREATE(dev_alloc(h, &h->d_cem_ll, ctk_cem_fused_ll_words((int)N, (int)H)));
     TRY_CREATE(dev_alloc(h, &h->d_unom[0], HC));
     TRY_CREATE(dev_alloc(h, &h->d_unom[1], HC));
     TRY_CREATE(dev_alloc(h, &h->d_std, HC));
@@ -1067,6 +1090,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
                     : cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_name(cfg->predictor, mat, cfg->num_rollouts, cfg->period_interpolation_inducing_points == 1 && h->P == (int)H, false)
                                                      : ctk_affine_rollout_name(cfg->predictor, mat);
     }
+    if (h->d_cem_ll && h->variant == CTK_OPT_CEM && cfg->cem_best_k <= (int)N) h->dominant = ctk_cem_fused_name(mat);
     if (cfg->optimizer != CTK_OPT_RPGD) TRY_CREATE(ctk_reset(h, nullptr, CTK_LOC_NONE));
     HIP_CREATE(hipStreamSynchronize(h->stream));
     *out = h;
@@ -1081,7 +1105,7 @@ void ctk_destroy(ctk_handle* h) {
     hipStreamSynchronize(h->stream);   // also correct for the null (default) stream handed in by ctk_set_stream
     for (auto& e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     void* bufs[] = {h->d_interp, h->d_samples, h->d_J, h->d_Q, h->d_traj, h->d_parts, h->d_parts2, h->d_parts3, h->d_unom[0], h->d_unom[1],
-                    h->d_std, h->d_base, h->d_scale, h->d_idx, h->d_u, h->d_weights, h->d_wperm, h->d_counter, h->d_ll, h->d_rec,
+                    h->d_std, h->d_base, h->d_scale, h->d_idx, h->d_u, h->d_weights, h->d_wperm, h->d_counter, h->d_ll, h->d_cem_ll, h->d_rec,
                     h->d_pop[0], h->d_pop[1], h->d_m[0], h->d_m[1], h->d_v[0], h->d_v[1], h->d_ages[0], h->d_ages[1], h->d_bc, h->d_scratch};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->d_shard_idx) hipFree(h->d_shard_idx);

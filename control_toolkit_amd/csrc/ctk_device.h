@@ -31,6 +31,18 @@ CTK_DEV float wave_reduce(float v, Op op) {
 CTK_DEV float wave_min(float v) { return wave_reduce(v, [](float a, float b) { return fminf(a, b); }); }
 CTK_DEV float wave_sum(float v) { return wave_reduce(v, [](float a, float b) { return a + b; }); }
 
+// order-preserving map float -> uint32 (total order; -0.0 < +0.0, NaNs sort last)
+CTK_DEV uint32_t f32_sortable(float f) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+CTK_DEV uint32_t wave_min_u32(uint32_t v) {
+    return __builtin_bit_cast(uint32_t, wave_reduce(__builtin_bit_cast(float, v), [](float a, float b) {
+        const uint32_t x = __builtin_bit_cast(uint32_t, a), y = __builtin_bit_cast(uint32_t, b);
+        return __builtin_bit_cast(float, x < y ? x : y);
+    }));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Cart-pole (build-defined predictor, oracle/ctk_oracle.py:Predictor._ode_step).  One explicit
 // Euler sub-step; sn/cs = sin/cos of the CURRENT angle (shared with the stage cost).

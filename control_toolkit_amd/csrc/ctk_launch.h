@@ -99,6 +99,23 @@ hipError_t ctk_launch_cem_finish(hipStream_t st, const float* Q, const int* idx,
 hipError_t ctk_launch_pick_best_first(hipStream_t st, const float* Q, const int* idx, int H, float* u_dev, float* u_host, uint32_t seq,
                                       int ldq);
 
+// ---- ctk_cem_fused.hip : one CEM step (all outer iterations) in ONE launch, CartPole ODE ---------
+constexpr int CTK_CEM_FUSED_MAX_BLOCKS = 128;     // workgroups of 64 rollouts, all co-resident (one per CU)
+struct CemFusedLaunch {
+    int its, K;                   // outer iterations of this step (optimizer_cem_tf.py:92), cem_best_k
+    unsigned long long* ll;       // ctk_cem_fused_ll_words(N, H) hand-off words, zero at allocation
+    uint32_t tag0;                // tags tag0 .. tag0 + its - 1: consecutive across launches
+    float std_min, std_max, init_std, mid;
+    float* mu; float* sd;         // [H] the handle's distribution, in / out
+    float* u_dev; float* u_host; int* idx_out; uint32_t seq;
+    double timeout_s;             // wall-clock bound of every in-launch wait
+};
+bool ctk_cem_fusable(int pred, int N, int H);
+size_t ctk_cem_fused_ll_words(int N, int H);
+const char* ctk_cem_fused_name(bool log);
+hipError_t ctk_launch_cem_fused(hipStream_t st, const RolloutArgs& a, const EnvK& k, const float* samples, const CemFusedLaunch& c, bool log,
+                                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+
 // ---- ctk_rpgd.hip ---------------------------------------------------------------------------
 const char* ctk_rpgd_descent_name(int pred, int N);
 constexpr int CTK_RPGD_WIDE_MAX_N = 4096;

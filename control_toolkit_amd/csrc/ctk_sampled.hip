@@ -26,18 +26,6 @@ __host__ __device__ inline int affine_carve_floats(int H, int traj) {
 }
 __host__ __device__ inline int affine_traj(int pred) { return pred == CTK_PRED_GRU ? GRU_TRAJ : SAMP_TRAJ; }
 
-// order-preserving map float -> uint32 (total order; -0.0 < +0.0, NaNs sort last)
-CTK_DEV uint32_t f32_sortable(float f) {
-    const uint32_t u = __builtin_bit_cast(uint32_t, f);
-    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-}
-CTK_DEV uint32_t wave_min_u32(uint32_t v) {
-    return __builtin_bit_cast(uint32_t, wave_reduce(__builtin_bit_cast(float, v), [](float a, float b) {
-        const uint32_t x = __builtin_bit_cast(uint32_t, a), y = __builtin_bit_cast(uint32_t, b);
-        return __builtin_bit_cast(float, x < y ? x : y);
-    }));
-}
-
 // Optional in-launch arg-min tail (random-action, optimizer_random_action_tf.py:62-68: u = first input of the cheapest
 // plan): every block hands {key(J), index, first input} of its cheapest rollout to block 0 as {payload, sequence number}
 // words (the hand-off form of ctk_mppi.hip), block 0 picks the global minimum under the total order (J, index) — what

@@ -11,21 +11,25 @@ from gpu_helpers import apply_env
 pytestmark = pytest.mark.gpu
 
 
-def make_cem(N, H, K, its, env, **kw):
+def make_cem(N, H, K, its, env, mat=True, **kw):
     pred = O.Predictor("ODE", dt=0.02, env=env)
     o = O.CEM(pred, O.Cost(env), num_rollouts=N, mpc_horizon=H, cem_outer_it=its, cem_best_k=K, **kw)
     e = CtkEngine("cem", "ODE", num_rollouts=N, mpc_horizon=H, dt=0.02, cem_outer_it=its, cem_best_k=K,
                   cem_initial_action_stdev=kw.get("cem_initial_action_stdev", 0.5), cem_stdev_min=kw.get("cem_stdev_min", 0.01),
                   warmup=int(kw.get("warmup", False)), warmup_iterations=kw.get("warmup_iterations", 250),
-                  materialize_trajectories=True)
+                  materialize_trajectories=mat)
     apply_env(e, env)
     return pred, o, e
 
 
-@pytest.mark.parametrize("N,H,K,its", [(4096, 30, 409, 3), (200, 40, 40, 3), (64, 8, 64, 1), (100, 5, 1, 2)])
-def test_cem_matches_oracle(N, H, K, its):
+# every size up to 128 workgroups runs the ONE-launch step (ctk_cem_fused.hip; <true> with trajectories, <false> without — the
+# benchmarked instantiation); (16384, ...) is beyond it and takes the launch-per-phase form
+@pytest.mark.parametrize("mat", [True, False])
+@pytest.mark.parametrize("N,H,K,its", [(4096, 30, 409, 3), (200, 40, 40, 3), (64, 8, 64, 1), (100, 5, 1, 2), (16384, 12, 900, 2)])
+def test_cem_matches_oracle(N, H, K, its, mat):
     env = O.EnvParams(terminal_weight=0.2)
-    pred, o, e = make_cem(N, H, K, its, env)
+    pred, o, e = make_cem(N, H, K, its, env, mat=mat)
+    assert e.dominant_kernel().startswith("ctk_cem_fused") == (N <= 8192)
     rng = np.random.default_rng(N)
     s = np.array([0.02, 0.1, 2.9, -0.5], np.float32)
     for t in range(3):
@@ -46,9 +50,77 @@ def test_cem_matches_oracle(N, H, K, its):
         np.testing.assert_allclose(e.read("U_NOM"), o.dist_mue, rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(e.read("STD"), o.stdev, rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(ug[0], uo, rtol=1e-5, atol=2e-6)
-        np.testing.assert_allclose(e.read("TRAJ"), o.rollout_trajectories, rtol=1e-4, atol=4e-5)
+        if mat:
+            np.testing.assert_allclose(e.read("TRAJ"), o.rollout_trajectories, rtol=1e-4, atol=4e-5)
         s = pred.step(s.reshape(1, 4), np.array([uo], np.float32))[0]
     e.close()
+
+
+def _cem_pair(monkeypatch, **kw):
+    """the same configuration as the one-launch step and (CTK_NO_CEM_FUSED at creation) as the launch-per-phase form"""
+    fused = CtkEngine("cem", "ODE", **kw)
+    monkeypatch.setenv("CTK_NO_CEM_FUSED", "1")
+    plain = CtkEngine("cem", "ODE", **kw)
+    monkeypatch.delenv("CTK_NO_CEM_FUSED")
+    assert fused.dominant_kernel().startswith("ctk_cem_fused") and plain.dominant_kernel().startswith("ctk_affine_rollout")
+    return fused, plain
+
+
+@pytest.mark.parametrize("N,H,K,its", [(4096, 30, 409, 3), (1000, 17, 77, 4), (8192, 10, 8000, 2)])
+def test_cem_one_launch_equals_launch_per_phase_device_rng(monkeypatch, N, H, K, its):
+    """in-kernel sampler (Philox keyed by global row / iteration): both forms see the same draws; closed loop over 5 steps"""
+    fused, plain = _cem_pair(monkeypatch, num_rollouts=N, mpc_horizon=H, dt=0.02, cem_outer_it=its, cem_best_k=K, seed=7)
+    pred = O.Predictor("ODE", dt=0.02, env=O.EnvParams())
+    s = np.array([0.02, 0.1, 2.9, -0.5], np.float32)
+    for t in range(5):
+        uf, up = fused.step(s), plain.step(s)
+        np.testing.assert_allclose(uf, up, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(fused.read("U_NOM"), plain.read("U_NOM"), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(fused.read("STD"), plain.read("STD"), rtol=5e-5, atol=1e-6)
+        np.testing.assert_allclose(fused.read("J"), plain.read("J"), rtol=3e-5)
+        np.testing.assert_array_equal(fused.read("BEST_IDX")[0], plain.read("BEST_IDX")[0])
+        s = pred.step(s.reshape(1, 4), np.asarray(up, np.float32))[0]
+    fused.close(); plain.close()
+
+
+@pytest.mark.parametrize("K", [31, 32, 1, 255])
+def test_cem_one_launch_breaks_cost_ties_by_index(monkeypatch, K):
+    """every plan appears twice (rows n and n + 128): each cost is an exact tie and an odd K cuts a pair — the elite set must be
+    the first K of (cost, index), as tf.argsort / ctk_select_topk give it; a wrong tie rule changes the refit visibly"""
+    N, H = 256, 9
+    fused, plain = _cem_pair(monkeypatch, num_rollouts=N, mpc_horizon=H, dt=0.02, cem_outer_it=2, cem_best_k=K)
+    rng = np.random.default_rng(K)
+    noise = rng.standard_normal((2, N, H, 1)).astype(np.float32)
+    noise[:, N // 2:] = noise[:, : N // 2]
+    s = np.array([0.0, 0.0, 1.0, 0.0], np.float32)
+    uf, up = fused.step(s, noise), plain.step(s, noise)
+    J = fused.read("J")
+    assert np.array_equal(J[: N // 2], J[N // 2:])
+    np.testing.assert_array_equal(fused.read("BEST_IDX"), np.argsort(J, kind="stable")[:K])
+    np.testing.assert_allclose(fused.read("U_NOM"), plain.read("U_NOM"), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(fused.read("STD"), plain.read("STD"), rtol=5e-5, atol=1e-6)
+    np.testing.assert_allclose(uf, up, rtol=1e-6, atol=1e-7)
+    fused.close(); plain.close()
+
+
+@pytest.mark.parametrize("N,K,groups", [(2048, 100, 1), (2048, 700, 1), (4096, 409, 3), (1536, 1000, 2)])
+def test_cem_one_launch_with_many_equal_costs(monkeypatch, N, K, groups):
+    """`groups` distinct plans, each repeated N / groups times: more equal costs than the selection's second stage holds, so
+    the one-launch step takes its radix-pass fallback and ranks the ties by index; elite set == first K of (cost, index)"""
+    H = 6
+    fused, plain = _cem_pair(monkeypatch, num_rollouts=N, mpc_horizon=H, dt=0.02, cem_outer_it=2, cem_best_k=K)
+    rng = np.random.default_rng(N + K)
+    base = rng.standard_normal((2, groups, H, 1)).astype(np.float32)
+    noise = np.ascontiguousarray(base[:, np.arange(N) % groups])
+    s = np.array([0.0, 0.0, 1.0, 0.0], np.float32)
+    uf, up = fused.step(s, noise), plain.step(s, noise)
+    J = fused.read("J")
+    assert len(np.unique(J)) <= groups
+    np.testing.assert_array_equal(fused.read("BEST_IDX"), np.argsort(J, kind="stable")[:K])
+    np.testing.assert_allclose(fused.read("U_NOM"), plain.read("U_NOM"), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(fused.read("STD"), plain.read("STD"), rtol=5e-5, atol=1e-6)
+    np.testing.assert_allclose(uf, up, rtol=1e-6, atol=1e-7)
+    fused.close(); plain.close()
 
 
 def test_cem_warmup_and_reset():
