@@ -547,9 +547,15 @@ int check_predictor(ctk_handle* h) {
 
 // ---- MPPI ------------------------------------------------------------------------------------
 int mppi_block_parts(const ctk_handle* h) { return h->generic ? ctk_g_rollout_blocks(h->N) : ctk_mppi_num_blocks(h->N, h->cfg.predictor); }
+// template path: the analytic predictor of ANY environment runs the 4-wave kernel of ctk_mppi.hip (in-launch hand-off included)
+// below the throughput sizes; its network predictors keep the one-wave kernels of ctk_generic_net.hip
+bool mppi_env_kernel(const ctk_handle* h) {
+    return h->generic && h->cfg.predictor == CTK_PRED_ODE && !ctk_mppi_uses_throughput_kernel(CTK_PRED_ODE, h->N) &&
+           ctk_mppi_rollout_env_lds(h->env, h->P, h->H, h->N) <= 160 * 1024;
+}
 bool mppi_can_fuse(const ctk_handle* h) {
-    return !h->generic && !ctk_mppi_uses_throughput_kernel(h->cfg.predictor, h->N) &&
-           ctk_mppi_fusable(h->P, mppi_block_parts(h), h->d_ll != nullptr);
+    if (h->generic) return mppi_env_kernel(h) && ctk_mppi_fusable(h->PC, mppi_block_parts(h), h->d_ll != nullptr);
+    return !ctk_mppi_uses_throughput_kernel(h->cfg.predictor, h->N) && ctk_mppi_fusable(h->P, mppi_block_parts(h), h->d_ll != nullptr);
 }
 
 // fuse_mode: 0 block records only; 1 the last block also merges + updates (single-GPU step);
@@ -561,6 +567,15 @@ int mppi_rollout(ctk_handle* h, const float* s, const float* u_prev, const float
     RolloutArgs a = make_args(h, s, u_prev, h->N, h->P);
     const bool log = h->cfg.materialize_trajectories != 0;
     if (int rc = check_predictor(h)) return rc;
+    if (mppi_env_kernel(h)) {
+        MppiFuse fz;
+        fz.mode = fuse_mode; fz.counter = h->d_counter; fz.out_rec = partial_dev; fz.ll = h->d_ll;
+        fz.u_nom_out = h->d_unom[h->cur ^ 1]; fz.u_dev = h->d_u; fz.u_host = h->h_u_dev; fz.seq = h->seq;
+        ProfSlot ps(h);
+        HIP_TRY(h, ctk_launch_mppi_rollout_env(h->stream, h->env, h->params, h->cfg.dt, h->cfg.intermediate_steps, a, h->mk, d_s, h->d_unom[h->cur],
+                                               h->d_parts, log, fz, ps.a, ps.b));
+        return CTK_OK;
+    }
     if (h->generic) {   // template kernel: block records only (merged by the launches that follow)
         ProfSlot ps(h);
         if (h->cfg.predictor != CTK_PRED_ODE)
@@ -1041,7 +1056,8 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     TRY_CREATE(dev_alloc(h, &h->d_parts3, ((nblk + 1023) / 1024) * (2 + PC)));
     TRY_CREATE(dev_alloc(h, &h->d_rec, 2 + PC));
     TRY_CREATE(dev_alloc(h, &h->d_counter, 1));
-    if (!generic && nblk <= (size_t)CTK_MPPI_FUSE_MAX_BLOCKS_LL && !std::getenv("CTK_NO_LL")) TRY_CREATE(dev_alloc(h, &h->d_ll, nblk * (2 + P)));
+    if ((!generic || cfg->predictor == CTK_PRED_ODE) && nblk <= (size_t)CTK_MPPI_FUSE_MAX_BLOCKS_LL && !std::getenv("CTK_NO_LL"))
+        TRY_CREATE(dev_alloc(h, &h->d_ll, nblk * (2 + PC)));
     if (!generic && cfg->optimizer == CTK_OPT_CEM && ctk_cem_fusable(cfg->predictor, (int)N, (int)H) && !std::getenv("CTK_NO_CEM_FUSED"))
         TRY_CREATE(dev_alloc(h, &h->d_cem_ll, ctk_cem_fused_ll_words((int)N, (int)H)));
     TRY_CREATE(dev_alloc(h, &h->d_unom[0], HC));
@@ -1091,6 +1107,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
                                                      : ctk_affine_rollout_name(cfg->predictor, mat);
     }
     if (h->d_cem_ll && h->variant == CTK_OPT_CEM && cfg->cem_best_k <= (int)N) h->dominant = ctk_cem_fused_name(mat);
+    if (cfg->optimizer == CTK_OPT_MPPI && mppi_env_kernel(h)) h->dominant = ctk_mppi_rollout_env_name(h->env, mat);
     if (cfg->optimizer != CTK_OPT_RPGD) TRY_CREATE(ctk_reset(h, nullptr, CTK_LOC_NONE));
     HIP_CREATE(hipStreamSynchronize(h->stream));
     *out = h;

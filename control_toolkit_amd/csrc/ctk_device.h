@@ -232,6 +232,17 @@ CTK_DEV void publish_u(float* u_dev, float* u_host, float u, uint32_t seq) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(u_host), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// {u[C], seq} to the pinned host slot: the vector first (floats 4..), then ONE 8-byte release store {u[0], seq} the
+// host polls (ctk_api.hip:finish_step) — the release orders the vector's stores before it.  Single thread.
+CTK_DEV void publish_u_vec(float* u_dev, float* u_host, const float* u, int C, uint32_t seq) {
+    for (int c = 0; c < C; ++c) {
+        u_dev[c] = u[c];
+        __hip_atomic_store(u_host + 4 + c, u[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const unsigned long long v = ((unsigned long long)seq << 32) | (unsigned long long)__builtin_bit_cast(unsigned, u[0]);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(u_host), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Kernel-argument prefetch.  Arguments are read with scalar loads at their points of use; the scalar
 // cache is cold at every launch and each first touch of a 64-B line of the kernarg segment is a
 // full memory round trip (~1-2 k cycles), paid serially wherever the compiler sank the load

@@ -54,6 +54,32 @@ struct Env<CTK_ENV_CARTPOLE> {
     CTK_DEV static float terminal_cost(const K& k, const float (&s)[S]) {
         return ::terminal_cost(k, State4{s[0], s[1], s[2], s[3]});
     }
+    // ---- hooks of the 4-wave rollout kernels (ctk_mppi.hip): the stage cost splits into a state part and an input-only part
+    //      (summed off the recurrence); the recurrence consumes the inputs in the form prep_input() stored them ----------------
+    static constexpr bool SEPARABLE = true;
+    CTK_DEV static float input_cost(const K& k, const float (&u)[C], const float (&up)[C]) { return stage_cost_input(k, u[0], up[0]); }
+    CTK_DEV static float prep_input(const K& k, float u, int /*c*/) { return k.u_max * u; }   // the force
+    CTK_DEV static bool fast_ok(const K& k) { return k.intermediate_steps == 1; }
+    CTK_DEV static bool out_of_range(float amax) { return !(amax <= CTK_SINCOS_FAST_LIMIT); }
+    // stage cost of the state (dd + ep + ekp), then s <- step(s, f).  FAST: unchecked sincos shared by cost and dynamics, one
+    // Euler sub-step, max |angle| tracked in amax (the caller re-runs an out-of-range wave with FAST = false)
+    template <bool FAST>
+    CTK_DEV static void cost_step(const K& k, float (&s)[S], const float (&f)[C], float& csum, float& amax) {
+        State4 st{s[0], s[1], s[2], s[3]};
+        float sn, cs;
+        if constexpr (FAST) { ctk_sincosf_fast(st.th, &sn, &cs); amax = fmaxf(amax, fabsf(st.th)); }
+        else ctk_sincosf(st.th, &sn, &cs);
+        csum += stage_cost_state(k, st, cs);
+        ode_substep(k, st, f[0], sn, cs);
+        if constexpr (!FAST) {
+            for (int i = 1; i < k.intermediate_steps; ++i) {
+                float sn2, cs2;
+                ctk_sincosf(st.th, &sn2, &cs2);
+                ode_substep(k, st, f[0], sn2, cs2);
+            }
+        }
+        s[0] = st.x; s[1] = st.v; s[2] = st.th; s[3] = st.om;
+    }
     // adjoint of one Euler step (intermediate_steps == 1): lam = dL/ds' -> ds = dL/ds, du = dL/du
     CTK_DEV static void step_vjp(const K& k, const float (&s)[S], const float (&u)[C], const float (&lam)[S], float (&ds)[S],
                                  float (&du)[C]) {
@@ -164,6 +190,38 @@ struct Env<CTK_ENV_QUAD2D> {
         return state_terms(k, s) + vel + k.ccR * (u[0] * u[0] + u[1] * u[1]) + k.ccrc_weight * (d0 * d0 + d1 * d1);
     }
     CTK_DEV static float terminal_cost(const K& k, const float (&s)[S]) { return k.terminal_weight * state_terms(k, s); }
+    // hooks of the 4-wave rollout kernels (see CartPole): inputs are consumed as they are; sin / cos of the attitude are shared
+    // by the cost's 1 - cos(theta) and the first Euler sub-step
+    static constexpr bool SEPARABLE = true;
+    CTK_DEV static float input_cost(const K& k, const float (&u)[C], const float (&up)[C]) {
+        const float d0 = u[0] - up[0], d1 = u[1] - up[1];
+        return k.ccR * (u[0] * u[0] + u[1] * u[1]) + k.ccrc_weight * (d0 * d0 + d1 * d1);
+    }
+    CTK_DEV static float prep_input(const K&, float u, int /*c*/) { return u; }
+    CTK_DEV static bool fast_ok(const K&) { return true; }
+    CTK_DEV static bool out_of_range(float amax) { return !(amax <= CTK_SINCOS_FAST_LIMIT); }
+    template <bool FAST>
+    CTK_DEV static void cost_step(const K& k, float (&s)[S], const float (&u)[C], float& csum, float& amax) {
+        float sn, cs;
+        if constexpr (FAST) { ctk_sincosf_fast(s[4], &sn, &cs); amax = fmaxf(amax, fabsf(s[4])); }
+        else ctk_sincosf(s[4], &sn, &cs);
+        const float dx = s[0] - k.tx, dz = s[2] - k.tz;
+        csum += k.pos_c * (dx * dx + dz * dz) + k.ang_w * (1.0f - cs) + k.vel_w * (s[1] * s[1] + s[3] * s[3]) + k.angvel_w * s[5] * s[5];
+        const float aF = k.g + k.kF * (u[0] + u[1]);
+        const float aM = k.kM * (u[0] - u[1]);
+        for (int i = 0; i < k.intermediate_steps; ++i) {
+            if (i > 0) {
+                if constexpr (FAST) { ctk_sincosf_fast(s[4], &sn, &cs); amax = fmaxf(amax, fabsf(s[4])); }
+                else ctk_sincosf(s[4], &sn, &cs);
+            }
+            const float ax = -aF * sn - k.c_v * s[1];
+            const float az = aF * cs - k.g - k.c_v * s[3];
+            const float al = aM - k.c_w * s[5];
+            const float nx = s[0] + k.dt * s[1], nvx = s[1] + k.dt * ax, nz = s[2] + k.dt * s[3], nvz = s[3] + k.dt * az;
+            const float nth = s[4] + k.dt * s[5], nom = s[5] + k.dt * al;
+            s[0] = nx; s[1] = nvx; s[2] = nz; s[3] = nvz; s[4] = nth; s[5] = nom;
+        }
+    }
 
     CTK_DEV static void step_vjp(const K& k, const float (&s)[S], const float (&u)[C], const float (&lam)[S], float (&ds)[S],
                                  float (&du)[C]) {
@@ -207,6 +265,51 @@ struct Env<CTK_ENV_QUAD2D> {
         }
     }
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// The recurrence of the 4-wave rollout kernels, for any environment: steps [hb, he) of ONE trajectory per lane.  F: the
+// trajectory's prepared inputs [H*C] in LDS (Env::prep_input form), read one step ahead of their use; s / csum / amax are
+// carried so that the caller may split the horizon (ctk_mppi_rollout runs the first steps while the other waves still
+// prepare the inputs of the later ones).  traj: this trajectory's [H+1, S] rows (WRITE_TRAJ) or nullptr.
+// ---------------------------------------------------------------------------------------------------------------
+template <int S>
+CTK_DEV void store_state(float* dst, const float (&s)[S]) {
+    if constexpr (S % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < S / 4; ++i) reinterpret_cast<float4*>(dst)[i] = make_float4(s[4 * i], s[4 * i + 1], s[4 * i + 2], s[4 * i + 3]);
+    } else if constexpr (S % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < S / 2; ++i) reinterpret_cast<float2*>(dst)[i] = make_float2(s[2 * i], s[2 * i + 1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < S; ++i) dst[i] = s[i];
+    }
+}
+
+template <int ENV, bool WRITE_TRAJ, bool FAST>
+CTK_DEV void recur_env_range(const typename Env<ENV>::K& k, float* traj, bool valid, const float* F, int hb, int he,
+                             float (&s)[Env<ENV>::S], float& csum, float& amax) {
+    using E = Env<ENV>;
+    constexpr int C = E::C, S = E::S;
+    if (hb >= he) return;
+    float fn[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) fn[c] = F[hb * C + c];
+#pragma unroll 2
+    for (int h = hb; h < he; ++h) {
+        float f[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) f[c] = fn[c];
+        if (h + 1 < he) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) fn[c] = F[(h + 1) * C + c];
+        }
+        if constexpr (WRITE_TRAJ) {
+            if (valid && traj) store_state<S>(traj + (size_t)h * S, s);
+        }
+        E::template cost_step<FAST>(k, s, f, csum, amax);
+    }
+}
 
 // dispatch on the runtime environment id: CTK_FOR_ENV(id, ENVV, stmt) runs `stmt` with the constant ENVV
 #define CTK_FOR_ENV(id, ENVV, ...)                                              \

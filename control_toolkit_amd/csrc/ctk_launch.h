@@ -15,7 +15,7 @@
 const char* ctk_mppi_rollout_name(int pred, bool log, int N, bool identity_interp = false, bool have_samples = true);
 int ctk_mppi_num_blocks(int N, int pred);   // workgroups = block records of one rollout launch (64 trajectories each; GRU: 16)
 bool ctk_mppi_uses_throughput_kernel(int pred, int N);
-size_t ctk_mppi_rollout_lds(int P, int H, int pred = 0, int N = 1 << 30);
+size_t ctk_mppi_rollout_lds(int P, int H, int pred = 0, int N = 1 << 30, int C = 1);
 // MLP, N <= CTK_MPPI_PAIR_MAX_N: workgroups of 32 trajectories with a tile's network step shared by two waves (ctk_mlp.h:
 // mlp_step_pair) — at these sizes 16 trajectories per wave leave half of the chip's SIMDs idle.
 constexpr int CTK_MPPI_PAIR_MAX_N = 8192;
@@ -45,6 +45,12 @@ hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& 
                                    const float* samples, const float* u_nom, const float* wperm, float* parts, bool log,
                                    const MppiFuse& fuse, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
                                    const char** ran = nullptr);   // *ran: name of the kernel this call launched
+// the 4-wave kernel for any environment's analytic predictor (a.P inducing points, a.C inputs; constants derived from `params`)
+hipError_t ctk_launch_mppi_rollout_env(hipStream_t st, int env, const float* params, float dt, int isteps, const RolloutArgs& a, const MppiK& m,
+                                       const float* samples, const float* u_nom, float* parts, bool log, const MppiFuse& fuse,
+                                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+size_t ctk_mppi_rollout_env_lds(int env, int P, int H, int N);
+const char* ctk_mppi_rollout_env_name(int env, bool log);
 hipError_t ctk_launch_mppi_merge_partial(hipStream_t st, const float* parts, int n_parts, int per_block, int P,
                                          float neg_inv_lbd, float* out_rec);
 // direct peer-to-peer record exchange + merge + update (ctk_mppi.hip: ctk_mppi_p2p_exchange)

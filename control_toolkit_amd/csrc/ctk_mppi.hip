@@ -25,6 +25,7 @@
 #endif
 
 #include "ctk_rollout.h"
+#include "ctk_env.h"
 #include "ctk_mlp.h"
 #include "ctk_gru.h"
 #include "ctk_launch.h"
@@ -59,20 +60,24 @@ CTK_DEV void st_rec(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAX
 
 struct MppiUpdateArgs {
     // per-step tables already resident in this block's LDS (fused tail) — nullptr: read them from memory
+    // (un_l: the shifted nominal plan [H*C])
     const float* w0_l = nullptr; const float* w1_l = nullptr; const float* un_l = nullptr; const int* i0_l = nullptr;
     int H;
     const InterpEntry* interp;
     const float* u_nom_in;
     float* u_nom_out;
-    float lo, hi;
+    float lo, hi;          // C == 1
     float* u_dev;
     float* u_host;
     uint32_t seq;
+    int C = 1;             // control inputs: records carry b[P*C], the update runs per channel
+    float lo_c[CTK_MAX_INPUTS] = {}, hi_c[CTK_MAX_INPUTS] = {};   // C > 1
 };
 
 // scratch: >= 8 + (P + 1) + min(cnt, MERGE_CHUNK) floats of LDS, plus cnt*(2+P) more when `stage`
 // (all records fetched into LDS by ONE wide pass: one memory round trip instead of one per record).
-template <bool FINAL, int SC1>
+// CH: control inputs of the FINAL update (compile time: the C == 1 instantiations are CartPole's statement sequence, unchanged)
+template <bool FINAL, int SC1, int CH = 1>
 CTK_DEV void mppi_merge_block(float* scratch, const float* base, int cnt, int P, float neg_inv_lbd, float* out_rec,
                               const MppiUpdateArgs& up, int stage) {
     float* red = scratch;             // [4] cross-wave scratch
@@ -149,14 +154,34 @@ CTK_DEV void mppi_merge_block(float* scratch, const float* base, int cnt, int P,
         }
         if (t == 0) b_s[P] = 0.0f;   // pad read by i0+1 when P == 1
         __syncthreads();
-        for (int h = t; h < up.H; h += MERGE_BLOCK) {
-            InterpEntry e; float un;
-            if (up.w0_l) { e = InterpEntry{up.i0_l[h], up.w0_l[h], up.w1_l[h]}; un = up.un_l[h]; }
-            else { e = up.interp[h]; un = up.u_nom_in[min(h + 1, up.H - 1)]; }
-            const float w = (b_s[e.i0] * e.w0 + b_s[e.i0 + 1] * e.w1) / a_tot;
-            const float o = fminf(fmaxf(un + w, up.lo), up.hi);   // optimizer_mppi.py:190
-            up.u_nom_out[h] = o;
-            if (h == 0) publish_u(up.u_dev, up.u_host, o, up.seq);   // :191 u = u_nom[0,0,:]
+        if constexpr (CH == 1) {
+            for (int h = t; h < up.H; h += MERGE_BLOCK) {
+                InterpEntry e; float un;
+                if (up.w0_l) { e = InterpEntry{up.i0_l[h], up.w0_l[h], up.w1_l[h]}; un = up.un_l[h]; }
+                else { e = up.interp[h]; un = up.u_nom_in[min(h + 1, up.H - 1)]; }
+                const float w = (b_s[e.i0] * e.w0 + b_s[e.i0 + 1] * e.w1) / a_tot;
+                const float o = fminf(fmaxf(un + w, up.lo), up.hi);   // optimizer_mppi.py:190
+                up.u_nom_out[h] = o;
+                if (h == 0) publish_u(up.u_dev, up.u_host, o, up.seq);   // :191 u = u_nom[0,0,:]
+            }
+        } else {
+            // P here = P*C record columns; inducing point i of channel c is column i*C + c
+            constexpr int C = CH;
+            const int Pp = P / C;
+            float* u_s = scratch;             // red[] is dead: the C outputs of step 0
+            for (int hc = t; hc < up.H * C; hc += MERGE_BLOCK) {
+                const int h = hc / C, c = hc - h * C;
+                InterpEntry e; float un;
+                if (up.w0_l) { e = InterpEntry{up.i0_l[h], up.w0_l[h], up.w1_l[h]}; un = up.un_l[hc]; }
+                else { e = up.interp[h]; un = up.u_nom_in[min(h + 1, up.H - 1) * C + c]; }
+                const int i1 = min(e.i0 + 1, Pp - 1);
+                const float w = (b_s[e.i0 * C + c] * e.w0 + b_s[i1 * C + c] * e.w1) / a_tot;
+                const float o = fminf(fmaxf(un + w, up.lo_c[c]), up.hi_c[c]);   // optimizer_mppi.py:190
+                up.u_nom_out[hc] = o;
+                if (h == 0) u_s[c] = o;
+            }
+            __syncthreads();
+            if (t == 0) publish_u_vec(up.u_dev, up.u_host, u_s, C, up.seq);   // :191 u = u_nom[0,0,:]
         }
     }
 }
@@ -250,10 +275,12 @@ __global__ __launch_bounds__(MERGE_BLOCK) void ctk_mppi_merge(const float* __res
 // 16-byte aligned.
 // traj = trajectories per workgroup: 64 (ODE: one wave runs them, one per lane; MLP: 16 per wave) or
 // GRU_TRAJ = 16 (GRU: the four waves share one 16-trajectory MFMA column block, ctk_gru.h)
-__host__ __device__ inline int mppi_carve_floats(int P, int H, int traj) {
-    const int f = traj * tile_stride(P) + traj * ubuf_stride(H) + MPPI_BLOCK + traj + MPPI_WAVES * P + 4 * H;
+// PC = P*C sample columns, HC = H*C inputs per trajectory (C control inputs; CartPole: C = 1)
+__host__ __device__ inline int mppi_carve_floats(int PC, int HC, int traj, int H) {
+    const int f = traj * tile_stride(PC) + traj * ubuf_stride(HC) + MPPI_BLOCK + traj + MPPI_WAVES * PC + 3 * H + HC;
     return (f + 3) & ~3;
 }
+__host__ __device__ inline int mppi_carve_floats(int P, int H, int traj) { return mppi_carve_floats(P, H, traj, H); }
 constexpr int MPPI_PAIR_TRAJ = 32;   // MLP pair form: two tiles per workgroup, two waves per tile
 __host__ __device__ inline int mppi_traj(int pred) { return pred == CTK_PRED_GRU ? GRU_TRAJ : pred == CTK_PRED_MLP_PAIR ? MPPI_PAIR_TRAJ : MPPI_TRAJ; }
 
@@ -277,37 +304,45 @@ struct FuseArgs {
 // P2P: the instantiations whose merging block goes on to exchange records with peer GPUs (fuse mode 3, ctk_p2p_step);
 // kept apart because that tail costs the network-predictor kernels registers they need in the recurrence (measured:
 // GRU 83 -> 109 us per launch when every instantiation carried it).
-template <int PRED, bool LOG, bool P2P = false>
+// ENV: the environment (ctk_env.h).  The analytic-predictor instantiation (PRED = ODE) is written against Env<ENV> only — C
+// control inputs (sample columns P*C, inputs H*C per trajectory, per-channel interpolation / clip / correction / update), the
+// recurrence through Env::cost_step, the input-only cost terms through Env::input_cost; CartPole is Env<0>, C = 1.  The network
+// predictors' instantiations are CartPole's (other environments: ctk_generic_net.hip).
+// P_ = inducing points; pmagic_ = magic of the P_*C sample columns of a row.
+template <int ENV, int PRED, bool LOG, bool P2P = false>
 __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __restrict__ samples,
                                                                const float* __restrict__ u_nom,
                                                                const InterpEntry* __restrict__ interp,
                                                                const float* __restrict__ wperm,
                                                                float* __restrict__ parts, int N_, int H_, int P_,
-                                                               uint32_t pmagic_, RolloutArgs a_in, EnvK k, MppiK m, FuseArgs fz) {
+                                                               uint32_t pmagic_, RolloutArgs a_in, typename Env<ENV>::K k, MppiK m, FuseArgs fz) {
+    using E = Env<ENV>;
+    constexpr int C = E::C, S = E::S;
+    static_assert(PRED == CTK_PRED_ODE || ENV == CTK_ENV_CARTPOLE, "network predictors: CartPole instantiations only");
     extern __shared__ float lds[];
     RolloutArgs a = a_in;
-    a.N = N_; a.H = H_; a.P = P_; a.p_magic = pmagic_;
+    a.N = N_; a.H = H_; a.P = P_ * C; a.p_magic = pmagic_;      // a.P: sample COLUMNS of a row (what the tile loader walks)
     constexpr int TRAJ = (PRED == CTK_PRED_GRU) ? GRU_TRAJ : (PRED == CTK_PRED_MLP_PAIR) ? MPPI_PAIR_TRAJ : MPPI_TRAJ;   // trajectories of this workgroup
     constexpr int CHUNKS = MPPI_BLOCK / TRAJ;                             // horizon chunks of prologue 2 (4 / 16)
     constexpr int RPW = TRAJ / MPPI_WAVES;                                // tile rows per wave in the epilogue
-    const int P = a.P, H = a.H, ts = tile_stride(P), us = ubuf_stride(H);
-    float* tile = lds;                         // [TRAJ][ts]  stdev * noise at the inducing points
-    float* ubuf = tile + TRAJ * ts;            // [TRAJ][us]  clipped inputs u_run
+    const int Pp = P_, P = Pp * C, H = a.H, HC = H * C, ts = tile_stride(P), us = ubuf_stride(HC);   // Pp points, P columns
+    float* tile = lds;                         // [TRAJ][ts]  stdev * noise at the inducing points (point i, channel c: column i*C + c)
+    float* ubuf = tile + TRAJ * ts;            // [TRAJ][us]  clipped inputs u_run [H*C]
     float* corr_s = ubuf + TRAJ * us;          // [CHUNKS][TRAJ] per-chunk partial MPPI correction costs
     float* e_s = corr_s + MPPI_BLOCK;          // [TRAJ]
     float* col_s = e_s + TRAJ;                 // [4][P]    per-wave partial column sums
-    float* w0_s = col_s + MPPI_WAVES * P;      // [H] [H] [H] [H]  per-step tables
+    float* w0_s = col_s + MPPI_WAVES * P;      // [H] [H] [H*C] [H]  per-step tables
     float* w1_s = w0_s + H;
     float* un_s = w1_s + H;
-    int* i0_s = reinterpret_cast<int*>(un_s + H);
-    float* gru_ex = lds + mppi_carve_floats(P, H, TRAJ);   // GRU only: exchange slots of the four waves (ctk_gru.h)
+    int* i0_s = reinterpret_cast<int*>(un_s + HC);
+    float* gru_ex = lds + mppi_carve_floats(P, HC, TRAJ, H);   // GRU only: exchange slots of the four waves (ctk_gru.h)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int row0 = blockIdx.x * TRAJ;
     const int n = row0 + lane;                 // wave 0's view: lane = trajectory of the workgroup
     const bool valid = lane < TRAJ && n < a.N;
     const bool use_ll = fz.mode != 0 && fz.ll != nullptr;   // kernel-argument uniform
 
-    const uint32_t ka_sink = kernarg_prefetch<sizeof(RolloutArgs) + sizeof(EnvK) + sizeof(MppiK) + 5 * sizeof(void*) + 16 + sizeof(FuseArgs)>();
+    const uint32_t ka_sink = kernarg_prefetch<sizeof(RolloutArgs) + sizeof(typename E::K) + sizeof(MppiK) + 5 * sizeof(void*) + 16 + sizeof(FuseArgs)>();
     STAMP(0);
     // ---- prologue 1 (256 threads): per-step tables (interpolation entry, shifted nominal input) and
     //      the sample tile (coalesced HBM read or Philox draw) into LDS ------------------------------
@@ -315,7 +350,8 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
         for (int h = t; h < H; h += MPPI_BLOCK) {           // issued while the sample loads are in flight
             const InterpEntry e = interp[h];
             i0_s[h] = e.i0; w0_s[h] = e.w0; w1_s[h] = e.w1;
-            un_s[h] = u_nom[min(h + 1, H - 1)];                                    // optimizer_mppi.py:184 (shift)
+#pragma unroll
+            for (int c = 0; c < C; ++c) un_s[h * C + c] = u_nom[min(h + 1, H - 1) * C + c];   // optimizer_mppi.py:184 (shift)
         }
     });
     __syncthreads();
@@ -338,28 +374,39 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
         const bool pvalid = pn < a.N;
         const float* my = tile + ptraj * ts;
         const bool ident = a.identity_interp != 0;
-        auto input_at = [&](int h, float& du) {
+        auto input_at = [&](int h, int c, float& du) {
             if (ident) {
-                du = my[h];                                           // period 1: the matrix is the identity
+                du = my[h * C + c];                                   // period 1: the matrix is the identity
             } else {
                 const int i0 = i0_s[h];                               // LDS broadcast reads
-                du = my[i0] * w0_s[h] + my[i0 + 1] * w1_s[h];         // Interpolator.py:97-106
+                const int i1 = C == 1 ? i0 + 1 : min(i0 + 1, Pp - 1); // C == 1: column P is a zero pad
+                du = my[i0 * C + c] * w0_s[h] + my[i1 * C + c] * w1_s[h];   // Interpolator.py:97-106, per input channel
             }
-            return fminf(fmaxf(un_s[h] + du, a.lo[0]), a.hi[0]);            // optimizer_mppi.py:186-187
+            return fminf(fmaxf(un_s[h * C + c] + du, a.lo[c]), a.hi[c]);    // optimizer_mppi.py:186-187
         };
         const int h0 = hbeg, h1 = hend;
         float corr = 0.0f, cin = 0.0f, dummy;
-        float uprev = (h0 == 0 || h0 >= H) ? (a.u_prev_dev ? *a.u_prev_dev : a.u_prev[0]) : input_at(h0 - 1, dummy);
+        float uprev[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            uprev[c] = (h0 == 0 || h0 >= H) ? (a.u_prev_dev ? a.u_prev_dev[c] : a.u_prev[c]) : input_at(h0 - 1, c, dummy);
 #pragma unroll 2
         for (int h = h0; h < h1; ++h) {
-            float du;
-            const float u = input_at(h, du);
-            corr += m.cc * (m.k_dd * (du * du) + m.R * u * du + m.k_uu * (u * u));   // :154-155
-            cin += stage_cost_input(k, u, uprev);
-            uprev = u;
-            ubuf[ptraj * us + h] = (PRED == CTK_PRED_ODE) ? k.u_max * u : u;
-            if constexpr (LOG) {
-                if (pvalid) a.Q_out[(size_t)pn * H + h] = u;
+            float u[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float du;
+                u[c] = input_at(h, c, du);
+                corr += m.cc * (m.k_dd * (du * du) + m.R * u[c] * du + m.k_uu * (u[c] * u[c]));   // :154-155, summed over h and c
+            }
+            cin += E::input_cost(k, u, uprev);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                uprev[c] = u[c];
+                ubuf[ptraj * us + h * C + c] = (PRED == CTK_PRED_ODE) ? E::prep_input(k, u[c], c) : u[c];
+                if constexpr (LOG) {
+                    if (pvalid) a.Q_out[(size_t)pn * HC + h * C + c] = u[c];
+                }
             }
         }
         // mean over H+1 applies to the stage costs, not to the MPPI correction (optimizer_mppi.py:158-161)
@@ -380,18 +427,19 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
     // ---- the recurrence --------------------------------------------------------------------------
     float J = 0.0f;
     if constexpr (PRED == CTK_PRED_ODE) {
-        // wave 0 only: one trajectory per lane, state in registers
+        // wave 0 only: one trajectory per lane, state in registers, through the environment's cost_step
         const float* myF = ubuf + lane * us;
-        auto F_at = [&](int h) { return myF[h]; };
-        State4 st{a.s0[0], a.s0[1], a.s0[2], a.s0[3]};
+        float sx[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) sx[i] = a.s0[i];
         float csum = 0.0f, amax = 0.0f;
-        float4* traj = nullptr;
+        float* traj = nullptr;
         if constexpr (LOG) {
-            if (a.traj_out) traj = reinterpret_cast<float4*>(a.traj_out) + (size_t)n * (H + 1);
+            if (a.traj_out) traj = a.traj_out + (size_t)n * (H + 1) * S;
         }
-        const bool single = k.intermediate_steps == 1;
+        const bool single = E::fast_ok(k);
         if (wave == 0) {                           // steps [0, S1) while the others prepare [S1, H)
-            if (single) recur_ode_range<LOG, false, true>(k, traj, valid, F_at, 0, S1, st, csum, amax);
+            if (single) recur_env_range<ENV, LOG, true>(k, traj, valid, myF, 0, S1, sx, csum, amax);
         } else {
             const int Hb = (H - S1 + MPPI_WAVES - 2) / (MPPI_WAVES - 1);        // phase B: wave w takes its third of [S1, H)
             prologue2(lane, min(H, S1 + (wave - 1) * Hb), min(H, S1 + (wave - 1) * Hb + Hb), wave, corr_keep);
@@ -399,17 +447,25 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
         __syncthreads();                           // waves 1..3 have been waiting here since ~step 4 of wave 0
         if (wave == 0) {
             if (single) {
-                recur_ode_range<LOG, false, true>(k, traj, valid, F_at, S1, H, st, csum, amax);
+                recur_env_range<ENV, LOG, true>(k, traj, valid, myF, S1, H, sx, csum, amax);
                 if constexpr (LOG) {
-                    if (valid && traj) traj[H] = make_float4(st.x, st.v, st.th, st.om);
+                    if (valid && traj) store_state<S>(traj + (size_t)H * S, sx);
                 }
-                J = csum + terminal_cost(k, st);
+                J = csum + E::terminal_cost(k, sx);
             }
 #ifndef CTK_DIAG_NO_COLD
             // Euler sub-steps (intermediate_steps > 1), or an angle beyond the fast sincos range somewhere in the
             // wave (~never): the whole horizon with the checked sincos, all inputs being ready by now
-            if (!single || __builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0))
-                J = recur_ode_state_cost<LOG, true, false>(a, k, n, valid, F_at, &amax);
+            if (!single || __builtin_expect(__builtin_amdgcn_ballot_w64(E::out_of_range(amax)) != 0, 0)) {
+#pragma unroll
+                for (int i = 0; i < S; ++i) sx[i] = a.s0[i];
+                csum = 0.0f;
+                recur_env_range<ENV, LOG, false>(k, traj, valid, myF, 0, H, sx, csum, amax);
+                if constexpr (LOG) {
+                    if (valid && traj) store_state<S>(traj + (size_t)H * S, sx);
+                }
+                J = csum + E::terminal_cost(k, sx);
+            }
 #endif
             J *= a.inv_Hp1;
         }
@@ -528,8 +584,8 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
             __syncthreads();
             const size_t scratch_floats = 8 + P + 1 + min(nb, MERGE_CHUNK) + (size_t)tot;
             if (scratch_floats <= (size_t)(w0_s - lds)) { fz.up.w0_l = w0_s; fz.up.w1_l = w1_s; fz.up.un_l = un_s; fz.up.i0_l = i0_s; }
-            if (fz.mode == 1) mppi_merge_block<true, 0>(lds, nullptr, nb, P, m.neg_inv_lbd, nullptr, fz.up, 2);
-            else mppi_merge_block<false, 0>(lds, nullptr, nb, P, m.neg_inv_lbd, fz.out_rec, fz.up, 2);
+            if (fz.mode == 1) mppi_merge_block<true, 0, C>(lds, nullptr, nb, P, m.neg_inv_lbd, nullptr, fz.up, 2);
+            else mppi_merge_block<false, 0, C>(lds, nullptr, nb, P, m.neg_inv_lbd, fz.out_rec, fz.up, 2);
             if constexpr (P2P) {
                 // sharded step over peer-to-peer stores, all in this launch: the shard's record (just written to
                 // fz.out_rec = this rank's slot of its own exchange buffer by this block) goes to every peer, their
@@ -569,8 +625,8 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
             // whenever the scratch ends below them
             const size_t scratch_floats = 8 + P + 1 + min((int)gridDim.x, MERGE_CHUNK) + (fz.stage_ok ? (size_t)gridDim.x * (2 + P) : 0);
             if (scratch_floats <= (size_t)(w0_s - lds)) { fz.up.w0_l = w0_s; fz.up.w1_l = w1_s; fz.up.un_l = un_s; fz.up.i0_l = i0_s; }
-            if (fz.mode == 1) mppi_merge_block<true, 1>(lds, parts, (int)gridDim.x, P, m.neg_inv_lbd, nullptr, fz.up, fz.stage_ok != 0 ? 1 : 0);
-            else mppi_merge_block<false, 1>(lds, parts, (int)gridDim.x, P, m.neg_inv_lbd, fz.out_rec, fz.up, fz.stage_ok != 0 ? 1 : 0);
+            if (fz.mode == 1) mppi_merge_block<true, 1, C>(lds, parts, (int)gridDim.x, P, m.neg_inv_lbd, nullptr, fz.up, fz.stage_ok != 0 ? 1 : 0);
+            else mppi_merge_block<false, 1, C>(lds, parts, (int)gridDim.x, P, m.neg_inv_lbd, fz.out_rec, fz.up, fz.stage_ok != 0 ? 1 : 0);
             if (t == 0) __hip_atomic_store(fz.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -805,10 +861,11 @@ const char* ctk_mppi_rollout_name(int pred, bool log, int N, bool identity_inter
     const int tf = throughput_form(pred, N, have_samples, identity_interp);
     if (tf == 2) return log ? "ctk_mppi_rollout_tps<true>" : "ctk_mppi_rollout_tps<false>";
     if (tf == 1) return log ? "ctk_mppi_rollout_tp<true>" : "ctk_mppi_rollout_tp<false>";
-    if (pred == CTK_PRED_ODE) return log ? "ctk_mppi_rollout<0, true>" : "ctk_mppi_rollout<0, false>";
-    if (pred == CTK_PRED_GRU) return log ? "ctk_mppi_rollout<2, true>" : "ctk_mppi_rollout<2, false>";
-    if (kernel_pred(pred, N) == CTK_PRED_MLP_PAIR) return log ? "ctk_mppi_rollout<3, true>" : "ctk_mppi_rollout<3, false>";
-    return log ? "ctk_mppi_rollout<1, true>" : "ctk_mppi_rollout<1, false>";
+    // template arguments <environment, predictor form, materialise>: what rocprofv3's kernel trace shows
+    if (pred == CTK_PRED_ODE) return log ? "ctk_mppi_rollout<0, 0, true>" : "ctk_mppi_rollout<0, 0, false>";
+    if (pred == CTK_PRED_GRU) return log ? "ctk_mppi_rollout<0, 2, true>" : "ctk_mppi_rollout<0, 2, false>";
+    if (kernel_pred(pred, N) == CTK_PRED_MLP_PAIR) return log ? "ctk_mppi_rollout<0, 3, true>" : "ctk_mppi_rollout<0, 3, false>";
+    return log ? "ctk_mppi_rollout<0, 1, true>" : "ctk_mppi_rollout<0, 1, false>";
 }
 
 int ctk_mppi_num_blocks(int N, int pred) {
@@ -821,17 +878,19 @@ static size_t merge_lds(int P, int cnt) { return (size_t)(8 + P + 1 + (cnt < MER
 static size_t merge_lds_staged(int P, int cnt) { return merge_lds(P, cnt) + (size_t)cnt * (2 + P) * sizeof(float); }
 static bool merge_can_stage(int P, int cnt) { return merge_lds_staged(P, cnt) <= 64 * 1024; }
 
-size_t ctk_mppi_rollout_lds(int P, int H, int pred, int N) {
+// C control inputs (CartPole kernels: 1): P*C sample columns, H*C inputs per trajectory
+size_t ctk_mppi_rollout_lds(int P, int H, int pred, int N, int C) {
     const int kp = kernel_pred(pred, N);
-    const size_t roll = (size_t)(mppi_carve_floats(P, H, mppi_traj(kp)) + (kp == CTK_PRED_GRU ? GRU_EX_FLOATS : kp == CTK_PRED_MLP_PAIR ? 2 * MLP_PAIR_EX : 0)) * sizeof(float);
-    const size_t tail = merge_lds(P, CTK_MPPI_FUSE_MAX_BLOCKS);
+    const size_t roll = (size_t)(mppi_carve_floats(P * C, H * C, mppi_traj(kp), H) + (kp == CTK_PRED_GRU ? GRU_EX_FLOATS : kp == CTK_PRED_MLP_PAIR ? 2 * MLP_PAIR_EX : 0)) * sizeof(float);
+    const size_t tail = merge_lds(P * C, CTK_MPPI_FUSE_MAX_BLOCKS);
     return roll > tail ? roll : tail;
 }
 
 // LDS of one launch: the rollout carve, or the fused tail's (staged) merge scratch if larger
-static size_t rollout_launch_lds(int P, int H, int pred, int N, int blocks, int* stage_ok) {
-    size_t lds = ctk_mppi_rollout_lds(P, H, pred, N);
+static size_t rollout_launch_lds(int P, int H, int pred, int N, int blocks, int* stage_ok, int C = 1) {
+    size_t lds = ctk_mppi_rollout_lds(P, H, pred, N, C);
     *stage_ok = 0;
+    P *= C;
     if (blocks <= CTK_MPPI_FUSE_MAX_BLOCKS_LL && merge_can_stage(P, blocks)) {
         const size_t st = merge_lds_staged(P, blocks);
         if (st > lds) lds = st;
@@ -867,7 +926,7 @@ hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& 
     fz.ll = (fuse.mode != 0 && fz.stage_ok) ? fuse.ll : nullptr;
     fz.p2p = static_cast<const P2PArgs*>(fuse.p2p); fz.p2p_seq = fuse.p2p_seq;
     fz.up = MppiUpdateArgs{nullptr, nullptr, nullptr, nullptr, a.H, a.interp, u_nom, fuse.u_nom_out, a.lo[0], a.hi[0], fuse.u_dev, fuse.u_host, fuse.seq};
-#define CTK_MPPI_LAUNCH(PREDV, LOGV, P2PV) CTK_LAUNCH((ctk_mppi_rollout<PREDV, LOGV, P2PV>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, wperm, parts, a.N, a.H, a.P, a.p_magic, a, k, m, fz)
+#define CTK_MPPI_LAUNCH(PREDV, LOGV, P2PV) CTK_LAUNCH((ctk_mppi_rollout<CTK_ENV_CARTPOLE, PREDV, LOGV, P2PV>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, wperm, parts, a.N, a.H, a.P, a.p_magic, a, k, m, fz)
 #define CTK_MPPI_LAUNCH_PRED(PREDV)                                                            \
     do {                                                                                       \
         if (fuse.mode == 3) { if (log) CTK_MPPI_LAUNCH(PREDV, true, true); else CTK_MPPI_LAUNCH(PREDV, false, true); } \
@@ -880,6 +939,40 @@ hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& 
 #undef CTK_MPPI_LAUNCH_PRED
 #undef CTK_MPPI_LAUNCH
     return hipGetLastError();
+}
+
+// The same 4-wave kernel for any environment's analytic predictor (ctk_env.h): a.P = inducing points, a.C = control inputs,
+// a.lo / a.hi per input; the kernel constants are derived here from the environment's parameter table.  fuse as above
+// (modes 0, 1, 2; the peer-to-peer tail is CartPole's).
+hipError_t ctk_launch_mppi_rollout_env(hipStream_t st, int env, const float* params, float dt, int isteps, const RolloutArgs& a, const MppiK& m,
+                                       const float* samples, const float* u_nom, float* parts, bool log, const MppiFuse& fuse,
+                                       hipEvent_t e0, hipEvent_t e1) {
+    const dim3 grid((a.N + MPPI_TRAJ - 1) / MPPI_TRAJ), block(MPPI_BLOCK);
+    CTK_FOR_ENV(env, EV, {
+        using E = Env<EV>;
+        const int PC = a.P * E::C;
+        const typename E::K k = E::derive(params, dt, isteps);
+        FuseArgs fz{};
+        const size_t lds = rollout_launch_lds(a.P, a.H, CTK_PRED_ODE, a.N, (int)grid.x, &fz.stage_ok, E::C);
+        fz.mode = fuse.mode; fz.counter = fuse.counter; fz.out_rec = fuse.out_rec;
+        fz.ll = (fuse.mode != 0 && fz.stage_ok) ? fuse.ll : nullptr;
+        fz.up = MppiUpdateArgs{nullptr, nullptr, nullptr, nullptr, a.H, a.interp, u_nom, fuse.u_nom_out, a.lo[0], a.hi[0], fuse.u_dev, fuse.u_host, fuse.seq};
+        fz.up.C = E::C;
+        for (int c = 0; c < E::C; ++c) { fz.up.lo_c[c] = a.lo[c]; fz.up.hi_c[c] = a.hi[c]; }
+        const uint32_t pmagic = PC >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)PC - 1) / (uint64_t)PC) : 0u;
+        if (log) CTK_LAUNCH((ctk_mppi_rollout<EV, CTK_PRED_ODE, true, false>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, (const float*)nullptr, parts, a.N, a.H, a.P, pmagic, a, k, m, fz);
+        else CTK_LAUNCH((ctk_mppi_rollout<EV, CTK_PRED_ODE, false, false>), grid, block, lds, st, e0, e1, samples, u_nom, a.interp, (const float*)nullptr, parts, a.N, a.H, a.P, pmagic, a, k, m, fz);
+    });
+    return hipGetLastError();
+}
+size_t ctk_mppi_rollout_env_lds(int env, int P, int H, int N) {
+    const int C = env == CTK_ENV_CARTPOLE ? Env<CTK_ENV_CARTPOLE>::C : Env<CTK_ENV_QUAD2D>::C;
+    int stage_ok;
+    return rollout_launch_lds(P, H, CTK_PRED_ODE, N, (N + MPPI_TRAJ - 1) / MPPI_TRAJ, &stage_ok, C);
+}
+const char* ctk_mppi_rollout_env_name(int env, bool log) {
+    if (env == CTK_ENV_CARTPOLE) return log ? "ctk_mppi_rollout<0, 0, true>" : "ctk_mppi_rollout<0, 0, false>";
+    return log ? "ctk_mppi_rollout<1, 0, true>" : "ctk_mppi_rollout<1, 0, false>";
 }
 
 hipError_t ctk_launch_mppi_merge_partial(hipStream_t st, const float* parts, int n_parts, int per_block, int P,

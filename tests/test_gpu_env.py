@@ -40,7 +40,10 @@ def test_cartpole_generic_kernels_match_tuned_kernels(opt):
     if opt == "rpgd":
         kw.update(outer_its=3, resamp_per=2, opt_keep_k=48, sample_whole_control_space=1)
     a, b = CtkEngine(opt, "ODE", **kw), CtkEngine(opt, "ODE", generic_kernels=True, **kw)
-    assert "ctk_g_" in b.dominant_kernel() and "ctk_g_" not in a.dominant_kernel()
+    if opt == "mppi":   # the analytic predictor's MPPI kernel IS the template: Env<CartPole> instantiation of ctk_mppi_rollout<ENV, ODE, .>
+        assert a.dominant_kernel() == b.dominant_kernel() == "ctk_mppi_rollout<0, 0, true>"
+    else:
+        assert "ctk_g_" in b.dominant_kernel() and "ctk_g_" not in a.dominant_kernel()
     if opt == "rpgd":
         a.reset(); b.reset()
     s = np.array([0.05, -0.1, 2.8, 0.4], np.float32)
@@ -57,6 +60,22 @@ def test_cartpole_generic_kernels_match_tuned_kernels(opt):
         np.testing.assert_allclose(ub, ua, rtol=2e-4, atol=2e-4)
         b.set_state(a.get_state())                             # continue from identical warm-start state
         s = pred.step(s.reshape(1, 4), np.array([ua[0]], np.float32))[0]
+    a.close(); b.close()
+
+
+def test_generic_mppi_at_throughput_sizes_runs_the_one_wave_template_kernel():
+    """N >= 32768: CartPole's own path switches to its streaming kernels, the template path to ctk_g_rollout (one wave per 64
+    rollouts, records merged by separate launches) — the only sizes that kernel's MPPI mode still serves"""
+    N, H = 32768 + 64, 8
+    kw = dict(num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=1, seed=9)
+    a, b = CtkEngine("mppi", "ODE", **kw), CtkEngine("mppi", "ODE", generic_kernels=True, **kw)
+    assert "ctk_g_rollout" in b.dominant_kernel() and "ctk_mppi_rollout_tp" in a.dominant_kernel()
+    s = np.array([0.05, -0.1, 2.8, 0.4], np.float32)
+    for t in range(2):
+        ua, ub = a.step(s), b.step(s)
+        np.testing.assert_allclose(b.read("J"), a.read("J"), rtol=3e-5)
+        np.testing.assert_allclose(b.read("U_NOM"), a.read("U_NOM"), **U_TOL)
+        np.testing.assert_allclose(ub, ua, rtol=2e-4, atol=2e-4)
     a.close(); b.close()
 
 

@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_parts, (size_t)nb * (2 + P) * 4)); CK(hipMalloc(&d_tab, H * sizeof(InterpEntry))); CK(hipMalloc(&d_st, nb * 16 * 8)); CK(hipMemset(d_st, 0, nb * 16 * 8));
     CK(hipMemcpy(d_noise, noise.data(), noise.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemset(d_unom, 0, H * 4)); CK(hipMemcpy(d_tab, tab.data(), H * sizeof(InterpEntry), hipMemcpyHostToDevice));
-    RolloutArgs a{}; a.s0[0] = 0.05f; a.s0[1] = -0.1f; a.s0[2] = 2.8f; a.s0[3] = 0.4f; a.lo = -1; a.hi = 1; a.N = N; a.H = H; a.P = P;
+    RolloutArgs a{}; a.s0[0] = 0.05f; a.s0[1] = -0.1f; a.s0[2] = 2.8f; a.s0[3] = 0.4f; a.lo[0] = -1; a.hi[0] = 1; a.C = 1; a.N = N; a.H = H; a.P = P;
     a.inv_Hp1 = 1.f / (H + 1); a.p_magic = (uint32_t)((0x100000000ull + P - 1) / P); a.identity_interp = 1; a.interp = d_tab; a.J = d_J; a.stamps = d_st;
     unsigned* d_cnt; float *d_unom2, *d_u, *h_u; CK(hipMalloc(&d_cnt, 4)); CK(hipMemset(d_cnt, 0, 4)); CK(hipMalloc(&d_unom2, H * 4)); CK(hipMalloc(&d_u, 4)); CK(hipHostMalloc(&h_u, 64, hipHostMallocMapped));
     unsigned long long* d_ll; CK(hipMalloc(&d_ll, (size_t)nb * (2 + P) * 8)); CK(hipMemset(d_ll, 0, (size_t)nb * (2 + P) * 8));

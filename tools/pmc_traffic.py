@@ -35,11 +35,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fetch", required=True); ap.add_argument("--write", required=True)
     ap.add_argument("--workload", required=True); ap.add_argument("--samples", required=True)
-    ap.add_argument("--kernel", default="ctk_mppi_rollout<0, false>")
+    ap.add_argument("--kernel", default="ctk_mppi_rollout<0, 0, false>")
     ap.add_argument("--commit", default="unknown"); ap.add_argument("--out", required=True)
     a = ap.parse_args()
     import bench
-    prefix = a.kernel.split("(")[0].rstrip(">")     # rocprofv3 prints every template argument: "ctk_mppi_rollout<0, false, false>"
+    prefix = a.kernel.split("(")[0].rstrip(">")     # rocprofv3 prints every template argument: "ctk_mppi_rollout<0, 0, false, false>"
     f, nf = mean_counter(a.fetch, "FETCH_SIZE", prefix)
     w, nw = mean_counter(a.write, "WRITE_SIZE", prefix)
     rec = {"workload": a.workload, "samples": a.samples, "kernel": a.kernel, "commit": a.commit,
