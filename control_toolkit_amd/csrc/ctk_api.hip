@@ -663,10 +663,18 @@ int mppi_update(ctk_handle* h, const float* parts, int n_parts, float* u_out) {
 }
 
 // u[n,h,c] = clip(base[h,c] + sample[n,h,c] * scale[h,c]) rollouts (CEM, random-action, plain), tuned or template kernel
+// template path: the analytic predictor of ANY environment runs the 4-wave kernel of ctk_sampled.hip (ctk_affine_rollout<ENV, ODE, .>)
+bool affine_env_kernel(const ctk_handle* h) {
+    return h->generic && h->cfg.predictor == CTK_PRED_ODE && ctk_affine_rollout_env_lds(h->env, h->H) <= 160 * 1024;
+}
+
 int launch_affine(ctk_handle* h, const RolloutArgs& a, const float* d_s, int rng_kind, const float* base, const float* scale, bool log,
                   const AffineBest* bst = nullptr) {
     ProfSlot ps(h);
-    if (h->generic && h->cfg.predictor != CTK_PRED_ODE)
+    if (affine_env_kernel(h))
+        HIP_TRY(h, ctk_launch_affine_rollout_env(h->stream, h->env, h->params, h->cfg.dt, h->cfg.intermediate_steps, a, d_s, rng_kind, base, scale,
+                                                 log, ps.a, ps.b, bst));
+    else if (h->generic && h->cfg.predictor != CTK_PRED_ODE)
         HIP_TRY(h, ctk_launch_g_rollout_net(h->stream, h->env, h->cfg.predictor, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps,
                                             h->mk, d_s, base, scale, rng_kind, h->d_wperm, nullptr, log, ps.a, ps.b));
     else if (h->generic)
@@ -780,10 +788,10 @@ int cem_step(ctk_handle* h, const float* s, const float* u_prev, const float* sa
         const ctk_config& c = h->cfg;
         if ((uint32_t)(h->cem_tag + (uint32_t)its) < h->cem_tag) h->cem_tag = 1;   // wrapped: tag 0 is the never-written value
         const CemFusedLaunch cl{its, c.cem_best_k, h->d_cem_ll, h->cem_tag, c.cem_stdev_min, 1.0e8f, c.cem_initial_action_stdev,
-                                (c.action_low[0] + c.action_high[0]) * 0.5f, mu, h->d_std, h->d_u, h->h_u_dev, h->d_idx, h->seq, 0.5};
+                                mu, h->d_std, h->d_u, h->h_u_dev, h->d_idx, h->seq, 0.5};
         h->cem_tag += (uint32_t)its;
         ProfSlot ps(h);
-        HIP_TRY(h, ctk_launch_cem_fused(h->stream, a, h->k, d_s, cl, log, ps.a, ps.b));
+        HIP_TRY(h, ctk_launch_cem_fused(h->stream, h->env, h->params, c.dt, c.intermediate_steps, a, d_s, cl, log, ps.a, ps.b));
         h->idx_stale = true;
         ++h->count;
         return finish_step(h, u_out);
@@ -808,7 +816,7 @@ int random_step(ctk_handle* h, const float* s, const float* u_prev, const float*
     RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);
     const bool log = h->cfg.materialize_trajectories != 0;
     static const bool three_launches = std::getenv("CTK_NO_FUSED_ARGMIN") != nullptr;   // A/B switch
-    if (!h->generic && h->cfg.predictor == CTK_PRED_ODE && h->d_ll && !three_launches &&
+    if ((!h->generic || affine_env_kernel(h)) && h->cfg.predictor == CTK_PRED_ODE && h->d_ll && !three_launches &&
         ctk_affine_rollout_blocks(h->cfg.predictor, h->N) <= CTK_AFFINE_BEST_MAX_BLOCKS) {
         // ONE launch: rollout + arg-min over the block minima + u (optimizer_random_action_tf.py:62-68)
         const AffineBest bst{h->d_ll, h->seq, h->d_u, h->h_u_dev, h->d_idx};
@@ -1058,8 +1066,8 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     TRY_CREATE(dev_alloc(h, &h->d_counter, 1));
     if ((!generic || cfg->predictor == CTK_PRED_ODE) && nblk <= (size_t)CTK_MPPI_FUSE_MAX_BLOCKS_LL && !std::getenv("CTK_NO_LL"))
         TRY_CREATE(dev_alloc(h, &h->d_ll, nblk * (2 + PC)));
-    if (!generic && cfg->optimizer == CTK_OPT_CEM && ctk_cem_fusable(cfg->predictor, (int)N, (int)H) && !std::getenv("CTK_NO_CEM_FUSED"))
-        TRY_CREATE(dev_alloc(h, &h->d_cem_ll, ctk_cem_fused_ll_words((int)N, (int)H)));
+    if (cfg->optimizer == CTK_OPT_CEM && ctk_cem_fusable(cfg->predictor, (int)N, (int)HC) && !std::getenv("CTK_NO_CEM_FUSED"))
+        TRY_CREATE(dev_alloc(h, &h->d_cem_ll, ctk_cem_fused_ll_words((int)N, (int)HC)));   // tuned and template path alike
     TRY_CREATE(dev_alloc(h, &h->d_unom[0], HC));
     TRY_CREATE(dev_alloc(h, &h->d_unom[1], HC));
     TRY_CREATE(dev_alloc(h, &h->d_std, HC));
@@ -1106,8 +1114,9 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
                     : cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_name(cfg->predictor, mat, cfg->num_rollouts, cfg->period_interpolation_inducing_points == 1 && h->P == (int)H, false)
                                                      : ctk_affine_rollout_name(cfg->predictor, mat);
     }
-    if (h->d_cem_ll && h->variant == CTK_OPT_CEM && cfg->cem_best_k <= (int)N) h->dominant = ctk_cem_fused_name(mat);
+    if (h->d_cem_ll && h->variant == CTK_OPT_CEM && cfg->cem_best_k <= (int)N) h->dominant = ctk_cem_fused_name(h->env, mat);
     if (cfg->optimizer == CTK_OPT_MPPI && mppi_env_kernel(h)) h->dominant = ctk_mppi_rollout_env_name(h->env, mat);
+    if (!descends && cfg->optimizer != CTK_OPT_MPPI && affine_env_kernel(h) && !(h->d_cem_ll && h->variant == CTK_OPT_CEM)) h->dominant = ctk_affine_rollout_env_name(h->env, mat);
     if (cfg->optimizer != CTK_OPT_RPGD) TRY_CREATE(ctk_reset(h, nullptr, CTK_LOC_NONE));
     HIP_CREATE(hipStreamSynchronize(h->stream));
     *out = h;

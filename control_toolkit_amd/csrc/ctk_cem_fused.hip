@@ -1,4 +1,5 @@
-// ctk_cem_fused.hip — one CEM step (all outer iterations) in ONE launch, CartPole ODE predictor, <= CTK_CEM_FUSED_MAX_BLOCKS
+// ctk_cem_fused.hip — one CEM step (all outer iterations) in ONE launch, analytic predictor of any environment (ctk_env.h: C control
+// inputs -> H*C columns per plan, below "H" where a column count is meant), <= CTK_CEM_FUSED_MAX_BLOCKS
 // workgroups (all co-resident: one per CU).  Replaces, per outer iteration, the three launches rollout -> ctk_select_topk ->
 // ctk_cem_refit and, after the loop, ctk_cem_finish (optimizer_cem_tf.py:61-80,83-111): SURVEY 8e's all-reduce form of the
 // elite refit applied INSIDE one GPU, with the {value, tag} word hand-off of ctk_mppi.hip between workgroups.
@@ -19,6 +20,7 @@
 // Every wait is bounded by a wall clock; on expiry the error word behind {u, seq} is raised (ctk_api.hip:finish_step ->
 // CTK_ERR_STATE) — never a silently wrong result.
 #include "ctk_rollout.h"
+#include "ctk_env.h"
 #include "ctk_launch.h"
 
 #ifdef CTK_CEM_STAMPS   // diagnostic build (tools/diag_cem_fused.hip); never compiled into libctk_hip.so
@@ -46,8 +48,9 @@ struct CemFusedK {
     unsigned long long* llJ;        // [N]              {sortable key of J_n, tag}
     unsigned long long* llS;        // [nblk][1 + 2H]   {n_b | mean_b[H] | M2_b[H], tag}
     uint32_t tag0;                  // tag of iteration it = tag0 + it (host: consecutive across launches, never 0)
-    float std_min, std_max, init_std, mid;
-    float* mu; float* sd;           // [H] device, in / out
+    float std_min, std_max, init_std;
+    float mid[CTK_MAX_INPUTS];      // per input: the tail refill of the mean (:99-102)
+    float* mu; float* sd;           // [H*C] device, in / out
     float* u_dev; float* u_host; int* idx_out; uint32_t seq;
     unsigned long long timeout_ticks;   // wall_clock64 ticks (100 MHz) per hop
 };
@@ -177,11 +180,14 @@ CTK_DEV void cem_fetch_tile(float* tile, const float* __restrict__ samples, cons
     }
 }
 
-template <bool WTRAJ>
-__global__ __launch_bounds__(CF_BLOCK) void ctk_cem_fused(const float* __restrict__ samples, RolloutArgs a_in, EnvK k, CemFusedK cf) {
+template <int ENV, bool WTRAJ>
+__global__ __launch_bounds__(CF_BLOCK) void ctk_cem_fused(const float* __restrict__ samples, RolloutArgs a_in, typename Env<ENV>::K k, CemFusedK cf) {
+    using E = Env<ENV>;
+    constexpr int C = E::C, S = E::S;
     extern __shared__ float lds[];
     RolloutArgs a = a_in;
-    const int N = a.N, H = a.H, ts = tile_stride(a.P), us = (H + 1) | 1, rs = 1 + 2 * H;   // P == H: one sample per step
+    // Hs steps; H = Hs*C flat (step, input) columns of a plan = sample columns of a row (a.P): one sample per step and input
+    const int N = a.N, Hs = a.H, H = Hs * C, ts = tile_stride(a.P), us = (H + 1) | 1, rs = 1 + 2 * H;
     const CemCarve cv = cem_carve(N, H, cf.nblk);
     float* tiles[2] = {lds + cv.tile0, lds + cv.tile1};
     float* ubuf = lds + cv.ubuf;
@@ -207,7 +213,9 @@ __global__ __launch_bounds__(CF_BLOCK) void ctk_cem_fused(const float* __restric
     const int row0 = blockIdx.x * CF_TRAJ;
     const int n = row0 + lane;
     const bool valid = n < N;                                     // wave 0: lane = row of the workgroup
-    const float up0 = uniform_u_prev0(a);
+    float up0[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) up0[c] = a.u_prev_dev ? a.u_prev_dev[c] : a.u_prev[c];
     bool expired = false;
 
     for (int h = t; h < H; h += CF_BLOCK) { mu_s[h] = cf.mu[h]; sd_s[h] = cf.sd[h]; }
@@ -223,52 +231,62 @@ __global__ __launch_bounds__(CF_BLOCK) void ctk_cem_fused(const float* __restric
         // ---- 1. rollout ---------------------------------------------------------------------------------------------
         auto prepare = [&](int ptraj, int hbeg, int hend) {
             const float* my = tile + ptraj * ts;
-            auto input_at = [&](int h) { return fminf(fmaxf(mu_s[h] + my[h] * sd_s[h], a.lo[0]), a.hi[0]); };   // :64-66
+            auto input_at = [&](int h, int c) { return fminf(fmaxf(mu_s[h * C + c] + my[h * C + c] * sd_s[h * C + c], a.lo[c]), a.hi[c]); };   // :64-66
             float cin = 0.0f;
-            float uprev = (hbeg == 0 || hbeg >= H) ? up0 : input_at(hbeg - 1);
+            float uprev[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) uprev[c] = (hbeg == 0 || hbeg >= Hs) ? up0[c] : input_at(hbeg - 1, c);
 #pragma unroll 2
             for (int h = hbeg; h < hend; ++h) {
-                const float u = input_at(h);
-                cin += stage_cost_input(k, u, uprev);
-                uprev = u;
-                ubuf[ptraj * us + h] = u;
+                float u[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) u[c] = input_at(h, c);
+                cin += E::input_cost(k, u, uprev);
+#pragma unroll
+                for (int c = 0; c < C; ++c) { uprev[c] = u[c]; ubuf[ptraj * us + h * C + c] = u[c]; }
             }
             return cin;
         };
-        const int S1 = min(H, 16), Ha = (S1 + CF_WAVES - 1) / CF_WAVES;
+        const int S1 = min(Hs, 16), Ha = (S1 + CF_WAVES - 1) / CF_WAVES;
         const float cin_a = prepare(lane, min(S1, wave * Ha), min(S1, wave * Ha + Ha));
         if (wave == 0) cin_s[lane] = cin_a;
         __syncthreads();
         CSTAMP(1);
         const float* myu = ubuf + lane * us;
-        auto F_at = [&](int h) { return k.u_max * myu[h]; };
-        State4 st{a.s0[0], a.s0[1], a.s0[2], a.s0[3]};
+        float sx[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) sx[i] = a.s0[i];
         float csum = 0.0f, amax = 0.0f;
-        float4* traj = nullptr;
+        float* traj = nullptr;
         if constexpr (WTRAJ) {
-            if (a.traj_out && last_it) traj = reinterpret_cast<float4*>(a.traj_out) + (size_t)n * (H + 1);
+            if (a.traj_out && last_it) traj = a.traj_out + (size_t)n * (Hs + 1) * S;
         }
-        const bool single = k.intermediate_steps == 1;
+        const bool single = E::fast_ok(k);
         if (wave == 0) {
-            if (single) recur_ode_range<WTRAJ, false, true>(k, traj, valid, F_at, 0, S1, st, csum, amax);
+            if (single) recur_env_range<ENV, WTRAJ, true, true>(k, traj, valid, myu, 0, S1, sx, csum, amax);
         } else {
-            const int Hb = (H - S1 + CF_WAVES - 2) / (CF_WAVES - 1);
-            cin_s[wave * CF_TRAJ + lane] = cin_a + prepare(lane, min(H, S1 + (wave - 1) * Hb), min(H, S1 + (wave - 1) * Hb + Hb));
+            const int Hb = (Hs - S1 + CF_WAVES - 2) / (CF_WAVES - 1);
+            cin_s[wave * CF_TRAJ + lane] = cin_a + prepare(lane, min(Hs, S1 + (wave - 1) * Hb), min(Hs, S1 + (wave - 1) * Hb + Hb));
         }
         __syncthreads();
         if (wave == 0) {
             float J = 0.0f;
             if (single) {
-                recur_ode_range<WTRAJ, false, true>(k, traj, valid, F_at, S1, H, st, csum, amax);
+                recur_env_range<ENV, WTRAJ, true, true>(k, traj, valid, myu, S1, Hs, sx, csum, amax);
                 if constexpr (WTRAJ) {
-                    if (valid && traj) traj[H] = make_float4(st.x, st.v, st.th, st.om);
+                    if (valid && traj) store_state<S>(traj + (size_t)Hs * S, sx);
                 }
-                J = csum + terminal_cost(k, st);
+                J = csum + E::terminal_cost(k, sx);
             }
-            if (!single || __builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0)) {
-                RolloutArgs al = a;
-                if (!last_it) al.traj_out = nullptr;
-                J = recur_ode_state_cost<WTRAJ, true, false>(al, k, n, valid, F_at, &amax);
+            if (!single || __builtin_expect(__builtin_amdgcn_ballot_w64(E::out_of_range(amax)) != 0, 0)) {
+#pragma unroll
+                for (int i = 0; i < S; ++i) sx[i] = a.s0[i];
+                csum = 0.0f;
+                recur_env_range<ENV, WTRAJ, false, true>(k, traj, valid, myu, 0, Hs, sx, csum, amax);
+                if constexpr (WTRAJ) {
+                    if (valid && traj) store_state<S>(traj + (size_t)Hs * S, sx);
+                }
+                J = csum + E::terminal_cost(k, sx);
             }
             float cin = 0.0f;
 #pragma unroll
@@ -489,13 +507,14 @@ __global__ __launch_bounds__(CF_BLOCK) void ctk_cem_fused(const float* __restric
             if (t == 0 && gbest >= row0 && gbest < row0 + CF_TRAJ) {
                 cf.idx_out[0] = gbest;
                 if (expired) __hip_atomic_store(reinterpret_cast<uint32_t*>(cf.u_host) + 2, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                publish_u(cf.u_dev, cf.u_host, ubuf[(gbest - row0) * us], cf.seq);
+                if constexpr (C == 1) publish_u(cf.u_dev, cf.u_host, ubuf[(gbest - row0) * us], cf.seq);
+                else publish_u_vec(cf.u_dev, cf.u_host, ubuf + (gbest - row0) * us, C, cf.seq);
             }
             // :99-102 clip the std, shift both by one step, refill the tail — the handle's distribution for the next MPC step
             if (blockIdx.x == 0) {
                 for (int h = t; h < H; h += CF_BLOCK) {
-                    cf.mu[h] = (h + 1 < H) ? mu_s[h + 1] : cf.mid;
-                    cf.sd[h] = (h + 1 < H) ? fminf(fmaxf(sd_s[h + 1], cf.std_min), cf.std_max) : cf.init_std;
+                    cf.mu[h] = (h + C < H) ? mu_s[h + C] : cf.mid[h - (H - C)];      // shift by one STEP = C columns
+                    cf.sd[h] = (h + C < H) ? fminf(fmaxf(sd_s[h + C], cf.std_min), cf.std_max) : cf.init_std;
                 }
             }
         }
@@ -505,26 +524,40 @@ __global__ __launch_bounds__(CF_BLOCK) void ctk_cem_fused(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// H below: flat columns of a plan (mpc_horizon * control inputs)
 int ctk_cem_fused_blocks(int N) { return (N + CF_TRAJ - 1) / CF_TRAJ; }
 size_t ctk_cem_fused_ll_words(int N, int H) { return (size_t)N + (size_t)ctk_cem_fused_blocks(N) * (1 + 2 * H); }
 size_t ctk_cem_fused_lds(int N, int H) { return (size_t)cem_carve(N, H, ctk_cem_fused_blocks(N)).total * sizeof(float); }
 bool ctk_cem_fusable(int pred, int N, int H) {
     return pred == CTK_PRED_ODE && ctk_cem_fused_blocks(N) <= CTK_CEM_FUSED_MAX_BLOCKS && ctk_cem_fused_lds(N, H) <= 128 * 1024;
 }
-const char* ctk_cem_fused_name(bool log) { return log ? "ctk_cem_fused<true>" : "ctk_cem_fused<false>"; }
+const char* ctk_cem_fused_name(int env, bool log) {
+    if (env == CTK_ENV_CARTPOLE) return log ? "ctk_cem_fused<0, true>" : "ctk_cem_fused<0, false>";
+    return log ? "ctk_cem_fused<1, true>" : "ctk_cem_fused<1, false>";
+}
 
-hipError_t ctk_launch_cem_fused(hipStream_t st, const RolloutArgs& a, const EnvK& k, const float* samples, const CemFusedLaunch& c, bool log,
-                                hipEvent_t e0, hipEvent_t e1) {
-    const int nblk = ctk_cem_fused_blocks(a.N);
-    CemFusedK cf{};
-    cf.its = c.its; cf.K = c.K; cf.nblk = nblk; cf.per_it = (unsigned long long)a.N * a.H;
-    cf.llJ = c.ll; cf.llS = c.ll + a.N; cf.tag0 = c.tag0;
-    cf.std_min = c.std_min; cf.std_max = c.std_max; cf.init_std = c.init_std; cf.mid = c.mid;
-    cf.mu = c.mu; cf.sd = c.sd; cf.u_dev = c.u_dev; cf.u_host = c.u_host; cf.idx_out = c.idx_out; cf.seq = c.seq;
-    cf.timeout_ticks = (unsigned long long)(c.timeout_s * 1.0e8);
-    const size_t lds = ctk_cem_fused_lds(a.N, a.H);
+// a_in.H steps, a_in.C inputs (limits per input); the kernel constants are derived from the environment's parameter table
+hipError_t ctk_launch_cem_fused(hipStream_t st, int env, const float* params, float dt, int isteps, const RolloutArgs& a_in, const float* samples,
+                                const CemFusedLaunch& c, bool log, hipEvent_t e0, hipEvent_t e1) {
+    const int nblk = ctk_cem_fused_blocks(a_in.N);
     const dim3 grid(nblk), block(CF_BLOCK);
-    if (log) CTK_LAUNCH((ctk_cem_fused<true>), grid, block, lds, st, e0, e1, samples, a, k, cf);
-    else CTK_LAUNCH((ctk_cem_fused<false>), grid, block, lds, st, e0, e1, samples, a, k, cf);
+    CTK_FOR_ENV(env, EV, {
+        using E = Env<EV>;
+        RolloutArgs a = a_in;
+        const int HC = a.H * E::C;
+        a.C = E::C; a.P = HC;
+        a.p_magic = HC >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)HC - 1) / (uint64_t)HC) : 0u;
+        const typename E::K k = E::derive(params, dt, isteps);
+        CemFusedK cf{};
+        cf.its = c.its; cf.K = c.K; cf.nblk = nblk; cf.per_it = (unsigned long long)a.N * HC;
+        cf.llJ = c.ll; cf.llS = c.ll + a.N; cf.tag0 = c.tag0;
+        cf.std_min = c.std_min; cf.std_max = c.std_max; cf.init_std = c.init_std;
+        for (int i = 0; i < E::C; ++i) cf.mid[i] = 0.5f * (a.lo[i] + a.hi[i]);
+        cf.mu = c.mu; cf.sd = c.sd; cf.u_dev = c.u_dev; cf.u_host = c.u_host; cf.idx_out = c.idx_out; cf.seq = c.seq;
+        cf.timeout_ticks = (unsigned long long)(c.timeout_s * 1.0e8);
+        const size_t lds = ctk_cem_fused_lds(a.N, HC);
+        if (log) CTK_LAUNCH((ctk_cem_fused<EV, true>), grid, block, lds, st, e0, e1, samples, a, k, cf);
+        else CTK_LAUNCH((ctk_cem_fused<EV, false>), grid, block, lds, st, e0, e1, samples, a, k, cf);
+    });
     return hipGetLastError();
 }

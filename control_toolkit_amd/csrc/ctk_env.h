@@ -286,7 +286,8 @@ CTK_DEV void store_state(float* dst, const float (&s)[S]) {
     }
 }
 
-template <int ENV, bool WRITE_TRAJ, bool FAST>
+// PREP: F holds the raw inputs u (the affine-sampled kernels keep them for the plans they write out); Env::prep_input is applied here
+template <int ENV, bool WRITE_TRAJ, bool FAST, bool PREP = false>
 CTK_DEV void recur_env_range(const typename Env<ENV>::K& k, float* traj, bool valid, const float* F, int hb, int he,
                              float (&s)[Env<ENV>::S], float& csum, float& amax) {
     using E = Env<ENV>;
@@ -299,7 +300,7 @@ CTK_DEV void recur_env_range(const typename Env<ENV>::K& k, float* traj, bool va
     for (int h = hb; h < he; ++h) {
         float f[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) f[c] = fn[c];
+        for (int c = 0; c < C; ++c) f[c] = PREP ? E::prep_input(k, fn[c], c) : fn[c];
         if (h + 1 < he) {
 #pragma unroll
             for (int c = 0; c < C; ++c) fn[c] = F[(h + 1) * C + c];

@@ -86,6 +86,12 @@ int ctk_affine_rollout_blocks(int pred, int N);
 hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const float* samples,
                                      int rng_kind, const float* base, const float* scale, const float* wperm, bool log,
                                      hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const AffineBest* bst = nullptr);
+// the 4-wave kernel for any environment's analytic predictor (constants derived from `params`; bst: 2 + C words per workgroup)
+hipError_t ctk_launch_affine_rollout_env(hipStream_t st, int env, const float* params, float dt, int isteps, const RolloutArgs& a,
+                                         const float* samples, int rng_kind, const float* base, const float* scale, bool log,
+                                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const AffineBest* bst = nullptr);
+size_t ctk_affine_rollout_env_lds(int env, int H);
+const char* ctk_affine_rollout_env_name(int env, bool log);
 // Smallest-K selection under the total order (J, index) and CEM refit
 // (optimizer_cem_tf.py:73-78): idx_out[K] ascending, mu/std [H] from Q[idx].
 hipError_t ctk_launch_select_topk(hipStream_t st, const float* J, int N, int K, int* idx_out, int ldj = 1);
@@ -111,16 +117,18 @@ struct CemFusedLaunch {
     int its, K;                   // outer iterations of this step (optimizer_cem_tf.py:92), cem_best_k
     unsigned long long* ll;       // ctk_cem_fused_ll_words(N, H) hand-off words, zero at allocation
     uint32_t tag0;                // tags tag0 .. tag0 + its - 1: consecutive across launches
-    float std_min, std_max, init_std, mid;
-    float* mu; float* sd;         // [H] the handle's distribution, in / out
+    float std_min, std_max, init_std;
+    float* mu; float* sd;         // [H*C] the handle's distribution, in / out
     float* u_dev; float* u_host; int* idx_out; uint32_t seq;
     double timeout_s;             // wall-clock bound of every in-launch wait
 };
+// H: flat columns of a plan (mpc_horizon * control inputs)
 bool ctk_cem_fusable(int pred, int N, int H);
 size_t ctk_cem_fused_ll_words(int N, int H);
-const char* ctk_cem_fused_name(bool log);
-hipError_t ctk_launch_cem_fused(hipStream_t st, const RolloutArgs& a, const EnvK& k, const float* samples, const CemFusedLaunch& c, bool log,
-                                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+const char* ctk_cem_fused_name(int env, bool log);
+// a.H steps, a.C inputs with their limits; constants derived from the environment's parameter table `params`
+hipError_t ctk_launch_cem_fused(hipStream_t st, int env, const float* params, float dt, int isteps, const RolloutArgs& a, const float* samples,
+                                const CemFusedLaunch& c, bool log, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // ---- ctk_rpgd.hip ---------------------------------------------------------------------------
 const char* ctk_rpgd_descent_name(int pred, int N);

@@ -7,6 +7,7 @@
 // optimizer_cem_tf.py:73 / optimizer_rpgd.py:345 with ties fixed by index), the CEM elite
 // refit (:77-78) and the post-loop shift (:99-102).
 #include "ctk_rollout.h"
+#include "ctk_env.h"
 #include "ctk_mlp.h"
 #include "ctk_gru.h"
 #include "ctk_launch.h"
@@ -20,6 +21,7 @@ constexpr int SAMP_BLOCK = SAMP_TRAJ * SAMP_WAVES;
 // wave (ODE, one trajectory per lane) or on all four (MLP, 16 trajectories per wave on MFMA).
 // GRU: the four waves share ONE 16-trajectory column block (ctk_gru.h), so a workgroup owns 16 trajectories.
 // LDS carve (floats): tile[TRAJ][ts] | ubuf[TRAJ][us] | cin[256/TRAJ][TRAJ] | base[H] | scale[H] | (GRU) exchange slots
+// H here = H*C flat (step, input) columns of a plan (C control inputs; CartPole: C = 1)
 __host__ __device__ inline int affine_carve_floats(int H, int traj) {
     const int f = traj * tile_stride(H) + traj * ((H + 1) | 1) + SAMP_BLOCK + 2 * H;
     return (f + 3) & ~3;
@@ -31,7 +33,7 @@ __host__ __device__ inline int affine_traj(int pred) { return pred == CTK_PRED_G
 // words (the hand-off form of ctk_mppi.hip), block 0 picks the global minimum under the total order (J, index) — what
 // ctk_select_topk(K = 1) + ctk_pick_best_first do in two more launches — and publishes u.
 struct BestArgs {
-    unsigned long long* ll;   // [blocks][3] words; nullptr: no tail
+    unsigned long long* ll;   // [blocks][2 + C] words {key, index, first input[C]}; nullptr: no tail
     uint32_t seq;
     float* u_dev;
     float* u_host;
@@ -51,56 +53,67 @@ CTK_DEV uint32_t ll_get(const unsigned long long* p, uint32_t seq, bool* expired
     return (uint32_t)w;
 }
 
-template <int PRED, bool WTRAJ>
+// ENV: the environment (ctk_env.h); the analytic-predictor instantiation is written against Env<ENV> only (C control inputs:
+// H*C sample columns and inputs per trajectory, per-channel base / scale / clip; recurrence through Env::cost_step); the network
+// predictors' instantiations are CartPole's.  P_ = H*C sample columns of a row, pmagic_ its magic.
+template <int ENV, int PRED, bool WTRAJ>
 // (argument order: see ctk_mppi_rollout — the leading 14 dwords are preloaded into SGPRs at wave launch)
 __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(const float* __restrict__ samples, const float* __restrict__ base,
                                                                  const float* __restrict__ scale,
                                                                  const float* __restrict__ wperm, int rng_kind, int N_, int H_,
-                                                                 int P_, uint32_t pmagic_, RolloutArgs a_in, EnvK k, BestArgs best) {
+                                                                 int P_, uint32_t pmagic_, RolloutArgs a_in, typename Env<ENV>::K k, BestArgs best) {
+    using E = Env<ENV>;
+    constexpr int C = E::C, S = E::S;
+    static_assert(PRED == CTK_PRED_ODE || ENV == CTK_ENV_CARTPOLE, "network predictors: CartPole instantiations only");
     extern __shared__ float lds[];
     RolloutArgs a = a_in;
     a.N = N_; a.H = H_; a.P = P_; a.p_magic = pmagic_;
     constexpr int TRAJ = (PRED == CTK_PRED_GRU) ? GRU_TRAJ : SAMP_TRAJ;
     constexpr int CHUNKS = SAMP_BLOCK / TRAJ;
-    const int H = a.H, ts = tile_stride(a.P), us = (H + 1) | 1;   // P == H here: one sample per step
+    const int H = a.H, HC = H * C, ts = tile_stride(a.P), us = (HC + 1) | 1;   // a.P == H*C here: one sample per step and input
     float* tile = lds;
     float* ubuf = tile + TRAJ * ts;
     float* cin_s = ubuf + TRAJ * us;
     float* base_s = cin_s + SAMP_BLOCK;
-    float* scale_s = base_s + H;
-    float* gru_ex = lds + affine_carve_floats(H, TRAJ);
+    float* scale_s = base_s + HC;
+    float* gru_ex = lds + affine_carve_floats(HC, TRAJ);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int row0 = blockIdx.x * TRAJ;
     const int n = row0 + lane;
     const bool valid = lane < TRAJ && n < a.N;
 
     load_tile_early<TRAJ, SAMP_BLOCK>(tile, samples, a, row0, 1.0f, rng_kind, [&] {
-        for (int h = t; h < H; h += SAMP_BLOCK) { base_s[h] = base[h]; scale_s[h] = scale[h]; }
+        for (int h = t; h < HC; h += SAMP_BLOCK) { base_s[h] = base[h]; scale_s[h] = scale[h]; }
     });
     __syncthreads();
 
     // inputs of the steps [hbeg, hend) of trajectory ptraj into ubuf + their input-only stage-cost terms (returned)
     auto prepare = [&](int ptraj, int hbeg, int hend) {
         const float* my = tile + ptraj * ts;
-        auto input_at = [&](int h) { return fminf(fmaxf(base_s[h] + my[h] * scale_s[h], a.lo[0]), a.hi[0]); };
+        auto input_at = [&](int h, int c) { return fminf(fmaxf(base_s[h * C + c] + my[h * C + c] * scale_s[h * C + c], a.lo[c]), a.hi[c]); };
         float cin = 0.0f;
-        float uprev = (hbeg == 0 || hbeg >= H) ? (a.u_prev_dev ? *a.u_prev_dev : a.u_prev[0]) : input_at(hbeg - 1);
+        float uprev[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            uprev[c] = (hbeg == 0 || hbeg >= H) ? (a.u_prev_dev ? a.u_prev_dev[c] : a.u_prev[c]) : input_at(hbeg - 1, c);
 #pragma unroll 2
         for (int h = hbeg; h < hend; ++h) {
-            const float u = input_at(h);
-            cin += stage_cost_input(k, u, uprev);
-            uprev = u;
-            ubuf[ptraj * us + h] = u;
+            float u[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) u[c] = input_at(h, c);
+            cin += E::input_cost(k, u, uprev);
+#pragma unroll
+            for (int c = 0; c < C; ++c) { uprev[c] = u[c]; ubuf[ptraj * us + h * C + c] = u[c]; }
         }
         return cin;
     };
     // the plans, coalesced: Q[row0*H + i] for the block's contiguous span (elite refit / logging read it)
     auto write_plans = [&](int first, int stride) {
-        const int total = min(TRAJ, a.N - row0) * H;
-        float* dst = a.Q_out + (size_t)row0 * H;
+        const int total = min(TRAJ, a.N - row0) * HC;
+        float* dst = a.Q_out + (size_t)row0 * HC;
         for (int i = first; i < total; i += stride) {
-            const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i;
-            dst[i] = ubuf[r * us + (i - r * H)];
+            const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i;
+            dst[i] = ubuf[r * us + (i - r * HC)];
         }
     };
 
@@ -114,16 +127,17 @@ __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(const float* __
         if (wave == 0) cin_s[lane] = cin_a;
         __syncthreads();
         const float* myu = ubuf + lane * us;
-        auto F_at = [&](int h) { return k.u_max * myu[h]; };
-        State4 st{a.s0[0], a.s0[1], a.s0[2], a.s0[3]};
+        float sx[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) sx[i] = a.s0[i];
         float csum = 0.0f, amax = 0.0f;
-        float4* traj = nullptr;
+        float* traj = nullptr;
         if constexpr (WTRAJ) {
-            if (a.traj_out) traj = reinterpret_cast<float4*>(a.traj_out) + (size_t)n * (H + 1);
+            if (a.traj_out) traj = a.traj_out + (size_t)n * (H + 1) * S;
         }
-        const bool single = k.intermediate_steps == 1;
+        const bool single = E::fast_ok(k);
         if (wave == 0) {
-            if (single) recur_ode_range<WTRAJ, false, true>(k, traj, valid, F_at, 0, S1, st, csum, amax);
+            if (single) recur_env_range<ENV, WTRAJ, true, true>(k, traj, valid, myu, 0, S1, sx, csum, amax);
         } else {
             const int Hb = (H - S1 + SAMP_WAVES - 2) / (SAMP_WAVES - 1);
             cin_s[wave * SAMP_TRAJ + lane] = cin_a + prepare(lane, min(H, S1 + (wave - 1) * Hb), min(H, S1 + (wave - 1) * Hb + Hb));
@@ -132,14 +146,22 @@ __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(const float* __
         if (wave == 0) {
             float J = 0.0f;
             if (single) {
-                recur_ode_range<WTRAJ, false, true>(k, traj, valid, F_at, S1, H, st, csum, amax);
+                recur_env_range<ENV, WTRAJ, true, true>(k, traj, valid, myu, S1, H, sx, csum, amax);
                 if constexpr (WTRAJ) {
-                    if (valid && traj) traj[H] = make_float4(st.x, st.v, st.th, st.om);
+                    if (valid && traj) store_state<S>(traj + (size_t)H * S, sx);
                 }
-                J = csum + terminal_cost(k, st);
+                J = csum + E::terminal_cost(k, sx);
             }
-            if (!single || __builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= CTK_SINCOS_FAST_LIMIT)) != 0, 0))
-                J = recur_ode_state_cost<WTRAJ, true, false>(a, k, n, valid, F_at, &amax);
+            if (!single || __builtin_expect(__builtin_amdgcn_ballot_w64(E::out_of_range(amax)) != 0, 0)) {
+#pragma unroll
+                for (int i = 0; i < S; ++i) sx[i] = a.s0[i];
+                csum = 0.0f;
+                recur_env_range<ENV, WTRAJ, false, true>(k, traj, valid, myu, 0, H, sx, csum, amax);
+                if constexpr (WTRAJ) {
+                    if (valid && traj) store_state<S>(traj + (size_t)H * S, sx);
+                }
+                J = csum + E::terminal_cost(k, sx);
+            }
             J += (cin_s[lane] + cin_s[SAMP_TRAJ + lane]) + (cin_s[2 * SAMP_TRAJ + lane] + cin_s[3 * SAMP_TRAJ + lane]);
             J *= a.inv_Hp1;
             if (valid) a.J[n] = J;
@@ -147,19 +169,28 @@ __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(const float* __
                 const uint32_t key = valid ? f32_sortable(J) : 0xFFFFFFFFu;
                 const uint32_t kmin = wave_min_u32(key);
                 const uint32_t imin = wave_min_u32(key == kmin && valid ? (uint32_t)n : 0x7FFFFFFFu);   // ties: smallest index
+                constexpr int BW = 2 + C;           // words per workgroup: key, index, the plan's first input [C]
                 if (lane == 0) {
-                    unsigned long long* r = best.ll + (size_t)blockIdx.x * 3;
+                    unsigned long long* r = best.ll + (size_t)blockIdx.x * BW;
                     ll_put(r, kmin, best.seq);
                     ll_put(r + 1, imin, best.seq);
-                    ll_put(r + 2, imin < (uint32_t)a.N ? __builtin_bit_cast(uint32_t, ubuf[(imin - (uint32_t)row0) * us]) : 0u, best.seq);
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        ll_put(r + 2 + c, imin < (uint32_t)a.N ? __builtin_bit_cast(uint32_t, ubuf[(imin - (uint32_t)row0) * us + c]) : 0u, best.seq);
                 }
                 if (blockIdx.x == 0) {              // every block finishes unconditionally: the polls terminate (and are bounded)
-                    uint32_t bk = 0xFFFFFFFFu, bi = 0x7FFFFFFFu, bu = 0;
+                    uint32_t bk = 0xFFFFFFFFu, bi = 0x7FFFFFFFu, bu[C] = {};
                     bool expired = false;
                     for (int b = lane; b < (int)gridDim.x; b += 64) {
-                        const uint32_t kb = ll_get(best.ll + (size_t)b * 3, best.seq, &expired), ib = ll_get(best.ll + (size_t)b * 3 + 1, best.seq, &expired);
-                        const uint32_t ub = ll_get(best.ll + (size_t)b * 3 + 2, best.seq, &expired);
-                        if (kb < bk || (kb == bk && ib < bi)) { bk = kb; bi = ib; bu = ub; }
+                        const uint32_t kb = ll_get(best.ll + (size_t)b * BW, best.seq, &expired), ib = ll_get(best.ll + (size_t)b * BW + 1, best.seq, &expired);
+                        uint32_t ub[C];
+#pragma unroll
+                        for (int c = 0; c < C; ++c) ub[c] = ll_get(best.ll + (size_t)b * BW + 2 + c, best.seq, &expired);
+                        if (kb < bk || (kb == bk && ib < bi)) {
+                            bk = kb; bi = ib;
+#pragma unroll
+                            for (int c = 0; c < C; ++c) bu[c] = ub[c];
+                        }
                     }
                     // a stale record may have won or lost wrongly: tell the host (ctk_api.hip:finish_step -> CTK_ERR_STATE)
                     if (expired) __hip_atomic_store(reinterpret_cast<uint32_t*>(best.u_host) + 2, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -167,7 +198,13 @@ __global__ __launch_bounds__(SAMP_BLOCK) void ctk_affine_rollout(const float* __
                     const uint32_t gi = wave_min_u32(bk == gk ? bi : 0x7FFFFFFFu);
                     if (bk == gk && bi == gi) {     // exactly one lane holds the winner
                         best.idx_out[0] = (int)gi;
-                        publish_u(best.u_dev, best.u_host, __builtin_bit_cast(float, bu), best.seq);
+                        if constexpr (C == 1) publish_u(best.u_dev, best.u_host, __builtin_bit_cast(float, bu[0]), best.seq);
+                        else {
+                            float uo[C];
+#pragma unroll
+                            for (int c = 0; c < C; ++c) uo[c] = __builtin_bit_cast(float, bu[c]);
+                            publish_u_vec(best.u_dev, best.u_host, uo, C, best.seq);
+                        }
                     }
                 }
             }
@@ -449,10 +486,15 @@ hipError_t ctk_launch_copy4(hipStream_t st, const CopyJob (&jobs)[4]) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// template arguments <environment, predictor, materialise>
 const char* ctk_affine_rollout_name(int pred, bool log) {
-    if (pred == CTK_PRED_ODE) return log ? "ctk_affine_rollout<0, true>" : "ctk_affine_rollout<0, false>";
-    if (pred == CTK_PRED_GRU) return log ? "ctk_affine_rollout<2, true>" : "ctk_affine_rollout<2, false>";
-    return log ? "ctk_affine_rollout<1, true>" : "ctk_affine_rollout<1, false>";
+    if (pred == CTK_PRED_ODE) return log ? "ctk_affine_rollout<0, 0, true>" : "ctk_affine_rollout<0, 0, false>";
+    if (pred == CTK_PRED_GRU) return log ? "ctk_affine_rollout<0, 2, true>" : "ctk_affine_rollout<0, 2, false>";
+    return log ? "ctk_affine_rollout<0, 1, true>" : "ctk_affine_rollout<0, 1, false>";
+}
+const char* ctk_affine_rollout_env_name(int env, bool log) {
+    if (env == CTK_ENV_CARTPOLE) return ctk_affine_rollout_name(CTK_PRED_ODE, log);
+    return log ? "ctk_affine_rollout<1, 0, true>" : "ctk_affine_rollout<1, 0, false>";
 }
 
 hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const float* samples,
@@ -464,16 +506,42 @@ hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs
     const dim3 grid((a.N + tr - 1) / tr), block(SAMP_BLOCK);
     const size_t lds = ctk_affine_rollout_lds(a.H, pred);
     if (pred == CTK_PRED_ODE) {
-        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
-        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
+        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_ENV_CARTPOLE, CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
+        else CTK_LAUNCH((ctk_affine_rollout<CTK_ENV_CARTPOLE, CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
     } else if (pred == CTK_PRED_MLP) {
-        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_MLP, true>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
-        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_MLP, false>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
+        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_ENV_CARTPOLE, CTK_PRED_MLP, true>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
+        else CTK_LAUNCH((ctk_affine_rollout<CTK_ENV_CARTPOLE, CTK_PRED_MLP, false>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
     } else {
-        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_GRU, true>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
-        else CTK_LAUNCH((ctk_affine_rollout<CTK_PRED_GRU, false>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
+        if (log) CTK_LAUNCH((ctk_affine_rollout<CTK_ENV_CARTPOLE, CTK_PRED_GRU, true>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
+        else CTK_LAUNCH((ctk_affine_rollout<CTK_ENV_CARTPOLE, CTK_PRED_GRU, false>), grid, block, lds, st, e0, e1, samples, base, scale, wperm, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
     }
     return hipGetLastError();
+}
+
+// The same 4-wave kernel for any environment's analytic predictor: a.H steps, a.C inputs (a.lo / a.hi per input); samples
+// [N, H, C] or nullptr (Philox over the flat columns); base / scale [H*C]; bst as above with 2 + C words per workgroup.
+hipError_t ctk_launch_affine_rollout_env(hipStream_t st, int env, const float* params, float dt, int isteps, const RolloutArgs& a_in,
+                                         const float* samples, int rng_kind, const float* base, const float* scale, bool log,
+                                         hipEvent_t e0, hipEvent_t e1, const AffineBest* bst) {
+    BestArgs bargs{nullptr, 0u, nullptr, nullptr, nullptr};
+    if (bst && bst->ll) bargs = BestArgs{bst->ll, bst->seq, bst->u_dev, bst->u_host, bst->idx_out};
+    const dim3 grid((a_in.N + SAMP_TRAJ - 1) / SAMP_TRAJ), block(SAMP_BLOCK);
+    CTK_FOR_ENV(env, EV, {
+        using E = Env<EV>;
+        RolloutArgs a = a_in;
+        const int HC = a.H * E::C;
+        a.C = E::C; a.P = HC;
+        a.p_magic = HC >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)HC - 1) / (uint64_t)HC) : 0u;
+        const typename E::K k = E::derive(params, dt, isteps);
+        const size_t lds = (size_t)affine_carve_floats(HC, SAMP_TRAJ) * sizeof(float);
+        if (log) CTK_LAUNCH((ctk_affine_rollout<EV, CTK_PRED_ODE, true>), grid, block, lds, st, e0, e1, samples, base, scale, (const float*)nullptr, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
+        else CTK_LAUNCH((ctk_affine_rollout<EV, CTK_PRED_ODE, false>), grid, block, lds, st, e0, e1, samples, base, scale, (const float*)nullptr, rng_kind, a.N, a.H, a.P, a.p_magic, a, k, bargs);
+    });
+    return hipGetLastError();
+}
+size_t ctk_affine_rollout_env_lds(int env, int H) {
+    const int C = env == CTK_ENV_CARTPOLE ? Env<CTK_ENV_CARTPOLE>::C : Env<CTK_ENV_QUAD2D>::C;
+    return (size_t)affine_carve_floats(H * C, SAMP_TRAJ) * sizeof(float);
 }
 
 int ctk_affine_rollout_blocks(int pred, int N) { const int tr = affine_traj(pred); return (N + tr - 1) / tr; }

@@ -40,8 +40,14 @@ def test_cartpole_generic_kernels_match_tuned_kernels(opt):
     if opt == "rpgd":
         kw.update(outer_its=3, resamp_per=2, opt_keep_k=48, sample_whole_control_space=1)
     a, b = CtkEngine(opt, "ODE", **kw), CtkEngine(opt, "ODE", generic_kernels=True, **kw)
-    if opt == "mppi":   # the analytic predictor's MPPI kernel IS the template: Env<CartPole> instantiation of ctk_mppi_rollout<ENV, ODE, .>
+    # the analytic predictor's sampling kernels ARE templates over the environment: generic CartPole = the Env<CartPole>
+    # instantiation of ctk_mppi_rollout / ctk_affine_rollout (CEM's tuned path additionally fuses its step into one launch)
+    if opt == "mppi":
         assert a.dominant_kernel() == b.dominant_kernel() == "ctk_mppi_rollout<0, 0, true>"
+    elif opt == "random_action":
+        assert a.dominant_kernel() == b.dominant_kernel() == "ctk_affine_rollout<0, 0, true>"
+    elif opt == "cem":
+        assert a.dominant_kernel() == b.dominant_kernel() == "ctk_cem_fused<0, true>"
     else:
         assert "ctk_g_" in b.dominant_kernel() and "ctk_g_" not in a.dominant_kernel()
     if opt == "rpgd":

@@ -11,7 +11,6 @@
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 4096, H = argc > 2 ? atoi(argv[2]) : 30, K = argc > 3 ? atoi(argv[3]) : 409, its = 3;
     float params[CTK_P_COUNT] = {9.81f, 0.230f, 0.087f, 0.1975f, 2.62f, 4.77f, 2.5e-4f, 0.f, 1.f, 600.f, 20000.f, 80.f, 1.f, 1.f, 1.f, 0.198f, 0.f};
-    EnvK k = derive_constants(params, 0.02f, 1);
     std::vector<float> noise((size_t)its * N * H);
     unsigned s = 1; for (auto& v : noise) { s = s * 1664525u + 1013904223u; v = ((s >> 8) * (1.f / 16777216.f) - 0.5f) * 3.f; }
     const int nb = ctk_cem_fused_blocks(N);
@@ -30,10 +29,10 @@ int main(int argc, char** argv) {
     uint32_t tag = 1;
     for (int rep = 0; rep < 20; ++rep) {
         CK(hipMemcpy(d_mu, mu.data(), H * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_sd, sd.data(), H * 4, hipMemcpyHostToDevice));
-        CemFusedLaunch c{its, K, d_ll, tag, 0.01f, 1e8f, 0.5f, 0.f, d_mu, d_sd, d_u, h_u, d_idx, (uint32_t)(rep + 1), 0.5};
+        CemFusedLaunch c{its, K, d_ll, tag, 0.01f, 1e8f, 0.5f, d_mu, d_sd, d_u, h_u, d_idx, (uint32_t)(rep + 1), 0.5};
         tag += its;
         CK(hipEventRecord(e0, 0));
-        CK(ctk_launch_cem_fused(0, a, k, d_noise, c, false));
+        CK(ctk_launch_cem_fused(0, CTK_ENV_CARTPOLE, params, 0.02f, 1, a, d_noise, c, false));
         CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize()); CK(hipEventElapsedTime(&ms, e0, e1));
     }
     std::vector<unsigned long long> st((size_t)nb * 8 * 16);
