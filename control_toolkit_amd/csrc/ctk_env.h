@@ -80,6 +80,52 @@ struct Env<CTK_ENV_CARTPOLE> {
         }
         s[0] = st.x; s[1] = st.v; s[2] = st.th; s[3] = st.om;
     }
+    // ---- hooks of the descent kernels (ctk_generic.hip: ctk_g_rpgd_descent): the forward pass of a gradient iteration needs
+    //      no cost, only what the reverse sweep will use — NT taped values per step, so that the sweep recomputes nothing
+    //      (one Euler sub-step, as step_vjp).  tape: x, omega, sin, cos, tmp, thdd ----------------------------------------------
+    static constexpr int NT = 6;
+    CTK_DEV static void fwd_tape(const K& k, float (&s)[S], const float (&u)[C], float (&tp)[NT]) {
+        float sn, cs;
+        ctk_sincosf(s[2], &sn, &cs);
+        const float F = k.u_max * u[0];
+        const float A = F + k.k_ml * s[3] * s[3] * sn - k.M_fric * s[1];
+        const float tmp = A * k.inv_mt;
+        const float D = k.k43l - k.k_mpl_mt * cs * cs;
+        const float Nn = k.g * sn - cs * tmp - k.k_jf * s[3];
+        const float thdd = fdiv_pos(Nn, D);
+        const float xdd = tmp - k.k_mpl_mt * thdd * cs;
+        tp[0] = s[0]; tp[1] = s[3]; tp[2] = sn; tp[3] = cs; tp[4] = tmp; tp[5] = thdd;
+        const float nx = s[0] + k.dt * s[1], nv = s[1] + k.dt * xdd, nth = s[2] + k.dt * s[3], nom = s[3] + k.dt * thdd;
+        s[0] = nx; s[1] = nv; s[2] = nth; s[3] = nom;
+    }
+    // lam: dL/ds_{h+1} in, dL/ds_h out (= stage-cost state gradient * inv + J^T lam); du: dL/du_h through the dynamics
+    CTK_DEV static void bwd_tape(const K& k, const float (&tp)[NT], const float (&)[C], float (&lam)[S], float (&du)[C], float inv) {
+        const float x = tp[0], om = tp[1], sn = tp[2], cs = tp[3], tmp = tp[4], thdd = tp[5];
+        const float lx = lam[0], lv = lam[1], lth = lam[2], lom = lam[3];
+        const float two_dd = 2.0f * k.dd_weight * k.inv_xs * k.inv_xs;
+        const float D = k.k43l - k.k_mpl_mt * cs * cs;
+        const float dt = k.dt;
+        const float a_xdd = dt * lv;
+        const float a_thdd = dt * lom - k.k_mpl_mt * cs * a_xdd;
+        float a_tmp = a_xdd;
+        float a_cs = -k.k_mpl_mt * thdd * a_xdd;
+        const float a_Nn = fdiv_pos(a_thdd, D);
+        const float a_D = -a_Nn * thdd;
+        float a_sn = k.g * a_Nn;
+        a_cs = a_cs - tmp * a_Nn - 2.0f * k.k_mpl_mt * cs * a_D;
+        a_tmp = a_tmp - cs * a_Nn;
+        const float a_A = a_tmp * k.inv_mt;
+        a_sn = a_sn + k.k_ml * om * om * a_A;
+        const float o_x = lx;
+        const float o_v = lv + dt * lx - k.M_fric * a_A;
+        const float o_th = lth + cs * a_sn - sn * a_cs;
+        const float o_om = lom + dt * lth - k.k_jf * a_Nn + 2.0f * k.k_ml * om * sn * a_A;
+        du[0] = k.u_max * a_A;
+        lam[0] = two_dd * (x - k.target_position) * inv + o_x;
+        lam[1] = o_v;
+        lam[2] = 2.0f * k.ep_c * (1.0f - cs) * sn * inv + o_th;
+        lam[3] = 2.0f * k.ekp_weight * om * inv + o_om;
+    }
     // adjoint of one Euler step (intermediate_steps == 1): lam = dL/ds' -> ds = dL/ds, du = dL/du
     CTK_DEV static void step_vjp(const K& k, const float (&s)[S], const float (&u)[C], const float (&lam)[S], float (&ds)[S],
                                  float (&du)[C]) {
@@ -223,6 +269,40 @@ struct Env<CTK_ENV_QUAD2D> {
         }
     }
 
+    // hooks of the descent kernels (see CartPole).  tape: the six states, sin, cos of the attitude
+    static constexpr int NT = 8;
+    CTK_DEV static void fwd_tape(const K& k, float (&s)[S], const float (&u)[C], float (&tp)[NT]) {
+        float sn, cs;
+        ctk_sincosf(s[4], &sn, &cs);
+#pragma unroll
+        for (int i = 0; i < S; ++i) tp[i] = s[i];
+        tp[6] = sn; tp[7] = cs;
+        const float aF = k.g + k.kF * (u[0] + u[1]);
+        const float aM = k.kM * (u[0] - u[1]);
+        const float ax = -aF * sn - k.c_v * s[1];
+        const float az = aF * cs - k.g - k.c_v * s[3];
+        const float al = aM - k.c_w * s[5];
+        const float nx = s[0] + k.dt * s[1], nvx = s[1] + k.dt * ax, nz = s[2] + k.dt * s[3], nvz = s[3] + k.dt * az;
+        const float nth = s[4] + k.dt * s[5], nom = s[5] + k.dt * al;
+        s[0] = nx; s[1] = nvx; s[2] = nz; s[3] = nvz; s[4] = nth; s[5] = nom;
+    }
+    CTK_DEV static void bwd_tape(const K& k, const float (&tp)[NT], const float (&u)[C], float (&lam)[S], float (&du)[C], float inv) {
+        const float sn = tp[6], cs = tp[7];
+        const float aF = k.g + k.kF * (u[0] + u[1]);
+        const float dt = k.dt;
+        const float a_ax = dt * lam[1], a_az = dt * lam[3], a_al = dt * lam[5];
+        const float a_aF = -sn * a_ax + cs * a_az;
+        const float d0 = lam[0], d1 = lam[1] + dt * lam[0] - k.c_v * a_ax, d2 = lam[2], d3 = lam[3] + dt * lam[2] - k.c_v * a_az;
+        const float d4 = lam[4] - aF * (cs * a_ax + sn * a_az), d5 = lam[5] + dt * lam[4] - k.c_w * a_al;
+        du[0] = k.kF * a_aF + k.kM * a_al;
+        du[1] = k.kF * a_aF - k.kM * a_al;
+        lam[0] = 2.0f * k.pos_c * (tp[0] - k.tx) * inv + d0;
+        lam[1] = 2.0f * k.vel_w * tp[1] * inv + d1;
+        lam[2] = 2.0f * k.pos_c * (tp[2] - k.tz) * inv + d2;
+        lam[3] = 2.0f * k.vel_w * tp[3] * inv + d3;
+        lam[4] = k.ang_w * sn * inv + d4;
+        lam[5] = 2.0f * k.angvel_w * tp[5] * inv + d5;
+    }
     CTK_DEV static void step_vjp(const K& k, const float (&s)[S], const float (&u)[C], const float (&lam)[S], float (&ds)[S],
                                  float (&du)[C]) {
         float sn, cs;

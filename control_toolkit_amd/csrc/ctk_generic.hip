@@ -17,6 +17,7 @@
 //        (optimizer_rpgd.py:306-338, :342)
 // The block-record merge (ctk_mppi_merge<false>), the selection (ctk_select_topk), the refit (ctk_cem_refit) and the
 // RPGD warm start are shared with the CartPole kernels: they only ever see P*C / H*C columns.
+#include <type_traits>
 #include "ctk_rollout.h"
 #include "ctk_env.h"
 #include "ctk_adam.h"
@@ -243,13 +244,14 @@ __global__ __launch_bounds__(GR_BLOCK) void ctk_g_rpgd_descent(RolloutArgs a, ty
     float* q_s = lds;                        // [HC][65]
     float* g_s = q_s + HC * GR_LD;           // [HC][65]
     float* sc_s = g_s + HC * GR_LD;          // [64]
-    float* tape_l = sc_s + G_TRAJ;           // [H][S][64]
+    float* tape_l = sc_s + G_TRAJ;           // [H][NT][64]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int row0 = blockIdx.x * G_TRAJ;
     const int rows = min(G_TRAJ, a.N - row0);
     const int total = rows * HC;
     const size_t gbase = (size_t)row0 * HC;
-    float* tape = tape_in_lds ? tape_l : scratch + (size_t)blockIdx.x * H * S * 64;
+    constexpr int NT = E::NT;                // taped values per step (Env::fwd_tape / bwd_tape: the sweep recomputes nothing)
+    float* tape = tape_in_lds ? tape_l : scratch + (size_t)blockIdx.x * H * NT * 64;
 
     for (int i = t; i < G_TRAJ * HC; i += GR_BLOCK) {      // a.p_magic = ceil(2^32 / HC)
         const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, hc = i - r * HC;
@@ -262,34 +264,71 @@ __global__ __launch_bounds__(GR_BLOCK) void ctk_g_rpgd_descent(RolloutArgs a, ty
     for (int c = 0; c < C; ++c) up0[c] = a.u_prev_dev ? a.u_prev_dev[c] : a.u_prev[c];
     const float inv = a.inv_Hp1;
 
-    auto forward = [&](bool with_tape, float (&sF)[S]) {     // returns J of the lane's plan, the final state in sF
-        float s[S], up[C], csum = 0.0f;
+    // forward pass of a gradient iteration: no cost, NT taped values per step; the final state in sF
+    auto forward_tape = [&](float (&sF)[S]) {
+        float s[S];
 #pragma unroll
         for (int i = 0; i < S; ++i) s[i] = a.s0[i];
+        float un[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) up[c] = up0[c];
+        for (int c = 0; c < C; ++c) un[c] = q_s[c * GR_LD + lane];
         for (int h = 0; h < H; ++h) {
-            float u[C];
+            float u[C], tp[NT];
 #pragma unroll
-            for (int c = 0; c < C; ++c) u[c] = q_s[(h * C + c) * GR_LD + lane];
-            if (with_tape) {
+            for (int c = 0; c < C; ++c) u[c] = un[c];
+            if (h + 1 < H) {
 #pragma unroll
-                for (int i = 0; i < S; ++i) tape[((size_t)h * S + i) * 64 + lane] = s[i];
+                for (int c = 0; c < C; ++c) un[c] = q_s[((h + 1) * C + c) * GR_LD + lane];
             }
-            csum += E::stage_cost(k, s, u, up);
-            E::step(k, s, u);
+            E::fwd_tape(k, s, u, tp);
 #pragma unroll
-            for (int c = 0; c < C; ++c) up[c] = u[c];
+            for (int i = 0; i < NT; ++i) tape[((size_t)h * NT + i) * 64 + lane] = tp[i];
         }
 #pragma unroll
         for (int i = 0; i < S; ++i) sF[i] = s[i];
-        return (csum + E::terminal_cost(k, s)) * inv;
+    };
+    // get_action's cost pass (:342): the recurrence of the sampling kernels (Env::cost_step, checked fallback) + the input-only terms
+    auto final_cost = [&]() {
+        float u[C], up[C], cin = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) up[c] = up0[c];
+        for (int h = 0; h < H; ++h) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) u[c] = q_s[(h * C + c) * GR_LD + lane];
+            cin += E::input_cost(k, u, up);
+#pragma unroll
+            for (int c = 0; c < C; ++c) up[c] = u[c];
+        }
+        auto run = [&](auto fast) {
+            constexpr bool FAST = decltype(fast)::value;
+            float s[S], csum = 0.0f, amax = 0.0f;
+#pragma unroll
+            for (int i = 0; i < S; ++i) s[i] = a.s0[i];
+            float un[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) un[c] = q_s[c * GR_LD + lane];
+            for (int h = 0; h < H; ++h) {
+                float f[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) f[c] = E::prep_input(k, un[c], c);
+                if (h + 1 < H) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) un[c] = q_s[((h + 1) * C + c) * GR_LD + lane];
+                }
+                E::template cost_step<FAST>(k, s, f, csum, amax);
+            }
+            const float J = csum + E::terminal_cost(k, s);
+            return __builtin_amdgcn_ballot_w64(FAST && E::out_of_range(amax)) != 0 ? __builtin_nanf("") : J;
+        };
+        float J = E::fast_ok(k) ? run(std::true_type{}) : __builtin_nanf("");
+        if (__builtin_amdgcn_ballot_w64(J != J) != 0) J = run(std::false_type{});   // wave-uniform: Euler sub-steps or an angle out of range
+        return (J + cin) * inv;
     };
 
     for (int it = 0; it < iters; ++it) {
         if (wave == 0) {
             float sH[S], lam[S];
-            (void)forward(true, sH);
+            forward_tape(sH);
             E::terminal_grad(k, sH, lam);
 #pragma unroll
             for (int i = 0; i < S; ++i) lam[i] *= inv;
@@ -298,16 +337,16 @@ __global__ __launch_bounds__(GR_BLOCK) void ctk_g_rpgd_descent(RolloutArgs a, ty
 #pragma unroll
             for (int c = 0; c < C; ++c) gp_next[c] = 0.0f;
             for (int h = H - 1; h >= 0; --h) {
-                float s[S], u[C], upv[C];
+                float tp[NT], u[C], upv[C];
 #pragma unroll
-                for (int i = 0; i < S; ++i) s[i] = tape[((size_t)h * S + i) * 64 + lane];
+                for (int i = 0; i < NT; ++i) tp[i] = tape[((size_t)h * NT + i) * 64 + lane];
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     u[c] = q_s[(h * C + c) * GR_LD + lane];
                     upv[c] = h > 0 ? q_s[((h - 1) * C + c) * GR_LD + lane] : up0[c];
                 }
-                float ds[S], du[C], gu[C], gp[C], gs[S];
-                E::step_vjp(k, s, u, lam, ds, du);
+                float du[C], gu[C], gp[C];
+                E::bwd_tape(k, tp, u, lam, du, inv);
                 E::input_grad(k, u, upv, gu, gp);
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
@@ -316,9 +355,6 @@ __global__ __launch_bounds__(GR_BLOCK) void ctk_g_rpgd_descent(RolloutArgs a, ty
                     nrm2 += g * g;
                     gp_next[c] = gp[c];
                 }
-                E::stage_grad_state(k, s, gs);
-#pragma unroll
-                for (int i = 0; i < S; ++i) lam[i] = gs[i] * inv + ds[i];
             }
             sc_s[lane] = ad.clip / fmaxf(sqrtf(nrm2), ad.clip);       // clip_by_norm over [H,C] (:315,:334)
         }
@@ -337,8 +373,7 @@ __global__ __launch_bounds__(GR_BLOCK) void ctk_g_rpgd_descent(RolloutArgs a, ty
         __syncthreads();
     }
     if (wave == 0) {                          // get_action's forward pass (:342)
-        float sH[S];
-        const float J = forward(false, sH);
+        const float J = final_cost();
         if (row0 + lane < a.N) a.J[row0 + lane] = J;
     }
     __syncthreads();
@@ -415,18 +450,18 @@ hipError_t ctk_launch_g_pick_best_first(hipStream_t st, const float* Q, const in
 static size_t g_rpgd_lds_base(int H, int C) { return (size_t)(2 * H * C * GR_LD + G_TRAJ) * sizeof(float); }
 
 size_t ctk_g_rpgd_descent_lds(int env, int H, bool* tape_in_lds) {
-    int S = 0, C = 0;
-    CTK_FOR_ENV(env, EV, { S = Env<EV>::S; C = Env<EV>::C; });
-    const size_t base = g_rpgd_lds_base(H, C), tape = (size_t)H * S * 64 * sizeof(float);
+    int NT = 0, C = 0;
+    CTK_FOR_ENV(env, EV, { NT = Env<EV>::NT; C = Env<EV>::C; });
+    const size_t base = g_rpgd_lds_base(H, C), tape = (size_t)H * NT * 64 * sizeof(float);
     const bool fits = base + tape <= 160 * 1024;
     if (tape_in_lds) *tape_in_lds = fits;
     return fits ? base + tape : base;
 }
 
 size_t ctk_g_rpgd_scratch_floats(int env, int N, int H) {
-    int S = 0;
-    CTK_FOR_ENV(env, EV, { S = Env<EV>::S; });
-    return (size_t)((N + G_TRAJ - 1) / G_TRAJ) * H * S * 64;
+    int NT = 0;
+    CTK_FOR_ENV(env, EV, { NT = Env<EV>::NT; });
+    return (size_t)((N + G_TRAJ - 1) / G_TRAJ) * H * NT * 64;
 }
 
 const char* ctk_g_rpgd_descent_name(int env) { return env == CTK_ENV_CARTPOLE ? "ctk_g_rpgd_descent<0>" : "ctk_g_rpgd_descent<1>"; }
