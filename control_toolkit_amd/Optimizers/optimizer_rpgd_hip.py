@@ -41,6 +41,12 @@ class optimizer_rpgd_hip(template_optimizer):
         self.first_iter_count = warmup_iterations if warmup else outer_its    # :219-221
         self.learning_rate = learning_rate
         self.adam_beta_1, self.adam_beta_2, self.adam_epsilon = adam_beta_1, adam_beta_2, adam_epsilon
+        # The reference picks the update rule with the computation library (optimizer_rpgd.py:35-53): TensorFlow wraps
+        # tf.keras.optimizers.Adam (the YAML entry `rpgd-tf`), PyTorch runs the in-repo Adam (:56-82).  Here it is a key of its
+        # own: adam_rule: torch (default) | keras.
+        self.adam_rule = kwargs.get("adam_rule", "torch")
+        if self.adam_rule not in ("torch", "keras"):
+            raise ValueError(f"adam_rule must be 'torch' or 'keras', got {self.adam_rule!r}")
         self.summed_stage_cost = None
         self.count = 0
 
@@ -58,6 +64,7 @@ class optimizer_rpgd_hip(template_optimizer):
             sample_stdev=self.sample_stdev, sample_mean=self.sample_mean, sample_min=self.sample_min,
             sample_max=self.sample_max, learning_rate=self.learning_rate, gradmax_clip=self.gradmax_clip,
             adam_beta_1=self.adam_beta_1, adam_beta_2=self.adam_beta_2, adam_epsilon=self.adam_epsilon,
+            adam_rule=1 if self.adam_rule == "keras" else 0,
             warmup=int(bool(self.do_warmup)), warmup_iterations=self.warmup_iterations,
             period_interpolation_inducing_points=self.period_interpolation_inducing_points)
         self.number_of_interpolation_inducing_points = self.engine.inducing_points()

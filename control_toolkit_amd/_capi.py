@@ -48,7 +48,7 @@ class CtkConfig(C.Structure):
         ("sampling_distribution", C.c_int32), ("sample_whole_control_space", C.c_int32),
         ("sample_stdev", C.c_float), ("sample_mean", C.c_float), ("sample_min", C.c_float), ("sample_max", C.c_float),
         ("learning_rate", C.c_float), ("gradmax_clip", C.c_float), ("adam_beta_1", C.c_float),
-        ("adam_beta_2", C.c_float), ("adam_epsilon", C.c_float),
+        ("adam_beta_2", C.c_float), ("adam_epsilon", C.c_float), ("adam_rule", C.c_int32),
     ]
 
 
@@ -144,7 +144,7 @@ def load_library():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.ctk_abi_version() != 3:
+    if lib.ctk_abi_version() != 4:
         raise CtkError("libctk_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -216,7 +216,7 @@ class CtkEngine:
                         warmup=0, warmup_iterations=0, cem_initial_action_stdev=0.5, cem_stdev_min=0.01,
                         outer_its=1, resamp_per=1, shift_previous=1, opt_keep_k=1, sampling_distribution=0,
                         sample_whole_control_space=0, sample_stdev=0.5, sample_mean=0.0, sample_min=-1.0, sample_max=1.0, learning_rate=0.05,
-                        gradmax_clip=5.0, adam_beta_1=0.9, adam_beta_2=0.999, adam_epsilon=1e-8)
+                        gradmax_clip=5.0, adam_beta_1=0.9, adam_beta_2=0.999, adam_epsilon=1e-8, adam_rule=0)
         unknown = set(kw) - set(defaults)
         if unknown:
             raise TypeError(f"unknown engine arguments: {sorted(unknown)}")

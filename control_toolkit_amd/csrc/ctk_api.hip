@@ -851,7 +851,7 @@ int rpgd_descent(ctk_handle* h, const float* s, const float* u_prev, const RpgdF
     const int iters = rpgd_iterations(h);
     RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);   // p_magic divides by H in the descent kernel
     if (int rc = launch_descent(h, a, c.learning_rate, c.adam_beta_1, c.adam_beta_2, c.adam_epsilon, h->d_pop[h->rcur], h->d_m[h->rcur],
-                                h->d_v[h->rcur], h->d_bc, h->bc_len, h->adam_step, iters, h->variant == CTK_OPT_GRADIENT ? 1 : 0, fused)) return rc;
+                                h->d_v[h->rcur], h->d_bc, h->bc_len, h->adam_step, iters, (h->variant == CTK_OPT_GRADIENT || c.adam_rule == 1) ? 1 : 0, fused)) return rc;
     h->adam_step += iters;
     return CTK_OK;
 }

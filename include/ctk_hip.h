@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CTK_ABI_VERSION 3
+#define CTK_ABI_VERSION 4
 #define CTK_MAX_STATES 8   /* S <= 8 */
 #define CTK_MAX_INPUTS 4   /* C <= 4 */
 
@@ -169,6 +169,9 @@ typedef struct ctk_config {
                                            (optimizer_rpgd.py:200-203); 0: [sample_min, sample_max] for every input  */
     float sample_stdev, sample_mean, sample_min, sample_max;
     float learning_rate, gradmax_clip, adam_beta_1, adam_beta_2, adam_epsilon;
+    int32_t adam_rule;   /* RPGD update rule: 0 = the in-repo torch Adam (optimizer_rpgd.py:56-82); 1 = tf.keras.optimizers.Adam,
+                            what the reference's TensorFlow branch wraps (:38-43,:306-320; the YAML entry `rpgd-tf`) — third-party
+                            arithmetic, published rule: lr_t = lr sqrt(1-b2^t)/(1-b1^t), epsilon not bias-corrected            */
 } ctk_config;
 
 /* -------------------------------------------------------------------------------------------

@@ -916,7 +916,7 @@ class RPGD:
                  uniform_dist_max=1.0, resamp_per=10, period_interpolation_inducing_points=10,
                  SAMPLING_DISTRIBUTION="uniform", shift_previous=1, warmup=False, warmup_iterations=250,
                  learning_rate=0.05, opt_keep_k_ratio=0.25, gradmax_clip=5.0, adam_beta_1=0.9,
-                 adam_beta_2=0.999, adam_epsilon=1e-8):
+                 adam_beta_2=0.999, adam_epsilon=1e-8, adam_rule="torch"):
         self.predictor, self.cost = predictor, cost
         self.N, self.H = num_rollouts, mpc_horizon
         self.S, self.C = predictor.S, predictor.C
@@ -936,7 +936,11 @@ class RPGD:
         self.first_iter_count = warmup_iterations if warmup else outer_its   # :219-221
         self.k = int(max(int(num_rollouts * opt_keep_k_ratio), 1))           # :213
         self.gradmax_clip = f32(gradmax_clip)
-        self.opt = Adam(learning_rate, adam_beta_1, adam_beta_2, adam_epsilon)
+        # optimizer_rpgd.py:35-53: the TensorFlow branch wraps tf.keras.optimizers.Adam (third party; published rule, KerasAdam below),
+        # the torch branch is the in-repo Adam (:56-82); everything around the update is shared
+        if adam_rule not in ("torch", "keras"):
+            raise ValueError(f"adam_rule must be 'torch' or 'keras', got {adam_rule!r}")
+        self.opt = (KerasAdam if adam_rule == "keras" else Adam)(learning_rate, adam_beta_1, adam_beta_2, adam_epsilon)
         self.u = _u_out(np.zeros(self.C, np.float32))
 
     def sample_actions(self, draws):

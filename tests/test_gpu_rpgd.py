@@ -145,6 +145,43 @@ def test_rpgd_device_rng_reset_and_step_run():
     e.close()
 
 
+def descent_fp64(env, w, dt, s0, u_prev, Q0, m0, v0, t0, its, lr=0.05, b1=0.9, b2=0.999, eps=1e-8, clip=5.0, low=-1.0, high=1.0):
+    """The descent of optimizer_rpgd.py:306-338 (torch branch: autograd, clip_by_norm over [1,2], the in-repo Adam :56-82, clip to
+    the limits) in FLOAT64 on the CartPole MLP predictor and cost of the oracle — the reference point against which the fp32
+    oracle's own rounding is measured.  Returns Q, m, v after `its` iterations from (Q0, m0, v0, Adam step t0)."""
+    import torch
+    T = lambda a: torch.tensor(np.asarray(a, np.float64))
+    k = {kk: float(v) for kk, v in O.derived_constants(env, dt, 1).items()}
+    W1, b1_, W2, b2_, W3, b3_ = (T(a) for a in O.mlp_unpack(w))
+    Q, m, v = T(Q0), T(m0), T(v0)
+    N, H, _ = Q.shape
+    s_init = T(s0).reshape(1, 4).repeat(N, 1)
+    for it in range(its):
+        Qv = Q.clone().requires_grad_(True)
+        s, J = s_init, torch.zeros(N, dtype=torch.float64)
+        up = torch.full((N,), float(u_prev), dtype=torch.float64)
+        for h in range(H):
+            u = Qv[:, h, 0]
+            dxn = (s[:, 0] - float(env.target_position)) * k["inv_xs"]
+            omc = 1.0 - torch.cos(s[:, 2])
+            J = J + float(env.dd_weight) * dxn * dxn + k["ep_c"] * omc * omc + float(env.ekp_weight) * s[:, 3] ** 2 \
+                + k["ccR"] * u * u + float(env.ccrc_weight) * (u - up) ** 2
+            x = torch.cat([s, u[:, None]], 1)
+            s = torch.tanh(torch.tanh(x @ W1.T + b1_) @ W2.T + b2_) @ W3.T + b3_
+            up = u
+        dxn = (s[:, 0] - float(env.target_position)) * k["inv_xs"]
+        omc = 1.0 - torch.cos(s[:, 2])
+        J = (J + float(env.terminal_weight) * (float(env.dd_weight) * dxn * dxn + k["ep_c"] * omc * omc)) / (H + 1)
+        g, = torch.autograd.grad(J.sum(), Qv)
+        nrm = torch.sqrt((g * g).sum(dim=(1, 2), keepdim=True))
+        g = g * clip / torch.clamp(nrm, min=clip)
+        t = t0 + it + 1
+        m = b1 * m + (1 - b1) * g
+        v = b2 * v + (1 - b2) * g * g
+        Q = torch.clamp(Q - lr * (m / (1 - b1 ** t)) / (torch.sqrt(v / (1 - b2 ** t)) + eps), low, high)
+    return Q.numpy(), m.numpy(), v.numpy()
+
+
 @pytest.mark.parametrize("N,H,p,its", [(256, 50, 10, 20), (48, 12, 4, 3), (24, 10, 5, 3), (40, 70, 7, 2)])
 def test_rpgd_mlp_matches_oracle(N, H, p, its):
     # (256, 50, 10, 20) is BASELINE config 4: RPGD, N=256 x 20 Adam iterations, H=50, MLP predictor (MFMA path)
@@ -167,15 +204,31 @@ def test_rpgd_mlp_matches_oracle(N, H, p, its):
     tol = dict(rtol=1e-3, atol=3e-3) if its >= 20 else dict(rtol=2e-4, atol=2e-4)
     for t in range(2):
         dr = rng.random((N - o.k, o.P, 1), dtype=np.float32) if t % 10 == 0 else None
+        start = (o.Q.copy(), None if o.opt.m is None else o.opt.m.copy(), None if o.opt.v is None else o.opt.v.copy(), o.opt.step_count, float(o.u))
         uo = o.step(s, dr)
         ug = e.step(s, dr)
-        # the golden test above holds the SAME configuration (N 256, 20 iterations, MLP) to the reference-recorded
-        # fixture with no outlier allowance at all; here, against the oracle on other inputs, at most a handful
+        # DERIVED outlier allowance.  Adam's normalised update has magnitude ~lr whatever the gradient's size, so an element
+        # whose gradient is within fp32 rounding of zero may move the other way.  How many such elements THIS step has is
+        # measured, not fitted: the same descent in float64 (descent_fp64), pushed through the same keep-k / shift, against the
+        # fp32 oracle's result — every keeper element where the fp32 oracle itself leaves the stated tolerance of the float64
+        # result is one whose outcome fp32 rounding decides.  The device (another fp32 evaluation, other association) gets
+        # twice that count + 2 (its flips need not coincide with the oracle's), on the keeper rows; fresh rows must match exactly.
+        z = np.zeros_like(start[0])
+        Q64, m64, v64 = descent_fp64(env, w, 0.02, s, start[4], start[0], z if start[1] is None else start[1], z if start[2] is None else start[2],
+                                     start[3], its)
+        resampled = dr is not None                          # resampling step: rows N-k.. are the keepers in the fp32 oracle's order
+        keep = o.best_idx if resampled else np.arange(N)    # otherwise every plan is kept in place (optimizer_rpgd.py:496-513)
+        first = N - o.k if resampled else 0
+        shift = lambda A, fill_last: np.concatenate([A[keep, 1:], A[keep, -1:] if fill_last else np.zeros_like(A[keep, -1:])], 1)
+        n_unstable_q = count_outliers(o.Q[first:], shift(Q64, True), **tol)
+        n_unstable_m = count_outliers(o.opt.m[first:], shift(m64, False), **tol)
+        allow_q, allow_m = 2 * n_unstable_q + 2, 2 * n_unstable_m + 2
         n_q, n_m = count_outliers(e.read("PLAN"), o.Q, **tol), count_outliers(e.read("ADAM_M"), o.opt.m, **tol)
-        print(f"rpgd_mlp N={N} its={its} step {t}: outliers Q {n_q} / {o.Q.size}, m {n_m}")
-        # measured on MI355X at (256, 50, 10, 20): 0 / 0 after the first step, 5 / 22 of 12 800 after the second
-        assert_close_mostly(e.read("PLAN"), o.Q, max_outliers=max(4, o.Q.size // 400), **tol)
-        assert_close_mostly(e.read("ADAM_M"), o.opt.m, max_outliers=max(4, o.Q.size // 400), **tol)
+        print(f"rpgd_mlp N={N} its={its} step {t}: fp32-vs-fp64 unstable Q {n_unstable_q} m {n_unstable_m} -> allowed {allow_q} / {allow_m}; "
+              f"device outliers Q {n_q} / {o.Q.size}, m {n_m}")
+        np.testing.assert_allclose(e.read("PLAN")[:first], o.Q[:first], rtol=1e-6, atol=1e-7)   # fresh rows: no descent behind them
+        assert_close_mostly(e.read("PLAN"), o.Q, max_outliers=allow_q, **tol)
+        assert_close_mostly(e.read("ADAM_M"), o.opt.m, max_outliers=allow_m, **tol)
         np.testing.assert_allclose(ug[0], uo, **tol)
         e.set_state(state_vec(o.Q, o.opt.m, o.opt.v, o.trajectory_ages, float(o.u), o.opt.step_count, o.count))
         s = pred.step(s.reshape(1, 4), np.array([uo], np.float32))[0]
@@ -267,4 +320,53 @@ def test_rpgd_whole_control_space_on_fused_and_unfused_steps(pred_name, N):
         np.testing.assert_allclose(ug[0], uo, rtol=2e-4, atol=2e-4)
         e.set_state(state_vec(o.Q, o.opt.m, o.opt.v, o.trajectory_ages, float(o.u), o.opt.step_count, o.count))
         s = pred.step(s.reshape(1, 4), np.array([uo], np.float32))[0]
+    e.close()
+
+
+@pytest.mark.parametrize("pred_name,N,its", [("ODE", 256, 5), ("ODE", 48, 3), ("MLP", 64, 4), ("MLP", 24, 3)])
+def test_rpgd_keras_adam_rule_matches_oracle(pred_name, N, its):
+    """adam_rule = keras: the update the reference's TensorFlow branch delegates to tf.keras.optimizers.Adam
+    (optimizer_rpgd.py:38-43,306-320) — third-party arithmetic, restated from its published rule (oracle KerasAdam):
+    PARITY UNPINNED (TensorFlow is not importable here).  Covers the one-launch step, the wide MLP form and the plain form."""
+    from control_toolkit_amd import CtkEngine
+    from gpu_helpers import apply_env
+    H, p = 20, 5
+    env = O.EnvParams(terminal_weight=0.3)
+    w = O.mlp_default_weights(4) if pred_name == "MLP" else None
+    pred = O.Predictor(pred_name, dt=0.02, env=env, weights=w)
+    o = O.RPGD(pred, O.Cost(env), num_rollouts=N, mpc_horizon=H, outer_its=its, resamp_per=2, period_interpolation_inducing_points=p,
+               SAMPLING_DISTRIBUTION="uniform", shift_previous=1, learning_rate=0.05, opt_keep_k_ratio=0.25, gradmax_clip=5.0,
+               adam_rule="keras")
+    e = CtkEngine("rpgd", pred_name, num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p, outer_its=its,
+                  resamp_per=2, shift_previous=1, opt_keep_k=o.k, sampling_distribution=0, sample_min=-1.0, sample_max=1.0,
+                  learning_rate=0.05, gradmax_clip=5.0, adam_rule=1)
+    apply_env(e, env)
+    if w is not None:
+        e.set_predictor_weights(w)
+    rng = np.random.default_rng(N + its)
+    d0 = rng.random((N, o.P, 1), dtype=np.float32)
+    o.optimizer_reset(d0); e.reset(d0)
+    s = np.array([0.05, 0.0, 2.9, 0.3], np.float32)
+    differs_from_torch_rule = False
+    for t in range(3):
+        dr = rng.random((N - o.k, o.P, 1), dtype=np.float32) if t % 2 == 0 else None
+        uo = o.step(s, dr)
+        ug = e.step(s, dr)
+        assert_close_mostly(e.read("PLAN"), o.Q, rtol=2e-4, atol=2e-4, max_outliers=max(2, o.Q.size // 1000))
+        np.testing.assert_allclose(e.read("ADAM_V"), o.opt.v, rtol=4e-4, atol=1e-9)
+        np.testing.assert_allclose(ug[0], uo, rtol=2e-4, atol=2e-4)
+        np.testing.assert_array_equal(e.read("AGES"), o.trajectory_ages)
+        e.set_state(state_vec(o.Q, o.opt.m, o.opt.v, o.trajectory_ages, float(o.u), o.opt.step_count, o.count))
+        s = pred.step(s.reshape(1, 4), np.array([uo], np.float32))[0]
+    # and the rule is not a no-op: the same problem under the torch rule ends elsewhere (epsilon is bias-corrected there)
+    o2 = O.RPGD(pred, O.Cost(env), num_rollouts=N, mpc_horizon=H, outer_its=its, resamp_per=2, period_interpolation_inducing_points=p,
+                SAMPLING_DISTRIBUTION="uniform", shift_previous=1, learning_rate=0.05, opt_keep_k_ratio=0.25, gradmax_clip=5.0,
+                adam_epsilon=1e-3)
+    o3 = O.RPGD(pred, O.Cost(env), num_rollouts=N, mpc_horizon=H, outer_its=its, resamp_per=2, period_interpolation_inducing_points=p,
+                SAMPLING_DISTRIBUTION="uniform", shift_previous=1, learning_rate=0.05, opt_keep_k_ratio=0.25, gradmax_clip=5.0,
+                adam_epsilon=1e-3, adam_rule="keras")
+    o2.optimizer_reset(d0); o3.optimizer_reset(d0)
+    dr = rng.random((N - o.k, o.P, 1), dtype=np.float32)
+    o2.step(s, dr); o3.step(s, dr)
+    assert np.abs(o2.Q[-o.k:] - o3.Q[-o.k:]).max() > 1e-4
     e.close()
