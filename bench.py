@@ -469,10 +469,28 @@ def main():
     kpass = max(8, min(64, args.steps))
     s = s0.copy()
     eng.profile_enable(True, every=1)
+    if sharded is not None:
+        sharded.enable_timing(True)          # four stream events per step: begin kernels | exchange | end kernels
     for i in range(kpass):
         plant_step(s, np.asarray(kstep(s, i)).reshape(-1)[0])
     kern_ms = eng.profile_read()
     eng.profile_enable(False)
+    exch = None
+    if sharded is not None:
+        torch.cuda.synchronize()
+        exch = sharded.timing_us()
+        sharded.enable_timing(False)
+    # every rank's dominant-kernel time and exchange time to rank 0 (a scaling curve is read per rank: the slowest one sets the step)
+    per_rank = None
+    if use_pg:
+        mine = torch.tensor([float(np.mean(kern_ms)) * 1e3 if len(kern_ms) else float("nan"),
+                             float(np.mean(exch["begin_us"])) if exch and exch["begin_us"] else float("nan"),
+                             float(np.mean(exch["exchange_us"])) if exch and exch["exchange_us"] else float("nan"),
+                             float(np.mean(exch["end_us"])) if exch and exch["end_us"] else float("nan")], dtype=torch.float64,
+                            device=dev if backend == "nccl" else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(v) for v in t.cpu()] for t in allr]
 
     if rank == 0:
         total_units = Ng * H * args.steps
@@ -495,6 +513,24 @@ def main():
                             "wave per 64 trajectories (DESIGN.md 5); the large-N point below is where the chip is full"}
         roof.update({"kernel": kname, "kernel_us": kms * 1e3, "algorithmic_bytes": alg_bytes,
                      "kernel_timed_launches": int(len(kern_ms)), "kernel_timing": "separate pass after the timed region, every launch"})
+        sharded_fields = {}
+        if sharded is not None:
+            # where a sharded step's time goes, on the device timeline of this rank (events on the stream the engine and the collective share):
+            # begin = rollout (+ local merge / selection), exchange = the collective incl. the wait for the slowest peer, end = merge / update
+            mean = lambda k: (float(np.mean(exch[k])) if exch and exch[k] else None)
+            sharded_fields["exchange_us"] = mean("exchange_us")
+            sharded_fields["step_decomposition_us"] = {"begin_kernels": mean("begin_us"), "exchange": mean("exchange_us"), "end_kernels": mean("end_us"),
+                                                       "exchange_kind": ("p2p stores" if getattr(sharded, "exchange", "rccl") == "p2p" else
+                                                                         ("RCCL all-gather" if backend == "nccl" else f"{backend} all-gather (rehearsal)") if use_pg else "none (one rank)"),
+                                                       "note": "stream events around begin / collective / end in the kernel-timing pass; p2p: one launch, not decomposed"}
+            if per_rank is not None:
+                unit_alg = alg_flops if alg_flops is not None else alg_bytes
+                scale = 1e12 if alg_flops is not None else 1e9
+                peak = MFMA_F32_PEAK_TF if alg_flops is not None else HBM_PEAK_GBS
+                sharded_fields["roofline_per_rank"] = [
+                    {"rank": r, "kernel_us": v[0], "achieved": (unit_alg / (v[0] * 1e-6) / scale) if v[0] == v[0] and v[0] > 0 else None,
+                     "frac": (unit_alg / (v[0] * 1e-6) / scale / peak) if v[0] == v[0] and v[0] > 0 else None,
+                     "begin_us": v[1], "exchange_us": v[2], "end_us": v[3]} for r, v in enumerate(per_rank)]
         ps = per_step * 1e3
         out = {
             "metric": "trajectory-steps/sec (N*H per controller.step)", "value": total_units / elapsed,
@@ -512,6 +548,7 @@ def main():
             "step_ms_median": float(np.median(ps)),
             "roofline": roof,
         }
+        out.update(sharded_fields)
         # what the barrier + synchronize bracket itself contributes to `ms_per_step` (fixed per region, so 1/K of it per step: a K = 20
         # run reads ~2 us per step higher than a K = 200 run of the same steady state; the median does not move)
         out["timed_region"] = {"first_step_ms": float(ps[0]), "closing_synchronize_ms": bracket_close_ms,
@@ -536,16 +573,20 @@ def main():
             elif w["pred"] == "GRU":
                 e1.set_predictor_weights(gru_weights(0))
             big = torch.randn((Ng * P,), device=dev, dtype=torch.float32)
+            # the SAME boundary as the sharded step (Sharded*.step: begin / [no collective for one rank] / end), so that value / this
+            # value is a like-for-like strong-scaling ratio
+            one = ShardedMPPI(e1, 0, 1, device=dev)
             s = s0.copy()
             for _ in range(5):
-                plant_step(s, e1.step(s, big.data_ptr() if samples == "buffer" else None)[0])
+                plant_step(s, one.step(s, big.data_ptr() if samples == "buffer" else None)[0])
             torch.cuda.synchronize(); t0 = time.perf_counter()
             n1 = min(args.steps, 50)
             for _ in range(n1):
-                plant_step(s, e1.step(s, big.data_ptr() if samples == "buffer" else None)[0])
+                plant_step(s, one.step(s, big.data_ptr() if samples == "buffer" else None)[0])
             torch.cuda.synchronize(); el1 = time.perf_counter() - t0
             out["single_gpu_same_workload"] = {"value": Ng * H * n1 / el1, "ms_per_step": el1 / n1 * 1e3, "steps": n1,
-                                               "note": "engine.step of the whole N on rank 0's GPU, outside the timed region"}
+                                               "boundary": "control_toolkit_amd.dist.ShardedMPPI.step with one rank (begin / end, no collective)",
+                                               "note": "the whole N on rank 0's GPU, outside the timed region, while the other ranks wait"}
             e1.close()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     os.close(result_fd)

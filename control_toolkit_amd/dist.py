@@ -5,7 +5,14 @@ records with the same kernel and arrives at the identical u_nom without a second
 The payload is 408 B per rank at cfg5, so the collective is latency-bound, not xGMI-bandwidth-bound.
 
 The engine is injected so that the collective plumbing can be exercised on CPU with the gloo
-backend (tests/test_dist_gloo.py); on the GPU box the engine is a CtkEngine."""
+backend (tests/test_dist_gloo.py); on the GPU box the engine is a CtkEngine.
+
+What does and does not depend on the world size: the DRAWS do not (device Philox is addressed by the global rollout index),
+and neither does the algorithm (the merged record / the global best-K / the global keep-k are those of the whole
+population).  The BITS of a result agree across world sizes to fp32 rounding only: partial sums are associated per shard,
+and the MLP rollout kernel's form depends on the shard size (<= 8192 rollouts: two waves per tile, larger: one wave per
+tile — another summation order inside the network step).  tests/test_gpu_mlp.py holds 8 shards of 8192 against one handle
+of 65536 at rtol 3e-6 on the costs."""
 from __future__ import annotations
 
 import numpy as np
@@ -38,6 +45,41 @@ class _StreamBound:
             return
         if self.torch.cuda.current_stream(self.device).cuda_stream != self._bound:
             self._bind()
+
+    # ---- where a sharded step's time goes (bench.py: exchange_us) ---------------------------------------------------------
+    # With timing on, every step leaves four events on the stream: start | begin kernels done | exchange done | end kernels done.
+    # exchange = the collective as the stream sees it (its own time + waiting for the slowest peer); off by default: recording
+    # events costs host time.
+    _timing = None
+
+    def enable_timing(self, on: bool = True):
+        cuda = getattr(self.device, "type", "cpu") == "cuda"
+        self._timing = [] if (on and cuda) else None
+
+    def _mark(self, marks):
+        if marks is not None:
+            ev = self.torch.cuda.Event(enable_timing=True)
+            ev.record(self.torch.cuda.current_stream(self.device))
+            marks.append(ev)
+
+    def _new_marks(self):
+        if self._timing is None:
+            return None
+        marks = []
+        self._timing.append(marks)
+        self._mark(marks)
+        return marks
+
+    def timing_us(self):
+        """per recorded step: (begin_us, exchange_us, end_us) lists — device-timeline intervals between the four events; a step with
+        several exchanges (CEM: one per outer iteration) contributes their sums.  Call after a device synchronize."""
+        out = {"begin_us": [], "exchange_us": [], "end_us": []}
+        for marks in self._timing or []:
+            b = x = e = 0.0
+            for i in range(0, len(marks) - 3, 3):
+                b += marks[i].elapsed_time(marks[i + 1]); x += marks[i + 1].elapsed_time(marks[i + 2]); e += marks[i + 2].elapsed_time(marks[i + 3])
+            out["begin_us"].append(b * 1e3); out["exchange_us"].append(x * 1e3); out["end_us"].append(e * 1e3)
+        return out
 
 
 class _EngineSnapshot:
@@ -142,17 +184,26 @@ class ShardedMPPI(_StreamBound):
 
     def step(self, s, samples=None, u_prev=None) -> np.ndarray:
         """samples: this rank's slice of the draws (host array / device pointer) or None (device
-        Philox addressed by GLOBAL rollout index, so the result does not depend on world_size)."""
+        Philox addressed by GLOBAL rollout index, so the draws do not depend on world_size; the result agrees across
+        world sizes to fp32 rounding — see the module docstring)."""
         self._rebind_if_stream_changed()
         if self.exchange == "p2p":
             return self.engine.p2p_step(s, samples, u_prev=u_prev)
+        marks = self._new_marks()
         self.engine.mppi_step_begin(s, self.mine.data_ptr(), samples, u_prev=u_prev)
+        self._mark(marks)
         if self.world_size > 1 or self.always_collective:
             self.dist.all_gather_into_tensor(self.all, self.mine, group=self.group)
             parts = self.all
         else:
             parts = self.mine
-        return self.engine.mppi_step_end(parts.data_ptr(), self.world_size)
+        self._mark(marks)
+        if marks is None:
+            return self.engine.mppi_step_end(parts.data_ptr(), self.world_size)
+        # timed pass: the end launch is issued, marked, and only then waited for (the result is published by the end kernel)
+        u = self.engine.mppi_step_end(parts.data_ptr(), self.world_size)
+        self._mark(marks)
+        return u
 
 
 class ShardedTopK(_StreamBound):
@@ -176,15 +227,19 @@ class ShardedTopK(_StreamBound):
         """samples: None (device Philox by global rollout index) or this rank's draws [iterations, N_local, H, 1]."""
         self._rebind_if_stream_changed()
         its = self.engine.shard_iterations()
+        marks = self._new_marks()
         for it in range(its):
             smp = None if samples is None else samples[it]
             self.engine.shard_iter_begin(s, self.mine.data_ptr(), smp, u_prev=u_prev)
+            self._mark(marks)
             if self.world_size > 1:
                 self.dist.all_gather_into_tensor(self.all, self.mine, group=self.group)
                 parts = self.all
             else:
                 parts = self.mine
+            self._mark(marks)
             self.engine.shard_iter_end(parts.data_ptr(), self.world_size)
+            self._mark(marks)
         return self.engine.shard_finish()
 
 
@@ -210,10 +265,15 @@ class ShardedRPGD(_StreamBound):
     def step(self, s, draws=None, u_prev=None) -> np.ndarray:
         """draws: None (device Philox by global row) or raw draws [fresh_rows(), P, 1] for this shard."""
         self._rebind_if_stream_changed()
+        marks = self._new_marks()
         self.engine.rpgd_step_begin(s, self.mine.data_ptr(), u_prev=u_prev)
+        self._mark(marks)
         if self.world_size > 1:
             self.dist.all_gather_into_tensor(self.all, self.mine, group=self.group)
             parts = self.all
         else:
             parts = self.mine
-        return self.engine.rpgd_step_end(parts.data_ptr(), self.world_size, draws)
+        self._mark(marks)
+        u = self.engine.rpgd_step_end(parts.data_ptr(), self.world_size, draws)
+        self._mark(marks)
+        return u
