@@ -18,6 +18,7 @@ constexpr int CTK_MLP_TRAJ_PER_WAVE = 16;   // MFMA 16x16x4: trajectories are th
 struct EnvK {
     float dt, u_max, g, M_fric, inv_mt, k_ml, k_jf, k43l, k_mpl_mt;            // dynamics
     float inv_xs, ep_c, ccR, target_position, dd_weight, ekp_weight, ccrc_weight, terminal_weight;  // cost
+    float dd_c;               // dd_weight / x_scale^2 (the recurrence's folded form)
     int intermediate_steps;
 };
 
@@ -36,6 +37,7 @@ inline EnvK derive_constants(const float* p /* CTK_P_COUNT primary params (fp32)
     k.k43l = (float)(d(CTK_P_L) * (4.0 / 3.0));
     k.k_mpl_mt = (float)(ml * inv_mt);
     k.inv_xs = (float)(1.0 / d(CTK_P_X_SCALE));
+    k.dd_c = (float)(d(CTK_P_DD_WEIGHT) / (d(CTK_P_X_SCALE) * d(CTK_P_X_SCALE)));
     k.ep_c = (float)(d(CTK_P_EP_WEIGHT) * d(CTK_P_TARGET_EQUILIBRIUM) * 0.25);
     k.ccR = (float)(d(CTK_P_CC_WEIGHT) * d(CTK_P_R));
     k.target_position = p[CTK_P_TARGET_POSITION];

@@ -93,12 +93,13 @@ CTK_DEV void ctk_sincosf(float x, float* sn, float* cs) {
 // The same without the range check: the caller tracks max|x| over the horizon and re-runs the rare
 // out-of-range wave through the checked version (keeps a divergent branch out of the recurrence).
 constexpr float CTK_SINCOS_FAST_LIMIT = 32768.0f;
+// SIGNED reduction (n = rint(x 2/pi) keeps its sign; two's complement n & 3 is the quadrant): no |x| and no sign transfer from x —
+// bitwise the results of the |x| form (the reduction and the polynomials are odd / even in x), three instructions fewer per call.
+//   sin x = [s, c, -s, -c][n & 3]     cos x = [c, -s, -c, s][n & 3]
 CTK_DEV void ctk_sincosf_fast(float x, float* sn, float* cs) {
-    const float ax = fabsf(x);
-    const float fn = rintf(ax * 0.636619772f);
-    float r = fmaf(fn, -1.57079637e+00f, ax);
-    r = fmaf(fn, 4.37113883e-08f, r);
-    r = fmaf(fn, 1.71512489e-15f, r);
+    const float fn = rintf(x * 0.636619772f);
+    float r = fmaf(fn, -1.57079637e+00f, x);
+    r = fmaf(fn, 4.37113883e-08f, r);                // two Cody-Waite terms: the third (1.7e-15 fn) is < 4e-11 inside the fast range
     const int n = (int)fn;
     const float r2 = r * r;
     float ps = fmaf(r2, -1.95152959e-04f, 8.33216087e-03f);
@@ -111,10 +112,8 @@ CTK_DEV void ctk_sincosf_fast(float x, float* sn, float* cs) {
     const bool odd = n & 1;
     const unsigned sbits = __builtin_bit_cast(unsigned, odd ? c : s);
     const unsigned cbits = __builtin_bit_cast(unsigned, odd ? s : c);
-    const unsigned sgn_s = ((unsigned)(n & 2) << 30) ^ (__builtin_bit_cast(unsigned, x) & 0x80000000u);
-    const unsigned sgn_c = ((unsigned)((n + 1) & 2) << 30);
-    *sn = __builtin_bit_cast(float, sbits ^ sgn_s);
-    *cs = __builtin_bit_cast(float, cbits ^ sgn_c);
+    *sn = __builtin_bit_cast(float, sbits ^ (((unsigned)n << 30) & 0x80000000u));          // bit 1 of n
+    *cs = __builtin_bit_cast(float, cbits ^ (((unsigned)(n + 1) << 30) & 0x80000000u));    // bit 1 of n + 1
 }
 
 struct State4 {
@@ -132,6 +131,33 @@ CTK_DEV void ode_substep(const EnvK& k, State4& s, float F, float sn, float cs) 
     float nv = s.v + k.dt * xdd;
     float nth = s.th + k.dt * s.om;
     float nom = s.om + k.dt * thdd;
+    s.x = nx; s.v = nv; s.th = nth; s.om = nom;
+}
+
+// N / D by v_rcp_f32 + ONE correction of the quotient (q += (N - D q) r): <= 1 ulp for the well-conditioned denominator above; two
+// instructions fewer than fdiv_pos.  The rollout kernels' recurrence uses this form (issue-bound: every instruction counts).
+CTK_DEV float fdiv_pos_q(float num, float den) {
+    const float r = __builtin_amdgcn_rcpf(den);
+    const float q = num * r;
+    return fmaf(fmaf(-den, q, num), r, q);
+}
+
+// The recurrence of the rollout kernels in one piece: the state part of the stage cost (dd + ep + ekp, accumulated into csum) and
+// one Euler sub-step, sharing omega^2 and with the cost weights folded (k.dd_c = dd_weight / x_scale^2): 27 instructions.
+// Same terms as stage_cost_state + ode_substep, other association of the products (|relative difference| ~ 1e-7).
+CTK_DEV void ode_cost_substep(const EnvK& k, State4& s, float F, float sn, float cs, float& csum) {
+    const float om2 = s.om * s.om;
+    const float d = s.x - k.target_position, omc = 1.0f - cs;
+    csum = fmaf(k.dd_c * d, d, csum);
+    csum = fmaf(k.ep_c * omc, omc, csum);
+    csum = fmaf(k.ekp_weight, om2, csum);
+    const float A = fmaf(k.k_ml * om2, sn, F) - k.M_fric * s.v;
+    const float tmp = A * k.inv_mt;
+    const float D = fmaf(-k.k_mpl_mt * cs, cs, k.k43l);
+    const float Nn = fmaf(k.g, sn, -cs * tmp) - k.k_jf * s.om;
+    const float thdd = fdiv_pos_q(Nn, D);
+    const float xdd = fmaf(-k.k_mpl_mt * thdd, cs, tmp);
+    const float nx = fmaf(k.dt, s.v, s.x), nv = fmaf(k.dt, xdd, s.v), nth = fmaf(k.dt, s.om, s.th), nom = fmaf(k.dt, thdd, s.om);
     s.x = nx; s.v = nv; s.th = nth; s.om = nom;
 }
 

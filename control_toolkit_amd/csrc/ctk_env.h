@@ -69,8 +69,7 @@ struct Env<CTK_ENV_CARTPOLE> {
         float sn, cs;
         if constexpr (FAST) { ctk_sincosf_fast(st.th, &sn, &cs); amax = fmaxf(amax, fabsf(st.th)); }
         else ctk_sincosf(st.th, &sn, &cs);
-        csum += stage_cost_state(k, st, cs);
-        ode_substep(k, st, f[0], sn, cs);
+        ode_cost_substep(k, st, f[0], sn, cs, csum);
         if constexpr (!FAST) {
             for (int i = 1; i < k.intermediate_steps; ++i) {
                 float sn2, cs2;

@@ -766,7 +766,7 @@ __global__ __launch_bounds__(64) void ctk_mppi_rollout_tps(RolloutArgs a, EnvK k
     bool redo = k.intermediate_steps != 1;
     if (!redo) {
         State4 s{a.s0[0], a.s0[1], a.s0[2], a.s0[3]};
-        float csum = 0.0f, am = 0.0f;
+        float csum = 0.0f, am = 0.0f, e_dd = 0.0f, e_ud = 0.0f;
         float4* traj = nullptr;
         if constexpr (LOG) {
             if (a.traj_out) traj = reinterpret_cast<float4*>(a.traj_out) + (size_t)n * (H + 1);
@@ -778,26 +778,27 @@ __global__ __launch_bounds__(64) void ctk_mppi_rollout_tps(RolloutArgs a, EnvK k
             for (int i = 0; i < TPS_CK; ++i) {
                 const int h = h0 + i;
                 if (h < H) {
-                    const float du = cur[i] * m.stdev;
-                    const float u = fminf(fmaxf(un_s[h] + du, a.lo[0]), a.hi[0]);
+                    // u = clip(u_nom + stdev * eps) as one fma + one median; the sums over the RAW draw (scaled once after the loop)
+                    const float eps = cur[i];
+                    const float u = __builtin_amdgcn_fmed3f(fmaf(eps, m.stdev, un_s[h]), a.lo[0], a.hi[0]);
                     const float dr = u - uprev;
-                    s_dd = fmaf(du, du, s_dd); s_ud = fmaf(u, du, s_ud); s_uu = fmaf(u, u, s_uu); s_rc = fmaf(dr, dr, s_rc);
+                    e_dd = fmaf(eps, eps, e_dd); e_ud = fmaf(u, eps, e_ud); s_uu = fmaf(u, u, s_uu); s_rc = fmaf(dr, dr, s_rc);
                     uprev = u;
                     float sn, cs;
                     ctk_sincosf_fast(s.th, &sn, &cs);
                     am = fmaxf(am, fabsf(s.th));
-                    csum += stage_cost_state(k, s, cs);
                     if constexpr (LOG) {
                         if (valid) a.Q_out[(size_t)n * H + h] = u;
                         if (valid && traj) traj[h] = make_float4(s.x, s.v, s.th, s.om);
                     }
-                    ode_substep(k, s, k.u_max * u, sn, cs);
+                    ode_cost_substep(k, s, k.u_max * u, sn, cs, csum);
                 }
             }
         }
         if constexpr (LOG) {
             if (valid && traj) traj[H] = make_float4(s.x, s.v, s.th, s.om);
         }
+        s_dd = m.stdev * m.stdev * e_dd; s_ud = m.stdev * e_ud;
         J = csum + terminal_cost(k, s);
         redo = __builtin_amdgcn_ballot_w64(!(am <= CTK_SINCOS_FAST_LIMIT)) != 0;
     }
@@ -828,12 +829,29 @@ __global__ __launch_bounds__(64) void ctk_mppi_rollout_tps(RolloutArgs a, EnvK k
     __syncthreads();
     float* rec = parts + (size_t)blockIdx.x * (2 + P);
     if (lane == 0) { rec[0] = rho; rec[1] = asum; }
-    for (int p = lane; p < P; p += 64) {
-        const float* colp = cbase + p;
+    // b[p] = sum_r e_r eps[r][p] over the block's 64 rows, in the CHUNK layout of the main loop: lane (row group crow, column ccol)
+    // holds rows crow, crow+4, ... of column h0 + ccol — 16 row-segment loads all in flight, 16 FMAs against the rows' weights (LDS
+    // broadcast), two cross-group adds; every lane busy.  (Each lane walking one column over 64 rows: 16 of the kernel's 113 us at
+    // N = 2^20 — 50 of 64 lanes active, 8 loads in flight.)  The rows are still in L2 / MALL.  Rows beyond N carry weight 0.
+    auto fetch_into = [&](float (&dst)[TPS_CK], int h0) {
+        const int c = min(h0 + ccol, H - 1);
+#pragma unroll
+        for (int i = 0; i < TPS_CK; ++i) dst[i] = cbase[(size_t)min(crow + 4 * i, last) * P + c];
+    };
+    auto column_sums = [&](const float (&v)[TPS_CK], int h0) {
         float acc = 0.0f;
-#pragma unroll 8
-        for (int r = 0; r < 64; ++r) acc = fmaf(e_s[r], colp[(size_t)min(r, last) * P], acc);
-        rec[2 + p] = acc * m.stdev;
+#pragma unroll
+        for (int i = 0; i < TPS_CK; ++i) acc = fmaf(e_s[crow + 4 * i], v[i], acc);
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        if (lane < TPS_CK && h0 + lane < H) rec[2 + h0 + lane] = acc * m.stdev;
+    };
+    fetch_into(nxt, 0);                                   // two chunks in flight: one being summed, the next one landing
+    for (int h0 = 0; h0 < H; h0 += 2 * TPS_CK) {
+        if (h0 + TPS_CK < H) fetch_into(cur, h0 + TPS_CK);
+        column_sums(nxt, h0);
+        if (h0 + 2 * TPS_CK < H) fetch_into(nxt, h0 + 2 * TPS_CK);
+        if (h0 + TPS_CK < H) column_sums(cur, h0 + TPS_CK);
     }
 }
 

@@ -141,11 +141,10 @@ CTK_DEV void recur_ode_range(const EnvK& k, float4* traj, bool valid, FFn&& ffn,
         float sn, cs;
         if constexpr (CHECKED) ctk_sincosf(s.th, &sn, &cs);
         else { ctk_sincosf_fast(s.th, &sn, &cs); am = fmaxf(am, fabsf(s.th)); }
-        csum += stage_cost_state(k, s, cs);
         if constexpr (WRITE_TRAJ) {
             if (valid && traj) traj[h] = make_float4(s.x, s.v, s.th, s.om);
         }
-        ode_substep(k, s, F, sn, cs);
+        ode_cost_substep(k, s, F, sn, cs, csum);
         if constexpr (!SINGLE) {
             for (int i = 1; i < k.intermediate_steps; ++i) {
                 float sn2, cs2;
