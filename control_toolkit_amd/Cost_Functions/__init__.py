@@ -27,8 +27,11 @@ DEFAULT_COST_BY_ENV = {
                      x_scale=0.198, terminal_weight=0.0),
     "Quad2D": dict(pos_weight=400.0, ang_weight=150.0, vel_weight=8.0, angvel_weight=1.5, cc_weight=1.0, ccrc_weight=2.0, R=1.0,
                    pos_scale=0.5, terminal_weight=0.0),
+    "Hover": dict(pos_weight=300.0, ang_weight=80.0, vel_weight=6.0, angvel_weight=1.0, wheel_weight=0.02, cc_weight=1.0, ccrc_weight=1.5, R=1.0,
+                  pos_scale=0.5, terminal_weight=0.0),
 }
-DEFAULT_ATTRIBUTES_BY_ENV = {"CartPole": dict(target_position=0.0, target_equilibrium=1.0), "Quad2D": dict(target_x=0.0, target_z=1.0)}
+DEFAULT_ATTRIBUTES_BY_ENV = {"CartPole": dict(target_position=0.0, target_equilibrium=1.0), "Quad2D": dict(target_x=0.0, target_z=1.0),
+                             "Hover": dict(target_x=0.0, target_y=0.0)}
 DEFAULT_COST = DEFAULT_COST_BY_ENV["CartPole"]
 DEFAULT_ATTRIBUTES = DEFAULT_ATTRIBUTES_BY_ENV["CartPole"]
 DEFAULT_CONFIG_PATH = os.path.join("Control_Toolkit_ASF", "config_cost_function.yml")   # reference cost_function_wrapper.py:14

@@ -7,10 +7,12 @@ import numpy as np
 # The environments built into libctk_hip.so (include/ctk_hip.h: ctk_environment): dimensions and the dynamics section of
 # their parameter lists (the cost section lives in Cost_Functions).  Static here so that describing a predictor does not
 # load the library; tests/test_host_cpu.py checks the table against ctk_env_info / ctk_param_name.
-ENVIRONMENT_DIMS = {"CartPole": (4, 1), "Quad2D": (6, 2)}
+ENVIRONMENT_DIMS = {"CartPole": (4, 1), "Quad2D": (6, 2), "Hover": (7, 3)}
 DEFAULT_DYNAMICS_BY_ENV = {
     "CartPole": dict(g=9.81, m_cart=0.230, m_pole=0.087, L=0.1975, u_max=2.62, M_fric=4.77, J_fric=2.5e-4),
     "Quad2D": dict(g=9.81, mass=0.5, inertia=0.004, arm=0.12, thrust_gain=0.6, drag_lin=0.25, drag_ang=0.4),
+    "Hover": dict(mass=1.2, inertia=0.05, wheel_inertia=0.01, thrust_max=4.0, lateral_max=1.5, torque_max=0.2, drag_lin=0.3, drag_ang=0.2,
+                  wheel_friction=0.05),
 }
 DEFAULT_DYNAMICS = DEFAULT_DYNAMICS_BY_ENV["CartPole"]
 MLP_NUM_WEIGHTS = 1380   # CartPole: W1[32,5] b1[32] W2[32,32] b2[32] W3[4,32] b3[4]

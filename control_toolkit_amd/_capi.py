@@ -18,7 +18,7 @@ _lib = None
 OPTIMIZERS = {"mppi": 0, "cem": 1, "rpgd": 2, "random_action": 3, "gradient": 4, "cem_naive_grad": 5,
               "cem_grad_bharadhwaj": 6}
 PREDICTORS = {"ODE": 0, "MLP": 1, "GRU": 2}
-ENVIRONMENTS = {"CartPole": 0, "Quad2D": 1}          # include/ctk_hip.h: enum ctk_environment
+ENVIRONMENTS = {"CartPole": 0, "Quad2D": 1, "Hover": 2}          # include/ctk_hip.h: enum ctk_environment
 MAX_STATES, MAX_INPUTS = 8, 4
 # CartPole's parameter names in id order (enum ctk_param); `environment_params(name)` asks the library for any environment's
 PARAMS = ("g", "m_cart", "m_pole", "L", "u_max", "M_fric", "J_fric", "target_position", "target_equilibrium",
@@ -181,7 +181,7 @@ class CtkEngine:
                  global_rollout_offset: int = 0, num_states: int = None, num_control_inputs: int = None,
                  environment: str = "CartPole", generic_kernels: bool = False, **kw):
         """action_low / action_high: scalars (every input) or one value per control input.  environment: the plant +
-        cost the kernels implement ("CartPole", "Quad2D"); num_states / num_control_inputs default to its dimensions and
+        cost the kernels implement ("CartPole", "Quad2D", "Hover"); num_states / num_control_inputs default to its dimensions and
         are checked against them.  generic_kernels: run the environment-agnostic template kernels even where a hand-tuned
         one exists."""
         lib = load_library()

@@ -200,6 +200,7 @@ std::vector<float> permute_mlp_weights(const float* raw, int S = CTK_S, int C = 
                 f[36 + m * 4 + r] = b2[16 * m + 4 * g + r];
             }
         for (int r = 0; r < 4; ++r) f[44 + r] = (r < 2 && 4 * r + g < S) ? b3[4 * r + g] : 0.0f;
+        for (int m = 0; m < 2; ++m) f[65 + m] = 8 + g < I ? W1[(16 * m + i) * I + 8 + g] : 0.0f;   // third k-step of layer 1 (S + C > 8)
         if (S == CTK_S && C == CTK_C) {   // thin-layer form of the CartPole kernels (ctk_mlp.h: MlpFwdT)
             for (int j = 0; j < 8; ++j) f[48 + j] = W3[(l & 3) * 32 + mlp_hid(j, g)];                  // A of the 4x4x1 blocks: output row lane % 4
             for (int m = 0; m < 2; ++m)
@@ -213,7 +214,7 @@ std::vector<float> permute_mlp_weights(const float* raw, int S = CTK_S, int C = 
                 b[2 * m + ks] = (4 * ks + g < S) ? W3[(4 * ks + g) * 32 + 16 * m + i] : 0.0f;           // rows: hidden, k: output component 4ks+g
         for (int mi = 0; mi < 2; ++mi)
             for (int j = 0; j < 8; ++j) b[4 + mi * 8 + j] = W2[mlp_hid(j, g) * 32 + 16 * mi + i];       // rows: hidden_in, k: hidden_out
-        const int inp = (i % 4 < 2 && io_of_row(i) < I) ? io_of_row(i) : -1;                            // rows: network inputs
+        const int inp = (i % 4 < 3 && io_of_row(i) < I) ? io_of_row(i) : -1;                            // rows: network inputs (rows 4g+2: inputs 8+g)
         for (int j = 0; j < 8; ++j) b[20 + j] = inp >= 0 ? W1[mlp_hid(j, g) * I + inp] : 0.0f;
     }
     return out;
@@ -267,9 +268,16 @@ const char* const kQuadNames[CTK_Q_COUNT] = {
     "pos_weight", "ang_weight", "vel_weight", "angvel_weight", "cc_weight", "ccrc_weight", "R", "pos_scale", "terminal_weight"};
 const float kQuadDefaults[CTK_Q_COUNT] = {9.81f, 0.5f, 0.004f, 0.12f, 0.6f, 0.25f, 0.4f, 0.0f, 1.0f,
                                           400.0f, 150.0f, 8.0f, 1.5f, 1.0f, 2.0f, 1.0f, 0.5f, 0.0f};
+const char* const kHoverNames[CTK_V_COUNT] = {
+    "mass", "inertia", "wheel_inertia", "thrust_max", "lateral_max", "torque_max", "drag_lin", "drag_ang", "wheel_friction", "target_x",
+    "target_y", "pos_weight", "ang_weight", "vel_weight", "angvel_weight", "wheel_weight", "cc_weight", "ccrc_weight", "R", "pos_scale",
+    "terminal_weight"};
+const float kHoverDefaults[CTK_V_COUNT] = {1.2f, 0.05f, 0.01f, 4.0f, 1.5f, 0.2f, 0.3f, 0.2f, 0.05f, 0.0f, 0.0f,
+                                           300.0f, 80.0f, 6.0f, 1.0f, 0.02f, 1.0f, 1.5f, 1.0f, 0.5f, 0.0f};
 const EnvInfo kEnvs[CTK_ENV_COUNT] = {
     {"CartPole", Env<CTK_ENV_CARTPOLE>::S, Env<CTK_ENV_CARTPOLE>::C, CTK_P_COUNT, kCartPoleNames, kCartPoleDefaults},
     {"Quad2D", Env<CTK_ENV_QUAD2D>::S, Env<CTK_ENV_QUAD2D>::C, CTK_Q_COUNT, kQuadNames, kQuadDefaults},
+    {"Hover", Env<CTK_ENV_HOVER>::S, Env<CTK_ENV_HOVER>::C, CTK_V_COUNT, kHoverNames, kHoverDefaults},
 };
 const EnvInfo* env_info(int env) { return (env >= 0 && env < CTK_ENV_COUNT) ? &kEnvs[env] : nullptr; }
 
@@ -944,8 +952,9 @@ int fill_const(ctk_handle* h, float* d, float v, int n) {
 extern "C" {
 
 int ctk_abi_version(void) { return CTK_ABI_VERSION; }
-static_assert(CTK_P_COUNT <= CTK_MAX_PARAMS && CTK_Q_COUNT <= CTK_MAX_PARAMS, "parameter table size");
+static_assert(CTK_P_COUNT <= CTK_MAX_PARAMS && CTK_Q_COUNT <= CTK_MAX_PARAMS && CTK_V_COUNT <= CTK_MAX_PARAMS, "parameter table size");
 static_assert(Env<CTK_ENV_QUAD2D>::S <= CTK_MAX_STATES && Env<CTK_ENV_QUAD2D>::C <= CTK_MAX_INPUTS, "environment dimensions");
+static_assert(Env<CTK_ENV_HOVER>::S <= CTK_MAX_STATES && Env<CTK_ENV_HOVER>::C <= CTK_MAX_INPUTS, "environment dimensions");
 
 const char* ctk_last_error(const ctk_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -955,7 +964,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     if (cfg->struct_size != sizeof(ctk_config))
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: ctk_config size mismatch (ABI)");
     const EnvInfo* einfo = env_info(cfg->environment);
-    if (!einfo) return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: unknown environment (built: CartPole, Quad2D)");
+    if (!einfo) return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: unknown environment (built: CartPole, Quad2D, Hover)");
     if (cfg->num_states != einfo->S || cfg->num_control_inputs != einfo->C)
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, std::string("ctk_create: environment ") + einfo->name + " has num_states == " +
                     std::to_string(einfo->S) + ", num_control_inputs == " + std::to_string(einfo->C));
@@ -970,6 +979,10 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
         if (!(cfg->action_low[c] <= cfg->action_high[c])) return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: action_low must be <= action_high for every control input");
     if (cfg->optimizer < CTK_OPT_MPPI || cfg->optimizer > CTK_OPT_CEM_GRAD_BHARADHWAJ)
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: unknown optimizer");
+    if (cfg->predictor < CTK_PRED_ODE || cfg->predictor > CTK_PRED_GRU) return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: unknown predictor");
+    if (cfg->predictor == CTK_PRED_GRU && einfo->S + einfo->C > 8)
+        return fail(nullptr, CTK_ERR_UNSUPPORTED, std::string("ctk_create: the GRU predictor takes at most 8 network inputs (num_states + num_control_inputs); ") +
+                    einfo->name + " has " + std::to_string(einfo->S + einfo->C) + " — use the MLP (three layer-1 k-steps) or the analytic predictor");
     // variants run on an engine family: gradient = RPGD machinery without resampling (Keras Adam, fresh tail);
     // cem-naive-grad = CEM machinery with one SGD step on the samples
     ctk_config mapped = *cfg;

@@ -532,8 +532,7 @@ bool ctk_cem_fusable(int pred, int N, int H) {
     return pred == CTK_PRED_ODE && ctk_cem_fused_blocks(N) <= CTK_CEM_FUSED_MAX_BLOCKS && ctk_cem_fused_lds(N, H) <= 128 * 1024;
 }
 const char* ctk_cem_fused_name(int env, bool log) {
-    if (env == CTK_ENV_CARTPOLE) return log ? "ctk_cem_fused<0, true>" : "ctk_cem_fused<0, false>";
-    return log ? "ctk_cem_fused<1, true>" : "ctk_cem_fused<1, false>";
+    return ctk_kernel_name("ctk_cem_fused<%d, %4$s>", env, 0, 0, log ? "true" : "false");
 }
 
 // a_in.H steps, a_in.C inputs (limits per input); the kernel constants are derived from the environment's parameter table

@@ -346,6 +346,160 @@ struct Env<CTK_ENV_QUAD2D> {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
+// Hover — planar hovercraft with a reaction wheel (oracle/ctk_oracle.py: HoverParams, Predictor._hover_step/_hover_vjp,
+// Cost._hover_*).  state (x, vx, y, vy, theta, omega, wheel speed); inputs (main thruster, lateral thruster, wheel torque) in
+// [-1, 1]; the wheel's torque reacts on the body.  S + C = 10: the network predictors need a third layer-1 k-step.
+// ---------------------------------------------------------------------------------------------------------------
+struct HoverK {
+    float dt, aF, aL, kT, kW, c_v, c_w, c_ww;                                                       // dynamics
+    float tx, ty, pos_c, ang_w, vel_w, angvel_w, wheel_w, ccR, ccrc_weight, terminal_weight;        // cost
+    int intermediate_steps;
+};
+
+template <>
+struct Env<CTK_ENV_HOVER> {
+    static constexpr int S = 7, C = 3;
+    using K = HoverK;
+    static K derive(const float* p, float dt, int isteps) {
+        auto d = [&](int id) { return (double)p[id]; };
+        K k;
+        k.dt = (float)((double)dt / isteps);
+        k.aF = (float)(d(CTK_V_THRUST_MAX) / d(CTK_V_MASS));
+        k.aL = (float)(d(CTK_V_LATERAL_MAX) / d(CTK_V_MASS));
+        k.kT = (float)(d(CTK_V_TORQUE_MAX) / d(CTK_V_INERTIA));
+        k.kW = (float)(d(CTK_V_TORQUE_MAX) / d(CTK_V_WHEEL_INERTIA));
+        k.c_v = (float)d(CTK_V_DRAG_LIN); k.c_w = (float)d(CTK_V_DRAG_ANG); k.c_ww = (float)d(CTK_V_WHEEL_FRICTION);
+        k.tx = p[CTK_V_TARGET_X]; k.ty = p[CTK_V_TARGET_Y];
+        k.pos_c = (float)(d(CTK_V_POS_WEIGHT) / (d(CTK_V_POS_SCALE) * d(CTK_V_POS_SCALE)));
+        k.ang_w = p[CTK_V_ANG_WEIGHT]; k.vel_w = p[CTK_V_VEL_WEIGHT]; k.angvel_w = p[CTK_V_ANGVEL_WEIGHT]; k.wheel_w = p[CTK_V_WHEEL_WEIGHT];
+        k.ccR = (float)(d(CTK_V_CC_WEIGHT) * d(CTK_V_R));
+        k.ccrc_weight = p[CTK_V_CCRC_WEIGHT];
+        k.terminal_weight = p[CTK_V_TERMINAL_WEIGHT];
+        k.intermediate_steps = isteps;
+        return k;
+    }
+    // one Euler sub-step with sin / cos of the attitude given
+    CTK_DEV static void substep(const K& k, float (&s)[S], const float (&u)[C], float sn, float cs) {
+        const float fb = k.aF * u[0], fl = k.aL * u[1];
+        const float ax = fb * cs - fl * sn - k.c_v * s[1];
+        const float ay = fb * sn + fl * cs - k.c_v * s[3];
+        const float al = -k.kT * u[2] - k.c_w * s[5];
+        const float aw = k.kW * u[2] - k.c_ww * s[6];
+        const float nx = s[0] + k.dt * s[1], nvx = s[1] + k.dt * ax, ny = s[2] + k.dt * s[3], nvy = s[3] + k.dt * ay;
+        const float nth = s[4] + k.dt * s[5], nom = s[5] + k.dt * al, nw = s[6] + k.dt * aw;
+        s[0] = nx; s[1] = nvx; s[2] = ny; s[3] = nvy; s[4] = nth; s[5] = nom; s[6] = nw;
+    }
+    CTK_DEV static void step(const K& k, float (&s)[S], const float (&u)[C]) {
+        for (int i = 0; i < k.intermediate_steps; ++i) {
+            float sn, cs;
+            ctk_sincosf(s[4], &sn, &cs);
+            substep(k, s, u, sn, cs);
+        }
+    }
+    CTK_DEV static float state_terms(const K& k, const float (&s)[S], float cs) {   // position + attitude (shared by stage and terminal)
+        const float dx = s[0] - k.tx, dy = s[2] - k.ty;
+        return k.pos_c * (dx * dx + dy * dy) + k.ang_w * (1.0f - cs);
+    }
+    CTK_DEV static float rate_terms(const K& k, const float (&s)[S]) {
+        return k.vel_w * (s[1] * s[1] + s[3] * s[3]) + k.angvel_w * s[5] * s[5] + k.wheel_w * s[6] * s[6];
+    }
+    CTK_DEV static float input_cost(const K& k, const float (&u)[C], const float (&up)[C]) {
+        const float d0 = u[0] - up[0], d1 = u[1] - up[1], d2 = u[2] - up[2];
+        return k.ccR * (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]) + k.ccrc_weight * (d0 * d0 + d1 * d1 + d2 * d2);
+    }
+    CTK_DEV static float stage_cost(const K& k, const float (&s)[S], const float (&u)[C], const float (&up)[C]) {
+        return state_terms(k, s, cosf(s[4])) + rate_terms(k, s) + input_cost(k, u, up);
+    }
+    CTK_DEV static float terminal_cost(const K& k, const float (&s)[S]) { return k.terminal_weight * state_terms(k, s, cosf(s[4])); }
+    // hooks of the 4-wave rollout kernels
+    static constexpr bool SEPARABLE = true;
+    CTK_DEV static float prep_input(const K&, float u, int /*c*/) { return u; }
+    CTK_DEV static bool fast_ok(const K&) { return true; }
+    CTK_DEV static bool out_of_range(float amax) { return !(amax <= CTK_SINCOS_FAST_LIMIT); }
+    template <bool FAST>
+    CTK_DEV static void cost_step(const K& k, float (&s)[S], const float (&u)[C], float& csum, float& amax) {
+        float sn, cs;
+        if constexpr (FAST) { ctk_sincosf_fast(s[4], &sn, &cs); amax = fmaxf(amax, fabsf(s[4])); }
+        else ctk_sincosf(s[4], &sn, &cs);
+        csum += state_terms(k, s, cs) + rate_terms(k, s);
+        for (int i = 0; i < k.intermediate_steps; ++i) {
+            if (i > 0) {
+                if constexpr (FAST) { ctk_sincosf_fast(s[4], &sn, &cs); amax = fmaxf(amax, fabsf(s[4])); }
+                else ctk_sincosf(s[4], &sn, &cs);
+            }
+            substep(k, s, u, sn, cs);
+        }
+    }
+    // hooks of the descent kernels.  tape: the seven states, sin, cos of the attitude
+    static constexpr int NT = 9;
+    CTK_DEV static void fwd_tape(const K& k, float (&s)[S], const float (&u)[C], float (&tp)[NT]) {
+        float sn, cs;
+        ctk_sincosf(s[4], &sn, &cs);
+#pragma unroll
+        for (int i = 0; i < S; ++i) tp[i] = s[i];
+        tp[7] = sn; tp[8] = cs;
+        substep(k, s, u, sn, cs);
+    }
+    CTK_DEV static void vjp_core(const K& k, float sn, float cs, const float (&u)[C], const float (&lam)[S], float (&ds)[S], float (&du)[C]) {
+        const float fb = k.aF * u[0], fl = k.aL * u[1];
+        const float dt = k.dt;
+        const float a_ax = dt * lam[1], a_ay = dt * lam[3], a_al = dt * lam[5], a_aw = dt * lam[6];
+        ds[0] = lam[0];
+        ds[1] = lam[1] + dt * lam[0] - k.c_v * a_ax;
+        ds[2] = lam[2];
+        ds[3] = lam[3] + dt * lam[2] - k.c_v * a_ay;
+        ds[4] = lam[4] + (-fb * sn - fl * cs) * a_ax + (fb * cs - fl * sn) * a_ay;
+        ds[5] = lam[5] + dt * lam[4] - k.c_w * a_al;
+        ds[6] = lam[6] - k.c_ww * a_aw;
+        du[0] = k.aF * (cs * a_ax + sn * a_ay);
+        du[1] = k.aL * (-sn * a_ax + cs * a_ay);
+        du[2] = -k.kT * a_al + k.kW * a_aw;
+    }
+    CTK_DEV static void bwd_tape(const K& k, const float (&tp)[NT], const float (&u)[C], float (&lam)[S], float (&du)[C], float inv) {
+        float ds[S];
+        vjp_core(k, tp[7], tp[8], u, lam, ds, du);
+        lam[0] = 2.0f * k.pos_c * (tp[0] - k.tx) * inv + ds[0];
+        lam[1] = 2.0f * k.vel_w * tp[1] * inv + ds[1];
+        lam[2] = 2.0f * k.pos_c * (tp[2] - k.ty) * inv + ds[2];
+        lam[3] = 2.0f * k.vel_w * tp[3] * inv + ds[3];
+        lam[4] = k.ang_w * tp[7] * inv + ds[4];
+        lam[5] = 2.0f * k.angvel_w * tp[5] * inv + ds[5];
+        lam[6] = 2.0f * k.wheel_w * tp[6] * inv + ds[6];
+    }
+    CTK_DEV static void step_vjp(const K& k, const float (&s)[S], const float (&u)[C], const float (&lam)[S], float (&ds)[S], float (&du)[C]) {
+        float sn, cs;
+        ctk_sincosf(s[4], &sn, &cs);
+        vjp_core(k, sn, cs, u, lam, ds, du);
+    }
+    CTK_DEV static void stage_grad_state(const K& k, const float (&s)[S], float (&g)[S]) {
+        g[0] = 2.0f * k.pos_c * (s[0] - k.tx);
+        g[1] = 2.0f * k.vel_w * s[1];
+        g[2] = 2.0f * k.pos_c * (s[2] - k.ty);
+        g[3] = 2.0f * k.vel_w * s[3];
+        g[4] = k.ang_w * sinf(s[4]);
+        g[5] = 2.0f * k.angvel_w * s[5];
+        g[6] = 2.0f * k.wheel_w * s[6];
+    }
+    CTK_DEV static void terminal_grad(const K& k, const float (&s)[S], float (&g)[S]) {
+        g[0] = k.terminal_weight * 2.0f * k.pos_c * (s[0] - k.tx);
+        g[1] = 0.0f;
+        g[2] = k.terminal_weight * 2.0f * k.pos_c * (s[2] - k.ty);
+        g[3] = 0.0f;
+        g[4] = k.terminal_weight * k.ang_w * sinf(s[4]);
+        g[5] = 0.0f;
+        g[6] = 0.0f;
+    }
+    CTK_DEV static void input_grad(const K& k, const float (&u)[C], const float (&up)[C], float (&gu)[C], float (&gp)[C]) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float d = 2.0f * k.ccrc_weight * (u[c] - up[c]);
+            gu[c] = 2.0f * k.ccR * u[c] + d;
+            gp[c] = -d;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
 // The recurrence of the 4-wave rollout kernels, for any environment: steps [hb, he) of ONE trajectory per lane.  F: the
 // trajectory's prepared inputs [H*C] in LDS (Env::prep_input form), read one step ahead of their use; s / csum / amax are
 // carried so that the caller may split the horizon (ctk_mppi_rollout runs the first steps while the other waves still
@@ -395,5 +549,6 @@ CTK_DEV void recur_env_range(const typename Env<ENV>::K& k, float* traj, bool va
 #define CTK_FOR_ENV(id, ENVV, ...)                                              \
     do {                                                                        \
         if ((id) == CTK_ENV_CARTPOLE) { constexpr int ENVV = CTK_ENV_CARTPOLE; __VA_ARGS__; } \
-        else { constexpr int ENVV = CTK_ENV_QUAD2D; __VA_ARGS__; }             \
+        else if ((id) == CTK_ENV_QUAD2D) { constexpr int ENVV = CTK_ENV_QUAD2D; __VA_ARGS__; } \
+        else { constexpr int ENVV = CTK_ENV_HOVER; __VA_ARGS__; }             \
     } while (0)

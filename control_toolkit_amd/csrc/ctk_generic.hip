@@ -395,10 +395,7 @@ size_t ctk_g_rollout_lds(int cols, int H, int C) {
 int ctk_g_rollout_blocks(int N) { return (N + G_TRAJ - 1) / G_TRAJ; }
 
 const char* ctk_g_rollout_name(int env, int mode, bool log) {
-    static const char* names[2][2][2] = {
-        {{"ctk_g_rollout<0, 0, false>", "ctk_g_rollout<0, 0, true>"}, {"ctk_g_rollout<0, 1, false>", "ctk_g_rollout<0, 1, true>"}},
-        {{"ctk_g_rollout<1, 0, false>", "ctk_g_rollout<1, 0, true>"}, {"ctk_g_rollout<1, 1, false>", "ctk_g_rollout<1, 1, true>"}}};
-    return names[env == CTK_ENV_CARTPOLE ? 0 : 1][mode == CTK_G_MODE_MPPI ? 0 : 1][log ? 1 : 0];
+    return ctk_kernel_name("ctk_g_rollout<%d, %d, %4$s>", env, mode == CTK_G_MODE_MPPI ? 0 : 1, 0, log ? "true" : "false");
 }
 
 hipError_t ctk_launch_g_rollout(hipStream_t st, int env, int mode, const RolloutArgs& a_in, const float* params, float dt, int isteps,
@@ -464,7 +461,7 @@ size_t ctk_g_rpgd_scratch_floats(int env, int N, int H) {
     return (size_t)((N + G_TRAJ - 1) / G_TRAJ) * H * NT * 64;
 }
 
-const char* ctk_g_rpgd_descent_name(int env) { return env == CTK_ENV_CARTPOLE ? "ctk_g_rpgd_descent<0>" : "ctk_g_rpgd_descent<1>"; }
+const char* ctk_g_rpgd_descent_name(int env) { return ctk_kernel_name("ctk_g_rpgd_descent<%d>", env); }
 
 hipError_t ctk_launch_g_rpgd_descent(hipStream_t st, int env, const RolloutArgs& a_in, const float* params, float dt, int isteps, float lr,
                                      float b1, float b2, float eps, float clip, float* Q, float* m, float* v, const float* bc_table,

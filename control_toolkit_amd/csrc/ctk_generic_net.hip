@@ -36,6 +36,13 @@ CTK_DEV float second_operand(float sv1, const float (&u)[C], int g) {
     return x1;
 }
 template <int S, int C>
+CTK_DEV float third_operand(const float (&u)[C], int g) {              // network input 8+g: a control input where S + C > 8 (S <= 8)
+    float x2 = 0.0f;
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) x2 = (8 + g == S + cc) ? u[cc] : x2;
+    return x2;
+}
+template <int S, int C>
 CTK_DEV float first_operand(float sv0, const float (&u)[C], int g) {   // S < 4 environments: inputs may already start in k-step 0
     float x0 = (g < S) ? sv0 : 0.0f;
 #pragma unroll
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(GN_BLOCK) void ctk_g_rollout_net(RolloutArgs a, typ
                 for (int i = 0; i < S; ++i) a.traj_out[((size_t)n * (H + 1) + h) * S + i] = s[i];
             }
         }
-        const MlpPair o = net.step(first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g), nullptr);
+        const MlpPair o = net.step(first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g), third_operand<S, C>(u, g), nullptr);
         sv0 = o.lo; sv1 = o.hi;
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) up[cc] = u[cc];
@@ -216,8 +223,8 @@ __global__ __launch_bounds__(GN_BLOCK) void ctk_g_rpgd_descent_net(RolloutArgs a
             float u[C];
 #pragma unroll
             for (int cc = 0; cc < C; ++cc) u[cc] = q_s[(h * C + cc) * GN_LD + col];
-            const MlpPair o = nf.step(first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g),
-                                      reinterpret_cast<float4*>(tape + ((size_t)h * 64 + lane) * GN_TAPE));   // tape[0] = the step's (x0, x1)
+            const MlpPair o = nf.step(first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g), third_operand<S, C>(u, g),
+                                      reinterpret_cast<float4*>(tape + ((size_t)h * 64 + lane) * GN_TAPE));   // tape[0] = the step's (x0, x1, x2)
             sv0 = o.lo; sv1 = o.hi;
         }
         // ---- reverse sweep
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(GN_BLOCK) void ctk_g_rpgd_descent_net(RolloutArgs a
             for (int cc = 0; cc < C; ++cc) {
                 const int kk = S + cc;                         // network input index of control input cc: lane group kk % 4, half kk / 4
                 if (g == (kk & 3)) {
-                    const float gq = (gu[cc] + gp_next[cc]) * inv + (kk >= 4 ? d.hi : d.lo);
+                    const float gq = (gu[cc] + gp_next[cc]) * inv + (kk >= 8 ? d.ex : (kk >= 4 ? d.hi : d.lo));
                     g_s[(h * C + cc) * GN_LD + col] = gq;
                     nrm2 += gq * gq;
                 }
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(GN_BLOCK) void ctk_g_rpgd_descent_net(RolloutArgs a
             for (int cc = 0; cc < C; ++cc) u[cc] = q_s[(h * C + cc) * GN_LD + col];
             gather_state<S>(sv0, sv1, c, s);
             csum += E::stage_cost(k, s, u, up);
-            const MlpPair o = nf.step(first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g), nullptr);
+            const MlpPair o = nf.step(first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g), third_operand<S, C>(u, g), nullptr);
             sv0 = o.lo; sv1 = o.hi;
 #pragma unroll
             for (int cc = 0; cc < C; ++cc) up[cc] = u[cc];
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(64) void ctk_g_gru_advance(RolloutArgs a, const flo
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) u[cc] = u_dev ? u_dev[cc] : a.u_prev[cc];
     const float sv0 = g < S ? lane_state4(a, g) : 0.0f, sv1 = 4 + g < S ? lane_state4(a, g, 4) : 0.0f;
-    (void)net.step(first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g), nullptr);
+    (void)net.step(first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g), 0.0f, nullptr);
     __syncthreads();                       // every lane has read `hidden` (begin) before column 0 overwrites it
     if (c == 0) {
 #pragma unroll
@@ -339,10 +346,9 @@ static size_t net_lds_fwd(int net) { return net == NET_GRU ? NetGru::LDS_FWD : 0
 static size_t net_lds_bwd(int net) { return net == NET_GRU ? NetGru::LDS_BWD : 0; }
 
 const char* ctk_g_rollout_net_name(int env, int net, int mode, bool log) {
-    static char buf[2][2][2][2][64];
-    char* b = buf[env == CTK_ENV_CARTPOLE ? 0 : 1][net == NET_GRU ? 1 : 0][mode == CTK_G_MODE_MPPI ? 0 : 1][log ? 1 : 0];
-    snprintf(b, 64, "ctk_g_rollout_net<%d, %s, %d, %s>", env, net == NET_GRU ? "NetGru" : "NetMlp", mode, log ? "true" : "false");
-    return b;
+    int io = 0;
+    CTK_FOR_ENV(env, EV, { io = Env<EV>::S + Env<EV>::C; });
+    return ctk_kernel_name("ctk_g_rollout_net<%d, %4$s, %d, %5$s>", env, mode, 0, net == NET_GRU ? "NetGru" : (io > 8 ? "NetMlpT<true>" : "NetMlp"), log ? "true" : "false");
 }
 
 size_t ctk_g_rollout_net_lds(int net, int cols, int H, int C) { return ctk_g_rollout_lds(cols, H, C) + net_lds_fwd(net) * sizeof(float); }
@@ -373,8 +379,9 @@ hipError_t ctk_launch_g_rollout_net(hipStream_t st, int env, int net, int mode, 
                                     const float* wperm, float* parts, bool log, hipEvent_t e0, hipEvent_t e1) {
     const float* hidden = wperm + ctk_g_net_table_floats(net);
     CTK_FOR_ENV(env, EV, {
+        using MLP = NetMlpT<(Env<EV>::S + Env<EV>::C > 8)>;      // a third layer-1 k-step where the environment has more than 8 network inputs
         if (net == NET_GRU) launch_rollout_net<EV, NetGru>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1);
-        else launch_rollout_net<EV, NetMlp>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1);
+        else launch_rollout_net<EV, MLP>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1);
     });
     return hipGetLastError();
 }
@@ -390,10 +397,9 @@ size_t ctk_g_rpgd_scratch_floats_net(int net, int N, int H) {
 }
 
 const char* ctk_g_rpgd_descent_net_name(int env, int net) {
-    static char buf[2][2][64];
-    char* b = buf[env == CTK_ENV_CARTPOLE ? 0 : 1][net == NET_GRU ? 1 : 0];
-    snprintf(b, 64, "ctk_g_rpgd_descent_net<%d, %s>", env, net == NET_GRU ? "NetGru" : "NetMlp");
-    return b;
+    int io = 0;
+    CTK_FOR_ENV(env, EV, { io = Env<EV>::S + Env<EV>::C; });
+    return ctk_kernel_name("ctk_g_rpgd_descent_net<%d, %4$s>", env, 0, 0, net == NET_GRU ? "NetGru" : (io > 8 ? "NetMlpT<true>" : "NetMlp"));
 }
 
 hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const RolloutArgs& a_in, const float* params, float dt, int isteps,
@@ -413,7 +419,7 @@ hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const
         if (net == NET_GRU)
             CTK_LAUNCH((ctk_g_rpgd_descent_net<EV, NetGru>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wb, hidden, scratch);
         else
-            CTK_LAUNCH((ctk_g_rpgd_descent_net<EV, NetMlp>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wb, hidden, scratch);
+            CTK_LAUNCH((ctk_g_rpgd_descent_net<EV, NetMlpT<(E::S + E::C > 8)>>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wb, hidden, scratch);
     });
     return hipGetLastError();
 }

@@ -11,6 +11,21 @@
         else hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                           \
     } while (0)
 
+// kernel names as rocprofv3's trace prints them, formatted once per (template, arguments) and kept for the process's lifetime
+// (ctk_dominant_kernel returns the pointer); any number of environments
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+inline const char* ctk_kernel_name(const char* fmt, int a = 0, int b = 0, int c = 0, const char* s0 = "", const char* s1 = "") {
+    static std::map<std::string, std::string> names;
+    static std::mutex mu;
+    char buf[160];
+    std::snprintf(buf, sizeof buf, fmt, a, b, c, s0, s1);
+    std::lock_guard<std::mutex> lock(mu);
+    return names.emplace(buf, buf).first->second.c_str();
+}
+
 // ---- ctk_mppi.hip ---------------------------------------------------------------------------
 const char* ctk_mppi_rollout_name(int pred, bool log, int N, bool identity_interp = false, bool have_samples = true);
 int ctk_mppi_num_blocks(int N, int pred);   // workgroups = block records of one rollout launch (64 trajectories each; GRU: 16)

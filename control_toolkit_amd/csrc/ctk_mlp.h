@@ -25,7 +25,7 @@ constexpr int MLP_BWD_PER_LANE = 28;   // floats per lane, backward ( 7 x float4
 __host__ __device__ inline int mlp_hid(int j, int g) { return 16 * (j >> 2) + 4 * g + (j & 3); }
 
 struct MlpFwdW {
-    float w1[2][2];   // [out tile m][k-step]
+    float w1[2][3];   // [out tile m][k-step]; k-step 2 (network inputs 8 + g) only where S + C > 8
     float w2[2][8];   // [out tile][k-step]
     float w3[8];      // [k-step]
     f32x4 b1[2], b2[2], b3;
@@ -38,6 +38,8 @@ CTK_DEV MlpFwdW mlp_load_fwd(const float* __restrict__ wperm) {
     for (int i = 0; i < 12; ++i) v[i] = p[i];
     MlpFwdW w;
     w.w1[0][0] = v[0].x; w.w1[0][1] = v[0].y; w.w1[1][0] = v[0].z; w.w1[1][1] = v[0].w;
+    const float4 v16 = p[16];                 // slots 65, 66: the third k-step of layer 1 (zero where S + C <= 8)
+    w.w1[0][2] = v16.y; w.w1[1][2] = v16.z;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int mo = i >> 1, j0 = (i & 1) * 4;
@@ -469,15 +471,21 @@ CTK_DEV float mlp_step_vjp(const MlpBwdW& w, const MlpAct& act, float lam, float
 // ---------------------------------------------------------------------------------------------
 struct MlpPair {
     float lo, hi;      // network input / output (or adjoint) index g and 4+g of the lane's trajectory
+    float ex = 0.0f;   // adjoints only: network input 8+g (environments with S + C > 8)
 };
 
-// x0 / x1: values of network inputs g and 4+g (0 where 4+g >= I).  Returns outputs g and 4+g.
-CTK_DEV MlpPair mlp_step2(const MlpFwdW& w, float x0, float x1, MlpAct* keep = nullptr) {
+// x0 / x1 / x2: values of network inputs g, 4+g and (K3: S + C > 8) 8+g (0 beyond I).  Returns outputs g and 4+g.
+template <bool K3 = false>
+CTK_DEV MlpPair mlp_step2(const MlpFwdW& w, float x0, float x1, float x2 = 0.0f, MlpAct* keep = nullptr) {
     f32x4 a0 = w.b1[0], a1 = w.b1[1];
     a0 = CTK_MFMA(w.w1[0][0], x0, a0);
     a1 = CTK_MFMA(w.w1[1][0], x0, a1);
     a0 = CTK_MFMA(w.w1[0][1], x1, a0);
     a1 = CTK_MFMA(w.w1[1][1], x1, a1);
+    if constexpr (K3) {
+        a0 = CTK_MFMA(w.w1[0][2], x2, a0);
+        a1 = CTK_MFMA(w.w1[1][2], x2, a1);
+    }
     f32x4 h1[2];
     h1[0] = ctk_tanhf4(a0); h1[1] = ctk_tanhf4(a1);
     f32x4 c0 = w.b2[0], c1 = w.b2[1];
@@ -514,7 +522,8 @@ CTK_DEV MlpBwdW2 mlp_load_bwd2(const float* __restrict__ wperm) {
     return w;
 }
 
-// lam0 / lam1: adjoints of the NEXT state's components g / 4+g.  Returns the adjoints w.r.t. network inputs g and 4+g.
+// lam0 / lam1: adjoints of the NEXT state's components g / 4+g.  Returns the adjoints w.r.t. network inputs g, 4+g and 8+g (D register r
+// of lane group g is tile row 4g + r = network input 4r + g: ctk_api.hip:permute_mlp_weights places W1^T's rows that way).
 CTK_DEV MlpPair mlp_step_vjp2(const MlpBwdW2& w, const MlpAct& act, float lam0, float lam1) {
     const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 t0 = CTK_MFMA(w.w3t[0][0], lam0, z), t1 = CTK_MFMA(w.w3t[1][0], lam0, z);
@@ -545,5 +554,5 @@ CTK_DEV MlpPair mlp_step_vjp2(const MlpBwdW2& w, const MlpAct& act, float lam0, 
         o0 = CTK_MFMA(w.w1t[j], d1[j >> 2][j & 3], o0);
         o1 = CTK_MFMA(w.w1t[j + 1], d1[(j + 1) >> 2][(j + 1) & 3], o1);
     }
-    return MlpPair{o0[0] + o1[0], o0[1] + o1[1]};
+    return MlpPair{o0[0] + o1[0], o0[1] + o1[1], o0[2] + o1[2]};
 }

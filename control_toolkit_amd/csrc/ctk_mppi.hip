@@ -984,13 +984,13 @@ hipError_t ctk_launch_mppi_rollout_env(hipStream_t st, int env, const float* par
     return hipGetLastError();
 }
 size_t ctk_mppi_rollout_env_lds(int env, int P, int H, int N) {
-    const int C = env == CTK_ENV_CARTPOLE ? Env<CTK_ENV_CARTPOLE>::C : Env<CTK_ENV_QUAD2D>::C;
+    int C = 1;
+    CTK_FOR_ENV(env, EV, { C = Env<EV>::C; });
     int stage_ok;
     return rollout_launch_lds(P, H, CTK_PRED_ODE, N, (N + MPPI_TRAJ - 1) / MPPI_TRAJ, &stage_ok, C);
 }
 const char* ctk_mppi_rollout_env_name(int env, bool log) {
-    if (env == CTK_ENV_CARTPOLE) return log ? "ctk_mppi_rollout<0, 0, true>" : "ctk_mppi_rollout<0, 0, false>";
-    return log ? "ctk_mppi_rollout<1, 0, true>" : "ctk_mppi_rollout<1, 0, false>";
+    return ctk_kernel_name("ctk_mppi_rollout<%d, 0, %4$s>", env, 0, 0, log ? "true" : "false");
 }
 
 hipError_t ctk_launch_mppi_merge_partial(hipStream_t st, const float* parts, int n_parts, int per_block, int P,

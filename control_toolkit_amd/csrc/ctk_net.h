@@ -18,17 +18,20 @@ CTK_DEV f32x4 ld4(const float4* p) { const float4 v = *p; return f32x4{v.x, v.y,
 CTK_DEV float4 st4(f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct NetMlp {
+// K3: the environment has more than 8 network inputs (S + C > 8): layer 1 takes a third k-step (inputs 8 + g)
+template <bool K3>
+struct NetMlpT {
     static constexpr int TAPE = 20, LDS_FWD = 0, LDS_BWD = 0, HIDDEN = 0;
+    static constexpr bool THREE_KSTEPS = K3;
     struct Fwd {
         MlpFwdW w;
         CTK_DEV void load(const float* __restrict__ table, float*) { w = mlp_load_fwd(table); }
         CTK_DEV void begin(const float*) {}
-        CTK_DEV MlpPair step(float x0, float x1, float4* tape) {
-            if (tape == nullptr) return mlp_step2(w, x0, x1);
+        CTK_DEV MlpPair step(float x0, float x1, float x2, float4* tape) {
+            if (tape == nullptr) return mlp_step2<K3>(w, x0, x1, x2);
             MlpAct act;
-            const MlpPair o = mlp_step2(w, x0, x1, &act);
-            tape[0] = make_float4(x0, x1, 0.f, 0.f);
+            const MlpPair o = mlp_step2<K3>(w, x0, x1, x2, &act);
+            tape[0] = make_float4(x0, x1, x2, 0.f);
             tape[1] = st4(act.h1[0]); tape[2] = st4(act.h1[1]); tape[3] = st4(act.h2[0]); tape[4] = st4(act.h2[1]);
             return o;
         }
@@ -44,6 +47,8 @@ struct NetMlp {
         }
     };
 };
+using NetMlp = NetMlpT<false>;
+using NetMlp3 = NetMlpT<true>;
 
 // ---------------------------------------------------------------------------------------------------------------
 // GRU.  Forward table (per lane, entry-major [e][64]), per layer L (KS = 2 for layer 1, 8 for layer 2):
@@ -67,6 +72,7 @@ CTK_DEV float gru_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __built
 
 struct NetGru {
     static constexpr int TAPE = 84, LDS_FWD = GRUG_FWD * 64, LDS_BWD = GRUG_BWD * 64, HIDDEN = 64;
+    static constexpr bool THREE_KSTEPS = false;      // S + C <= 8 only (ctk_create refuses the GRU for larger environments)
 
     template <int KS, class XFn>
     CTK_DEV static void layer_fwd(const float* tab, int lane, XFn&& xb, f32x4 (&h)[2], GruLayerTape* tp) {
@@ -131,7 +137,7 @@ struct NetGru {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { h1[m][r] = hidden[16 * m + 4 * g + r]; h2[m][r] = hidden[32 + 16 * m + 4 * g + r]; }
         }
-        CTK_DEV MlpPair step(float x0, float x1, float4* tape) {
+        CTK_DEV MlpPair step(float x0, float x1, float /*x2*/, float4* tape) {
             GruLayerTape t1, t2;
             layer_fwd<2>(tab, lane, [&](int ks) { return ks == 0 ? x0 : x1; }, h1, tape ? &t1 : nullptr);
             const f32x4 a = h1[0], b = h1[1];

@@ -493,8 +493,7 @@ const char* ctk_affine_rollout_name(int pred, bool log) {
     return log ? "ctk_affine_rollout<0, 1, true>" : "ctk_affine_rollout<0, 1, false>";
 }
 const char* ctk_affine_rollout_env_name(int env, bool log) {
-    if (env == CTK_ENV_CARTPOLE) return ctk_affine_rollout_name(CTK_PRED_ODE, log);
-    return log ? "ctk_affine_rollout<1, 0, true>" : "ctk_affine_rollout<1, 0, false>";
+    return ctk_kernel_name("ctk_affine_rollout<%d, 0, %4$s>", env, 0, 0, log ? "true" : "false");
 }
 
 hipError_t ctk_launch_affine_rollout(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, const float* samples,
@@ -540,7 +539,8 @@ hipError_t ctk_launch_affine_rollout_env(hipStream_t st, int env, const float* p
     return hipGetLastError();
 }
 size_t ctk_affine_rollout_env_lds(int env, int H) {
-    const int C = env == CTK_ENV_CARTPOLE ? Env<CTK_ENV_CARTPOLE>::C : Env<CTK_ENV_QUAD2D>::C;
+    int C = 1;
+    CTK_FOR_ENV(env, EV, { C = Env<EV>::C; });
     return (size_t)affine_carve_floats(H * C, SAMP_TRAJ) * sizeof(float);
 }
 

@@ -72,6 +72,9 @@ typedef enum ctk_environment {
                              parameters: enum ctk_param.  Also has hand-tuned kernels (ctk_mppi.hip ...).      */
     CTK_ENV_QUAD2D = 1,   /* planar quadrotor: S 6 (x, vx, z, vz, theta, omega), C 2 (normalised rotor commands);
                              parameters: enum ctk_param_quad2d                                                  */
+    CTK_ENV_HOVER = 2,    /* planar hovercraft with a reaction wheel: S 7 (x, vx, y, vy, theta, omega, wheel speed), C 3 (main
+                             thruster, lateral thruster, wheel torque); S + C = 10 network inputs: the environment that
+                             exercises a third layer-1 k-step of the network predictors; parameters: enum ctk_param_hover */
     CTK_ENV_COUNT
 } ctk_environment;
 
@@ -108,6 +111,15 @@ typedef enum ctk_param_quad2d {
     CTK_Q_R, CTK_Q_POS_SCALE, CTK_Q_TERMINAL_WEIGHT,
     CTK_Q_COUNT
 } ctk_param_quad2d;
+/* parameters of CTK_ENV_HOVER */
+typedef enum ctk_param_hover {
+    CTK_V_MASS = 0, CTK_V_INERTIA, CTK_V_WHEEL_INERTIA, CTK_V_THRUST_MAX, CTK_V_LATERAL_MAX, CTK_V_TORQUE_MAX, CTK_V_DRAG_LIN,
+    CTK_V_DRAG_ANG, CTK_V_WHEEL_FRICTION,
+    CTK_V_TARGET_X, CTK_V_TARGET_Y,
+    CTK_V_POS_WEIGHT, CTK_V_ANG_WEIGHT, CTK_V_VEL_WEIGHT, CTK_V_ANGVEL_WEIGHT, CTK_V_WHEEL_WEIGHT, CTK_V_CC_WEIGHT, CTK_V_CCRC_WEIGHT,
+    CTK_V_R, CTK_V_POS_SCALE, CTK_V_TERMINAL_WEIGHT,
+    CTK_V_COUNT
+} ctk_param_hover;
 #define CTK_MAX_PARAMS 32
 
 /* Device-resident tensors readable with ctk_read(); replaces the to_numpy() calls that fill

@@ -115,7 +115,66 @@ class Quad2DParams:
         return QUAD2D_PARAM_NAMES
 
 
-ENVIRONMENTS = {"CartPole": EnvParams, "Quad2D": Quad2DParams}
+# Third build-defined environment (more than 8 network inputs, a third layer-1 k-step): a planar hovercraft
+# with a reaction wheel.  State (x, vx, y, vy, theta, omega, wheel speed), inputs (u1, u2, u3) in [-1, 1] = main thruster
+# (body axis), lateral thruster, wheel torque; the wheel's torque reacts on the body.  7 states + 3 inputs = 10 network inputs.
+HOVER_PARAM_NAMES = (
+    "mass", "inertia", "wheel_inertia", "thrust_max", "lateral_max", "torque_max", "drag_lin", "drag_ang", "wheel_friction",   # dynamics
+    "target_x", "target_y",                                                                                                  # per-step attributes
+    "pos_weight", "ang_weight", "vel_weight", "angvel_weight", "wheel_weight", "cc_weight", "ccrc_weight",
+    "R", "pos_scale", "terminal_weight",
+)
+
+
+@dataclass
+class HoverParams:
+    NAME = "Hover"
+    S, C = 7, 3
+    mass: float = 1.2
+    inertia: float = 0.05
+    wheel_inertia: float = 0.01
+    thrust_max: float = 4.0
+    lateral_max: float = 1.5
+    torque_max: float = 0.2
+    drag_lin: float = 0.3
+    drag_ang: float = 0.2
+    wheel_friction: float = 0.05
+    target_x: float = 0.0
+    target_y: float = 0.0
+    pos_weight: float = 300.0
+    ang_weight: float = 80.0
+    vel_weight: float = 6.0
+    angvel_weight: float = 1.0
+    wheel_weight: float = 0.02
+    cc_weight: float = 1.0
+    ccrc_weight: float = 1.5
+    R: float = 1.0
+    pos_scale: float = 0.5
+    terminal_weight: float = 0.0
+
+    def as_array(self) -> np.ndarray:
+        return np.array([getattr(self, k) for k in HOVER_PARAM_NAMES], dtype=np.float32)
+
+    def param_names(self):
+        return HOVER_PARAM_NAMES
+
+
+ENVIRONMENTS = {"CartPole": EnvParams, "Quad2D": Quad2DParams, "Hover": HoverParams}
+
+
+def hover_constants(p: HoverParams, dt: float, intermediate_steps: int = 1) -> dict:
+    """Derived fp32 constants of the hovercraft (double, rounded once) — the same expressions as csrc/ctk_env.h:
+    Env<CTK_ENV_HOVER>::derive."""
+    q = {k: float(np.float32(getattr(p, k))) for k in HOVER_PARAM_NAMES}
+    d = dict(
+        dt=dt / intermediate_steps,
+        aF=q["thrust_max"] / q["mass"], aL=q["lateral_max"] / q["mass"],
+        kT=q["torque_max"] / q["inertia"], kW=q["torque_max"] / q["wheel_inertia"],
+        c_v=q["drag_lin"], c_w=q["drag_ang"], c_ww=q["wheel_friction"],
+        pos_c=q["pos_weight"] / (q["pos_scale"] * q["pos_scale"]),
+        ccR=q["cc_weight"] * q["R"],
+    )
+    return {k: np.float32(v) for k, v in d.items()}
 
 
 def quad2d_constants(p: Quad2DParams, dt: float, intermediate_steps: int = 1) -> dict:
@@ -139,6 +198,8 @@ def derived_constants(p, dt: float, intermediate_steps: int = 1) -> dict:
     The C library computes exactly the same expressions (csrc/ctk_common.h: derive_constants)."""
     if isinstance(p, Quad2DParams):
         return quad2d_constants(p, dt, intermediate_steps)
+    if isinstance(p, HoverParams):
+        return hover_constants(p, dt, intermediate_steps)
     q = {k: float(np.float32(getattr(p, k))) for k in PARAM_NAMES}  # primary params are fp32
     inv_mt = 1.0 / (q["m_cart"] + q["m_pole"])
     ml = q["m_pole"] * q["L"]
@@ -344,6 +405,44 @@ class Predictor:
             x, vx, z, vz, th, om = (x + dt * vx, vx + dt * ax, z + dt * vz, vz + dt * az, th + dt * om, om + dt * al)
         return np.stack([x, vx, z, vz, th, om], axis=1).astype(np.float32)
 
+    def _hover_step(self, s, q):
+        k = derived_constants(self.env, self.dt, self.intermediate_steps)
+        x, vx, y, vy, th, om, w = (s[:, i].copy() for i in range(7))
+        q = self._q2(q)
+        fb, fl = k["aF"] * q[:, 0], k["aL"] * q[:, 1]     # body-frame accelerations of the two thrusters
+        dt = k["dt"]
+        for _ in range(self.intermediate_steps):
+            sn, cs = np.sin(th), np.cos(th)
+            ax = fb * cs - fl * sn - k["c_v"] * vx
+            ay = fb * sn + fl * cs - k["c_v"] * vy
+            al = -k["kT"] * q[:, 2] - k["c_w"] * om        # the wheel's torque reacts on the body
+            aw = k["kW"] * q[:, 2] - k["c_ww"] * w
+            x, vx, y, vy, th, om, w = (x + dt * vx, vx + dt * ax, y + dt * vy, vy + dt * ay, th + dt * om, om + dt * al, w + dt * aw)
+        return np.stack([x, vx, y, vy, th, om, w], axis=1).astype(np.float32)
+
+    def _hover_vjp(self, s, q, lam):
+        assert self.intermediate_steps == 1, "adjoint restated for intermediate_steps == 1"
+        k = derived_constants(self.env, self.dt, 1)
+        q = self._q2(q)
+        th = s[:, 4]
+        lx, lvx, ly, lvy, lth, lom, lw = (lam[:, i] for i in range(7))
+        dt = k["dt"]
+        sn, cs = np.sin(th), np.cos(th)
+        fb, fl = k["aF"] * q[:, 0], k["aL"] * q[:, 1]
+        a_ax, a_ay, a_al, a_aw = dt * lvx, dt * lvy, dt * lom, dt * lw
+        o_x = lx
+        o_vx = lvx + dt * lx - k["c_v"] * a_ax
+        o_y = ly
+        o_vy = lvy + dt * ly - k["c_v"] * a_ay
+        o_th = lth + (-fb * sn - fl * cs) * a_ax + (fb * cs - fl * sn) * a_ay
+        o_om = lom + dt * lth - k["c_w"] * a_al
+        o_w = lw - k["c_ww"] * a_aw
+        g0 = k["aF"] * (cs * a_ax + sn * a_ay)
+        g1 = k["aL"] * (-sn * a_ax + cs * a_ay)
+        g2 = -k["kT"] * a_al + k["kW"] * a_aw
+        return (np.stack([o_x, o_vx, o_y, o_vy, o_th, o_om, o_w], 1).astype(np.float32),
+                np.stack([g0, g1, g2], 1).astype(np.float32))
+
     def _quad_vjp(self, s, q, lam):
         assert self.intermediate_steps == 1, "adjoint restated for intermediate_steps == 1"
         k = derived_constants(self.env, self.dt, 1)
@@ -369,6 +468,8 @@ class Predictor:
     def _ode_step(self, s, q):
         if isinstance(self.env, Quad2DParams):
             return self._quad_step(s, q)
+        if isinstance(self.env, HoverParams):
+            return self._hover_step(s, q)
         q = self._q2(q)[:, 0]
         k = derived_constants(self.env, self.dt, self.intermediate_steps)
         x, v, th, om = (s[:, i].copy() for i in range(4))
@@ -403,6 +504,8 @@ class Predictor:
     def _ode_vjp(self, s, q, lam):
         if isinstance(self.env, Quad2DParams):
             return self._quad_vjp(s, q, lam)
+        if isinstance(self.env, HoverParams):
+            return self._hover_vjp(s, q, lam)
         q = self._q2(q)[:, 0]
         assert self.intermediate_steps == 1, "adjoint restated for intermediate_steps == 1"
         k = derived_constants(self.env, self.dt, 1)
@@ -476,6 +579,7 @@ class Cost:
         self.dt = dt
         self.S, self.C = env.S, env.C
         self.quad = isinstance(env, Quad2DParams)
+        self.hover = isinstance(env, HoverParams)
 
     def _k(self):
         return derived_constants(self.env, self.dt, 1)
@@ -487,6 +591,24 @@ class Cost:
         pos = k["pos_c"] * (dx * dx + dz * dz)
         ang = f32(e.ang_weight) * (f32(1.0) - np.cos(states[..., 4]))
         return pos.astype(np.float32), ang.astype(np.float32)
+
+    # hovercraft (build-defined terms: position error, attitude, velocities, wheel speed, input, input change) ------------
+    def _hover_state_terms(self, states):
+        k, e = self._k(), self.env
+        dx, dy = states[..., 0] - f32(e.target_x), states[..., 2] - f32(e.target_y)
+        pos = k["pos_c"] * (dx * dx + dy * dy)
+        ang = f32(e.ang_weight) * (f32(1.0) - np.cos(states[..., 4]))
+        return pos.astype(np.float32), ang.astype(np.float32)
+
+    def _hover_stage_cost(self, states, inputs, previous_input):
+        k, e = self._k(), self.env
+        pos, ang = self._hover_state_terms(states)
+        vx, vy, om, w = states[..., 1], states[..., 3], states[..., 5], states[..., 6]
+        vel = f32(e.vel_weight) * (vx * vx + vy * vy) + f32(e.angvel_weight) * om * om + f32(e.wheel_weight) * w * w
+        du = inputs - self._prev_inputs(inputs, previous_input)
+        cc = k["ccR"] * np.sum(inputs * inputs, axis=2, dtype=np.float32)
+        ccrc = f32(e.ccrc_weight) * np.sum(du * du, axis=2, dtype=np.float32)
+        return (pos + ang + vel + cc + ccrc).astype(np.float32)
 
     def _prev_inputs(self, inputs, previous_input):
         """[N,H,C]: the input applied one step earlier (previous_input for h = 0)"""
@@ -518,6 +640,8 @@ class Cost:
         dd, ep, ekp, cc, ccrc — names from Control_Toolkit_ASF_Template/config_cost_function.yml)."""
         if self.quad:
             return self._quad_stage_cost(states, inputs, previous_input)
+        if self.hover:
+            return self._hover_stage_cost(states, inputs, previous_input)
         e = self.env
         k = self._k()
         dd, ep, om = self._state_terms(states)
@@ -541,6 +665,9 @@ class Cost:
         if self.quad:
             pos, ang = self._quad_state_terms(terminal_states)
             return (f32(self.env.terminal_weight) * (pos + ang)).astype(np.float32)
+        if self.hover:
+            pos, ang = self._hover_state_terms(terminal_states)
+            return (f32(self.env.terminal_weight) * (pos + ang)).astype(np.float32)
         dd, ep, _ = self._state_terms(terminal_states)
         return (f32(self.env.terminal_weight) * (dd + ep)).astype(np.float32)
 
@@ -560,6 +687,16 @@ class Cost:
         """d(stage or terminal cost)/d(state) for states [N,S] -> [N,S]."""
         e = self.env
         k = self._k()
+        if self.hover:
+            z0 = np.zeros_like(states[:, 0])
+            gx = f32(2.0) * k["pos_c"] * (states[:, 0] - f32(e.target_x))
+            gy = f32(2.0) * k["pos_c"] * (states[:, 2] - f32(e.target_y))
+            gth = f32(e.ang_weight) * np.sin(states[:, 4])
+            if terminal:
+                w = f32(e.terminal_weight)
+                return np.stack([w * gx, z0, w * gy, z0, w * gth, z0, z0], 1).astype(np.float32)
+            return np.stack([gx, f32(2.0) * f32(e.vel_weight) * states[:, 1], gy, f32(2.0) * f32(e.vel_weight) * states[:, 3], gth,
+                             f32(2.0) * f32(e.angvel_weight) * states[:, 5], f32(2.0) * f32(e.wheel_weight) * states[:, 6]], 1).astype(np.float32)
         if self.quad:
             z0 = np.zeros_like(states[:, 0])
             gx = f32(2.0) * k["pos_c"] * (states[:, 0] - f32(e.target_x))

@@ -97,6 +97,18 @@ def inject_quad(env: O.Quad2DParams, dt: float):
         cf.CONSTANTS[name] = float(np.float32(getattr(env, name)))
 
 
+def inject_hover(env: O.HoverParams, dt: float, mlp_weights):
+    """constants of the third environment (hovercraft with a reaction wheel, 7 states / 3 inputs) and its 10-32-32-7 MLP"""
+    import SI_Toolkit.Predictors.predictor_wrapper as pw
+    import Control_Toolkit_ASF.Cost_Functions.Hover.default as cf
+    k = {kk: float(v) for kk, v in O.hover_constants(env, dt, 1).items()}
+    pw.CONSTANTS.clear(); pw.CONSTANTS.update(k)
+    pw.MLP_WEIGHTS = tuple(torch.tensor(a) for a in O.mlp_unpack(mlp_weights, 10, 7))
+    cf.CONSTANTS.clear(); cf.CONSTANTS.update(k)
+    for name in ("target_x", "target_y", "ang_weight", "vel_weight", "angvel_weight", "wheel_weight", "ccrc_weight", "terminal_weight"):
+        cf.CONSTANTS[name] = float(np.float32(getattr(env, name)))
+
+
 def plant_step(pred: O.Predictor, s, u):
     return pred.step(np.asarray(s, np.float32).reshape(1, pred.S), np.asarray(u, np.float32).reshape(1, pred.C))[0]
 
@@ -354,6 +366,88 @@ def main():
         for t in range(c["steps"]):
             ndraw = len(rec.raw)
             u_prev = np.broadcast_to(np.asarray(opt.u, np.float32).reshape(-1), (2,)).copy()
+            u = ctrl.step(s.copy())
+            d[f"s_{t}"] = s.copy(); d[f"u_prev_{t}"] = u_prev
+            d[f"u_{t}"] = np.asarray(u, np.float32).reshape(-1)
+            if len(rec.raw) > ndraw:
+                d[f"resample_draws_{t}"] = rec.raw[-1]
+            d[f"Q_{t}"] = opt.Q_tf.detach().numpy().copy()
+            d[f"u_nom_{t}"] = opt.u_nom.detach().numpy().copy()
+            stp, m_arr, v_arr = opt.opt.get_weights()
+            d[f"adam_step_{t}"] = np.int32(stp); d[f"m_{t}"] = m_arr.copy(); d[f"v_{t}"] = v_arr.copy()
+            d[f"ages_{t}"] = opt.trajectory_ages.numpy().copy()
+            s = plant_step(plant, s, u)
+        d["steps"] = np.int32(c["steps"])
+        np.savez_compressed(os.path.join(out_dir, f"rpgd_{name}.npz"), **d)
+    # ---- third environment, S + C = 10 (> 8 network inputs), C = 3: the SAME unmodified reference optimizers on the hovercraft ----------
+    # ODE and the 10-32-32-7 MLP predictor: pins the C = 3 shapes and, for the MLP, gives the device network a reference-driven fixture
+    henv = O.HoverParams(terminal_weight=0.3, target_x=0.2, target_y=-0.1)
+    hover_w = O.mlp_default_weights(5, 10, 7)
+    inject_hover(henv, dt, hover_w)
+    pw.ENVIRONMENT = "Hover"
+    hlow, hhigh = np.array([-1.0, -0.7, -1.0], np.float32), np.array([0.9, 0.8, 1.0], np.float32)
+    hcommon = dict(environment=np.array("Hover"), env_params=henv.as_array(), env_param_names=np.array(O.HOVER_PARAM_NAMES),
+                   dt=np.float32(dt), low=hlow, high=hhigh, mlp_weights=hover_w)
+
+    def hover_state(seed):
+        r = np.random.default_rng(seed)
+        return np.array([r.uniform(-0.4, 0.4), r.uniform(-0.3, 0.3), r.uniform(-0.4, 0.4), r.uniform(-0.3, 0.3),
+                         r.uniform(-0.8, 0.8), r.uniform(-0.5, 0.5), r.uniform(-2, 2)], np.float32)
+
+    for name, c in {"hover_ode": dict(N=96, H=24, p=6, steps=3, seed=31, pred="ODE"), "hover_mlp": dict(N=64, H=16, p=4, steps=3, seed=32, pred="MLP")}.items():
+        cfg = dict(seed=1, mpc_horizon=c["H"], num_rollouts=c["N"], cc_weight=1.0, R=1.0, LBD=100.0, NU=1000.0,
+                   SQRTRHOINV=0.03, period_interpolation_inducing_points=c["p"], mpc_timestep=dt)
+        ctrl = make_controller("mppi", cfg, c["pred"], "Hover", (hlow, hhigh))
+        ctrl.controller_logging = True
+        ctrl.optimizer.optimizer_logging = True
+        opt = ctrl.optimizer
+        rec = RecordingRng(opt.rng); opt.rng = rec
+        plant = O.Predictor(kind="ODE", dt=dt, env=henv)
+        s = hover_state(c["seed"])
+        d = dict(hcommon, predictor=np.array(c["pred"]), **{k: np.float32(v) if isinstance(v, float) else np.array(v) for k, v in cfg.items()})
+        d["u_nom_init"] = opt.u_nom.numpy().copy()
+        for t in range(c["steps"]):
+            u_prev = np.broadcast_to(np.asarray(opt.u, np.float32).reshape(-1), (3,)).copy()
+            u = ctrl.step(s.copy())
+            lv = opt.logging_values
+            d[f"s_{t}"] = s.copy(); d[f"u_prev_{t}"] = u_prev
+            d[f"noise_{t}"] = rec.raw[-1]
+            d[f"u_{t}"] = np.asarray(u, np.float32).reshape(-1)
+            d[f"u_nom_{t}"] = opt.u_nom.numpy().copy()
+            d[f"J_{t}"] = lv["J_logged"].copy(); d[f"u_run_{t}"] = lv["Q_logged"].copy()
+            d[f"traj_{t}"] = lv["rollout_trajectories_logged"].copy()
+            s = plant_step(plant, s, u)
+        d["steps"] = np.int32(c["steps"])
+        np.savez_compressed(os.path.join(out_dir, f"mppi_{name}.npz"), **d)
+
+    for name, c in {"hover_ode": dict(N=32, H=16, p=4, its=3, steps=4, resamp=2, dist="uniform", seed=33, shift=1, pred="ODE"),
+                    "hover_mlp": dict(N=48, H=14, p=7, its=4, steps=3, resamp=2, dist="normal", seed=34, shift=1, pred="MLP")}.items():
+        cfg = dict(seed=1, mpc_horizon=c["H"], num_rollouts=c["N"], outer_its=c["its"], sample_stdev=0.5,
+                   sample_mean=0.0, sample_whole_control_space=True, uniform_dist_min=-1.0, uniform_dist_max=1.0,
+                   resamp_per=c["resamp"], period_interpolation_inducing_points=c["p"],
+                   SAMPLING_DISTRIBUTION=c["dist"], shift_previous=c["shift"], warmup=False, warmup_iterations=250,
+                   learning_rate=0.05, opt_keep_k_ratio=0.25, gradmax_clip=5.0, rtol=1e-3, adam_beta_1=0.9,
+                   adam_beta_2=0.999, adam_epsilon=1e-8, mpc_timestep=dt)
+        import Control_Toolkit.Optimizers as tmpl
+        orig_create = tmpl.create_rng
+        holder = {}
+        def recording_create(id, seed, computation_library=None):
+            holder["rec"] = RecordingRng(orig_create(id, seed, computation_library=computation_library))
+            return holder["rec"]
+        tmpl.create_rng = recording_create
+        try:
+            ctrl = make_controller("rpgd", cfg, c["pred"], "Hover", (hlow, hhigh))
+        finally:
+            tmpl.create_rng = orig_create
+        opt, rec = ctrl.optimizer, holder["rec"]
+        d = dict(hcommon, predictor=np.array(c["pred"]), **{k: (np.float32(v) if isinstance(v, float) else np.array(v)) for k, v in cfg.items()})
+        d["reset_draws"] = rec.raw[0]
+        d["Q_init"] = opt.Q_tf.detach().numpy().copy()
+        plant = O.Predictor(kind="ODE", dt=dt, env=henv)
+        s = hover_state(c["seed"])
+        for t in range(c["steps"]):
+            ndraw = len(rec.raw)
+            u_prev = np.broadcast_to(np.asarray(opt.u, np.float32).reshape(-1), (3,)).copy()
             u = ctrl.step(s.copy())
             d[f"s_{t}"] = s.copy(); d[f"u_prev_{t}"] = u_prev
             d[f"u_{t}"] = np.asarray(u, np.float32).reshape(-1)

@@ -64,3 +64,6 @@ RPGD_CASES = ["ode_small", "ode_its20", "mlp_cfg4", "ode_normal"]
 # recorded from the same unmodified reference optimizers on the second environment (6 states, 2 control inputs)
 MPPI_QUAD_CASES = ["quad2d", "quad2d_p1"]
 RPGD_QUAD_CASES = ["quad2d", "quad2d_its20"]
+# ... and on the third environment (7 states, 3 control inputs: 10 network inputs), analytic and 10-32-32-7 MLP predictor
+MPPI_HOVER_CASES = ["hover_ode", "hover_mlp"]
+RPGD_HOVER_CASES = ["hover_ode", "hover_mlp"]

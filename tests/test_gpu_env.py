@@ -492,11 +492,15 @@ def test_quad2d_mlp_gradient_and_rpgd_match_oracle():
 # ---- SURVEY 8e with the second environment: shards of N/2 + the record exchange == one handle of N ----------------
 @pytest.mark.parametrize("opt", ["mppi", "cem", "random_action", "rpgd"])
 def test_quad2d_two_shards_equal_one_handle(opt):
-    """records carry [.., H*C] plans for C = 2: MPPI partials (2 + P*C), best-K candidates (2 + H*C), RPGD keepers (3 + 3*H*C)"""
+    two_shards_equal_one_handle(opt, "Quad2D", quad_env(), QLO, QHI, S0)
+
+
+def two_shards_equal_one_handle(opt, envname, env, lo, hi, s0, kind="ODE", weights=None):
+    """records carry [.., H*C] plans: MPPI partials (2 + P*C), best-K candidates (2 + H*C), RPGD keepers (3 + 3*H*C)"""
     import torch
-    env = quad_env()
+    S, C = env.S, env.C
     N, H, p, K, its = 256, 20, 5, 32, 3
-    kw = dict(environment="Quad2D", mpc_horizon=H, dt=0.02, action_low=QLO, action_high=QHI)
+    kw = dict(environment=envname, mpc_horizon=H, dt=0.02, action_low=lo, action_high=hi)
     if opt == "mppi":
         kw.update(period_interpolation_inducing_points=p)
     elif opt == "cem":
@@ -504,28 +508,31 @@ def test_quad2d_two_shards_equal_one_handle(opt):
     elif opt == "rpgd":
         kw.update(period_interpolation_inducing_points=p, outer_its=its, resamp_per=2, shift_previous=1, opt_keep_k=K,
                   sampling_distribution=0, sample_whole_control_space=1, learning_rate=0.05, gradmax_clip=5.0)
-    full = CtkEngine(opt, "ODE", num_rollouts=N, **kw)
-    sh = [CtkEngine(opt, "ODE", num_rollouts=N // 2, global_rollout_offset=i * N // 2, **kw) for i in range(2)]
+    full = CtkEngine(opt, kind, num_rollouts=N, **kw)
+    sh = [CtkEngine(opt, kind, num_rollouts=N // 2, global_rollout_offset=i * N // 2, **kw) for i in range(2)]
     for e in sh + [full]:
         apply_params(e, env)
+        if weights is not None:
+            e.set_predictor_weights(weights)
+    pred = O.Predictor(kind, env=env, weights=weights)
     P = O.num_inducing_points(H, p)
     rng = np.random.default_rng(17)
     half = lambda a, i: a[i * N // 2:(i + 1) * N // 2]
     if opt == "mppi":
-        rec = full.mppi_partial_size(); assert rec == 2 + P * 2
+        rec = full.mppi_partial_size(); assert rec == 2 + P * C
     elif opt == "rpgd":
-        rec = sh[0].rpgd_keepers_size(); assert rec == K * (3 + 3 * H * 2)
-        d0 = rng.random((N, P, 2), dtype=np.float32)
+        rec = sh[0].rpgd_keepers_size(); assert rec == K * (3 + 3 * H * C)
+        d0 = rng.random((N, P, C), dtype=np.float32)
         full.reset(d0)
         for i, e in enumerate(sh):
             e.reset(half(d0, i))
     else:
-        rec = sh[0].shard_candidates_size(); assert rec == (K if opt == "cem" else 1) * (2 + H * 2)
+        rec = sh[0].shard_candidates_size(); assert rec == (K if opt == "cem" else 1) * (2 + H * C)
     buf = torch.zeros(2 * rec, dtype=torch.float32, device="cuda")
-    s = S0.copy()
+    s = s0.copy()
     for t in range(4):
         if opt == "mppi":
-            noise = rng.standard_normal((N, P, 2)).astype(np.float32)
+            noise = rng.standard_normal((N, P, C)).astype(np.float32)
             u_full = full.step(s, noise)
             for i, e in enumerate(sh):
                 e.mppi_step_begin(s, buf.data_ptr() + 4 * i * rec, half(noise, i))
@@ -534,7 +541,7 @@ def test_quad2d_two_shards_equal_one_handle(opt):
         elif opt == "rpgd":
             fresh = [e.rpgd_fresh_rows(2) for e in sh]
             assert fresh == ([N // 2, N // 2 - K] if t % 2 == 0 else [0, 0])
-            dr = rng.random((N - K, P, 2), dtype=np.float32) if t % 2 == 0 else None
+            dr = rng.random((N - K, P, C), dtype=np.float32) if t % 2 == 0 else None
             u_full = full.step(s, dr)
             for i, e in enumerate(sh):
                 e.rpgd_step_begin(s, buf.data_ptr() + 4 * i * rec)
@@ -544,7 +551,7 @@ def test_quad2d_two_shards_equal_one_handle(opt):
                 np.testing.assert_allclose(np.concatenate([e.read(name) for e in sh]), full.read(name), rtol=1e-6, atol=1e-7, err_msg=name)
         else:
             n_it = sh[0].shard_iterations()
-            draws = (rng.standard_normal((n_it, N, H, 2)) if opt == "cem" else rng.random((n_it, N, H, 2))).astype(np.float32)
+            draws = (rng.standard_normal((n_it, N, H, C)) if opt == "cem" else rng.random((n_it, N, H, C))).astype(np.float32)
             u_full = full.step(s, draws if opt == "cem" else draws[0])
             for it in range(n_it):
                 for i, e in enumerate(sh):
@@ -553,11 +560,11 @@ def test_quad2d_two_shards_equal_one_handle(opt):
                 for e in sh:
                     e.shard_iter_end(buf.data_ptr(), 2)
             us = [e.shard_finish() for e in sh]
-        assert us[0].shape == (2,)
+        assert us[0].shape == (C,)
         np.testing.assert_array_equal(us[0], us[1])
         np.testing.assert_allclose(us[0], u_full, **U_TOL)
         if opt in ("mppi", "cem"):
             np.testing.assert_allclose(sh[0].read("U_NOM"), full.read("U_NOM"), **U_TOL)
-        s = O.Predictor("ODE", env=env).step(s.reshape(1, 6), u_full.reshape(1, 2))[0]
+        s = pred.step(s.reshape(1, S), u_full.reshape(1, C))[0]
     for e in sh + [full]:
         e.close()

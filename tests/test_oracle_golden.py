@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import ctk_oracle as O
-from helpers import load, env_from, mppi_oracle_from, rpgd_oracle_from, MPPI_CASES, RPGD_CASES, MPPI_QUAD_CASES, RPGD_QUAD_CASES
+from helpers import load, env_from, mppi_oracle_from, rpgd_oracle_from, MPPI_CASES, RPGD_CASES, MPPI_QUAD_CASES, RPGD_QUAD_CASES, MPPI_HOVER_CASES, RPGD_HOVER_CASES
 
 
 def test_interpolator_matches_reference():
@@ -219,14 +219,14 @@ def test_torch_cpu_restatement_matches_the_numpy_oracle():
 
 
 # ---- second environment (Quad2D, C = 2): the same reference optimizers, recorded by tests/golden/make_golden.py -------------
-@pytest.mark.parametrize("case", MPPI_QUAD_CASES)
+@pytest.mark.parametrize("case", MPPI_QUAD_CASES + MPPI_HOVER_CASES)
 def test_mppi_two_inputs_matches_reference(case):
     d = load(f"mppi_{case}.npz")
     o = mppi_oracle_from(d)
-    assert (o.S, o.C) == (6, 2)
+    assert (o.S, o.C) == ((6, 2) if case.startswith("quad") else (7, 3))
     np.testing.assert_array_equal(o.u_nom, d["u_nom_init"])
     for t in range(int(d["steps"])):
-        np.testing.assert_array_equal(np.broadcast_to(np.asarray(o.u, np.float32).reshape(-1), (2,)), d[f"u_prev_{t}"])
+        np.testing.assert_array_equal(np.broadcast_to(np.asarray(o.u, np.float32).reshape(-1), (o.C,)), d[f"u_prev_{t}"])
         u = o.step(d[f"s_{t}"], d[f"noise_{t}"])
         np.testing.assert_allclose(o.u_run, d[f"u_run_{t}"], rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(o.J, d[f"J_{t}"], rtol=2e-5)
@@ -236,7 +236,7 @@ def test_mppi_two_inputs_matches_reference(case):
         o.u_nom = d[f"u_nom_{t}"].copy(); o.u = d[f"u_{t}"].copy()
 
 
-@pytest.mark.parametrize("case", RPGD_QUAD_CASES)
+@pytest.mark.parametrize("case", RPGD_QUAD_CASES + RPGD_HOVER_CASES)
 def test_rpgd_two_inputs_matches_reference(case):
     d = load(f"rpgd_{case}.npz")
     o = rpgd_oracle_from(d)
@@ -257,7 +257,7 @@ def test_rpgd_two_inputs_matches_reference(case):
 
 
 # ---- the oracle's hand-written reverse modes against torch autograd in fp64 (build container and GPU box: torch-CPU) ------------
-@pytest.mark.parametrize("kind,envname", [("GRU", "CartPole"), ("GRU", "Quad2D"), ("MLP", "Quad2D"), ("ODE", "Quad2D")])
+@pytest.mark.parametrize("kind,envname", [("GRU", "CartPole"), ("GRU", "Quad2D"), ("MLP", "Quad2D"), ("ODE", "Quad2D"), ("ODE", "Hover"), ("MLP", "Hover")])
 def test_oracle_adjoints_match_torch_autograd_fp64(kind, envname):
     """d(sum_n J_n)/dQ from rollout_cost_and_grad (what the HIP reverse sweeps are tested against) == autograd through a
     float64 torch restatement of the same rollout and cost (what the reference does at optimizer_rpgd.py:329-333)."""
@@ -296,6 +296,14 @@ def test_oracle_adjoints_match_torch_autograd_fp64(kind, envname):
                 x = (1 - z) * n + z * hprev
                 new.append(x)
             return x @ T(Wo).T + T(bo), new
+        if envname == "Hover":                                            # hovercraft ODE
+            x_, vx, y_, vy, th, om, w = s.unbind(1)
+            fb, fl = k["aF"] * u[:, 0], k["aL"] * u[:, 1]
+            ax = fb * torch.cos(th) - fl * torch.sin(th) - k["c_v"] * vx
+            ay = fb * torch.sin(th) + fl * torch.cos(th) - k["c_v"] * vy
+            al, aw = -k["kT"] * u[:, 2] - k["c_w"] * om, k["kW"] * u[:, 2] - k["c_ww"] * w
+            dt = k["dt"]
+            return torch.stack([x_ + dt * vx, vx + dt * ax, y_ + dt * vy, vy + dt * ay, th + dt * om, om + dt * al, w + dt * aw], 1), hid
         x_, vx, z_, vz, th, om = s.unbind(1)                              # Quad2D ODE
         aF, aM = k["g"] + k["kF"] * (u[:, 0] + u[:, 1]), k["kM"] * (u[:, 0] - u[:, 1])
         ax, az, al = -aF * torch.sin(th) - k["c_v"] * vx, aF * torch.cos(th) - k["g"] - k["c_v"] * vz, aM - k["c_w"] * om
@@ -304,6 +312,10 @@ def test_oracle_adjoints_match_torch_autograd_fp64(kind, envname):
 
     def stage(s, u, upv):
         e = env
+        if envname == "Hover":
+            pos = k["pos_c"] * ((s[:, 0] - e.target_x) ** 2 + (s[:, 2] - e.target_y) ** 2) + e.ang_weight * (1 - torch.cos(s[:, 4]))
+            return (pos + e.vel_weight * (s[:, 1] ** 2 + s[:, 3] ** 2) + e.angvel_weight * s[:, 5] ** 2 + e.wheel_weight * s[:, 6] ** 2
+                    + k["ccR"] * (u ** 2).sum(1) + e.ccrc_weight * ((u - upv) ** 2).sum(1)), pos
         if envname == "Quad2D":
             pos = k["pos_c"] * ((s[:, 0] - e.target_x) ** 2 + (s[:, 2] - e.target_z) ** 2) + e.ang_weight * (1 - torch.cos(s[:, 4]))
             return (pos + e.vel_weight * (s[:, 1] ** 2 + s[:, 3] ** 2) + e.angvel_weight * s[:, 5] ** 2
