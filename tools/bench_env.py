@@ -65,16 +65,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=300)
     a = ap.parse_args()
-    print(f"{'workload':<18}{'N':>6}{'H':>5}{'p':>4} | {'CartPole tuned':>16} | {'CartPole template':>18} | {'Quad2D template':>16}   (us / step, median (mean))")
+    print(f"{'workload':<18}{'N':>6}{'H':>5}{'p':>4} | {'CartPole tuned':>16} | {'CartPole template':>18} | {'Quad2D template':>16} | {'Hover template':>16}   (us / step, median (mean))")
     for label, opt, pred, N, H, p, kw in ROWS:
         cells = []
-        for env, generic in (("CartPole", False), ("CartPole", True), ("Quad2D", False)):
+        for env, generic in (("CartPole", False), ("CartPole", True), ("Quad2D", False), ("Hover", False)):
             try:
                 med, mean, _ = run(env, generic, opt, pred, N, H, p, kw, a.steps)
                 cells.append(f"{med:8.1f} ({mean:6.1f})")
             except Exception as ex:                                  # a combination the library refuses is part of the table
                 cells.append(f"refused: {type(ex).__name__}")
-        print(f"{label:<18}{N:>6}{H:>5}{p:>4} | {cells[0]:>16} | {cells[1]:>18} | {cells[2]:>16}", flush=True)
+        print(f"{label:<18}{N:>6}{H:>5}{p:>4} | {cells[0]:>16} | {cells[1]:>18} | {cells[2]:>16} | {cells[3]:>16}", flush=True)
 
 
 if __name__ == "__main__":
