@@ -1055,7 +1055,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
         size_t lds;
         const int cols = (int)(cfg->optimizer == CTK_OPT_MPPI ? PC : HC);
         if (generic && cfg->predictor != CTK_PRED_ODE)
-            lds = descends ? ctk_g_rpgd_descent_net_lds(h->env, cfg->predictor, (int)H) : ctk_g_rollout_net_lds(cfg->predictor, cols, (int)H, h->C);
+            lds = descends ? ctk_g_rpgd_descent_net_lds(h->env, cfg->predictor, (int)N, (int)H) : ctk_g_rollout_net_lds(cfg->predictor, cols, (int)H, h->C);
         else if (generic) lds = descends ? ctk_g_rpgd_descent_lds(h->env, (int)H, nullptr) : ctk_g_rollout_lds(cols, (int)H, h->C);
         else lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_lds((int)P, (int)H, cfg->predictor, (int)N)
                  : descends ? ctk_rpgd_descent_lds(cfg->predictor, (int)H, nullptr) : ctk_affine_rollout_lds((int)H, cfg->predictor);
@@ -1120,7 +1120,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     }
     const bool mat = cfg->materialize_trajectories != 0;
     const bool gnet = generic && cfg->predictor != CTK_PRED_ODE;
-    if (descends) h->dominant = gnet ? ctk_g_rpgd_descent_net_name(h->env, cfg->predictor) : generic ? ctk_g_rpgd_descent_name(h->env) : ctk_rpgd_descent_name(cfg->predictor, (int)N);
+    if (descends) h->dominant = gnet ? ctk_g_rpgd_descent_net_name(h->env, cfg->predictor, (int)N, (int)H) : generic ? ctk_g_rpgd_descent_name(h->env) : ctk_rpgd_descent_name(cfg->predictor, (int)N);
     else {
         const int mode = cfg->optimizer == CTK_OPT_MPPI ? CTK_G_MODE_MPPI : CTK_G_MODE_AFFINE;
         h->dominant = gnet ? ctk_g_rollout_net_name(h->env, cfg->predictor, mode, mat) : generic ? ctk_g_rollout_name(h->env, mode, mat)

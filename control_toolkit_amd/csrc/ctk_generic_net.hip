@@ -9,6 +9,7 @@
 #include "ctk_net.h"
 #include "ctk_adam.h"
 #include "ctk_launch.h"
+#include <algorithm>
 
 constexpr int GN_TRAJ = 64, GN_BLOCK = 256, GN_LD = GN_TRAJ + 1;
 
@@ -386,17 +387,20 @@ hipError_t ctk_launch_g_rollout_net(hipStream_t st, int env, int net, int mode, 
     return hipGetLastError();
 }
 
-size_t ctk_g_rpgd_descent_net_lds(int env, int net, int H) {
+size_t ctk_g_rpgd_descent_net_lds(int env, int net, int N, int H) {
     int C = 0;
     CTK_FOR_ENV(env, EV, { C = Env<EV>::C; });
+    if (net == NET_GRU && ctk_g_rpgd_gru4_ok(env, N, H)) return ctk_g_rpgd_descent_gru4_lds(H, C);
     return (size_t)(2 * H * C * GN_LD + GN_TRAJ + net_lds_fwd(net) + net_lds_bwd(net)) * sizeof(float);
 }
 
 size_t ctk_g_rpgd_scratch_floats_net(int net, int N, int H) {
-    return (size_t)((N + GN_TRAJ - 1) / GN_TRAJ) * 4 * H * 64 * (net == NET_GRU ? NetGru::TAPE : NetMlp::TAPE);
+    const size_t one_wave = (size_t)((N + GN_TRAJ - 1) / GN_TRAJ) * 4 * H * 64 * (net == NET_GRU ? NetGru::TAPE : NetMlp::TAPE);
+    return net == NET_GRU ? std::max(one_wave, ctk_g_rpgd_scratch_floats_gru4(N, H)) : one_wave;
 }
 
-const char* ctk_g_rpgd_descent_net_name(int env, int net) {
+const char* ctk_g_rpgd_descent_net_name(int env, int net, int N, int H) {
+    if (net == NET_GRU && ctk_g_rpgd_gru4_ok(env, N, H)) return ctk_g_rpgd_descent_gru4_name(env);
     int io = 0;
     CTK_FOR_ENV(env, EV, { io = Env<EV>::S + Env<EV>::C; });
     return ctk_kernel_name("ctk_g_rpgd_descent_net<%d, %4$s>", env, 0, 0, net == NET_GRU ? "NetGru" : (io > 8 ? "NetMlpT<true>" : "NetMlp"));
@@ -409,13 +413,15 @@ hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const
     AdamK ad{lr, b1, b2, (float)(1.0 - (double)b1), (float)(1.0 - (double)b2), eps, clip, rule};
     const float* hidden = wperm + ctk_g_net_table_floats(net);
     const float* wb = bwd_table(net, wperm);
+    if (net == NET_GRU && ctk_g_rpgd_gru4_ok(env, a_in.N, a_in.H))      // one tile over four waves while the population leaves SIMDs idle
+        return ctk_launch_g_rpgd_descent_gru4(st, env, a_in, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wb, hidden, scratch, e0, e1);
     CTK_FOR_ENV(env, EV, {
         using E = Env<EV>;
         RolloutArgs a = a_in;
         a.C = E::C; a.p_magic = magic_of(a.H * E::C);
         const typename E::K k = E::derive(params, dt, isteps);
         const dim3 grid((a.N + GN_TRAJ - 1) / GN_TRAJ), block(GN_BLOCK);
-        const size_t lds = ctk_g_rpgd_descent_net_lds(env, net, a.H);
+        const size_t lds = ctk_g_rpgd_descent_net_lds(env, net, 1 << 30, a.H);   // this (one-wave) form
         if (net == NET_GRU)
             CTK_LAUNCH((ctk_g_rpgd_descent_net<EV, NetGru>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wb, hidden, scratch);
         else

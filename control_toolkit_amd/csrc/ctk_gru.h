@@ -81,13 +81,18 @@ CTK_DEV GruState gru_load_state(const float* __restrict__ h0, int g) {
     return st;
 }
 
+// what wave (m, q) leaves for the adjoint of its two units (registers 2q, 2q+1 of tile m): ctk_gru4.hip
+struct GruPairTape {
+    float r[2], z[2], n[2], ghn[2], hp[2];
+};
+
 // One GRU layer for the workgroup's 16 trajectories; called by all four waves.  wv: [KS] A.ih, [8] A.hh, [8] B.
 // ex1: [4 waves][64 lanes] float4, ex2: [2 tiles][64 lanes] float4 (this layer's exchange slots).
 // Slot reuse needs no extra barrier: a slot is rewritten one full step later, after at least one workgroup
 // barrier that every reader of the old value reaches only after consuming it.
 template <int KS, class XFn>
 CTK_DEV void gru_layer(const float* wv, f32x4 biasA, f32x4 biasB, XFn&& xb, f32x4 (&h)[2], float* ex1, float* ex2,
-                       int wave, int lane) {
+                       int wave, int lane, GruPairTape* tp = nullptr) {
     const int m = wave >> 1, q = wave & 1;
     f32x4 a = biasA, b = biasB;
     if (q == 0) {   // r rows: input + recurrent products; n rows: input products
@@ -125,6 +130,10 @@ CTK_DEV void gru_layer(const float* wv, f32x4 biasA, f32x4 biasB, XFn&& xb, f32x
     const float zz0 = ctk_sigmoidf(z0), zz1 = ctk_sigmoidf(z1);
     const float nn0 = ctk_tanhf(ni0 + rr0 * nh0), nn1 = ctk_tanhf(ni1 + rr1 * nh1);
     const float hn0 = (1.0f - zz0) * nn0 + zz0 * ho0, hn1 = (1.0f - zz1) * nn1 + zz1 * ho1;
+    if (tp) {
+        tp->r[0] = rr0; tp->r[1] = rr1; tp->z[0] = zz0; tp->z[1] = zz1; tp->n[0] = nn0; tp->n[1] = nn1;
+        tp->ghn[0] = nh0; tp->ghn[1] = nh1; tp->hp[0] = ho0; tp->hp[1] = ho1;
+    }
     // (2) publish, then everybody reads the full new hidden vector of its lane: 2 tiles x 4 registers
     reinterpret_cast<float2*>(ex2)[(m * 64 + lane) * 2 + q] = make_float2(hn0, hn1);
     __syncthreads();

@@ -216,9 +216,19 @@ size_t ctk_g_rollout_net_lds(int net, int cols, int H, int C);
 hipError_t ctk_launch_g_rollout_net(hipStream_t st, int env, int net, int mode, const RolloutArgs& a, const float* params, float dt, int isteps,
                                     const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
                                     const float* wperm, float* parts, bool log, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
-size_t ctk_g_rpgd_descent_net_lds(int env, int net, int H);
+size_t ctk_g_rpgd_descent_net_lds(int env, int net, int N, int H);
 size_t ctk_g_rpgd_scratch_floats_net(int net, int N, int H);
-const char* ctk_g_rpgd_descent_net_name(int env, int net);
+const char* ctk_g_rpgd_descent_net_name(int env, int net, int N, int H);
+// ctk_gru4.hip: the recurrent predictor with one 16-plan tile spread over the four waves of a workgroup (forward and BPTT)
+struct AdamK;
+bool ctk_g_rpgd_gru4_ok(int env, int N, int H);
+size_t ctk_g_rpgd_descent_gru4_lds(int H, int C);
+size_t ctk_g_rpgd_scratch_floats_gru4(int N, int H);
+const char* ctk_g_rpgd_descent_gru4_name(int env);
+hipError_t ctk_launch_g_rpgd_descent_gru4(hipStream_t st, int env, const RolloutArgs& a, const float* params, float dt, int isteps,
+                                          const AdamK& ad, float* Q, float* m, float* v, const float* bc_table, int bc_len, int t0, int iters,
+                                          const float* wperm, const float* wperm_bwd, const float* hidden, float* scratch,
+                                          hipEvent_t e0, hipEvent_t e1);
 hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const RolloutArgs& a, const float* params, float dt, int isteps,
                                          float lr, float b1, float b2, float eps, float clip, float* Q, float* m, float* v,
                                          const float* bc_table, int bc_len, int t0, int iters, const float* wperm, float* scratch,

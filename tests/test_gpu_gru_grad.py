@@ -119,3 +119,47 @@ def test_cartpole_rpgd_with_gru_matches_oracle():
         e.set_state(np.concatenate([o.Q.ravel(), o.opt.m.ravel(), o.opt.v.ravel(), o.trajectory_ages.ravel(), [float(o.u)], [o.opt.step_count], [o.count]]).astype(np.float32))
         s = s + np.array([0.01, 0.0, -0.02, 0.01], np.float32)
     e.close()
+
+
+@pytest.mark.parametrize("N,H", [(40, 12), (17, 3), (1, 1), (200, 33)])
+def test_cartpole_rpgd_with_gru_ragged_populations_match_oracle(N, H):
+    """the four-wave form (ctk_gru4.hip) owns 16 plans per workgroup: populations that are not multiples of 16 (a partial last tile),
+    a single plan, a horizon of one"""
+    env = O.EnvParams(terminal_weight=0.3)
+    w = O.gru_default_weights(3)
+    pred = O.Predictor("GRU", env=env, weights=w)
+    pred.hidden = (0.1 * np.random.default_rng(2).standard_normal((2, 32))).astype(np.float32)
+    its, p = 2, 1
+    k = max(N // 4, 1)
+    o = O.RPGD(pred, O.Cost(env), num_rollouts=N, mpc_horizon=H, outer_its=its, resamp_per=1000, period_interpolation_inducing_points=p,
+               SAMPLING_DISTRIBUTION="uniform", opt_keep_k_ratio=k / N)
+    e = CtkEngine("rpgd", "GRU", num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p, outer_its=its, resamp_per=1000,
+                  opt_keep_k=o.k, sampling_distribution=0, sample_whole_control_space=1)
+    assert "gru4" in e.dominant_kernel()
+    for n in env.param_names():
+        e.set_param(n, float(getattr(env, n)))
+    e.set_predictor_weights(w)
+    e.predictor_set_hidden(pred.hidden)
+    d0 = np.random.default_rng(N).random((N, o.P, 1), dtype=np.float32)
+    o.optimizer_reset(d0); e.reset(d0)
+    s = np.array([0.05, -0.1, 2.8, 0.4], np.float32)
+    tol = dict(rtol=5e-4, atol=5e-4)
+    dr = np.random.default_rng(N + 1).random((N - o.k, o.P, 1), dtype=np.float32)      # the first step resamples (count % resamp_per == 0)
+    uo, ug = o.step(s, dr), e.step(s, dr if N > o.k else None)
+    assert_close_mostly(e.read("PLAN"), o.Q, max_outliers=max(2, o.Q.size // 400), **tol)
+    assert_close_mostly(e.read("ADAM_M"), o.opt.m, max_outliers=max(2, o.Q.size // 400), **tol)
+    np.testing.assert_allclose(e.read("J"), o.J, rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(ug[0], uo, **tol)
+    e.close()
+
+
+def test_one_wave_gru_reverse_form_also_matches_oracle():
+    """Populations above 8 192 plans (and horizons whose states do not fit LDS) keep one wave per tile (ctk_net.h: NetGru::Bwd); its
+    diagnostic switch (read once per process) puts it under the same oracle tests in a child process."""
+    import os, subprocess, sys
+    env = dict(os.environ, CTK_RPGD_GRU_ONE_WAVE="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(here, "test_gpu_gru_grad.py"),
+                        "-k", "(single_gradient or rpgd_with_gru_matches) and not one_wave"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

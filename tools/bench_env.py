@@ -64,9 +64,12 @@ def run(env, generic, opt, pred, N, H, p, kw, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--rows", default="", help="only the rows whose label contains this text")
     a = ap.parse_args()
     print(f"{'workload':<18}{'N':>6}{'H':>5}{'p':>4} | {'CartPole tuned':>16} | {'CartPole template':>18} | {'Quad2D template':>16} | {'Hover template':>16}   (us / step, median (mean))")
     for label, opt, pred, N, H, p, kw in ROWS:
+        if a.rows and a.rows not in label:
+            continue
         cells = []
         for env, generic in (("CartPole", False), ("CartPole", True), ("Quad2D", False), ("Hover", False)):
             try:
