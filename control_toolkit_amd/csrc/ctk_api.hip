@@ -554,7 +554,10 @@ int check_predictor(ctk_handle* h) {
 }
 
 // ---- MPPI ------------------------------------------------------------------------------------
-int mppi_block_parts(const ctk_handle* h) { return h->generic ? ctk_g_rollout_blocks(h->N) : ctk_mppi_num_blocks(h->N, h->cfg.predictor); }
+int mppi_block_parts(const ctk_handle* h) {
+    if (h->generic && h->cfg.predictor != CTK_PRED_ODE) return ctk_g_rollout_net_blocks(h->env, h->cfg.predictor, CTK_G_MODE_MPPI, h->N, h->P, h->H);
+    return h->generic ? ctk_g_rollout_blocks(h->N) : ctk_mppi_num_blocks(h->N, h->cfg.predictor);
+}
 // template path: the analytic predictor of ANY environment runs the 4-wave kernel of ctk_mppi.hip (in-launch hand-off included)
 // below the throughput sizes; its network predictors keep the one-wave kernels of ctk_generic_net.hip
 bool mppi_env_kernel(const ctk_handle* h) {
@@ -1055,7 +1058,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
         size_t lds;
         const int cols = (int)(cfg->optimizer == CTK_OPT_MPPI ? PC : HC);
         if (generic && cfg->predictor != CTK_PRED_ODE)
-            lds = descends ? ctk_g_rpgd_descent_net_lds(h->env, cfg->predictor, (int)N, (int)H) : ctk_g_rollout_net_lds(cfg->predictor, cols, (int)H, h->C);
+            lds = descends ? ctk_g_rpgd_descent_net_lds(h->env, cfg->predictor, (int)N, (int)H) : ctk_g_rollout_net_lds(h->env, cfg->predictor, (int)N, cols, (int)H, h->C);
         else if (generic) lds = descends ? ctk_g_rpgd_descent_lds(h->env, (int)H, nullptr) : ctk_g_rollout_lds(cols, (int)H, h->C);
         else lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_lds((int)P, (int)H, cfg->predictor, (int)N)
                  : descends ? ctk_rpgd_descent_lds(cfg->predictor, (int)H, nullptr) : ctk_affine_rollout_lds((int)H, cfg->predictor);
@@ -1123,7 +1126,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     if (descends) h->dominant = gnet ? ctk_g_rpgd_descent_net_name(h->env, cfg->predictor, (int)N, (int)H) : generic ? ctk_g_rpgd_descent_name(h->env) : ctk_rpgd_descent_name(cfg->predictor, (int)N);
     else {
         const int mode = cfg->optimizer == CTK_OPT_MPPI ? CTK_G_MODE_MPPI : CTK_G_MODE_AFFINE;
-        h->dominant = gnet ? ctk_g_rollout_net_name(h->env, cfg->predictor, mode, mat) : generic ? ctk_g_rollout_name(h->env, mode, mat)
+        h->dominant = gnet ? ctk_g_rollout_net_name(h->env, cfg->predictor, mode, mat, (int)N, (int)P, (int)H) : generic ? ctk_g_rollout_name(h->env, mode, mat)
                     : cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_name(cfg->predictor, mat, cfg->num_rollouts, cfg->period_interpolation_inducing_points == 1 && h->P == (int)H, false)
                                                      : ctk_affine_rollout_name(cfg->predictor, mat);
     }

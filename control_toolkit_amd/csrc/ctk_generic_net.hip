@@ -346,13 +346,28 @@ static const float* bwd_table(int net, const float* wperm) { return net == NET_G
 static size_t net_lds_fwd(int net) { return net == NET_GRU ? NetGru::LDS_FWD : 0; }
 static size_t net_lds_bwd(int net) { return net == NET_GRU ? NetGru::LDS_BWD : 0; }
 
-const char* ctk_g_rollout_net_name(int env, int net, int mode, bool log) {
+int ctk_g_rollout_net_cols(int env, int mode, int P, int H) {
+    int C = 0;
+    CTK_FOR_ENV(env, EV, { C = Env<EV>::C; });
+    return (mode == CTK_G_MODE_MPPI ? P : H) * C;
+}
+
+// workgroups = block records of one MPPI launch
+int ctk_g_rollout_net_blocks(int env, int net, int mode, int N, int P, int H) {
+    return net == NET_GRU && ctk_g_rollout_gru4_ok(env, N, H, ctk_g_rollout_net_cols(env, mode, P, H)) ? ctk_g_rollout_gru4_blocks(N) : ctk_g_rollout_blocks(N);
+}
+
+const char* ctk_g_rollout_net_name(int env, int net, int mode, bool log, int N, int P, int H) {
+    if (net == NET_GRU && ctk_g_rollout_gru4_ok(env, N, H, ctk_g_rollout_net_cols(env, mode, P, H))) return ctk_g_rollout_gru4_name(env, mode, log);
     int io = 0;
     CTK_FOR_ENV(env, EV, { io = Env<EV>::S + Env<EV>::C; });
     return ctk_kernel_name("ctk_g_rollout_net<%d, %4$s, %d, %5$s>", env, mode, 0, net == NET_GRU ? "NetGru" : (io > 8 ? "NetMlpT<true>" : "NetMlp"), log ? "true" : "false");
 }
 
-size_t ctk_g_rollout_net_lds(int net, int cols, int H, int C) { return ctk_g_rollout_lds(cols, H, C) + net_lds_fwd(net) * sizeof(float); }
+size_t ctk_g_rollout_net_lds(int env, int net, int N, int cols, int H, int C) {
+    if (net == NET_GRU && ctk_g_rollout_gru4_ok(env, N, H, cols)) return ctk_g_rollout_gru4_lds(cols, H, C);
+    return ctk_g_rollout_lds(cols, H, C) + net_lds_fwd(net) * sizeof(float);
+}
 
 template <int EV, class NETT>
 static void launch_rollout_net(hipStream_t st, int mode, const RolloutArgs& a_in, const float* params, float dt, int isteps, const MppiK& mk,
@@ -379,6 +394,8 @@ hipError_t ctk_launch_g_rollout_net(hipStream_t st, int env, int net, int mode, 
                                     const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
                                     const float* wperm, float* parts, bool log, hipEvent_t e0, hipEvent_t e1) {
     const float* hidden = wperm + ctk_g_net_table_floats(net);
+    if (net == NET_GRU && ctk_g_rollout_gru4_ok(env, a.N, a.H, ctk_g_rollout_net_cols(env, mode, a.P, a.H)))   // one tile over four waves
+        return ctk_launch_g_rollout_gru4(st, env, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1);
     CTK_FOR_ENV(env, EV, {
         using MLP = NetMlpT<(Env<EV>::S + Env<EV>::C > 8)>;      // a third layer-1 k-step where the environment has more than 8 network inputs
         if (net == NET_GRU) launch_rollout_net<EV, NetGru>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1);

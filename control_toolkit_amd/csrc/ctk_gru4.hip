@@ -402,6 +402,159 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rpgd_descent_gru4(RolloutArgs 
     }
 }
 
+// ---- rollout + cost (MPPI / affine modes of ctk_generic_net.hip: ctk_g_rollout_net) ---------------------------------------------------
+// 16 trajectories per workgroup.  Inputs (interpolation, shifted nominal, clip, MPPI correction) are formed for all (step, trajectory)
+// pairs before the recurrence, the costs from the states it leaves in LDS after it; the recurrence itself is gru4_step only.
+// LDS: exchange slots | reductions | states xs[H+1][64][2] | inputs u[HC][17] | sample tile [16][ts] | e[16] | base, scale [HC] | interp tables
+template <int ENV, int MODE, bool LOG>
+__global__ __launch_bounds__(G4_BLOCK) void ctk_g_rollout_gru4(RolloutArgs a, typename Env<ENV>::K k, MppiK mk, const float* __restrict__ samples,
+                                                              const float* __restrict__ base, const float* __restrict__ scale, int rng_kind,
+                                                              const float* __restrict__ wperm, const float* __restrict__ hidden,
+                                                              float* __restrict__ parts) {
+    using E = Env<ENV>;
+    constexpr int S = E::S, C = E::C;
+    static_assert(S + C <= 8, "the GRU's input tile holds 8 columns");
+    extern __shared__ float lds[];
+    const int H = a.H, HC = H * C, cols = a.P, ts = tile_stride(cols);
+    float* ex = lds;
+    float* red_s = ex + G4_EX_FWD;
+    float* xs_s = red_s + G4_RED;
+    float* u_s = xs_s + (H + 1) * 128;
+    float* tile = u_s + HC * G4_LD;
+    float* e_s = tile + G4_TRAJ * ts;
+    float* base_s = e_s + G4_TRAJ;
+    float* scale_s = base_s + HC;
+    float* w0_s = scale_s + HC;
+    float* w1_s = w0_s + H;
+    int* i0_s = reinterpret_cast<int*>(w1_s + H);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * G4_TRAJ;
+    const int pc = t & 15, part = t >> 4;
+    const int n = row0 + pc;
+    const bool valid = n < a.N;
+
+    const GruW wf = gru4_load_fwd(wperm, wave >> 1, wave & 1, lane);
+    load_tile_early<G4_TRAJ, G4_BLOCK>(tile, samples, a, row0, MODE == CTK_G_MODE_MPPI ? mk.stdev : 1.0f, rng_kind, [&] {
+        if constexpr (MODE == CTK_G_MODE_MPPI) {
+            for (int h = t; h < H; h += G4_BLOCK) {
+                const InterpEntry e = a.interp[h];
+                i0_s[h] = e.i0; w0_s[h] = e.w0; w1_s[h] = e.w1;
+            }
+            for (int hc = t; hc < HC; hc += G4_BLOCK) {
+                const int h = hc / C, cc = hc - h * C;
+                base_s[hc] = base[min(h + 1, H - 1) * C + cc];
+            }
+        } else {
+            for (int hc = t; hc < HC; hc += G4_BLOCK) { base_s[hc] = base[hc]; scale_s[hc] = scale[hc]; }
+        }
+    });
+    float up0[C];
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) up0[cc] = a.u_prev_dev ? a.u_prev_dev[cc] : a.u_prev[cc];
+    const float s00 = g < S ? lane_state4(a, g) : 0.0f, s01 = 4 + g < S ? lane_state4(a, g, 4) : 0.0f;
+    __syncthreads();
+
+    auto sum_parts = [&](float v) {           // over the 16 parts of a trajectory (part = 4 * wave + g), fixed order; valid in every thread
+        v = sum_over_groups(v);
+        if (g == 0) red_s[wave * 16 + c] = v;
+        __syncthreads();
+        const float r = (red_s[c] + red_s[16 + c]) + (red_s[32 + c] + red_s[48 + c]);
+        __syncthreads();
+        return r;
+    };
+
+    // ---- inputs of all steps, and what of the cost depends on them only
+    float corr = 0.0f;
+    {
+        const float* my = tile + pc * ts;
+        const int Pm1 = cols / C - 1;
+        for (int h = part; h < H; h += 16) {
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) {
+                float u;
+                if constexpr (MODE == CTK_G_MODE_MPPI) {
+                    const int i0 = i0_s[h], i1 = min(i0 + 1, Pm1);
+                    const float du = my[i0 * C + cc] * w0_s[h] + my[i1 * C + cc] * w1_s[h];
+                    u = fminf(fmaxf(base_s[h * C + cc] + du, a.lo[cc]), a.hi[cc]);
+                    corr += mk.cc * (mk.k_dd * (du * du) + mk.R * u * du + mk.k_uu * (u * u));
+                } else {
+                    u = fminf(fmaxf(base_s[h * C + cc] + my[h * C + cc] * scale_s[h * C + cc], a.lo[cc]), a.hi[cc]);
+                }
+                u_s[(h * C + cc) * G4_LD + pc] = u;
+                if constexpr (LOG || MODE == CTK_G_MODE_AFFINE) {
+                    if (valid && a.Q_out) a.Q_out[(size_t)n * HC + h * C + cc] = u;
+                }
+            }
+        }
+        if constexpr (MODE == CTK_G_MODE_MPPI) corr = sum_parts(corr);
+        else __syncthreads();
+    }
+    // ---- the recurrence
+    {
+        GruState st = gru_load_state(hidden, g);
+        float sv0 = s00, sv1 = s01;
+        for (int h = 0; h < H; ++h) {
+            float u[C];
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) u[cc] = u_s[(h * C + cc) * G4_LD + c];
+            if (wave == (h & 3)) reinterpret_cast<float2*>(xs_s)[h * 64 + lane] = make_float2(sv0, sv1);
+            float x0, x1;
+            gru4_operands<S, C>(sv0, sv1, u, g, x0, x1);
+            const MlpPair o = gru4_step(wf, st, x0, x1, ex, wave, lane, nullptr, nullptr);
+            sv0 = o.lo; sv1 = o.hi;
+        }
+        if (wave == 0) reinterpret_cast<float2*>(xs_s)[H * 64 + lane] = make_float2(sv0, sv1);
+        __syncthreads();
+    }
+    // ---- costs from the states
+    float cs = 0.0f;
+    for (int h = part; h <= H; h += 16) {
+        float s[S];
+#pragma unroll
+        for (int j = 0; j < S; ++j) s[j] = xs_s[(h * 64 + (j & 3) * 16 + pc) * 2 + (j >> 2)];
+        if constexpr (LOG) {
+            if (valid && a.traj_out) {
+#pragma unroll
+                for (int j = 0; j < S; ++j) a.traj_out[((size_t)n * (H + 1) + h) * S + j] = s[j];
+            }
+        }
+        if (h < H) {
+            float u[C], upv[C];
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) {
+                u[cc] = u_s[(h * C + cc) * G4_LD + pc];
+                upv[cc] = h > 0 ? u_s[((h - 1) * C + cc) * G4_LD + pc] : up0[cc];
+            }
+            cs += E::stage_cost(k, s, u, upv);
+        } else {
+            cs += E::terminal_cost(k, s);
+        }
+    }
+    cs = sum_parts(cs);
+    const float J = cs * a.inv_Hp1 + corr;                      // of trajectory c = pc, in every thread
+    if (wave == 0 && g == 0 && valid) a.J[n] = J;
+
+    if constexpr (MODE == CTK_G_MODE_MPPI) {
+        float rho = valid ? J : INFINITY;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) rho = fminf(rho, __shfl_xor(rho, o, 64));
+        const float e = valid ? expf(mk.neg_inv_lbd * (J - rho)) : 0.0f;
+        float aw = e;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) aw += __shfl_xor(aw, o, 64);
+        if (wave == 0 && g == 0) e_s[c] = e;
+        __syncthreads();
+        float* rec = parts + (size_t)blockIdx.x * (2 + cols);
+        if (t == 0) { rec[0] = rho; rec[1] = aw; }
+        for (int p = t; p < cols; p += G4_BLOCK) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int r = 0; r < G4_TRAJ; ++r) acc += e_s[r] * tile[r * ts + p];
+            rec[2 + p] = acc;
+        }
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
 static uint32_t g4_magic_of(int d) { return d >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d) : 0u; }
 
@@ -434,6 +587,48 @@ hipError_t ctk_launch_g_rpgd_descent_gru4(hipStream_t st, int env, const Rollout
             const dim3 grid((a.N + G4_TRAJ - 1) / G4_TRAJ), block(G4_BLOCK);
             const size_t lds = ctk_g_rpgd_descent_gru4_lds(a.H, E::C);
             CTK_LAUNCH((ctk_g_rpgd_descent_gru4<EV>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wperm_bwd, hidden, scratch);
+        } else {
+            return hipErrorInvalidValue;
+        }
+    });
+    return hipGetLastError();
+}
+
+size_t ctk_g_rollout_gru4_lds(int cols, int H, int C) {
+    return (size_t)(G4_EX_FWD + G4_RED + (H + 1) * 128 + H * C * G4_LD + G4_TRAJ * tile_stride(cols) + G4_TRAJ + 2 * H * C + 3 * H) * sizeof(float);
+}
+
+// the four-wave rollout: while 16-trajectory workgroups leave the chip room (one-wave tiles: 4 per workgroup of ctk_g_rollout_net)
+bool ctk_g_rollout_gru4_ok(int env, int N, int H, int cols) {
+    static const bool off = getenv("CTK_GRU_ONE_WAVE") != nullptr;            // diagnostic switch (A/B measurements)
+    int S = 0, C = 0;
+    CTK_FOR_ENV(env, EV, { S = Env<EV>::S; C = Env<EV>::C; });
+    return !off && S + C <= 8 && N <= 8192 && ctk_g_rollout_gru4_lds(cols, H, C) <= 160 * 1024;
+}
+
+int ctk_g_rollout_gru4_blocks(int N) { return (N + G4_TRAJ - 1) / G4_TRAJ; }
+
+const char* ctk_g_rollout_gru4_name(int env, int mode, bool log) { return ctk_kernel_name("ctk_g_rollout_gru4<%d, %d, %4$s>", env, mode, 0, log ? "true" : "false"); }
+
+hipError_t ctk_launch_g_rollout_gru4(hipStream_t st, int env, int mode, const RolloutArgs& a_in, const float* params, float dt, int isteps,
+                                     const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
+                                     const float* wperm, const float* hidden, float* parts, bool log, hipEvent_t e0, hipEvent_t e1) {
+    CTK_FOR_ENV(env, EV, {
+        using E = Env<EV>;
+        if constexpr (E::S + E::C <= 8) {
+            RolloutArgs a = a_in;
+            const int cols = (mode == CTK_G_MODE_MPPI ? a_in.P : a_in.H) * E::C;
+            a.P = cols; a.p_magic = g4_magic_of(cols); a.C = E::C;
+            const typename E::K k = E::derive(params, dt, isteps);
+            const dim3 grid(ctk_g_rollout_gru4_blocks(a.N)), block(G4_BLOCK);
+            const size_t lds = ctk_g_rollout_gru4_lds(cols, a.H, E::C);
+            if (mode == CTK_G_MODE_MPPI) {
+                if (log) CTK_LAUNCH((ctk_g_rollout_gru4<EV, CTK_G_MODE_MPPI, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts);
+                else CTK_LAUNCH((ctk_g_rollout_gru4<EV, CTK_G_MODE_MPPI, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts);
+            } else {
+                if (log) CTK_LAUNCH((ctk_g_rollout_gru4<EV, CTK_G_MODE_AFFINE, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts);
+                else CTK_LAUNCH((ctk_g_rollout_gru4<EV, CTK_G_MODE_AFFINE, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts);
+            }
         } else {
             return hipErrorInvalidValue;
         }

@@ -211,8 +211,10 @@ hipError_t ctk_launch_g_rpgd_descent(hipStream_t st, int env, const RolloutArgs&
 // wperm: the policy's per-lane operand tables (forward | reverse), followed by the GRU's carried hidden state [64]
 size_t ctk_g_net_table_floats(int net);
 size_t ctk_g_net_hidden_floats(int net);
-const char* ctk_g_rollout_net_name(int env, int net, int mode, bool log);
-size_t ctk_g_rollout_net_lds(int net, int cols, int H, int C);
+const char* ctk_g_rollout_net_name(int env, int net, int mode, bool log, int N, int P, int H);
+int ctk_g_rollout_net_cols(int env, int mode, int P, int H);
+int ctk_g_rollout_net_blocks(int env, int net, int mode, int N, int P, int H);   // workgroups = block records of one MPPI launch
+size_t ctk_g_rollout_net_lds(int env, int net, int N, int cols, int H, int C);
 hipError_t ctk_launch_g_rollout_net(hipStream_t st, int env, int net, int mode, const RolloutArgs& a, const float* params, float dt, int isteps,
                                     const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
                                     const float* wperm, float* parts, bool log, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
@@ -222,6 +224,13 @@ const char* ctk_g_rpgd_descent_net_name(int env, int net, int N, int H);
 // ctk_gru4.hip: the recurrent predictor with one 16-plan tile spread over the four waves of a workgroup (forward and BPTT)
 struct AdamK;
 bool ctk_g_rpgd_gru4_ok(int env, int N, int H);
+bool ctk_g_rollout_gru4_ok(int env, int N, int H, int cols);
+size_t ctk_g_rollout_gru4_lds(int cols, int H, int C);
+int ctk_g_rollout_gru4_blocks(int N);
+const char* ctk_g_rollout_gru4_name(int env, int mode, bool log);
+hipError_t ctk_launch_g_rollout_gru4(hipStream_t st, int env, int mode, const RolloutArgs& a, const float* params, float dt, int isteps,
+                                     const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
+                                     const float* wperm, const float* hidden, float* parts, bool log, hipEvent_t e0, hipEvent_t e1);
 size_t ctk_g_rpgd_descent_gru4_lds(int H, int C);
 size_t ctk_g_rpgd_scratch_floats_gru4(int N, int H);
 const char* ctk_g_rpgd_descent_gru4_name(int env);

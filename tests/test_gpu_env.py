@@ -96,7 +96,7 @@ def test_quad2d_env_info_and_errors():
     with pytest.raises(ValueError, match="num_states"):
         CtkEngine("mppi", "ODE", environment="Quad2D", num_states=4, num_control_inputs=1, num_rollouts=8, mpc_horizon=5, dt=0.02)
     eg = CtkEngine("mppi", "GRU", environment="Quad2D", num_rollouts=8, mpc_horizon=5, dt=0.02)     # every predictor on every environment
-    assert eg.predictor_weight_count() == O.gru_num_weights(8, 6) and "NetGru" in eg.dominant_kernel()
+    assert eg.predictor_weight_count() == O.gru_num_weights(8, 6) and "ctk_g_rollout_gru4<1," in eg.dominant_kernel()
     eg.close()
     em = CtkEngine("mppi", "MLP", environment="Quad2D", num_rollouts=8, mpc_horizon=5, dt=0.02)
     assert em.predictor_weight_count() == O.mlp_num_weights(8, 6)

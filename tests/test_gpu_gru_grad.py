@@ -24,7 +24,9 @@ def test_cartpole_generic_gru_matches_four_wave_gru(opt):
         kw.update(cem_outer_it=2, cem_best_k=12)
     w = O.gru_default_weights(3)
     a, b = CtkEngine(opt, "GRU", **kw), CtkEngine(opt, "GRU", generic_kernels=True, **kw)
-    assert "NetGru" in b.dominant_kernel() and "NetGru" not in a.dominant_kernel()
+    import os
+    form = "NetGru" if os.environ.get("CTK_GRU_ONE_WAVE") else "ctk_g_rollout_gru4"        # (the child process of the last test in this file)
+    assert form in b.dominant_kernel() and "ctk_g_" not in a.dominant_kernel()             # template (ctk_gru4.hip) vs tuned (ctk_gru.h)
     a.set_predictor_weights(w); b.set_predictor_weights(w)
     h0 = (0.2 * np.random.default_rng(0).standard_normal((2, 32))).astype(np.float32)
     a.predictor_set_hidden(h0); b.predictor_set_hidden(h0)
@@ -157,9 +159,10 @@ def test_one_wave_gru_reverse_form_also_matches_oracle():
     """Populations above 8 192 plans (and horizons whose states do not fit LDS) keep one wave per tile (ctk_net.h: NetGru::Bwd); its
     diagnostic switch (read once per process) puts it under the same oracle tests in a child process."""
     import os, subprocess, sys
-    env = dict(os.environ, CTK_RPGD_GRU_ONE_WAVE="1")
+    env = dict(os.environ, CTK_RPGD_GRU_ONE_WAVE="1", CTK_GRU_ONE_WAVE="1")
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(here, "test_gpu_gru_grad.py"),
-                        "-k", "(single_gradient or rpgd_with_gru_matches) and not one_wave"], env=env, capture_output=True, text=True, timeout=600)
+                        "-k", "(single_gradient or rpgd_with_gru_matches or quad2d_gru_mppi or generic_gru_matches) and not one_wave"],
+                       env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
