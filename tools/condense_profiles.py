@@ -106,6 +106,27 @@ def main():
     copy_text("cem_stamps_cfg3.txt", f"{tag}_cem_stamps_cfg3.txt", "# tools/diag_cem_fused (stamped diagnostic build of ctk_cem_fused): where an outer iteration's time goes\n")
     copy_text("cem_stamps_default.txt", f"{tag}_cem_stamps_default.txt", "# tools/diag_cem_fused 200 40 40 (the reference's default CEM size)\n")
     copy_text("sweep_n.txt", f"{tag}_mppi_sweep_n.txt", "# tools/sweep_n.py\n")
+    p = pmc("pmc_largen")
+    if fresh(p):
+        import collections
+        import csv
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(p)):
+            acc[r["Kernel_Name"].replace("void ", "").split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        N, H = 1 << 20, 50
+        text = ("# rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES -- python3 tools/large_n_once.py  (MPPI N = 2^20, H = 50, period 1, ODE, sample buffer)\n"
+                "# VALU instructions per trajectory-step = SQ_INSTS_VALU (wave instructions) / (N / 64 waves * H steps); whole kernel incl. prologue / epilogue\n"
+                f"{'kernel':44s} {'n':>3s} {'SQ_INSTS_VALU':>14s} {'SQ_WAVES':>9s} {'per traj-step':>14s}\n")
+        for kname, c in acc.items():
+            if kname.startswith("__amd") or kname.startswith("at::"):
+                continue
+            iv = sum(c["SQ_INSTS_VALU"]) / max(1, len(c["SQ_INSTS_VALU"]))
+            wv = sum(c["SQ_WAVES"]) / max(1, len(c["SQ_WAVES"]))
+            per = iv / (N / 64 * H) if "rollout" in kname else float("nan")
+            text += f"{kname[:44]:44s} {len(c['SQ_INSTS_VALU']):3d} {iv:14.0f} {wv:9.0f} {per:14.1f}\n"
+        text += ("# static count of the 16-step loop body (llvm-objdump of ctk_mppi.o): round 2: 1165 VALU of which 135 v_pk_* (half rate) = 72.8 instructions /\n"
+                 "# 81 issue slots per trajectory-step; round 3: 1026, none packed = 64.1\n")
+        put(f"{tag}_mppi_largeN_insts.txt", text)
 
     rows = []
     for f in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
