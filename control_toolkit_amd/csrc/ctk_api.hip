@@ -565,6 +565,8 @@ bool mppi_env_kernel(const ctk_handle* h) {
            ctk_mppi_rollout_env_lds(h->env, h->P, h->H, h->N) <= 160 * 1024;
 }
 bool mppi_can_fuse(const ctk_handle* h) {
+    if (h->generic && h->cfg.predictor != CTK_PRED_ODE)     // network template kernels: the {value, seq} hand-off only
+        return h->d_ll != nullptr && ctk_g_rollout_net_fusable(h->env, h->cfg.predictor, h->N, h->P, h->H);
     if (h->generic) return mppi_env_kernel(h) && ctk_mppi_fusable(h->PC, mppi_block_parts(h), h->d_ll != nullptr);
     return !ctk_mppi_uses_throughput_kernel(h->cfg.predictor, h->N) && ctk_mppi_fusable(h->P, mppi_block_parts(h), h->d_ll != nullptr);
 }
@@ -587,12 +589,15 @@ int mppi_rollout(ctk_handle* h, const float* s, const float* u_prev, const float
                                                h->d_parts, log, fz, ps.a, ps.b));
         return CTK_OK;
     }
-    if (h->generic) {   // template kernel: block records only (merged by the launches that follow)
+    if (h->generic) {   // template kernels: network predictors hand their records over in-launch when asked to; else block records only
         ProfSlot ps(h);
-        if (h->cfg.predictor != CTK_PRED_ODE)
+        if (h->cfg.predictor != CTK_PRED_ODE) {
+            MppiFuse fz;
+            fz.mode = fuse_mode; fz.out_rec = partial_dev; fz.ll = h->d_ll;
+            fz.u_nom_out = h->d_unom[h->cur ^ 1]; fz.u_dev = h->d_u; fz.u_host = h->h_u_dev; fz.seq = h->seq;
             HIP_TRY(h, ctk_launch_g_rollout_net(h->stream, h->env, h->cfg.predictor, CTK_G_MODE_MPPI, a, h->params, h->cfg.dt, h->cfg.intermediate_steps,
-                                                h->mk, d_s, h->d_unom[h->cur], nullptr, 0, h->d_wperm, h->d_parts, log, ps.a, ps.b));
-        else
+                                                h->mk, d_s, h->d_unom[h->cur], nullptr, 0, h->d_wperm, h->d_parts, log, ps.a, ps.b, &fz));
+        } else
             HIP_TRY(h, ctk_launch_g_rollout(h->stream, h->env, CTK_G_MODE_MPPI, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s,
                                             h->d_unom[h->cur], nullptr, 0, h->d_parts, log, ps.a, ps.b));
         return CTK_OK;
@@ -1080,7 +1085,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     TRY_CREATE(dev_alloc(h, &h->d_parts3, ((nblk + 1023) / 1024) * (2 + PC)));
     TRY_CREATE(dev_alloc(h, &h->d_rec, 2 + PC));
     TRY_CREATE(dev_alloc(h, &h->d_counter, 1));
-    if ((!generic || cfg->predictor == CTK_PRED_ODE) && nblk <= (size_t)CTK_MPPI_FUSE_MAX_BLOCKS_LL && !std::getenv("CTK_NO_LL"))
+    if (nblk <= (size_t)CTK_MPPI_FUSE_MAX_BLOCKS_LL && !std::getenv("CTK_NO_LL"))
         TRY_CREATE(dev_alloc(h, &h->d_ll, nblk * (2 + PC)));
     if (cfg->optimizer == CTK_OPT_CEM && ctk_cem_fusable(cfg->predictor, (int)N, (int)HC) && !std::getenv("CTK_NO_CEM_FUSED"))
         TRY_CREATE(dev_alloc(h, &h->d_cem_ll, ctk_cem_fused_ll_words((int)N, (int)HC)));   // tuned and template path alike

@@ -9,6 +9,7 @@
 #include "ctk_net.h"
 #include "ctk_adam.h"
 #include "ctk_launch.h"
+#include "ctk_mppi_merge.h"
 #include <algorithm>
 
 constexpr int GN_TRAJ = 64, GN_BLOCK = 256, GN_LD = GN_TRAJ + 1;
@@ -58,7 +59,7 @@ template <int ENV, class NET, int MODE, bool LOG>
 __global__ __launch_bounds__(GN_BLOCK) void ctk_g_rollout_net(RolloutArgs a, typename Env<ENV>::K k, MppiK m, const float* __restrict__ samples,
                                                              const float* __restrict__ base, const float* __restrict__ scale, int rng_kind,
                                                              const float* __restrict__ wperm, const float* __restrict__ hidden,
-                                                             int net_lds_off, float* __restrict__ parts) {
+                                                             int net_lds_off, float* __restrict__ parts, NetFuse gz) {
     using E = Env<ENV>;
     constexpr int S = E::S, C = E::C;
     extern __shared__ float lds[];
@@ -161,12 +162,23 @@ __global__ __launch_bounds__(GN_BLOCK) void ctk_g_rollout_net(RolloutArgs a, typ
         if (lane == 0) red_s[4 + wave] = aw;
         __syncthreads();
         float* rec = parts + (size_t)blockIdx.x * (2 + cols);
-        if (t == 0) { rec[0] = rho; rec[1] = (red_s[4] + red_s[5]) + (red_s[6] + red_s[7]); }
+        const bool use_ll = gz.mode != 0;            // kernel-argument uniform: the records are handed over inside this launch
+        unsigned long long* llr = gz.ll + (size_t)blockIdx.x * (2 + cols);
+        if (t == 0) {
+            const float aw_b = (red_s[4] + red_s[5]) + (red_s[6] + red_s[7]);
+            if (use_ll) { ll_store(llr, rho, gz.up.seq); ll_store(llr + 1, aw_b, gz.up.seq); }
+            else { rec[0] = rho; rec[1] = aw_b; }
+        }
         for (int p = t; p < cols; p += GN_BLOCK) {
             float acc = 0.0f;
 #pragma unroll 8
             for (int r = 0; r < GN_TRAJ; ++r) acc += e_s[r] * tile[r * ts + p];
-            rec[2 + p] = acc;
+            if (use_ll) ll_store(llr + 2 + p, acc, gz.up.seq);
+            else rec[2 + p] = acc;
+        }
+        if (use_ll && blockIdx.x == 0) {             // block 0 gathers every block's words, merges, updates / emits the shard record
+            __syncthreads();
+            mppi_ll_tail<C>(lds, gz.ll, (int)gridDim.x, cols, m.neg_inv_lbd, gz.mode, gz.out_rec, gz.up);
         }
     }
 }
@@ -369,37 +381,57 @@ size_t ctk_g_rollout_net_lds(int env, int net, int N, int cols, int H, int C) {
     return ctk_g_rollout_lds(cols, H, C) + net_lds_fwd(net) * sizeof(float);
 }
 
+// the kernel-side fuse argument of an MPPI launch (mode 0 unless the caller asked for the in-launch hand-off and it fits)
+NetFuse ctk_net_fuse(const MppiFuse* fuse, int mode, const RolloutArgs& a, int C, const float* u_nom, int blocks, int cols) {
+    NetFuse gz{};
+    if (fuse == nullptr || mode != CTK_G_MODE_MPPI || fuse->mode == 0 || fuse->ll == nullptr) return gz;
+    if (blocks > CTK_MPPI_FUSE_MAX_BLOCKS_LL || !merge_can_stage(cols, blocks)) return gz;
+    gz.mode = fuse->mode; gz.ll = fuse->ll; gz.out_rec = fuse->out_rec;
+    gz.up = MppiUpdateArgs{nullptr, nullptr, nullptr, nullptr, a.H, a.interp, u_nom, fuse->u_nom_out, a.lo[0], a.hi[0], fuse->u_dev, fuse->u_host, fuse->seq};
+    gz.up.C = C;
+    for (int c = 0; c < C; ++c) { gz.up.lo_c[c] = a.lo[c]; gz.up.hi_c[c] = a.hi[c]; }
+    return gz;
+}
+
+// may an MPPI step of this handle run as ONE launch?  (the API asks before it chooses the fuse mode)
+bool ctk_g_rollout_net_fusable(int env, int net, int N, int P, int H) {
+    const int blocks = ctk_g_rollout_net_blocks(env, net, CTK_G_MODE_MPPI, N, P, H);
+    return blocks <= CTK_MPPI_FUSE_MAX_BLOCKS_LL && merge_can_stage(ctk_g_rollout_net_cols(env, CTK_G_MODE_MPPI, P, H), blocks);
+}
+
 template <int EV, class NETT>
 static void launch_rollout_net(hipStream_t st, int mode, const RolloutArgs& a_in, const float* params, float dt, int isteps, const MppiK& mk,
                                const float* samples, const float* base, const float* scale, int rng_kind, const float* wperm,
-                               const float* hidden, float* parts, bool log, hipEvent_t e0, hipEvent_t e1) {
+                               const float* hidden, float* parts, bool log, hipEvent_t e0, hipEvent_t e1, const MppiFuse* fuse) {
     using E = Env<EV>;
     RolloutArgs a = a_in;
     const int cols = (mode == CTK_G_MODE_MPPI ? a_in.P : a_in.H) * E::C;
     a.P = cols; a.p_magic = magic_of(cols); a.C = E::C;
     const typename E::K k = E::derive(params, dt, isteps);
     const dim3 grid(ctk_g_rollout_blocks(a.N)), block(GN_BLOCK);
-    const size_t lds0 = ctk_g_rollout_lds(cols, a.H, E::C), lds = lds0 + NETT::LDS_FWD * sizeof(float);
+    const size_t lds0 = ctk_g_rollout_lds(cols, a.H, E::C);
+    const NetFuse gz = ctk_net_fuse(fuse, mode, a, E::C, base, (int)grid.x, cols);
+    const size_t lds = std::max(lds0 + NETT::LDS_FWD * sizeof(float), gz.mode ? merge_lds_staged(cols, (int)grid.x) : 0);
     const int off = (int)(lds0 / sizeof(float));
     if (mode == CTK_G_MODE_MPPI) {
-        if (log) CTK_LAUNCH((ctk_g_rollout_net<EV, NETT, CTK_G_MODE_MPPI, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, off, parts);
-        else CTK_LAUNCH((ctk_g_rollout_net<EV, NETT, CTK_G_MODE_MPPI, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, off, parts);
+        if (log) CTK_LAUNCH((ctk_g_rollout_net<EV, NETT, CTK_G_MODE_MPPI, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, off, parts, gz);
+        else CTK_LAUNCH((ctk_g_rollout_net<EV, NETT, CTK_G_MODE_MPPI, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, off, parts, gz);
     } else {
-        if (log) CTK_LAUNCH((ctk_g_rollout_net<EV, NETT, CTK_G_MODE_AFFINE, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, off, parts);
-        else CTK_LAUNCH((ctk_g_rollout_net<EV, NETT, CTK_G_MODE_AFFINE, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, off, parts);
+        if (log) CTK_LAUNCH((ctk_g_rollout_net<EV, NETT, CTK_G_MODE_AFFINE, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, off, parts, gz);
+        else CTK_LAUNCH((ctk_g_rollout_net<EV, NETT, CTK_G_MODE_AFFINE, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, off, parts, gz);
     }
 }
 
 hipError_t ctk_launch_g_rollout_net(hipStream_t st, int env, int net, int mode, const RolloutArgs& a, const float* params, float dt, int isteps,
                                     const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
-                                    const float* wperm, float* parts, bool log, hipEvent_t e0, hipEvent_t e1) {
+                                    const float* wperm, float* parts, bool log, hipEvent_t e0, hipEvent_t e1, const MppiFuse* fuse) {
     const float* hidden = wperm + ctk_g_net_table_floats(net);
     if (net == NET_GRU && ctk_g_rollout_gru4_ok(env, a.N, a.H, ctk_g_rollout_net_cols(env, mode, a.P, a.H)))   // one tile over four waves
-        return ctk_launch_g_rollout_gru4(st, env, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1);
+        return ctk_launch_g_rollout_gru4(st, env, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
     CTK_FOR_ENV(env, EV, {
         using MLP = NetMlpT<(Env<EV>::S + Env<EV>::C > 8)>;      // a third layer-1 k-step where the environment has more than 8 network inputs
-        if (net == NET_GRU) launch_rollout_net<EV, NetGru>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1);
-        else launch_rollout_net<EV, MLP>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1);
+        if (net == NET_GRU) launch_rollout_net<EV, NetGru>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
+        else launch_rollout_net<EV, MLP>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
     });
     return hipGetLastError();
 }
@@ -449,6 +481,8 @@ hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const
 
 hipError_t ctk_launch_g_gru_advance(hipStream_t st, int env, const RolloutArgs& a, const float* u_dev, float* wperm) {
     float* hidden = wperm + ctk_g_net_table_floats(NET_GRU);
+    static const bool one_wave = getenv("CTK_GRU_ONE_WAVE") != nullptr;
+    if (!one_wave) return ctk_launch_g_gru_advance4(st, env, a, u_dev, wperm, hidden);      // ctk_gru4.hip: the four-wave step
     CTK_FOR_ENV(env, EV, {
         hipLaunchKernelGGL((ctk_g_gru_advance<EV>), dim3(1), dim3(64), NetGru::LDS_FWD * sizeof(float), st, a, u_dev, wperm, hidden);
     });

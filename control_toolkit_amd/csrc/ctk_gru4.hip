@@ -25,6 +25,10 @@
 #include "ctk_net.h"
 #include "ctk_adam.h"
 #include "ctk_launch.h"
+#include "ctk_mppi_merge.h"
+#include <algorithm>
+
+NetFuse ctk_net_fuse(const MppiFuse* fuse, int mode, const RolloutArgs& a, int C, const float* u_nom, int blocks, int cols);   // ctk_generic_net.hip
 
 constexpr int G4_TRAJ = 16, G4_BLOCK = 256, G4_LD = G4_TRAJ + 1;
 constexpr int G4_TAPE_F4 = 5;                       // float4 per lane, wave and step
@@ -410,7 +414,7 @@ template <int ENV, int MODE, bool LOG>
 __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rollout_gru4(RolloutArgs a, typename Env<ENV>::K k, MppiK mk, const float* __restrict__ samples,
                                                               const float* __restrict__ base, const float* __restrict__ scale, int rng_kind,
                                                               const float* __restrict__ wperm, const float* __restrict__ hidden,
-                                                              float* __restrict__ parts) {
+                                                              float* __restrict__ parts, NetFuse gz) {
     using E = Env<ENV>;
     constexpr int S = E::S, C = E::C;
     static_assert(S + C <= 8, "the GRU's input tile holds 8 columns");
@@ -545,13 +549,51 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rollout_gru4(RolloutArgs a, ty
         if (wave == 0 && g == 0) e_s[c] = e;
         __syncthreads();
         float* rec = parts + (size_t)blockIdx.x * (2 + cols);
-        if (t == 0) { rec[0] = rho; rec[1] = aw; }
+        const bool use_ll = gz.mode != 0;            // kernel-argument uniform: the records are handed over inside this launch
+        unsigned long long* llr = gz.ll + (size_t)blockIdx.x * (2 + cols);
+        if (t == 0) {
+            if (use_ll) { ll_store(llr, rho, gz.up.seq); ll_store(llr + 1, aw, gz.up.seq); }
+            else { rec[0] = rho; rec[1] = aw; }
+        }
         for (int p = t; p < cols; p += G4_BLOCK) {
             float acc = 0.0f;
 #pragma unroll
             for (int r = 0; r < G4_TRAJ; ++r) acc += e_s[r] * tile[r * ts + p];
-            rec[2 + p] = acc;
+            if (use_ll) ll_store(llr + 2 + p, acc, gz.up.seq);
+            else rec[2 + p] = acc;
         }
+        if (use_ll && blockIdx.x == 0) {             // block 0 gathers every block's words, merges, updates / emits the shard record
+            __syncthreads();
+            mppi_ll_tail<C>(lds, gz.ll, (int)gridDim.x, cols, mk.neg_inv_lbd, gz.mode, gz.out_rec, gz.up);
+        }
+    }
+}
+
+// ---- predictor.update(s, Q0) (optimizer_mppi.py:195-197): the carried hidden state advanced by the measured state and the applied
+// input — one workgroup, the same four-wave step (all 16 MFMA columns carry the same values; column 0 writes back), operands straight
+// from the tables into registers (the one-wave form stages 59 KiB in LDS with 64 threads: 27 us behind every MPPI step)
+template <int ENV>
+__global__ __launch_bounds__(G4_BLOCK) void ctk_g_gru_advance4(RolloutArgs a, const float* __restrict__ u_dev, const float* __restrict__ wperm,
+                                                              float* __restrict__ hidden) {
+    using E = Env<ENV>;
+    constexpr int S = E::S, C = E::C;
+    static_assert(S + C <= 8, "the GRU's input tile holds 8 columns");
+    __shared__ float ex[G4_EX_FWD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 15, g = lane >> 4;
+    const GruW wf = gru4_load_fwd(wperm, wave >> 1, wave & 1, lane);
+    GruState st = gru_load_state(hidden, g);
+    float u[C];
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) u[cc] = u_dev ? u_dev[cc] : a.u_prev[cc];
+    const float sv0 = g < S ? lane_state4(a, g) : 0.0f, sv1 = 4 + g < S ? lane_state4(a, g, 4) : 0.0f;
+    float x0, x1;
+    gru4_operands<S, C>(sv0, sv1, u, g, x0, x1);
+    (void)gru4_step(wf, st, x0, x1, ex, wave, lane, nullptr, nullptr);      // its barriers order every lane's read of `hidden` before the write below
+    if (wave == 0 && c == 0) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { hidden[16 * m + 4 * g + r] = st.h1[m][r]; hidden[32 + 16 * m + 4 * g + r] = st.h2[m][r]; }
     }
 }
 
@@ -612,7 +654,8 @@ const char* ctk_g_rollout_gru4_name(int env, int mode, bool log) { return ctk_ke
 
 hipError_t ctk_launch_g_rollout_gru4(hipStream_t st, int env, int mode, const RolloutArgs& a_in, const float* params, float dt, int isteps,
                                      const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
-                                     const float* wperm, const float* hidden, float* parts, bool log, hipEvent_t e0, hipEvent_t e1) {
+                                     const float* wperm, const float* hidden, float* parts, bool log, hipEvent_t e0, hipEvent_t e1,
+                                     const MppiFuse* fuse) {
     CTK_FOR_ENV(env, EV, {
         using E = Env<EV>;
         if constexpr (E::S + E::C <= 8) {
@@ -621,17 +664,26 @@ hipError_t ctk_launch_g_rollout_gru4(hipStream_t st, int env, int mode, const Ro
             a.P = cols; a.p_magic = g4_magic_of(cols); a.C = E::C;
             const typename E::K k = E::derive(params, dt, isteps);
             const dim3 grid(ctk_g_rollout_gru4_blocks(a.N)), block(G4_BLOCK);
-            const size_t lds = ctk_g_rollout_gru4_lds(cols, a.H, E::C);
+            const NetFuse gz = ctk_net_fuse(fuse, mode, a, E::C, base, (int)grid.x, cols);
+            const size_t lds = std::max(ctk_g_rollout_gru4_lds(cols, a.H, E::C), gz.mode ? merge_lds_staged(cols, (int)grid.x) : 0);
             if (mode == CTK_G_MODE_MPPI) {
-                if (log) CTK_LAUNCH((ctk_g_rollout_gru4<EV, CTK_G_MODE_MPPI, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts);
-                else CTK_LAUNCH((ctk_g_rollout_gru4<EV, CTK_G_MODE_MPPI, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts);
+                if (log) CTK_LAUNCH((ctk_g_rollout_gru4<EV, CTK_G_MODE_MPPI, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
+                else CTK_LAUNCH((ctk_g_rollout_gru4<EV, CTK_G_MODE_MPPI, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
             } else {
-                if (log) CTK_LAUNCH((ctk_g_rollout_gru4<EV, CTK_G_MODE_AFFINE, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts);
-                else CTK_LAUNCH((ctk_g_rollout_gru4<EV, CTK_G_MODE_AFFINE, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts);
+                if (log) CTK_LAUNCH((ctk_g_rollout_gru4<EV, CTK_G_MODE_AFFINE, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
+                else CTK_LAUNCH((ctk_g_rollout_gru4<EV, CTK_G_MODE_AFFINE, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
             }
         } else {
             return hipErrorInvalidValue;
         }
+    });
+    return hipGetLastError();
+}
+
+hipError_t ctk_launch_g_gru_advance4(hipStream_t st, int env, const RolloutArgs& a, const float* u_dev, const float* wperm, float* hidden) {
+    CTK_FOR_ENV(env, EV, {
+        if constexpr (Env<EV>::S + Env<EV>::C <= 8) hipLaunchKernelGGL((ctk_g_gru_advance4<EV>), dim3(1), dim3(G4_BLOCK), 0, st, a, u_dev, wperm, hidden);
+        else return hipErrorInvalidValue;
     });
     return hipGetLastError();
 }

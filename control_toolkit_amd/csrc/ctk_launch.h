@@ -217,7 +217,8 @@ int ctk_g_rollout_net_blocks(int env, int net, int mode, int N, int P, int H);  
 size_t ctk_g_rollout_net_lds(int env, int net, int N, int cols, int H, int C);
 hipError_t ctk_launch_g_rollout_net(hipStream_t st, int env, int net, int mode, const RolloutArgs& a, const float* params, float dt, int isteps,
                                     const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
-                                    const float* wperm, float* parts, bool log, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+                                    const float* wperm, float* parts, bool log, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
+                                    const MppiFuse* fuse = nullptr);   // MPPI mode: the in-launch hand-off (modes 1, 2) when it fits
 size_t ctk_g_rpgd_descent_net_lds(int env, int net, int N, int H);
 size_t ctk_g_rpgd_scratch_floats_net(int net, int N, int H);
 const char* ctk_g_rpgd_descent_net_name(int env, int net, int N, int H);
@@ -230,7 +231,10 @@ int ctk_g_rollout_gru4_blocks(int N);
 const char* ctk_g_rollout_gru4_name(int env, int mode, bool log);
 hipError_t ctk_launch_g_rollout_gru4(hipStream_t st, int env, int mode, const RolloutArgs& a, const float* params, float dt, int isteps,
                                      const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
-                                     const float* wperm, const float* hidden, float* parts, bool log, hipEvent_t e0, hipEvent_t e1);
+                                     const float* wperm, const float* hidden, float* parts, bool log, hipEvent_t e0, hipEvent_t e1,
+                                     const MppiFuse* fuse = nullptr);
+hipError_t ctk_launch_g_gru_advance4(hipStream_t st, int env, const RolloutArgs& a, const float* u_dev, const float* wperm, float* hidden);
+bool ctk_g_rollout_net_fusable(int env, int net, int N, int P, int H);   // may an MPPI step with this network predictor run as ONE launch?
 size_t ctk_g_rpgd_descent_gru4_lds(int H, int C);
 size_t ctk_g_rpgd_scratch_floats_gru4(int N, int H);
 const char* ctk_g_rpgd_descent_gru4_name(int env);

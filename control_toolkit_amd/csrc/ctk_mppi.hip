@@ -29,6 +29,7 @@
 #include "ctk_mlp.h"
 #include "ctk_gru.h"
 #include "ctk_launch.h"
+#include "ctk_mppi_merge.h"
 #include <cstring>
 
 constexpr int MPPI_TRAJ = 64;     // trajectories per block: one wave runs the recurrence
@@ -37,154 +38,6 @@ constexpr int MPPI_BLOCK = MPPI_TRAJ * MPPI_WAVES;
 
 // LDS carve (floats): tile[64][ts] | ubuf[64][us] | corr[4][64] | e[64] | colsum[4][P] | w0,w1,un,i0 [H] each
 __host__ __device__ inline int ubuf_stride(int H) { return (H + 1) | 1; }
-
-// ---------------------------------------------------------------------------------------------
-// merge of partial records {rho, a, b[P]} by one 256-thread block.
-// FINAL=false: writes one merged record to `out_rec`.
-// FINAL=true : applies the MPPI update and publishes u.
-// SC1: the records were handed over inside ONE launch (fused tail below): every load of them is an
-//      agent-scope relaxed atomic load (global_load ... sc1), cdna_hip_programming.md G16.
-// ---------------------------------------------------------------------------------------------
-constexpr int MERGE_BLOCK = 256;
-constexpr int MERGE_CHUNK = 1024;
-
-// LD: 0 plain loads (records written by an earlier launch); 1 agent-scope (handed over inside ONE launch);
-//     2 system-scope (records stored by peer GPUs into this GPU's uncached exchange buffer, ctk_mppi_p2p_exchange)
-template <int LD>
-CTK_DEV float ld_rec(const float* p) {
-    if constexpr (LD == 1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else if constexpr (LD == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    else return *p;
-}
-CTK_DEV void st_rec(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-struct MppiUpdateArgs {
-    // per-step tables already resident in this block's LDS (fused tail) — nullptr: read them from memory
-    // (un_l: the shifted nominal plan [H*C])
-    const float* w0_l = nullptr; const float* w1_l = nullptr; const float* un_l = nullptr; const int* i0_l = nullptr;
-    int H;
-    const InterpEntry* interp;
-    const float* u_nom_in;
-    float* u_nom_out;
-    float lo, hi;          // C == 1
-    float* u_dev;
-    float* u_host;
-    uint32_t seq;
-    int C = 1;             // control inputs: records carry b[P*C], the update runs per channel
-    float lo_c[CTK_MAX_INPUTS] = {}, hi_c[CTK_MAX_INPUTS] = {};   // C > 1
-};
-
-// scratch: >= 8 + (P + 1) + min(cnt, MERGE_CHUNK) floats of LDS, plus cnt*(2+P) more when `stage`
-// (all records fetched into LDS by ONE wide pass: one memory round trip instead of one per record).
-// CH: control inputs of the FINAL update (compile time: the C == 1 instantiations are CartPole's statement sequence, unchanged)
-template <bool FINAL, int SC1, int CH = 1>
-CTK_DEV void mppi_merge_block(float* scratch, const float* base, int cnt, int P, float neg_inv_lbd, float* out_rec,
-                              const MppiUpdateArgs& up, int stage) {
-    float* red = scratch;             // [4] cross-wave scratch
-    float* b_s = scratch + 8;         // [P + 1] merged numerator
-    float* sc_s = b_s + P + 1;        // [chunk] per-record rescale factors
-    float* st_s = sc_s + (cnt < MERGE_CHUNK ? cnt : MERGE_CHUNK);   // [cnt][2+P] staged records
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int rs = 2 + P;
-    if (stage == 1) {
-        const int tot = cnt * rs;
-        for (int i0 = 0; i0 < tot; i0 += 4 * MERGE_BLOCK) {
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = i0 + j * MERGE_BLOCK + t;
-                if (i < tot) v[j] = ld_rec<SC1>(base + i);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = i0 + j * MERGE_BLOCK + t;
-                if (i < tot) st_s[i] = v[j];
-            }
-        }
-        __syncthreads();
-    }
-    auto rec_at = [&](int i, int f) -> float { return stage != 0 ? st_s[i * rs + f] : ld_rec<SC1>(base + (size_t)i * rs + f); };
-
-    float r = INFINITY;
-    for (int i = t; i < cnt; i += MERGE_BLOCK) r = fminf(r, rec_at(i, 0));
-    r = wave_min(r);
-    if (lane == 0) red[wave] = r;
-    __syncthreads();
-    const float rho = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
-    __syncthreads();
-
-    float a_acc = 0.0f;
-    float b_acc[4] = {0.f, 0.f, 0.f, 0.f};   // thread t owns columns t, t+256, ... (P <= 1024)
-    for (int c0 = 0; c0 < cnt; c0 += MERGE_CHUNK) {
-        const int cn = min(MERGE_CHUNK, cnt - c0);
-        for (int i = t; i < cn; i += MERGE_BLOCK) {
-            const float sc = expf(neg_inv_lbd * (rec_at(c0 + i, 0) - rho));   // e^{-(rho_r - rho)/lambda}
-            sc_s[i] = sc;
-            a_acc += rec_at(c0 + i, 1) * sc;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = t + j * MERGE_BLOCK;
-            if (p < P) {
-                float acc = b_acc[j];
-                for (int i = 0; i < cn; ++i) acc += rec_at(c0 + i, 2 + p) * sc_s[i];
-                b_acc[j] = acc;
-            }
-        }
-        __syncthreads();
-    }
-    a_acc = wave_sum(a_acc);
-    if (lane == 0) red[wave] = a_acc;
-    __syncthreads();
-    const float a_tot = red[0] + red[1] + red[2] + red[3];
-
-    if constexpr (!FINAL) {
-        if (t == 0) { out_rec[0] = rho; out_rec[1] = a_tot; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = t + j * MERGE_BLOCK;
-            if (p < P) out_rec[2 + p] = b_acc[j];
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = t + j * MERGE_BLOCK;
-            if (p < P) b_s[p] = b_acc[j];
-        }
-        if (t == 0) b_s[P] = 0.0f;   // pad read by i0+1 when P == 1
-        __syncthreads();
-        if constexpr (CH == 1) {
-            for (int h = t; h < up.H; h += MERGE_BLOCK) {
-                InterpEntry e; float un;
-                if (up.w0_l) { e = InterpEntry{up.i0_l[h], up.w0_l[h], up.w1_l[h]}; un = up.un_l[h]; }
-                else { e = up.interp[h]; un = up.u_nom_in[min(h + 1, up.H - 1)]; }
-                const float w = (b_s[e.i0] * e.w0 + b_s[e.i0 + 1] * e.w1) / a_tot;
-                const float o = fminf(fmaxf(un + w, up.lo), up.hi);   // optimizer_mppi.py:190
-                up.u_nom_out[h] = o;
-                if (h == 0) publish_u(up.u_dev, up.u_host, o, up.seq);   // :191 u = u_nom[0,0,:]
-            }
-        } else {
-            // P here = P*C record columns; inducing point i of channel c is column i*C + c
-            constexpr int C = CH;
-            const int Pp = P / C;
-            float* u_s = scratch;             // red[] is dead: the C outputs of step 0
-            for (int hc = t; hc < up.H * C; hc += MERGE_BLOCK) {
-                const int h = hc / C, c = hc - h * C;
-                InterpEntry e; float un;
-                if (up.w0_l) { e = InterpEntry{up.i0_l[h], up.w0_l[h], up.w1_l[h]}; un = up.un_l[hc]; }
-                else { e = up.interp[h]; un = up.u_nom_in[min(h + 1, up.H - 1) * C + c]; }
-                const int i1 = min(e.i0 + 1, Pp - 1);
-                const float w = (b_s[e.i0 * C + c] * e.w0 + b_s[i1 * C + c] * e.w1) / a_tot;
-                const float o = fminf(fmaxf(un + w, up.lo_c[c]), up.hi_c[c]);   // optimizer_mppi.py:190
-                up.u_nom_out[hc] = o;
-                if (h == 0) u_s[c] = o;
-            }
-            __syncthreads();
-            if (t == 0) publish_u_vec(up.u_dev, up.u_host, u_s, C, up.seq);   // :191 u = u_nom[0,0,:]
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Multi-GPU exchange without a collective library call (xGMI is point-to-point): every rank owns an
@@ -247,16 +100,6 @@ __global__ __launch_bounds__(MERGE_BLOCK) void ctk_mppi_p2p_exchange(P2PArgs x, 
     extern __shared__ float lds[];
     __shared__ int bad;
     p2p_exchange_and_update(lds, &bad, x, P, neg_inv_lbd, up, stage_ok);
-}
-
-// start of the staged records inside the merge scratch (see mppi_merge_block)
-CTK_DEV float* merge_stage_ptr(float* scratch, int cnt, int P) { return scratch + 8 + (P + 1) + (cnt < MERGE_CHUNK ? cnt : MERGE_CHUNK); }
-
-// Low-latency hand-off of a record word: value and the launch's sequence number travel in ONE 8-byte store, so
-// the reader polls the data itself — no "drain my stores, then signal" step and no ticket (cf. RCCL's LL protocol).
-CTK_DEV void ll_store(unsigned long long* p, float v, uint32_t seq) {
-    __hip_atomic_store(p, ((unsigned long long)seq << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // grid.x blocks; block b merges records [b*per_block, ...)
@@ -891,10 +734,6 @@ int ctk_mppi_num_blocks(int N, int pred) {
     return (N + tr - 1) / tr;
 }
 
-static size_t merge_lds(int P, int cnt) { return (size_t)(8 + P + 1 + (cnt < MERGE_CHUNK ? cnt : MERGE_CHUNK)) * sizeof(float); }
-// with all records staged in LDS (used when it stays <= 64 KiB)
-static size_t merge_lds_staged(int P, int cnt) { return merge_lds(P, cnt) + (size_t)cnt * (2 + P) * sizeof(float); }
-static bool merge_can_stage(int P, int cnt) { return merge_lds_staged(P, cnt) <= 64 * 1024; }
 
 // C control inputs (CartPole kernels: 1): P*C sample columns, H*C inputs per trajectory
 size_t ctk_mppi_rollout_lds(int P, int H, int pred, int N, int C) {
