@@ -366,18 +366,18 @@ int ctk_g_rollout_net_cols(int env, int mode, int P, int H) {
 
 // workgroups = block records of one MPPI launch
 int ctk_g_rollout_net_blocks(int env, int net, int mode, int N, int P, int H) {
-    return net == NET_GRU && ctk_g_rollout_gru4_ok(env, N, H, ctk_g_rollout_net_cols(env, mode, P, H)) ? ctk_g_rollout_gru4_blocks(N) : ctk_g_rollout_blocks(N);
+    return ctk_g_rollout_split_ok(env, net, N, H, ctk_g_rollout_net_cols(env, mode, P, H)) ? ctk_g_rollout_split_blocks(N) : ctk_g_rollout_blocks(N);
 }
 
 const char* ctk_g_rollout_net_name(int env, int net, int mode, bool log, int N, int P, int H) {
-    if (net == NET_GRU && ctk_g_rollout_gru4_ok(env, N, H, ctk_g_rollout_net_cols(env, mode, P, H))) return ctk_g_rollout_gru4_name(env, mode, log);
+    if (ctk_g_rollout_split_ok(env, net, N, H, ctk_g_rollout_net_cols(env, mode, P, H))) return ctk_g_rollout_split_name(env, net, mode, log);
     int io = 0;
     CTK_FOR_ENV(env, EV, { io = Env<EV>::S + Env<EV>::C; });
     return ctk_kernel_name("ctk_g_rollout_net<%d, %4$s, %d, %5$s>", env, mode, 0, net == NET_GRU ? "NetGru" : (io > 8 ? "NetMlpT<true>" : "NetMlp"), log ? "true" : "false");
 }
 
 size_t ctk_g_rollout_net_lds(int env, int net, int N, int cols, int H, int C) {
-    if (net == NET_GRU && ctk_g_rollout_gru4_ok(env, N, H, cols)) return ctk_g_rollout_gru4_lds(cols, H, C);
+    if (ctk_g_rollout_split_ok(env, net, N, H, cols)) return ctk_g_rollout_split_lds(net, cols, H, C);
     return ctk_g_rollout_lds(cols, H, C) + net_lds_fwd(net) * sizeof(float);
 }
 
@@ -396,6 +396,8 @@ NetFuse ctk_net_fuse(const MppiFuse* fuse, int mode, const RolloutArgs& a, int C
 // may an MPPI step of this handle run as ONE launch?  (the API asks before it chooses the fuse mode)
 bool ctk_g_rollout_net_fusable(int env, int net, int N, int P, int H) {
     const int blocks = ctk_g_rollout_net_blocks(env, net, CTK_G_MODE_MPPI, N, P, H);
+    // the merge tail is written for 256-thread workgroups: the two-wave MLP form (128 threads) keeps the separate update launch (~1 us)
+    if (net != NET_GRU && ctk_g_rollout_split_ok(env, net, N, H, ctk_g_rollout_net_cols(env, CTK_G_MODE_MPPI, P, H))) return false;
     return blocks <= CTK_MPPI_FUSE_MAX_BLOCKS_LL && merge_can_stage(ctk_g_rollout_net_cols(env, CTK_G_MODE_MPPI, P, H), blocks);
 }
 
@@ -426,8 +428,8 @@ hipError_t ctk_launch_g_rollout_net(hipStream_t st, int env, int net, int mode, 
                                     const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
                                     const float* wperm, float* parts, bool log, hipEvent_t e0, hipEvent_t e1, const MppiFuse* fuse) {
     const float* hidden = wperm + ctk_g_net_table_floats(net);
-    if (net == NET_GRU && ctk_g_rollout_gru4_ok(env, a.N, a.H, ctk_g_rollout_net_cols(env, mode, a.P, a.H)))   // one tile over four waves
-        return ctk_launch_g_rollout_gru4(st, env, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
+    if (ctk_g_rollout_split_ok(env, net, a.N, a.H, ctk_g_rollout_net_cols(env, mode, a.P, a.H)))   // one tile over several waves (ctk_net_split.hip)
+        return ctk_launch_g_rollout_split(st, env, net, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
     CTK_FOR_ENV(env, EV, {
         using MLP = NetMlpT<(Env<EV>::S + Env<EV>::C > 8)>;      // a third layer-1 k-step where the environment has more than 8 network inputs
         if (net == NET_GRU) launch_rollout_net<EV, NetGru>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
@@ -439,17 +441,17 @@ hipError_t ctk_launch_g_rollout_net(hipStream_t st, int env, int net, int mode, 
 size_t ctk_g_rpgd_descent_net_lds(int env, int net, int N, int H) {
     int C = 0;
     CTK_FOR_ENV(env, EV, { C = Env<EV>::C; });
-    if (net == NET_GRU && ctk_g_rpgd_gru4_ok(env, N, H)) return ctk_g_rpgd_descent_gru4_lds(H, C);
+    if (ctk_g_rpgd_split_ok(env, net, N, H)) return ctk_g_rpgd_descent_split_lds(net, H, C);
     return (size_t)(2 * H * C * GN_LD + GN_TRAJ + net_lds_fwd(net) + net_lds_bwd(net)) * sizeof(float);
 }
 
 size_t ctk_g_rpgd_scratch_floats_net(int net, int N, int H) {
     const size_t one_wave = (size_t)((N + GN_TRAJ - 1) / GN_TRAJ) * 4 * H * 64 * (net == NET_GRU ? NetGru::TAPE : NetMlp::TAPE);
-    return net == NET_GRU ? std::max(one_wave, ctk_g_rpgd_scratch_floats_gru4(N, H)) : one_wave;
+    return std::max(one_wave, ctk_g_rpgd_scratch_floats_split(net, N, H));
 }
 
 const char* ctk_g_rpgd_descent_net_name(int env, int net, int N, int H) {
-    if (net == NET_GRU && ctk_g_rpgd_gru4_ok(env, N, H)) return ctk_g_rpgd_descent_gru4_name(env);
+    if (ctk_g_rpgd_split_ok(env, net, N, H)) return ctk_g_rpgd_descent_split_name(env, net);
     int io = 0;
     CTK_FOR_ENV(env, EV, { io = Env<EV>::S + Env<EV>::C; });
     return ctk_kernel_name("ctk_g_rpgd_descent_net<%d, %4$s>", env, 0, 0, net == NET_GRU ? "NetGru" : (io > 8 ? "NetMlpT<true>" : "NetMlp"));
@@ -462,8 +464,8 @@ hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const
     AdamK ad{lr, b1, b2, (float)(1.0 - (double)b1), (float)(1.0 - (double)b2), eps, clip, rule};
     const float* hidden = wperm + ctk_g_net_table_floats(net);
     const float* wb = bwd_table(net, wperm);
-    if (net == NET_GRU && ctk_g_rpgd_gru4_ok(env, a_in.N, a_in.H))      // one tile over four waves while the population leaves SIMDs idle
-        return ctk_launch_g_rpgd_descent_gru4(st, env, a_in, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wb, hidden, scratch, e0, e1);
+    if (ctk_g_rpgd_split_ok(env, net, a_in.N, a_in.H))      // one tile over several waves while the population leaves SIMDs idle (ctk_net_split.hip)
+        return ctk_launch_g_rpgd_descent_split(st, env, net, a_in, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wb, hidden, scratch, e0, e1);
     CTK_FOR_ENV(env, EV, {
         using E = Env<EV>;
         RolloutArgs a = a_in;
@@ -481,8 +483,8 @@ hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const
 
 hipError_t ctk_launch_g_gru_advance(hipStream_t st, int env, const RolloutArgs& a, const float* u_dev, float* wperm) {
     float* hidden = wperm + ctk_g_net_table_floats(NET_GRU);
-    static const bool one_wave = getenv("CTK_GRU_ONE_WAVE") != nullptr;
-    if (!one_wave) return ctk_launch_g_gru_advance4(st, env, a, u_dev, wperm, hidden);      // ctk_gru4.hip: the four-wave step
+    static const bool one_wave = getenv("CTK_NET_ONE_WAVE") != nullptr;
+    if (!one_wave) return ctk_launch_g_gru_advance4(st, env, a, u_dev, wperm, hidden);      // ctk_net_split.hip: the four-wave step
     CTK_FOR_ENV(env, EV, {
         hipLaunchKernelGGL((ctk_g_gru_advance<EV>), dim3(1), dim3(64), NetGru::LDS_FWD * sizeof(float), st, a, u_dev, wperm, hidden);
     });

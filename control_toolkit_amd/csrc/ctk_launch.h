@@ -222,17 +222,25 @@ hipError_t ctk_launch_g_rollout_net(hipStream_t st, int env, int net, int mode, 
 size_t ctk_g_rpgd_descent_net_lds(int env, int net, int N, int H);
 size_t ctk_g_rpgd_scratch_floats_net(int net, int N, int H);
 const char* ctk_g_rpgd_descent_net_name(int env, int net, int N, int H);
-// ctk_gru4.hip: the recurrent predictor with one 16-plan tile spread over the four waves of a workgroup (forward and BPTT)
+// ctk_net_split.hip: the network predictors with one 16-trajectory tile spread over several waves of a workgroup (GRU: four, forward and
+// BPTT; MLP: two), for the populations that leave SIMDs idle with one wave per tile
 struct AdamK;
-bool ctk_g_rpgd_gru4_ok(int env, int N, int H);
-bool ctk_g_rollout_gru4_ok(int env, int N, int H, int cols);
-size_t ctk_g_rollout_gru4_lds(int cols, int H, int C);
-int ctk_g_rollout_gru4_blocks(int N);
-const char* ctk_g_rollout_gru4_name(int env, int mode, bool log);
-hipError_t ctk_launch_g_rollout_gru4(hipStream_t st, int env, int mode, const RolloutArgs& a, const float* params, float dt, int isteps,
-                                     const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
-                                     const float* wperm, const float* hidden, float* parts, bool log, hipEvent_t e0, hipEvent_t e1,
-                                     const MppiFuse* fuse = nullptr);
+bool ctk_g_rpgd_split_ok(int env, int net, int N, int H);
+size_t ctk_g_rpgd_descent_split_lds(int net, int H, int C);
+size_t ctk_g_rpgd_scratch_floats_split(int net, int N, int H);
+const char* ctk_g_rpgd_descent_split_name(int env, int net);
+hipError_t ctk_launch_g_rpgd_descent_split(hipStream_t st, int env, int net, const RolloutArgs& a, const float* params, float dt, int isteps,
+                                           const AdamK& ad, float* Q, float* m, float* v, const float* bc_table, int bc_len, int t0, int iters,
+                                           const float* wperm, const float* wperm_bwd, const float* hidden, float* scratch,
+                                           hipEvent_t e0, hipEvent_t e1);
+bool ctk_g_rollout_split_ok(int env, int net, int N, int H, int cols);
+size_t ctk_g_rollout_split_lds(int net, int cols, int H, int C);
+int ctk_g_rollout_split_blocks(int N);
+const char* ctk_g_rollout_split_name(int env, int net, int mode, bool log);
+hipError_t ctk_launch_g_rollout_split(hipStream_t st, int env, int net, int mode, const RolloutArgs& a, const float* params, float dt, int isteps,
+                                      const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
+                                      const float* wperm, const float* hidden, float* parts, bool log, hipEvent_t e0, hipEvent_t e1,
+                                      const MppiFuse* fuse = nullptr);
 hipError_t ctk_launch_g_gru_advance4(hipStream_t st, int env, const RolloutArgs& a, const float* u_dev, const float* wperm, float* hidden);
 bool ctk_g_rollout_net_fusable(int env, int net, int N, int P, int H);   // may an MPPI step with this network predictor run as ONE launch?
 size_t ctk_g_rpgd_descent_gru4_lds(int H, int C);

@@ -1,24 +1,27 @@
-// ctk_gru4.hip — the recurrent predictor of the template kernels with ONE 16-trajectory tile spread over the FOUR waves (= four SIMDs)
-// of a workgroup, forward AND reverse (back-propagation through time), for any environment with S + C <= 8.
+// ctk_net_split.hip — the network predictors of the template kernels with ONE 16-trajectory MFMA tile spread over SEVERAL waves (= SIMDs)
+// of a workgroup, forward AND reverse, for small populations: the chip has 1 024 SIMDs, an MPC population of 1 024 rollouts is 64
+// tiles, and on gfx950 a wave's fp32 MFMA and VALU time add up — so the step's matrix AND vector work is divided.
 //
-// Why: a GRU step on one wave (ctk_net.h: NetGru) is 164 dependent-ish MFMAs + 48 gate nonlinearities per lane forward and 172 MFMAs +
-// the gate adjoints reverse, every A operand re-read from LDS — 6.3 ms for RPGD at N 256 / H 50 x 10 Adam iterations while 16 waves
-// occupy 16 of the chip's 1 024 SIMDs.  The population is small exactly where the gradient-based optimizers run
-// (optimizer_rpgd.py:306-338 differentiates through whatever predictor it is given), so the step is split instead:
-//
-//   forward  — ctk_gru.h: gru_layer.  Wave (m, q) owns hidden tile m; q = 0: r rows + the input half of the n rows, q = 1: z rows + the
+//   SplitGru   2 x 32 GRU + dense over FOUR waves (S + C <= 8).  One wave per tile (ctk_net.h: NetGru) is 164 dependent-ish MFMAs + 48
+//              gate nonlinearities per lane forward, 172 MFMAs + the gate adjoints reverse, every A operand re-read from LDS: 6.3 ms for
+//              RPGD at N 256 / H 50 x 10 Adam iterations (optimizer_rpgd.py:306-338 differentiates through whatever predictor it gets).
+//     forward  ctk_gru.h: gru_layer.  Wave (m, q) owns hidden tile m; q = 0: r rows + the input half of the n rows, q = 1: z rows + the
 //              recurrent half; 18 + 24 + 8 MFMAs per wave and step, operands in registers, two LDS exchanges per layer.  Each wave turns
 //              TWO of a lane's four units of tile m into gates (registers 2q, 2q+1) and tapes exactly those (GruPairTape).
-//   reverse  — the same ownership: wave (m, q) forms the gate adjoints of ITS two units element-wise from its own tape, and those are
+//     reverse  the same ownership: wave (m, q) forms the gate adjoints of ITS two units element-wise from its own tape, and those are
 //              k-steps (gate G, tile m, register 2q+i) of the transposed products W_i^T dgi, W_h^T dgh (ctk_net.h: layer_products) — the
 //              contraction over the 96 gate neurons is split four ways, every wave accumulates partial tiles of ALL outputs (2 + 24 + 18
 //              MFMAs per step), and the partial sums meet through LDS once per layer: two barriers per reverse step.
-//   the cost — nothing of it rides on the recurrence: the forward pass leaves the states in LDS, and the stage / terminal cost, their
-//              state gradients and the input-only gradient terms are evaluated afterwards by all 256 threads over (step, plan) pairs.
+//   SplitMlp   (S+C)-32-32-S tanh MLP over TWO waves (any environment; K3: a third layer-1 k-step where S + C > 8).  Wave m owns hidden
+//              units 16m .. 16m+15 of both layers (ctk_mlp.h: mlp_step_pair is CartPole's thin-layer version of this): forward 2-3 + 8 + 4
+//              MFMAs and 8 tanh per wave (one wave: 28-30 and 16), h1 halves and partial outputs meet through LDS; reverse 2 + 8 + 4:
+//              W2^T and W1^T contract over the wave's OWN hidden units, partial tiles meet through LDS — two barriers each way.
+//   the cost   nothing of it rides on the recurrence: the forward pass leaves the states in LDS, and the stage / terminal cost, their
+//              state gradients, the inputs (interpolation, clip, MPPI correction) and the input-only gradient terms are evaluated
+//              before / after it by all threads over (step, trajectory) pairs.
 //
-// Tables: the per-lane operand tables of NetGru as they are (ctk_net.h: GRUG_FWD / GRUG_BWD entry-major layouts); a wave picks its own
-// entries once per launch.  Tape: 5 float4 per lane, wave and step in the L2-resident scratch (20 KiB per workgroup-step), read back
-// one step ahead of its use.
+// Tables: the per-lane operand tables of NetGru / NetMlp as they are (ctk_net.h, ctk_mlp.h); a wave picks its own entries once per
+// launch into registers.  Tape: TAPE_F4 float4 per lane, wave and step in the L2-resident scratch, read back one step ahead of its use.
 #include "ctk_rollout.h"
 #include "ctk_env.h"
 #include "ctk_gru.h"
@@ -30,12 +33,14 @@
 
 NetFuse ctk_net_fuse(const MppiFuse* fuse, int mode, const RolloutArgs& a, int C, const float* u_nom, int blocks, int cols);   // ctk_generic_net.hip
 
-constexpr int G4_TRAJ = 16, G4_BLOCK = 256, G4_LD = G4_TRAJ + 1;
+constexpr int G4_TRAJ = 16, G4_LD = G4_TRAJ + 1;
 constexpr int G4_TAPE_F4 = 5;                       // float4 per lane, wave and step
 constexpr int G4_EX_FWD = GRU_EX_FLOATS;            // 3072: gru_layer's exchange slots
 constexpr int G4_EX_A = 4 * 4 * 64 * 4;             // reverse, layer 2: [4 waves][dx0 dx1 dhp0 dhp1][64] float4
 constexpr int G4_EX_B = 4 * 3 * 64 * 4;             // reverse, layer 1: [4 waves][din dhp0 dhp1][64] float4
 constexpr int G4_RED = 4 * 16 + 16;
+constexpr int M2_EX_FWD = 2 * 64 * 4 + 2 * 64 * 2;   // SplitMlp forward: [2 waves][64] float4 h1 halves + [2][64] float2 partial outputs
+constexpr int M2_EX_BWD = 2 * 64 * 4 + 2 * 64 * 4;   // SplitMlp reverse: [2][64] float4 W2^T partials + [2][64] float4 W1^T partials
 
 // ---- operands ---------------------------------------------------------------------------------------------------------------------
 // forward operands of wave (m, q) in GruW's order (ctk_gru.h) from the generic table (ctk_net.h: per layer Wi[gate][m][ks], Wh[gate][m][j],
@@ -210,53 +215,187 @@ CTK_DEV MlpPair gru4_vjp(const Gru4BwdW& w, Gru4Adj& ad, const float4 (&tp)[G4_T
     return MlpPair{lo, hi};
 }
 
-// network operands of a step from the (component g, component 4+g) state layout and the step's inputs
+// network operands of a step (inputs g, 4+g, 8+g) from the (component g, component 4+g) state layout and the step's inputs
 template <int S, int C>
-CTK_DEV void gru4_operands(float sv0, float sv1, const float (&u)[C], int g, float& x0, float& x1) {
+CTK_DEV void split_operands(float sv0, float sv1, const float (&u)[C], int g, float& x0, float& x1, float& x2) {
     x0 = (g < S) ? sv0 : 0.0f;
     x1 = (4 + g < S) ? sv1 : 0.0f;
+    x2 = 0.0f;
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
         x0 = (g == S + cc) ? u[cc] : x0;
         x1 = (4 + g == S + cc) ? u[cc] : x1;
+        x2 = (8 + g == S + cc) ? u[cc] : x2;
     }
 }
 
+// ---- the split policies: WAVES per tile; Fwd {load, begin, step<TAPE>} / Bwd {load, begin, vjp}; exchange slots in floats ----------------
+struct SplitGru {
+    static constexpr int WAVES = 4, TAPE_F4 = G4_TAPE_F4, EX_FWD = G4_EX_FWD, EX_BWD = G4_EX_A + G4_EX_B, NET = NET_GRU;
+    struct Fwd {
+        GruW w;
+        GruState st;
+        CTK_DEV void load(const float* __restrict__ tab, int wave, int lane) { w = gru4_load_fwd(tab, wave >> 1, wave & 1, lane); }
+        CTK_DEV void begin(const float* __restrict__ hidden, int g) { st = gru_load_state(hidden, g); }
+        // tq: this wave's tape of the step (+ i * 64 per float4), used when TAPE
+        template <bool TAPE>
+        CTK_DEV MlpPair step(float x0, float x1, float, float* ex, int wave, int lane, float4* tq) {
+            GruPairTape t1, t2;
+            const MlpPair o = gru4_step(w, st, x0, x1, ex, wave, lane, TAPE ? &t1 : nullptr, TAPE ? &t2 : nullptr);
+            if constexpr (TAPE) {
+                tq[0 * 64] = make_float4(t1.r[0], t1.r[1], t1.z[0], t1.z[1]);
+                tq[1 * 64] = make_float4(t1.n[0], t1.n[1], t1.ghn[0], t1.ghn[1]);
+                tq[2 * 64] = make_float4(t1.hp[0], t1.hp[1], t2.hp[0], t2.hp[1]);
+                tq[3 * 64] = make_float4(t2.r[0], t2.r[1], t2.z[0], t2.z[1]);
+                tq[4 * 64] = make_float4(t2.n[0], t2.n[1], t2.ghn[0], t2.ghn[1]);
+            }
+            return o;
+        }
+    };
+    struct Bwd {
+        Gru4BwdW w;
+        Gru4Adj adj;
+        CTK_DEV void load(const float* __restrict__ tab, int wave, int lane) { w = gru4_load_bwd(tab, wave >> 1, wave & 1, lane); }
+        CTK_DEV void begin() { adj = Gru4Adj{{0.f, 0.f}, {0.f, 0.f}}; }
+        CTK_DEV MlpPair vjp(const float4 (&tp)[TAPE_F4], float lam0, float lam1, float* ex, int wave, int lane) {
+            return gru4_vjp(w, adj, tp, lam0, lam1, ex, ex + G4_EX_A, wave, lane);
+        }
+    };
+};
+
+template <bool K3>
+struct SplitMlp {
+    static constexpr int WAVES = 2, TAPE_F4 = 2, EX_FWD = M2_EX_FWD, EX_BWD = M2_EX_BWD, NET = NET_MLP;
+    struct Fwd {
+        float w1[3], w2o[4], w2x[4], w3[4];     // own row tile m: layer 1 k-steps; layer 2 k-steps of the OWN / the OTHER wave's units; layer 3 k-steps of the own units
+        f32x4 b1, b2;
+        float b3lo, b3hi;
+        CTK_DEV void load(const float* __restrict__ tab, int m, int) {
+            const MlpFwdW f = mlp_load_fwd(tab);
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) w1[ks] = m ? f.w1[1][ks] : f.w1[0][ks];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                w2o[j] = m ? f.w2[1][4 + j] : f.w2[0][j];
+                w2x[j] = m ? f.w2[1][j] : f.w2[0][4 + j];
+                w3[j] = m ? f.w3[4 + j] : f.w3[j];
+            }
+            b1 = m ? f.b1[1] : f.b1[0]; b2 = m ? f.b2[1] : f.b2[0];
+            b3lo = f.b3[0]; b3hi = f.b3[1];
+        }
+        CTK_DEV void begin(const float*, int) {}
+        template <bool TAPE>
+        CTK_DEV MlpPair step(float x0, float x1, float x2, float* ex, int m, int lane, float4* tq) {
+            float4* ex_h = reinterpret_cast<float4*>(ex);                  // [2][64]
+            float2* ex_o = reinterpret_cast<float2*>(ex + 2 * 64 * 4);     // [2][64]
+            f32x4 a = CTK_MFMA(w1[0], x0, b1);
+            a = CTK_MFMA(w1[1], x1, a);
+            if constexpr (K3) a = CTK_MFMA(w1[2], x2, a);
+            const f32x4 h1m = ctk_tanhf4(a);
+            ex_h[m * 64 + lane] = st4(h1m);
+            __syncthreads();
+            f32x4 c = b2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c = CTK_MFMA(w2o[j], h1m[j], c);   // own half first: the other one is still arriving
+            const f32x4 h1x = ld4(ex_h + (m ^ 1) * 64 + lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c = CTK_MFMA(w2x[j], h1x[j], c);
+            const f32x4 h2m = ctk_tanhf4(c);
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 p0 = CTK_MFMA(w3[0], h2m[0], z), p1 = CTK_MFMA(w3[1], h2m[1], z);
+            p0 = CTK_MFMA(w3[2], h2m[2], p0);
+            p1 = CTK_MFMA(w3[3], h2m[3], p1);
+            const float mylo = p0[0] + p1[0], myhi = p0[1] + p1[1];
+            ex_o[m * 64 + lane] = make_float2(mylo, myhi);
+            if constexpr (TAPE) { tq[0] = st4(h1m); tq[64] = st4(h2m); }
+            __syncthreads();
+            const float2 o = ex_o[(m ^ 1) * 64 + lane];
+            // the same association in both waves: (units 0..15) + (units 16..31) + bias
+            return MlpPair{(m == 0 ? mylo + o.x : o.x + mylo) + b3lo, (m == 0 ? myhi + o.y : o.y + myhi) + b3hi};
+        }
+    };
+    struct Bwd {
+        float w3t[2], w2t[2][4], w1t[4];        // own hidden tile m: W3^T k-steps (outputs g, 4+g); W2^T [input tile][own k-steps]; W1^T own k-steps
+        CTK_DEV void load(const float* __restrict__ tab, int m, int) {
+            const MlpBwdW2 b = mlp_load_bwd2(tab);
+            w3t[0] = m ? b.w3t[1][0] : b.w3t[0][0]; w3t[1] = m ? b.w3t[1][1] : b.w3t[0][1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                w2t[0][j] = m ? b.w2t[0][4 + j] : b.w2t[0][j];
+                w2t[1][j] = m ? b.w2t[1][4 + j] : b.w2t[1][j];
+                w1t[j] = m ? b.w1t[4 + j] : b.w1t[j];
+            }
+        }
+        CTK_DEV void begin() {}
+        // tp: (h1 half, h2 half) of this wave.  Returns the adjoints of network inputs g, 4+g, 8+g — identical in both waves
+        CTK_DEV MlpPair vjp(const float4 (&tp)[TAPE_F4], float lam0, float lam1, float* ex, int m, int lane) {
+            float4* exA = reinterpret_cast<float4*>(ex);                   // [2][64]
+            float4* exB = exA + 2 * 64;                                    // [2][64]
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 h1m = ld4(&tp[0]), h2m = ld4(&tp[1]);
+            f32x4 t = CTK_MFMA(w3t[0], lam0, z);
+            t = CTK_MFMA(w3t[1], lam1, t);
+            f32x4 s0 = z, s1 = z;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d2 = t[r] * (1.0f - h2m[r] * h2m[r]);
+                s0 = CTK_MFMA(w2t[0][r], d2, s0);
+                s1 = CTK_MFMA(w2t[1][r], d2, s1);
+            }
+            exA[m * 64 + lane] = st4(m ? s0 : s1);                          // the OTHER wave's tile
+            __syncthreads();
+            const f32x4 so = ld4(exA + (m ^ 1) * 64 + lane), sm = m ? s1 : s0;
+            f32x4 o0 = z, o1 = z;
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                const float da = (sm[r] + so[r]) * (1.0f - h1m[r] * h1m[r]), db = (sm[r + 1] + so[r + 1]) * (1.0f - h1m[r + 1] * h1m[r + 1]);
+                o0 = CTK_MFMA(w1t[r], da, o0);
+                o1 = CTK_MFMA(w1t[r + 1], db, o1);
+            }
+            const f32x4 mine = o0 + o1;
+            exB[m * 64 + lane] = st4(mine);
+            __syncthreads();
+            const f32x4 oth = ld4(exB + (m ^ 1) * 64 + lane);
+            return m == 0 ? MlpPair{mine[0] + oth[0], mine[1] + oth[1], mine[2] + oth[2]} : MlpPair{oth[0] + mine[0], oth[1] + mine[1], oth[2] + mine[2]};
+        }
+    };
+};
+
 // ---- RPGD descent ----------------------------------------------------------------------------------------------------------------
 // LDS: exchange slots | states xs[H+1][64][2] | cost-gradient terms gs[H+1][64][2] | plans q[HC][17] | gradients g[HC][17] | reductions
-template <int ENV>
-__global__ __launch_bounds__(G4_BLOCK) void ctk_g_rpgd_descent_gru4(RolloutArgs a, typename Env<ENV>::K k, AdamK ad, float* __restrict__ Q,
+template <int ENV, class SP>
+__global__ __launch_bounds__(64 * SP::WAVES) void ctk_g_rpgd_descent_split(RolloutArgs a, typename Env<ENV>::K k, AdamK ad, float* __restrict__ Q,
                                                                    float* __restrict__ mom, float* __restrict__ var,
                                                                    const float* __restrict__ bc_table, int bc_len, int t0, int iters,
                                                                    const float* __restrict__ wperm, const float* __restrict__ wperm_bwd,
                                                                    const float* __restrict__ hidden, float* __restrict__ scratch) {
     using E = Env<ENV>;
-    constexpr int S = E::S, C = E::C;
-    static_assert(S + C <= 8, "the GRU's input tile holds 8 columns");
+    constexpr int S = E::S, C = E::C, WAVES = SP::WAVES, BLOCK = 64 * WAVES, NPARTS = BLOCK / G4_TRAJ, TAPE_F4 = SP::TAPE_F4;
     extern __shared__ float lds[];
     const int H = a.H, HC = H * C;
     float* ex = lds;
-    float* exA = ex + G4_EX_FWD;
-    float* exB = exA + G4_EX_A;
-    float* red_s = exB + G4_EX_B;
+    float* exR = ex + SP::EX_FWD;
+    float* red_s = exR + SP::EX_BWD;
     float* xs_s = red_s + G4_RED;
     float* gs_s = xs_s + (H + 1) * 128;
     float* q_s = gs_s + (H + 1) * 128;
     float* g_s = q_s + HC * G4_LD;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 15, g = lane >> 4, m = wave >> 1, q = wave & 1;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 15, g = lane >> 4;
     const int row0 = blockIdx.x * G4_TRAJ;
     const int rows = min(G4_TRAJ, a.N - row0);
     const int total = rows * HC;
     const size_t gbase = (size_t)row0 * HC;
-    float4* tape = reinterpret_cast<float4*>(scratch) + ((size_t)blockIdx.x * H * 4 + wave) * G4_TAPE_F4 * 64 + lane;   // + h * 4 * 5 * 64 + i * 64
-    const size_t tape_step = (size_t)4 * G4_TAPE_F4 * 64;
+    float4* tape = reinterpret_cast<float4*>(scratch) + ((size_t)blockIdx.x * H * WAVES + wave) * TAPE_F4 * 64 + lane;   // + h * tape_step + i * 64
+    const size_t tape_step = (size_t)WAVES * TAPE_F4 * 64;
 
-    for (int i = t; i < G4_TRAJ * HC; i += G4_BLOCK) {
+    for (int i = t; i < G4_TRAJ * HC; i += BLOCK) {
         const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, hc = i - r * HC;
         q_s[hc * G4_LD + r] = i < total ? Q[gbase + i] : 0.0f;
     }
-    const GruW wf = gru4_load_fwd(wperm, m, q, lane);
-    const Gru4BwdW wb = gru4_load_bwd(wperm_bwd, m, q, lane);
+    typename SP::Fwd nf;
+    typename SP::Bwd nb;
+    nf.load(wperm, wave, lane);
+    nb.load(wperm_bwd, wave, lane);
     float up0[C];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) up0[cc] = a.u_prev_dev ? a.u_prev_dev[cc] : a.u_prev[cc];
@@ -267,25 +406,16 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rpgd_descent_gru4(RolloutArgs 
 
     auto forward = [&](auto taping) {
         constexpr bool TAPE = decltype(taping)::value;
-        GruState st = gru_load_state(hidden, g);
+        nf.begin(hidden, g);
         float sv0 = s00, sv1 = s01;
         for (int h = 0; h < H; ++h) {
             float u[C];
 #pragma unroll
             for (int cc = 0; cc < C; ++cc) u[cc] = q_s[(h * C + cc) * G4_LD + c];
-            if (wave == (h & 3)) reinterpret_cast<float2*>(xs_s)[h * 64 + lane] = make_float2(sv0, sv1);
-            float x0, x1;
-            gru4_operands<S, C>(sv0, sv1, u, g, x0, x1);
-            GruPairTape t1, t2;
-            const MlpPair o = gru4_step(wf, st, x0, x1, ex, wave, lane, TAPE ? &t1 : nullptr, TAPE ? &t2 : nullptr);
-            if constexpr (TAPE) {
-                float4* tq = tape + (size_t)h * tape_step;
-                tq[0 * 64] = make_float4(t1.r[0], t1.r[1], t1.z[0], t1.z[1]);
-                tq[1 * 64] = make_float4(t1.n[0], t1.n[1], t1.ghn[0], t1.ghn[1]);
-                tq[2 * 64] = make_float4(t1.hp[0], t1.hp[1], t2.hp[0], t2.hp[1]);
-                tq[3 * 64] = make_float4(t2.r[0], t2.r[1], t2.z[0], t2.z[1]);
-                tq[4 * 64] = make_float4(t2.n[0], t2.n[1], t2.ghn[0], t2.ghn[1]);
-            }
+            if (wave == (h & (WAVES - 1))) reinterpret_cast<float2*>(xs_s)[h * 64 + lane] = make_float2(sv0, sv1);
+            float x0, x1, x2;
+            split_operands<S, C>(sv0, sv1, u, g, x0, x1, x2);
+            const MlpPair o = nf.template step<TAPE>(x0, x1, x2, ex, wave, lane, tape + (size_t)h * tape_step);
             sv0 = o.lo; sv1 = o.hi;
         }
         if (wave == 0) reinterpret_cast<float2*>(xs_s)[H * 64 + lane] = make_float2(sv0, sv1);
@@ -295,12 +425,13 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rpgd_descent_gru4(RolloutArgs 
 #pragma unroll
         for (int j = 0; j < S; ++j) s[j] = xs_s[(h * 64 + (j & 3) * 16 + p) * 2 + (j >> 2)];
     };
-    // sum over the 16 parts of a plan, in a fixed order; valid in every thread
+    // sum over the NPARTS parts of a plan, in a fixed order; valid in every thread
     auto sum_parts = [&](float v) {
         v = sum_over_groups(v);
         if (g == 0) red_s[wave * 16 + c] = v;
         __syncthreads();
-        const float r = (red_s[c] + red_s[16 + c]) + (red_s[32 + c] + red_s[48 + c]);
+        float r = red_s[c] + red_s[16 + c];
+        if constexpr (WAVES == 4) r += red_s[32 + c] + red_s[48 + c];
         __syncthreads();
         return r;
     };
@@ -308,7 +439,7 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rpgd_descent_gru4(RolloutArgs 
     for (int it = 0; it < iters; ++it) {
         forward(std::true_type{});
         // ---- everything of the gradient that does not ride on the adjoint chain, over (step, plan) pairs
-        for (int idx = t; idx < (H + 1) * G4_TRAJ; idx += G4_BLOCK) {
+        for (int idx = t; idx < (H + 1) * G4_TRAJ; idx += BLOCK) {
             const int h = idx >> 4, p = idx & 15;
             float s[S], gs[S];
             state_of(h, p, s);
@@ -334,25 +465,25 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rpgd_descent_gru4(RolloutArgs 
         // ---- reverse sweep
         {
             float2 lam = reinterpret_cast<const float2*>(gs_s)[H * 64 + lane];
-            Gru4Adj adj{{0.f, 0.f}, {0.f, 0.f}};
-            float4 nxt[G4_TAPE_F4];
+            nb.begin();
+            float4 nxt[TAPE_F4];
 #pragma unroll
-            for (int i = 0; i < G4_TAPE_F4; ++i) nxt[i] = tape[(size_t)(H - 1) * tape_step + i * 64];
+            for (int i = 0; i < TAPE_F4; ++i) nxt[i] = tape[(size_t)(H - 1) * tape_step + i * 64];
             for (int h = H - 1; h >= 0; --h) {
-                float4 cur[G4_TAPE_F4];
+                float4 cur[TAPE_F4];
 #pragma unroll
-                for (int i = 0; i < G4_TAPE_F4; ++i) cur[i] = nxt[i];
+                for (int i = 0; i < TAPE_F4; ++i) cur[i] = nxt[i];
                 if (h > 0) {
 #pragma unroll
-                    for (int i = 0; i < G4_TAPE_F4; ++i) nxt[i] = tape[(size_t)(h - 1) * tape_step + i * 64];
+                    for (int i = 0; i < TAPE_F4; ++i) nxt[i] = tape[(size_t)(h - 1) * tape_step + i * 64];
                 }
-                const MlpPair d = gru4_vjp(wb, adj, cur, lam.x, lam.y, exA, exB, wave, lane);
+                const MlpPair d = nb.vjp(cur, lam.x, lam.y, exR, wave, lane);
                 const float2 gsv = reinterpret_cast<const float2*>(gs_s)[h * 64 + lane];
                 if (wave == 0) {
 #pragma unroll
                     for (int cc = 0; cc < C; ++cc) {
                         const int kk = S + cc;                         // network input index of control input cc
-                        if (g == (kk & 3)) g_s[(h * C + cc) * G4_LD + c] += (kk >= 4 ? d.hi : d.lo);
+                        if (g == (kk & 3)) g_s[(h * C + cc) * G4_LD + c] += (kk >= 8 ? d.ex : (kk >= 4 ? d.hi : d.lo));
                     }
                 }
                 lam.x = gsv.x + (g < S ? d.lo : 0.0f);
@@ -362,7 +493,7 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rpgd_descent_gru4(RolloutArgs 
         __syncthreads();
         // ---- per-plan clip_by_norm, Adam, clip
         float n2 = 0.0f;
-        for (int hc = part; hc < HC; hc += 16) { const float x = g_s[hc * G4_LD + pc]; n2 += x * x; }
+        for (int hc = part; hc < HC; hc += NPARTS) { const float x = g_s[hc * G4_LD + pc]; n2 += x * x; }
         n2 = sum_parts(n2);
         const float scl = ad.clip / fmaxf(sqrtf(n2), ad.clip);       // of plan pc = c
         if (wave == 0 && g == 0) red_s[64 + c] = scl;
@@ -370,7 +501,7 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rpgd_descent_gru4(RolloutArgs 
         const int ti = t0 + it + 1;
         const float bc1 = ti <= bc_len ? bc_table[2 * (ti - 1)] : 1.0f;
         const float bc2 = ti <= bc_len ? bc_table[2 * (ti - 1) + 1] : 1.0f;
-        for (int i = t; i < total; i += G4_BLOCK) {
+        for (int i = t; i < total; i += BLOCK) {
             const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, hc = i - r * HC, cc = hc % C;
             float mm = 0.0f, vv = 0.0f;
             if (ad.rule != 2) { mm = mom[gbase + i]; vv = var[gbase + i]; }
@@ -383,7 +514,7 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rpgd_descent_gru4(RolloutArgs 
     // ---- get_action's forward pass (optimizer_rpgd.py:342): costs of the refined plans
     forward(std::false_type{});
     float cs = 0.0f;
-    for (int h = part; h < H; h += 16) {
+    for (int h = part; h < H; h += NPARTS) {
         float s[S], u[C], upv[C];
         state_of(h, pc, s);
 #pragma unroll
@@ -400,7 +531,7 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rpgd_descent_gru4(RolloutArgs 
     }
     cs = sum_parts(cs);
     if (wave == 0 && g == 0 && row0 + c < a.N) a.J[row0 + c] = cs * inv;
-    for (int i = t; i < total; i += G4_BLOCK) {
+    for (int i = t; i < total; i += BLOCK) {
         const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, hc = i - r * HC;
         Q[gbase + i] = q_s[hc * G4_LD + r];
     }
@@ -410,18 +541,18 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rpgd_descent_gru4(RolloutArgs 
 // 16 trajectories per workgroup.  Inputs (interpolation, shifted nominal, clip, MPPI correction) are formed for all (step, trajectory)
 // pairs before the recurrence, the costs from the states it leaves in LDS after it; the recurrence itself is gru4_step only.
 // LDS: exchange slots | reductions | states xs[H+1][64][2] | inputs u[HC][17] | sample tile [16][ts] | e[16] | base, scale [HC] | interp tables
-template <int ENV, int MODE, bool LOG>
-__global__ __launch_bounds__(G4_BLOCK) void ctk_g_rollout_gru4(RolloutArgs a, typename Env<ENV>::K k, MppiK mk, const float* __restrict__ samples,
+// (the Philox path of load_tile_early spreads a row's column blocks over BLOCK / 16 threads)
+template <int ENV, class SP, int MODE, bool LOG>
+__global__ __launch_bounds__(64 * SP::WAVES) void ctk_g_rollout_split(RolloutArgs a, typename Env<ENV>::K k, MppiK mk, const float* __restrict__ samples,
                                                               const float* __restrict__ base, const float* __restrict__ scale, int rng_kind,
                                                               const float* __restrict__ wperm, const float* __restrict__ hidden,
                                                               float* __restrict__ parts, NetFuse gz) {
     using E = Env<ENV>;
-    constexpr int S = E::S, C = E::C;
-    static_assert(S + C <= 8, "the GRU's input tile holds 8 columns");
+    constexpr int S = E::S, C = E::C, WAVES = SP::WAVES, BLOCK = 64 * WAVES, NPARTS = BLOCK / G4_TRAJ;
     extern __shared__ float lds[];
     const int H = a.H, HC = H * C, cols = a.P, ts = tile_stride(cols);
     float* ex = lds;
-    float* red_s = ex + G4_EX_FWD;
+    float* red_s = ex + SP::EX_FWD;
     float* xs_s = red_s + G4_RED;
     float* u_s = xs_s + (H + 1) * 128;
     float* tile = u_s + HC * G4_LD;
@@ -437,19 +568,20 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rollout_gru4(RolloutArgs a, ty
     const int n = row0 + pc;
     const bool valid = n < a.N;
 
-    const GruW wf = gru4_load_fwd(wperm, wave >> 1, wave & 1, lane);
-    load_tile_early<G4_TRAJ, G4_BLOCK>(tile, samples, a, row0, MODE == CTK_G_MODE_MPPI ? mk.stdev : 1.0f, rng_kind, [&] {
+    typename SP::Fwd nf;
+    nf.load(wperm, wave, lane);
+    load_tile_early<G4_TRAJ, BLOCK>(tile, samples, a, row0, MODE == CTK_G_MODE_MPPI ? mk.stdev : 1.0f, rng_kind, [&] {
         if constexpr (MODE == CTK_G_MODE_MPPI) {
-            for (int h = t; h < H; h += G4_BLOCK) {
+            for (int h = t; h < H; h += BLOCK) {
                 const InterpEntry e = a.interp[h];
                 i0_s[h] = e.i0; w0_s[h] = e.w0; w1_s[h] = e.w1;
             }
-            for (int hc = t; hc < HC; hc += G4_BLOCK) {
+            for (int hc = t; hc < HC; hc += BLOCK) {
                 const int h = hc / C, cc = hc - h * C;
                 base_s[hc] = base[min(h + 1, H - 1) * C + cc];
             }
         } else {
-            for (int hc = t; hc < HC; hc += G4_BLOCK) { base_s[hc] = base[hc]; scale_s[hc] = scale[hc]; }
+            for (int hc = t; hc < HC; hc += BLOCK) { base_s[hc] = base[hc]; scale_s[hc] = scale[hc]; }
         }
     });
     float up0[C];
@@ -462,7 +594,8 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rollout_gru4(RolloutArgs a, ty
         v = sum_over_groups(v);
         if (g == 0) red_s[wave * 16 + c] = v;
         __syncthreads();
-        const float r = (red_s[c] + red_s[16 + c]) + (red_s[32 + c] + red_s[48 + c]);
+        float r = red_s[c] + red_s[16 + c];
+        if constexpr (WAVES == 4) r += red_s[32 + c] + red_s[48 + c];
         __syncthreads();
         return r;
     };
@@ -472,7 +605,7 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rollout_gru4(RolloutArgs a, ty
     {
         const float* my = tile + pc * ts;
         const int Pm1 = cols / C - 1;
-        for (int h = part; h < H; h += 16) {
+        for (int h = part; h < H; h += NPARTS) {
 #pragma unroll
             for (int cc = 0; cc < C; ++cc) {
                 float u;
@@ -495,16 +628,16 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rollout_gru4(RolloutArgs a, ty
     }
     // ---- the recurrence
     {
-        GruState st = gru_load_state(hidden, g);
+        nf.begin(hidden, g);
         float sv0 = s00, sv1 = s01;
         for (int h = 0; h < H; ++h) {
             float u[C];
 #pragma unroll
             for (int cc = 0; cc < C; ++cc) u[cc] = u_s[(h * C + cc) * G4_LD + c];
-            if (wave == (h & 3)) reinterpret_cast<float2*>(xs_s)[h * 64 + lane] = make_float2(sv0, sv1);
-            float x0, x1;
-            gru4_operands<S, C>(sv0, sv1, u, g, x0, x1);
-            const MlpPair o = gru4_step(wf, st, x0, x1, ex, wave, lane, nullptr, nullptr);
+            if (wave == (h & (WAVES - 1))) reinterpret_cast<float2*>(xs_s)[h * 64 + lane] = make_float2(sv0, sv1);
+            float x0, x1, x2;
+            split_operands<S, C>(sv0, sv1, u, g, x0, x1, x2);
+            const MlpPair o = nf.template step<false>(x0, x1, x2, ex, wave, lane, nullptr);
             sv0 = o.lo; sv1 = o.hi;
         }
         if (wave == 0) reinterpret_cast<float2*>(xs_s)[H * 64 + lane] = make_float2(sv0, sv1);
@@ -512,7 +645,7 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rollout_gru4(RolloutArgs a, ty
     }
     // ---- costs from the states
     float cs = 0.0f;
-    for (int h = part; h <= H; h += 16) {
+    for (int h = part; h <= H; h += NPARTS) {
         float s[S];
 #pragma unroll
         for (int j = 0; j < S; ++j) s[j] = xs_s[(h * 64 + (j & 3) * 16 + pc) * 2 + (j >> 2)];
@@ -555,7 +688,7 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rollout_gru4(RolloutArgs a, ty
             if (use_ll) { ll_store(llr, rho, gz.up.seq); ll_store(llr + 1, aw, gz.up.seq); }
             else { rec[0] = rho; rec[1] = aw; }
         }
-        for (int p = t; p < cols; p += G4_BLOCK) {
+        for (int p = t; p < cols; p += BLOCK) {
             float acc = 0.0f;
 #pragma unroll
             for (int r = 0; r < G4_TRAJ; ++r) acc += e_s[r] * tile[r * ts + p];
@@ -573,7 +706,7 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_rollout_gru4(RolloutArgs a, ty
 // input — one workgroup, the same four-wave step (all 16 MFMA columns carry the same values; column 0 writes back), operands straight
 // from the tables into registers (the one-wave form stages 59 KiB in LDS with 64 threads: 27 us behind every MPPI step)
 template <int ENV>
-__global__ __launch_bounds__(G4_BLOCK) void ctk_g_gru_advance4(RolloutArgs a, const float* __restrict__ u_dev, const float* __restrict__ wperm,
+__global__ __launch_bounds__(256) void ctk_g_gru_advance4(RolloutArgs a, const float* __restrict__ u_dev, const float* __restrict__ wperm,
                                                               float* __restrict__ hidden) {
     using E = Env<ENV>;
     constexpr int S = E::S, C = E::C;
@@ -586,8 +719,8 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_gru_advance4(RolloutArgs a, co
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) u[cc] = u_dev ? u_dev[cc] : a.u_prev[cc];
     const float sv0 = g < S ? lane_state4(a, g) : 0.0f, sv1 = 4 + g < S ? lane_state4(a, g, 4) : 0.0f;
-    float x0, x1;
-    gru4_operands<S, C>(sv0, sv1, u, g, x0, x1);
+    float x0, x1, x2;
+    split_operands<S, C>(sv0, sv1, u, g, x0, x1, x2);
     (void)gru4_step(wf, st, x0, x1, ex, wave, lane, nullptr, nullptr);      // its barriers order every lane's read of `hidden` before the write below
     if (wave == 0 && c == 0) {
 #pragma unroll
@@ -599,82 +732,113 @@ __global__ __launch_bounds__(G4_BLOCK) void ctk_g_gru_advance4(RolloutArgs a, co
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
 static uint32_t g4_magic_of(int d) { return d >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d) : 0u; }
-
-size_t ctk_g_rpgd_descent_gru4_lds(int H, int C) {
-    return (size_t)(G4_EX_FWD + G4_EX_A + G4_EX_B + G4_RED + 2 * (H + 1) * 128 + 2 * H * C * G4_LD) * sizeof(float);
-}
-
-// the four-wave form: while a 16-plan workgroup per tile still leaves SIMDs idle (<= 256 CUs x 2 workgroups) and its LDS fits
-bool ctk_g_rpgd_gru4_ok(int env, int N, int H) {
-    static const bool off = getenv("CTK_RPGD_GRU_ONE_WAVE") != nullptr;      // diagnostic switch (A/B measurements)
+static int split_waves(int net) { return net == NET_GRU ? SplitGru::WAVES : SplitMlp<false>::WAVES; }
+static int split_ex_fwd(int net) { return net == NET_GRU ? SplitGru::EX_FWD : SplitMlp<false>::EX_FWD; }
+static int split_ex_bwd(int net) { return net == NET_GRU ? SplitGru::EX_BWD : SplitMlp<false>::EX_BWD; }
+static int split_tape_f4(int net) { return net == NET_GRU ? SplitGru::TAPE_F4 : SplitMlp<false>::TAPE_F4; }
+static void env_dims(int env, int* S, int* C) { CTK_FOR_ENV(env, EV, { *S = Env<EV>::S; *C = Env<EV>::C; }); }
+static const char* split_policy_name(int env, int net) {
     int S = 0, C = 0;
-    CTK_FOR_ENV(env, EV, { S = Env<EV>::S; C = Env<EV>::C; });
-    return !off && S + C <= 8 && N <= 8192 && ctk_g_rpgd_descent_gru4_lds(H, C) <= 160 * 1024;
+    env_dims(env, &S, &C);
+    return net == NET_GRU ? "SplitGru" : (S + C > 8 ? "SplitMlp<true>" : "SplitMlp<false>");
+}
+// the split forms serve the populations that leave SIMDs idle with one wave per tile (N <= 8 192: 512 tiles on 1 024 SIMDs); larger
+// ones keep ctk_generic_net.hip's kernels.  CTK_NET_ONE_WAVE / CTK_RPGD_NET_ONE_WAVE: diagnostic switches (A/B measurements, tests)
+static bool split_env_ok(int env, int net) {
+    int S = 0, C = 0;
+    env_dims(env, &S, &C);
+    return net == NET_MLP || (net == NET_GRU && S + C <= 8);
 }
 
-size_t ctk_g_rpgd_scratch_floats_gru4(int N, int H) { return (size_t)((N + G4_TRAJ - 1) / G4_TRAJ) * H * 4 * G4_TAPE_F4 * 64 * 4; }
+size_t ctk_g_rpgd_descent_split_lds(int net, int H, int C) {
+    return (size_t)(split_ex_fwd(net) + split_ex_bwd(net) + G4_RED + 2 * (H + 1) * 128 + 2 * H * C * G4_LD) * sizeof(float);
+}
+bool ctk_g_rpgd_split_ok(int env, int net, int N, int H) {
+    static const bool off = getenv("CTK_RPGD_NET_ONE_WAVE") != nullptr;
+    int S = 0, C = 0;
+    env_dims(env, &S, &C);
+    return !off && split_env_ok(env, net) && N <= 8192 && ctk_g_rpgd_descent_split_lds(net, H, C) <= 160 * 1024;
+}
+size_t ctk_g_rpgd_scratch_floats_split(int net, int N, int H) {
+    return (size_t)((N + G4_TRAJ - 1) / G4_TRAJ) * H * split_waves(net) * split_tape_f4(net) * 64 * 4;
+}
+const char* ctk_g_rpgd_descent_split_name(int env, int net) { return ctk_kernel_name("ctk_g_rpgd_descent_split<%d, %4$s>", env, 0, 0, split_policy_name(env, net)); }
 
-const char* ctk_g_rpgd_descent_gru4_name(int env) { return ctk_kernel_name("ctk_g_rpgd_descent_gru4<%d>", env); }
+template <int EV, class SP>
+static void launch_descent_split(hipStream_t st, const RolloutArgs& a_in, const float* params, float dt, int isteps, const AdamK& ad, float* Q, float* m,
+                                 float* v, const float* bc_table, int bc_len, int t0, int iters, const float* wperm, const float* wperm_bwd,
+                                 const float* hidden, float* scratch, hipEvent_t e0, hipEvent_t e1) {
+    using E = Env<EV>;
+    RolloutArgs a = a_in;
+    a.C = E::C; a.p_magic = g4_magic_of(a.H * E::C);
+    const typename E::K k = E::derive(params, dt, isteps);
+    const dim3 grid((a.N + G4_TRAJ - 1) / G4_TRAJ), block(64 * SP::WAVES);
+    const size_t lds = ctk_g_rpgd_descent_split_lds(SP::NET, a.H, E::C);
+    CTK_LAUNCH((ctk_g_rpgd_descent_split<EV, SP>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wperm_bwd, hidden, scratch);
+}
 
-hipError_t ctk_launch_g_rpgd_descent_gru4(hipStream_t st, int env, const RolloutArgs& a_in, const float* params, float dt, int isteps,
-                                          const AdamK& ad, float* Q, float* m, float* v, const float* bc_table, int bc_len, int t0, int iters,
-                                          const float* wperm, const float* wperm_bwd, const float* hidden, float* scratch,
-                                          hipEvent_t e0, hipEvent_t e1) {
+hipError_t ctk_launch_g_rpgd_descent_split(hipStream_t st, int env, int net, const RolloutArgs& a, const float* params, float dt, int isteps,
+                                           const AdamK& ad, float* Q, float* m, float* v, const float* bc_table, int bc_len, int t0, int iters,
+                                           const float* wperm, const float* wperm_bwd, const float* hidden, float* scratch,
+                                           hipEvent_t e0, hipEvent_t e1) {
     CTK_FOR_ENV(env, EV, {
         using E = Env<EV>;
-        if constexpr (E::S + E::C <= 8) {
-            RolloutArgs a = a_in;
-            a.C = E::C; a.p_magic = g4_magic_of(a.H * E::C);
-            const typename E::K k = E::derive(params, dt, isteps);
-            const dim3 grid((a.N + G4_TRAJ - 1) / G4_TRAJ), block(G4_BLOCK);
-            const size_t lds = ctk_g_rpgd_descent_gru4_lds(a.H, E::C);
-            CTK_LAUNCH((ctk_g_rpgd_descent_gru4<EV>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wperm_bwd, hidden, scratch);
+        if (net == NET_GRU) {
+            if constexpr (E::S + E::C <= 8) launch_descent_split<EV, SplitGru>(st, a, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wperm_bwd, hidden, scratch, e0, e1);
+            else return hipErrorInvalidValue;
         } else {
-            return hipErrorInvalidValue;
+            launch_descent_split<EV, SplitMlp<(E::S + E::C > 8)>>(st, a, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wperm_bwd, hidden, scratch, e0, e1);
         }
     });
     return hipGetLastError();
 }
 
-size_t ctk_g_rollout_gru4_lds(int cols, int H, int C) {
-    return (size_t)(G4_EX_FWD + G4_RED + (H + 1) * 128 + H * C * G4_LD + G4_TRAJ * tile_stride(cols) + G4_TRAJ + 2 * H * C + 3 * H) * sizeof(float);
+size_t ctk_g_rollout_split_lds(int net, int cols, int H, int C) {
+    return (size_t)(split_ex_fwd(net) + G4_RED + (H + 1) * 128 + H * C * G4_LD + G4_TRAJ * tile_stride(cols) + G4_TRAJ + 2 * H * C + 3 * H) * sizeof(float);
 }
-
-// the four-wave rollout: while 16-trajectory workgroups leave the chip room (one-wave tiles: 4 per workgroup of ctk_g_rollout_net)
-bool ctk_g_rollout_gru4_ok(int env, int N, int H, int cols) {
-    static const bool off = getenv("CTK_GRU_ONE_WAVE") != nullptr;            // diagnostic switch (A/B measurements)
+bool ctk_g_rollout_split_ok(int env, int net, int N, int H, int cols) {
+    static const bool off = getenv("CTK_NET_ONE_WAVE") != nullptr;
     int S = 0, C = 0;
-    CTK_FOR_ENV(env, EV, { S = Env<EV>::S; C = Env<EV>::C; });
-    return !off && S + C <= 8 && N <= 8192 && ctk_g_rollout_gru4_lds(cols, H, C) <= 160 * 1024;
+    env_dims(env, &S, &C);
+    return !off && split_env_ok(env, net) && N <= 8192 && ctk_g_rollout_split_lds(net, cols, H, C) <= 160 * 1024;
+}
+int ctk_g_rollout_split_blocks(int N) { return (N + G4_TRAJ - 1) / G4_TRAJ; }
+const char* ctk_g_rollout_split_name(int env, int net, int mode, bool log) {
+    return ctk_kernel_name("ctk_g_rollout_split<%d, %4$s, %d, %5$s>", env, mode, 0, split_policy_name(env, net), log ? "true" : "false");
 }
 
-int ctk_g_rollout_gru4_blocks(int N) { return (N + G4_TRAJ - 1) / G4_TRAJ; }
+template <int EV, class SP>
+static void launch_rollout_split(hipStream_t st, int mode, const RolloutArgs& a_in, const float* params, float dt, int isteps, const MppiK& mk,
+                                 const float* samples, const float* base, const float* scale, int rng_kind, const float* wperm, const float* hidden,
+                                 float* parts, bool log, hipEvent_t e0, hipEvent_t e1, const MppiFuse* fuse) {
+    using E = Env<EV>;
+    RolloutArgs a = a_in;
+    const int cols = (mode == CTK_G_MODE_MPPI ? a_in.P : a_in.H) * E::C;
+    a.P = cols; a.p_magic = g4_magic_of(cols); a.C = E::C;
+    const typename E::K k = E::derive(params, dt, isteps);
+    const dim3 grid(ctk_g_rollout_split_blocks(a.N)), block(64 * SP::WAVES);
+    const NetFuse gz = ctk_net_fuse(SP::WAVES == 4 ? fuse : nullptr, mode, a, E::C, base, (int)grid.x, cols);   // mppi_ll_tail: 256-thread workgroups
+    const size_t lds = std::max(ctk_g_rollout_split_lds(SP::NET, cols, a.H, E::C), gz.mode ? merge_lds_staged(cols, (int)grid.x) : 0);
+    if (mode == CTK_G_MODE_MPPI) {
+        if (log) CTK_LAUNCH((ctk_g_rollout_split<EV, SP, CTK_G_MODE_MPPI, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
+        else CTK_LAUNCH((ctk_g_rollout_split<EV, SP, CTK_G_MODE_MPPI, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
+    } else {
+        if (log) CTK_LAUNCH((ctk_g_rollout_split<EV, SP, CTK_G_MODE_AFFINE, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
+        else CTK_LAUNCH((ctk_g_rollout_split<EV, SP, CTK_G_MODE_AFFINE, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
+    }
+}
 
-const char* ctk_g_rollout_gru4_name(int env, int mode, bool log) { return ctk_kernel_name("ctk_g_rollout_gru4<%d, %d, %4$s>", env, mode, 0, log ? "true" : "false"); }
-
-hipError_t ctk_launch_g_rollout_gru4(hipStream_t st, int env, int mode, const RolloutArgs& a_in, const float* params, float dt, int isteps,
-                                     const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
-                                     const float* wperm, const float* hidden, float* parts, bool log, hipEvent_t e0, hipEvent_t e1,
-                                     const MppiFuse* fuse) {
+hipError_t ctk_launch_g_rollout_split(hipStream_t st, int env, int net, int mode, const RolloutArgs& a, const float* params, float dt, int isteps,
+                                      const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
+                                      const float* wperm, const float* hidden, float* parts, bool log, hipEvent_t e0, hipEvent_t e1,
+                                      const MppiFuse* fuse) {
     CTK_FOR_ENV(env, EV, {
         using E = Env<EV>;
-        if constexpr (E::S + E::C <= 8) {
-            RolloutArgs a = a_in;
-            const int cols = (mode == CTK_G_MODE_MPPI ? a_in.P : a_in.H) * E::C;
-            a.P = cols; a.p_magic = g4_magic_of(cols); a.C = E::C;
-            const typename E::K k = E::derive(params, dt, isteps);
-            const dim3 grid(ctk_g_rollout_gru4_blocks(a.N)), block(G4_BLOCK);
-            const NetFuse gz = ctk_net_fuse(fuse, mode, a, E::C, base, (int)grid.x, cols);
-            const size_t lds = std::max(ctk_g_rollout_gru4_lds(cols, a.H, E::C), gz.mode ? merge_lds_staged(cols, (int)grid.x) : 0);
-            if (mode == CTK_G_MODE_MPPI) {
-                if (log) CTK_LAUNCH((ctk_g_rollout_gru4<EV, CTK_G_MODE_MPPI, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
-                else CTK_LAUNCH((ctk_g_rollout_gru4<EV, CTK_G_MODE_MPPI, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
-            } else {
-                if (log) CTK_LAUNCH((ctk_g_rollout_gru4<EV, CTK_G_MODE_AFFINE, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
-                else CTK_LAUNCH((ctk_g_rollout_gru4<EV, CTK_G_MODE_AFFINE, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
-            }
+        if (net == NET_GRU) {
+            if constexpr (E::S + E::C <= 8) launch_rollout_split<EV, SplitGru>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
+            else return hipErrorInvalidValue;
         } else {
-            return hipErrorInvalidValue;
+            launch_rollout_split<EV, SplitMlp<(E::S + E::C > 8)>>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
         }
     });
     return hipGetLastError();
@@ -682,7 +846,7 @@ hipError_t ctk_launch_g_rollout_gru4(hipStream_t st, int env, int mode, const Ro
 
 hipError_t ctk_launch_g_gru_advance4(hipStream_t st, int env, const RolloutArgs& a, const float* u_dev, const float* wperm, float* hidden) {
     CTK_FOR_ENV(env, EV, {
-        if constexpr (Env<EV>::S + Env<EV>::C <= 8) hipLaunchKernelGGL((ctk_g_gru_advance4<EV>), dim3(1), dim3(G4_BLOCK), 0, st, a, u_dev, wperm, hidden);
+        if constexpr (Env<EV>::S + Env<EV>::C <= 8) hipLaunchKernelGGL((ctk_g_gru_advance4<EV>), dim3(1), dim3(256), 0, st, a, u_dev, wperm, hidden);
         else return hipErrorInvalidValue;
     });
     return hipGetLastError();

@@ -96,7 +96,7 @@ def test_quad2d_env_info_and_errors():
     with pytest.raises(ValueError, match="num_states"):
         CtkEngine("mppi", "ODE", environment="Quad2D", num_states=4, num_control_inputs=1, num_rollouts=8, mpc_horizon=5, dt=0.02)
     eg = CtkEngine("mppi", "GRU", environment="Quad2D", num_rollouts=8, mpc_horizon=5, dt=0.02)     # every predictor on every environment
-    assert eg.predictor_weight_count() == O.gru_num_weights(8, 6) and "ctk_g_rollout_gru4<1," in eg.dominant_kernel()
+    assert eg.predictor_weight_count() == O.gru_num_weights(8, 6) and "ctk_g_rollout_split<1, SplitGru," in eg.dominant_kernel()
     eg.close()
     em = CtkEngine("mppi", "MLP", environment="Quad2D", num_rollouts=8, mpc_horizon=5, dt=0.02)
     assert em.predictor_weight_count() == O.mlp_num_weights(8, 6)
@@ -381,7 +381,7 @@ def test_cartpole_generic_mlp_kernels_match_tuned_mlp_kernels(opt):
         kw.update(outer_its=3, resamp_per=2, opt_keep_k=40, sample_whole_control_space=1)
     w = O.mlp_default_weights(2)
     a, b = CtkEngine(opt, "MLP", **kw), CtkEngine(opt, "MLP", generic_kernels=True, **kw)
-    assert "ctk_g_" in b.dominant_kernel() and "NetMlp" in b.dominant_kernel()
+    assert "ctk_g_" in b.dominant_kernel() and "Mlp" in b.dominant_kernel()      # SplitMlp<.> (N <= 8192) or NetMlp
     a.set_predictor_weights(w); b.set_predictor_weights(w)
     if opt == "rpgd":
         a.reset(); b.reset()

@@ -121,7 +121,7 @@ def test_gru_accepted_by_every_optimizer_and_device_rng_runs():
     # the gradient-based optimizers take the recurrent predictor too (reverse mode: ctk_net.h:NetGru::Bwd; parity: test_gpu_gru_grad.py)
     for opt in ("rpgd", "gradient", "cem_naive_grad", "cem_grad_bharadhwaj"):
         e = CtkEngine(opt, "GRU", num_rollouts=64, mpc_horizon=10, dt=0.02, cem_best_k=8)
-        assert "ctk_g_rpgd_descent_gru4" in e.dominant_kernel()      # N <= 8192: one tile over four waves (ctk_gru4.hip)
+        assert "ctk_g_rpgd_descent_split<0, SplitGru>" in e.dominant_kernel()      # N <= 8192: one tile over four waves (ctk_net_split.hip)
         e.set_predictor_weights(O.gru_default_weights(0))
         if opt in ("rpgd", "gradient"):
             e.reset()

@@ -25,8 +25,8 @@ def test_cartpole_generic_gru_matches_four_wave_gru(opt):
     w = O.gru_default_weights(3)
     a, b = CtkEngine(opt, "GRU", **kw), CtkEngine(opt, "GRU", generic_kernels=True, **kw)
     import os
-    form = "NetGru" if os.environ.get("CTK_GRU_ONE_WAVE") else "ctk_g_rollout_gru4"        # (the child process of the last test in this file)
-    assert form in b.dominant_kernel() and "ctk_g_" not in a.dominant_kernel()             # template (ctk_gru4.hip) vs tuned (ctk_gru.h)
+    form = "NetGru" if os.environ.get("CTK_NET_ONE_WAVE") else "ctk_g_rollout_split<0, SplitGru"        # (the child process of the last test in this file)
+    assert form in b.dominant_kernel() and "ctk_g_" not in a.dominant_kernel()             # template (ctk_net_split.hip) vs tuned (ctk_gru.h)
     a.set_predictor_weights(w); b.set_predictor_weights(w)
     h0 = (0.2 * np.random.default_rng(0).standard_normal((2, 32))).astype(np.float32)
     a.predictor_set_hidden(h0); b.predictor_set_hidden(h0)
@@ -125,7 +125,7 @@ def test_cartpole_rpgd_with_gru_matches_oracle():
 
 @pytest.mark.parametrize("N,H", [(40, 12), (17, 3), (1, 1), (200, 33)])
 def test_cartpole_rpgd_with_gru_ragged_populations_match_oracle(N, H):
-    """the four-wave form (ctk_gru4.hip) owns 16 plans per workgroup: populations that are not multiples of 16 (a partial last tile),
+    """the four-wave form (ctk_net_split.hip) owns 16 plans per workgroup: populations that are not multiples of 16 (a partial last tile),
     a single plan, a horizon of one"""
     env = O.EnvParams(terminal_weight=0.3)
     w = O.gru_default_weights(3)
@@ -137,7 +137,7 @@ def test_cartpole_rpgd_with_gru_ragged_populations_match_oracle(N, H):
                SAMPLING_DISTRIBUTION="uniform", opt_keep_k_ratio=k / N)
     e = CtkEngine("rpgd", "GRU", num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p, outer_its=its, resamp_per=1000,
                   opt_keep_k=o.k, sampling_distribution=0, sample_whole_control_space=1)
-    assert "gru4" in e.dominant_kernel()
+    assert "SplitGru" in e.dominant_kernel()
     for n in env.param_names():
         e.set_param(n, float(getattr(env, n)))
     e.set_predictor_weights(w)
@@ -155,14 +155,16 @@ def test_cartpole_rpgd_with_gru_ragged_populations_match_oracle(N, H):
     e.close()
 
 
-def test_one_wave_gru_reverse_form_also_matches_oracle():
-    """Populations above 8 192 plans (and horizons whose states do not fit LDS) keep one wave per tile (ctk_net.h: NetGru::Bwd); its
-    diagnostic switch (read once per process) puts it under the same oracle tests in a child process."""
+def test_one_wave_network_forms_also_match_oracle():
+    """Populations above 8 192 (and horizons whose states do not fit LDS) keep one wave per tile (ctk_generic_net.hip with ctk_net.h:
+    NetGru / NetMlpT, forward and reverse); their diagnostic switches (read once per process) put them under the same oracle / golden
+    tests in a child process: the GRU tests of this file, the third environment's suite and the second environment's MLP tests."""
     import os, subprocess, sys
-    env = dict(os.environ, CTK_RPGD_GRU_ONE_WAVE="1", CTK_GRU_ONE_WAVE="1")
+    env = dict(os.environ, CTK_RPGD_NET_ONE_WAVE="1", CTK_NET_ONE_WAVE="1")
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(here, "test_gpu_gru_grad.py"),
-                        "-k", "(single_gradient or rpgd_with_gru_matches or quad2d_gru_mppi or generic_gru_matches) and not one_wave"],
+                        os.path.join(here, "test_gpu_hover.py"), os.path.join(here, "test_gpu_env.py"),
+                        "-k", "(single_gradient or rpgd_with_gru_matches or quad2d_gru_mppi or generic_gru_matches or hover or mlp) and not one_wave and not shards"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
