@@ -591,6 +591,8 @@ def main():
         out.update(sharded_fields)
         # what the barrier + synchronize bracket itself contributes to `ms_per_step` (fixed per region, so 1/K of it per step: a K = 20
         # run reads ~2 us per step higher than a K = 200 run of the same steady state; the median does not move)
+        if os.environ.get("CTK_BENCH_TRACE_STEPS"):
+            print("per-step us of the timed region:", " ".join(f"{x * 1e3:.1f}" for x in ps[:24]), file=sys.stderr)
         out["timed_region"] = {"first_step_ms": float(ps[0]), "closing_synchronize_ms": bracket_close_ms,
                                "ms_per_step_without_first_and_close": float((elapsed * 1e3 - ps[0] - (bracket_close_ms or 0.0)) / max(1, args.steps - 1))}
         if args.steps >= 100:

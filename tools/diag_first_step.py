@@ -29,4 +29,19 @@ for label, opener in (("torch.cuda.synchronize()", torch.cuda.synchronize), ("ti
             tb = time.perf_counter(); per[rep, i] = tb - ta; ta = tb
         torch.cuda.synchronize()
     med = np.median(per, axis=0) * 1e6
+    print("   bracket 0:", np.round(per[0, :8] * 1e6, 1), " bracket 1:", np.round(per[1, :8] * 1e6, 1), " bracket 15:", np.round(per[15, :8] * 1e6, 1))
     print(f"opener = {label}: step 0 {med[0]:.1f} us, step 1 {med[1]:.1f}, step 2 {med[2]:.1f}, steps 3.. {np.median(med[3:]):.1f}")
+
+# kernel time (dispatch timestamps) against wall time of the steps around a synchronize: is the first step's excess inside the kernel?
+eng.profile_enable(True, every=1)
+walls, kerns = [], []
+for rep in range(20):
+    torch.cuda.synchronize()
+    w = []
+    for i in range(6):
+        t0 = time.perf_counter(); ctrl.step(s); w.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    k = np.asarray(eng.profile_read(), np.float64).ravel()
+    walls.append(w); kerns.append(k[-6:] if k.size >= 6 else np.full(6, np.nan))
+print("with per-launch timing on: wall us (median over 20 brackets) of steps 0..5:", np.round(np.median(np.array(walls), 0) * 1e6, 1))
+print("                           kernel us of the same launches               :", np.round(np.nanmedian(np.array(kerns), 0) * 1e-3, 1))
