@@ -718,15 +718,13 @@ static int throughput_form(int pred, int N, bool have_samples, bool identity_int
 }
 
 // name of the kernel ctk_launch_mppi_rollout runs for these arguments (identity_interp as RolloutArgs carries it: period 1 AND P == H)
-const char* ctk_mppi_rollout_name(int pred, bool log, int N, bool identity_interp, bool have_samples) {
+const char* ctk_mppi_rollout_name(int pred, bool log, int N, bool identity_interp, bool have_samples, bool p2p) {
     const int tf = throughput_form(pred, N, have_samples, identity_interp);
     if (tf == 2) return log ? "ctk_mppi_rollout_tps<true>" : "ctk_mppi_rollout_tps<false>";
     if (tf == 1) return log ? "ctk_mppi_rollout_tp<true>" : "ctk_mppi_rollout_tp<false>";
-    // template arguments <environment, predictor form, materialise>: what rocprofv3's kernel trace shows
-    if (pred == CTK_PRED_ODE) return log ? "ctk_mppi_rollout<0, 0, true>" : "ctk_mppi_rollout<0, 0, false>";
-    if (pred == CTK_PRED_GRU) return log ? "ctk_mppi_rollout<0, 2, true>" : "ctk_mppi_rollout<0, 2, false>";
-    if (kernel_pred(pred, N) == CTK_PRED_MLP_PAIR) return log ? "ctk_mppi_rollout<0, 3, true>" : "ctk_mppi_rollout<0, 3, false>";
-    return log ? "ctk_mppi_rollout<0, 1, true>" : "ctk_mppi_rollout<0, 1, false>";
+    // template arguments <environment, predictor form, materialise, peer-to-peer tail>: what rocprofv3's kernel trace shows
+    const int kp = pred == CTK_PRED_ODE ? CTK_PRED_ODE : pred == CTK_PRED_GRU ? CTK_PRED_GRU : kernel_pred(pred, N);
+    return ctk_kernel_name("ctk_mppi_rollout<0, %d, %4$s, %5$s>", kp, 0, 0, log ? "true" : "false", p2p ? "true" : "false");
 }
 
 int ctk_mppi_num_blocks(int N, int pred) {
@@ -760,7 +758,7 @@ hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& 
                                    const float* samples, const float* u_nom, const float* wperm, float* parts, bool log,
                                    const MppiFuse& fuse, hipEvent_t e0, hipEvent_t e1, const char** ran) {
     const dim3 grid(ctk_mppi_num_blocks(a.N, pred)), block(MPPI_BLOCK);
-    if (ran) *ran = ctk_mppi_rollout_name(pred, log, a.N, a.identity_interp != 0, samples != nullptr);
+    if (ran) *ran = ctk_mppi_rollout_name(pred, log, a.N, a.identity_interp != 0, samples != nullptr, fuse.mode == 3);
     if (const int tf = throughput_form(pred, a.N, samples != nullptr, a.identity_interp != 0)) {
         if (tf == 2) {
             const size_t lds_d = (size_t)(64 * TPS_LD + 64 + a.H) * sizeof(float);
@@ -829,7 +827,7 @@ size_t ctk_mppi_rollout_env_lds(int env, int P, int H, int N) {
     return rollout_launch_lds(P, H, CTK_PRED_ODE, N, (N + MPPI_TRAJ - 1) / MPPI_TRAJ, &stage_ok, C);
 }
 const char* ctk_mppi_rollout_env_name(int env, bool log) {
-    return ctk_kernel_name("ctk_mppi_rollout<%d, 0, %4$s>", env, 0, 0, log ? "true" : "false");
+    return ctk_kernel_name("ctk_mppi_rollout<%d, 0, %4$s, false>", env, 0, 0, log ? "true" : "false");
 }
 
 hipError_t ctk_launch_mppi_merge_partial(hipStream_t st, const float* parts, int n_parts, int per_block, int P,

@@ -43,7 +43,7 @@ def test_cartpole_generic_kernels_match_tuned_kernels(opt):
     # the analytic predictor's sampling kernels ARE templates over the environment: generic CartPole = the Env<CartPole>
     # instantiation of ctk_mppi_rollout / ctk_affine_rollout (CEM's tuned path additionally fuses its step into one launch)
     if opt == "mppi":
-        assert a.dominant_kernel() == b.dominant_kernel() == "ctk_mppi_rollout<0, 0, true>"
+        assert a.dominant_kernel() == b.dominant_kernel() == "ctk_mppi_rollout<0, 0, true, false>"
     elif opt == "random_action":
         assert a.dominant_kernel() == b.dominant_kernel() == "ctk_affine_rollout<0, 0, true>"
     elif opt == "cem":

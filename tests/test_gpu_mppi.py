@@ -26,7 +26,7 @@ ODE_CASES = [c for c in MPPI_CASES if c != "mlp"]
 def test_mppi_matches_reference_golden(case, materialize):
     d = load(f"mppi_{case}.npz")
     e = mppi_engine_from(d, materialize=materialize)
-    assert e.dominant_kernel() == f"ctk_mppi_rollout<0, 0, {'true' if materialize else 'false'}>"
+    assert e.dominant_kernel() == f"ctk_mppi_rollout<0, 0, {'true' if materialize else 'false'}, false>"
     H = int(d["mpc_horizon"])
     np.testing.assert_array_equal(e.read("U_NOM"), d["u_nom_init"])
     for t in range(int(d["steps"])):

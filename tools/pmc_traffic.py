@@ -35,7 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fetch", required=True); ap.add_argument("--write", required=True)
     ap.add_argument("--workload", required=True); ap.add_argument("--samples", required=True)
-    ap.add_argument("--kernel", default="ctk_mppi_rollout<0, 0, false>")
+    ap.add_argument("--kernel", default="ctk_mppi_rollout<0, 0, false, false>")
     ap.add_argument("--commit", default="unknown"); ap.add_argument("--out", required=True)
     a = ap.parse_args()
     import bench

@@ -17,19 +17,49 @@ engs = {
  "mppi_mlp": CtkEngine("mppi", "MLP", num_rollouts=1000, mpc_horizon=30, dt=0.02, seed=6, period_interpolation_inducing_points=5),
  "rpgd_mlp": CtkEngine("rpgd", "MLP", num_rollouts=72, mpc_horizon=25, dt=0.02, seed=7, outer_its=3, resamp_per=5, shift_previous=1, opt_keep_k=18, sampling_distribution=0, sample_min=-1.0, sample_max=1.0, learning_rate=0.05, gradmax_clip=5.0, period_interpolation_inducing_points=5),
 }
+ # round 3: the one-launch CEM at cfg3's size, the split network kernels of the template path (GRU over four waves forward and BPTT, MLP over two),
+ # the second and third environment
+engs.update({
+ "cem_cfg3": CtkEngine("cem", "ODE", num_rollouts=4096, mpc_horizon=30, dt=0.02, seed=8, cem_outer_it=3, cem_best_k=409),
+ "mppi_gru_t": CtkEngine("mppi", "GRU", generic_kernels=True, num_rollouts=256, mpc_horizon=25, dt=0.02, seed=9, period_interpolation_inducing_points=5),
+ "rpgd_gru_t": CtkEngine("rpgd", "GRU", num_rollouts=40, mpc_horizon=20, dt=0.02, seed=10, outer_its=2, resamp_per=5, opt_keep_k=10, sampling_distribution=0, period_interpolation_inducing_points=5),
+ "mppi_mlp_t": CtkEngine("mppi", "MLP", generic_kernels=True, num_rollouts=500, mpc_horizon=30, dt=0.02, seed=12, period_interpolation_inducing_points=5),
+ "rpgd_mlp_t": CtkEngine("rpgd", "MLP", generic_kernels=True, num_rollouts=72, mpc_horizon=25, dt=0.02, seed=13, outer_its=3, resamp_per=5, opt_keep_k=18, sampling_distribution=0, period_interpolation_inducing_points=5),
+})
+others = {
+ "quad_mppi": CtkEngine("mppi", "ODE", environment="Quad2D", num_rollouts=512, mpc_horizon=30, dt=0.02, seed=14, period_interpolation_inducing_points=5),
+ "quad_cem": CtkEngine("cem", "MLP", environment="Quad2D", num_rollouts=256, mpc_horizon=20, dt=0.02, seed=15, cem_outer_it=2, cem_best_k=25),
+ "hover_mppi_mlp": CtkEngine("mppi", "MLP", environment="Hover", num_rollouts=256, mpc_horizon=20, dt=0.02, seed=16, period_interpolation_inducing_points=4),
+ "hover_rpgd": CtkEngine("rpgd", "ODE", environment="Hover", num_rollouts=48, mpc_horizon=16, dt=0.02, seed=17, outer_its=2, resamp_per=4, opt_keep_k=12, sampling_distribution=0, period_interpolation_inducing_points=4),
+}
+for k, e in list(engs.items()) + list(others.items()):
+    n = e.predictor_weight_count()
+    if n and k not in ("mppi_mlp", "rpgd_mlp"):
+        e.set_predictor_weights((np.random.default_rng(20).standard_normal(n) * 0.15).astype(np.float32))
+for k in ("rpgd_gru_t", "rpgd_mlp_t"):
+    engs[k].reset()
+others["hover_rpgd"].reset()
+ostate = {k: np.zeros(e.S, np.float32) for k, e in others.items()}
+for v in ostate.values():
+    v[:3] = [0.1, 0.0, 0.2]
 _w = (np.random.default_rng(11).standard_normal(engs["mppi_mlp"].predictor_weight_count()) * 0.15).astype(np.float32)
 engs["mppi_mlp"].set_predictor_weights(_w); engs["rpgd_mlp"].set_predictor_weights(_w)
 engs["rpgd"].reset(); engs["rpgd_mlp"].reset()
 engs["mppi_log"].log_enable(64)
 states = {k: np.array([0.0, 0.0, 3.0, 0.0], np.float32) for k in engs}
 t0 = time.time()
-for i in range(3000):
+STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+for i in range(STEPS):
     for k, e in engs.items():
         u = e.step(states[k])
         assert np.isfinite(u).all() and abs(float(u[0])) <= 1.0 + 1e-6, (k, i, u)
         plant_step(states[k], float(u[0]))
         if not np.isfinite(states[k]).all() or abs(states[k][0]) > 50:
             states[k] = np.array([0.0, 0.0, rng.uniform(-3, 3), 0.0], np.float32)
+    for k, e in others.items():            # no host plant for these: the state drifts a little every step
+        u = e.step(ostate[k])
+        assert np.isfinite(u).all() and (np.abs(u) <= 1.0 + 1e-6).all(), (k, i, u)
+        ostate[k][0] = 0.1 + 0.05 * np.sin(0.01 * i); ostate[k][2] = 0.2 + 0.05 * np.cos(0.013 * i)
     if i % 97 == 0:
         engs["mppi"].set_param("target_position", float(rng.uniform(-0.2, 0.2)))
         st = engs["cem"].get_state(); engs["cem"].set_state(st)
@@ -38,4 +68,4 @@ for i in range(3000):
         a = engs["mppi_log"].log_read("J", max(0, engs["mppi_log"].log_count() - 10), min(10, engs["mppi_log"].log_count()))
         assert np.isfinite(a).all()
 print("soak ok", time.time() - t0, "s;", {k: [round(float(x), 3) for x in v] for k, v in states.items()})
-for e in engs.values(): e.close()
+for e in list(engs.values()) + list(others.values()): e.close()
