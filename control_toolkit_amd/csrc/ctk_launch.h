@@ -27,7 +27,7 @@ inline const char* ctk_kernel_name(const char* fmt, int a = 0, int b = 0, int c 
 }
 
 // ---- ctk_mppi.hip ---------------------------------------------------------------------------
-const char* ctk_mppi_rollout_name(int pred, bool log, int N, bool identity_interp = false, bool have_samples = true, bool p2p = false);
+const char* ctk_mppi_rollout_name(int pred, bool log, int N, bool identity_interp = false, bool have_samples = true, bool p2p = false, int H = 0);
 int ctk_mppi_num_blocks(int N, int pred);   // workgroups = block records of one rollout launch (64 trajectories each; GRU: 16)
 bool ctk_mppi_uses_throughput_kernel(int pred, int N);
 size_t ctk_mppi_rollout_lds(int P, int H, int pred = 0, int N = 1 << 30, int C = 1);

@@ -570,13 +570,16 @@ __global__ __launch_bounds__(64) void ctk_mppi_rollout_tp(RolloutArgs a, EnvK k,
 // ---------------------------------------------------------------------------------------------
 constexpr int TPS_CK = 16, TPS_LD = TPS_CK + 1;
 
-template <bool LOG>
+// RES (round 3, opt-in — measured slower, see tps_resident): the patch becomes the wave's WHOLE [64][H+1] tile, filled chunk by chunk as
+// the stream arrives, so the epilogue's weighted column sums read LDS instead of re-reading the block's rows.
+template <bool LOG, bool RES = false>
 __global__ __launch_bounds__(64) void ctk_mppi_rollout_tps(RolloutArgs a, EnvK k, MppiK m, const float* __restrict__ samples,
                                                            const float* __restrict__ u_nom, float* __restrict__ parts) {
     extern __shared__ float lds[];
     const int P = a.P, H = a.H;               // P == H (identity interpolation)
-    float* xs = lds;                          // [64][TPS_LD] transposition patch
-    float* e_s = xs + 64 * TPS_LD;            // [64]
+    const int LD = RES ? (H | 1) : TPS_LD;    // RES: an odd row stride >= H (conflict-free row walk)
+    float* xs = lds;                          // [64][LD]: transposition patch, or (RES) the whole tile
+    float* e_s = xs + 64 * LD;                // [64]
     float* un_s = e_s + 64;                   // [H] shifted nominal input
     const int lane = threadIdx.x;
     const int row0 = blockIdx.x * 64;
@@ -592,12 +595,22 @@ __global__ __launch_bounds__(64) void ctk_mppi_rollout_tps(RolloutArgs a, EnvK k
 #pragma unroll
         for (int i = 0; i < TPS_CK; ++i) nxt[i] = cbase[(size_t)min(crow + 4 * i, last) * P + c];
     };
-    auto transpose = [&]() {                  // nxt (chunk layout) -> cur (this lane's 16 steps); the patch is the wave's own
+    auto transpose = [&](int h0) {            // nxt (chunk layout) -> cur (this lane's 16 steps); the patch / tile is the wave's own
+        if constexpr (RES) {
+            if (h0 + ccol < H) {
 #pragma unroll
-        for (int i = 0; i < TPS_CK; ++i) xs[(crow + 4 * i) * TPS_LD + ccol] = nxt[i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                for (int i = 0; i < TPS_CK; ++i) xs[(crow + 4 * i) * LD + h0 + ccol] = nxt[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-        for (int i = 0; i < TPS_CK; ++i) cur[i] = xs[lane * TPS_LD + i];
+            for (int i = 0; i < TPS_CK; ++i) cur[i] = xs[lane * LD + min(h0 + i, H - 1)];
+        } else {
+#pragma unroll
+            for (int i = 0; i < TPS_CK; ++i) xs[(crow + 4 * i) * TPS_LD + ccol] = nxt[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+            for (int i = 0; i < TPS_CK; ++i) cur[i] = xs[lane * TPS_LD + i];
+        }
     };
     fetch(0);
     for (int h = lane; h < H; h += 64) un_s[h] = u_nom[min(h + 1, H - 1)];   // optimizer_mppi.py:184 (shift)
@@ -615,7 +628,7 @@ __global__ __launch_bounds__(64) void ctk_mppi_rollout_tps(RolloutArgs a, EnvK k
             if (a.traj_out) traj = reinterpret_cast<float4*>(a.traj_out) + (size_t)n * (H + 1);
         }
         for (int h0 = 0; h0 < H; h0 += TPS_CK) {
-            transpose();
+            transpose(h0);
             if (h0 + TPS_CK < H) fetch(h0 + TPS_CK);
 #pragma unroll
             for (int i = 0; i < TPS_CK; ++i) {
@@ -689,6 +702,18 @@ __global__ __launch_bounds__(64) void ctk_mppi_rollout_tps(RolloutArgs a, EnvK k
         acc += __shfl_xor(acc, 32, 64);
         if (lane < TPS_CK && h0 + lane < H) rec[2 + h0 + lane] = acc * m.stdev;
     };
+    if constexpr (RES) {                                  // the tile is resident: no second pass through memory
+        for (int h0 = 0; h0 < H; h0 += TPS_CK) {
+            const int c = min(h0 + ccol, H - 1);
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < TPS_CK; ++i) acc = fmaf(e_s[crow + 4 * i], xs[(crow + 4 * i) * LD + c], acc);
+            acc += __shfl_xor(acc, 16, 64);
+            acc += __shfl_xor(acc, 32, 64);
+            if (lane < TPS_CK && h0 + lane < H) rec[2 + h0 + lane] = acc * m.stdev;
+        }
+        return;
+    }
     fetch_into(nxt, 0);                                   // two chunks in flight: one being summed, the next one landing
     for (int h0 = 0; h0 < H; h0 += 2 * TPS_CK) {
         if (h0 + TPS_CK < H) fetch_into(cur, h0 + TPS_CK);
@@ -717,10 +742,17 @@ static int throughput_form(int pred, int N, bool have_samples, bool identity_int
     return (have_samples && identity_interp && !no_direct) ? 2 : 1;
 }
 
+// the streaming kernel's resident-tile form (RES) is opt-in: measured SLOWER than the patch + re-read form (N = 2^20: 112.4 vs 105.4 us) —
+// the re-read hits L2 / MALL, and 13 KiB of LDS per wave costs a twelfth of the residency.  CTK_MPPI_TPS_RESIDENT: diagnostic switch (A/B)
+static bool tps_resident(int H) {
+    static const bool on = getenv("CTK_MPPI_TPS_RESIDENT") != nullptr;
+    return on && (size_t)64 * (H | 1) * sizeof(float) <= 16 * 1024;
+}
+
 // name of the kernel ctk_launch_mppi_rollout runs for these arguments (identity_interp as RolloutArgs carries it: period 1 AND P == H)
-const char* ctk_mppi_rollout_name(int pred, bool log, int N, bool identity_interp, bool have_samples, bool p2p) {
+const char* ctk_mppi_rollout_name(int pred, bool log, int N, bool identity_interp, bool have_samples, bool p2p, int H) {
     const int tf = throughput_form(pred, N, have_samples, identity_interp);
-    if (tf == 2) return log ? "ctk_mppi_rollout_tps<true>" : "ctk_mppi_rollout_tps<false>";
+    if (tf == 2) return ctk_kernel_name("ctk_mppi_rollout_tps<%4$s, %5$s>", 0, 0, 0, log ? "true" : "false", (H > 0 && tps_resident(H)) ? "true" : "false");
     if (tf == 1) return log ? "ctk_mppi_rollout_tp<true>" : "ctk_mppi_rollout_tp<false>";
     // template arguments <environment, predictor form, materialise, peer-to-peer tail>: what rocprofv3's kernel trace shows
     const int kp = pred == CTK_PRED_ODE ? CTK_PRED_ODE : pred == CTK_PRED_GRU ? CTK_PRED_GRU : kernel_pred(pred, N);
@@ -758,9 +790,15 @@ hipError_t ctk_launch_mppi_rollout(hipStream_t st, int pred, const RolloutArgs& 
                                    const float* samples, const float* u_nom, const float* wperm, float* parts, bool log,
                                    const MppiFuse& fuse, hipEvent_t e0, hipEvent_t e1, const char** ran) {
     const dim3 grid(ctk_mppi_num_blocks(a.N, pred)), block(MPPI_BLOCK);
-    if (ran) *ran = ctk_mppi_rollout_name(pred, log, a.N, a.identity_interp != 0, samples != nullptr, fuse.mode == 3);
+    if (ran) *ran = ctk_mppi_rollout_name(pred, log, a.N, a.identity_interp != 0, samples != nullptr, fuse.mode == 3, a.H);
     if (const int tf = throughput_form(pred, a.N, samples != nullptr, a.identity_interp != 0)) {
         if (tf == 2) {
+            if (tps_resident(a.H)) {
+                const size_t lds_r = (size_t)(64 * (a.H | 1) + 64 + a.H) * sizeof(float);
+                if (log) CTK_LAUNCH((ctk_mppi_rollout_tps<true, true>), grid, dim3(64), lds_r, st, e0, e1, a, k, m, samples, u_nom, parts);
+                else CTK_LAUNCH((ctk_mppi_rollout_tps<false, true>), grid, dim3(64), lds_r, st, e0, e1, a, k, m, samples, u_nom, parts);
+                return hipGetLastError();
+            }
             const size_t lds_d = (size_t)(64 * TPS_LD + 64 + a.H) * sizeof(float);
             if (log) CTK_LAUNCH((ctk_mppi_rollout_tps<true>), grid, dim3(64), lds_d, st, e0, e1, a, k, m, samples, u_nom, parts);
             else CTK_LAUNCH((ctk_mppi_rollout_tps<false>), grid, dim3(64), lds_d, st, e0, e1, a, k, m, samples, u_nom, parts);
