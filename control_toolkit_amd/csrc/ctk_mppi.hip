@@ -573,7 +573,7 @@ constexpr int TPS_CK = 16, TPS_LD = TPS_CK + 1;
 // RES (round 3, opt-in — measured slower, see tps_resident): the patch becomes the wave's WHOLE [64][H+1] tile, filled chunk by chunk as
 // the stream arrives, so the epilogue's weighted column sums read LDS instead of re-reading the block's rows.
 template <bool LOG, bool RES = false>
-__global__ __launch_bounds__(64, 4) void ctk_mppi_rollout_tps(RolloutArgs a, EnvK k, MppiK m, const float* __restrict__ samples,
+__global__ __launch_bounds__(64) void ctk_mppi_rollout_tps(RolloutArgs a, EnvK k, MppiK m, const float* __restrict__ samples,
                                                            const float* __restrict__ u_nom, float* __restrict__ parts) {
     extern __shared__ float lds[];
     const int P = a.P, H = a.H;               // P == H (identity interpolation)
