@@ -159,322 +159,8 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
                                                                const float* __restrict__ wperm,
                                                                float* __restrict__ parts, int N_, int H_, int P_,
                                                                uint32_t pmagic_, RolloutArgs a_in, typename Env<ENV>::K k, MppiK m, FuseArgs fz) {
-    using E = Env<ENV>;
-    constexpr int C = E::C, S = E::S;
-    static_assert(PRED == CTK_PRED_ODE || ENV == CTK_ENV_CARTPOLE, "network predictors: CartPole instantiations only");
     extern __shared__ float lds[];
-    RolloutArgs a = a_in;
-    a.N = N_; a.H = H_; a.P = P_ * C; a.p_magic = pmagic_;      // a.P: sample COLUMNS of a row (what the tile loader walks)
-    constexpr int TRAJ = (PRED == CTK_PRED_GRU) ? GRU_TRAJ : (PRED == CTK_PRED_MLP_PAIR) ? MPPI_PAIR_TRAJ : MPPI_TRAJ;   // trajectories of this workgroup
-    constexpr int CHUNKS = MPPI_BLOCK / TRAJ;                             // horizon chunks of prologue 2 (4 / 16)
-    constexpr int RPW = TRAJ / MPPI_WAVES;                                // tile rows per wave in the epilogue
-    const int Pp = P_, P = Pp * C, H = a.H, HC = H * C, ts = tile_stride(P), us = ubuf_stride(HC);   // Pp points, P columns
-    float* tile = lds;                         // [TRAJ][ts]  stdev * noise at the inducing points (point i, channel c: column i*C + c)
-    float* ubuf = tile + TRAJ * ts;            // [TRAJ][us]  clipped inputs u_run [H*C]
-    float* corr_s = ubuf + TRAJ * us;          // [CHUNKS][TRAJ] per-chunk partial MPPI correction costs
-    float* e_s = corr_s + MPPI_BLOCK;          // [TRAJ]
-    float* col_s = e_s + TRAJ;                 // [4][P]    per-wave partial column sums
-    float* w0_s = col_s + MPPI_WAVES * P;      // [H] [H] [H*C] [H]  per-step tables
-    float* w1_s = w0_s + H;
-    float* un_s = w1_s + H;
-    int* i0_s = reinterpret_cast<int*>(un_s + HC);
-    float* gru_ex = lds + mppi_carve_floats(P, HC, TRAJ, H);   // GRU only: exchange slots of the four waves (ctk_gru.h)
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int row0 = blockIdx.x * TRAJ;
-    const int n = row0 + lane;                 // wave 0's view: lane = trajectory of the workgroup
-    const bool valid = lane < TRAJ && n < a.N;
-    const bool use_ll = fz.mode != 0 && fz.ll != nullptr;   // kernel-argument uniform
-
-    const uint32_t ka_sink = kernarg_prefetch<sizeof(RolloutArgs) + sizeof(typename E::K) + sizeof(MppiK) + 5 * sizeof(void*) + 16 + sizeof(FuseArgs)>();
-    STAMP(0);
-    // ---- prologue 1 (256 threads): per-step tables (interpolation entry, shifted nominal input) and
-    //      the sample tile (coalesced HBM read or Philox draw) into LDS ------------------------------
-    load_tile_early<TRAJ, MPPI_BLOCK>(tile, samples, a, row0, m.stdev, /*normal*/ 0, [&] {
-        for (int h = t; h < H; h += MPPI_BLOCK) {           // issued while the sample loads are in flight
-            const InterpEntry e = interp[h];
-            i0_s[h] = e.i0; w0_s[h] = e.w0; w1_s[h] = e.w1;
-#pragma unroll
-            for (int c = 0; c < C; ++c) un_s[h * C + c] = u_nom[min(h + 1, H - 1) * C + c];   // optimizer_mppi.py:184 (shift)
-        }
-    });
-    __syncthreads();
-    STAMP(1);
-
-    // ---- prologue 2 (256 threads): everything that depends on the inputs only, for all H steps, off
-    //      the recurrence's critical path: interpolate, add the shifted nominal, clip (-> u_run), the
-    //      MPPI control-cost correction and the input-only stage-cost terms (cc + ccrc).  Thread (trajectory
-    //      t % TRAJ, chunk t / TRAJ — lane and wave when TRAJ = 64) takes the contiguous steps [chunk*Hc,
-    //      (chunk+1)*Hc) so that u[h-1] is at hand (recomputed once per chunk).
-    //      ubuf receives u (MLP, GRU) or the force u_max*u (ODE).
-    //      ODE: done in two phases so that the recurrence wave waits for the first S1 steps' inputs only: phase A
-    //      (all four waves) prepares steps [0, S1); then wave 0 runs the recurrence over them while waves 1..3
-    //      prepare [S1, H) and are at the second barrier long before wave 0 gets there.
-    constexpr bool ODE = PRED == CTK_PRED_ODE;
-    const int S1 = ODE ? min(H, 16) : H;
-    float corr_keep = 0.0f;               // ODE: a wave's phase-A partial, carried into its phase-B sum
-    auto prologue2 = [&](int ptraj, int hbeg, int hend, int slot, float carry) {
-        const int pn = row0 + ptraj;
-        const bool pvalid = pn < a.N;
-        const float* my = tile + ptraj * ts;
-        const bool ident = a.identity_interp != 0;
-        auto input_at = [&](int h, int c, float& du) {
-            if (ident) {
-                du = my[h * C + c];                                   // period 1: the matrix is the identity
-            } else {
-                const int i0 = i0_s[h];                               // LDS broadcast reads
-                const int i1 = C == 1 ? i0 + 1 : min(i0 + 1, Pp - 1); // C == 1: column P is a zero pad
-                du = my[i0 * C + c] * w0_s[h] + my[i1 * C + c] * w1_s[h];   // Interpolator.py:97-106, per input channel
-            }
-            return fminf(fmaxf(un_s[h * C + c] + du, a.lo[c]), a.hi[c]);    // optimizer_mppi.py:186-187
-        };
-        const int h0 = hbeg, h1 = hend;
-        float corr = 0.0f, cin = 0.0f, dummy;
-        float uprev[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-            uprev[c] = (h0 == 0 || h0 >= H) ? (a.u_prev_dev ? a.u_prev_dev[c] : a.u_prev[c]) : input_at(h0 - 1, c, dummy);
-#pragma unroll 2
-        for (int h = h0; h < h1; ++h) {
-            float u[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                float du;
-                u[c] = input_at(h, c, du);
-                corr += m.cc * (m.k_dd * (du * du) + m.R * u[c] * du + m.k_uu * (u[c] * u[c]));   // :154-155, summed over h and c
-            }
-            cin += E::input_cost(k, u, uprev);
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                uprev[c] = u[c];
-                ubuf[ptraj * us + h * C + c] = (PRED == CTK_PRED_ODE) ? E::prep_input(k, u[c], c) : u[c];
-                if constexpr (LOG) {
-                    if (pvalid) a.Q_out[(size_t)pn * HC + h * C + c] = u[c];
-                }
-            }
-        }
-        // mean over H+1 applies to the stage costs, not to the MPPI correction (optimizer_mppi.py:158-161)
-        const float part = carry + (corr + cin * a.inv_Hp1);
-        if (slot >= 0) corr_s[slot * TRAJ + ptraj] = part;
-        return part;
-    };
-    if constexpr (ODE) {
-        const int Ha = (S1 + MPPI_WAVES - 1) / MPPI_WAVES;                       // phase A: wave w takes [w*Ha, (w+1)*Ha) of [0, S1)
-        corr_keep = prologue2(lane, min(S1, wave * Ha), min(S1, wave * Ha + Ha), wave == 0 ? 0 : -1, 0.0f);
-    } else {
-        const int Hc = (H + CHUNKS - 1) / CHUNKS, chunk = t / TRAJ;
-        prologue2(t % TRAJ, min(H, chunk * Hc), min(H, chunk * Hc + Hc), chunk, 0.0f);
-    }
-    __syncthreads();
-    STAMP(2);
-
-    // ---- the recurrence --------------------------------------------------------------------------
-    float J = 0.0f;
-    if constexpr (PRED == CTK_PRED_ODE) {
-        // wave 0 only: one trajectory per lane, state in registers, through the environment's cost_step
-        const float* myF = ubuf + lane * us;
-        float sx[S];
-#pragma unroll
-        for (int i = 0; i < S; ++i) sx[i] = a.s0[i];
-        float csum = 0.0f, amax = 0.0f;
-        float* traj = nullptr;
-        if constexpr (LOG) {
-            if (a.traj_out) traj = a.traj_out + (size_t)n * (H + 1) * S;
-        }
-        const bool single = E::fast_ok(k);
-        if (wave == 0) {                           // steps [0, S1) while the others prepare [S1, H)
-            if (single) recur_env_range<ENV, LOG, true>(k, traj, valid, myF, 0, S1, sx, csum, amax);
-        } else {
-            const int Hb = (H - S1 + MPPI_WAVES - 2) / (MPPI_WAVES - 1);        // phase B: wave w takes its third of [S1, H)
-            prologue2(lane, min(H, S1 + (wave - 1) * Hb), min(H, S1 + (wave - 1) * Hb + Hb), wave, corr_keep);
-        }
-        __syncthreads();                           // waves 1..3 have been waiting here since ~step 4 of wave 0
-        if (wave == 0) {
-            if (single) {
-                recur_env_range<ENV, LOG, true>(k, traj, valid, myF, S1, H, sx, csum, amax);
-                if constexpr (LOG) {
-                    if (valid && traj) store_state<S>(traj + (size_t)H * S, sx);
-                }
-                J = csum + E::terminal_cost(k, sx);
-            }
-#ifndef CTK_DIAG_NO_COLD
-            // Euler sub-steps (intermediate_steps > 1), or an angle beyond the fast sincos range somewhere in the
-            // wave (~never): the whole horizon with the checked sincos, all inputs being ready by now
-            if (!single || __builtin_expect(__builtin_amdgcn_ballot_w64(E::out_of_range(amax)) != 0, 0)) {
-#pragma unroll
-                for (int i = 0; i < S; ++i) sx[i] = a.s0[i];
-                csum = 0.0f;
-                recur_env_range<ENV, LOG, false>(k, traj, valid, myF, 0, H, sx, csum, amax);
-                if constexpr (LOG) {
-                    if (valid && traj) store_state<S>(traj + (size_t)H * S, sx);
-                }
-                J = csum + E::terminal_cost(k, sx);
-            }
-#endif
-            J *= a.inv_Hp1;
-        }
-    } else if constexpr (PRED == CTK_PRED_MLP) {
-        // all four waves: 16 trajectories each on the fp32 matrix cores (ctk_mlp.h)
-        const int tr = wave * CTK_MLP_TRAJ_PER_WAVE + (lane & 15);
-        const float* myu = ubuf + tr * us;
-        const MlpFwdT w = mlp_load_fwd_thin(wperm);
-        const float Jw = rollout_mlp<false, LOG, false>(a, k, w, row0 + wave * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return myu[h]; });
-        if (lane < 16) e_s[tr] = Jw;          // hand the 64 costs to wave 0 (e_s doubles as J scratch)
-        __syncthreads();
-        if (wave == 0) J = e_s[lane];
-        __syncthreads();
-    } else if constexpr (PRED == CTK_PRED_MLP_PAIR) {
-        // waves (2p, 2p+1) share tile p of the workgroup's two (ctk_mlp.h: mlp_step_pair)
-        const int pair = wave >> 1, half = wave & 1;
-        const int tr = pair * CTK_MLP_TRAJ_PER_WAVE + (lane & 15);
-        const float* myu = ubuf + tr * us;
-        const MlpFwdHalf w = mlp_half_of(mlp_load_fwd_thin(wperm), half);
-        float* ex = gru_ex + pair * MLP_PAIR_EX;           // the exchange slots follow the rollout carve
-        float amax;
-        float Jw = rollout_mlp_pair_impl<false, LOG, false, false>(a, k, w, row0 + pair * CTK_MLP_TRAJ_PER_WAVE, half, ex, [&](int h) { return myu[h]; }, &amax);
-        // an angle beyond the unchecked cos's range anywhere in the WORKGROUP (never in practice): all waves redo, checked
-        if (__builtin_expect(__syncthreads_or(!(amax <= CTK_SINCOS_FAST_LIMIT)), 0))
-            Jw = rollout_mlp_pair_impl<false, LOG, false, true>(a, k, w, row0 + pair * CTK_MLP_TRAJ_PER_WAVE, half, ex, [&](int h) { return myu[h]; }, &amax);
-        if (half == 0 && lane < 16) e_s[tr] = Jw;
-        __syncthreads();
-        if (wave == 0) J = e_s[lane & (TRAJ - 1)];
-        __syncthreads();
-    } else {
-        // the four waves share the workgroup's 16 trajectories (ctk_gru.h); wave 0 ends with J of trajectory
-        // lane & 15 in every lane, i.e. lane = trajectory for lanes 0..15
-        const float* myu = ubuf + (lane & 15) * us;
-        J = rollout_gru<LOG, false>(a, k, wperm, wperm + GRU_TABLE_FLOATS, gru_ex, row0, [&](int h) { return myu[h]; });
-    }
-    if (wave == 0) {
-        if constexpr (TRAJ == MPPI_TRAJ) {
-            J += (corr_s[lane] + corr_s[TRAJ + lane]) + (corr_s[2 * TRAJ + lane] + corr_s[3 * TRAJ + lane]);
-        } else {
-            float cs = 0.0f;
-#pragma unroll
-            for (int cnk = 0; cnk < CHUNKS; ++cnk) cs += corr_s[cnk * TRAJ + (lane & (TRAJ - 1))];
-            J += cs;
-        }
-        STAMP(3);
-        if (valid) a.J[n] = J;
-        // block-local soft-min partial (optimizer_mppi.py:163-168 restricted to this block)
-        const float rho = wave_min(valid ? J : INFINITY);
-        const float e = valid ? expf(m.neg_inv_lbd * (J - rho)) : 0.0f;
-        const float asum = wave_sum(e);
-        if (lane < TRAJ) e_s[lane] = e;
-        if (lane == 0) {
-            if (use_ll) {
-                unsigned long long* rl = fz.ll + (size_t)blockIdx.x * (2 + P);
-                ll_store(rl, rho, fz.up.seq); ll_store(rl + 1, asum, fz.up.seq);
-            } else {
-                float* rec = parts + (size_t)blockIdx.x * (2 + P);
-                st_rec(rec, rho); st_rec(rec + 1, asum);
-            }
-        }
-    }
-    __syncthreads();
-    STAMP(4);
-
-    // ---- epilogue (256 threads): b_b[p] = sum_r e_r * tile[r][p]; wave w sums rows RPW*w..RPW*w+RPW-1 ----
-    for (int p = lane; p < P; p += 64) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) acc += e_s[wave * RPW + r] * tile[(wave * RPW + r) * ts + p];
-        col_s[wave * P + p] = acc;
-    }
-    __syncthreads();
-    float* rec = parts + (size_t)blockIdx.x * (2 + P);
-    for (int p = t; p < P; p += MPPI_BLOCK) {
-        const float v = (col_s[p] + col_s[P + p]) + (col_s[2 * P + p] + col_s[3 * P + p]);
-        if (use_ll) ll_store(fz.ll + (size_t)blockIdx.x * (2 + P) + 2 + p, v, fz.up.seq);
-        else st_rec(rec + 2 + p, v);
-    }
-    STAMP(5);
-
-    // ---- fused tail, low-latency form: block 0 polls every record word until it carries this launch's sequence
-    //      number (the words ARE the data), staging them in LDS, then merges.  One memory round trip after the
-    //      slowest block's stores instead of three (drain stores / ticket / fetch).  The other blocks are done.
-    //      Every block of the grid finishes unconditionally, so the wait terminates; it is bounded anyway.
-    if (use_ll) {
-        if (blockIdx.x == 0) {
-            __syncthreads();                      // col_s / tile are dead: the merge scratch may overwrite them
-            const int nb = (int)gridDim.x, tot = nb * (2 + P);
-            float* st = merge_stage_ptr(lds, nb, P);
-            bool expired = false;                 // a bounded poll ran out: surfaced to the host through the error word
-            constexpr int LLW = 8;                // words in flight per thread: the first pass over a thread's words is
-            for (int i0 = t; i0 < tot; i0 += MPPI_BLOCK * LLW) {   // one pipelined batch of loads, not LLW round trips
-                unsigned long long w[LLW];
-#pragma unroll
-                for (int j = 0; j < LLW; ++j) {
-                    const int i = i0 + j * MPPI_BLOCK;
-                    if (i < tot) w[j] = __hip_atomic_load(fz.ll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#pragma unroll
-                for (int j = 0; j < LLW; ++j) {
-                    const int i = i0 + j * MPPI_BLOCK;
-                    if (i < tot) {
-                        for (int spin = 0; (uint32_t)(w[j] >> 32) != fz.up.seq && spin < (1 << 22); ++spin) {
-                            __builtin_amdgcn_s_sleep(1);
-                            w[j] = __hip_atomic_load(fz.ll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        const bool got = (uint32_t)(w[j] >> 32) == fz.up.seq;
-                        expired |= !got;
-                        st[i] = got ? __builtin_bit_cast(float, (uint32_t)w[j]) : __builtin_nanf("");
-                    }
-                }
-            }
-            // ctk_api.hip:finish_step turns a non-zero error word (the dword behind {u, seq}) into CTK_ERR_STATE
-            if (expired && fz.up.u_host)
-                __hip_atomic_store(reinterpret_cast<uint32_t*>(fz.up.u_host) + 2, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __syncthreads();
-            const size_t scratch_floats = 8 + P + 1 + min(nb, MERGE_CHUNK) + (size_t)tot;
-            if (scratch_floats <= (size_t)(w0_s - lds)) { fz.up.w0_l = w0_s; fz.up.w1_l = w1_s; fz.up.un_l = un_s; fz.up.i0_l = i0_s; }
-            if (fz.mode == 1) mppi_merge_block<true, 0, C>(lds, nullptr, nb, P, m.neg_inv_lbd, nullptr, fz.up, 2);
-            else mppi_merge_block<false, 0, C>(lds, nullptr, nb, P, m.neg_inv_lbd, fz.out_rec, fz.up, 2);
-            if constexpr (P2P) {
-                // sharded step over peer-to-peer stores, all in this launch: the shard's record (just written to
-                // fz.out_rec = this rank's slot of its own exchange buffer by this block) goes to every peer, their
-                // records arrive, merge, update (ctk_mppi_p2p_exchange's body)
-                __shared__ int bad;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record's stores have landed
-                __syncthreads();
-                P2PArgs x = *fz.p2p;
-                x.seq = fz.p2p_seq;
-                const size_t scratch_w = 8 + P + 1 + min(x.world, MERGE_CHUNK) + (size_t)x.world * (2 + P);
-                if (scratch_w > (size_t)(w0_s - lds)) { fz.up.w0_l = nullptr; fz.up.w1_l = nullptr; fz.up.un_l = nullptr; fz.up.i0_l = nullptr; }
-                p2p_exchange_and_update(lds, &bad, x, P, m.neg_inv_lbd, fz.up, 1);
-            }
-        }
-        STAMP(6);
-        kernarg_prefetch_sink(ka_sink, parts);
-        return;
-    }
-
-    // ---- fused tail: hand-off of the block records inside the launch (cdna_hip_programming.md G16,
-    //      sc1 form: every record store above is a write-through agent-scope store, every storing wave
-    //      drains its stores, the workgroup meets, ONE lane takes a ticket; the block that drew the last
-    //      ticket reads every record with sc1 loads).  Placement-independent.
-    if (fz.mode != 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int* last_s = reinterpret_cast<int*>(lds);
-        if (t == 0) {
-            const unsigned ticket = __hip_atomic_fetch_add(fz.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *last_s = (ticket == gridDim.x - 1) ? 1 : 0;
-        }
-        __syncthreads();
-        const bool last = *last_s != 0;
-        __syncthreads();
-        if (last) {
-            // the merge scratch grows from lds[0]; the per-step tables at the end of the carve stay intact
-            // whenever the scratch ends below them
-            const size_t scratch_floats = 8 + P + 1 + min((int)gridDim.x, MERGE_CHUNK) + (fz.stage_ok ? (size_t)gridDim.x * (2 + P) : 0);
-            if (scratch_floats <= (size_t)(w0_s - lds)) { fz.up.w0_l = w0_s; fz.up.w1_l = w1_s; fz.up.un_l = un_s; fz.up.i0_l = i0_s; }
-            if (fz.mode == 1) mppi_merge_block<true, 1, C>(lds, parts, (int)gridDim.x, P, m.neg_inv_lbd, nullptr, fz.up, fz.stage_ok != 0 ? 1 : 0);
-            else mppi_merge_block<false, 1, C>(lds, parts, (int)gridDim.x, P, m.neg_inv_lbd, fz.out_rec, fz.up, fz.stage_ok != 0 ? 1 : 0);
-            if (t == 0) __hip_atomic_store(fz.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    STAMP(6);
-    kernarg_prefetch_sink(ka_sink, parts);
+#include "ctk_mppi_body.inc"
 }
 
 // ---------------------------------------------------------------------------------------------
