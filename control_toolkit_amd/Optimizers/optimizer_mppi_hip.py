@@ -25,6 +25,9 @@ class optimizer_mppi_hip(template_optimizer):
         self._SQRTRHOINV = SQRTRHOINV
         self.period_interpolation_inducing_points = period_interpolation_inducing_points
         self.global_rollout_offset = int(kwargs.get("global_rollout_offset", 0))
+        # optional key of the optimizer entry (swallowed by **kwargs in the reference's constructors): resident_idle_us > 0 serves the steps
+        # from a kernel that stays on the device (include/ctk_hip.h: ctk_resident_*); it leaves by itself after that long without a step
+        self.resident_idle_us = float(kwargs.get("resident_idle_us", 0.0) or 0.0)
 
     def configure(self, num_states: int, num_control_inputs: int, dt: float, predictor_specification: str, **kwargs):
         super().configure(num_states=num_states, num_control_inputs=num_control_inputs, default_configure=False)
@@ -33,6 +36,8 @@ class optimizer_mppi_hip(template_optimizer):
                            period_interpolation_inducing_points=self.period_interpolation_inducing_points,
                            global_rollout_offset=self.global_rollout_offset)
         self.number_of_interpolation_inducing_points = self.engine.inducing_points()
+        if self.resident_idle_us > 0.0:
+            self.engine.resident_enable(True, self.resident_idle_us)
         self.optimizer_reset()
 
     def step(self, s: np.ndarray, time=None):

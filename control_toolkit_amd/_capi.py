@@ -116,6 +116,9 @@ SYMBOLS = {
     "ctk_log_enable": (C.c_int, [_H, C.c_size_t]),
     "ctk_log_count": (C.c_size_t, [_H]),
     "ctk_log_read": (C.c_int, [_H, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ctk_resident_enable": (C.c_int, [_H, C.c_int, C.c_double]),
+    "ctk_resident_stop": (C.c_int, [_H]),
+    "ctk_resident_stats": (C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 
 
@@ -144,7 +147,7 @@ def load_library():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.ctk_abi_version() != 4:
+    if lib.ctk_abi_version() != 5:
         raise CtkError("libctk_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -467,6 +470,20 @@ class CtkEngine:
         if name == "BEST_IDX":
             return out.astype(np.int64)
         return out.reshape(shapes[name])
+
+    # resident MPPI step (include/ctk_hip.h: ctk_resident_*): the first step launches a kernel that stays on the device and serves the
+    # following steps from a pinned mailbox; it leaves by itself after idle_us without a request, and at once on resident_stop() or any
+    # other call that touches device state
+    def resident_enable(self, on: bool = True, idle_us: float = 200.0):
+        self._check(self._lib.ctk_resident_enable(self._h, 1 if on else 0, float(idle_us)))
+
+    def resident_stop(self):
+        self._check(self._lib.ctk_resident_stop(self._h))
+
+    def resident_stats(self) -> dict:
+        a, b, r, m = C.c_uint64(0), C.c_uint64(0), C.c_int(0), C.c_int(0)
+        self._check(self._lib.ctk_resident_stats(self._h, C.byref(a), C.byref(b), C.byref(r), C.byref(m)))
+        return {"launches": int(a.value), "steps": int(b.value), "running": bool(r.value), "mailbox": "device memory" if m.value else "pinned host memory"}
 
     # device-resident step log (include/ctk_hip.h: ctk_log_*)
     def log_enable(self, capacity_steps: int):

@@ -1,6 +1,7 @@
 // ctk_api.hip — the C ABI of libctk_hip.so (include/ctk_hip.h): handle, device state, step
 // sequencing.  All compute is in the HIP kernels; there is no CPU fallback.
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -107,6 +108,20 @@ struct ctk_handle {
     std::string err;
     std::string dominant;
     const char* dominant_ran = nullptr;   // name the MPPI launcher reported last (kernel choice depends on the sample mode)
+    // the resident form (ctk_resident_enable): mailbox in pinned host memory, relay in device memory
+    bool res_enabled = false, res_running = false;
+    double res_idle_us = 200.0;
+    CtkResidentBox* res_box = nullptr;    // what the host stores requests into: fine-grained device memory through the BAR (res_local) or pinned host memory
+    CtkResidentBox* res_box_dev = nullptr;   // the same memory as the kernel addresses it
+    bool res_local = false;
+    CtkResidentStat* res_stat = nullptr;  // pinned host memory: what the kernel reports
+    CtkResidentStat* res_stat_dev = nullptr;
+    CtkResidentBox* d_res_relay = nullptr;
+    void* d_res_args = nullptr;           // the resident kernel's argument block (device) and its staging copy
+    alignas(16) unsigned char res_args_host[CTK_RES_ARGS_BYTES];
+    uint32_t res_req = 0;                 // last request number issued
+    uint32_t res_relay_prime[2] = {0, 0}; // staging words of the copy that primes the relay before a launch
+    uint64_t res_launches = 0, res_steps = 0;
 };
 
 namespace {
@@ -546,6 +561,90 @@ int guarded(ctk_handle* h, F&& body) {
     if (rc != CTK_OK && h->seq == seq0) ++h->seq;
     return rc;
 }
+
+// ---- the resident form of the MPPI step (ctk_mppi.hip: ctk_mppi_resident) -------------------------------------------------------
+// Ends a running resident kernel at once (cmd = EXIT) and waits for it; every API entry other than ctk_step does this first, so that
+// nothing is ever queued behind it and nothing reads state it is still writing.
+int resident_quiesce(ctk_handle* h) {
+    if (!h->res_running) return CTK_OK;
+    if (__atomic_load_n(&h->res_stat->state, __ATOMIC_ACQUIRE) != CTK_RES_LEFT) {
+        volatile CtkResidentBox* b = h->res_box;
+        b->cmd = CTK_RES_CMD_EXIT;
+        __builtin_ia32_sfence();                         // (write-combined stores into device memory: payload before the number)
+        b->req = ++h->res_req;
+        __builtin_ia32_sfence();
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));       // bounded on the device side: the kernel leaves on EXIT, or after its idle time-out
+    h->res_running = false;
+    return CTK_OK;
+}
+
+bool resident_ok(const ctk_handle* h, int samples_loc) {
+    return h->res_enabled && !h->mppi_pending && samples_loc != CTK_LOC_HOST && h->log_cap == 0 && !h->prof;
+}
+
+int resident_launch(ctk_handle* h, uint32_t first_req) {
+    float zs[CTK_MAX_STATES] = {};
+    RolloutArgs a = make_args(h, zs, nullptr, h->N, h->P);      // per-step fields come from the mailbox; u_prev_dev = d_u stays
+    MppiFuse fz;
+    fz.mode = 1; fz.ll = h->d_ll; fz.u_dev = h->d_u; fz.u_host = h->h_u_dev;
+    __atomic_store_n(&h->res_stat->state, (uint32_t)CTK_RES_RUNNING, __ATOMIC_RELEASE);
+    // the relay as the new session expects it: request number = the last one served, cmd = STEP (a session that left has raised EXIT there)
+    h->res_relay_prime[0] = first_req - 1u; h->res_relay_prime[1] = CTK_RES_CMD_STEP;
+    HIP_TRY(h, hipMemcpyAsync(h->d_res_relay, h->res_relay_prime, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, ctk_launch_mppi_resident(h->stream, h->env, h->params, h->cfg.dt, h->cfg.intermediate_steps, a, h->mk, h->d_unom[0], h->d_unom[1],
+                                        h->d_parts, fz, h->res_box_dev, h->res_local ? 1 : 0, h->res_stat_dev, h->d_res_relay, h->res_idle_us, first_req, h->d_res_args, h->res_args_host));
+    h->res_running = true;
+    ++h->res_launches;
+    h->dominant = ctk_mppi_resident_name(h->env);
+    return CTK_OK;
+}
+
+// one MPPI step through the mailbox; samples: device pointer or nullptr (in-kernel sampler)
+int resident_step(ctk_handle* h, const float* s, const float* u_prev, const float* d_samples, float* u_out) {
+    volatile CtkResidentBox* b = h->res_box;
+    CtkResidentStat* st = h->res_stat;
+    if (h->res_running && __atomic_load_n(&st->state, __ATOMIC_ACQUIRE) == CTK_RES_LEFT) {      // it timed out idle since the last step
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->res_running = false;
+    }
+    const uint32_t req = h->res_req + 1;
+    if (!h->res_running) if (int rc = resident_launch(h, req)) return rc;
+    b->cmd = CTK_RES_CMD_STEP; b->seq = h->seq; b->call = h->call; b->cur = (uint32_t)h->cur; b->dev_uprev = u_prev ? 0u : 1u;
+    b->samples = d_samples;
+    for (int i = 0; i < h->S; ++i) b->s[i] = s[i];
+    for (int c = 0; c < h->C; ++c) b->u_prev[c] = u_prev ? u_prev[c] : 0.0f;
+    __builtin_ia32_sfence();                                    // payload before the number (write-combined stores when the box is device memory)
+    b->req = req;
+    __builtin_ia32_sfence();
+    h->res_req = req;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    const uint32_t want = h->seq;
+    volatile uint32_t* slot = reinterpret_cast<volatile uint32_t*>(h->h_u) + 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spin = 0;; ++spin) {
+        if (*slot == want) break;
+        if ((spin & 63) == 63) {
+            if (__atomic_load_n(&st->state, __ATOMIC_ACQUIRE) == CTK_RES_LEFT && *slot != want) {
+                // the kernel left without taking this request (idle time-out raced the request, or a device-side wait ran out): launch anew
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                h->res_running = false;
+                if (*slot == want) break;
+                if (int rc = resident_launch(h, req)) return rc;   // first_req = this request: it is served at once
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
+                (void)resident_quiesce(h);
+                return fail(h, CTK_ERR_HIP, "resident step: no result within 5 s");
+            }
+        }
+        __builtin_ia32_pause();
+    }
+    ++h->res_steps;
+    h->cur ^= 1;
+    return finish_step(h, u_out);        // sees the result at once; error word, sequence / Philox counters as for a launched step
+}
+
+#define RES_Q(h) do { if ((h) != nullptr && (h)->res_running) { const int _q = resident_quiesce(h); if (_q != CTK_OK) return _q; } } while (0)
 
 int check_predictor(ctk_handle* h) {
     if (h->cfg.predictor != CTK_PRED_ODE && !h->have_weights)
@@ -1149,6 +1248,11 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
 void ctk_destroy(ctk_handle* h) {
     if (!h) return;
     hipSetDevice(h->cfg.device);
+    (void)resident_quiesce(h);
+    if (h->res_box) { if (h->res_local) hipFree(h->res_box); else hipHostFree(h->res_box); }
+    if (h->res_stat) hipHostFree(h->res_stat);
+    if (h->d_res_relay) hipFree(h->d_res_relay);
+    if (h->d_res_args) hipFree(h->d_res_args);
     hipStreamSynchronize(h->stream);   // also correct for the null (default) stream handed in by ctk_set_stream
     for (auto& e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     void* bufs[] = {h->d_interp, h->d_samples, h->d_J, h->d_Q, h->d_traj, h->d_parts, h->d_parts2, h->d_parts3, h->d_unom[0], h->d_unom[1],
@@ -1164,6 +1268,7 @@ void ctk_destroy(ctk_handle* h) {
 }
 
 int ctk_set_stream(ctk_handle* h, void* hip_stream) {
+    RES_Q(h);
     if (!h) return CTK_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->own_stream && h->stream) HIP_TRY(h, hipStreamDestroy(h->stream));
@@ -1173,6 +1278,7 @@ int ctk_set_stream(ctk_handle* h, void* hip_stream) {
 }
 
 int ctk_reset(ctk_handle* h, const float* draws, int draws_loc) {
+    RES_Q(h);
     if (!h) return CTK_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     float mid[CTK_MAX_INPUTS], span[CTK_MAX_INPUTS];
@@ -1200,6 +1306,7 @@ int ctk_reset(ctk_handle* h, const float* draws, int draws_loc) {
 }
 
 int ctk_set_param(ctk_handle* h, int id, float value) {
+    RES_Q(h);
     if (!h) return CTK_ERR_INVALID_ARGUMENT;
     if (id < 0 || id >= env_info(h->env)->n_params) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_set_param: unknown parameter id for this environment");
     if (h->mppi_pending) return fail(h, CTK_ERR_STATE, "ctk_set_param: illegal between step_begin and step_end");
@@ -1236,6 +1343,7 @@ const char* ctk_environment_name(int environment) {
 size_t ctk_predictor_weight_count(const ctk_handle* h) { return h ? weight_count(h->cfg.predictor, h->S, h->C) : 0; }
 
 int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n) {
+    RES_Q(h);
     if (!h || !w) return CTK_ERR_INVALID_ARGUMENT;
     if (h->cfg.predictor == CTK_PRED_ODE) return fail(h, CTK_ERR_STATE, "ctk_set_predictor_weights: the ODE predictor has no weights");
     const bool gru = h->cfg.predictor == CTK_PRED_GRU;
@@ -1262,6 +1370,7 @@ int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n) {
 size_t ctk_predictor_hidden_size(const ctk_handle* h) { return (h && h->cfg.predictor == CTK_PRED_GRU) ? (size_t)GRU_HIDDEN_FLOATS : 0; }
 
 int ctk_predictor_update(ctk_handle* h, const float* s, const float* u) {
+    RES_Q(h);
     if (!h || !s) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_predictor_update: NULL state") : CTK_ERR_INVALID_ARGUMENT;
     if (h->cfg.predictor != CTK_PRED_GRU) return CTK_OK;   // predictor.update is a no-op for stateless predictors
     if (int rc = check_predictor(h)) return rc;
@@ -1270,6 +1379,7 @@ int ctk_predictor_update(ctk_handle* h, const float* s, const float* u) {
 }
 
 int ctk_predictor_get_hidden(ctk_handle* h, float* dst, size_t cap) {
+    RES_Q(h);
     if (!h || !dst) return CTK_ERR_INVALID_ARGUMENT;
     if (h->cfg.predictor != CTK_PRED_GRU) return fail(h, CTK_ERR_STATE, "ctk_predictor_get_hidden: predictor has no hidden state");
     if (cap < (size_t)GRU_HIDDEN_FLOATS) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_predictor_get_hidden: need room for 64 floats");
@@ -1280,6 +1390,7 @@ int ctk_predictor_get_hidden(ctk_handle* h, float* dst, size_t cap) {
 }
 
 int ctk_predictor_set_hidden(ctk_handle* h, const float* src, size_t n) {
+    RES_Q(h);
     if (!h) return CTK_ERR_INVALID_ARGUMENT;
     if (h->cfg.predictor != CTK_PRED_GRU) return fail(h, CTK_ERR_STATE, "ctk_predictor_set_hidden: predictor has no hidden state");
     if (src && n != (size_t)GRU_HIDDEN_FLOATS) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_predictor_set_hidden: expected 64 floats");
@@ -1314,6 +1425,12 @@ int ctk_step(ctk_handle* h, const float* s, const float* u_prev, const float* sa
     switch (h->cfg.optimizer) {
         case CTK_OPT_MPPI: {
             for (int i = 0; i < h->S; ++i) h->mppi_s[i] = s[i];
+            if (resident_ok(h, samples_loc)) {   // opt-in: the step is served by the kernel that stays on the device
+                const float* d_s = nullptr;
+                if (int rc = resolve_samples(h, samples, samples_loc, (size_t)h->N * h->PC, &d_s)) return rc;
+                return resident_step(h, s, u_prev, d_s, u_out);
+            }
+            if (int rc = resident_quiesce(h)) return rc;
             if (mppi_can_fuse(h)) {   // one launch: the last block to finish merges and updates
                 if (int rc = mppi_rollout(h, s, u_prev, samples, samples_loc, 1, nullptr)) return rc;
                 h->cur ^= 1;
@@ -1337,6 +1454,7 @@ size_t ctk_mppi_partial_size(const ctk_handle* h) { return h ? (size_t)(2 + h->P
 
 int ctk_mppi_step_begin(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int samples_loc,
                         float* partial_dev) {
+    RES_Q(h);
     if (!h || !s || !partial_dev) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_mppi_step_begin: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
     return guarded(h, [&]() -> int {
     if (h->cfg.optimizer != CTK_OPT_MPPI) return fail(h, CTK_ERR_STATE, "ctk_mppi_step_begin: handle is not MPPI");
@@ -1357,6 +1475,7 @@ int ctk_mppi_step_begin(ctk_handle* h, const float* s, const float* u_prev, cons
 }
 
 int ctk_mppi_step_end(ctk_handle* h, const float* parts_dev, int n_parts, float* u_out) {
+    RES_Q(h);
     if (!h || !parts_dev || n_parts < 1) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_mppi_step_end: bad argument") : CTK_ERR_INVALID_ARGUMENT;
     return guarded(h, [&]() -> int {
     if (!h->mppi_pending) return fail(h, CTK_ERR_STATE, "ctk_mppi_step_end: no sharded step pending");
@@ -1380,6 +1499,7 @@ int ctk_shard_iterations(const ctk_handle* h) {
 }
 
 int ctk_shard_iter_begin(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int samples_loc, float* cand_dev) {
+    RES_Q(h);
     if (!h || !s || !cand_dev) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_shard_iter_begin: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
     return guarded(h, [&]() -> int {
     const bool cem = h->cfg.optimizer == CTK_OPT_CEM;
@@ -1403,6 +1523,7 @@ int ctk_shard_iter_begin(ctk_handle* h, const float* s, const float* u_prev, con
 }
 
 int ctk_shard_iter_end(ctk_handle* h, const float* cands_all_dev, int n_ranks) {
+    RES_Q(h);
     if (!h || !cands_all_dev || n_ranks < 1) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_shard_iter_end: bad argument") : CTK_ERR_INVALID_ARGUMENT;
     return guarded(h, [&]() -> int {
     if (!h->shard_pending) return fail(h, CTK_ERR_STATE, "ctk_shard_iter_end: no iteration pending");
@@ -1427,6 +1548,7 @@ int ctk_shard_iter_end(ctk_handle* h, const float* cands_all_dev, int n_ranks) {
 }
 
 int ctk_shard_finish(ctk_handle* h, float* u_out) {
+    RES_Q(h);
     if (!h) return CTK_ERR_INVALID_ARGUMENT;
     return guarded(h, [&]() -> int {
     if (h->shard_pending || h->shard_it == 0 || !h->shard_last_cands) return fail(h, CTK_ERR_STATE, "ctk_shard_finish: no completed iteration");
@@ -1464,6 +1586,7 @@ size_t ctk_rpgd_fresh_rows(const ctk_handle* h, int n_ranks) {
 }
 
 int ctk_rpgd_step_begin(ctk_handle* h, const float* s, const float* u_prev, float* keep_dev) {
+    RES_Q(h);
     if (!h || !s || !keep_dev) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_rpgd_step_begin: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
     return guarded(h, [&]() -> int {
     if (h->cfg.optimizer != CTK_OPT_RPGD || h->variant != CTK_OPT_RPGD) return fail(h, CTK_ERR_STATE, "ctk_rpgd_step_begin: handle is not RPGD");
@@ -1485,6 +1608,7 @@ int ctk_rpgd_step_begin(ctk_handle* h, const float* s, const float* u_prev, floa
 }
 
 int ctk_rpgd_step_end(ctk_handle* h, const float* keep_all_dev, int n_ranks, const float* draws, int draws_loc, float* u_out) {
+    RES_Q(h);
     if (!h || !keep_all_dev || n_ranks < 1) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_rpgd_step_end: bad argument") : CTK_ERR_INVALID_ARGUMENT;
     return guarded(h, [&]() -> int {
     if (h->cfg.optimizer != CTK_OPT_RPGD || !h->shard_pending) return fail(h, CTK_ERR_STATE, "ctk_rpgd_step_end: no sharded RPGD step pending");
@@ -1519,6 +1643,7 @@ int ctk_rpgd_step_end(ctk_handle* h, const float* keep_all_dev, int n_ranks, con
 }
 
 int ctk_rollout(ctk_handle* h, const float* s, const float* u_prev, const float* Q, int n, float* traj_out, float* J_out) {
+    RES_Q(h);
     if (!h || !s || !Q) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_rollout: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
     if (n < 1 || n > h->N) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_rollout: need 1 <= n <= num_rollouts");
     if (int rc = check_predictor(h)) return rc;
@@ -1558,6 +1683,7 @@ int ctk_rollout(ctk_handle* h, const float* s, const float* u_prev, const float*
 }
 
 int ctk_read(ctk_handle* h, int which, float* dst, size_t cap, size_t* n_out) {
+    RES_Q(h);
     if (!h || !dst) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: NULL destination") : CTK_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const float* src = nullptr; size_t n = 0; bool is_int = false;
@@ -1583,6 +1709,7 @@ size_t ctk_state_size(const ctk_handle* h) {
 }
 
 int ctk_get_state(ctk_handle* h, float* dst, size_t cap) {
+    RES_Q(h);
     if (!h || !dst) return CTK_ERR_INVALID_ARGUMENT;
     const size_t n = ctk_state_size(h), H = h->HC, C = h->C;
     if (cap < n) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_get_state: destination too small");
@@ -1617,6 +1744,7 @@ int ctk_get_state(ctk_handle* h, float* dst, size_t cap) {
 }
 
 int ctk_set_state(ctk_handle* h, const float* src, size_t n) {
+    RES_Q(h);
     if (!h || !src) return CTK_ERR_INVALID_ARGUMENT;
     if (n != ctk_state_size(h)) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_set_state: wrong state size");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -1651,6 +1779,7 @@ int ctk_set_state(ctk_handle* h, const float* src, size_t n) {
 }
 
 int ctk_profile_enable(ctk_handle* h, int on) {
+    RES_Q(h);
     if (!h) return CTK_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (on && h->events.empty()) {
@@ -1665,6 +1794,7 @@ int ctk_profile_enable(ctk_handle* h, int on) {
 }
 
 int ctk_profile_read(ctk_handle* h, float* ms_out, size_t cap, size_t* n_out) {
+    RES_Q(h);
     if (!h || !ms_out) return CTK_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1678,6 +1808,7 @@ int ctk_profile_read(ctk_handle* h, float* ms_out, size_t cap, size_t* n_out) {
 const char* ctk_dominant_kernel(const ctk_handle* h) { return h ? h->dominant.c_str() : ""; }
 
 int ctk_p2p_close(ctk_handle* h) {
+    RES_Q(h);
     if (!h) return CTK_ERR_INVALID_ARGUMENT;
     if (h->p2p_world == 0) return CTK_OK;
     hipSetDevice(h->cfg.device);
@@ -1693,6 +1824,7 @@ int ctk_p2p_close(ctk_handle* h) {
 }
 
 int ctk_p2p_alloc(ctk_handle* h, int rank, int world, void* handle_out) {
+    RES_Q(h);
     if (!h || !handle_out) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_p2p_alloc: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
     if (h->cfg.optimizer != CTK_OPT_MPPI) return fail(h, CTK_ERR_STATE, "ctk_p2p_alloc: handle is not MPPI");
     if (h->generic) return fail(h, CTK_ERR_UNSUPPORTED, "ctk_p2p_alloc: the peer-to-peer exchange is built into the CartPole kernels only (use the begin / all-gather / end path)");
@@ -1716,6 +1848,7 @@ int ctk_p2p_alloc(ctk_handle* h, int rank, int world, void* handle_out) {
 }
 
 int ctk_p2p_connect(ctk_handle* h, const void* handles) {
+    RES_Q(h);
     if (!h || !handles) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_p2p_connect: NULL argument") : CTK_ERR_INVALID_ARGUMENT;
     if (h->p2p_world == 0) return fail(h, CTK_ERR_STATE, "ctk_p2p_connect: call ctk_p2p_alloc first");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -1739,6 +1872,7 @@ int ctk_p2p_connect(ctk_handle* h, const void* handles) {
 }
 
 int ctk_p2p_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int samples_loc, float* u_out) {
+    RES_Q(h);
     if (!h || !s) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_p2p_step: NULL state") : CTK_ERR_INVALID_ARGUMENT;
     return guarded(h, [&]() -> int {
     if (!h->p2p_connected) return fail(h, CTK_ERR_STATE, "ctk_p2p_step: call ctk_p2p_alloc and ctk_p2p_connect first");
@@ -1773,7 +1907,82 @@ int ctk_p2p_step(ctk_handle* h, const float* s, const float* u_prev, const float
     });
 }
 
+// ---- the resident form: opt-in per handle --------------------------------------------------------------------------------------------
+int ctk_resident_enable(ctk_handle* h, int on, double idle_us) {
+    if (!h) return CTK_ERR_INVALID_ARGUMENT;
+    RES_Q(h);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (!on) { h->res_enabled = false; return CTK_OK; }
+    if (h->cfg.optimizer != CTK_OPT_MPPI || h->cfg.predictor != CTK_PRED_ODE)
+        return fail(h, CTK_ERR_UNSUPPORTED, "ctk_resident_enable: MPPI with the analytic predictor only");
+    if (h->cfg.materialize_trajectories || ctk_mppi_uses_throughput_kernel(CTK_PRED_ODE, h->N) || !mppi_can_fuse(h) || h->d_ll == nullptr ||
+        ctk_mppi_rollout_env_lds(h->env, h->P, h->H, h->N) > 160 * 1024)
+        return fail(h, CTK_ERR_UNSUPPORTED, "ctk_resident_enable: needs the one-launch step with the {value, seq} hand-off (<= 128 workgroups, no materialised trajectories)");
+    if (!(idle_us >= 1.0 && idle_us <= 1.0e6)) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_resident_enable: idle_us must be within [1, 1e6]");
+    if (!h->res_box) {
+        HIP_TRY(h, hipHostMalloc((void**)&h->res_stat, sizeof(CtkResidentStat), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(h->res_stat, 0, sizeof(CtkResidentStat));
+        HIP_TRY(h, hipHostGetDevicePointer((void**)&h->res_stat_dev, h->res_stat, 0));
+        HIP_TRY(h, hipMalloc((void**)&h->d_res_relay, sizeof(CtkResidentBox)));
+        HIP_TRY(h, hipMalloc(&h->d_res_args, CTK_RES_ARGS_BYTES));
+        HIP_TRY(h, hipMemsetAsync(h->d_res_relay, 0, sizeof(CtkResidentBox), h->stream));
+        // the mailbox in device memory the HOST can store into (fine-grained allocation, reached through the PCIe BAR) — probed: a pattern
+        // stored by the host must read back through a device-side copy.  CTK_RES_HOST_MAILBOX forces the pinned-host fallback (A/B, tests)
+        void* vram = nullptr;
+        bool local = false;
+        if (!std::getenv("CTK_RES_HOST_MAILBOX") && hipExtMallocWithFlags(&vram, 4096, hipDeviceMallocFinegrained) == hipSuccess && vram) {
+            hipPointerAttribute_t at{};
+            if (hipMemset(vram, 0, 4096) == hipSuccess && hipDeviceSynchronize() == hipSuccess && hipPointerGetAttributes(&at, vram) == hipSuccess) {
+                volatile uint32_t* pv = static_cast<volatile uint32_t*>(vram);
+                for (int i = 0; i < 32; ++i) pv[i] = 0xC0DE0000u + (uint32_t)i;
+                __builtin_ia32_sfence();
+                uint32_t back[32] = {};
+                if (hipMemcpy(back, vram, sizeof(back), hipMemcpyDeviceToHost) == hipSuccess) {
+                    local = true;
+                    for (int i = 0; i < 32; ++i) local = local && back[i] == 0xC0DE0000u + (uint32_t)i;
+                }
+            }
+            if (!local) { (void)hipFree(vram); vram = nullptr; }
+        }
+        (void)hipGetLastError();
+        if (local) {
+            (void)hipMemset(vram, 0, 4096);
+            HIP_TRY(h, hipDeviceSynchronize());
+            h->res_box = static_cast<CtkResidentBox*>(vram); h->res_box_dev = h->res_box; h->res_local = true;
+        } else {
+            HIP_TRY(h, hipHostMalloc((void**)&h->res_box, sizeof(CtkResidentBox), hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(h->res_box, 0, sizeof(CtkResidentBox));
+            HIP_TRY(h, hipHostGetDevicePointer((void**)&h->res_box_dev, h->res_box, 0));
+            h->res_local = false;
+        }
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    h->res_idle_us = idle_us;
+    h->res_enabled = true;
+    return CTK_OK;
+}
+
+int ctk_resident_stop(ctk_handle* h) {
+    if (!h) return CTK_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    return resident_quiesce(h);
+}
+
+int ctk_resident_stats(const ctk_handle* h, uint64_t* launches, uint64_t* steps, int* running, int* mailbox_in_device_memory) {
+    if (!h) return CTK_ERR_INVALID_ARGUMENT;
+    if (h->res_stat && getenv("CTK_RES_TRACE"))
+        fprintf(stderr, "[ctk resident] mailbox in %s memory; last request: fetch%s %.2f us, block 0's step %.2f us\n", h->res_local ? "device" : "pinned host",
+                h->res_local ? "" : " + relay", h->res_stat->t_relay * 0.01, h->res_stat->t_body * 0.01);
+    if (launches) *launches = h->res_launches;
+    if (steps) *steps = h->res_steps;
+    if (running) *running = h->res_running ? 1 : 0;
+    if (mailbox_in_device_memory) *mailbox_in_device_memory = h->res_local ? 1 : 0;
+    return CTK_OK;
+}
+
+
 int ctk_log_enable(ctk_handle* h, size_t capacity_steps) {
+    RES_Q(h);
     if (!h) return CTK_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1795,6 +2004,7 @@ int ctk_log_enable(ctk_handle* h, size_t capacity_steps) {
 size_t ctk_log_count(const ctk_handle* h) { return h ? h->log_count : 0; }
 
 int ctk_log_read(ctk_handle* h, int which, size_t first_step, size_t n_steps, float* dst, size_t cap, size_t* n_out) {
+    RES_Q(h);
     if (!h || !dst) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_log_read: NULL destination") : CTK_ERR_INVALID_ARGUMENT;
     if (h->log_cap == 0) return fail(h, CTK_ERR_STATE, "ctk_log_read: logging is not enabled (ctk_log_enable)");
     const int ring = which == CTK_BUF_Q ? 0 : which == CTK_BUF_J ? 1 : which == CTK_BUF_TRAJ ? 2 : which == CTK_BUF_AGES ? 3 : -1;

@@ -44,6 +44,30 @@ bool ctk_mppi_fusable(int P, int blocks, bool have_ll);
 // From this many rollouts on (ODE predictor) the latency-oriented 4-wave block gives way to the
 // throughput-oriented single-wave block (half the LDS, 2x the resident recurrence waves per CU).
 constexpr int CTK_MPPI_THROUGHPUT_MIN_N = 32768;
+// The resident form's mailbox: one request per MPPI step, written by the HOST only — the payload first, then `req`.  Where it lives:
+// in fine-grained DEVICE memory that the host stores into through the PCIe BAR (posted writes + sfence; every workgroup then polls LOCAL
+// memory: no PCIe read on the request path), or — where the host cannot reach device memory — in pinned host memory, polled by ONE
+// workgroup that relays it to the others through device memory (`relay`).  What the DEVICE reports goes to CtkResidentStat in pinned host
+// memory.  ctk_mppi.hip: ctk_mppi_resident.
+enum { CTK_RES_CMD_STEP = 0, CTK_RES_CMD_EXIT = 1 };
+enum { CTK_RES_IDLE = 0, CTK_RES_RUNNING = 1, CTK_RES_LEAVING = 2, CTK_RES_LEFT = 3 };
+struct CtkResidentBox {
+    uint32_t req;                       // request number (monotonic within a handle); written LAST
+    uint32_t cmd;                       // CTK_RES_CMD_*
+    uint32_t seq;                       // the step's sequence number: tag of its record words and of {u, seq}
+    uint32_t call;                      // Philox position of the step (in-kernel sampler)
+    uint32_t cur;                       // which u_nom buffer holds the current plan
+    uint32_t dev_uprev;                 // 1: the previous input is the optimizer's own last output on the device (u_prev == NULL at the API)
+    const float* samples;               // this step's draws (device pointer), or nullptr
+    float s[CTK_MAX_STATES];
+    float u_prev[CTK_MAX_INPUTS];
+};
+struct CtkResidentStat {                // device -> host
+    uint32_t state;                     // CTK_RES_*
+    uint32_t served;                    // last request taken, written when the kernel leaves
+    uint32_t t_relay, t_body;           // diagnostics: wall-clock ticks (10 ns) block 0 spent fetching / relaying the last request, and in its step
+};
+
 struct MppiFuse {
     int mode = 0;              // 0 records only, 1 merge + update u_nom/u, 2 merge into ONE record (sharded step_begin),
                                // 3 = 2 + peer-to-peer exchange + update in the same launch (ctk_p2p_step)
@@ -65,6 +89,12 @@ hipError_t ctk_launch_mppi_rollout_env(hipStream_t st, int env, const float* par
                                        const float* samples, const float* u_nom, float* parts, bool log, const MppiFuse& fuse,
                                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 size_t ctk_mppi_rollout_env_lds(int env, int P, int H, int N);
+// the resident form of the same kernel (fuse mode 1 with the {value, seq} hand-off only): launched once, serves requests from `box`
+hipError_t ctk_launch_mppi_resident(hipStream_t st, int env, const float* params, float dt, int isteps, const RolloutArgs& a, const MppiK& m,
+                                    float* u_nom0, float* u_nom1, float* parts, const MppiFuse& fuse, const CtkResidentBox* box_dev, int box_local,
+                                    CtkResidentStat* stat_dev, CtkResidentBox* relay, double idle_us, uint32_t first_req, void* args_dev, void* args_host);
+constexpr size_t CTK_RES_ARGS_BYTES = 1024;   // device + host staging block for the resident kernel's argument struct
+const char* ctk_mppi_resident_name(int env);
 const char* ctk_mppi_rollout_env_name(int env, bool log);
 hipError_t ctk_launch_mppi_merge_partial(hipStream_t st, const float* parts, int n_parts, int per_block, int P,
                                          float neg_inv_lbd, float* out_rec);

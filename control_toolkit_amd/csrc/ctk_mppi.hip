@@ -164,6 +164,159 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_rollout(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------
+// The RESIDENT form (opt-in: ctk_resident_enable): the same step — the same statements, ctk_mppi_body.inc — served
+// by a kernel that stays on the device and takes its per-step inputs (state, previous input, sample pointer, sequence number, Philox
+// position, which u_nom buffer is current) from a MAILBOX instead of a launch: what a launch-per-step loop pays per step in the runtime
+// and the command processor is paid once.
+//   * the mailbox lives in fine-grained DEVICE memory that the host stores into through the PCIe BAR (posted writes): every workgroup
+//     polls local memory, and no PCIe READ is left on the request path (a read round trip is 1.4 - 5 us depending on the box,
+//     tools/diag_mailbox_vram.hip).  Where the host cannot reach device memory (ctk_api.hip probes it) the mailbox is pinned host memory:
+//     block 0 polls it — ONE poller: sixteen queue on the read path — fetches the request in one coalesced access and relays it through
+//     device memory.  Everything a step leaves for the next one (u_nom, u) is published by the step's closing fence and acquired with
+//     the next request;
+//   * every wait is bounded by the wall clock: no request for `idle_ticks` -> the kernel leaves (the next ctk_step launches it again);
+//     the other workgroups follow block 0 (its "left" flag) or give up after 4 x that.  It therefore never holds the device longer than
+//     idle_ticks beyond its last step — a device-wide synchronize of anybody else waits at most that long; ctk_resident_stop / every
+//     other API call on the handle ends it at once (cmd = EXIT);
+//   * leaving is announced (state = LEAVING, fence, re-read the request number; then LEFT as the kernel's last store).  A request that
+//     crosses the announcement in flight is either seen by the re-read and served, or lost with the kernel — the host sees LEFT while it
+//     waits for the result and launches the kernel again with that request as its first.
+// ---------------------------------------------------------------------------------------------
+CTK_DEV uint32_t box_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+CTK_DEV void box_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// what a launch passes as kernel arguments, in DEVICE memory here: as by-value kernel arguments these ~120 dwords stay live in SGPRs across
+// the request loop (218 spilled, read back lane by lane inside the recurrence: block 0's step 14.8 us); behind a pointer they are
+// scalar-loaded where a step needs them, as a launched kernel loads its kernarg segment
+template <class K>
+struct ResidentArgs {
+    const InterpEntry* interp;
+    float* parts;
+    int N, H, P;
+    uint32_t pmagic;
+    float* unom0;
+    float* unom1;
+    RolloutArgs base;
+    K k;
+    MppiK m;
+    FuseArgs fz0;
+};
+
+template <int ENV>
+__global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_resident(const ResidentArgs<typename Env<ENV>::K>* __restrict__ ra,
+                                                                const CtkResidentBox* box, int box_local, CtkResidentStat* stat, CtkResidentBox* relay,
+                                                                unsigned long long idle_ticks, uint32_t first_req) {
+    extern __shared__ float lds[];
+    __shared__ CtkResidentBox req_s;
+    uint32_t served = first_req - 1u;                 // request number of the last step this workgroup has taken
+    unsigned long long t_seen = 0, t_relayed = 0;
+    for (;;) {
+        // ---- the next request.  Wave 0: lane 0 polls ONE word; then the request is moved as a whole — its dwords by as many lanes in one
+        //      coalesced access (a dword at a time over PCIe is a round trip each: 24 us measured).  box_local: every workgroup reads the
+        //      box itself (device memory); else block 0 reads it (host memory) and relays it.  The relay's cmd word is also the "block 0 has
+        //      left" flag the other workgroups watch.
+        if (threadIdx.x < 64) {
+            constexpr int BOXW = (int)(sizeof(CtkResidentBox) / sizeof(uint32_t));
+            static_assert(BOXW <= 64 && offsetof(CtkResidentBox, req) == 0 && offsetof(CtkResidentBox, cmd) == 4, "request layout");
+            const int lane = threadIdx.x;
+            const unsigned long long t0 = wall_clock64();
+            int leave = 0, from_relay = 0;
+            uint32_t w = 0;
+            if (blockIdx.x == 0) {
+                if (lane == 0) {
+                    for (;;) {
+                        if (__hip_atomic_load(&box->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != served) break;
+                        if (wall_clock64() - t0 > idle_ticks) {          // nothing to do: leave, unless a request slips in right now
+                            box_store(&stat->state, CTK_RES_LEAVING);
+                            __threadfence_system();
+                            if (box_load(&box->req) != served) { box_store(&stat->state, CTK_RES_RUNNING); break; }
+                            leave = 1;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                leave = __builtin_amdgcn_readfirstlane(leave);
+                t_seen = wall_clock64();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");           // the payload was written before the number
+                if (!leave) {
+                    if (lane < BOXW) w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(box) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else {
+                    w = lane == 0 ? served + 1u : (lane == 1 ? (uint32_t)CTK_RES_CMD_EXIT : 0u);
+                }
+                if (lane < BOXW) reinterpret_cast<uint32_t*>(&req_s)[lane] = w;
+                if (!box_local || leave) {
+                    // hand it to the other workgroups; the release also publishes what the last step left (u_nom, u)
+                    if (lane != 0 && lane < BOXW) __hip_atomic_store(reinterpret_cast<uint32_t*>(relay) + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (lane == 0) __hip_atomic_store(&relay->req, w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                t_relayed = wall_clock64();
+            } else {
+                if (lane == 0) {
+                    leave = 1;
+                    for (;;) {
+                        if (box_local && __hip_atomic_load(&box->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != served) { leave = 0; break; }
+                        if (__hip_atomic_load(&relay->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == CTK_RES_CMD_EXIT) break;   // block 0 has left
+                        if (!box_local && __hip_atomic_load(&relay->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != served) { leave = 0; from_relay = 1; break; }
+                        if (wall_clock64() - t0 > 4 * idle_ticks + 100000ull) break;       // never wait for ever
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                leave = __builtin_amdgcn_readfirstlane(leave);
+                from_relay = __builtin_amdgcn_readfirstlane(from_relay);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");           // the request's payload; what the last step left (u_nom, u)
+                if (leave) w = lane == 1 ? (uint32_t)CTK_RES_CMD_EXIT : 0u;
+                else if (lane < BOXW)
+                    w = from_relay ? __hip_atomic_load(reinterpret_cast<const uint32_t*>(relay) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                   : __hip_atomic_load(reinterpret_cast<const uint32_t*>(box) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (lane < BOXW) reinterpret_cast<uint32_t*>(&req_s)[lane] = w;
+            }
+        }
+        __syncthreads();
+        if (req_s.cmd != CTK_RES_CMD_STEP) break;        // workgroup-uniform
+        {
+            // ---- one MPPI step: the names ctk_mppi_body.inc expects
+            constexpr int PRED = CTK_PRED_ODE;
+            constexpr bool LOG = false, P2P = false;
+            const InterpEntry* interp = ra->interp;
+            float* parts = ra->parts;
+            const int N_ = ra->N, H_ = ra->H, P_ = ra->P;
+            const uint32_t pmagic_ = ra->pmagic;
+            float* const unom0 = ra->unom0; float* const unom1 = ra->unom1;
+            const typename Env<ENV>::K k = ra->k;
+            const MppiK m = ra->m;
+            const float* samples = req_s.samples;
+            const float* u_nom = req_s.cur ? unom1 : unom0;
+            const float* wperm = nullptr;
+            RolloutArgs a_in = ra->base;
+#pragma unroll
+            for (int i = 0; i < CTK_MAX_STATES; ++i) a_in.s0[i] = req_s.s[i];
+#pragma unroll
+            for (int i = 0; i < CTK_MAX_INPUTS; ++i) a_in.u_prev[i] = req_s.u_prev[i];
+            a_in.call = req_s.call;
+            if (!req_s.dev_uprev) a_in.u_prev_dev = nullptr;          // else base.u_prev_dev: the optimizer's own last output
+            FuseArgs fz = ra->fz0;
+            fz.up.u_nom_in = u_nom; fz.up.u_nom_out = req_s.cur ? unom0 : unom1; fz.up.seq = req_s.seq;
+            served = req_s.req;
+            [&]() {
+#include "ctk_mppi_body.inc"
+            }();
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            __hip_atomic_store(&stat->t_relay, (uint32_t)(t_relayed - t_seen), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&stat->t_body, (uint32_t)(wall_clock64() - t_relayed), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __threadfence();                                  // what this step left (u_nom, u: block 0) before the next request is released
+        __syncthreads();                                  // req_s and the LDS carve are free again
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        box_store(&stat->served, served);
+        box_store(&stat->state, CTK_RES_LEFT);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Throughput variant (ODE, N >= CTK_MPPI_THROUGHPUT_MIN_N): one wave per block, 64 trajectories, the
 // inputs formed inline in the recurrence instead of through an LDS input buffer.  LDS per block is the
 // sample tile only (13.5 KiB at P = 50 instead of 27 KiB), so ~11 recurrence waves are resident per CU
@@ -544,6 +697,35 @@ hipError_t ctk_launch_mppi_rollout_env(hipStream_t st, int env, const float* par
     });
     return hipGetLastError();
 }
+hipError_t ctk_launch_mppi_resident(hipStream_t st, int env, const float* params, float dt, int isteps, const RolloutArgs& a, const MppiK& m,
+                                    float* u_nom0, float* u_nom1, float* parts, const MppiFuse& fuse, const CtkResidentBox* box_dev, int box_local,
+                                    CtkResidentStat* stat_dev, CtkResidentBox* relay, double idle_us, uint32_t first_req, void* args_dev, void* args_host) {
+    const dim3 grid((a.N + MPPI_TRAJ - 1) / MPPI_TRAJ), block(MPPI_BLOCK);
+    CTK_FOR_ENV(env, EV, {
+        using E = Env<EV>;
+        const int PC = a.P * E::C;
+        const typename E::K k = E::derive(params, dt, isteps);
+        FuseArgs fz{};
+        const size_t lds = rollout_launch_lds(a.P, a.H, CTK_PRED_ODE, a.N, (int)grid.x, &fz.stage_ok, E::C);
+        if (!fz.stage_ok || fuse.ll == nullptr) return hipErrorInvalidValue;          // the resident form is the {value, seq} hand-off only
+        fz.mode = 1; fz.ll = fuse.ll;
+        fz.up = MppiUpdateArgs{nullptr, nullptr, nullptr, nullptr, a.H, a.interp, u_nom0, u_nom1, a.lo[0], a.hi[0], fuse.u_dev, fuse.u_host, 0u};
+        fz.up.C = E::C;
+        for (int c = 0; c < E::C; ++c) { fz.up.lo_c[c] = a.lo[c]; fz.up.hi_c[c] = a.hi[c]; }
+        const uint32_t pmagic = PC >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)PC - 1) / (uint64_t)PC) : 0u;
+        const unsigned long long ticks = (unsigned long long)(idle_us * 100.0);        // wall_clock64: 100 MHz
+        using RA = ResidentArgs<typename E::K>;
+        static_assert(sizeof(RA) <= CTK_RES_ARGS_BYTES, "resident argument block");
+        RA* hostra = static_cast<RA*>(args_host);               // staging that outlives the asynchronous copy (the handle's)
+        *hostra = RA{a.interp, parts, a.N, a.H, a.P, pmagic, u_nom0, u_nom1, a, k, m, fz};
+        const hipError_t ce = hipMemcpyAsync(args_dev, hostra, sizeof(RA), hipMemcpyHostToDevice, st);
+        if (ce != hipSuccess) return ce;
+        hipLaunchKernelGGL((ctk_mppi_resident<EV>), grid, block, lds, st, static_cast<const RA*>(args_dev), box_dev, box_local, stat_dev, relay, ticks, first_req);
+    });
+    return hipGetLastError();
+}
+const char* ctk_mppi_resident_name(int env) { return ctk_kernel_name("ctk_mppi_resident<%d>", env); }
+
 size_t ctk_mppi_rollout_env_lds(int env, int P, int H, int N) {
     int C = 1;
     CTK_FOR_ENV(env, EV, { C = Env<EV>::C; });

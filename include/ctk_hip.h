@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CTK_ABI_VERSION 4
+#define CTK_ABI_VERSION 5
 #define CTK_MAX_STATES 8   /* S <= 8 */
 #define CTK_MAX_INPUTS 4   /* C <= 4 */
 
@@ -375,6 +375,27 @@ int ctk_log_enable(ctk_handle* h, size_t capacity_steps);
 size_t ctk_log_count(const ctk_handle* h); /* steps logged since ctk_log_enable */
 /* which: CTK_BUF_Q | CTK_BUF_J | CTK_BUF_TRAJ | CTK_BUF_AGES; steps [first_step, first_step + n_steps)   */
 int ctk_log_read(ctk_handle* h, int which, size_t first_step, size_t n_steps, float* dst, size_t cap, size_t* n_out);
+
+/* -------------------------------------------------------------------------------------------
+ * resident MPPI step (opt-in; ABI v5).  The reference's loop calls optimizer.step once per control period
+ * (Controllers/controller_mpc.py:104, controller_server/controller_server.py:55-86): one kernel launch per call costs ~6 us of
+ * runtime + command processor on top of the kernel.  With ctk_resident_enable(h, 1, idle_us) the FIRST ctk_step launches a kernel that
+ * stays on the device and serves every following ctk_step from a pinned mailbox — same arguments, same results, same error
+ * behaviour.  MPPI with the analytic predictor in the one-launch regime only (<= 128 workgroups, trajectories not materialised);
+ * steps that hand over HOST samples, logging or per-launch timing run the launched form (the resident kernel is ended first).
+ *  - every device-side wait is bounded by the wall clock: without a request for `idle_us` microseconds (1 .. 1e6; 200 is a good
+ *    value for a closed loop) the kernel leaves by itself and the next ctk_step launches it again;
+ *  - it therefore holds the device at most idle_us beyond its last step: a device-wide synchronize issued by anybody else
+ *    (another handle, torch.cuda.synchronize) waits at most that long.  ctk_resident_stop ends it at once; so does every
+ *    other call on the handle that touches device state (read, reset, set_param, set_state, rollout, ...), and ctk_destroy;
+ *  - the mailbox lives in fine-grained device memory that the host stores into through the PCIe BAR (every workgroup polls local memory;
+ *    no PCIe read on the request path), or — where a probe at enable time finds the host cannot reach device memory — in pinned host
+ *    memory polled by one workgroup that relays the request to the others;
+ *  - ctk_resident_stats: kernel launches and steps served so far, whether the kernel is believed to be running, where the mailbox is.
+ * ----------------------------------------------------------------------------------------- */
+int ctk_resident_enable(ctk_handle* h, int on, double idle_us);
+int ctk_resident_stop(ctk_handle* h);
+int ctk_resident_stats(const ctk_handle* h, uint64_t* launches, uint64_t* steps, int* running, int* mailbox_in_device_memory);
 
 #ifdef __cplusplus
 }
