@@ -122,6 +122,7 @@ struct ctk_handle {
     uint32_t res_req = 0;                 // last request number issued
     uint32_t res_relay_prime[2] = {0, 0}; // staging words of the copy that primes the relay before a launch
     uint64_t res_launches = 0, res_steps = 0;
+    std::string res_dominant_saved;       // ctk_dominant_kernel of the launched form while the resident kernel runs
 };
 
 namespace {
@@ -576,6 +577,7 @@ int resident_quiesce(ctk_handle* h) {
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));       // bounded on the device side: the kernel leaves on EXIT, or after its idle time-out
     h->res_running = false;
+    if (!h->res_dominant_saved.empty()) { h->dominant = h->res_dominant_saved; h->res_dominant_saved.clear(); }
     return CTK_OK;
 }
 
@@ -596,6 +598,7 @@ int resident_launch(ctk_handle* h, uint32_t first_req) {
                                         h->d_parts, fz, h->res_box_dev, h->res_local ? 1 : 0, h->res_stat_dev, h->d_res_relay, h->res_idle_us, first_req, h->d_res_args, h->res_args_host));
     h->res_running = true;
     ++h->res_launches;
+    if (h->res_dominant_saved.empty()) h->res_dominant_saved = h->dominant;      // restored when the kernel is ended
     h->dominant = ctk_mppi_resident_name(h->env);
     return CTK_OK;
 }

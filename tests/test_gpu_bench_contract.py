@@ -36,4 +36,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
-    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 1e5
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e5        # oracle/ctk_cpu.c on the box's host cores (C + OpenMP)
+    assert "ctk_cpu.c" in cb["sample"] and d["cpu_baseline_numpy"]["cores"] == 1     # the single-thread NumPy oracle stays beside it
+    res = d.get("resident")                                                          # the opt-in resident form: its own field, never `value`
+    assert res is not None and "error" not in res, res
+    assert res["value"] > 1e8 and res["kernel_launches_total"] >= 1 and res["boundary"] == "controller_mpc.step"
