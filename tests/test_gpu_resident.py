@@ -135,3 +135,25 @@ def test_resident_on_the_other_environments():
             s[0] += 0.01
         assert b.resident_stats()["launches"] == 1
         a.close(); b.close()
+
+
+def test_requests_racing_the_idle_exit_are_never_lost():
+    """gaps between steps drawn around the idle time: the kernel's leave announcement and the host's next request cross in flight again and
+    again — every step must still be served (by the leaving kernel's re-read, or by the relaunch), bit-identical to the launched twin"""
+    rng = np.random.default_rng(0)
+    a, b = _pair(num_rollouts=256, mpc_horizon=12, dt=0.02, period_interpolation_inducing_points=3, seed=11)
+    b.resident_enable(True, idle_us=60.0)
+    s = S0.copy()
+    t_start = time.perf_counter()
+    for t in range(1500):
+        gap = rng.uniform(0.0, 140e-6)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < gap:
+            pass
+        ua, ub = a.step(s), b.step(s)
+        assert np.array_equal(ua, ub), t
+        s[0] = 0.05 + 0.01 * np.sin(0.1 * t)
+    st = b.resident_stats()
+    assert st["steps"] == 1500 and 1 < st["launches"] < 1500, st          # some gaps were short enough to stay, some long enough to leave
+    assert time.perf_counter() - t_start < 20.0
+    a.close(); b.close()
