@@ -106,6 +106,9 @@ def main():
     copy_text("cem_stamps_cfg3.txt", f"{tag}_cem_stamps_cfg3.txt", "# tools/diag_cem_fused (stamped diagnostic build of ctk_cem_fused): where an outer iteration's time goes\n")
     copy_text("cem_stamps_default.txt", f"{tag}_cem_stamps_default.txt", "# tools/diag_cem_fused 200 40 40 (the reference's default CEM size)\n")
     copy_text("sweep_n.txt", f"{tag}_mppi_sweep_n.txt", "# tools/sweep_n.py\n")
+    copy_text("resident.txt", f"{tag}_resident.txt", "# tools/bench_resident.py (CtkEngine.step, launched form against the resident form), then tools/diag_mailbox_vram (round trip of one word:\n"
+              "# mailbox in pinned host memory against mailbox in host-written device memory)\n")
+    copy_text("soak.txt", f"{tag}_soak.txt", "# tools/soak.py 1500: closed-loop soak of 21 engines (every optimizer, predictor, environment, the one-launch CEM, the split network kernels)\n")
     p = pmc("pmc_largen")
     if fresh(p):
         import collections

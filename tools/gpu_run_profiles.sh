@@ -48,6 +48,9 @@ python tools/bench_env.py --steps 300 > $O/env_kernels.txt 2> $O/env_kernels.err
 ./tools/diag_cem_fused 4096 30 409 > $O/cem_stamps_cfg3.txt 2>&1; say "cem stamps" $?
 ./tools/diag_cem_fused 200 40 40 > $O/cem_stamps_default.txt 2>&1
 python tools/sweep_n.py > $O/sweep_n.txt 2> $O/sweep_n.err; say "sweep_n" $?
+python tools/bench_resident.py > $O/resident.txt 2> $O/resident.err; say "bench_resident" $?
+./tools/diag_mailbox_vram >> $O/resident.txt 2>&1; say "mailbox diag" $?
+python tools/soak.py 1500 > $O/soak.txt 2>&1; say "soak" $?
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_largen -o p -- python3 tools/large_n_once.py > /dev/null 2> $O/pmc_largen.err; say "pmc large-N insts" $?
 # 7. condense HERE, then drop the big CSVs
 python3 tools/condense_profiles.py --src $O --round 3 --out $O/condensed; say "condense" $?
