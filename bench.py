@@ -239,7 +239,8 @@ def cpu_baseline_torch(w, budget_s=4.0):
 # HBM traffic of the dominant kernel: read from the newest profiles/*traffic*.json that was taken from THESE sources
 # ------------------------------------------------------------------------------------------------------------------
 # kernel sources AND what selects the kernel / sizes its buffers (fuse mode, thresholds, ABI structs)
-KERNEL_SOURCES = ("ctk_mppi.hip", "ctk_mppi_body.inc", "ctk_mppi_merge.h", "ctk_env.h", "ctk_rollout.h", "ctk_device.h", "ctk_common.h", "ctk_mlp.h", "ctk_gru.h", "Makefile",
+KERNEL_SOURCES = ("ctk_mppi.hip", "ctk_mppi_body.inc", "ctk_mppi_body_1_decl.inc", "ctk_mppi_body_2_pro1.inc", "ctk_mppi_body_3_defs.inc",
+                  "ctk_mppi_body_4_phase_a.inc", "ctk_mppi_body_5_post.inc", "ctk_mppi_merge.h", "ctk_env.h", "ctk_rollout.h", "ctk_device.h", "ctk_common.h", "ctk_mlp.h", "ctk_gru.h", "Makefile",
                   "ctk_api.hip", "ctk_launch.h", "../../include/ctk_hip.h")
 
 

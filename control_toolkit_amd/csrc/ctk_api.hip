@@ -1,6 +1,7 @@
 // ctk_api.hip — the C ABI of libctk_hip.so (include/ctk_hip.h): handle, device state, step
 // sequencing.  All compute is in the HIP kernels; there is no CPU fallback.
 #include <atomic>
+#include <unordered_map>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -123,6 +124,8 @@ struct ctk_handle {
     uint32_t res_relay_prime[2] = {0, 0}; // staging words of the copy that primes the relay before a launch
     uint64_t res_launches = 0, res_steps = 0;
     std::string res_dominant_saved;       // ctk_dominant_kernel of the launched form while the resident kernel runs
+    std::unordered_map<const float*, const float*> res_follow;   // sample buffer -> the buffer that followed it last time
+    const float* res_prev_samples = nullptr;
 };
 
 namespace {
@@ -571,6 +574,7 @@ int resident_quiesce(ctk_handle* h) {
     if (__atomic_load_n(&h->res_stat->state, __ATOMIC_ACQUIRE) != CTK_RES_LEFT) {
         volatile CtkResidentBox* b = h->res_box;
         b->cmd = CTK_RES_CMD_EXIT;
+        b->tail = h->res_req + 1;
         __builtin_ia32_sfence();                         // (write-combined stores into device memory: payload before the number)
         b->req = ++h->res_req;
         __builtin_ia32_sfence();
@@ -617,6 +621,21 @@ int resident_step(ctk_handle* h, const float* s, const float* u_prev, const floa
     b->samples = d_samples;
     for (int i = 0; i < h->S; ++i) b->s[i] = s[i];
     for (int c = 0; c < h->C; ++c) b->u_prev[c] = u_prev ? u_prev[c] : 0.0f;
+    // a guess at the NEXT step's draws, so that the kernel can form that step's inputs while the host works on this one: the in-kernel
+    // sampler's next position is known; for buffers, "what followed this buffer the last time it was used" (callers cycle through a pool)
+    {
+        const float* guess = nullptr;
+        uint32_t known = d_samples == nullptr ? 1u : 0u;
+        if (d_samples != nullptr) {
+            if (h->res_prev_samples != nullptr) h->res_follow[h->res_prev_samples] = d_samples;
+            const auto it = h->res_follow.find(d_samples);
+            if (it != h->res_follow.end()) { guess = it->second; known = 1u; }
+            if (h->res_follow.size() > 4096) h->res_follow.clear();
+        }
+        h->res_prev_samples = d_samples;
+        b->next_samples = guess; b->next_known = known;
+    }
+    b->tail = req;
     __builtin_ia32_sfence();                                    // payload before the number (write-combined stores when the box is device memory)
     b->req = req;
     __builtin_ia32_sfence();
@@ -1974,8 +1993,15 @@ int ctk_resident_stop(ctk_handle* h) {
 int ctk_resident_stats(const ctk_handle* h, uint64_t* launches, uint64_t* steps, int* running, int* mailbox_in_device_memory) {
     if (!h) return CTK_ERR_INVALID_ARGUMENT;
     if (h->res_stat && getenv("CTK_RES_TRACE"))
-        fprintf(stderr, "[ctk resident] mailbox in %s memory; last request: fetch%s %.2f us, block 0's step %.2f us\n", h->res_local ? "device" : "pinned host",
-                h->res_local ? "" : " + relay", h->res_stat->t_relay * 0.01, h->res_stat->t_body * 0.01);
+        fprintf(stderr, "[ctk resident] mailbox in %s memory; last request: fetch%s %.2f us, block 0's step %.2f us, inputs %s\n", h->res_local ? "device" : "pinned host",
+                h->res_local ? "" : " + relay", (h->res_stat->t_relay & 0x7FFFFFFFu) * 0.01, h->res_stat->t_body * 0.01,
+                (h->res_stat->t_relay & 0x80000000u) ? "prepared ahead" : "formed at the request");
+    if (h->res_stat && getenv("CTK_RES_TRACE"))
+    {
+        fprintf(stderr, "[ctk resident] block 0's step: %u shader cycles -> %.0f MHz; stamps", h->res_stat->c_body, h->res_stat->c_body / (h->res_stat->t_body * 0.01 + 1e-9));
+        for (int i = 1; i < 12; ++i) fprintf(stderr, " %d", (int)(h->res_stat->stamps[i] - h->res_stat->stamps[0]));   // 10 ns units since block 0 took the request
+        fprintf(stderr, "\n");
+    }
     if (launches) *launches = h->res_launches;
     if (steps) *steps = h->res_steps;
     if (running) *running = h->res_running ? 1 : 0;

@@ -61,11 +61,18 @@ struct CtkResidentBox {
     const float* samples;               // this step's draws (device pointer), or nullptr
     float s[CTK_MAX_STATES];
     float u_prev[CTK_MAX_INPUTS];
+    const float* next_samples;          // the host's guess at the NEXT step's draws (nullptr with next_known: the in-kernel sampler): the kernel forms
+    uint32_t next_known;                // that step's inputs while the host works on this one; a wrong guess costs nothing but that work
+    uint32_t tail;                      // == req, written with the payload BEFORE req: a reader that finds req == tail in ONE pass over the box has a
+    uint32_t pad;                       //    consistent request (writes arrive in order), and needs no second round trip for the payload
+    uint32_t upd;                       // relay only: request number whose update (u_nom, u) block 0 has published
 };
 struct CtkResidentStat {                // device -> host
     uint32_t state;                     // CTK_RES_*
     uint32_t served;                    // last request taken, written when the kernel leaves
     uint32_t t_relay, t_body;           // diagnostics: wall-clock ticks (10 ns) block 0 spent fetching / relaying the last request, and in its step
+    uint32_t c_body;                    // ... and that step in shader-clock cycles (clock64)
+    uint32_t stamps[12];                // diagnostic builds (-DCTK_RES_STAMPS): the body's STAMP(i) points, shader cycles since the request
 };
 
 struct MppiFuse {

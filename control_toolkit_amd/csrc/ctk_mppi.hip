@@ -208,8 +208,58 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_resident(const ResidentAr
                                                                 unsigned long long idle_ticks, uint32_t first_req) {
     extern __shared__ float lds[];
     __shared__ CtkResidentBox req_s;
+    __shared__ float uown_s[CTK_MAX_INPUTS];          // the optimizer's own last output, as the prepared inputs assumed it
+    __shared__ int upd_ok_s;
+    // ---- the names the body's parts expect; what changes per step is assigned before the part that reads it
+    constexpr int PRED = CTK_PRED_ODE;
+    constexpr bool LOG = false, P2P = false;
+    const InterpEntry* interp = ra->interp;
+    float* parts = ra->parts;
+    const int N_ = ra->N, H_ = ra->H, P_ = ra->P;
+    const uint32_t pmagic_ = ra->pmagic;
+    float* const unom0 = ra->unom0; float* const unom1 = ra->unom1;
+    const typename Env<ENV>::K& k = ra->k;
+    const MppiK& m = ra->m;
+    const float* samples = nullptr;
+    const float* u_nom = unom0;
+    const float* wperm = nullptr;
+    const RolloutArgs& a_in = ra->base;
+    FuseArgs fz = ra->fz0;
+    const float* const d_u = ra->base.u_prev_dev;     // where the step publishes its own output
+#ifdef CTK_RES_STAMPS                                   // diagnostic build only: where block 0's step goes (shader cycles since the request was fetched)
+    unsigned long long c_req = 0;
+#pragma push_macro("STAMP")
+#undef STAMP
+#define STAMP(i) do { if ((blockIdx.x == 0 || blockIdx.x == 5) && threadIdx.x == 0 && (i) >= 3) __hip_atomic_store(&stat->stamps[(blockIdx.x ? 6 : 0) + (i) - 2], (uint32_t)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+#endif
+#define CTK_BODY_S1 16                                // as the launched kernel: the same split of the steps over the waves = the same sums, bit for bit
+#include "ctk_mppi_body_1_decl.inc"
+#include "ctk_mppi_body_3_defs.inc"
+#undef CTK_BODY_S1
+    // inputs of a whole step (sample tile, tables, clipped inputs, input-only costs) from `samples` / `a.call` / `u_nom` / `a.u_prev*`
+    auto do_pre = [&]() {
+#include "ctk_mppi_body_2_pro1.inc"
+#include "ctk_mppi_body_4_phase_a.inc"
+        // phase B too (part 5 runs it under the first S1 steps of the recurrence; it is idempotent, so running it here as well only means
+        // that the recurrence finds every input ready): waves 1..3, their thirds of [S1, H)
+        if (wave != 0) {
+            const int Hb = (H - S1 + MPPI_WAVES - 2) / (MPPI_WAVES - 1);
+            prologue2(lane, min(H, S1 + (wave - 1) * Hb), min(H, S1 + (wave - 1) * Hb + Hb), wave, corr_keep);
+        }
+        __syncthreads();
+    };
+    // recurrence from `a.s0`, costs, block record, hand-off; block 0: merge, update, publish {u, seq}
+    auto do_post = [&]() {
+#include "ctk_mppi_body_5_post.inc"
+    };
+#ifdef CTK_RES_STAMPS
+#pragma pop_macro("STAMP")
+#endif
     uint32_t served = first_req - 1u;                 // request number of the last step this workgroup has taken
     unsigned long long t_seen = 0, t_relayed = 0;
+    bool pre_ok = false;                              // the inputs of the NEXT step are already in LDS, formed for ...
+    const float* pre_samples = nullptr;               // ... these draws (nullptr: the in-kernel sampler at position pre_call)
+    uint32_t pre_call = 0, pre_cur = 0;
     for (;;) {
         // ---- the next request.  Wave 0: lane 0 polls ONE word; then the request is moved as a whole — its dwords by as many lanes in one
         //      coalesced access (a dword at a time over PCIe is a round trip each: 24 us measured).  box_local: every workgroup reads the
@@ -217,98 +267,128 @@ __global__ __launch_bounds__(MPPI_BLOCK) void ctk_mppi_resident(const ResidentAr
         //      left" flag the other workgroups watch.
         if (threadIdx.x < 64) {
             constexpr int BOXW = (int)(sizeof(CtkResidentBox) / sizeof(uint32_t));
-            static_assert(BOXW <= 64 && offsetof(CtkResidentBox, req) == 0 && offsetof(CtkResidentBox, cmd) == 4, "request layout");
+            static_assert(BOXW <= 64 && offsetof(CtkResidentBox, req) == 0 && offsetof(CtkResidentBox, cmd) == 4 &&
+                          offsetof(CtkResidentBox, upd) == sizeof(CtkResidentBox) - 4, "request layout");
             const int lane = threadIdx.x;
             const unsigned long long t0 = wall_clock64();
             int leave = 0, from_relay = 0;
             uint32_t w = 0;
+            constexpr int TAILW = (int)(offsetof(CtkResidentBox, tail) / sizeof(uint32_t));
+            // box_local: the whole box in ONE pass per poll (its dwords by as many lanes); req == tail != served: a complete new request
+            auto poll_box = [&]() {
+                const uint32_t x = lane < BOXW ? __hip_atomic_load(reinterpret_cast<const uint32_t*>(box) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+                const uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)x, 0), tl = (uint32_t)__builtin_amdgcn_readlane((int)x, TAILW);
+                w = x;
+                return head != served && tl == head;
+            };
             if (blockIdx.x == 0) {
-                if (lane == 0) {
-                    for (;;) {
-                        if (__hip_atomic_load(&box->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != served) break;
-                        if (wall_clock64() - t0 > idle_ticks) {          // nothing to do: leave, unless a request slips in right now
-                            box_store(&stat->state, CTK_RES_LEAVING);
-                            __threadfence_system();
-                            if (box_load(&box->req) != served) { box_store(&stat->state, CTK_RES_RUNNING); break; }
-                            leave = 1;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
+                bool have = false;                                       // w already holds the request (box_local)
+                for (;;) {
+                    if (box_local) { if (poll_box()) { have = true; break; } }
+                    else if (__builtin_amdgcn_readfirstlane((int)(lane == 0 ? __hip_atomic_load(&box->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u)) != (int)served) break;
+                    if (wall_clock64() - t0 > idle_ticks) {              // nothing to do: leave, unless a request slips in right now
+                        if (lane == 0) { box_store(&stat->state, CTK_RES_LEAVING); __threadfence_system(); }
+                        const int slipped = __builtin_amdgcn_readfirstlane((int)(lane == 0 ? (box_load(&box->req) != served ? 1u : 0u) : 0u));
+                        if (slipped) { if (lane == 0) box_store(&stat->state, CTK_RES_RUNNING); continue; }   // (its tail may still be in flight: poll on)
+                        leave = 1;
+                        break;
                     }
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                leave = __builtin_amdgcn_readfirstlane(leave);
                 t_seen = wall_clock64();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");           // the payload was written before the number
                 if (!leave) {
-                    if (lane < BOXW) w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(box) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (!have && lane < BOXW) w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(box) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 } else {
                     w = lane == 0 ? served + 1u : (lane == 1 ? (uint32_t)CTK_RES_CMD_EXIT : 0u);
                 }
                 if (lane < BOXW) reinterpret_cast<uint32_t*>(&req_s)[lane] = w;
                 if (!box_local || leave) {
                     // hand it to the other workgroups; the release also publishes what the last step left (u_nom, u)
-                    if (lane != 0 && lane < BOXW) __hip_atomic_store(reinterpret_cast<uint32_t*>(relay) + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane != 0 && lane < BOXW - 1)     // (not the last word: relay->upd is block 0's "update published" flag)
+                        __hip_atomic_store(reinterpret_cast<uint32_t*>(relay) + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     if (lane == 0) __hip_atomic_store(&relay->req, w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 t_relayed = wall_clock64();
             } else {
-                if (lane == 0) {
-                    leave = 1;
-                    for (;;) {
-                        if (box_local && __hip_atomic_load(&box->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != served) { leave = 0; break; }
-                        if (__hip_atomic_load(&relay->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == CTK_RES_CMD_EXIT) break;   // block 0 has left
-                        if (!box_local && __hip_atomic_load(&relay->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != served) { leave = 0; from_relay = 1; break; }
-                        if (wall_clock64() - t0 > 4 * idle_ticks + 100000ull) break;       // never wait for ever
-                        __builtin_amdgcn_s_sleep(1);
+                leave = 1;
+                for (;;) {                                               // (wave-uniform: every lane takes every turn)
+                    if (box_local && poll_box()) { leave = 0; break; }
+                    const uint32_t rc = lane == 0 ? __hip_atomic_load(&relay->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    if (__builtin_amdgcn_readfirstlane((int)rc) == CTK_RES_CMD_EXIT) break;                      // block 0 has left
+                    if (!box_local) {
+                        const uint32_t rr = lane == 0 ? __hip_atomic_load(&relay->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : served;
+                        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)rr) != served) { leave = 0; from_relay = 1; break; }
                     }
+                    if (wall_clock64() - t0 > 4 * idle_ticks + 100000ull) break;       // never wait for ever
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                leave = __builtin_amdgcn_readfirstlane(leave);
-                from_relay = __builtin_amdgcn_readfirstlane(from_relay);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");           // the request's payload; what the last step left (u_nom, u)
                 if (leave) w = lane == 1 ? (uint32_t)CTK_RES_CMD_EXIT : 0u;
-                else if (lane < BOXW)
-                    w = from_relay ? __hip_atomic_load(reinterpret_cast<const uint32_t*>(relay) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                   : __hip_atomic_load(reinterpret_cast<const uint32_t*>(box) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else if (from_relay && lane < BOXW) w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(relay) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (lane < BOXW) reinterpret_cast<uint32_t*>(&req_s)[lane] = w;
             }
         }
         __syncthreads();
         if (req_s.cmd != CTK_RES_CMD_STEP) break;        // workgroup-uniform
-        {
-            // ---- one MPPI step: the names ctk_mppi_body.inc expects
-            constexpr int PRED = CTK_PRED_ODE;
-            constexpr bool LOG = false, P2P = false;
-            const InterpEntry* interp = ra->interp;
-            float* parts = ra->parts;
-            const int N_ = ra->N, H_ = ra->H, P_ = ra->P;
-            const uint32_t pmagic_ = ra->pmagic;
-            float* const unom0 = ra->unom0; float* const unom1 = ra->unom1;
-            const typename Env<ENV>::K k = ra->k;
-            const MppiK m = ra->m;
-            const float* samples = req_s.samples;
-            const float* u_nom = req_s.cur ? unom1 : unom0;
-            const float* wperm = nullptr;
-            RolloutArgs a_in = ra->base;
+        served = req_s.req;
+        // ---- are the prepared inputs those of THIS request?  (workgroup-uniform: every thread evaluates the same LDS words)
+        bool hit = pre_ok && req_s.samples == pre_samples && (req_s.samples != nullptr || req_s.call == pre_call) && req_s.cur == pre_cur;
+        if (hit && !req_s.dev_uprev) {
 #pragma unroll
-            for (int i = 0; i < CTK_MAX_STATES; ++i) a_in.s0[i] = req_s.s[i];
-#pragma unroll
-            for (int i = 0; i < CTK_MAX_INPUTS; ++i) a_in.u_prev[i] = req_s.u_prev[i];
-            a_in.call = req_s.call;
-            if (!req_s.dev_uprev) a_in.u_prev_dev = nullptr;          // else base.u_prev_dev: the optimizer's own last output
-            FuseArgs fz = ra->fz0;
-            fz.up.u_nom_in = u_nom; fz.up.u_nom_out = req_s.cur ? unom0 : unom1; fz.up.seq = req_s.seq;
-            served = req_s.req;
-            [&]() {
-#include "ctk_mppi_body.inc"
-            }();
+            for (int c = 0; c < C; ++c) hit = hit && __builtin_bit_cast(uint32_t, req_s.u_prev[c]) == __builtin_bit_cast(uint32_t, uown_s[c]);
         }
+#pragma unroll
+        for (int i = 0; i < S; ++i) a.s0[i] = req_s.s[i];
+        fz.up.seq = req_s.seq;
+        fz.up.u_nom_in = req_s.cur ? unom1 : unom0; fz.up.u_nom_out = req_s.cur ? unom0 : unom1;
+        fz.up.w0_l = nullptr; fz.up.w1_l = nullptr; fz.up.un_l = nullptr; fz.up.i0_l = nullptr;
+        // (no acquire fence on the way here: the request was read with uncached atomics, in program order behind the poll that saw its
+        //  number; what the prepared inputs were formed from was acquired when they were formed.  An acquire HERE would empty the L2 that
+        //  the inputs' preparation has just warmed for the merge tail: + 2 us measured.)
+        if (!hit) {                                       // first step, an unexpected sample buffer / previous input: form them now
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");       // draws written by the host or by another kernel; u_nom / u of the last step
+            samples = req_s.samples; u_nom = fz.up.u_nom_in; a.call = req_s.call;
+#pragma unroll
+            for (int c = 0; c < C; ++c) a.u_prev[c] = req_s.u_prev[c];
+            a.u_prev_dev = req_s.dev_uprev ? d_u : nullptr;
+            do_pre();
+        }
+        const unsigned long long c_post0 = clock64();
+#ifdef CTK_RES_STAMPS
+        c_req = c_post0;
+        if ((blockIdx.x == 0 || blockIdx.x == 5) && threadIdx.x == 0) __hip_atomic_store(&stat->stamps[blockIdx.x ? 6 : 0], (uint32_t)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+        do_post();
         if (blockIdx.x == 0 && threadIdx.x == 0) {
-            __hip_atomic_store(&stat->t_relay, (uint32_t)(t_relayed - t_seen), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&stat->c_body, (uint32_t)(clock64() - c_post0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&stat->t_relay, (uint32_t)(t_relayed - t_seen) | (hit ? 0x80000000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&stat->t_body, (uint32_t)(wall_clock64() - t_relayed), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        __threadfence();                                  // what this step left (u_nom, u: block 0) before the next request is released
-        __syncthreads();                                  // req_s and the LDS carve are free again
+        // ---- while the host works on the result: the NEXT step's inputs.  They need this step's update (u_nom, u), which block 0
+        //      publishes behind its merge: fence, then the request number in relay->upd (agent scope); the others wait for it — bounded
+        __threadfence();
+        __syncthreads();                                  // req_s is stable until the next wait; the LDS carve is free again
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0) { __hip_atomic_store(&relay->upd, req_s.req, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); upd_ok_s = 1; }
+        } else if (threadIdx.x == 0) {
+            const unsigned long long t0 = wall_clock64();
+            int ok = 1;
+            while (__hip_atomic_load(&relay->upd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != req_s.req) {
+                if (wall_clock64() - t0 > 20000ull) { ok = 0; break; }          // 200 us: then this workgroup forms its inputs at the next request
+                __builtin_amdgcn_s_sleep(1);
+            }
+            upd_ok_s = ok;
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        pre_ok = false;
+        if (upd_ok_s && req_s.next_known) {
+            if (threadIdx.x < C) uown_s[threadIdx.x] = __hip_atomic_load(d_u + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pre_samples = req_s.next_samples; pre_call = req_s.call + 1u; pre_cur = req_s.cur ^ 1u;
+            samples = pre_samples; u_nom = pre_cur ? unom1 : unom0; a.call = pre_call; a.u_prev_dev = d_u;
+            do_pre();                                     // ends with a workgroup barrier: uown_s is visible too
+            pre_ok = true;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         box_store(&stat->served, served);
