@@ -1952,7 +1952,9 @@ int ctk_resident_enable(ctk_handle* h, int on, double idle_us) {
         // stored by the host must read back through a device-side copy.  CTK_RES_HOST_MAILBOX forces the pinned-host fallback (A/B, tests)
         void* vram = nullptr;
         bool local = false;
-        if (!std::getenv("CTK_RES_HOST_MAILBOX") && hipExtMallocWithFlags(&vram, 4096, hipDeviceMallocFinegrained) == hipSuccess && vram) {
+        int large_bar = 0;                                  // without a large BAR the host cannot address device memory at all: do not touch it
+        if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->cfg.device) != hipSuccess) large_bar = 0;
+        if (large_bar && !std::getenv("CTK_RES_HOST_MAILBOX") && hipExtMallocWithFlags(&vram, 4096, hipDeviceMallocFinegrained) == hipSuccess && vram) {
             hipPointerAttribute_t at{};
             if (hipMemset(vram, 0, 4096) == hipSuccess && hipDeviceSynchronize() == hipSuccess && hipPointerGetAttributes(&at, vram) == hipSuccess) {
                 volatile uint32_t* pv = static_cast<volatile uint32_t*>(vram);
