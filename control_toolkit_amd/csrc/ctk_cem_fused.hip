@@ -10,9 +10,13 @@
 //   2. hop 1      publishes its 64 costs as words {sortable key, tag}; polls all N words into LDS;
 //   3. selection  finds the K-th smallest (key, index) of all N REDUNDANTLY (4-pass radix select on an LDS histogram; ties
 //                 broken by index, the total order of ctk_select_topk / tf.argsort) -> which of ITS rows are elite (:73-75);
-//   4. hop 2      publishes {n_b, mean_b[H], M2_b[H]} of its elite rows (exact two-pass locally); polls every workgroup's record;
-//   5. refit      merges the records in workgroup order with Chan's update (no cancellation, identical bits in every
-//                 workgroup) -> mu, population std (:77-78) in LDS for the next iteration.
+//   4. hop 2      publishes {n_b, m_b[H], M2_b[H]} of its elite rows: m_b = mean of d = q - mu (mu: the mean the samples were drawn around),
+//                 M2_b = centred sum of squares — formed in one pass in double, published as floats; polls every workgroup's record;
+//   5. refit      ONE pass over the records in a fixed order, in double: A = sum n_b m_b, B = sum (M2_b + n_b m_b^2) -> mean = mu + A/K,
+//                 M2 = B - A^2/K (the 53 bits absorb the cancellation; the shift by mu keeps it small), identical bits in every
+//                 workgroup -> mu, population std (:77-78) in LDS for the next iteration.  (First form: Chan's pairwise update in
+//                 float — two passes, three barriers: 2.0 us per iteration against 1.0.  Raw sums as doubles, two words each: the
+//                 records double and their gather eats the gain, 3.3 against 1.9 us.)
 // After the loop: the workgroup that owns the cheapest row publishes u = elite[0,0] (:101); workgroup 0 clips the std, shifts
 // both by one step and refills the tail (:99-102) into the handle's mu / std.
 // Only the last iteration's plans, costs (and trajectories, WTRAJ) reach memory; BEST_IDX is materialised on demand by
@@ -46,7 +50,7 @@ struct CemFusedK {
     int its, K, nblk;
     unsigned long long per_it;      // samples per outer iteration (N * H)
     unsigned long long* llJ;        // [N]              {sortable key of J_n, tag}
-    unsigned long long* llS;        // [nblk][1 + 2H]   {n_b | mean_b[H] | M2_b[H], tag}
+    unsigned long long* llS;        // [nblk][1 + 2H]   {n_b | m_b[H] | M2_b[H], tag}
     uint32_t tag0;                  // tag of iteration it = tag0 + it (host: consecutive across launches, never 0)
     float std_min, std_max, init_std;
     float mid[CTK_MAX_INPUTS];      // per input: the tail refill of the mean (:99-102)
@@ -57,7 +61,7 @@ struct CemFusedK {
 
 // LDS carve (4-byte words)
 struct CemCarve {
-    int tile0, tile1, ubuf, cin, mu, sd, keys, recs, hist, misc, total;
+    int tile0, tile1, ubuf, cin, mu, sd, keys, recs, part, hist, misc, total;
 };
 __host__ __device__ inline CemCarve cem_carve(int N, int H, int nblk) {
     const int ts = tile_stride(H), us = (H + 1) | 1, rs = 1 + 2 * H;
@@ -71,6 +75,8 @@ __host__ __device__ inline CemCarve cem_carve(int N, int H, int nblk) {
     c.sd = o; o += H;
     c.keys = o; o += (N + CF_BLOCK * CF_CHUNK - 1) / (CF_BLOCK * CF_CHUNK) * (CF_BLOCK * CF_CHUNK);   // padded: the counting loop reads whole chunks
     c.recs = o; o += nblk * rs;
+    o = (o + 1) & ~1;
+    c.part = o; o += 4 * CF_BLOCK;          // [SEG][H] {S1, S2} doubles of the segmented refit (SEG * H <= CF_BLOCK)
     c.hist = o; o += 256;
     c.misc = o; o += 80 + 2 * CF_WAVES;   // [0..7] selection scalars | [8] n_b | [16..79] elite rows | [80..) two per-wave reduction rows
     c.total = (o + 3) & ~3;
@@ -196,6 +202,7 @@ __global__ __launch_bounds__(CF_BLOCK) void ctk_cem_fused(const float* __restric
     float* sd_s = lds + cv.sd;
     uint32_t* keys = reinterpret_cast<uint32_t*>(lds + cv.keys);
     float* recs = lds + cv.recs;
+    double* part = reinterpret_cast<double*>(lds + cv.part);
     int* hist = reinterpret_cast<int*>(lds + cv.hist);
     int* sel = reinterpret_cast<int*>(lds + cv.misc);            // [0] prefix (as bits) [1] want
     int* nb_s = reinterpret_cast<int*>(lds + cv.misc) + 8;
@@ -413,15 +420,14 @@ __global__ __launch_bounds__(CF_BLOCK) void ctk_cem_fused(const float* __restric
         unsigned long long* myrec = cf.llS + (size_t)blockIdx.x * rs;
         if (t == 0) ll_st(myrec, (uint32_t)nb, tag);
         for (int h = t; h < H; h += CF_BLOCK) {
-            float s1 = 0.0f;
+            const double mu0 = (double)mu_s[h];
+            double s1 = 0.0, s2 = 0.0;
 #pragma unroll 4
-            for (int e = 0; e < nb; ++e) s1 += ubuf[erow[e] * us + h];
-            const float mean = nb > 0 ? s1 / (float)nb : 0.0f;
-            float m2 = 0.0f;
-#pragma unroll 4
-            for (int e = 0; e < nb; ++e) { const float d = ubuf[erow[e] * us + h] - mean; m2 = fmaf(d, d, m2); }
-            ll_st(myrec + 1 + h, __builtin_bit_cast(uint32_t, mean), tag);
-            ll_st(myrec + 1 + H + h, __builtin_bit_cast(uint32_t, m2), tag);
+            for (int e = 0; e < nb; ++e) { const double d = (double)ubuf[erow[e] * us + h] - mu0; s1 += d; s2 = fma(d, d, s2); }
+            const double mb = nb > 0 ? s1 / (double)nb : 0.0;
+            const double m2 = fma(-mb, s1, s2);                   // sum (d - m_b)^2 = s2 - s1^2 / n_b
+            ll_st(myrec + 1 + h, __builtin_bit_cast(uint32_t, (float)mb), tag);
+            ll_st(myrec + 1 + H + h, __builtin_bit_cast(uint32_t, (float)(m2 > 0.0 ? m2 : 0.0)), tag);
         }
         CSTAMP(6);
         expired |= ll_gather(cf.llS, cf.nblk * rs, tag, t, CF_BLOCK, cf.timeout_ticks,
@@ -429,64 +435,45 @@ __global__ __launch_bounds__(CF_BLOCK) void ctk_cem_fused(const float* __restric
         __syncthreads();
 
         CSTAMP(7);
-        // ---- 5. refit (:77-78; population std): mean = sum_b n_b mean_b / K, then M2 = sum_b (M2_b + n_b (mean_b - mean)^2) —
-        //      no cancellation; the workgroups are summed in a fixed order (segments of the index range, then the segments), so
-        //      every workgroup arrives at the same bits.  Thread (column h, segment sg) keeps its <= 8 records in registers
-        //      (independent LDS reads, one wait); partials through cin_s (free here); every thread forms the mean itself from
-        //      the segment partials, which saves a barrier.  (One thread per column walking all workgroups: 4.4 us at cfg3.)
+        // ---- 5. refit (:77-78; population std): A = sum n_b m_b, B = sum (M2_b + n_b m_b^2) in double, in a fixed order (segments of the
+        //      workgroup range, then the segments): every workgroup arrives at the same bits.  One pass, one barrier.
+        //      (One thread per column walking all workgroups: 4.4 us at cfg3.)
         {
-            constexpr int MB = 8, SEGMAX = 16;
-            const float cnt = (float)cf.K;                        // == sum_b n_b: the elite set has exactly K rows
+            constexpr int SEGMAX = 16;
+            const double invK = 1.0 / (double)cf.K;               // == 1 / sum_b n_b: the elite set has exactly K rows
             const int* nrec = reinterpret_cast<const int*>(recs);
-            const bool multi = H <= CF_BLOCK;                     // [SEG][H] partials fit cin_s' CF_BLOCK floats
+            auto add_rec = [&](int bq, int h, double& A, double& B) {
+                const double nbq = (double)nrec[bq * rs], mb = (double)recs[bq * rs + 1 + h];
+                A = fma(nbq, mb, A);
+                B += (double)recs[bq * rs + 1 + H + h] + nbq * mb * mb;
+            };
+            auto finish = [&](int h, double A, double B) {
+                const double mshift = A * invK;
+                const double var = fma(-mshift, mshift, B * invK);
+                mu_s[h] = (float)((double)mu_s[h] + mshift);
+                sd_s[h] = (float)sqrt(var > 0.0 ? var : 0.0);     // tf.math.reduce_std: ddof = 0
+            };
+            const bool multi = H <= CF_BLOCK && cf.nblk > 8;      // few workgroups: the plain walk is shorter than the barrier
             const int SEG = multi ? min(SEGMAX, CF_BLOCK / H) : 1, per = (cf.nblk + SEG - 1) / SEG;
-            if (multi && per <= MB && cf.nblk > 8) {              // few workgroups: the plain walk below is shorter than the barriers
-                float* part = cin_s;                              // [SEG][H], SEG * H <= CF_BLOCK
+            if (multi) {
                 const int hcol = t % H, sg = t / H;
-                const bool active = sg < SEG;
-                const int bb = sg * per, be = min(cf.nblk, bb + per);
-                float nbr[MB], mbr[MB], m2r[MB];
-#pragma unroll
-                for (int q = 0; q < MB; ++q) {
-                    const int bq = min(bb + q, cf.nblk - 1);
-                    const bool on = active && bb + q < be;
-                    nbr[q] = on ? (float)nrec[bq * rs] : 0.0f;
-                    mbr[q] = recs[bq * rs + 1 + hcol];
-                    m2r[q] = on ? recs[bq * rs + 1 + H + hcol] : 0.0f;
+                if (sg < SEG) {
+                    double A = 0.0, B = 0.0;
+                    const int bb = sg * per, be = min(cf.nblk, bb + per);
+                    for (int bq = bb; bq < be; ++bq) add_rec(bq, hcol, A, B);
+                    part[(sg * H + hcol) * 2] = A; part[(sg * H + hcol) * 2 + 1] = B;
                 }
-                float acc = 0.0f;
-#pragma unroll
-                for (int q = 0; q < MB; ++q) acc = fmaf(nbr[q], mbr[q], acc);
-                if (active) part[sg * H + hcol] = acc;
-                __syncthreads();
-                float mean = 0.0f;
-#pragma unroll
-                for (int q = 0; q < SEGMAX; ++q) mean += q < SEG ? part[q * H + hcol] : 0.0f;
-                mean /= cnt;
-                acc = 0.0f;
-#pragma unroll
-                for (int q = 0; q < MB; ++q) { const float dl = mbr[q] - mean; acc += m2r[q] + nbr[q] * dl * dl; }
-                __syncthreads();                                  // every thread has read the mean partials
-                if (active) part[sg * H + hcol] = acc;
                 __syncthreads();
                 if (t < H) {
-                    float m2 = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < SEGMAX; ++q) m2 += q < SEG ? part[q * H + t] : 0.0f;
-                    mu_s[t] = mean;
-                    sd_s[t] = sqrtf(m2 / cnt);                    // tf.math.reduce_std: ddof = 0
+                    double A = 0.0, B = 0.0;
+                    for (int q = 0; q < SEG; ++q) { A += part[(q * H + t) * 2]; B += part[(q * H + t) * 2 + 1]; }
+                    finish(t, A, B);
                 }
             } else {
                 for (int h = t; h < H; h += CF_BLOCK) {
-                    float mean = 0.0f, m2 = 0.0f;
-                    for (int bq = 0; bq < cf.nblk; ++bq) mean = fmaf((float)nrec[bq * rs], recs[bq * rs + 1 + h], mean);
-                    mean /= cnt;
-                    for (int bq = 0; bq < cf.nblk; ++bq) {
-                        const float dl = recs[bq * rs + 1 + h] - mean;
-                        m2 += recs[bq * rs + 1 + H + h] + (float)nrec[bq * rs] * dl * dl;
-                    }
-                    mu_s[h] = mean;
-                    sd_s[h] = sqrtf(m2 / cnt);
+                    double A = 0.0, B = 0.0;
+                    for (int bq = 0; bq < cf.nblk; ++bq) add_rec(bq, h, A, B);
+                    finish(h, A, B);
                 }
             }
         }

@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
     printf("N=%d H=%d K=%d blocks=%d its=%d: event time %.2f us (stamped build); err word %u\n", N, H, K, nb, its, ms * 1e3, reinterpret_cast<unsigned*>(h_u)[2]);
     const char* names[8] = {"prepare first 16 steps (+barrier)", "recurrence -> J (thread 0 = wave 0)", "publish J + gather all N costs", "range reduce + radix select",
-                            "ties + elite flags", "local moments + publish", "gather all records", "merge (Chan) + barrier"};
+                            "ties + elite flags", "local moments + publish", "gather all records", "refit from the records     "};
     for (int it = 0; it < its; ++it) {
         printf(" iteration %d (ns, median over workgroups | max)\n", it);
         for (int ph = 0; ph < 8; ++ph) {
