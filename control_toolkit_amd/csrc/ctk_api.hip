@@ -115,6 +115,7 @@ struct ctk_handle {
     CtkResidentBox* res_box = nullptr;    // what the host stores requests into: fine-grained device memory through the BAR (res_local) or pinned host memory
     CtkResidentBox* res_box_dev = nullptr;   // the same memory as the kernel addresses it
     bool res_local = false;
+    bool res_stream_isolated = false;     // the handle's own stream has been re-created at the highest priority (its own hardware queue)
     CtkResidentStat* res_stat = nullptr;  // pinned host memory: what the kernel reports
     CtkResidentStat* res_stat_dev = nullptr;
     CtkResidentBox* d_res_relay = nullptr;
@@ -1980,6 +1981,24 @@ int ctk_resident_enable(ctk_handle* h, int on, double idle_us) {
             h->res_local = false;
         }
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    // HIP multiplexes a process's streams over a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and a queue is in order: work of
+    // ANOTHER stream that lands on the resident kernel's queue waits until it leaves (<= idle_us each time — measured: a neighbour's 50 us
+    // step became 50 ms beside a resident kernel with idle_us = 50 000 in an 18-stream process).  Streams of another priority are served
+    // from other queues, so the handle's own stream is re-created at the highest priority once; a stream handed in by ctk_set_stream is
+    // the caller's business (include/ctk_hip.h says so).
+    if (h->own_stream && !h->res_stream_isolated) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) {
+            hipStream_t ns = nullptr;
+            if (hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, hi) == hipSuccess) {
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                (void)hipStreamDestroy(h->stream);
+                h->stream = ns;
+            }
+        }
+        (void)hipGetLastError();
+        h->res_stream_isolated = true;
     }
     h->res_idle_us = idle_us;
     h->res_enabled = true;

@@ -391,6 +391,10 @@ int ctk_log_read(ctk_handle* h, int which, size_t first_step, size_t n_steps, fl
  *  - the mailbox lives in fine-grained device memory that the host stores into through the PCIe BAR (every workgroup polls local memory;
  *    no PCIe read on the request path), or — where a probe at enable time finds the host cannot reach device memory — in pinned host
  *    memory polled by one workgroup that relays the request to the others;
+ *  - hardware queues: HIP multiplexes a process's streams over a few in-order hardware queues (GPU_MAX_HW_QUEUES, 4 by default); work of
+ *    another stream that lands on the resident kernel's queue waits until it leaves (<= idle_us each time).  ctk_resident_enable
+ *    therefore re-creates the handle's OWN stream at the highest stream priority (served from other queues than default-priority
+ *    streams).  A stream handed in with ctk_set_stream is used as it is: give it a priority of its own, or keep idle_us short;
  *  - ctk_resident_stats: kernel launches and steps served so far, whether the kernel is believed to be running, where the mailbox is.
  * ----------------------------------------------------------------------------------------- */
 int ctk_resident_enable(ctk_handle* h, int on, double idle_us);

@@ -36,6 +36,11 @@ for k, e in list(engs.items()) + list(others.items()):
     n = e.predictor_weight_count()
     if n and k not in ("mppi_mlp", "rpgd_mlp"):
         e.set_predictor_weights((np.random.default_rng(20).standard_normal(n) * 0.15).astype(np.float32))
+# the resident form under two regimes: idle time shorter than the gap between its steps here (it leaves and is launched again every step) and longer
+engs["mppi_res_short"] = CtkEngine("mppi", "ODE", num_rollouts=1024, mpc_horizon=50, dt=0.02, seed=21)
+engs["mppi_res_long"] = CtkEngine("mppi", "ODE", num_rollouts=512, mpc_horizon=30, dt=0.02, seed=22, period_interpolation_inducing_points=5)
+engs["mppi_res_short"].resident_enable(True, 50.0)
+engs["mppi_res_long"].resident_enable(True, 50000.0)
 for k in ("rpgd_gru_t", "rpgd_mlp_t"):
     engs[k].reset()
 others["hover_rpgd"].reset()
@@ -49,15 +54,20 @@ engs["mppi_log"].log_enable(64)
 states = {k: np.array([0.0, 0.0, 3.0, 0.0], np.float32) for k in engs}
 t0 = time.time()
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+slow = {}
 for i in range(STEPS):
     for k, e in engs.items():
+        _t0 = time.perf_counter()
         u = e.step(states[k])
+        slow[k] = max(slow.get(k, 0.0), time.perf_counter() - _t0) if i > 5 else 0.0
         assert np.isfinite(u).all() and abs(float(u[0])) <= 1.0 + 1e-6, (k, i, u)
         plant_step(states[k], float(u[0]))
         if not np.isfinite(states[k]).all() or abs(states[k][0]) > 50:
             states[k] = np.array([0.0, 0.0, rng.uniform(-3, 3), 0.0], np.float32)
     for k, e in others.items():            # no host plant for these: the state drifts a little every step
+        _t0 = time.perf_counter()
         u = e.step(ostate[k])
+        slow[k] = max(slow.get(k, 0.0), time.perf_counter() - _t0) if i > 5 else 0.0
         assert np.isfinite(u).all() and (np.abs(u) <= 1.0 + 1e-6).all(), (k, i, u)
         ostate[k][0] = 0.1 + 0.05 * np.sin(0.01 * i); ostate[k][2] = 0.2 + 0.05 * np.cos(0.013 * i)
     if i % 97 == 0:
@@ -67,5 +77,7 @@ for i in range(STEPS):
         engs["mppi"].reset(); engs["rand"].reset()
         a = engs["mppi_log"].log_read("J", max(0, engs["mppi_log"].log_count() - 10), min(10, engs["mppi_log"].log_count()))
         assert np.isfinite(a).all()
+print("slowest step per engine (ms):", {k: round(v * 1e3, 2) for k, v in slow.items()})
+print("resident:", {k: engs[k].resident_stats() for k in ("mppi_res_short", "mppi_res_long")})
 print("soak ok", time.time() - t0, "s;", {k: [round(float(x), 3) for x in v] for k, v in states.items()})
 for e in list(engs.values()) + list(others.values()): e.close()
