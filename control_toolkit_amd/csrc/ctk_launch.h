@@ -270,6 +270,12 @@ hipError_t ctk_launch_g_rpgd_descent_split(hipStream_t st, int env, int net, con
                                            const AdamK& ad, float* Q, float* m, float* v, const float* bc_table, int bc_len, int t0, int iters,
                                            const float* wperm, const float* wperm_bwd, const float* hidden, float* scratch,
                                            hipEvent_t e0, hipEvent_t e1);
+bool ctk_g_rpgd_wide_ok(int env, int net, int N, int H);          // the MLP descent as phase + Jacobian launches (N <= 4 096)
+size_t ctk_g_rpgd_scratch_floats_wide(int N, int H);
+const char* ctk_g_rpgd_wide_name(int env);
+hipError_t ctk_launch_g_rpgd_wide_split(hipStream_t st, int env, const RolloutArgs& a, const float* params, float dt, int isteps, const AdamK& ad,
+                                        float* Q, float* m, float* v, const float* bc_table, int bc_len, int t0, int iters, const float* wperm,
+                                        float* scratch, hipEvent_t e0, hipEvent_t e1);
 bool ctk_g_rollout_split_ok(int env, int net, int N, int H, int cols);
 size_t ctk_g_rollout_split_lds(int net, int cols, int H, int C);
 int ctk_g_rollout_split_blocks(int N);

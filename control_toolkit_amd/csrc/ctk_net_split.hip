@@ -537,6 +537,268 @@ __global__ __launch_bounds__(64 * SP::WAVES) void ctk_g_rpgd_descent_split(Rollo
     }
 }
 
+// ---- RPGD descent with the MLP predictor, WIDE form (the template counterpart of ctk_rpgd.hip: ctk_rpgd_mlp_wide / _jacobians) -----------
+// The reverse sweep of ctk_g_rpgd_descent_split is a chain of H dependent network products per tile (two barriers per step) while the chip
+// idles.  But lambda_h = c_h + J_h^T lambda_{h+1} is LINEAR in lambda once the step Jacobians J_h = d s_{h+1} / d (s_h, u_h) — S x (S + C)
+// — are known, and those depend on the taped activations only:
+//   ctk_g_rpgd_jac_split    one wave per (16-plan tile, step), grid-wide: S + C forward-mode tangent passes through the network on the matrix
+//                           cores (layer 1 of tangent j is column j of W1 — one MFMA per tile against an indicator B operand; 2 + 16 + 8
+//                           MFMAs per tangent); lane (c, g) ends with rows g and 4+g of column j for plan c and stores them into the record
+//                           [tile][step][plan 16][column 16][row 8];
+//   ctk_g_rpgd_wide_split   the phase launch (16 plans per workgroup, two waves): [update from the previous launch's states and Jacobians:
+//                           cost gradients over (step, plan) pairs, the adjoint chain — 8 lanes per plan, lane i owns columns i and 8+i,
+//                           lambda passed round by 8 shuffles per step, records read two steps ahead —, clip_by_norm, Adam] then
+//                           [forward with tape (SplitMlp) | final cost pass].
+// iters + 1 phase launches and iters Jacobian launches per MPC step, in stream order.  Scratch per tile: activations [H][2][2][64] float4,
+// states [H+1][64][2], records [H][16][16][8].
+constexpr int GW_REC = 16 * 16 * 8;                                  // floats of one (tile, step) record
+__host__ __device__ inline size_t gw_tile_floats(int H) { return (size_t)H * (2 * 2 * 64 * 4) + (size_t)(H + 1) * 128 + (size_t)H * GW_REC; }
+__host__ __device__ inline size_t gw_xs_off(int H) { return (size_t)H * (2 * 2 * 64 * 4); }
+__host__ __device__ inline size_t gw_rec_off(int H) { return gw_xs_off(H) + (size_t)(H + 1) * 128; }
+
+template <int ENV, bool K3>
+__global__ __launch_bounds__(64) void ctk_g_rpgd_jac_split(int H, const float* __restrict__ wperm, float* __restrict__ scratch) {
+    using E = Env<ENV>;
+    constexpr int IO = E::S + E::C;
+    static_assert(IO <= (K3 ? 12 : 8), "network inputs");
+    const int tile = blockIdx.x / H, h = blockIdx.x - tile * H;
+    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+    const MlpFwdW w = mlp_load_fwd(wperm);
+    float* base = scratch + (size_t)tile * gw_tile_floats(H);
+    const float4* act = reinterpret_cast<const float4*>(base) + (size_t)h * (2 * 2 * 64) + lane;     // [wave m][h1 | h2][64]
+    f32x4 d1[2], d2[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const f32x4 h1 = ld4(act + (m * 2 + 0) * 64), h2 = ld4(act + (m * 2 + 1) * 64);
+        d1[m] = 1.0f - h1 * h1;
+        d2[m] = 1.0f - h2 * h2;
+    }
+    float* rec = base + gw_rec_off(H) + (size_t)h * GW_REC + c * 128;
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < IO; ++j) {
+        const float ind = (g == (j & 3)) ? 1.0f : 0.0f;                 // B = e_j: input j lives in k-step j / 4, k-slot j % 4
+        f32x4 t1[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) t1[m] = CTK_MFMA(w.w1[m][j >> 2], ind, z) * d1[m];
+        f32x4 z0 = z, z1 = z;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float b = t1[q >> 2][q & 3];
+            z0 = CTK_MFMA(w.w2[0][q], b, z0);
+            z1 = CTK_MFMA(w.w2[1][q], b, z1);
+        }
+        const f32x4 t2[2] = {z0 * d2[0], z1 * d2[1]};
+        f32x4 o0 = z, o1 = z;
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+            o0 = CTK_MFMA(w.w3[q], t2[q >> 2][q & 3], o0);
+            o1 = CTK_MFMA(w.w3[q + 1], t2[(q + 1) >> 2][(q + 1) & 3], o1);
+        }
+        rec[j * 8 + g] = o0[0] + o1[0];                                 // d s'_g / d x_j, d s'_{4+g} / d x_j of plan c
+        rec[j * 8 + 4 + g] = o0[1] + o1[1];
+    }
+}
+
+// LDS: exchange slots | reductions | states xs[H+1][64][2] | cost-gradient terms gs[H+1][64][2] | plans q[HC][17] | gradients g[HC][17]
+template <int ENV, bool K3>
+__global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, typename Env<ENV>::K k, AdamK ad, float* __restrict__ Q,
+                                                            float* __restrict__ mom, float* __restrict__ var, const float* __restrict__ bc_table,
+                                                            int bc_len, int ti, const float* __restrict__ wperm, float* __restrict__ scratch,
+                                                            int do_update, int last) {
+    using E = Env<ENV>;
+    using SP = SplitMlp<K3>;
+    constexpr int S = E::S, C = E::C, IO = S + C, BLOCK = 128, NPARTS = BLOCK / G4_TRAJ;
+    extern __shared__ float lds[];
+    const int H = a.H, HC = H * C;
+    float* ex = lds;
+    float* red_s = ex + SP::EX_FWD;
+    float* xs_s = red_s + G4_RED;
+    float* gs_s = xs_s + (H + 1) * 128;
+    float* q_s = gs_s + (H + 1) * 128;
+    float* g_s = q_s + HC * G4_LD;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * G4_TRAJ;
+    const int rows = min(G4_TRAJ, a.N - row0);
+    const int total = rows * HC;
+    const size_t gbase = (size_t)row0 * HC;
+    float* tbase = scratch + (size_t)blockIdx.x * gw_tile_floats(H);
+    float4* tape = reinterpret_cast<float4*>(tbase) + wave * 2 * 64 + lane;          // + h * 256 + i * 64
+    float* xs_g = tbase + gw_xs_off(H);
+    const float* rec_g = tbase + gw_rec_off(H);
+
+    for (int i = t; i < G4_TRAJ * HC; i += BLOCK) {
+        const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, hc = i - r * HC;
+        q_s[hc * G4_LD + r] = i < total ? Q[gbase + i] : 0.0f;
+    }
+    if (do_update) {                                       // (xs: (H + 1) * 128 floats, 16-byte aligned on both sides)
+        for (int i = t; i < (H + 1) * 32; i += BLOCK) reinterpret_cast<float4*>(xs_s)[i] = reinterpret_cast<const float4*>(xs_g)[i];
+    }
+    typename SP::Fwd nf;
+    nf.load(wperm, wave, lane);
+    float up0[C];
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) up0[cc] = a.u_prev_dev ? a.u_prev_dev[cc] : a.u_prev[cc];
+    const float inv = a.inv_Hp1;
+    const float s00 = g < S ? lane_state4(a, g) : 0.0f, s01 = 4 + g < S ? lane_state4(a, g, 4) : 0.0f;
+    const int pc = t & 15, part = t >> 4;
+    __syncthreads();
+    auto state_of = [&](int h, int p, float (&s)[S]) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) s[j] = xs_s[(h * 64 + (j & 3) * 16 + p) * 2 + (j >> 2)];
+    };
+    auto sum_parts = [&](float v) {
+        v = sum_over_groups(v);
+        if (g == 0) red_s[wave * 16 + c] = v;
+        __syncthreads();
+        const float r = red_s[c] + red_s[16 + c];
+        __syncthreads();
+        return r;
+    };
+
+    if (do_update) {
+        // ---- what of the gradient does not ride on the adjoint chain, over (step, plan) pairs (as ctk_g_rpgd_descent_split)
+        for (int idx = t; idx < (H + 1) * G4_TRAJ; idx += BLOCK) {
+            const int h = idx >> 4, p = idx & 15;
+            float s[S], gs[S];
+            state_of(h, p, s);
+            if (h < H) E::stage_grad_state(k, s, gs); else E::terminal_grad(k, s, gs);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gs_s[(h * 64 + (j & 3) * 16 + p) * 2 + (j >> 2)] = j < S ? gs[j < S ? j : 0] * inv : 0.0f;
+            if (h < H) {
+                float u[C], upv[C], un[C], gu[C], gp[C], gu2[C], gpn[C];
+#pragma unroll
+                for (int cc = 0; cc < C; ++cc) {
+                    u[cc] = q_s[(h * C + cc) * G4_LD + p];
+                    upv[cc] = h > 0 ? q_s[((h - 1) * C + cc) * G4_LD + p] : up0[cc];
+                    un[cc] = h + 1 < H ? q_s[((h + 1) * C + cc) * G4_LD + p] : 0.0f;
+                    gpn[cc] = 0.0f;
+                }
+                E::input_grad(k, u, upv, gu, gp);
+                if (h + 1 < H) E::input_grad(k, un, u, gu2, gpn);
+#pragma unroll
+                for (int cc = 0; cc < C; ++cc) g_s[(h * C + cc) * G4_LD + p] = (gu[cc] + gpn[cc]) * inv;
+            }
+        }
+        __syncthreads();
+        // ---- the adjoint chain: plan p = t / 8 (its 8 lanes are neighbours), lane i owns column i (a state component: lambda_i; or an
+        //      input: its gradient) and, where the network has more than 8 inputs, column 8 + i
+        {
+            const int p = t >> 3, i = t & 7, lbase = lane & ~7;
+            auto gs_at = [&](int h, int j) { return gs_s[(h * 64 + (j & 3) * 16 + p) * 2 + (j >> 2)]; };
+            float lam = i < S ? gs_at(H, i) : 0.0f;
+            // the records were written by waves on every XCD: a load is a trip to memory (~2 us), so they are read in register chunks of
+            // CH steps, TWO chunks deep — the whole of chunk k+1 is in flight while chunk k is walked
+            constexpr int CH = 8, W4 = IO > 8 ? 4 : 2;          // float4 per step and lane: column i (+ column 8+i)
+            float4 cur[CH][W4], nxt[CH][W4];
+            auto fetch_chunk = [&](int htop, float4 (&dst)[CH][W4]) {   // steps htop, htop-1, ..., htop-CH+1 (those >= 0)
+#pragma unroll
+                for (int d = 0; d < CH; ++d) {
+                    const int h = htop - d;
+                    if (h >= 0) {
+                        const float4* r4 = reinterpret_cast<const float4*>(rec_g + (size_t)h * GW_REC + p * 128);
+                        dst[d][0] = r4[i * 2]; dst[d][1] = r4[i * 2 + 1];
+                        if constexpr (IO > 8) { dst[d][2] = r4[(8 + i) * 2]; dst[d][3] = r4[(8 + i) * 2 + 1]; }
+                    }
+                }
+            };
+            fetch_chunk(H - 1, cur);
+            for (int htop = H - 1; htop >= 0; htop -= CH) {
+                fetch_chunk(htop - CH, nxt);
+#pragma unroll
+                for (int d = 0; d < CH; ++d) {
+                    const int h = htop - d;
+                    if (h >= 0) {
+                        const float4 A0 = cur[d][0], A1 = cur[d][1];
+                        float l[8];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) l[r] = r < S ? __shfl(lam, lbase + r, 64) : 0.0f;
+                        const float dA = (A0.x * l[0] + A0.y * l[1]) + (A0.z * l[2] + A0.w * l[3]) + ((A1.x * l[4] + A1.y * l[5]) + (A1.z * l[6] + A1.w * l[7]));
+                        if (i < S) lam = gs_at(h, i) + dA;
+                        else if (i < IO) g_s[(h * C + (i - S)) * G4_LD + p] += dA;
+                        if constexpr (IO > 8) {
+                            if (8 + i < IO) {
+                                const float4 B0 = cur[d][2], B1 = cur[d][3];
+                                const float dB = (B0.x * l[0] + B0.y * l[1]) + (B0.z * l[2] + B0.w * l[3]) + ((B1.x * l[4] + B1.y * l[5]) + (B1.z * l[6] + B1.w * l[7]));
+                                g_s[(h * C + (8 + i - S)) * G4_LD + p] += dB;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < CH; ++d)
+#pragma unroll
+                    for (int q = 0; q < W4; ++q) cur[d][q] = nxt[d][q];
+            }
+        }
+        __syncthreads();
+        // ---- per-plan clip_by_norm, Adam, clip
+        float n2 = 0.0f;
+        for (int hc = part; hc < HC; hc += NPARTS) { const float x = g_s[hc * G4_LD + pc]; n2 += x * x; }
+        n2 = sum_parts(n2);
+        const float scl = ad.clip / fmaxf(sqrtf(n2), ad.clip);
+        if (wave == 0 && g == 0) red_s[64 + c] = scl;
+        __syncthreads();
+        const float bc1 = ti <= bc_len ? bc_table[2 * (ti - 1)] : 1.0f;
+        const float bc2 = ti <= bc_len ? bc_table[2 * (ti - 1) + 1] : 1.0f;
+        for (int i = t; i < total; i += BLOCK) {
+            const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, hc = i - r * HC, cc = hc % C;
+            float mm = 0.0f, vv = 0.0f;
+            if (ad.rule != 2) { mm = mom[gbase + i]; vv = var[gbase + i]; }
+            const float gg = g_s[hc * G4_LD + r] * red_s[64 + r];
+            q_s[hc * G4_LD + r] = adam_update(ad, q_s[hc * G4_LD + r], gg, mm, vv, bc1, bc2, a.lo[cc], a.hi[cc]);
+            if (ad.rule != 2) { mom[gbase + i] = mm; var[gbase + i] = vv; }
+        }
+        __syncthreads();
+    }
+    // ---- forward: with tape for the next launch's update, or get_action's cost pass (optimizer_rpgd.py:342)
+    {
+        nf.begin(nullptr, g);
+        float sv0 = s00, sv1 = s01;
+        for (int h = 0; h < H; ++h) {
+            float u[C];
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) u[cc] = q_s[(h * C + cc) * G4_LD + c];
+            if (wave == (h & 1)) reinterpret_cast<float2*>(xs_s)[h * 64 + lane] = make_float2(sv0, sv1);
+            float x0, x1, x2;
+            split_operands<S, C>(sv0, sv1, u, g, x0, x1, x2);
+            const MlpPair o = last ? nf.template step<false>(x0, x1, x2, ex, wave, lane, nullptr)
+                                   : nf.template step<true>(x0, x1, x2, ex, wave, lane, tape + (size_t)h * (2 * 2 * 64));
+            sv0 = o.lo; sv1 = o.hi;
+        }
+        if (wave == 0) reinterpret_cast<float2*>(xs_s)[H * 64 + lane] = make_float2(sv0, sv1);
+        __syncthreads();
+    }
+    if (!last) {
+        for (int i = t; i < (H + 1) * 32; i += BLOCK) reinterpret_cast<float4*>(xs_g)[i] = reinterpret_cast<const float4*>(xs_s)[i];
+    } else {
+        float cs = 0.0f;
+        for (int h = part; h < H; h += NPARTS) {
+            float s[S], u[C], upv[C];
+            state_of(h, pc, s);
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) {
+                u[cc] = q_s[(h * C + cc) * G4_LD + pc];
+                upv[cc] = h > 0 ? q_s[((h - 1) * C + cc) * G4_LD + pc] : up0[cc];
+            }
+            cs += E::stage_cost(k, s, u, upv);
+        }
+        if (part == 0) {
+            float s[S];
+            state_of(H, pc, s);
+            cs += E::terminal_cost(k, s);
+        }
+        cs = sum_parts(cs);
+        if (wave == 0 && g == 0 && row0 + c < a.N) a.J[row0 + c] = cs * inv;
+    }
+    if (do_update) {
+        for (int i = t; i < total; i += BLOCK) {
+            const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, hc = i - r * HC;
+            Q[gbase + i] = q_s[hc * G4_LD + r];
+        }
+    }
+}
+
 // ---- rollout + cost (MPPI / affine modes of ctk_generic_net.hip: ctk_g_rollout_net) ---------------------------------------------------
 // 16 trajectories per workgroup.  Inputs (interpolation, shifted nominal, clip, MPPI correction) are formed for all (step, trajectory)
 // pairs before the recurrence, the costs from the states it leaves in LDS after it; the recurrence itself is gru4_step only.
@@ -790,6 +1052,52 @@ hipError_t ctk_launch_g_rpgd_descent_split(hipStream_t st, int env, int net, con
             launch_descent_split<EV, SplitMlp<(E::S + E::C > 8)>>(st, a, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wperm_bwd, hidden, scratch, e0, e1);
         }
     });
+    return hipGetLastError();
+}
+
+// the wide form of the MLP descent: populations that leave the chip idle under the chain (as CartPole's own, ctk_rpgd.hip: N <= 4 096)
+bool ctk_g_rpgd_wide_ok(int env, int net, int N, int H) {
+    static const bool narrow = getenv("CTK_RPGD_NARROW") != nullptr;      // diagnostic switch: A/B the two forms (shared with ctk_rpgd.hip)
+    int S = 0, C = 0;
+    env_dims(env, &S, &C);
+    // (more than 8 network inputs: S + C tangent passes and two record columns per lane — measured slower than the split chain, 760 vs 742 us)
+    return !narrow && net == NET_MLP && S + C <= 8 && N <= 4096 && ctk_g_rpgd_split_ok(env, net, N, H);
+}
+size_t ctk_g_rpgd_scratch_floats_wide(int N, int H) { return (size_t)((N + G4_TRAJ - 1) / G4_TRAJ) * gw_tile_floats(H); }
+const char* ctk_g_rpgd_wide_name(int env) {
+    int S = 0, C = 0;
+    env_dims(env, &S, &C);
+    return ctk_kernel_name("ctk_g_rpgd_wide_split<%d, %4$s> + ctk_g_rpgd_jac_split", env, 0, 0, S + C > 8 ? "true" : "false");
+}
+
+template <int EV>
+static void launch_wide_split(hipStream_t st, const RolloutArgs& a_in, const float* params, float dt, int isteps, const AdamK& ad, float* Q, float* m,
+                              float* v, const float* bc_table, int bc_len, int t0, int iters, const float* wperm, float* scratch, hipEvent_t e0,
+                              hipEvent_t e1) {
+    using E = Env<EV>;
+    constexpr bool K3 = E::S + E::C > 8;
+    RolloutArgs a = a_in;
+    a.C = E::C; a.p_magic = g4_magic_of(a.H * E::C);
+    const typename E::K k = E::derive(params, dt, isteps);
+    const int tiles = (a.N + G4_TRAJ - 1) / G4_TRAJ;
+    const size_t lds = (size_t)(SplitMlp<K3>::EX_FWD + G4_RED + 2 * (a.H + 1) * 128 + 2 * a.H * E::C * G4_LD) * sizeof(float);
+    for (int it = 0; it <= iters; ++it) {
+        const bool last = it == iters;
+        hipEvent_t s0 = it == 0 ? e0 : nullptr, s1 = last ? e1 : nullptr;
+        if (s0 || s1)
+            hipExtLaunchKernelGGL((ctk_g_rpgd_wide_split<EV, K3>), dim3(tiles), dim3(128), lds, st, s0, s1, 0, a, k, ad, Q, m, v, bc_table, bc_len, t0 + it, wperm,
+                                  scratch, it > 0 ? 1 : 0, last ? 1 : 0);
+        else
+            hipLaunchKernelGGL((ctk_g_rpgd_wide_split<EV, K3>), dim3(tiles), dim3(128), lds, st, a, k, ad, Q, m, v, bc_table, bc_len, t0 + it, wperm, scratch,
+                               it > 0 ? 1 : 0, last ? 1 : 0);
+        if (!last) hipLaunchKernelGGL((ctk_g_rpgd_jac_split<EV, K3>), dim3(tiles * a.H), dim3(64), 0, st, a.H, wperm, scratch);
+    }
+}
+
+hipError_t ctk_launch_g_rpgd_wide_split(hipStream_t st, int env, const RolloutArgs& a, const float* params, float dt, int isteps, const AdamK& ad,
+                                        float* Q, float* m, float* v, const float* bc_table, int bc_len, int t0, int iters, const float* wperm,
+                                        float* scratch, hipEvent_t e0, hipEvent_t e1) {
+    CTK_FOR_ENV(env, EV, { launch_wide_split<EV>(st, a, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, scratch, e0, e1); });
     return hipGetLastError();
 }
 

@@ -381,7 +381,7 @@ def test_cartpole_generic_mlp_kernels_match_tuned_mlp_kernels(opt):
         kw.update(outer_its=3, resamp_per=2, opt_keep_k=40, sample_whole_control_space=1)
     w = O.mlp_default_weights(2)
     a, b = CtkEngine(opt, "MLP", **kw), CtkEngine(opt, "MLP", generic_kernels=True, **kw)
-    assert "ctk_g_" in b.dominant_kernel() and "Mlp" in b.dominant_kernel()      # SplitMlp<.> (N <= 8192) or NetMlp
+    assert "ctk_g_" in b.dominant_kernel() and ("Mlp" in b.dominant_kernel() or "wide_split" in b.dominant_kernel())   # SplitMlp<.> / the wide RPGD form
     a.set_predictor_weights(w); b.set_predictor_weights(w)
     if opt == "rpgd":
         a.reset(); b.reset()
