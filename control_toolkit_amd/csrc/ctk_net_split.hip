@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64 * SP::WAVES) void ctk_g_rpgd_descent_split(Rollo
 //                           [tile][step][plan 16][column 16][row 8];
 //   ctk_g_rpgd_wide_split   the phase launch (16 plans per workgroup, two waves): [update from the previous launch's states and Jacobians:
 //                           cost gradients over (step, plan) pairs, the adjoint chain — 8 lanes per plan, lane i owns columns i and 8+i,
-//                           lambda passed round by 8 shuffles per step, records read two steps ahead —, clip_by_norm, Adam] then
+//                           lambda passed round by DPP quad broadcasts, records read through a register ring —, clip_by_norm, Adam] then
 //                           [forward with tape (SplitMlp) | final cost pass].
 // iters + 1 phase launches and iters Jacobian launches per MPC step, in stream order.  Scratch per tile: activations [H][2][2][64] float4,
 // states [H+1][64][2], records [H][16][16][8].
@@ -626,13 +626,69 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
     float4* tape = reinterpret_cast<float4*>(tbase) + wave * 2 * 64 + lane;          // + h * 256 + i * 64
     float* xs_g = tbase + gw_xs_off(H);
     const float* rec_g = tbase + gw_rec_off(H);
+    // The adjoint chain's operands (below): lane (plan cp = t / 8, ci = t % 8) reads rows < S of column ci (and of column 8 + ci where the
+    // network has more than 8 inputs) of every step's record.  The records were written by waves on every XCD, so a load is a trip to
+    // memory (~2 us) against ~0.1 us of chain work per step: they travel through a register ring RING steps deep that is filled HERE, before
+    // anything else, and refilled slot by slot as the chain consumes it.
+    constexpr int RW = S > 4 ? 2 : 1, W4 = RW * (IO > 8 ? 2 : 1), RING = 32 / W4;
+    float4 ring[RING][W4];
+    const int cp = t >> 3, ci = t & 7;
+    auto rec_fetch = [&](int h, float4 (&dst)[W4]) {
+        const float4* r4 = reinterpret_cast<const float4*>(rec_g + (size_t)h * GW_REC + cp * 128);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            dst[r] = r4[ci * 2 + r];
+            if constexpr (IO > 8) dst[RW + r] = r4[(8 + ci) * 2 + r];
+        }
+    };
+    auto rec_dot = [&](const float4 (&v)[W4], int o, const float (&l)[8]) {
+        float d = (v[o].x * l[0] + v[o].y * l[1]) + (v[o].z * l[2] + v[o].w * l[3]);
+        if constexpr (RW == 2) d += (v[o + 1].x * l[4] + v[o + 1].y * l[5]) + (v[o + 1].z * l[6] + v[o + 1].w * l[7]);
+        return d;
+    };
+    if (do_update) {
+#pragma unroll
+        for (int d = 0; d < RING; ++d) rec_fetch(max(H - 1 - d, 0), ring[d]);
+    }
 
-    for (int i = t; i < G4_TRAJ * HC; i += BLOCK) {
-        const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, hc = i - r * HC;
-        q_s[hc * G4_LD + r] = i < total ? Q[gbase + i] : 0.0f;
+    // Everything this launch reads was written by other launches, on every XCD: a dependent trip to memory costs ~1-2 us, so the loads go
+    // out in batches of AB per thread with nothing waited for in between (a plain copy loop waits once per element): the chain's ring
+    // (above), the Adam moments of this thread's first AB elements, the plans, the state tape
+    constexpr int AB = 8;
+    float mm0[AB], vv0[AB];
+    float bc1 = 1.0f, bc2 = 1.0f;
+    if (do_update) {
+        if (ti <= bc_len) { bc1 = bc_table[2 * (ti - 1)]; bc2 = bc_table[2 * (ti - 1) + 1]; }
+#pragma unroll
+        for (int j = 0; j < AB; ++j) {
+            const int i = min(t + j * BLOCK, total - 1);
+            mm0[j] = 0.0f; vv0[j] = 0.0f;
+            if (ad.rule != 2) { mm0[j] = mom[gbase + i]; vv0[j] = var[gbase + i]; }
+        }
+    }
+    for (int b = t; b < G4_TRAJ * HC; b += AB * BLOCK) {
+        float qv[AB];
+#pragma unroll
+        for (int j = 0; j < AB; ++j) qv[j] = Q[gbase + min(b + j * BLOCK, total - 1)];
+#pragma unroll
+        for (int j = 0; j < AB; ++j) {
+            const int i = b + j * BLOCK;
+            if (i < G4_TRAJ * HC) {
+                const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, hc = i - r * HC;
+                q_s[hc * G4_LD + r] = i < total ? qv[j] : 0.0f;
+            }
+        }
     }
     if (do_update) {                                       // (xs: (H + 1) * 128 floats, 16-byte aligned on both sides)
-        for (int i = t; i < (H + 1) * 32; i += BLOCK) reinterpret_cast<float4*>(xs_s)[i] = reinterpret_cast<const float4*>(xs_g)[i];
+        const int n4 = (H + 1) * 32;
+        for (int b = t; b < n4; b += AB * BLOCK) {
+            float4 xv[AB];
+#pragma unroll
+            for (int j = 0; j < AB; ++j) xv[j] = reinterpret_cast<const float4*>(xs_g)[min(b + j * BLOCK, n4 - 1)];
+#pragma unroll
+            for (int j = 0; j < AB; ++j)
+                if (b + j * BLOCK < n4) reinterpret_cast<float4*>(xs_s)[b + j * BLOCK] = xv[j];
+        }
     }
     typename SP::Fwd nf;
     nf.load(wperm, wave, lane);
@@ -684,51 +740,60 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
         // ---- the adjoint chain: plan p = t / 8 (its 8 lanes are neighbours), lane i owns column i (a state component: lambda_i; or an
         //      input: its gradient) and, where the network has more than 8 inputs, column 8 + i
         {
-            const int p = t >> 3, i = t & 7, lbase = lane & ~7;
-            auto gs_at = [&](int h, int j) { return gs_s[(h * 64 + (j & 3) * 16 + p) * 2 + (j >> 2)]; };
-            float lam = i < S ? gs_at(H, i) : 0.0f;
-            // the records were written by waves on every XCD: a load is a trip to memory (~2 us), so they are read in register chunks of
-            // CH steps, TWO chunks deep — the whole of chunk k+1 is in flight while chunk k is walked
-            constexpr int CH = 8, W4 = IO > 8 ? 4 : 2;          // float4 per step and lane: column i (+ column 8+i)
-            float4 cur[CH][W4], nxt[CH][W4];
-            auto fetch_chunk = [&](int htop, float4 (&dst)[CH][W4]) {   // steps htop, htop-1, ..., htop-CH+1 (those >= 0)
+            const int p = cp, i = ci;
+            // the lane's own LDS word of step h: a state lane's cost-gradient term gs[h][i][p]; an input lane's direct gradient term
+            // g[h][i - S][p], which it overwrites with the total.  Read BEFORE the shuffles are waited for, written without a wait: the
+            // step's dependent path is shuffle -> dot -> add only
+            const bool is_state = i < S, is_input = i >= S && i < IO;
+            const int w0 = is_state ? (int)(gs_s - lds) + ((i & 3) * 16 + p) * 2 + (i >> 2) : is_input ? (int)(g_s - lds) + (i - S) * G4_LD + p : (int)(gs_s - lds);
+            const int wstep = is_state ? 128 : is_input ? C * G4_LD : 0;
+            float lam = is_state ? lds[w0 + H * 128] : 0.0f;
+            // the walk: step h uses ring slot (H - 1 - h) % RING and refills it with step h - RING.  Whole blocks of RING steps with nothing
+            // conditional in them (the steps below 0 of the last block run on clamped addresses and write nothing; refills nobody uses re-read
+            // step 0): the compiler then knows how many loads are in flight at every use and waits for that one alone — with a guard per step
+            // it waits for ALL of them at the top of every block, a trip to memory each
+            const int nblk = (H + RING - 1) / RING;
+            float o0 = lds[w0 + (H - 1) * wstep], o1 = lds[w0 + max(H - 2, 0) * wstep];
+            for (int blk = 0, htop = H - 1; blk < nblk; ++blk, htop -= RING) {
 #pragma unroll
-                for (int d = 0; d < CH; ++d) {
-                    const int h = htop - d;
-                    if (h >= 0) {
-                        const float4* r4 = reinterpret_cast<const float4*>(rec_g + (size_t)h * GW_REC + p * 128);
-                        dst[d][0] = r4[i * 2]; dst[d][1] = r4[i * 2 + 1];
-                        if constexpr (IO > 8) { dst[d][2] = r4[(8 + i) * 2]; dst[d][3] = r4[(8 + i) * 2 + 1]; }
-                    }
-                }
-            };
-            fetch_chunk(H - 1, cur);
-            for (int htop = H - 1; htop >= 0; htop -= CH) {
-                fetch_chunk(htop - CH, nxt);
-#pragma unroll
-                for (int d = 0; d < CH; ++d) {
-                    const int h = htop - d;
-                    if (h >= 0) {
-                        const float4 A0 = cur[d][0], A1 = cur[d][1];
+                for (int d = 0; d < RING; ++d) {
+                    const int hr = htop - d, h = max(hr, 0);
+                    {
+                        const int w = w0 + h * wstep;
+                        const float own = o0;
+                        o0 = o1;
+                        o1 = lds[w0 + max(hr - 2, 0) * wstep];         // two steps ahead: an LDS read takes longer than a step
+                        __builtin_amdgcn_sched_barrier(0);             // (issued here, not after the dot product)
+                        // lambda_r of the plan sits in lane r of its 8: a quad broadcast of lamA gives components 0..3, of lamB 4..7 — DPP
+                        // operands of the multiplies themselves, no trip through the LDS crossbar
+                        // (bank masks, not a select: a select becomes a branch, and DPP reads nothing from lanes the branch switched off)
+                        const int lami = __builtin_bit_cast(int, lam);
+                        const float lamA = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(lami, lami, 0x114, 0xF, 0xA, false));   // lanes 4..7 <- 0..3 (row_shr:4)
+                        float lamB = 0.0f;
+                        if constexpr (S > 4) lamB = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(lami, lami, 0x104, 0xF, 0x5, false));   // lanes 0..3 <- 4..7 (row_shl:4)
                         float l[8];
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) l[r] = r < S ? __shfl(lam, lbase + r, 64) : 0.0f;
-                        const float dA = (A0.x * l[0] + A0.y * l[1]) + (A0.z * l[2] + A0.w * l[3]) + ((A1.x * l[4] + A1.y * l[5]) + (A1.z * l[6] + A1.w * l[7]));
-                        if (i < S) lam = gs_at(h, i) + dA;
-                        else if (i < IO) g_s[(h * C + (i - S)) * G4_LD + p] += dA;
+                        for (int r = 0; r < 8; ++r) l[r] = 0.0f;
+                        l[0] = dpp_mov<0x00>(lamA);
+                        if constexpr (S > 1) l[1] = dpp_mov<0x55>(lamA);
+                        if constexpr (S > 2) l[2] = dpp_mov<0xAA>(lamA);
+                        if constexpr (S > 3) l[3] = dpp_mov<0xFF>(lamA);
+                        if constexpr (S > 4) l[4] = dpp_mov<0x00>(lamB);
+                        if constexpr (S > 5) l[5] = dpp_mov<0x55>(lamB);
+                        if constexpr (S > 6) l[6] = dpp_mov<0xAA>(lamB);
+                        if constexpr (S > 7) l[7] = dpp_mov<0xFF>(lamB);
+                        const float dA = rec_dot(ring[d], 0, l);
+                        float dB = 0.0f;
+                        if constexpr (IO > 8) dB = rec_dot(ring[d], RW, l);
+                        rec_fetch(max(hr - RING, 0), ring[d]);
+                        const float v = own + dA;
+                        if (is_input && hr >= 0) lds[w] = v;
+                        lam = is_state ? v : 0.0f;
                         if constexpr (IO > 8) {
-                            if (8 + i < IO) {
-                                const float4 B0 = cur[d][2], B1 = cur[d][3];
-                                const float dB = (B0.x * l[0] + B0.y * l[1]) + (B0.z * l[2] + B0.w * l[3]) + ((B1.x * l[4] + B1.y * l[5]) + (B1.z * l[6] + B1.w * l[7]));
-                                g_s[(h * C + (8 + i - S)) * G4_LD + p] += dB;
-                            }
+                            if (8 + i < IO && hr >= 0) g_s[(h * C + (8 + i - S)) * G4_LD + p] += dB;
                         }
                     }
                 }
-#pragma unroll
-                for (int d = 0; d < CH; ++d)
-#pragma unroll
-                    for (int q = 0; q < W4; ++q) cur[d][q] = nxt[d][q];
             }
         }
         __syncthreads();
@@ -739,15 +804,26 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
         const float scl = ad.clip / fmaxf(sqrtf(n2), ad.clip);
         if (wave == 0 && g == 0) red_s[64 + c] = scl;
         __syncthreads();
-        const float bc1 = ti <= bc_len ? bc_table[2 * (ti - 1)] : 1.0f;
-        const float bc2 = ti <= bc_len ? bc_table[2 * (ti - 1) + 1] : 1.0f;
-        for (int i = t; i < total; i += BLOCK) {
+        auto adam_element = [&](int i, float mm, float vv) {
             const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, hc = i - r * HC, cc = hc % C;
-            float mm = 0.0f, vv = 0.0f;
-            if (ad.rule != 2) { mm = mom[gbase + i]; vv = var[gbase + i]; }
             const float gg = g_s[hc * G4_LD + r] * red_s[64 + r];
             q_s[hc * G4_LD + r] = adam_update(ad, q_s[hc * G4_LD + r], gg, mm, vv, bc1, bc2, a.lo[cc], a.hi[cc]);
             if (ad.rule != 2) { mom[gbase + i] = mm; var[gbase + i] = vv; }
+        };
+#pragma unroll
+        for (int j = 0; j < AB; ++j)
+            if (t + j * BLOCK < total) adam_element(t + j * BLOCK, mm0[j], vv0[j]);
+        for (int b = t + AB * BLOCK; b < total; b += AB * BLOCK) {
+            float mm[AB], vv[AB];
+#pragma unroll
+            for (int j = 0; j < AB; ++j) {
+                const int i = min(b + j * BLOCK, total - 1);
+                mm[j] = 0.0f; vv[j] = 0.0f;
+                if (ad.rule != 2) { mm[j] = mom[gbase + i]; vv[j] = var[gbase + i]; }
+            }
+#pragma unroll
+            for (int j = 0; j < AB; ++j)
+                if (b + j * BLOCK < total) adam_element(b + j * BLOCK, mm[j], vv[j]);
         }
         __syncthreads();
     }
