@@ -370,7 +370,7 @@ int ctk_g_rollout_net_blocks(int env, int net, int mode, int N, int P, int H) {
 }
 
 const char* ctk_g_rollout_net_name(int env, int net, int mode, bool log, int N, int P, int H) {
-    if (ctk_g_rollout_split_ok(env, net, N, H, ctk_g_rollout_net_cols(env, mode, P, H))) return ctk_g_rollout_split_name(env, net, mode, log);
+    if (ctk_g_rollout_split_ok(env, net, N, H, ctk_g_rollout_net_cols(env, mode, P, H))) return ctk_g_rollout_split_name(env, net, mode, log, N, H, ctk_g_rollout_net_cols(env, mode, P, H));
     int io = 0;
     CTK_FOR_ENV(env, EV, { io = Env<EV>::S + Env<EV>::C; });
     return ctk_kernel_name("ctk_g_rollout_net<%d, %4$s, %d, %5$s>", env, mode, 0, net == NET_GRU ? "NetGru" : (io > 8 ? "NetMlpT<true>" : "NetMlp"), log ? "true" : "false");

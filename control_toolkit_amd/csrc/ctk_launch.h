@@ -279,7 +279,7 @@ hipError_t ctk_launch_g_rpgd_wide_split(hipStream_t st, int env, const RolloutAr
 bool ctk_g_rollout_split_ok(int env, int net, int N, int H, int cols);
 size_t ctk_g_rollout_split_lds(int net, int cols, int H, int C);
 int ctk_g_rollout_split_blocks(int N);
-const char* ctk_g_rollout_split_name(int env, int net, int mode, bool log);
+const char* ctk_g_rollout_split_name(int env, int net, int mode, bool log, int N, int H, int cols);
 hipError_t ctk_launch_g_rollout_split(hipStream_t st, int env, int net, int mode, const RolloutArgs& a, const float* params, float dt, int isteps,
                                       const MppiK& mk, const float* samples, const float* base, const float* scale, int rng_kind,
                                       const float* wperm, const float* hidden, float* parts, bool log, hipEvent_t e0, hipEvent_t e1,

@@ -875,20 +875,34 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
     }
 }
 
+// floats of one tile's LDS carve in ctk_g_rollout_split (a multiple of 4: the second tile of a workgroup starts 16-byte aligned)
+__host__ __device__ inline size_t split_tile_floats(int ex_fwd, int cols, int H, int C) {
+    const size_t n = (size_t)ex_fwd + G4_RED + (size_t)(H + 1) * 128 + (size_t)H * C * G4_LD + (size_t)G4_TRAJ * tile_stride(cols) + G4_TRAJ + 2 * (size_t)H * C + 3 * (size_t)H;
+    return (n + 3) & ~(size_t)3;
+}
+
 // ---- rollout + cost (MPPI / affine modes of ctk_generic_net.hip: ctk_g_rollout_net) ---------------------------------------------------
 // 16 trajectories per workgroup.  Inputs (interpolation, shifted nominal, clip, MPPI correction) are formed for all (step, trajectory)
 // pairs before the recurrence, the costs from the states it leaves in LDS after it; the recurrence itself is gru4_step only.
 // LDS: exchange slots | reductions | states xs[H+1][64][2] | inputs u[HC][17] | sample tile [16][ts] | e[16] | base, scale [HC] | interp tables
 // (the Philox path of load_tile_early spreads a row's column blocks over BLOCK / 16 threads)
-template <int ENV, class SP, int MODE, bool LOG>
-__global__ __launch_bounds__(64 * SP::WAVES) void ctk_g_rollout_split(RolloutArgs a, typename Env<ENV>::K k, MppiK mk, const float* __restrict__ samples,
+template <int ENV, class SP, int MODE, bool LOG, int TILES>
+__global__ __launch_bounds__(64 * SP::WAVES * TILES) void ctk_g_rollout_split(RolloutArgs a, typename Env<ENV>::K k, MppiK mk, const float* __restrict__ samples,
                                                               const float* __restrict__ base, const float* __restrict__ scale, int rng_kind,
                                                               const float* __restrict__ wperm, const float* __restrict__ hidden,
                                                               float* __restrict__ parts, NetFuse gz) {
     using E = Env<ENV>;
     constexpr int S = E::S, C = E::C, WAVES = SP::WAVES, BLOCK = 64 * WAVES, NPARTS = BLOCK / G4_TRAJ;
-    extern __shared__ float lds[];
+    static_assert(TILES == 1 || WAVES == 2, "two tiles per workgroup: the two-wave policies");
+    extern __shared__ float lds_all[];
     const int H = a.H, HC = H * C, cols = a.P, ts = tile_stride(cols);
+    // TILES == 2: the workgroup is two independent halves (sub = 0, 1) of BLOCK threads, each with its own tile, LDS carve and record;
+    // they only share the barriers (same control flow: every tile is full, the host sees to it).  Why: a CU gives the four waves of ONE
+    // workgroup four different SIMDs, but puts the waves of two 2-wave workgroups where it likes — measured at N = 8 192 (512 tiles,
+    // two per CU): one SIMD holds a wave of each and one idles, and the later workgroup runs its 100 steps in 78 us against 60
+    const int sub = TILES > 1 ? (int)threadIdx.x / BLOCK : 0;
+    const int vb = (int)blockIdx.x * TILES + sub;                       // the tile = the "block" of the one-tile form
+    float* lds = lds_all + (size_t)sub * split_tile_floats(SP::EX_FWD, cols, H, C);
     float* ex = lds;
     float* red_s = ex + SP::EX_FWD;
     float* xs_s = red_s + G4_RED;
@@ -900,8 +914,8 @@ __global__ __launch_bounds__(64 * SP::WAVES) void ctk_g_rollout_split(RolloutArg
     float* w0_s = scale_s + HC;
     float* w1_s = w0_s + H;
     int* i0_s = reinterpret_cast<int*>(w1_s + H);
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 15, g = lane >> 4;
-    const int row0 = blockIdx.x * G4_TRAJ;
+    const int t = (int)threadIdx.x - sub * BLOCK, lane = t & 63, wave = t >> 6, c = lane & 15, g = lane >> 4;
+    const int row0 = vb * G4_TRAJ;
     const int pc = t & 15, part = t >> 4;
     const int n = row0 + pc;
     const bool valid = n < a.N;
@@ -921,7 +935,7 @@ __global__ __launch_bounds__(64 * SP::WAVES) void ctk_g_rollout_split(RolloutArg
         } else {
             for (int hc = t; hc < HC; hc += BLOCK) { base_s[hc] = base[hc]; scale_s[hc] = scale[hc]; }
         }
-    });
+    }, t);
     float up0[C];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) up0[cc] = a.u_prev_dev ? a.u_prev_dev[cc] : a.u_prev[cc];
@@ -1019,9 +1033,9 @@ __global__ __launch_bounds__(64 * SP::WAVES) void ctk_g_rollout_split(RolloutArg
         for (int o = 1; o < 16; o <<= 1) aw += __shfl_xor(aw, o, 64);
         if (wave == 0 && g == 0) e_s[c] = e;
         __syncthreads();
-        float* rec = parts + (size_t)blockIdx.x * (2 + cols);
+        float* rec = parts + (size_t)vb * (2 + cols);
         const bool use_ll = gz.mode != 0;            // kernel-argument uniform: the records are handed over inside this launch
-        unsigned long long* llr = gz.ll + (size_t)blockIdx.x * (2 + cols);
+        unsigned long long* llr = gz.ll + (size_t)vb * (2 + cols);
         if (t == 0) {
             if (use_ll) { ll_store(llr, rho, gz.up.seq); ll_store(llr + 1, aw, gz.up.seq); }
             else { rec[0] = rho; rec[1] = aw; }
@@ -1033,9 +1047,11 @@ __global__ __launch_bounds__(64 * SP::WAVES) void ctk_g_rollout_split(RolloutArg
             if (use_ll) ll_store(llr + 2 + p, acc, gz.up.seq);
             else rec[2 + p] = acc;
         }
-        if (use_ll && blockIdx.x == 0) {             // block 0 gathers every block's words, merges, updates / emits the shard record
-            __syncthreads();
-            mppi_ll_tail<C>(lds, gz.ll, (int)gridDim.x, cols, mk.neg_inv_lbd, gz.mode, gz.out_rec, gz.up);
+        if constexpr (TILES == 1) {
+            if (use_ll && blockIdx.x == 0) {         // block 0 gathers every block's words, merges, updates / emits the shard record
+                __syncthreads();
+                mppi_ll_tail<C>(lds, gz.ll, (int)gridDim.x, cols, mk.neg_inv_lbd, gz.mode, gz.out_rec, gz.up);
+            }
         }
     }
 }
@@ -1177,9 +1193,13 @@ hipError_t ctk_launch_g_rpgd_wide_split(hipStream_t st, int env, const RolloutAr
     return hipGetLastError();
 }
 
-size_t ctk_g_rollout_split_lds(int net, int cols, int H, int C) {
-    return (size_t)(split_ex_fwd(net) + G4_RED + (H + 1) * 128 + H * C * G4_LD + G4_TRAJ * tile_stride(cols) + G4_TRAJ + 2 * H * C + 3 * H) * sizeof(float);
+// two tiles per workgroup (kernel comment): the two-wave policies, more than one tile per CU, every tile full
+static bool rollout_split_two_tiles(int net, int N, int H, int cols, int C) {
+    const int tiles = (N + G4_TRAJ - 1) / G4_TRAJ;
+    return net != NET_GRU && tiles > 256 && tiles % 2 == 0 && N % G4_TRAJ == 0 &&
+           2 * split_tile_floats(split_ex_fwd(net), cols, H, C) * sizeof(float) <= 160 * 1024 && getenv("CTK_SPLIT_ONE_TILE") == nullptr;
 }
+size_t ctk_g_rollout_split_lds(int net, int cols, int H, int C) { return split_tile_floats(split_ex_fwd(net), cols, H, C) * sizeof(float); }
 bool ctk_g_rollout_split_ok(int env, int net, int N, int H, int cols) {
     static const bool off = getenv("CTK_NET_ONE_WAVE") != nullptr;
     int S = 0, C = 0;
@@ -1187,8 +1207,11 @@ bool ctk_g_rollout_split_ok(int env, int net, int N, int H, int cols) {
     return !off && split_env_ok(env, net) && N <= 8192 && ctk_g_rollout_split_lds(net, cols, H, C) <= 160 * 1024;
 }
 int ctk_g_rollout_split_blocks(int N) { return (N + G4_TRAJ - 1) / G4_TRAJ; }
-const char* ctk_g_rollout_split_name(int env, int net, int mode, bool log) {
-    return ctk_kernel_name("ctk_g_rollout_split<%d, %4$s, %d, %5$s>", env, mode, 0, split_policy_name(env, net), log ? "true" : "false");
+const char* ctk_g_rollout_split_name(int env, int net, int mode, bool log, int N, int H, int cols) {
+    int S = 0, C = 0;
+    env_dims(env, &S, &C);
+    return ctk_kernel_name("ctk_g_rollout_split<%d, %4$s, %d, %5$s, %3$d>", env, mode, rollout_split_two_tiles(net, N, H, cols, C) ? 2 : 1,
+                           split_policy_name(env, net), log ? "true" : "false");
 }
 
 template <int EV, class SP>
@@ -1200,16 +1223,25 @@ static void launch_rollout_split(hipStream_t st, int mode, const RolloutArgs& a_
     const int cols = (mode == CTK_G_MODE_MPPI ? a_in.P : a_in.H) * E::C;
     a.P = cols; a.p_magic = g4_magic_of(cols); a.C = E::C;
     const typename E::K k = E::derive(params, dt, isteps);
-    const dim3 grid(ctk_g_rollout_split_blocks(a.N)), block(64 * SP::WAVES);
-    const NetFuse gz = ctk_net_fuse(SP::WAVES == 4 ? fuse : nullptr, mode, a, E::C, base, (int)grid.x, cols);   // mppi_ll_tail: 256-thread workgroups
-    const size_t lds = std::max(ctk_g_rollout_split_lds(SP::NET, cols, a.H, E::C), gz.mode ? merge_lds_staged(cols, (int)grid.x) : 0);
-    if (mode == CTK_G_MODE_MPPI) {
-        if (log) CTK_LAUNCH((ctk_g_rollout_split<EV, SP, CTK_G_MODE_MPPI, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
-        else CTK_LAUNCH((ctk_g_rollout_split<EV, SP, CTK_G_MODE_MPPI, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
-    } else {
-        if (log) CTK_LAUNCH((ctk_g_rollout_split<EV, SP, CTK_G_MODE_AFFINE, true>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
-        else CTK_LAUNCH((ctk_g_rollout_split<EV, SP, CTK_G_MODE_AFFINE, false>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
+    const int tiles = ctk_g_rollout_split_blocks(a.N);
+    const NetFuse gz = ctk_net_fuse(SP::WAVES == 4 ? fuse : nullptr, mode, a, E::C, base, tiles, cols);   // mppi_ll_tail: 256-thread workgroups
+    const size_t lds1 = std::max(ctk_g_rollout_split_lds(SP::NET, cols, a.H, E::C), gz.mode ? merge_lds_staged(cols, tiles) : 0);
+    auto go = [&](auto tiles_per_wg) {
+        constexpr int T = decltype(tiles_per_wg)::value;
+        const dim3 grid(tiles / T), block(64 * SP::WAVES * T);
+        const size_t lds = T == 1 ? lds1 : (size_t)T * ctk_g_rollout_split_lds(SP::NET, cols, a.H, E::C);
+        if (mode == CTK_G_MODE_MPPI) {
+            if (log) CTK_LAUNCH((ctk_g_rollout_split<EV, SP, CTK_G_MODE_MPPI, true, T>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
+            else CTK_LAUNCH((ctk_g_rollout_split<EV, SP, CTK_G_MODE_MPPI, false, T>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
+        } else {
+            if (log) CTK_LAUNCH((ctk_g_rollout_split<EV, SP, CTK_G_MODE_AFFINE, true, T>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
+            else CTK_LAUNCH((ctk_g_rollout_split<EV, SP, CTK_G_MODE_AFFINE, false, T>), grid, block, lds, st, e0, e1, a, k, mk, samples, base, scale, rng_kind, wperm, hidden, parts, gz);
+        }
+    };
+    if constexpr (SP::WAVES == 2) {
+        if (rollout_split_two_tiles(SP::NET, a.N, a.H, cols, E::C)) { go(std::integral_constant<int, 2>{}); return; }
     }
+    go(std::integral_constant<int, 1>{});
 }
 
 hipError_t ctk_launch_g_rollout_split(hipStream_t st, int env, int net, int mode, const RolloutArgs& a, const float* params, float dt, int isteps,

@@ -16,10 +16,10 @@
 // them: other global loads placed there share the same memory round trip.
 template <int ROWS, int THREADS, class Early>
 CTK_DEV void load_tile_early(float* tile, const float* __restrict__ samples, const RolloutArgs& a, int row0, float scale,
-                       int rng_kind, Early&& early) {
+                       int rng_kind, Early&& early, int tid = -1) {
     const int P = a.P, ts = tile_stride(P);
     const int rows = min(ROWS, a.N - row0);
-    const int t = threadIdx.x;
+    const int t = tid < 0 ? (int)threadIdx.x : tid;       // (tid: the caller's THREADS are a part of the workgroup)
     if (rows < ROWS) {
         for (int i = t; i < ROWS * ts; i += THREADS) tile[i] = 0.0f;
         __syncthreads();

@@ -400,6 +400,26 @@ def test_cartpole_generic_mlp_kernels_match_tuned_mlp_kernels(opt):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("N,tiles_per_wg", [(8192, 2), (8176, 1), (4096, 1)])
+def test_template_mlp_two_tiles_per_workgroup_at_full_chip_sizes(N, tiles_per_wg):
+    """More than one 16-trajectory tile per CU: the two-wave MLP rollout puts two tiles in a four-wave workgroup (each wave its own SIMD);
+    ragged populations and smaller ones keep one tile.  Results equal the tuned kernel's either way."""
+    kw = dict(num_rollouts=N, mpc_horizon=40, dt=0.02, period_interpolation_inducing_points=10, seed=4)
+    w = O.mlp_default_weights(2)
+    a, b = CtkEngine("mppi", "MLP", **kw), CtkEngine("mppi", "MLP", generic_kernels=True, **kw)
+    assert b.dominant_kernel().startswith("ctk_g_rollout_split<0, SplitMlp<false>, 0, false, %d>" % tiles_per_wg), b.dominant_kernel()
+    a.set_predictor_weights(w); b.set_predictor_weights(w)
+    s = np.array([0.05, -0.1, 2.8, 0.4], np.float32)
+    for t in range(3):
+        ua, ub = a.step(s), b.step(s)
+        np.testing.assert_allclose(b.read("J"), a.read("J"), rtol=5e-5, atol=1e-3)
+        np.testing.assert_allclose(b.read("U_NOM"), a.read("U_NOM"), rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(ub, ua, rtol=2e-4, atol=2e-4)
+        b.set_state(a.get_state())
+        s = s + np.array([0.01, 0.0, -0.02, 0.01], np.float32)
+    a.close(); b.close()
+
+
 def quad_mlp(seed=3):
     env = quad_env()
     w = O.mlp_default_weights(seed, 8, 6)
