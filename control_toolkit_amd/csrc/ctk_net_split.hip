@@ -552,19 +552,47 @@ __global__ __launch_bounds__(64 * SP::WAVES) void ctk_g_rpgd_descent_split(Rollo
 // iters + 1 phase launches and iters Jacobian launches per MPC step, in stream order.  Scratch per tile: activations [H][2][2][64] float4,
 // states [H+1][64][2], records [H][16][16][8].
 constexpr int GW_REC = 16 * 16 * 8;                                  // floats of one (tile, step) record
-__host__ __device__ inline size_t gw_tile_floats(int H) { return (size_t)H * (2 * 2 * 64 * 4) + (size_t)(H + 1) * 128 + (size_t)H * GW_REC; }
 __host__ __device__ inline size_t gw_xs_off(int H) { return (size_t)H * (2 * 2 * 64 * 4); }
 __host__ __device__ inline size_t gw_rec_off(int H) { return gw_xs_off(H) + (size_t)(H + 1) * 128; }
+__host__ __device__ inline size_t gw_gs_off(int H) { return gw_rec_off(H) + (size_t)H * GW_REC; }                 // cost-gradient terms gs[H+1][64][2]
+__host__ __device__ inline size_t gw_gd_off(int H) { return gw_gs_off(H) + (size_t)(H + 1) * 128; }               // direct input-gradient terms g[HC][17]
+__host__ __device__ inline size_t gw_gd_floats(int H, int C) { return ((size_t)H * C * G4_LD + 3) & ~(size_t)3; }
+__host__ __device__ inline size_t gw_tile_floats(int H, int C) { return gw_gd_off(H) + gw_gd_floats(H, C); }
 
 template <int ENV, bool K3>
-__global__ __launch_bounds__(64) void ctk_g_rpgd_jac_split(int H, const float* __restrict__ wperm, float* __restrict__ scratch) {
+__global__ __launch_bounds__(64) void ctk_g_rpgd_jac_split(RolloutArgs a, typename Env<ENV>::K k, const float* __restrict__ Q, const float* __restrict__ wperm,
+                                                          float* __restrict__ scratch) {
     using E = Env<ENV>;
-    constexpr int IO = E::S + E::C;
+    constexpr int S = E::S, C = E::C, IO = S + C;
     static_assert(IO <= (K3 ? 12 : 8), "network inputs");
+    const int H = a.H;
     const int tile = blockIdx.x / H, h = blockIdx.x - tile * H;
     const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
     const MlpFwdW w = mlp_load_fwd(wperm);
-    float* base = scratch + (size_t)tile * gw_tile_floats(H);
+    float* base = scratch + (size_t)tile * gw_tile_floats(H, C);
+    // what of the gradient does not ride on the adjoint chain, for this step and (lanes g = 1 of the last step's wave) the terminal one:
+    // the cost's state gradient of plan c and the input-only terms — here, where the whole chip works, not in the phase launch's 16
+    // workgroups; written in the phase launch's LDS layout, which copies them in with LDS-DMA.  Operands are loaded here, with the
+    // activations; the arithmetic follows the tangent passes
+    const int hh = g == 0 ? h : H;
+    const bool costs = g == 0 || (g == 1 && h == H - 1);
+    float cs_s[S], cs_u[C], cs_up[C], cs_un[C];
+    {
+        const float* xs_g = base + gw_xs_off(H);
+#pragma unroll
+        for (int j = 0; j < S; ++j) cs_s[j] = xs_g[(hh * 64 + (j & 3) * 16 + c) * 2 + (j >> 2)];
+        const int HC = H * C, n = tile * G4_TRAJ + c;
+        const bool live = n < a.N;                                       // (plans beyond N read as zeros, as the phase launch holds them)
+        const float* q = Q + (size_t)(live ? n : 0) * HC;
+        const int h0 = min(hh, H - 1);
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) {
+            const float qu = q[h0 * C + cc], qp = q[max(h0 - 1, 0) * C + cc], qn = q[min(h0 + 1, H - 1) * C + cc];
+            cs_u[cc] = live ? qu : 0.0f;
+            cs_up[cc] = h0 > 0 ? (live ? qp : 0.0f) : (a.u_prev_dev ? a.u_prev_dev[cc] : a.u_prev[cc]);
+            cs_un[cc] = h0 + 1 < H && live ? qn : 0.0f;
+        }
+    }
     const float4* act = reinterpret_cast<const float4*>(base) + (size_t)h * (2 * 2 * 64) + lane;     // [wave m][h1 | h2][64]
     f32x4 d1[2], d2[2];
 #pragma unroll
@@ -598,6 +626,23 @@ __global__ __launch_bounds__(64) void ctk_g_rpgd_jac_split(int H, const float* _
         rec[j * 8 + g] = o0[0] + o1[0];                                 // d s'_g / d x_j, d s'_{4+g} / d x_j of plan c
         rec[j * 8 + 4 + g] = o0[1] + o1[1];
     }
+    if (costs) {
+        float gs[S];
+        if (hh < H) E::stage_grad_state(k, cs_s, gs); else E::terminal_grad(k, cs_s, gs);
+        float* gs_g = base + gw_gs_off(H);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gs_g[(hh * 64 + (j & 3) * 16 + c) * 2 + (j >> 2)] = j < S ? gs[j < S ? j : 0] * a.inv_Hp1 : 0.0f;
+        if (hh < H) {
+            float gu[C], gp[C], gu2[C], gpn[C];
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) gpn[cc] = 0.0f;
+            E::input_grad(k, cs_u, cs_up, gu, gp);
+            if (hh + 1 < H) E::input_grad(k, cs_un, cs_u, gu2, gpn);
+            float* gd_g = base + gw_gd_off(H);
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) gd_g[(hh * C + cc) * G4_LD + c] = (gu[cc] + gpn[cc]) * a.inv_Hp1;
+        }
+    }
 }
 
 // LDS: exchange slots | reductions | states xs[H+1][64][2] | cost-gradient terms gs[H+1][64][2] | plans q[HC][17] | gradients g[HC][17]
@@ -615,14 +660,14 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
     float* red_s = ex + SP::EX_FWD;
     float* xs_s = red_s + G4_RED;
     float* gs_s = xs_s + (H + 1) * 128;
-    float* q_s = gs_s + (H + 1) * 128;
-    float* g_s = q_s + HC * G4_LD;
+    float* g_s = gs_s + (H + 1) * 128;                                  // (16-byte aligned like gs: both are LDS-DMA destinations)
+    float* q_s = g_s + gw_gd_floats(H, C);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 15, g = lane >> 4;
     const int row0 = blockIdx.x * G4_TRAJ;
     const int rows = min(G4_TRAJ, a.N - row0);
     const int total = rows * HC;
     const size_t gbase = (size_t)row0 * HC;
-    float* tbase = scratch + (size_t)blockIdx.x * gw_tile_floats(H);
+    float* tbase = scratch + (size_t)blockIdx.x * gw_tile_floats(H, C);
     float4* tape = reinterpret_cast<float4*>(tbase) + wave * 2 * 64 + lane;          // + h * 256 + i * 64
     float* xs_g = tbase + gw_xs_off(H);
     const float* rec_g = tbase + gw_rec_off(H);
@@ -679,16 +724,16 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
             }
         }
     }
-    if (do_update) {                                       // (xs: (H + 1) * 128 floats, 16-byte aligned on both sides)
-        const int n4 = (H + 1) * 32;
-        for (int b = t; b < n4; b += AB * BLOCK) {
-            float4 xv[AB];
-#pragma unroll
-            for (int j = 0; j < AB; ++j) xv[j] = reinterpret_cast<const float4*>(xs_g)[min(b + j * BLOCK, n4 - 1)];
-#pragma unroll
-            for (int j = 0; j < AB; ++j)
-                if (b + j * BLOCK < n4) reinterpret_cast<float4*>(xs_s)[b + j * BLOCK] = xv[j];
-        }
+    if (do_update) {
+        // the cost-gradient terms the Jacobian launch left (gs, then the direct input-gradient terms g: one span in memory and in LDS):
+        // LDS-DMA, 1 KiB per wave-instruction, no registers; the barrier below waits for it
+        const int n4 = (int)(((size_t)(H + 1) * 128 + gw_gd_floats(H, C)) / 4);
+        const float4* src = reinterpret_cast<const float4*>(tbase + gw_gs_off(H));
+        float4* dst = reinterpret_cast<float4*>(gs_s);
+        for (int b = wave * 64; b < n4; b += BLOCK)
+            if (b + lane < n4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + b + lane),
+                                                 (__attribute__((address_space(3))) void*)(dst + b), 16, 0, 0);
     }
     typename SP::Fwd nf;
     nf.load(wperm, wave, lane);
@@ -713,30 +758,6 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
     };
 
     if (do_update) {
-        // ---- what of the gradient does not ride on the adjoint chain, over (step, plan) pairs (as ctk_g_rpgd_descent_split)
-        for (int idx = t; idx < (H + 1) * G4_TRAJ; idx += BLOCK) {
-            const int h = idx >> 4, p = idx & 15;
-            float s[S], gs[S];
-            state_of(h, p, s);
-            if (h < H) E::stage_grad_state(k, s, gs); else E::terminal_grad(k, s, gs);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) gs_s[(h * 64 + (j & 3) * 16 + p) * 2 + (j >> 2)] = j < S ? gs[j < S ? j : 0] * inv : 0.0f;
-            if (h < H) {
-                float u[C], upv[C], un[C], gu[C], gp[C], gu2[C], gpn[C];
-#pragma unroll
-                for (int cc = 0; cc < C; ++cc) {
-                    u[cc] = q_s[(h * C + cc) * G4_LD + p];
-                    upv[cc] = h > 0 ? q_s[((h - 1) * C + cc) * G4_LD + p] : up0[cc];
-                    un[cc] = h + 1 < H ? q_s[((h + 1) * C + cc) * G4_LD + p] : 0.0f;
-                    gpn[cc] = 0.0f;
-                }
-                E::input_grad(k, u, upv, gu, gp);
-                if (h + 1 < H) E::input_grad(k, un, u, gu2, gpn);
-#pragma unroll
-                for (int cc = 0; cc < C; ++cc) g_s[(h * C + cc) * G4_LD + p] = (gu[cc] + gpn[cc]) * inv;
-            }
-        }
-        __syncthreads();
         // ---- the adjoint chain: plan p = t / 8 (its 8 lanes are neighbours), lane i owns column i (a state component: lambda_i; or an
         //      input: its gradient) and, where the network has more than 8 inputs, column 8 + i
         {
@@ -1155,7 +1176,7 @@ bool ctk_g_rpgd_wide_ok(int env, int net, int N, int H) {
     // (more than 8 network inputs: S + C tangent passes and two record columns per lane — measured slower than the split chain, 760 vs 742 us)
     return !narrow && net == NET_MLP && S + C <= 8 && N <= 4096 && ctk_g_rpgd_split_ok(env, net, N, H);
 }
-size_t ctk_g_rpgd_scratch_floats_wide(int N, int H) { return (size_t)((N + G4_TRAJ - 1) / G4_TRAJ) * gw_tile_floats(H); }
+size_t ctk_g_rpgd_scratch_floats_wide(int N, int H) { return (size_t)((N + G4_TRAJ - 1) / G4_TRAJ) * gw_tile_floats(H, 4); }   // (C <= 4)
 const char* ctk_g_rpgd_wide_name(int env) {
     int S = 0, C = 0;
     env_dims(env, &S, &C);
@@ -1172,7 +1193,7 @@ static void launch_wide_split(hipStream_t st, const RolloutArgs& a_in, const flo
     a.C = E::C; a.p_magic = g4_magic_of(a.H * E::C);
     const typename E::K k = E::derive(params, dt, isteps);
     const int tiles = (a.N + G4_TRAJ - 1) / G4_TRAJ;
-    const size_t lds = (size_t)(SplitMlp<K3>::EX_FWD + G4_RED + 2 * (a.H + 1) * 128 + 2 * a.H * E::C * G4_LD) * sizeof(float);
+    const size_t lds = (size_t)(SplitMlp<K3>::EX_FWD + G4_RED + 2 * (a.H + 1) * 128 + gw_gd_floats(a.H, E::C) + a.H * E::C * G4_LD) * sizeof(float);
     for (int it = 0; it <= iters; ++it) {
         const bool last = it == iters;
         hipEvent_t s0 = it == 0 ? e0 : nullptr, s1 = last ? e1 : nullptr;
@@ -1182,7 +1203,7 @@ static void launch_wide_split(hipStream_t st, const RolloutArgs& a_in, const flo
         else
             hipLaunchKernelGGL((ctk_g_rpgd_wide_split<EV, K3>), dim3(tiles), dim3(128), lds, st, a, k, ad, Q, m, v, bc_table, bc_len, t0 + it, wperm, scratch,
                                it > 0 ? 1 : 0, last ? 1 : 0);
-        if (!last) hipLaunchKernelGGL((ctk_g_rpgd_jac_split<EV, K3>), dim3(tiles * a.H), dim3(64), 0, st, a.H, wperm, scratch);
+        if (!last) hipLaunchKernelGGL((ctk_g_rpgd_jac_split<EV, K3>), dim3(tiles * a.H), dim3(64), 0, st, a, k, Q, wperm, scratch);
     }
 }
 
