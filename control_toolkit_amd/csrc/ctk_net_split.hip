@@ -28,6 +28,7 @@
 #include "ctk_net.h"
 #include "ctk_adam.h"
 #include "ctk_launch.h"
+#include <atomic>
 #include "ctk_mppi_merge.h"
 #include <algorithm>
 
@@ -263,6 +264,23 @@ struct SplitGru {
     };
 };
 
+// Stores that go through to memory (sc1: another XCD's L2 never holds the line), for data handed to other workgroups INSIDE a launch
+// (ctk_g_rpgd_wide_split).  asm: the compiler offers this cache policy on atomics only, which stop at 8 bytes.  (s_nop: a store of more
+// than 8 bytes reads its data registers late — one wait state before they may be rewritten, which the compiler's hazard recogniser
+// cannot add around an asm statement.)
+CTK_DEV void st4_through(float4* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory"); }
+CTK_DEV void st2_through(float* p, float v0, float v1) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {v0, v1};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+// The flag behind such stores: this wave's stores complete in order, so once at most `younger` (an immediate) are outstanding, everything
+// older than those has reached memory — no full drain on the recurrence.
+template <int YOUNGER>
+CTK_DEV void flag_through(uint32_t* p, uint32_t seq) {
+    asm volatile("s_waitcnt vmcnt(%2)\n\tglobal_store_dword %0, %1, off sc1" : : "v"(p), "v"(seq), "n"(YOUNGER) : "memory");
+}
+
 template <bool K3>
 struct SplitMlp {
     static constexpr int WAVES = 2, TAPE_F4 = 2, EX_FWD = M2_EX_FWD, EX_BWD = M2_EX_BWD, NET = NET_MLP;
@@ -284,7 +302,7 @@ struct SplitMlp {
             b3lo = f.b3[0]; b3hi = f.b3[1];
         }
         CTK_DEV void begin(const float*, int) {}
-        template <bool TAPE>
+        template <int TAPE>                     // 0: none; 1: float4 tape at tq[0], tq[64]; 2: the same, stored through to memory from where the wave waits anyway
         CTK_DEV MlpPair step(float x0, float x1, float x2, float* ex, int m, int lane, float4* tq) {
             float4* ex_h = reinterpret_cast<float4*>(ex);                  // [2][64]
             float2* ex_o = reinterpret_cast<float2*>(ex + 2 * 64 * 4);     // [2][64]
@@ -298,6 +316,7 @@ struct SplitMlp {
 #pragma unroll
             for (int j = 0; j < 4; ++j) c = CTK_MFMA(w2o[j], h1m[j], c);   // own half first: the other one is still arriving
             const f32x4 h1x = ld4(ex_h + (m ^ 1) * 64 + lane);
+            if constexpr (TAPE == 2) st4_through(tq, h1m);
 #pragma unroll
             for (int j = 0; j < 4; ++j) c = CTK_MFMA(w2x[j], h1x[j], c);
             const f32x4 h2m = ctk_tanhf4(c);
@@ -305,9 +324,10 @@ struct SplitMlp {
             f32x4 p0 = CTK_MFMA(w3[0], h2m[0], z), p1 = CTK_MFMA(w3[1], h2m[1], z);
             p0 = CTK_MFMA(w3[2], h2m[2], p0);
             p1 = CTK_MFMA(w3[3], h2m[3], p1);
+            if constexpr (TAPE == 2) st4_through(tq + 64, h2m);
             const float mylo = p0[0] + p1[0], myhi = p0[1] + p1[1];
             ex_o[m * 64 + lane] = make_float2(mylo, myhi);
-            if constexpr (TAPE) { tq[0] = st4(h1m); tq[64] = st4(h2m); }
+            if constexpr (TAPE == 1) { tq[0] = st4(h1m); tq[64] = st4(h2m); }
             __syncthreads();
             const float2 o = ex_o[(m ^ 1) * 64 + lane];
             // the same association in both waves: (units 0..15) + (units 16..31) + bias
@@ -557,7 +577,38 @@ __host__ __device__ inline size_t gw_rec_off(int H) { return gw_xs_off(H) + (siz
 __host__ __device__ inline size_t gw_gs_off(int H) { return gw_rec_off(H) + (size_t)H * GW_REC; }                 // cost-gradient terms gs[H+1][64][2]
 __host__ __device__ inline size_t gw_gd_off(int H) { return gw_gs_off(H) + (size_t)(H + 1) * 128; }               // direct input-gradient terms g[HC][17]
 __host__ __device__ inline size_t gw_gd_floats(int H, int C) { return ((size_t)H * C * G4_LD + 3) & ~(size_t)3; }
-__host__ __device__ inline size_t gw_tile_floats(int H, int C) { return gw_gd_off(H) + gw_gd_floats(H, C); }
+__host__ __device__ inline size_t gw_flag_off(int H, int C) { return gw_gd_off(H) + gw_gd_floats(H, C); }     // hand-off flags [H+1][2 waves] (launch sequence numbers)
+__host__ __device__ inline size_t gw_tile_floats(int H, int C) { return gw_flag_off(H, C) + (((size_t)(H + 1) * 2 + 3) & ~(size_t)3); }
+
+// S + C forward-mode tangents through the network (j = j0, j0 + jstep, ...): column j of d s' / d (s, u) of plan c, rows g and 4 + g, into rec
+template <int IO>
+CTK_DEV void jac_tangents(const MlpFwdW& w, const f32x4 (&d1)[2], const f32x4 (&d2)[2], float* rec, int g, int j0, int jstep) {
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < IO; ++j) {
+        if (jstep != 1 && (j % 2) != j0) continue;                      // (wave-uniform)
+        const float ind = (g == (j & 3)) ? 1.0f : 0.0f;                 // B = e_j: input j lives in k-step j / 4, k-slot j % 4
+        f32x4 t1[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) t1[m] = CTK_MFMA(w.w1[m][j >> 2], ind, z) * d1[m];
+        f32x4 z0 = z, z1 = z;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float b = t1[q >> 2][q & 3];
+            z0 = CTK_MFMA(w.w2[0][q], b, z0);
+            z1 = CTK_MFMA(w.w2[1][q], b, z1);
+        }
+        const f32x4 t2[2] = {z0 * d2[0], z1 * d2[1]};
+        f32x4 o0 = z, o1 = z;
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+            o0 = CTK_MFMA(w.w3[q], t2[q >> 2][q & 3], o0);
+            o1 = CTK_MFMA(w.w3[q + 1], t2[(q + 1) >> 2][(q + 1) & 3], o1);
+        }
+        rec[j * 8 + g] = o0[0] + o1[0];                                 // d s'_g / d x_j, d s'_{4+g} / d x_j of plan c
+        rec[j * 8 + 4 + g] = o0[1] + o1[1];
+    }
+}
 
 template <int ENV, bool K3>
 __global__ __launch_bounds__(64) void ctk_g_rpgd_jac_split(RolloutArgs a, typename Env<ENV>::K k, const float* __restrict__ Q, const float* __restrict__ wperm,
@@ -601,31 +652,7 @@ __global__ __launch_bounds__(64) void ctk_g_rpgd_jac_split(RolloutArgs a, typena
         d1[m] = 1.0f - h1 * h1;
         d2[m] = 1.0f - h2 * h2;
     }
-    float* rec = base + gw_rec_off(H) + (size_t)h * GW_REC + c * 128;
-    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < IO; ++j) {
-        const float ind = (g == (j & 3)) ? 1.0f : 0.0f;                 // B = e_j: input j lives in k-step j / 4, k-slot j % 4
-        f32x4 t1[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) t1[m] = CTK_MFMA(w.w1[m][j >> 2], ind, z) * d1[m];
-        f32x4 z0 = z, z1 = z;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float b = t1[q >> 2][q & 3];
-            z0 = CTK_MFMA(w.w2[0][q], b, z0);
-            z1 = CTK_MFMA(w.w2[1][q], b, z1);
-        }
-        const f32x4 t2[2] = {z0 * d2[0], z1 * d2[1]};
-        f32x4 o0 = z, o1 = z;
-#pragma unroll
-        for (int q = 0; q < 8; q += 2) {
-            o0 = CTK_MFMA(w.w3[q], t2[q >> 2][q & 3], o0);
-            o1 = CTK_MFMA(w.w3[q + 1], t2[(q + 1) >> 2][(q + 1) & 3], o1);
-        }
-        rec[j * 8 + g] = o0[0] + o1[0];                                 // d s'_g / d x_j, d s'_{4+g} / d x_j of plan c
-        rec[j * 8 + 4 + g] = o0[1] + o1[1];
-    }
+    jac_tangents<IO>(w, d1, d2, base + gw_rec_off(H) + (size_t)h * GW_REC + c * 128, g, 0, 1);
     if (costs) {
         float gs[S];
         if (hh < H) E::stage_grad_state(k, cs_s, gs); else E::terminal_grad(k, cs_s, gs);
@@ -645,17 +672,97 @@ __global__ __launch_bounds__(64) void ctk_g_rpgd_jac_split(RolloutArgs a, typena
     }
 }
 
-// LDS: exchange slots | reductions | states xs[H+1][64][2] | cost-gradient terms gs[H+1][64][2] | plans q[HC][17] | gradients g[HC][17]
+// A Jacobian workgroup INSIDE the phase launch (ovl_seq != 0: workgroups tiles.. of the grid, one per (step, tile), step-major).  The forward
+// pass stores every step's activations and state through to memory as it goes (st4_through, in the shadow of its matrix products) and, two
+// steps later, raises that step's flag = this launch's sequence number behind a counted wait (flag_through: no drain on the recurrence);
+// this workgroup polls the flags, reads the step with loads that bypass its own L2, and does what ctk_g_rpgd_jac_split does: the tangents
+// (split over its two waves) and the cost's state gradient.  When the forward pass ends only the last steps' records are outstanding: the
+// separate Jacobian launch and its boundary (~8 us per Adam iteration) are off the iteration's path.
+// Producers never wait for workers, and the launch's LDS size keeps a CU to one workgroup, so workers never sit on a producer's SIMDs.
+// A poll that runs out leaves NaN records: loud, not a hang.
+template <int ENV, bool K3>
+CTK_DEV void rpgd_jac_worker(const RolloutArgs& a, const typename Env<ENV>::K& k, const float* __restrict__ wperm, float* __restrict__ scratch,
+                             int tile, int h, uint32_t seq) {
+    using E = Env<ENV>;
+    constexpr int S = E::S, C = E::C, IO = S + C;
+    const int H = a.H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const MlpFwdW w = mlp_load_fwd(wperm);
+    float* base = scratch + (size_t)tile * gw_tile_floats(H, C);
+    const uint32_t* flags = reinterpret_cast<const uint32_t*>(base + gw_flag_off(H, C));
+    auto await = [&](int i, int nap) {                                 // flag i; false: gave up
+        uint32_t v = __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int spin = 0; v != seq && spin < (1 << 17); ++spin) {
+            if (nap) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(2);
+            v = __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return v == seq;
+    };
+    bool ok = true;
+    if (h >= 3) ok &= await((h - 3) * 2 + 1, 1);                       // far from its step: seldom
+    ok &= await(h * 2, 0);
+    ok &= await(h * 2 + 1, 0);
+    const unsigned long long* act = reinterpret_cast<const unsigned long long*>(base) + ((size_t)h * (2 * 2 * 64) + lane) * 2;   // [wave m][h1 | h2][64] float4
+    f32x4 d1[2], d2[2];
+    {
+        unsigned long long v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = __hip_atomic_load(act + (size_t)(q >> 1) * 128 + (q & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            f32x4 h1, h2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                h1[r] = __builtin_bit_cast(float, (uint32_t)(v[m * 4 + (r >> 1)] >> ((r & 1) * 32)));
+                h2[r] = __builtin_bit_cast(float, (uint32_t)(v[m * 4 + 2 + (r >> 1)] >> ((r & 1) * 32)));
+            }
+            d1[m] = 1.0f - h1 * h1;
+            d2[m] = 1.0f - h2 * h2;
+        }
+    }
+    if (!__all(ok)) {
+        const float nan = __builtin_nanf("");
+#pragma unroll
+        for (int m = 0; m < 2; ++m) { d1[m] = f32x4{nan, nan, nan, nan}; d2[m] = d1[m]; }
+    }
+    jac_tangents<IO>(w, d1, d2, base + gw_rec_off(H) + (size_t)h * GW_REC + c * 128, g, wave, 2);
+    // the cost's state gradient of this step (wave 0) and, with the last step, of the terminal state (wave 1), plan c = lanes g == 0
+    const int hh = wave == 0 ? h : H;
+    if (wave == 0 || h == H - 1) {
+        const bool got = hh < H ? __all(ok) : await(H * 2, 0);
+        if (g == 0) {
+            const uint32_t* xs_u = reinterpret_cast<const uint32_t*>(base + gw_xs_off(H));
+            float sx[S], gs[S];
+#pragma unroll
+            for (int j = 0; j < S; ++j)
+                sx[j] = __builtin_bit_cast(float, __hip_atomic_load(xs_u + (hh * 64 + (j & 3) * 16 + c) * 2 + (j >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (hh < H) E::stage_grad_state(k, sx, gs); else E::terminal_grad(k, sx, gs);
+            float* gs_g = base + gw_gs_off(H);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gs_g[(hh * 64 + (j & 3) * 16 + c) * 2 + (j >> 2)] = !got ? __builtin_nanf("") : j < S ? gs[j < S ? j : 0] * a.inv_Hp1 : 0.0f;
+        }
+    }
+}
+
+// LDS: exchange slots | reductions | states xs[H+1][64][2] | cost-gradient terms gs[H+1][64][2] | gradients g[HC][17] | plans q[HC][17]
 template <int ENV, bool K3>
 __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, typename Env<ENV>::K k, AdamK ad, float* __restrict__ Q,
                                                             float* __restrict__ mom, float* __restrict__ var, const float* __restrict__ bc_table,
                                                             int bc_len, int ti, const float* __restrict__ wperm, float* __restrict__ scratch,
-                                                            int do_update, int last) {
+                                                            int do_update, int last, uint32_t ovl_seq) {
     using E = Env<ENV>;
     using SP = SplitMlp<K3>;
     constexpr int S = E::S, C = E::C, IO = S + C, BLOCK = 128, NPARTS = BLOCK / G4_TRAJ;
     extern __shared__ float lds[];
     const int H = a.H, HC = H * C;
+    {
+        const int tiles = (a.N + G4_TRAJ - 1) / G4_TRAJ;
+        if ((int)blockIdx.x >= tiles) {                                 // (ovl_seq != 0 and not the last launch: the grid is tiles * (1 + H))
+            const int idx = (int)blockIdx.x - tiles, h = idx / tiles;
+            rpgd_jac_worker<ENV, K3>(a, k, wperm, scratch, idx - h * tiles, h, ovl_seq);
+            return;
+        }
+    }
     float* ex = lds;
     float* red_s = ex + SP::EX_FWD;
     float* xs_s = red_s + G4_RED;
@@ -850,23 +957,56 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
     }
     // ---- forward: with tape for the next launch's update, or get_action's cost pass (optimizer_rpgd.py:342)
     {
+        const bool ovl = ovl_seq != 0 && !last;
+        uint32_t* flags = reinterpret_cast<uint32_t*>(tbase + gw_flag_off(H, C));
         nf.begin(nullptr, g);
         float sv0 = s00, sv1 = s01;
         for (int h = 0; h < H; ++h) {
             float u[C];
 #pragma unroll
             for (int cc = 0; cc < C; ++cc) u[cc] = q_s[(h * C + cc) * G4_LD + c];
-            if (wave == (h & 1)) reinterpret_cast<float2*>(xs_s)[h * 64 + lane] = make_float2(sv0, sv1);
+            if (wave == (h & 1)) {
+                reinterpret_cast<float2*>(xs_s)[h * 64 + lane] = make_float2(sv0, sv1);
+                if (ovl) st2_through(xs_g + (h * 64 + lane) * 2, sv0, sv1);
+            }
             float x0, x1, x2;
             split_operands<S, C>(sv0, sv1, u, g, x0, x1, x2);
-            const MlpPair o = last ? nf.template step<false>(x0, x1, x2, ex, wave, lane, nullptr)
-                                   : nf.template step<true>(x0, x1, x2, ex, wave, lane, tape + (size_t)h * (2 * 2 * 64));
+            const MlpPair o = last ? nf.template step<0>(x0, x1, x2, ex, wave, lane, nullptr)
+                              : ovl ? nf.template step<2>(x0, x1, x2, ex, wave, lane, tape + (size_t)h * (2 * 2 * 64))
+                                    : nf.template step<1>(x0, x1, x2, ex, wave, lane, tape + (size_t)h * (2 * 2 * 64));
             sv0 = o.lo; sv1 = o.hi;
+            // step h - 2 is in memory once at most the four activation stores of steps h - 1 and h are outstanding
+            if (ovl && h >= 2) flag_through<4>(flags + (h - 2) * 2 + wave, ovl_seq);
         }
-        if (wave == 0) reinterpret_cast<float2*>(xs_s)[H * 64 + lane] = make_float2(sv0, sv1);
+        if (wave == 0) {
+            reinterpret_cast<float2*>(xs_s)[H * 64 + lane] = make_float2(sv0, sv1);
+            if (ovl) st2_through(xs_g + (H * 64 + lane) * 2, sv0, sv1);
+        }
+        if (ovl) {
+            for (int hq = max(H - 2, 0); hq < H; ++hq) flag_through<0>(flags + hq * 2 + wave, ovl_seq);
+            if (wave == 0) flag_through<0>(flags + H * 2, ovl_seq);
+        }
         __syncthreads();
     }
-    if (!last) {
+    if (!last && ovl_seq != 0) {
+        // the input-only gradient terms of the new plans, for the next launch (the Jacobian workgroups take the state terms)
+        float* gd_g = tbase + gw_gd_off(H);
+        for (int idx = t; idx < H * G4_TRAJ; idx += BLOCK) {
+            const int h = idx >> 4, p = idx & 15;
+            float u[C], upv[C], un[C], gu[C], gp[C], gu2[C], gpn[C];
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) {
+                u[cc] = q_s[(h * C + cc) * G4_LD + p];
+                upv[cc] = h > 0 ? q_s[((h - 1) * C + cc) * G4_LD + p] : up0[cc];
+                un[cc] = h + 1 < H ? q_s[((h + 1) * C + cc) * G4_LD + p] : 0.0f;
+                gpn[cc] = 0.0f;
+            }
+            E::input_grad(k, u, upv, gu, gp);
+            if (h + 1 < H) E::input_grad(k, un, u, gu2, gpn);
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) gd_g[(h * C + cc) * G4_LD + p] = (gu[cc] + gpn[cc]) * inv;
+        }
+    } else if (!last) {
         for (int i = t; i < (H + 1) * 32; i += BLOCK) reinterpret_cast<float4*>(xs_g)[i] = reinterpret_cast<const float4*>(xs_s)[i];
     } else {
         float cs = 0.0f;
@@ -1193,17 +1333,26 @@ static void launch_wide_split(hipStream_t st, const RolloutArgs& a_in, const flo
     a.C = E::C; a.p_magic = g4_magic_of(a.H * E::C);
     const typename E::K k = E::derive(params, dt, isteps);
     const int tiles = (a.N + G4_TRAJ - 1) / G4_TRAJ;
-    const size_t lds = (size_t)(SplitMlp<K3>::EX_FWD + G4_RED + 2 * (a.H + 1) * 128 + gw_gd_floats(a.H, E::C) + a.H * E::C * G4_LD) * sizeof(float);
+    size_t lds = (size_t)(SplitMlp<K3>::EX_FWD + G4_RED + 2 * (a.H + 1) * 128 + gw_gd_floats(a.H, E::C) + a.H * E::C * G4_LD) * sizeof(float);
+    // the Jacobian work rides inside the phase launch (rpgd_jac_worker); CTK_RPGD_NO_OVERLAP: its own launch after each phase launch
+    static const bool no_overlap = getenv("CTK_RPGD_NO_OVERLAP") != nullptr;
+    static std::atomic<uint32_t> launch_seq{0};
+    const bool ovl = !no_overlap;
+    if (ovl) lds = std::max(lds, (size_t)84 * 1024);      // more than half a CU's LDS: one workgroup per CU, no worker beside a forward pass
     for (int it = 0; it <= iters; ++it) {
         const bool last = it == iters;
         hipEvent_t s0 = it == 0 ? e0 : nullptr, s1 = last ? e1 : nullptr;
+        uint32_t seq = 0;
+        if (ovl && !last) { seq = ++launch_seq; if (seq == 0) seq = ++launch_seq; }
+        static const bool diag_no_workers = getenv("CTK_DIAG_OVL_NOWORKERS") != nullptr;   // timing experiments only: results are wrong
+        const dim3 grid(ovl && !last && !diag_no_workers ? tiles * (1 + a.H) : tiles);
         if (s0 || s1)
-            hipExtLaunchKernelGGL((ctk_g_rpgd_wide_split<EV, K3>), dim3(tiles), dim3(128), lds, st, s0, s1, 0, a, k, ad, Q, m, v, bc_table, bc_len, t0 + it, wperm,
-                                  scratch, it > 0 ? 1 : 0, last ? 1 : 0);
+            hipExtLaunchKernelGGL((ctk_g_rpgd_wide_split<EV, K3>), grid, dim3(128), lds, st, s0, s1, 0, a, k, ad, Q, m, v, bc_table, bc_len, t0 + it, wperm,
+                                  scratch, it > 0 ? 1 : 0, last ? 1 : 0, seq);
         else
-            hipLaunchKernelGGL((ctk_g_rpgd_wide_split<EV, K3>), dim3(tiles), dim3(128), lds, st, a, k, ad, Q, m, v, bc_table, bc_len, t0 + it, wperm, scratch,
-                               it > 0 ? 1 : 0, last ? 1 : 0);
-        if (!last) hipLaunchKernelGGL((ctk_g_rpgd_jac_split<EV, K3>), dim3(tiles * a.H), dim3(64), 0, st, a, k, Q, wperm, scratch);
+            hipLaunchKernelGGL((ctk_g_rpgd_wide_split<EV, K3>), grid, dim3(128), lds, st, a, k, ad, Q, m, v, bc_table, bc_len, t0 + it, wperm, scratch,
+                               it > 0 ? 1 : 0, last ? 1 : 0, seq);
+        if (!last && !ovl) hipLaunchKernelGGL((ctk_g_rpgd_jac_split<EV, K3>), dim3(tiles * a.H), dim3(64), 0, st, a, k, Q, wperm, scratch);
     }
 }
 
