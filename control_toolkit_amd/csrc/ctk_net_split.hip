@@ -699,7 +699,7 @@ CTK_DEV void rpgd_jac_worker(const RolloutArgs& a, const typename Env<ENV>::K& k
         return v == seq;
     };
     bool ok = true;
-    if (h >= 3) ok &= await((h - 3) * 2 + 1, 1);                       // far from its step: seldom
+    if (h >= 6) ok &= await((h - 6) * 2 + 1, 1);                       // far from its step: seldom
     ok &= await(h * 2, 0);
     ok &= await(h * 2 + 1, 0);
     const unsigned long long* act = reinterpret_cast<const unsigned long long*>(base) + ((size_t)h * (2 * 2 * 64) + lane) * 2;   // [wave m][h1 | h2][64] float4
@@ -958,6 +958,7 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
     // ---- forward: with tape for the next launch's update, or get_action's cost pass (optimizer_rpgd.py:342)
     {
         const bool ovl = ovl_seq != 0 && !last;
+        constexpr int LAG = 4;          // steps between a step's stores and its flag (a store through to memory is acknowledged after ~1-2 us)
         uint32_t* flags = reinterpret_cast<uint32_t*>(tbase + gw_flag_off(H, C));
         nf.begin(nullptr, g);
         float sv0 = s00, sv1 = s01;
@@ -975,15 +976,15 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
                               : ovl ? nf.template step<2>(x0, x1, x2, ex, wave, lane, tape + (size_t)h * (2 * 2 * 64))
                                     : nf.template step<1>(x0, x1, x2, ex, wave, lane, tape + (size_t)h * (2 * 2 * 64));
             sv0 = o.lo; sv1 = o.hi;
-            // step h - 2 is in memory once at most the four activation stores of steps h - 1 and h are outstanding
-            if (ovl && h >= 2) flag_through<4>(flags + (h - 2) * 2 + wave, ovl_seq);
+            // step h - LAG is in memory once at most the 2 * LAG activation stores of the steps since are outstanding
+            if (ovl && h >= LAG) flag_through<2 * LAG>(flags + (h - LAG) * 2 + wave, ovl_seq);
         }
         if (wave == 0) {
             reinterpret_cast<float2*>(xs_s)[H * 64 + lane] = make_float2(sv0, sv1);
             if (ovl) st2_through(xs_g + (H * 64 + lane) * 2, sv0, sv1);
         }
         if (ovl) {
-            for (int hq = max(H - 2, 0); hq < H; ++hq) flag_through<0>(flags + hq * 2 + wave, ovl_seq);
+            for (int hq = max(H - LAG, 0); hq < H; ++hq) flag_through<0>(flags + hq * 2 + wave, ovl_seq);
             if (wave == 0) flag_through<0>(flags + H * 2, ovl_seq);
         }
         __syncthreads();

@@ -420,6 +420,17 @@ def test_template_mlp_two_tiles_per_workgroup_at_full_chip_sizes(N, tiles_per_wg
     a.close(); b.close()
 
 
+def test_wide_rpgd_with_its_own_jacobian_launch_also_matches():
+    """The template's wide RPGD descent hands every forward step to Jacobian workgroups inside the phase launch; CTK_RPGD_NO_OVERLAP (read once
+    per process) keeps the Jacobians in their own launch after each phase launch.  Same tests, child process."""
+    import os, subprocess, sys
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.abspath(__file__),
+                        "-k", "(generic_mlp_kernels_match_tuned and rpgd) or quad2d_mlp_gradient_and_rpgd"],
+                       env=dict(os.environ, CTK_RPGD_NO_OVERLAP="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def quad_mlp(seed=3):
     env = quad_env()
     w = O.mlp_default_weights(seed, 8, 6)
