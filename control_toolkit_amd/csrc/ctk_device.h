@@ -292,3 +292,47 @@ CTK_DEV void kernarg_prefetch_sink(uint32_t acc, float* some_global) {
 // row stride of the per-block sample tile in LDS: odd (conflict-free column walks with
 // ds_read_b32: bank = addr/4 mod 32) and >= P+1 so that column P is a readable zero pad.
 __host__ __device__ inline int tile_stride(int P) { return (P + 1) | 1; }
+
+// ---------------------------------------------------------------------------------------------
+// hand-off of data to OTHER workgroups of the same launch (the wide RPGD forms: Jacobian workgroups inside the phase launch)
+// ---------------------------------------------------------------------------------------------
+constexpr int CTK_HANDOFF_MAX_TILES = 64;       // 16-plan tiles whose forward passes leave enough idle CUs for the Jacobian workgroups
+constexpr int CTK_HANDOFF_LAG = 4;              // steps between a step's stores and its flag (a store through to memory is acknowledged after ~1-2 us;
+                                                // 2, 4 measured alike, 8 slower: the last LAG steps' flags wait for the drain after the loop)
+// Stores that go through to memory (sc1: another XCD's L2 never holds the line), for data handed to other workgroups INSIDE a launch
+// (ctk_g_rpgd_wide_split).  asm: the compiler offers this cache policy on atomics only, which stop at 8 bytes.  (s_nop: a store of more
+// than 8 bytes reads its data registers late — one wait state before they may be rewritten, which the compiler's hazard recogniser
+// cannot add around an asm statement.)
+CTK_DEV void st4_through(float4* p, const float4& v) {
+    typedef float f32v4 __attribute__((ext_vector_type(4)));
+    const f32v4 w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(w) : "memory");
+}
+CTK_DEV void st2_through(float* p, float v0, float v1) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {v0, v1};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+// The flag behind such stores: this wave's stores complete in order, so once at most `younger` (an immediate) are outstanding, everything
+// older than those has reached memory — no full drain on the recurrence.
+template <int YOUNGER>
+CTK_DEV void flag_through(uint32_t* p, uint32_t seq) {
+    asm volatile("s_waitcnt vmcnt(%2)\n\tglobal_store_dword %0, %1, off sc1" : : "v"(p), "v"(seq), "n"(YOUNGER) : "memory");
+}
+
+// the consumer's side: loads that bypass this XCD's L2
+CTK_DEV float4 ld4_through(const float4* p) {
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__builtin_bit_cast(float, (uint32_t)a), __builtin_bit_cast(float, (uint32_t)(a >> 32)), __builtin_bit_cast(float, (uint32_t)b),
+                       __builtin_bit_cast(float, (uint32_t)(b >> 32)));
+}
+// flag i == seq?  nap: poll seldom (the producer is steps away).  false: gave up (1 << 17 polls)
+CTK_DEV bool await_flag(const uint32_t* flag, uint32_t seq, bool nap) {
+    uint32_t v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spin = 0; v != seq && spin < (1 << 17); ++spin) {
+        if (nap) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(2);
+        v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return v == seq;
+}

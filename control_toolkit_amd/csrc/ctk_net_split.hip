@@ -264,23 +264,6 @@ struct SplitGru {
     };
 };
 
-// Stores that go through to memory (sc1: another XCD's L2 never holds the line), for data handed to other workgroups INSIDE a launch
-// (ctk_g_rpgd_wide_split).  asm: the compiler offers this cache policy on atomics only, which stop at 8 bytes.  (s_nop: a store of more
-// than 8 bytes reads its data registers late — one wait state before they may be rewritten, which the compiler's hazard recogniser
-// cannot add around an asm statement.)
-CTK_DEV void st4_through(float4* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory"); }
-CTK_DEV void st2_through(float* p, float v0, float v1) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 v = {v0, v1};
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-}
-// The flag behind such stores: this wave's stores complete in order, so once at most `younger` (an immediate) are outstanding, everything
-// older than those has reached memory — no full drain on the recurrence.
-template <int YOUNGER>
-CTK_DEV void flag_through(uint32_t* p, uint32_t seq) {
-    asm volatile("s_waitcnt vmcnt(%2)\n\tglobal_store_dword %0, %1, off sc1" : : "v"(p), "v"(seq), "n"(YOUNGER) : "memory");
-}
-
 template <bool K3>
 struct SplitMlp {
     static constexpr int WAVES = 2, TAPE_F4 = 2, EX_FWD = M2_EX_FWD, EX_BWD = M2_EX_BWD, NET = NET_MLP;
@@ -316,7 +299,7 @@ struct SplitMlp {
 #pragma unroll
             for (int j = 0; j < 4; ++j) c = CTK_MFMA(w2o[j], h1m[j], c);   // own half first: the other one is still arriving
             const f32x4 h1x = ld4(ex_h + (m ^ 1) * 64 + lane);
-            if constexpr (TAPE == 2) st4_through(tq, h1m);
+            if constexpr (TAPE == 2) st4_through(tq, st4(h1m));
 #pragma unroll
             for (int j = 0; j < 4; ++j) c = CTK_MFMA(w2x[j], h1x[j], c);
             const f32x4 h2m = ctk_tanhf4(c);
@@ -324,7 +307,7 @@ struct SplitMlp {
             f32x4 p0 = CTK_MFMA(w3[0], h2m[0], z), p1 = CTK_MFMA(w3[1], h2m[1], z);
             p0 = CTK_MFMA(w3[2], h2m[2], p0);
             p1 = CTK_MFMA(w3[3], h2m[3], p1);
-            if constexpr (TAPE == 2) st4_through(tq + 64, h2m);
+            if constexpr (TAPE == 2) st4_through(tq + 64, st4(h2m));
             const float mylo = p0[0] + p1[0], myhi = p0[1] + p1[1];
             ex_o[m * 64 + lane] = make_float2(mylo, myhi);
             if constexpr (TAPE == 1) { tq[0] = st4(h1m); tq[64] = st4(h2m); }
@@ -699,7 +682,7 @@ CTK_DEV void rpgd_jac_worker(const RolloutArgs& a, const typename Env<ENV>::K& k
         return v == seq;
     };
     bool ok = true;
-    if (h >= 6) ok &= await((h - 6) * 2 + 1, 1);                       // far from its step: seldom
+    if (h >= CTK_HANDOFF_LAG + 2) ok &= await((h - CTK_HANDOFF_LAG - 2) * 2 + 1, 1);   // far from its step: seldom
     ok &= await(h * 2, 0);
     ok &= await(h * 2 + 1, 0);
     const unsigned long long* act = reinterpret_cast<const unsigned long long*>(base) + ((size_t)h * (2 * 2 * 64) + lane) * 2;   // [wave m][h1 | h2][64] float4
@@ -958,7 +941,7 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
     // ---- forward: with tape for the next launch's update, or get_action's cost pass (optimizer_rpgd.py:342)
     {
         const bool ovl = ovl_seq != 0 && !last;
-        constexpr int LAG = 4;          // steps between a step's stores and its flag (a store through to memory is acknowledged after ~1-2 us)
+        constexpr int LAG = CTK_HANDOFF_LAG;
         uint32_t* flags = reinterpret_cast<uint32_t*>(tbase + gw_flag_off(H, C));
         nf.begin(nullptr, g);
         float sv0 = s00, sv1 = s01;
@@ -1338,7 +1321,7 @@ static void launch_wide_split(hipStream_t st, const RolloutArgs& a_in, const flo
     // the Jacobian work rides inside the phase launch (rpgd_jac_worker); CTK_RPGD_NO_OVERLAP: its own launch after each phase launch
     static const bool no_overlap = getenv("CTK_RPGD_NO_OVERLAP") != nullptr;
     static std::atomic<uint32_t> launch_seq{0};
-    const bool ovl = !no_overlap;
+    const bool ovl = !no_overlap && tiles <= CTK_HANDOFF_MAX_TILES;   // (the Jacobian workgroups need CUs of their own while the forward passes run)
     if (ovl) lds = std::max(lds, (size_t)84 * 1024);      // more than half a CU's LDS: one workgroup per CU, no worker beside a forward pass
     for (int it = 0; it <= iters; ++it) {
         const bool last = it == iters;
