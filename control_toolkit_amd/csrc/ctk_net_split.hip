@@ -1297,8 +1297,9 @@ bool ctk_g_rpgd_wide_ok(int env, int net, int N, int H) {
     static const bool narrow = getenv("CTK_RPGD_NARROW") != nullptr;      // diagnostic switch: A/B the two forms (shared with ctk_rpgd.hip)
     int S = 0, C = 0;
     env_dims(env, &S, &C);
-    // (more than 8 network inputs: S + C tangent passes and two record columns per lane — measured slower than the split chain, 760 vs 742 us)
-    return !narrow && net == NET_MLP && S + C <= 8 && N <= 4096 && ctk_g_rpgd_split_ok(env, net, N, H);
+    // (more than 8 network inputs — S + C tangent passes, two record columns per lane — was slower than the split chain before the register
+    // ring, the DPP chain and the in-launch Jacobian workgroups: 760 vs 742 us; now 637)
+    return !narrow && net == NET_MLP && S + C <= 12 && N <= 4096 && ctk_g_rpgd_split_ok(env, net, N, H);
 }
 size_t ctk_g_rpgd_scratch_floats_wide(int N, int H) { return (size_t)((N + G4_TRAJ - 1) / G4_TRAJ) * gw_tile_floats(H, 4); }   // (C <= 4)
 const char* ctk_g_rpgd_wide_name(int env) {
