@@ -765,7 +765,10 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
     // network has more than 8 inputs) of every step's record.  The records were written by waves on every XCD, so a load is a trip to
     // memory (~2 us) against ~0.1 us of chain work per step: they travel through a register ring RING steps deep that is filled HERE, before
     // anything else, and refilled slot by slot as the chain consumes it.
-    constexpr int RW = S > 4 ? 2 : 1, W4 = RW * (IO > 8 ? 2 : 1), RING = 32 / W4;
+    // Depth: as many steps as ~32 float4 of registers hold, trimmed to what divides the usual horizons with little left over — the walk
+    // goes in whole blocks (below), so H = 50 at depth 32 walks 64 steps, at depth 25 exactly 50 (CartPole 496 -> 490 us; 16 -> 17:
+    // Quad2D 548 -> 540; 8 -> 10: Hover 637 -> 627)
+    constexpr int RW = S > 4 ? 2 : 1, W4 = RW * (IO > 8 ? 2 : 1), RING = W4 == 1 ? 25 : W4 == 2 ? 17 : 10;
     float4 ring[RING][W4];
     const int cp = t >> 3, ci = t & 7;
     auto rec_fetch = [&](int h, float4 (&dst)[W4]) {
