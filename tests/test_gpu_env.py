@@ -520,6 +520,36 @@ def test_quad2d_mlp_gradient_and_rpgd_match_oracle():
     e.close()
 
 
+@pytest.mark.parametrize("N,H", [(40, 1), (50, 2), (37, 3), (200, 7), (72, 26), (1100, 12)])
+def test_quad2d_mlp_wide_rpgd_edge_shapes_match_oracle(N, H):
+    """The wide RPGD descent of the template (Jacobian workgroups inside the phase launch: flags lag the forward pass by four steps; the
+    adjoint chain walks whole blocks of its ring depth) at horizons shorter than the lag and the ring, ragged populations, and more tiles
+    (N = 1100: 69) than the in-launch form takes (64: there the Jacobians keep their own launch)."""
+    env, w, pred = quad_mlp()
+    cost = O.Cost(env)
+    p = 1 if H < 4 else 3
+    o = O.RPGD(pred, cost, QLO, QHI, num_rollouts=N, mpc_horizon=H, outer_its=3, resamp_per=2, period_interpolation_inducing_points=p,
+               SAMPLING_DISTRIBUTION="uniform", opt_keep_k_ratio=0.25)
+    e = CtkEngine("rpgd", "MLP", environment="Quad2D", num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p,
+                  outer_its=3, resamp_per=2, opt_keep_k=o.k, sampling_distribution=0, sample_whole_control_space=1, action_low=QLO, action_high=QHI)
+    assert "wide_split" in e.dominant_kernel(), e.dominant_kernel()
+    apply_params(e, env); e.set_predictor_weights(w)
+    rng = np.random.default_rng(N + H)
+    d0 = rng.random((N, o.P, 2), dtype=np.float32)
+    o.optimizer_reset(d0); e.reset(d0)
+    tol = dict(rtol=2e-4, atol=3e-4)
+    s = S0.copy()
+    for t in range(2):
+        dr = rng.random((N - o.k, o.P, 2), dtype=np.float32) if t % 2 == 0 else None
+        uo, ug = o.step(s, dr), e.step(s, dr)
+        assert_close_mostly(e.read("PLAN"), o.Q, max_outliers=max(4, o.Q.size // 400), **tol)
+        assert_close_mostly(e.read("ADAM_M"), o.opt.m, max_outliers=max(4, o.Q.size // 400), **tol)
+        np.testing.assert_allclose(ug, np.asarray(uo).reshape(-1), **tol)
+        e.set_state(rpgd_state(o))
+        s = pred.step(s.reshape(1, 6), np.asarray(uo, np.float32).reshape(1, 2))[0]
+    e.close()
+
+
 # ---- SURVEY 8e with the second environment: shards of N/2 + the record exchange == one handle of N ----------------
 @pytest.mark.parametrize("opt", ["mppi", "cem", "random_action", "rpgd"])
 def test_quad2d_two_shards_equal_one_handle(opt):
