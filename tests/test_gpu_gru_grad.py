@@ -164,7 +164,7 @@ def test_one_wave_network_forms_also_match_oracle():
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(here, "test_gpu_gru_grad.py"),
                         os.path.join(here, "test_gpu_hover.py"), os.path.join(here, "test_gpu_env.py"),
-                        "-k", "(single_gradient or rpgd_with_gru_matches or quad2d_gru_mppi or generic_gru_matches or hover or mlp) and not one_wave and not shards and not two_tiles and not own_jacobian"],
+                        "-k", "(single_gradient or rpgd_with_gru_matches or quad2d_gru_mppi or generic_gru_matches or hover or mlp) and not one_wave and not shards and not two_tiles and not own_jacobian and not edge_shapes"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
