@@ -1332,8 +1332,7 @@ static void launch_wide_split(hipStream_t st, const RolloutArgs& a_in, const flo
         hipEvent_t s0 = it == 0 ? e0 : nullptr, s1 = last ? e1 : nullptr;
         uint32_t seq = 0;
         if (ovl && !last) { seq = ++launch_seq; if (seq == 0) seq = ++launch_seq; }
-        static const bool diag_no_workers = getenv("CTK_DIAG_OVL_NOWORKERS") != nullptr;   // timing experiments only: results are wrong
-        const dim3 grid(ovl && !last && !diag_no_workers ? tiles * (1 + a.H) : tiles);
+        const dim3 grid(ovl && !last ? tiles * (1 + a.H) : tiles);
         if (s0 || s1)
             hipExtLaunchKernelGGL((ctk_g_rpgd_wide_split<EV, K3>), grid, dim3(128), lds, st, s0, s1, 0, a, k, ad, Q, m, v, bc_table, bc_len, t0 + it, wperm,
                                   scratch, it > 0 ? 1 : 0, last ? 1 : 0, seq);
