@@ -109,6 +109,7 @@ def main():
     copy_text("resident.txt", f"{tag}_resident.txt", "# tools/bench_resident.py (CtkEngine.step, launched form against the resident form), then tools/diag_mailbox_vram (round trip of one word:\n"
               "# mailbox in pinned host memory against mailbox in host-written device memory)\n")
     copy_text("placement.txt", f"{tag}_wave_placement.txt", "# tools/diag_wave_placement: where a CU puts the waves of small workgroups (every wave: a dependent chain of 14 fp32 MFMAs per step; XCC / SE / CU / SIMD from s_getreg)\n")
+    copy_text("soak_handoff.txt", f"{tag}_soak_handoff.txt", "# tools/soak_handoff.py 1000: the in-launch hand-off of the template wide RPGD descent while a second process keeps the GPU busy\n")
     copy_text("soak.txt", f"{tag}_soak.txt", "# tools/soak.py 1500: closed-loop soak of 21 engines (every optimizer, predictor, environment, the one-launch CEM, the split network kernels)\n")
     p = pmc("pmc_largen")
     if fresh(p):

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""The in-launch hand-off of the template's wide RPGD descent under a loaded GPU: a second process keeps every CU busy with
+MPPI + MLP steps at N = 65 536 while this one runs closed-loop RPGD + MLP steps (CartPole through the template, Quad2D, Hover).  The same
+steps run again on the idle GPU must give the same inputs bit for bit: a poll that ran out would have left NaN records, a stale read a
+different plan."""
+import os, subprocess, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+LOAD = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from control_toolkit_amd import CtkEngine
+e = CtkEngine("mppi", "MLP", num_rollouts=65536, mpc_horizon=100, dt=0.02, period_interpolation_inducing_points=10, seed=3)
+e.set_predictor_weights((np.random.default_rng(0).standard_normal(e.predictor_weight_count()) * 0.15).astype(np.float32))
+s = np.array([0.05, -0.1, 2.8, 0.4], np.float32)
+import time
+t0 = time.time()
+n = 0
+while time.time() - t0 < float(sys.argv[1]):
+    e.step(s); n += 1
+print("load steps", n)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(steps):
+    from control_toolkit_amd import CtkEngine
+    out = {}
+    for env, kw in (("CartPole", dict(generic_kernels=True)), ("Quad2D", {}), ("Hover", {})):
+        e = CtkEngine("rpgd", "MLP", environment=env, num_rollouts=256, mpc_horizon=50, dt=0.02, period_interpolation_inducing_points=10,
+                      outer_its=10, resamp_per=10, opt_keep_k=64, seed=5, **kw)
+        assert "wide_split" in e.dominant_kernel(), e.dominant_kernel()
+        e.set_predictor_weights((np.random.default_rng(0).standard_normal(e.predictor_weight_count()) * 0.15).astype(np.float32))
+        e.reset()
+        S = {"CartPole": 4, "Quad2D": 6, "Hover": 7}[env]
+        s = (0.05 * np.arange(1, S + 1)).astype(np.float32)
+        us = []
+        for t in range(steps):
+            u = np.asarray(e.step(s)).reshape(-1).copy()
+            us.append(u)
+            s = (0.97 * s + 0.02 * np.resize(u, S) + 0.01 * np.sin(0.1 * t + np.arange(S))).astype(np.float32)
+        e.close()
+        out[env] = np.stack(us)
+    return out
+
+
+if __name__ == "__main__":
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    t0 = time.time()
+    idle = run(steps)
+    t_idle = time.time() - t0
+    load = subprocess.Popen([sys.executable, "-c", LOAD, str(3 * t_idle + 20)], stdout=subprocess.PIPE, text=True)
+    time.sleep(8)                                # the load process has created its engine and is stepping
+    t0 = time.time()
+    busy = run(steps)
+    t_busy = time.time() - t0
+    load.terminate(); load.wait()
+    ok = True
+    for env in idle:
+        same = np.array_equal(idle[env], busy[env]) and np.isfinite(busy[env]).all()
+        ok &= same
+        print(f"{env:9s} {steps} steps x 10 hand-off launches: idle GPU vs loaded GPU {'identical' if same else 'DIFFERENT'}; last u {busy[env][-1]}")
+    print(f"wall: idle {t_idle:.1f} s, under load {t_busy:.1f} s")
+    print("soak_handoff", "ok" if ok else "FAILED")
+    sys.exit(0 if ok else 1)
