@@ -239,7 +239,9 @@ struct SplitGru {
         CTK_DEV void load(const float* __restrict__ tab, int wave, int lane) { w = gru4_load_fwd(tab, wave >> 1, wave & 1, lane); }
         CTK_DEV void begin(const float* __restrict__ hidden, int g) { st = gru_load_state(hidden, g); }
         // tq: this wave's tape of the step (+ i * 64 per float4), used when TAPE
-        template <bool TAPE>
+        template <int S, int C> CTK_DEV void fold_load(int) {}                       // (SplitMlp: layer-1 input columns as a bias update)
+        template <int S, int C> CTK_DEV void fold_inputs(const float (&)[C]) {}
+        template <bool TAPE, int = 0, int = 0>
         CTK_DEV MlpPair step(float x0, float x1, float, float* ex, int wave, int lane, float4* tq) {
             GruPairTape t1, t2;
             const MlpPair o = gru4_step(w, st, x0, x1, ex, wave, lane, TAPE ? &t1 : nullptr, TAPE ? &t2 : nullptr);
@@ -285,13 +287,41 @@ struct SplitMlp {
             b3lo = f.b3[0]; b3hi = f.b3[1];
         }
         CTK_DEV void begin(const float*, int) {}
-        template <int TAPE>                     // 0: none; 1: float4 tape at tq[0], tq[64]; 2: the same, stored through to memory from where the wave waits anyway
+        // Where the LAST layer-1 k-step holds control inputs only (S <= 4 * (k-steps - 1): CartPole 4 + 1, Hover 7 + 3) its matrix product is
+        // a rank-NF update that does not depend on the state: b1u = b1 + sum_f W1[:, input f] * u_f is formed as soon as the inputs are
+        // known and opens the step's first product as its accumulator — one dependent MFMA less per step (what CartPole's own thin
+        // layer 1 does, ctk_mlp.h).  S = C = 0 (the default of step): no folding.
+        static constexpr int KS = K3 ? 3 : 2;
+        template <int S, int C> static constexpr int fold_n() { return (S + C > 4 * (KS - 1) && S <= 4 * (KS - 1)) ? S + C - 4 * (KS - 1) : 0; }
+        f32x4 w1u[4], b1u;
+        template <int S, int C>
+        CTK_DEV void fold_load(int lane) {                                 // after load(): this lane's accumulator rows of the folded columns
+            constexpr int NF = fold_n<S, C>();
+            const int g = lane >> 4;
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w1u[f][r] = __shfl(w1[KS - 1], 4 * g + r + 16 * f, 64);    // A operand: lane (i, k) holds W1[16m + i][4 (KS-1) + k]
+            b1u = b1;
+        }
+        template <int S, int C>
+        CTK_DEV void fold_inputs(const float (&u)[C]) {
+            constexpr int NF = fold_n<S, C>(), CC0 = 4 * (KS - 1) - S;      // the first folded input channel
+            if constexpr (NF > 0) {
+                f32x4 b = b1;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) b += w1u[f] * u[CC0 + f];
+                b1u = b;
+            }
+        }
+        template <int TAPE, int S = 0, int C = 0>   // TAPE 0: none; 1: float4 tape at tq[0], tq[64]; 2: the same, stored through to memory from where the wave waits anyway
         CTK_DEV MlpPair step(float x0, float x1, float x2, float* ex, int m, int lane, float4* tq) {
             float4* ex_h = reinterpret_cast<float4*>(ex);                  // [2][64]
             float2* ex_o = reinterpret_cast<float2*>(ex + 2 * 64 * 4);     // [2][64]
-            f32x4 a = CTK_MFMA(w1[0], x0, b1);
-            a = CTK_MFMA(w1[1], x1, a);
-            if constexpr (K3) a = CTK_MFMA(w1[2], x2, a);
+            constexpr bool FOLD = fold_n<S, C>() > 0;
+            f32x4 a = CTK_MFMA(w1[0], x0, FOLD ? b1u : b1);
+            if constexpr (!(FOLD && !K3)) a = CTK_MFMA(w1[1], x1, a);
+            if constexpr (K3 && !FOLD) a = CTK_MFMA(w1[2], x2, a);
             const f32x4 h1m = ctk_tanhf4(a);
             ex_h[m * 64 + lane] = st4(h1m);
             __syncthreads();
@@ -398,6 +428,7 @@ __global__ __launch_bounds__(64 * SP::WAVES) void ctk_g_rpgd_descent_split(Rollo
     typename SP::Fwd nf;
     typename SP::Bwd nb;
     nf.load(wperm, wave, lane);
+    nf.template fold_load<S, C>(lane);
     nb.load(wperm_bwd, wave, lane);
     float up0[C];
 #pragma unroll
@@ -418,7 +449,8 @@ __global__ __launch_bounds__(64 * SP::WAVES) void ctk_g_rpgd_descent_split(Rollo
             if (wave == (h & (WAVES - 1))) reinterpret_cast<float2*>(xs_s)[h * 64 + lane] = make_float2(sv0, sv1);
             float x0, x1, x2;
             split_operands<S, C>(sv0, sv1, u, g, x0, x1, x2);
-            const MlpPair o = nf.template step<TAPE>(x0, x1, x2, ex, wave, lane, tape + (size_t)h * tape_step);
+            nf.template fold_inputs<S, C>(u);
+            const MlpPair o = nf.template step<TAPE, S, C>(x0, x1, x2, ex, wave, lane, tape + (size_t)h * tape_step);
             sv0 = o.lo; sv1 = o.hi;
         }
         if (wave == 0) reinterpret_cast<float2*>(xs_s)[H * 64 + lane] = make_float2(sv0, sv1);
@@ -830,6 +862,7 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
     }
     typename SP::Fwd nf;
     nf.load(wperm, wave, lane);
+    nf.template fold_load<S, C>(lane);
     float up0[C];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) up0[cc] = a.u_prev_dev ? a.u_prev_dev[cc] : a.u_prev[cc];
@@ -958,9 +991,10 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
             }
             float x0, x1, x2;
             split_operands<S, C>(sv0, sv1, u, g, x0, x1, x2);
-            const MlpPair o = last ? nf.template step<0>(x0, x1, x2, ex, wave, lane, nullptr)
-                              : ovl ? nf.template step<2>(x0, x1, x2, ex, wave, lane, tape + (size_t)h * (2 * 2 * 64))
-                                    : nf.template step<1>(x0, x1, x2, ex, wave, lane, tape + (size_t)h * (2 * 2 * 64));
+            nf.template fold_inputs<S, C>(u);
+            const MlpPair o = last ? nf.template step<0, S, C>(x0, x1, x2, ex, wave, lane, nullptr)
+                              : ovl ? nf.template step<2, S, C>(x0, x1, x2, ex, wave, lane, tape + (size_t)h * (2 * 2 * 64))
+                                    : nf.template step<1, S, C>(x0, x1, x2, ex, wave, lane, tape + (size_t)h * (2 * 2 * 64));
             sv0 = o.lo; sv1 = o.hi;
             // step h - LAG is in memory once at most the 2 * LAG activation stores of the steps since are outstanding
             if (ovl && h >= LAG) flag_through<2 * LAG>(flags + (h - LAG) * 2 + wave, ovl_seq);
@@ -1070,6 +1104,7 @@ __global__ __launch_bounds__(64 * SP::WAVES * TILES) void ctk_g_rollout_split(Ro
 
     typename SP::Fwd nf;
     nf.load(wperm, wave, lane);
+    nf.template fold_load<S, C>(lane);
     load_tile_early<G4_TRAJ, BLOCK>(tile, samples, a, row0, MODE == CTK_G_MODE_MPPI ? mk.stdev : 1.0f, rng_kind, [&] {
         if constexpr (MODE == CTK_G_MODE_MPPI) {
             for (int h = t; h < H; h += BLOCK) {
@@ -1130,7 +1165,7 @@ __global__ __launch_bounds__(64 * SP::WAVES * TILES) void ctk_g_rollout_split(Ro
     {
         nf.begin(hidden, g);
         float sv0 = s00, sv1 = s01;
-        for (int h = 0; h < H; ++h) {
+        for (int h = 0; h < H; ++h) {                      // (no input fold here: measured no gain in this kernel, CartPole 45.6 / 73.5 us either way)
             float u[C];
 #pragma unroll
             for (int cc = 0; cc < C; ++cc) u[cc] = u_s[(h * C + cc) * G4_LD + c];
