@@ -9,8 +9,13 @@ What the fixtures therefore pin is the logic that IS in the reference:
   Optimizers/optimizer_rpgd.py (ADAM torch branch + RPGD step), others/globals_and_utils.py
   (create_rng / torch_gen_like_TF), Controllers/controller_mpc.py + Controllers/__init__.py
   (construction order and step plumbing).
-What they do NOT pin (build-defined, "parity unpinned"): the predictor, the concrete cost terms,
-CEM and random-action (their modules import tensorflow at module level).
+Round 4: Optimizers/optimizer_cem_tf.py, optimizer_random_action_tf.py and optimizer_cem_naive_grad_tf.py too — their module-level
+`import tensorflow as tf` resolves to a torch-backed, build-authored stand-in (standins/tensorflow; its semantic choices — stable
+ascending argsort, population std — are listed in standins/README.md), `computation_library: tensorflow` in the work
+directory's config_controllers.yml, driven through the reference's own controller_mpc like MPPI.
+What they do NOT pin (build-defined, "parity unpinned"): the predictor, the concrete cost terms, the meaning of the `lib.*` / `tf.*`
+primitives (the stand-ins'), and everything that needs tf.keras.optimizers.Adam (optimizer_gradient_tf, cem_grad_bharadhwaj, RPGD's
+TF branch).
 
 Usage (build container only):  python tests/golden/make_golden.py
 Neither this script nor the stand-ins run on the GPU box; only the .npz outputs travel.
@@ -117,6 +122,160 @@ def initial_state(seed):
     rng = np.random.default_rng(seed)   # SURVEY 8d common synthetic inputs
     return np.array([rng.uniform(-0.2, 0.2), rng.uniform(-0.5, 0.5), rng.uniform(-np.pi, np.pi),
                      rng.uniform(-2, 2)], dtype=np.float32)
+
+
+def set_computation_library(name):
+    """`computation_library:` of the work directory's config_controllers.yml, which template_controller.__init__ reads at every
+    construction (Controllers/__init__.py:40-58)"""
+    import yaml
+    path = os.path.join("Control_Toolkit_ASF", "config_controllers.yml")
+    with open(path) as f:
+        cfg = yaml.safe_load(f)
+    cfg["mpc"]["computation_library"] = name
+    with open(path, "w") as f:
+        yaml.safe_dump(cfg, f)
+
+
+def record_tf_only_optimizers(out_dir, cm, envs, dt):
+    """optimizer_cem_tf / optimizer_random_action_tf / optimizer_cem_naive_grad_tf, UNMODIFIED, driven through the reference's own
+    controller_mpc with `computation_library: tensorflow`.  Their `import tensorflow as tf` resolves to the torch-backed stand-in
+    (standins/tensorflow: semantic choices listed there and in standins/README.md), `TensorFlowLibrary` to the SI_Toolkit stand-in's."""
+    import Control_Toolkit.Optimizers as tmpl
+    import SI_Toolkit.Predictors.predictor_wrapper as pw
+
+    def controller(opt_name, cfg, pred, envname):
+        e = envs[envname]
+        e["inject"]()
+        pw.ENVIRONMENT = envname
+        orig_create, holder = tmpl.create_rng, {}
+
+        def recording_create(id, seed, computation_library=None):
+            holder["rec"] = RecordingRng(orig_create(id, seed, computation_library=computation_library))
+            return holder["rec"]
+        tmpl.create_rng = recording_create
+        try:
+            cm.config_optimizers[opt_name] = dict(cfg)
+            ctrl = cm.controller_mpc(envname, (e["low"], e["high"]), {})
+            ctrl.controller_logging = True
+            ctrl.configure(optimizer_name=opt_name, predictor_specification=pred)
+        finally:
+            tmpl.create_rng = orig_create
+        assert ctrl.lib.lib == "TF" and ctrl.optimizer.optimizer_logging
+        return ctrl, holder["rec"]
+
+    def header(c, cfg, envname):
+        e = envs[envname]
+        d = dict(e["common"], low=e["low"], high=e["high"], predictor=np.array(c["pred"]), environment=np.array(envname),
+                 **{k: (np.float32(v) if isinstance(v, float) else np.array(v)) for k, v in cfg.items()})
+        if c["pred"] != "MLP":
+            d.pop("mlp_weights", None)
+        return d
+
+    def u_prev_of(opt, C):
+        return np.broadcast_to(np.asarray(opt.u, np.float32).reshape(-1), (C,)).copy()
+
+    set_computation_library("tensorflow")
+    try:
+        # ---- CEM (Optimizers/optimizer_cem_tf.py:54-117) --------------------------------------------------------------
+        cem_cases = {
+            "tiny":    dict(env="CartPole", pred="ODE", N=16, H=8, K=4, its=2, steps=3, seed=41, traj=True),
+            "default": dict(env="CartPole", pred="ODE", N=200, H=40, K=40, its=3, steps=3, seed=42, traj=True),   # config_optimizers.yml:5-14
+            "cfg3":    dict(env="CartPole", pred="ODE", N=4096, H=30, K=409, its=3, steps=3, seed=43, traj=False),  # BASELINE configs[2]
+            "warmup":  dict(env="CartPole", pred="ODE", N=64, H=12, K=8, its=2, steps=3, seed=44, traj=True, warmup=True, warmup_iterations=5),
+            "mlp":     dict(env="CartPole", pred="MLP", N=128, H=20, K=16, its=2, steps=3, seed=45, traj=True),
+            "quad2d":  dict(env="Quad2D", pred="ODE", N=128, H=20, K=20, its=3, steps=3, seed=46, traj=True),
+            "hover":   dict(env="Hover", pred="ODE", N=96, H=16, K=12, its=2, steps=3, seed=47, traj=True),
+            "hover_mlp": dict(env="Hover", pred="MLP", N=64, H=12, K=9, its=3, steps=3, seed=48, traj=True),
+        }
+        for name, c in cem_cases.items():
+            e = envs[c["env"]]
+            cfg = dict(seed=1, mpc_horizon=c["H"], cem_outer_it=c["its"], cem_initial_action_stdev=0.5, num_rollouts=c["N"],
+                       cem_stdev_min=0.01, cem_best_k=c["K"], warmup=c.get("warmup", False),
+                       warmup_iterations=c.get("warmup_iterations", 250), mpc_timestep=dt)
+            ctrl, rec = controller("cem-tf", cfg, c["pred"], c["env"])
+            opt = ctrl.optimizer
+            d = header(c, cfg, c["env"])
+            d["dist_mue_init"] = opt.dist_mue.numpy().copy(); d["stdev_init"] = opt.stdev.numpy().copy()
+            plant = O.Predictor(kind="ODE", dt=dt, env=e["env"])
+            s = e["state"](c["seed"])
+            for t in range(c["steps"]):
+                ndraw = len(rec.raw)
+                u_prev = u_prev_of(opt, e["C"])
+                u = ctrl.step(s.copy())
+                lv = opt.logging_values
+                d[f"s_{t}"] = s.copy(); d[f"u_prev_{t}"] = u_prev
+                d[f"noise_{t}"] = np.stack(rec.raw[ndraw:])                     # [iterations, N, H, C]: one rng.normal per outer iteration (:64-65)
+                d[f"u_{t}"] = np.asarray(u, np.float32).reshape(-1)
+                d[f"dist_mue_{t}"] = opt.dist_mue.numpy().copy(); d[f"stdev_{t}"] = opt.stdev.numpy().copy()
+                d[f"J_{t}"] = np.asarray(lv["J_logged"]).copy()                 # last iteration's costs / plans (:96,:105-107)
+                d[f"Q_{t}"] = np.asarray(lv["Q_logged"]).copy()
+                if c["traj"]:
+                    d[f"traj_{t}"] = np.asarray(lv["rollout_trajectories_logged"]).copy()
+                s = plant_step(plant, s, u)
+            assert opt.count == c["steps"]
+            d["steps"] = np.int32(c["steps"])
+            np.savez_compressed(os.path.join(out_dir, f"cem_{name}.npz"), **d)
+
+        # ---- random-action (Optimizers/optimizer_random_action_tf.py:38-86) -------------------------------------------
+        random_cases = {
+            "cfg1":    dict(env="CartPole", pred="ODE", N=32, H=10, steps=3, seed=51),     # BASELINE configs[0]
+            "default": dict(env="CartPole", pred="ODE", N=320, H=35, steps=3, seed=52),    # config_optimizers.yml:212-215
+            "quad2d":  dict(env="Quad2D", pred="ODE", N=64, H=12, steps=3, seed=53),
+            "hover_mlp": dict(env="Hover", pred="MLP", N=48, H=9, steps=2, seed=54),
+        }
+        for name, c in random_cases.items():
+            e = envs[c["env"]]
+            cfg = dict(seed=1, mpc_horizon=c["H"], num_rollouts=c["N"], mpc_timestep=dt)
+            ctrl, rec = controller("random-action-tf", cfg, c["pred"], c["env"])
+            opt = ctrl.optimizer
+            assert len(rec.raw) == 1            # optimizer_reset draws one population and drops it (:78-86): it advances the stream
+            d = header(c, cfg, c["env"])
+            plant = O.Predictor(kind="ODE", dt=dt, env=e["env"])
+            s = e["state"](c["seed"])
+            for t in range(c["steps"]):
+                u_prev = u_prev_of(opt, e["C"])
+                u = ctrl.step(s.copy())
+                lv = opt.logging_values
+                d[f"s_{t}"] = s.copy(); d[f"u_prev_{t}"] = u_prev
+                d[f"u01_{t}"] = rec.raw[-1]
+                d[f"u_{t}"] = np.asarray(u, np.float32).reshape(-1)
+                d[f"Q_{t}"] = np.asarray(lv["Q_logged"]).copy(); d[f"J_{t}"] = np.asarray(lv["J_logged"]).copy()
+                d[f"traj_{t}"] = np.asarray(lv["rollout_trajectories_logged"]).copy()
+                s = plant_step(plant, s, u)
+            d["steps"] = np.int32(c["steps"])
+            np.savez_compressed(os.path.join(out_dir, f"random_{name}.npz"), **d)
+
+        # ---- CEM + one clipped-gradient step (Optimizers/optimizer_cem_naive_grad_tf.py:58-119) -----------------------
+        naive_cases = {
+            "default": dict(env="CartPole", pred="ODE", N=200, H=35, K=40, its=1, steps=3, seed=61),   # config_optimizers.yml:23-32
+            "its2":    dict(env="CartPole", pred="MLP", N=64, H=20, K=10, its=2, steps=3, seed=62),
+            "hover":   dict(env="Hover", pred="ODE", N=48, H=12, K=8, its=2, steps=3, seed=63),
+        }
+        for name, c in naive_cases.items():
+            e = envs[c["env"]]
+            cfg = dict(seed=1, mpc_horizon=c["H"], cem_outer_it=c["its"], num_rollouts=c["N"], cem_stdev_min=0.1,
+                       cem_initial_action_stdev=0.5, cem_best_k=c["K"], learning_rate=0.1, gradmax_clip=10.0, mpc_timestep=dt)
+            ctrl, rec = controller("cem-naive-grad-tf", cfg, c["pred"], c["env"])
+            opt = ctrl.optimizer
+            d = header(c, cfg, c["env"])
+            plant = O.Predictor(kind="ODE", dt=dt, env=e["env"])
+            s = e["state"](c["seed"])
+            for t in range(c["steps"]):
+                ndraw = len(rec.raw)
+                u_prev = u_prev_of(opt, e["C"])
+                u = ctrl.step(s.copy())
+                lv = opt.logging_values
+                d[f"s_{t}"] = s.copy(); d[f"u_prev_{t}"] = u_prev
+                d[f"noise_{t}"] = np.stack(rec.raw[ndraw:])
+                d[f"u_{t}"] = np.asarray(u, np.float32).reshape(-1)
+                d[f"dist_mue_{t}"] = opt.dist_mue.numpy().copy(); d[f"stdev_{t}"] = opt.stdev.numpy().copy()
+                d[f"J_{t}"] = np.asarray(lv["J_logged"]).copy(); d[f"Q_{t}"] = np.asarray(lv["Q_logged"]).copy()
+                s = plant_step(plant, s, u)
+            d["steps"] = np.int32(c["steps"])
+            np.savez_compressed(os.path.join(out_dir, f"cem_naive_grad_{name}.npz"), **d)
+    finally:
+        set_computation_library("pytorch")
+        pw.ENVIRONMENT = "CartPole"
 
 
 def main():
@@ -462,6 +621,18 @@ def main():
         d["steps"] = np.int32(c["steps"])
         np.savez_compressed(os.path.join(out_dir, f"rpgd_{name}.npz"), **d)
     pw.ENVIRONMENT = "CartPole"
+
+    # ---- the TF-only optimizers (CEM, random-action, CEM + naive gradient) --------------------------------------------
+    envs = {
+        "CartPole": dict(env=env, low=low, high=high, C=1, state=initial_state, inject=lambda: inject_constants(env, dt, mlp_w),
+                         common=dict(common)),
+        "Quad2D": dict(env=qenv, low=qlow, high=qhigh, C=2, state=quad_state, inject=lambda: inject_quad(qenv, dt),
+                       common=dict(env_params=qenv.as_array(), env_param_names=np.array(O.QUAD2D_PARAM_NAMES), dt=np.float32(dt))),
+        "Hover": dict(env=henv, low=hlow, high=hhigh, C=3, state=hover_state, inject=lambda: inject_hover(henv, dt, hover_w),
+                      common=dict(env_params=henv.as_array(), env_param_names=np.array(O.HOVER_PARAM_NAMES), dt=np.float32(dt),
+                                  mlp_weights=hover_w)),
+    }
+    record_tf_only_optimizers(out_dir, cm, envs, dt)
 
     print("golden fixtures written to", out_dir)
     for f in sorted(os.listdir(out_dir)):

@@ -37,12 +37,9 @@ class NumpyLibrary(ComputationLibrary):
         return np.asarray(x)
 
 
-class TensorFlowLibrary(ComputationLibrary):
-    lib = "TF"   # never instantiated here: TensorFlow is not installed
-
-
-class PyTorchLibrary(ComputationLibrary):
-    lib = "Pytorch"
+class _TorchBacked:
+    """the `lib.*` members, on torch-CPU tensors; shared by the two tensor libraries below (which must stay unrelated
+    classes: the reference branches on `isinstance(self.lib, TensorFlowLibrary)`, optimizer_rpgd.py:35,52,86)"""
     float32 = torch.float32
     int64 = torch.int64
     newaxis = None
@@ -63,7 +60,7 @@ class PyTorchLibrary(ComputationLibrary):
 
     @staticmethod
     def to_variable(x, dtype):
-        return PyTorchLibrary.to_tensor(x, dtype).clone()
+        return _TorchBacked.to_tensor(x, dtype).clone()
 
     @staticmethod
     def to_numpy(x):
@@ -127,6 +124,17 @@ class PyTorchLibrary(ComputationLibrary):
         # tf.clip_by_norm: x * clip / max(||x||, clip)
         nrm = torch.sqrt(torch.sum(x * x, dim=tuple(axes), keepdim=True))
         return x * clip_norm / torch.maximum(nrm, torch.as_tensor(clip_norm, dtype=x.dtype))
+
+
+class PyTorchLibrary(_TorchBacked, ComputationLibrary):
+    lib = "Pytorch"
+
+
+class TensorFlowLibrary(_TorchBacked, ComputationLibrary):
+    """`computation_library: tensorflow` in the golden runs of the TF-only optimizers (optimizer_cem_tf,
+    optimizer_random_action_tf, optimizer_cem_naive_grad_tf): the same torch-backed members under the tag the
+    reference expects; the `tf.*` names those modules call directly come from standins/tensorflow."""
+    lib = "TF"
 
 
 ComputationClasses = (NumpyLibrary, TensorFlowLibrary, PyTorchLibrary)

@@ -59,6 +59,35 @@ def rpgd_oracle_from(d) -> O.RPGD:
                   num_rollouts=int(d["num_rollouts"]), mpc_horizon=int(d["mpc_horizon"]), **rpgd_kwargs_from(d))
 
 
+def cem_oracle_from(d) -> O.CEM:
+    pred = predictor_from(d)
+    return O.CEM(pred, O.Cost(pred.env, pred.dt), d["low"], d["high"], num_rollouts=int(d["num_rollouts"]),
+                 mpc_horizon=int(d["mpc_horizon"]), cem_outer_it=int(d["cem_outer_it"]),
+                 cem_initial_action_stdev=float(d["cem_initial_action_stdev"]), cem_stdev_min=float(d["cem_stdev_min"]),
+                 cem_best_k=int(d["cem_best_k"]), warmup=bool(d["warmup"]), warmup_iterations=int(d["warmup_iterations"]))
+
+
+def random_oracle_from(d) -> O.RandomAction:
+    pred = predictor_from(d)
+    return O.RandomAction(pred, O.Cost(pred.env, pred.dt), d["low"], d["high"], num_rollouts=int(d["num_rollouts"]),
+                          mpc_horizon=int(d["mpc_horizon"]))
+
+
+def cem_naive_grad_oracle_from(d) -> O.CEMNaiveGrad:
+    pred = predictor_from(d)
+    return O.CEMNaiveGrad(pred, O.Cost(pred.env, pred.dt), d["low"], d["high"], num_rollouts=int(d["num_rollouts"]),
+                          mpc_horizon=int(d["mpc_horizon"]), cem_outer_it=int(d["cem_outer_it"]),
+                          cem_initial_action_stdev=float(d["cem_initial_action_stdev"]), cem_stdev_min=float(d["cem_stdev_min"]),
+                          cem_best_k=int(d["cem_best_k"]), learning_rate=float(d["learning_rate"]), gradmax_clip=float(d["gradmax_clip"]))
+
+
+def cut_is_separated(J, K, rel=1e-4):
+    """True when the K-th and (K+1)-th smallest costs are further apart than fp32 cost noise: only then is the elite SET (and
+    everything refitted from it) comparable between two fp32 evaluations of the same costs"""
+    srt = np.sort(np.asarray(J))
+    return K >= len(srt) or (srt[K] - srt[K - 1]) > rel * abs(srt[K - 1])
+
+
 MPPI_CASES = ["tiny_ode", "interp_ode", "cfg2_ode", "quirk_ode", "mlp"]
 RPGD_CASES = ["ode_small", "ode_its20", "mlp_cfg4", "ode_normal"]
 # recorded from the same unmodified reference optimizers on the second environment (6 states, 2 control inputs)
@@ -67,3 +96,8 @@ RPGD_QUAD_CASES = ["quad2d", "quad2d_its20"]
 # ... and on the third environment (7 states, 3 control inputs: 10 network inputs), analytic and 10-32-32-7 MLP predictor
 MPPI_HOVER_CASES = ["hover_ode", "hover_mlp"]
 RPGD_HOVER_CASES = ["hover_ode", "hover_mlp"]
+# recorded from the unmodified TF-only optimizers (optimizer_cem_tf, optimizer_random_action_tf, optimizer_cem_naive_grad_tf) through the
+# reference's controller_mpc with the torch-backed `tensorflow` stand-in (tests/golden/standins/tensorflow)
+CEM_CASES = ["tiny", "default", "cfg3", "warmup", "mlp", "quad2d", "hover", "hover_mlp"]
+RANDOM_CASES = ["cfg1", "default", "quad2d", "hover_mlp"]
+CEM_NAIVE_GRAD_CASES = ["default", "its2", "hover"]

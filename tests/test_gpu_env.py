@@ -15,6 +15,8 @@ from helpers import load
 from test_gpu_mppi import U_TOL
 from test_gpu_rpgd import assert_close_mostly
 
+from margins import close
+
 pytestmark = pytest.mark.gpu
 
 QLO, QHI = np.array([-1.0, -0.8], np.float32), np.array([1.0, 0.9], np.float32)   # different limits per input on purpose
@@ -330,11 +332,11 @@ def test_quad2d_mppi_matches_reference_golden(case, materialize):
     for t in range(int(d["steps"])):
         u = e.step(d[f"s_{t}"], d[f"noise_{t}"], u_prev=d[f"u_prev_{t}"])
         if materialize:
-            np.testing.assert_allclose(e.read("Q"), d[f"u_run_{t}"], rtol=1e-6, atol=1e-6)
-            np.testing.assert_allclose(e.read("TRAJ"), d[f"traj_{t}"], rtol=1e-4, atol=2e-5)
-        np.testing.assert_allclose(e.read("J"), d[f"J_{t}"], rtol=3e-5)
-        np.testing.assert_allclose(e.read("U_NOM"), d[f"u_nom_{t}"], **U_TOL)
-        np.testing.assert_allclose(u, d[f"u_{t}"], **U_TOL)
+            close(f"mppi_{case}[materialize={materialize}] step {t}", "q", e.read("Q"), d[f"u_run_{t}"], rtol=1e-6, atol=1e-6)
+            close(f"mppi_{case}[materialize={materialize}] step {t}", "traj", e.read("TRAJ"), d[f"traj_{t}"], rtol=1e-4, atol=2e-5)
+        close(f"mppi_{case}[materialize={materialize}] step {t}", "j", e.read("J"), d[f"J_{t}"], rtol=3e-5)
+        close(f"mppi_{case}[materialize={materialize}] step {t}", "u_nom", e.read("U_NOM"), d[f"u_nom_{t}"], **U_TOL)
+        close(f"mppi_{case}[materialize={materialize}] step {t}", "u", u, d[f"u_{t}"], **U_TOL)
         e.set_state(np.concatenate([d[f"u_nom_{t}"].reshape(H * 2), d[f"u_{t}"].reshape(2)]))
     e.close()
 
@@ -359,11 +361,11 @@ def test_quad2d_rpgd_matches_reference_golden(case):
         assert (e.samples_needed() > 0) == (key in d.files)
         u = e.step(d[f"s_{t}"], d[key] if key in d.files else None, u_prev=d[f"u_prev_{t}"])
         count += 1
-        np.testing.assert_allclose(e.read("U_NOM"), d[f"u_nom_{t}"], **tol)
-        np.testing.assert_allclose(u, d[f"u_{t}"], **tol)
-        np.testing.assert_allclose(e.read("PLAN"), d[f"Q_{t}"], **tol)
-        np.testing.assert_allclose(e.read("ADAM_M"), d[f"m_{t}"], **tol)
-        np.testing.assert_allclose(e.read("ADAM_V"), d[f"v_{t}"], **tol)
+        close(f"rpgd_{case} step {t}", "u_nom", e.read("U_NOM"), d[f"u_nom_{t}"], **tol)
+        close(f"rpgd_{case} step {t}", "u", u, d[f"u_{t}"], **tol)
+        close(f"rpgd_{case} step {t}", "plan", e.read("PLAN"), d[f"Q_{t}"], **tol)
+        close(f"rpgd_{case} step {t}", "adam_m", e.read("ADAM_M"), d[f"m_{t}"], **tol)
+        close(f"rpgd_{case} step {t}", "adam_v", e.read("ADAM_V"), d[f"v_{t}"], **tol)
         np.testing.assert_array_equal(e.read("AGES"), d[f"ages_{t}"])
         e.set_state(np.concatenate([d[f"Q_{t}"].ravel(), d[f"m_{t}"].ravel(), d[f"v_{t}"].ravel(), d[f"ages_{t}"].ravel(), d[f"u_{t}"].ravel(),
                                     [int(d[f"adam_step_{t}"])], [count]]).astype(np.float32))

@@ -16,6 +16,8 @@ from test_gpu_mppi import U_TOL
 from test_gpu_rpgd import assert_close_mostly
 from test_gpu_env import apply_params, two_shards_equal_one_handle
 
+from margins import close
+
 pytestmark = pytest.mark.gpu
 
 HLO, HHI = np.array([-1.0, -0.7, -0.5], np.float32), np.array([0.9, 1.0, 0.5], np.float32)
@@ -86,11 +88,11 @@ def test_hover_mppi_matches_reference_golden(case, materialize):
     for t in range(int(d["steps"])):
         u = e.step(d[f"s_{t}"], d[f"noise_{t}"], u_prev=d[f"u_prev_{t}"])
         if materialize:
-            np.testing.assert_allclose(e.read("Q"), d[f"u_run_{t}"], rtol=1e-6, atol=1e-6)
-            np.testing.assert_allclose(e.read("TRAJ"), d[f"traj_{t}"], rtol=1e-4, atol=3e-5)
-        np.testing.assert_allclose(e.read("J"), d[f"J_{t}"], rtol=5e-5 if mlp else 3e-5, atol=1e-3 if mlp else 0)
-        np.testing.assert_allclose(e.read("U_NOM"), d[f"u_nom_{t}"], **U_TOL)
-        np.testing.assert_allclose(u, d[f"u_{t}"], **U_TOL)
+            close(f"mppi_{case}[materialize={materialize}] step {t}", "q", e.read("Q"), d[f"u_run_{t}"], rtol=1e-6, atol=1e-6)
+            close(f"mppi_{case}[materialize={materialize}] step {t}", "traj", e.read("TRAJ"), d[f"traj_{t}"], rtol=1e-4, atol=3e-5)
+        close(f"mppi_{case}[materialize={materialize}] step {t}", "j", e.read("J"), d[f"J_{t}"], rtol=5e-5 if mlp else 3e-5, atol=1e-3 if mlp else 0)
+        close(f"mppi_{case}[materialize={materialize}] step {t}", "u_nom", e.read("U_NOM"), d[f"u_nom_{t}"], **U_TOL)
+        close(f"mppi_{case}[materialize={materialize}] step {t}", "u", u, d[f"u_{t}"], **U_TOL)
         e.set_state(np.concatenate([d[f"u_nom_{t}"].reshape(H * 3), d[f"u_{t}"].reshape(3)]))
     e.close()
 
@@ -115,8 +117,8 @@ def test_hover_rpgd_matches_reference_golden(case):
         u = e.step(d[f"s_{t}"], d[key] if key in d.files else None, u_prev=d[f"u_prev_{t}"])
         count += 1
         n_out = max(4, d[f"Q_{t}"].size // 400)
-        np.testing.assert_allclose(e.read("U_NOM"), d[f"u_nom_{t}"], **tol)
-        np.testing.assert_allclose(u, d[f"u_{t}"], **tol)
+        close(f"rpgd_{case} step {t}", "u_nom", e.read("U_NOM"), d[f"u_nom_{t}"], **tol)
+        close(f"rpgd_{case} step {t}", "u", u, d[f"u_{t}"], **tol)
         assert_close_mostly(e.read("PLAN"), d[f"Q_{t}"], max_outliers=n_out, **tol)
         assert_close_mostly(e.read("ADAM_M"), d[f"m_{t}"], max_outliers=n_out, **tol)
         assert_close_mostly(e.read("ADAM_V"), d[f"v_{t}"], max_outliers=n_out, **tol)

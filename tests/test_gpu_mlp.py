@@ -9,6 +9,8 @@ from helpers import load
 from gpu_helpers import mppi_engine_from, apply_env
 from test_gpu_mppi import U_TOL
 
+from margins import close
+
 pytestmark = pytest.mark.gpu
 
 
@@ -41,11 +43,11 @@ def test_mppi_mlp_matches_reference_golden(materialize):
     for t in range(int(d["steps"])):
         u = e.step(d[f"s_{t}"], d[f"noise_{t}"], u_prev=[d[f"u_prev_{t}"]])
         if materialize:
-            np.testing.assert_allclose(e.read("Q"), d[f"u_run_{t}"], rtol=1e-6, atol=1e-6)
-            np.testing.assert_allclose(e.read("TRAJ"), d[f"traj_{t}"], rtol=1e-4, atol=2e-5)
-        np.testing.assert_allclose(e.read("J"), d[f"J_{t}"], rtol=5e-5, atol=1e-3)
-        np.testing.assert_allclose(e.read("U_NOM"), d[f"u_nom_{t}"], **U_TOL)
-        np.testing.assert_allclose(u, d[f"u_{t}"], **U_TOL)
+            close(f"mppi_mlp[materialize={materialize}] step {t}", "q", e.read("Q"), d[f"u_run_{t}"], rtol=1e-6, atol=1e-6)
+            close(f"mppi_mlp[materialize={materialize}] step {t}", "traj", e.read("TRAJ"), d[f"traj_{t}"], rtol=1e-4, atol=2e-5)
+        close(f"mppi_mlp[materialize={materialize}] step {t}", "j", e.read("J"), d[f"J_{t}"], rtol=5e-5, atol=1e-3)
+        close(f"mppi_mlp[materialize={materialize}] step {t}", "u_nom", e.read("U_NOM"), d[f"u_nom_{t}"], **U_TOL)
+        close(f"mppi_mlp[materialize={materialize}] step {t}", "u", u, d[f"u_{t}"], **U_TOL)
         e.set_state(np.concatenate([d[f"u_nom_{t}"].reshape(H), d[f"u_{t}"].reshape(1)]))
     e.close()
 

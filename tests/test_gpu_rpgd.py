@@ -7,6 +7,8 @@ from oracle import ctk_oracle as O
 from helpers import load, rpgd_oracle_from, RPGD_CASES
 from gpu_helpers import rpgd_engine_from
 
+from margins import close
+
 pytestmark = pytest.mark.gpu
 
 
@@ -53,11 +55,11 @@ def test_rpgd_matches_reference_golden(case):
         assert (need > 0) == (key in d.files)
         u = e.step(d[f"s_{t}"], d[key] if key in d.files else None, u_prev=[d[f"u_prev_{t}"]])
         count += 1
-        np.testing.assert_allclose(e.read("U_NOM"), d[f"u_nom_{t}"], **tol)
-        np.testing.assert_allclose(u, d[f"u_{t}"], **tol)
-        np.testing.assert_allclose(e.read("PLAN"), d[f"Q_{t}"], **tol)
-        np.testing.assert_allclose(e.read("ADAM_M"), d[f"m_{t}"], rtol=tol["rtol"], atol=tol["atol"])
-        np.testing.assert_allclose(e.read("ADAM_V"), d[f"v_{t}"], rtol=tol["rtol"], atol=tol["atol"])
+        close(f"rpgd_{case} step {t}", "u_nom", e.read("U_NOM"), d[f"u_nom_{t}"], **tol)
+        close(f"rpgd_{case} step {t}", "u", u, d[f"u_{t}"], **tol)
+        close(f"rpgd_{case} step {t}", "plan", e.read("PLAN"), d[f"Q_{t}"], **tol)
+        close(f"rpgd_{case} step {t}", "adam_m", e.read("ADAM_M"), d[f"m_{t}"], rtol=tol["rtol"], atol=tol["atol"])
+        close(f"rpgd_{case} step {t}", "adam_v", e.read("ADAM_V"), d[f"v_{t}"], rtol=tol["rtol"], atol=tol["atol"])
         np.testing.assert_array_equal(e.read("AGES"), d[f"ages_{t}"])
         # continue from the reference's own state so that every step is pinned in isolation
         e.set_state(state_vec(d[f"Q_{t}"], d[f"m_{t}"], d[f"v_{t}"], d[f"ages_{t}"], d[f"u_{t}"][0],

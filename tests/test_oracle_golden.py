@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 
 from oracle import ctk_oracle as O
+from helpers import (cem_oracle_from, random_oracle_from, cem_naive_grad_oracle_from, cut_is_separated, CEM_CASES, RANDOM_CASES,
+                     CEM_NAIVE_GRAD_CASES)
 from helpers import load, env_from, mppi_oracle_from, rpgd_oracle_from, MPPI_CASES, RPGD_CASES, MPPI_QUAD_CASES, RPGD_QUAD_CASES, MPPI_HOVER_CASES, RPGD_HOVER_CASES
 
 
@@ -150,6 +152,72 @@ def test_rpgd_keepers_are_last_k_sorted():
     np.testing.assert_array_equal(o.Q[-k:], shifted[best])
     assert np.all(np.diff(o.J[best]) >= 0)
     assert np.all(o.trajectory_ages[:-k] == 1.0)
+
+
+@pytest.mark.parametrize("case", CEM_CASES)
+def test_cem_matches_reference(case):
+    """optimizer_cem_tf.py:54-117 as the unmodified module computed it (tests/golden/make_golden.py: record_tf_only_optimizers)"""
+    d = load(f"cem_{case}.npz")
+    o = cem_oracle_from(d)
+    np.testing.assert_array_equal(o.dist_mue, d["dist_mue_init"])
+    np.testing.assert_array_equal(o.stdev, d["stdev_init"])
+    K = int(d["cem_best_k"])
+    for t in range(int(d["steps"])):
+        np.testing.assert_array_equal(np.broadcast_to(np.asarray(o.u, np.float32).reshape(-1), d[f"u_prev_{t}"].shape), d[f"u_prev_{t}"])
+        noise = d[f"noise_{t}"]
+        assert noise.shape[0] == o.iterations()           # warm-up switch (:92): the reference drew this many populations
+        u = o.step(d[f"s_{t}"], noise)
+        # Q of the LAST iteration = mu + noise * std of the iteration before: it matching to 2e-6 says every earlier refit matched
+        np.testing.assert_allclose(o.Q, d[f"Q_{t}"], rtol=1e-6, atol=2e-6)
+        np.testing.assert_allclose(o.J, d[f"J_{t}"], rtol=2e-6)
+        if f"traj_{t}" in d.files:
+            np.testing.assert_allclose(o.rollout_trajectories, d[f"traj_{t}"], rtol=1e-4, atol=1e-5)
+        ref_best = np.argsort(d[f"J_{t}"], kind="stable")[:K]
+        assert set(o.best_idx.tolist()) == set(ref_best.tolist()) and o.best_idx[0] == ref_best[0]
+        np.testing.assert_allclose(o.dist_mue, d[f"dist_mue_{t}"], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(o.stdev, d[f"stdev_{t}"], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(np.asarray(u).reshape(-1), d[f"u_{t}"], rtol=1e-6, atol=1e-6)
+        # the recorded closed loop continues from the reference's own distribution
+        o.dist_mue, o.stdev = d[f"dist_mue_{t}"].copy(), d[f"stdev_{t}"].copy()
+        o.u = O._u_out(d[f"u_{t}"])
+    assert o.count == int(d["steps"])
+
+
+@pytest.mark.parametrize("case", RANDOM_CASES)
+def test_random_action_matches_reference(case):
+    """optimizer_random_action_tf.py:38-86 as the unmodified module computed it; `cfg1` is BASELINE configs[0] (N 32, H 10)"""
+    d = load(f"random_{case}.npz")
+    o = random_oracle_from(d)
+    for t in range(int(d["steps"])):
+        np.testing.assert_array_equal(np.broadcast_to(np.asarray(o.u, np.float32).reshape(-1), d[f"u_prev_{t}"].shape), d[f"u_prev_{t}"])
+        u = o.step(d[f"s_{t}"], d[f"u01_{t}"])
+        np.testing.assert_allclose(o.Q, d[f"Q_{t}"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(o.J, d[f"J_{t}"], rtol=2e-5)
+        np.testing.assert_allclose(o.rollout_trajectories, d[f"traj_{t}"], rtol=1e-4, atol=1e-5)
+        assert cut_is_separated(d[f"J_{t}"], 1)
+        assert int(o.best_idx) == int(np.argmin(d[f"J_{t}"]))
+        np.testing.assert_allclose(np.asarray(u).reshape(-1), d[f"u_{t}"], rtol=1e-6, atol=1e-7)
+        o.u = O._u_out(d[f"u_{t}"])
+
+
+@pytest.mark.parametrize("case", CEM_NAIVE_GRAD_CASES)
+def test_cem_naive_grad_matches_reference(case):
+    """optimizer_cem_naive_grad_tf.py:58-119 as the unmodified module computed it (tf.GradientTape -> torch autograd in the stand-in):
+    pins the variant's statement order — gradient at the CLIPPED samples, one clipped-norm SGD step, clip, re-rollout, refit, and
+    `u` = the refitted MEAN's first input (:103)"""
+    d = load(f"cem_naive_grad_{case}.npz")
+    o = cem_naive_grad_oracle_from(d)
+    K = int(d["cem_best_k"])
+    for t in range(int(d["steps"])):
+        u = o.step(d[f"s_{t}"], d[f"noise_{t}"])
+        np.testing.assert_allclose(o.Q, d[f"Q_{t}"], rtol=2e-5, atol=5e-6)
+        np.testing.assert_allclose(o.J, d[f"J_{t}"], rtol=5e-5)
+        if cut_is_separated(d[f"J_{t}"], K):
+            np.testing.assert_allclose(o.dist_mue, d[f"dist_mue_{t}"], rtol=2e-5, atol=5e-6)
+            np.testing.assert_allclose(o.stdev, d[f"stdev_{t}"], rtol=5e-5, atol=5e-6)
+            np.testing.assert_allclose(np.asarray(u).reshape(-1), d[f"u_{t}"], rtol=2e-5, atol=5e-6)
+        o.dist_mue, o.stdev = d[f"dist_mue_{t}"].copy(), d[f"stdev_{t}"].copy()
+        o.u = O._u_out(d[f"u_{t}"])
 
 
 def test_cem_properties():
