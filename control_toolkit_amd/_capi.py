@@ -474,8 +474,11 @@ class CtkEngine:
     # resident MPPI step (include/ctk_hip.h: ctk_resident_*): the first step launches a kernel that stays on the device and serves the
     # following steps from a pinned mailbox; it leaves by itself after idle_us without a request, and at once on resident_stop() or any
     # other call that touches device state
-    def resident_enable(self, on: bool = True, idle_us: float = 200.0):
-        self._check(self._lib.ctk_resident_enable(self._h, 1 if on else 0, float(idle_us)))
+    def resident_enable(self, on: bool = True, idle_us: float = 200.0, read_ahead: bool = False):
+        """read_ahead: the caller's promise that the device sample buffers it hands to step() keep their contents while the resident
+        form is enabled (a static pool): they are then read between steps.  Without it a buffer is read when its request arrives, so
+        refilling one buffer in place between steps is safe."""
+        self._check(self._lib.ctk_resident_enable(self._h, (2 if read_ahead else 1) if on else 0, float(idle_us)))
 
     def resident_stop(self):
         self._check(self._lib.ctk_resident_stop(self._h))

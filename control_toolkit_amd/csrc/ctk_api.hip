@@ -127,6 +127,7 @@ struct ctk_handle {
     std::string res_dominant_saved;       // ctk_dominant_kernel of the launched form while the resident kernel runs
     std::unordered_map<const float*, const float*> res_follow;   // sample buffer -> the buffer that followed it last time
     const float* res_prev_samples = nullptr;
+    bool res_readahead = false;           // ctk_resident_enable(h, 2, ...): the caller's sample buffers are immutable while enabled, so they may be read ahead
 };
 
 namespace {
@@ -546,13 +547,17 @@ int finish_step(ctk_handle* h, float* u_out) {
     ++h->seq;
     ++h->call;
     // error word behind {u, seq}: a bounded device-side wait ran out (1: a peer's record never arrived,
-    // ctk_mppi.hip:p2p_exchange_and_update; 2: a block record of the in-launch hand-off never arrived) — the published
+    // ctk_mppi.hip:p2p_exchange_and_update; 2: a block record of the in-launch hand-off never arrived; 3: an RPGD Jacobian record never
+    // arrived / non-finite gradient, ctk_net_split.hip: rpgd_jac_worker + the update's tile_bad) — the published
     // result is NaN or built from a stale record, never silently wrong
     volatile uint32_t* errw = reinterpret_cast<volatile uint32_t*>(h->h_u) + 2;
     if (const uint32_t dev_err = *errw) {
         *errw = 0;
         return fail(h, CTK_ERR_STATE, dev_err == 1 ? "timed out waiting for a peer's record (a rank is gone or out of step)"
-                                                   : "in-launch record hand-off timed out (a workgroup's record never arrived)");
+                                      : dev_err == 3 ? "RPGD: an in-launch Jacobian hand-off timed out or a plan's gradient was not finite; that iteration's "
+                                                       "update was skipped for the tile (its plans and Adam moments are as before it) — the returned "
+                                                       "control comes from a population that missed an update"
+                                                     : "in-launch record hand-off timed out (a workgroup's record never arrived)");
     }
     return h->log_cap ? log_step(h) : CTK_OK;
 }
@@ -627,7 +632,10 @@ int resident_step(ctk_handle* h, const float* s, const float* u_prev, const floa
     {
         const float* guess = nullptr;
         uint32_t known = d_samples == nullptr ? 1u : 0u;
-        if (d_samples != nullptr) {
+        // Buffers are read ahead ONLY under the caller's promise that their contents do not change while the resident form is enabled
+        // (ctk_resident_enable(h, 2, ...), include/ctk_hip.h).  Without it a caller who refills one buffer in place between steps would be
+        // served the previous contents (a pointer cannot tell): every buffer step then forms its inputs at the request.
+        if (d_samples != nullptr && h->res_readahead) {
             if (h->res_prev_samples != nullptr) h->res_follow[h->res_prev_samples] = d_samples;
             const auto it = h->res_follow.find(d_samples);
             if (it != h->res_follow.end()) { guess = it->second; known = 1u; }
@@ -830,7 +838,8 @@ int launch_descent(ctk_handle* h, const RolloutArgs& a, float lr, float b1, floa
     ProfSlot ps(h);
     if (h->generic && c.predictor != CTK_PRED_ODE)
         HIP_TRY(h, ctk_launch_g_rpgd_descent_net(h->stream, h->env, c.predictor, a, h->params, c.dt, c.intermediate_steps, lr, b1, b2, eps,
-                                                 c.gradmax_clip, Q, m, v, bc, bc_len, t0, iters, h->d_wperm, h->d_scratch, ps.a, ps.b, rule));
+                                                 c.gradmax_clip, Q, m, v, bc, bc_len, t0, iters, h->d_wperm, h->d_scratch, ps.a, ps.b, rule,
+                                                 reinterpret_cast<uint32_t*>(h->h_u_dev) + 2));     // (the error word behind {u, seq})
     else if (h->generic)
         HIP_TRY(h, ctk_launch_g_rpgd_descent(h->stream, h->env, a, h->params, c.dt, c.intermediate_steps, lr, b1, b2, eps, c.gradmax_clip, Q, m, v,
                                              bc, bc_len, t0, iters, h->d_scratch, ps.a, ps.b, rule));
@@ -1145,6 +1154,8 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
             return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: RPGD needs opt_keep_k >= 1 (<= the GLOBAL population), outer_its >= 0, resamp_per >= 1, shift_previous >= 0, sampling_distribution in {0,1}");
         if (cfg->intermediate_steps != 1)
             return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: the RPGD adjoint is built for intermediate_steps == 1");
+        if (cfg->adam_rule != 0 && cfg->adam_rule != 1)
+            return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: adam_rule must be 0 (the reference's torch ADAM, optimizer_rpgd.py:56-82) or 1 (tf.keras.optimizers.Adam)");
     }
     if (cfg->optimizer == CTK_OPT_MPPI && !(cfg->LBD > 0.0f && cfg->NU != 0.0f))
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: MPPI needs LBD > 0 and NU != 0");
@@ -1935,7 +1946,8 @@ int ctk_resident_enable(ctk_handle* h, int on, double idle_us) {
     if (!h) return CTK_ERR_INVALID_ARGUMENT;
     RES_Q(h);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    if (!on) { h->res_enabled = false; return CTK_OK; }
+    if (!on) { h->res_enabled = false; h->res_readahead = false; return CTK_OK; }
+    if (on != 1 && on != 2) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_resident_enable: on must be 0, 1 or 2 (2 = 1 + read-ahead of immutable sample buffers)");
     if (h->cfg.optimizer != CTK_OPT_MPPI || h->cfg.predictor != CTK_PRED_ODE)
         return fail(h, CTK_ERR_UNSUPPORTED, "ctk_resident_enable: MPPI with the analytic predictor only");
     if (h->cfg.materialize_trajectories || ctk_mppi_uses_throughput_kernel(CTK_PRED_ODE, h->N) || !mppi_can_fuse(h) || h->d_ll == nullptr ||
@@ -2001,6 +2013,8 @@ int ctk_resident_enable(ctk_handle* h, int on, double idle_us) {
         h->res_stream_isolated = true;
     }
     h->res_idle_us = idle_us;
+    h->res_readahead = on == 2;
+    h->res_follow.clear(); h->res_prev_samples = nullptr;
     h->res_enabled = true;
     return CTK_OK;
 }

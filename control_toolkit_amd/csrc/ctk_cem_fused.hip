@@ -38,9 +38,9 @@
 #define CSTAMP(i)
 #endif
 
-// 64 rollouts per workgroup: wave 0 runs their recurrence (one per lane).  SIXTEEN waves per workgroup: everything between two
-// recurrences (input preparation, hand-off polls, selection, moments, merge) is spread over 1024 threads — with four waves a SIMD
-// holds ONE wave, every instruction of these phases issues at 4+ cycles and every LDS latency is exposed (measured: selection
+// 64 rollouts per workgroup: wave 0 runs their recurrence (one per lane).  EIGHT waves per workgroup (CF_WAVES; launch_bounds(512)):
+// everything between two recurrences (input preparation, hand-off polls, selection, moments, merge) is spread over 512 threads, two
+// waves per SIMD — with four waves a SIMD holds ONE wave, every instruction of these phases issues at 4+ cycles and every LDS latency is exposed (measured: selection
 // 4.0 us, merge 1.7 us per outer iteration at cfg3).
 constexpr int CF_TRAJ = 64, CF_WAVES = 8, CF_BLOCK = CF_TRAJ * CF_WAVES;
 constexpr int CF_CHUNK = 8;   // keys per thread and chunk of the counting loop

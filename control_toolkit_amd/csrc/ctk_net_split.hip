@@ -694,10 +694,13 @@ __global__ __launch_bounds__(64) void ctk_g_rpgd_jac_split(RolloutArgs a, typena
 // (split over its two waves) and the cost's state gradient.  When the forward pass ends only the last steps' records are outstanding: the
 // separate Jacobian launch and its boundary (~8 us per Adam iteration) are off the iteration's path.
 // Producers never wait for workers, and the launch's LDS size keeps a CU to one workgroup, so workers never sit on a producer's SIMDs.
-// A poll that runs out leaves NaN records: loud, not a hang.
+// A poll that runs out is an ERROR, not a hang and not a silent NaN: the worker raises the error word behind {u, seq} (code 3: finish_step
+// returns CTK_ERR_STATE) and leaves NaN records; the tile's next phase launch sees a non-finite gradient norm and SKIPS its update, so
+// the plans and the Adam moments stay as they were (a NaN through `fminf(fmaxf(q - lr m / (sqrt(v) + eps), lo), hi)` would come out as
+// `lo` with NaN moments left behind for every later step).
 template <int ENV, bool K3>
 CTK_DEV void rpgd_jac_worker(const RolloutArgs& a, const typename Env<ENV>::K& k, const float* __restrict__ wperm, float* __restrict__ scratch,
-                             int tile, int h, uint32_t seq) {
+                             int tile, int h, uint32_t seq, uint32_t* __restrict__ err_word) {
     using E = Env<ENV>;
     constexpr int S = E::S, C = E::C, IO = S + C;
     const int H = a.H;
@@ -717,6 +720,12 @@ CTK_DEV void rpgd_jac_worker(const RolloutArgs& a, const typename Env<ENV>::K& k
     if (h >= CTK_HANDOFF_LAG + 2) ok &= await((h - CTK_HANDOFF_LAG - 2) * 2 + 1, 1);   // far from its step: seldom
     ok &= await(h * 2, 0);
     ok &= await(h * 2 + 1, 0);
+    // acquire (agent scope) between the flags and the data they publish: the producer's data stores are ordered before its flag store
+    // (flag_through: counted wait, then the store), and nothing below may be satisfied from before the flag was seen.  The cost is on this
+    // worker, not on the recurrence.
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (!__all(ok) && err_word != nullptr && threadIdx.x == 0)
+        __hip_atomic_store(err_word, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long* act = reinterpret_cast<const unsigned long long*>(base) + ((size_t)h * (2 * 2 * 64) + lane) * 2;   // [wave m][h1 | h2][64] float4
     f32x4 d1[2], d2[2];
     {
@@ -745,6 +754,10 @@ CTK_DEV void rpgd_jac_worker(const RolloutArgs& a, const typename Env<ENV>::K& k
     const int hh = wave == 0 ? h : H;
     if (wave == 0 || h == H - 1) {
         const bool got = hh < H ? __all(ok) : await(H * 2, 0);
+        if (hh == H) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (!got && err_word != nullptr && lane == 0) __hip_atomic_store(err_word, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         if (g == 0) {
             const uint32_t* xs_u = reinterpret_cast<const uint32_t*>(base + gw_xs_off(H));
             float sx[S], gs[S];
@@ -764,7 +777,8 @@ template <int ENV, bool K3>
 __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, typename Env<ENV>::K k, AdamK ad, float* __restrict__ Q,
                                                             float* __restrict__ mom, float* __restrict__ var, const float* __restrict__ bc_table,
                                                             int bc_len, int ti, const float* __restrict__ wperm, float* __restrict__ scratch,
-                                                            int do_update, int last, uint32_t ovl_seq) {
+                                                            int do_update, int last, uint32_t ovl_seq, uint32_t* __restrict__ err_word,
+                                                            int diag_withhold) {
     using E = Env<ENV>;
     using SP = SplitMlp<K3>;
     constexpr int S = E::S, C = E::C, IO = S + C, BLOCK = 128, NPARTS = BLOCK / G4_TRAJ;
@@ -774,7 +788,7 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
         const int tiles = (a.N + G4_TRAJ - 1) / G4_TRAJ;
         if ((int)blockIdx.x >= tiles) {                                 // (ovl_seq != 0 and not the last launch: the grid is tiles * (1 + H))
             const int idx = (int)blockIdx.x - tiles, h = idx / tiles;
-            rpgd_jac_worker<ENV, K3>(a, k, wperm, scratch, idx - h * tiles, h, ovl_seq);
+            rpgd_jac_worker<ENV, K3>(a, k, wperm, scratch, idx - h * tiles, h, ovl_seq, err_word);
             return;
         }
     }
@@ -948,6 +962,10 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
         float n2 = 0.0f;
         for (int hc = part; hc < HC; hc += NPARTS) { const float x = g_s[hc * G4_LD + pc]; n2 += x * x; }
         n2 = sum_parts(n2);
+        // a plan whose gradient norm is not finite (a Jacobian record that never arrived is NaN; so is a rollout that diverged): the
+        // whole tile keeps its plans and moments, and the step reports CTK_ERR_STATE
+        const int tile_bad = __syncthreads_or(!(n2 <= 3.0e38f));
+        if (tile_bad && t == 0 && err_word != nullptr) __hip_atomic_store(err_word, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const float scl = ad.clip / fmaxf(sqrtf(n2), ad.clip);
         if (wave == 0 && g == 0) red_s[64 + c] = scl;
         __syncthreads();
@@ -959,8 +977,8 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
         };
 #pragma unroll
         for (int j = 0; j < AB; ++j)
-            if (t + j * BLOCK < total) adam_element(t + j * BLOCK, mm0[j], vv0[j]);
-        for (int b = t + AB * BLOCK; b < total; b += AB * BLOCK) {
+            if (!tile_bad && t + j * BLOCK < total) adam_element(t + j * BLOCK, mm0[j], vv0[j]);
+        for (int b = t + AB * BLOCK; !tile_bad && b < total; b += AB * BLOCK) {
             float mm[AB], vv[AB];
 #pragma unroll
             for (int j = 0; j < AB; ++j) {
@@ -997,14 +1015,15 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
                                     : nf.template step<1, S, C>(x0, x1, x2, ex, wave, lane, tape + (size_t)h * (2 * 2 * 64));
             sv0 = o.lo; sv1 = o.hi;
             // step h - LAG is in memory once at most the 2 * LAG activation stores of the steps since are outstanding
-            if (ovl && h >= LAG) flag_through<2 * LAG>(flags + (h - LAG) * 2 + wave, ovl_seq);
+            if (ovl && h >= LAG && h - LAG != diag_withhold) flag_through<2 * LAG>(flags + (h - LAG) * 2 + wave, ovl_seq);
         }
         if (wave == 0) {
             reinterpret_cast<float2*>(xs_s)[H * 64 + lane] = make_float2(sv0, sv1);
             if (ovl) st2_through(xs_g + (H * 64 + lane) * 2, sv0, sv1);
         }
         if (ovl) {
-            for (int hq = max(H - LAG, 0); hq < H; ++hq) flag_through<0>(flags + hq * 2 + wave, ovl_seq);
+            for (int hq = max(H - LAG, 0); hq < H; ++hq)
+                if (hq != diag_withhold) flag_through<0>(flags + hq * 2 + wave, ovl_seq);
             if (wave == 0) flag_through<0>(flags + H * 2, ovl_seq);
         }
         __syncthreads();
@@ -1349,9 +1368,13 @@ const char* ctk_g_rpgd_wide_name(int env) {
 template <int EV>
 static void launch_wide_split(hipStream_t st, const RolloutArgs& a_in, const float* params, float dt, int isteps, const AdamK& ad, float* Q, float* m,
                               float* v, const float* bc_table, int bc_len, int t0, int iters, const float* wperm, float* scratch, hipEvent_t e0,
-                              hipEvent_t e1) {
+                              hipEvent_t e1, uint32_t* err_word) {
     using E = Env<EV>;
     constexpr bool K3 = E::S + E::C > 8;
+    // diagnostic switch, read once per process (tests/test_gpu_rpgd.py: the time-out path): CTK_DIAG_RPGD_WITHHOLD_FLAG=<step> makes the
+    // forward passes of the FIRST overlapped phase launch of the process never raise that step's flags
+    static const int diag_step = getenv("CTK_DIAG_RPGD_WITHHOLD_FLAG") ? atoi(getenv("CTK_DIAG_RPGD_WITHHOLD_FLAG")) : -1;
+    static std::atomic<int> diag_armed{diag_step >= 0 ? 1 : 0};
     RolloutArgs a = a_in;
     a.C = E::C; a.p_magic = g4_magic_of(a.H * E::C);
     const typename E::K k = E::derive(params, dt, isteps);
@@ -1368,20 +1391,21 @@ static void launch_wide_split(hipStream_t st, const RolloutArgs& a_in, const flo
         uint32_t seq = 0;
         if (ovl && !last) { seq = ++launch_seq; if (seq == 0) seq = ++launch_seq; }
         const dim3 grid(ovl && !last ? tiles * (1 + a.H) : tiles);
+        const int withhold = (ovl && !last && diag_armed.exchange(0)) ? diag_step : -1;
         if (s0 || s1)
             hipExtLaunchKernelGGL((ctk_g_rpgd_wide_split<EV, K3>), grid, dim3(128), lds, st, s0, s1, 0, a, k, ad, Q, m, v, bc_table, bc_len, t0 + it, wperm,
-                                  scratch, it > 0 ? 1 : 0, last ? 1 : 0, seq);
+                                  scratch, it > 0 ? 1 : 0, last ? 1 : 0, seq, err_word, withhold);
         else
             hipLaunchKernelGGL((ctk_g_rpgd_wide_split<EV, K3>), grid, dim3(128), lds, st, a, k, ad, Q, m, v, bc_table, bc_len, t0 + it, wperm, scratch,
-                               it > 0 ? 1 : 0, last ? 1 : 0, seq);
+                               it > 0 ? 1 : 0, last ? 1 : 0, seq, err_word, withhold);
         if (!last && !ovl) hipLaunchKernelGGL((ctk_g_rpgd_jac_split<EV, K3>), dim3(tiles * a.H), dim3(64), 0, st, a, k, Q, wperm, scratch);
     }
 }
 
 hipError_t ctk_launch_g_rpgd_wide_split(hipStream_t st, int env, const RolloutArgs& a, const float* params, float dt, int isteps, const AdamK& ad,
                                         float* Q, float* m, float* v, const float* bc_table, int bc_len, int t0, int iters, const float* wperm,
-                                        float* scratch, hipEvent_t e0, hipEvent_t e1) {
-    CTK_FOR_ENV(env, EV, { launch_wide_split<EV>(st, a, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, scratch, e0, e1); });
+                                        float* scratch, hipEvent_t e0, hipEvent_t e1, uint32_t* err_word) {
+    CTK_FOR_ENV(env, EV, { launch_wide_split<EV>(st, a, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, scratch, e0, e1, err_word); });
     return hipGetLastError();
 }
 

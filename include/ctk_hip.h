@@ -183,7 +183,9 @@ typedef struct ctk_config {
     float learning_rate, gradmax_clip, adam_beta_1, adam_beta_2, adam_epsilon;
     int32_t adam_rule;   /* RPGD update rule: 0 = the in-repo torch Adam (optimizer_rpgd.py:56-82); 1 = tf.keras.optimizers.Adam,
                             what the reference's TensorFlow branch wraps (:38-43,:306-320; the YAML entry `rpgd-tf`) — third-party
-                            arithmetic, published rule: lr_t = lr sqrt(1-b2^t)/(1-b1^t), epsilon not bias-corrected            */
+                            arithmetic, published rule: lr_t = lr sqrt(1-b2^t)/(1-b1^t), epsilon not bias-corrected.  Parity of rule 1 is
+                            pinned only against the oracle's restatement of that rule (no reference recording: it needs
+                            TensorFlow itself).  Any other value: CTK_ERR_INVALID_ARGUMENT at ctk_create.                     */
 } ctk_config;
 
 /* -------------------------------------------------------------------------------------------
@@ -250,6 +252,11 @@ int ctk_predictor_set_hidden(ctk_handle* h, const float* src, size_t n); /* src 
  * s: host [S].  u_prev: host [C] previous applied input (cost `previous_input`); NULL = the
  * optimizer's own last output, as the reference passes self.u.  u_out: host [C].
  * Synchronous: returns when u_out is valid.
+ * CTK_ERR_STATE from a step = a bounded device-side wait ran out (ctk_last_error says which): a peer's record (sharded MPPI over
+ * p2p), a workgroup's record of an in-launch hand-off (MPPI / CEM), or — RPGD with a network predictor — a step Jacobian of the
+ * in-launch hand-off / a non-finite gradient.  In the RPGD case the affected 16-plan tile SKIPPED that iteration's update: plans and
+ * Adam moments are finite and as they were before it, u_out comes from a population that missed an update, the handle stays usable
+ * and the next ctk_step is a normal step (ctk_reset / ctk_set_state re-pin it if the caller wants a defined population).
  * ----------------------------------------------------------------------------------------- */
 int ctk_step(ctk_handle* h, const float* s, const float* u_prev,
              const float* samples, int samples_loc, float* u_out);
@@ -395,9 +402,15 @@ int ctk_log_read(ctk_handle* h, int which, size_t first_step, size_t n_steps, fl
  *    another stream that lands on the resident kernel's queue waits until it leaves (<= idle_us each time).  ctk_resident_enable
  *    therefore re-creates the handle's OWN stream at the highest stream priority (served from other queues than default-priority
  *    streams).  A stream handed in with ctk_set_stream is used as it is: give it a priority of its own, or keep idle_us short;
+ *  - sample buffers (samples_loc = CTK_LOC_DEVICE): between two steps the kernel prepares the NEXT step's inputs.  With the in-kernel
+ *    sampler (samples = NULL) that includes the draws.  Caller-owned buffers are read ahead ONLY with on = 2, which is the caller's promise
+ *    that the contents of every buffer it hands over do not change while the resident form is enabled (a static pool, cycled in any order):
+ *    the library predicts the next buffer from the order seen so far and a changed buffer would be served with its OLD contents.  With
+ *    on = 1 (default) a buffer is read when its request arrives — refilling one buffer in place between steps is then as safe as with
+ *    the launched form (tests/test_gpu_resident.py: test_resident_refilled_buffer_is_read_at_the_request), at ~2 us more per step;
  *  - ctk_resident_stats: kernel launches and steps served so far, whether the kernel is believed to be running, where the mailbox is.
  * ----------------------------------------------------------------------------------------- */
-int ctk_resident_enable(ctk_handle* h, int on, double idle_us);
+int ctk_resident_enable(ctk_handle* h, int on /* 0 off | 1 on | 2 on + read-ahead of immutable sample buffers */, double idle_us);
 int ctk_resident_stop(ctk_handle* h);
 int ctk_resident_stats(const ctk_handle* h, uint64_t* launches, uint64_t* steps, int* running, int* mailbox_in_device_memory);
 

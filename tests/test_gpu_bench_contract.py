@@ -41,3 +41,22 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     res = d.get("resident")                                                          # the opt-in resident form: its own field, never `value`
     assert res is not None and "error" not in res, res
     assert res["value"] > 1e8 and res["kernel_launches_total"] >= 1 and res["boundary"] == "controller_mpc.step"
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus_2_as_a_bare_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment (the shape of the driver's 1-GPU command): the script starts one
+    process per rank as a child (torch.distributed.run), relays rank 0's line and the return code.  Rehearsed on the one-GPU box with
+    both ranks on device 0 and gloo instead of RCCL (CTK_BENCH_SINGLE_DEVICE / CTK_BENCH_BACKEND are never set by the driver)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CTK_BENCH_SINGLE_DEVICE="1", CTK_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=550, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["priming"] == 64 and d["scaling"] == "strong"
+    assert "mppi_cfg5" in d["config"]["workload"] and d["config"]["global_rollouts"] == 65536
+    assert d["exchange_us"] is not None and len(d["roofline_per_rank"]) == 2
+    assert abs(d["value"] - 65536 * 100 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6

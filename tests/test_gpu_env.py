@@ -12,7 +12,7 @@ import pytest
 from oracle import ctk_oracle as O
 from control_toolkit_amd import CtkEngine
 from helpers import load
-from test_gpu_mppi import U_TOL
+from test_gpu_mppi import U_TOL, GOLDEN_U_TOL, J_RTOL
 from test_gpu_rpgd import assert_close_mostly
 
 from margins import close
@@ -224,7 +224,7 @@ def test_quad2d_rpgd_matches_oracle(N, H, p, its, dist):
     d0 = draw((N, o.P, 2))
     o.optimizer_reset(d0); e.reset(d0)
     np.testing.assert_allclose(e.read("PLAN"), o.Q, rtol=1e-6, atol=1e-6)
-    tol = dict(rtol=1e-3, atol=3e-3) if its >= 20 else dict(rtol=2e-4, atol=2e-4)
+    tol = dict(rtol=1e-3, atol=3e-3) if its >= 20 else dict(rtol=2e-5, atol=2e-5)   # short descents: observed <= 1.3e-6 (profiles/r04_parity_margins.txt)
     s = S0.copy()
     for t in range(3):
         dr = draw((N - o.k, o.P, 2)) if t % 2 == 0 else None
@@ -334,9 +334,9 @@ def test_quad2d_mppi_matches_reference_golden(case, materialize):
         if materialize:
             close(f"mppi_{case}[materialize={materialize}] step {t}", "q", e.read("Q"), d[f"u_run_{t}"], rtol=1e-6, atol=1e-6)
             close(f"mppi_{case}[materialize={materialize}] step {t}", "traj", e.read("TRAJ"), d[f"traj_{t}"], rtol=1e-4, atol=2e-5)
-        close(f"mppi_{case}[materialize={materialize}] step {t}", "j", e.read("J"), d[f"J_{t}"], rtol=3e-5)
-        close(f"mppi_{case}[materialize={materialize}] step {t}", "u_nom", e.read("U_NOM"), d[f"u_nom_{t}"], **U_TOL)
-        close(f"mppi_{case}[materialize={materialize}] step {t}", "u", u, d[f"u_{t}"], **U_TOL)
+        close(f"mppi_{case}[materialize={materialize}] step {t}", "j", e.read("J"), d[f"J_{t}"], rtol=J_RTOL)
+        close(f"mppi_{case}[materialize={materialize}] step {t}", "u_nom", e.read("U_NOM"), d[f"u_nom_{t}"], **GOLDEN_U_TOL)
+        close(f"mppi_{case}[materialize={materialize}] step {t}", "u", u, d[f"u_{t}"], **GOLDEN_U_TOL)
         e.set_state(np.concatenate([d[f"u_nom_{t}"].reshape(H * 2), d[f"u_{t}"].reshape(2)]))
     e.close()
 
@@ -354,7 +354,7 @@ def test_quad2d_rpgd_matches_reference_golden(case):
                          gradmax_clip=k["gradmax_clip"], adam_beta_1=k["adam_beta_1"], adam_beta_2=k["adam_beta_2"], adam_epsilon=k["adam_epsilon"])
     e.reset(d["reset_draws"])
     np.testing.assert_allclose(e.read("PLAN"), d["Q_init"], rtol=1e-6, atol=1e-7)
-    tol = dict(rtol=1e-3, atol=3e-3) if k["outer_its"] >= 20 else dict(rtol=2e-4, atol=2e-4)
+    tol = dict(rtol=1e-3, atol=3e-3) if k["outer_its"] >= 20 else dict(rtol=2e-5, atol=2e-5)   # short descents: observed <= 1.3e-6 (profiles/r04_parity_margins.txt)
     count = 0
     for t in range(int(d["steps"])):
         key = f"resample_draws_{t}"

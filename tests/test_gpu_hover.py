@@ -12,7 +12,7 @@ import pytest
 from oracle import ctk_oracle as O
 from control_toolkit_amd import CtkEngine
 from helpers import load, env_from, rpgd_kwargs_from, MPPI_HOVER_CASES, RPGD_HOVER_CASES
-from test_gpu_mppi import U_TOL
+from test_gpu_mppi import U_TOL, GOLDEN_U_TOL, J_RTOL
 from test_gpu_rpgd import assert_close_mostly
 from test_gpu_env import apply_params, two_shards_equal_one_handle
 
@@ -90,9 +90,9 @@ def test_hover_mppi_matches_reference_golden(case, materialize):
         if materialize:
             close(f"mppi_{case}[materialize={materialize}] step {t}", "q", e.read("Q"), d[f"u_run_{t}"], rtol=1e-6, atol=1e-6)
             close(f"mppi_{case}[materialize={materialize}] step {t}", "traj", e.read("TRAJ"), d[f"traj_{t}"], rtol=1e-4, atol=3e-5)
-        close(f"mppi_{case}[materialize={materialize}] step {t}", "j", e.read("J"), d[f"J_{t}"], rtol=5e-5 if mlp else 3e-5, atol=1e-3 if mlp else 0)
-        close(f"mppi_{case}[materialize={materialize}] step {t}", "u_nom", e.read("U_NOM"), d[f"u_nom_{t}"], **U_TOL)
-        close(f"mppi_{case}[materialize={materialize}] step {t}", "u", u, d[f"u_{t}"], **U_TOL)
+        close(f"mppi_{case}[materialize={materialize}] step {t}", "j", e.read("J"), d[f"J_{t}"], rtol=J_RTOL, atol=1e-3 if mlp else 0)
+        close(f"mppi_{case}[materialize={materialize}] step {t}", "u_nom", e.read("U_NOM"), d[f"u_nom_{t}"], **GOLDEN_U_TOL)
+        close(f"mppi_{case}[materialize={materialize}] step {t}", "u", u, d[f"u_{t}"], **GOLDEN_U_TOL)
         e.set_state(np.concatenate([d[f"u_nom_{t}"].reshape(H * 3), d[f"u_{t}"].reshape(3)]))
     e.close()
 
@@ -109,7 +109,7 @@ def test_hover_rpgd_matches_reference_golden(case):
                           gradmax_clip=k["gradmax_clip"], adam_beta_1=k["adam_beta_1"], adam_beta_2=k["adam_beta_2"], adam_epsilon=k["adam_epsilon"])
     e.reset(d["reset_draws"])
     np.testing.assert_allclose(e.read("PLAN"), d["Q_init"], rtol=1e-6, atol=1e-7)
-    tol = dict(rtol=1e-3, atol=3e-3) if k["outer_its"] >= 20 else dict(rtol=2e-4, atol=3e-4)
+    tol = dict(rtol=1e-3, atol=3e-3) if k["outer_its"] >= 20 else dict(rtol=2e-5, atol=2e-5)   # short descents: observed <= 1.3e-6 (profiles/r04_parity_margins.txt)
     count = 0
     for t in range(int(d["steps"])):
         key = f"resample_draws_{t}"

@@ -7,7 +7,7 @@ from oracle import ctk_oracle as O
 from control_toolkit_amd import CtkEngine
 from helpers import load
 from gpu_helpers import mppi_engine_from, apply_env
-from test_gpu_mppi import U_TOL
+from test_gpu_mppi import U_TOL, GOLDEN_U_TOL, J_RTOL
 
 from margins import close
 
@@ -45,9 +45,9 @@ def test_mppi_mlp_matches_reference_golden(materialize):
         if materialize:
             close(f"mppi_mlp[materialize={materialize}] step {t}", "q", e.read("Q"), d[f"u_run_{t}"], rtol=1e-6, atol=1e-6)
             close(f"mppi_mlp[materialize={materialize}] step {t}", "traj", e.read("TRAJ"), d[f"traj_{t}"], rtol=1e-4, atol=2e-5)
-        close(f"mppi_mlp[materialize={materialize}] step {t}", "j", e.read("J"), d[f"J_{t}"], rtol=5e-5, atol=1e-3)
-        close(f"mppi_mlp[materialize={materialize}] step {t}", "u_nom", e.read("U_NOM"), d[f"u_nom_{t}"], **U_TOL)
-        close(f"mppi_mlp[materialize={materialize}] step {t}", "u", u, d[f"u_{t}"], **U_TOL)
+        close(f"mppi_mlp[materialize={materialize}] step {t}", "j", e.read("J"), d[f"J_{t}"], rtol=J_RTOL, atol=1e-3)
+        close(f"mppi_mlp[materialize={materialize}] step {t}", "u_nom", e.read("U_NOM"), d[f"u_nom_{t}"], **GOLDEN_U_TOL)
+        close(f"mppi_mlp[materialize={materialize}] step {t}", "u", u, d[f"u_{t}"], **GOLDEN_U_TOL)
         e.set_state(np.concatenate([d[f"u_nom_{t}"].reshape(H), d[f"u_{t}"].reshape(1)]))
     e.close()
 

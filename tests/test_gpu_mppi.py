@@ -16,7 +16,12 @@ pytestmark = pytest.mark.gpu
 #    J ~ 1e4 (ep_weight 2e4) fp32 rounding gives dJ ~ 1e-2..1e-1, LBD = 100 => 1e-4..1e-3 relative
 #    weight error on perturbations of size stdev = 0.21, averaged over N => a few 1e-6..1e-5 absolute.
 U_TOL = dict(rtol=1e-4, atol=2e-5)
-J_RTOL = 3e-5
+# Against the REFERENCE-RECORDED fixtures the observed errors are written to profiles/r04_parity_margins.txt (tests/margins.py) and the
+# bounds are set from them (round 4): J worst 1.3e-6 relative -> rtol 1e-5 (SURVEY 8c's proposal); u_nom / u worst 4.7e-6 absolute
+# (mppi_tiny_ode: N = 8, a handful of weights decides) and 9.1e-7 at cfg2 -> rtol 1e-5 / atol 1e-5.  SURVEY 8c's atol 1e-6 on u_nom
+# does not hold at N = 8 for the reason in the comment above; U_TOL stays for the oracle-seeded cases whose margins are not recorded.
+J_RTOL = 1e-5
+GOLDEN_U_TOL = dict(rtol=1e-5, atol=1e-5)
 
 ODE_CASES = [c for c in MPPI_CASES if c != "mlp"]
 
@@ -37,8 +42,8 @@ def test_mppi_matches_reference_golden(case, materialize):
         if materialize:
             close(tag, "u_run", e.read("Q"), d[f"u_run_{t}"], rtol=1e-6, atol=1e-6)
         close(tag, "J", e.read("J"), d[f"J_{t}"], rtol=J_RTOL)
-        close(tag, "u_nom", e.read("U_NOM"), d[f"u_nom_{t}"], **U_TOL)
-        close(tag, "u", u, d[f"u_{t}"], **U_TOL)
+        close(tag, "u_nom", e.read("U_NOM"), d[f"u_nom_{t}"], **GOLDEN_U_TOL)
+        close(tag, "u", u, d[f"u_{t}"], **GOLDEN_U_TOL)
         if materialize and f"traj_{t}" in d.files:
             close(tag, "traj", e.read("TRAJ"), d[f"traj_{t}"], rtol=1e-4, atol=2e-5)
         # re-pin to the reference's own warm-start state so every step is checked in isolation

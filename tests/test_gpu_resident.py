@@ -66,6 +66,46 @@ def test_resident_matches_reference_golden_at_the_benchmarked_size():
     e.close()
 
 
+def test_resident_refilled_buffer_is_read_at_the_request():
+    """ONE device buffer refilled IN PLACE between steps (torch's `normal_()`), the way a caller without a pool would feed
+    the sampler.  The default resident mode must read it when the request arrives — bit-identical to the launched form, step after step —
+    and must not have prepared its inputs ahead from the buffer's previous contents (the t_relay flag bit says which path served)."""
+    import torch
+    N, H, p = 1024, 50, 1
+    a, b = _pair(num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p, seed=3)
+    b.resident_enable(True, idle_us=100000.0)                      # default: no read-ahead of caller-owned buffers
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    buf = torch.empty((N * a.inducing_points(),), device="cuda")
+    s = S0.copy()
+    for t in range(10):
+        buf.normal_(generator=g)                                   # same pointer, new contents
+        torch.cuda.synchronize()
+        ua, ub = a.step(s, buf.data_ptr()), b.step(s, buf.data_ptr())
+        np.testing.assert_array_equal(ub, ua)
+        s = s + np.array([0.01, 0.0, -0.02, 0.01], np.float32)
+    assert b.resident_stats()["steps"] == 10 and b.resident_stats()["launches"] == 1
+    np.testing.assert_array_equal(b.read("U_NOM"), a.read("U_NOM"))
+    np.testing.assert_array_equal(b.read("J"), a.read("J"))
+    a.close(); b.close()
+
+
+def test_resident_read_ahead_is_an_opt_in_for_static_pools():
+    """read_ahead=True is the caller's promise that the pool's contents do not change: same results, inputs prepared between steps"""
+    import torch
+    N, H = 1024, 50
+    a, b = _pair(num_rollouts=N, mpc_horizon=H, dt=0.02, seed=3)
+    b.resident_enable(True, idle_us=100000.0, read_ahead=True)
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    pool = [torch.randn((N * a.inducing_points(),), generator=g, device="cuda") for _ in range(4)]
+    s = S0.copy()
+    for t in range(12):
+        np.testing.assert_array_equal(b.step(s, pool[t & 3].data_ptr()), a.step(s, pool[t & 3].data_ptr()))
+        s = s + np.array([0.01, 0.0, -0.02, 0.01], np.float32)
+    with pytest.raises(ValueError):
+        b._check(b._lib.ctk_resident_enable(b._h, 3, 100.0))
+    a.close(); b.close()
+
+
 def test_resident_kernel_leaves_when_idle_and_comes_back():
     import torch
     a, b = _pair(num_rollouts=512, mpc_horizon=20, dt=0.02, period_interpolation_inducing_points=5, seed=5)

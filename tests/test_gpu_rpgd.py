@@ -47,7 +47,7 @@ def test_rpgd_matches_reference_golden(case):
     its = int(d["outer_its"])
     # rtol 1e-3 on Q after 20 Adam iterations (m_hat/(sqrt(v_hat)+eps) amplifies tiny
     # gradient differences when v_hat is small); tighter for short descents
-    tol = dict(rtol=1e-3, atol=3e-3) if its >= 20 else dict(rtol=2e-4, atol=2e-4)
+    tol = dict(rtol=1e-3, atol=3e-3) if its >= 20 else dict(rtol=2e-5, atol=2e-5)   # short descents: observed <= 1.3e-6 (profiles/r04_parity_margins.txt)
     count = 0
     for t in range(int(d["steps"])):
         key = f"resample_draws_{t}"
@@ -203,7 +203,7 @@ def test_rpgd_mlp_matches_oracle(N, H, p, its):
     d0 = rng.random((N, o.P, 1), dtype=np.float32)
     o.optimizer_reset(d0); e.reset(d0)
     s = np.array([0.05, 0.0, 2.9, 0.3], np.float32)
-    tol = dict(rtol=1e-3, atol=3e-3) if its >= 20 else dict(rtol=2e-4, atol=2e-4)
+    tol = dict(rtol=1e-3, atol=3e-3) if its >= 20 else dict(rtol=2e-5, atol=2e-5)   # short descents: observed <= 1.3e-6 (profiles/r04_parity_margins.txt)
     for t in range(2):
         dr = rng.random((N - o.k, o.P, 1), dtype=np.float32) if t % 10 == 0 else None
         start = (o.Q.copy(), None if o.opt.m is None else o.opt.m.copy(), None if o.opt.v is None else o.opt.v.copy(), o.opt.step_count, float(o.u))
@@ -372,3 +372,62 @@ def test_rpgd_keras_adam_rule_matches_oracle(pred_name, N, its):
     o2.step(s, dr); o3.step(s, dr)
     assert np.abs(o2.Q[-o.k:] - o3.Q[-o.k:]).max() > 1e-4
     e.close()
+
+
+HANDOFF_TIMEOUT_SCRIPT = r'''
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from oracle import ctk_oracle as O
+from control_toolkit_amd import CtkEngine, CtkError
+from gpu_helpers import apply_env
+
+N, H, p, its = 64, 20, 5, 3
+env = O.EnvParams(terminal_weight=0.3)
+w = O.mlp_default_weights(0)
+pred = O.Predictor("MLP", dt=0.02, env=env, weights=w)
+o = O.RPGD(pred, O.Cost(env), num_rollouts=N, mpc_horizon=H, outer_its=its, resamp_per=10, period_interpolation_inducing_points=p,
+           SAMPLING_DISTRIBUTION="uniform", shift_previous=1, learning_rate=0.05, opt_keep_k_ratio=0.25, gradmax_clip=5.0)
+e = CtkEngine("rpgd", "MLP", generic_kernels=True, num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p, outer_its=its,
+              resamp_per=10, shift_previous=1, opt_keep_k=o.k, sampling_distribution=0, sample_min=-1.0, sample_max=1.0, learning_rate=0.05, gradmax_clip=5.0)
+apply_env(e, env); e.set_predictor_weights(w)
+assert "ctk_g_rpgd_wide_split" in e.dominant_kernel(), e.dominant_kernel()      # the form with the in-launch Jacobian hand-off
+rng = np.random.default_rng(3)
+d0 = rng.random((N, o.P, 1), dtype=np.float32)
+dr = rng.random((N - o.k, o.P, 1), dtype=np.float32)
+s = np.array([0.05, 0.0, 2.9, 0.3], np.float32)
+e.reset(d0)
+try:
+    e.step(s, dr)                 # CTK_DIAG_RPGD_WITHHOLD_FLAG: the first phase launch never raises step 3's flags
+    print("NO-ERROR")
+    raise SystemExit(3)
+except CtkError as ex:
+    assert "Jacobian hand-off" in str(ex), str(ex)
+# the optimizer state is intact: nothing non-finite reached the plans or the Adam moments
+for name in ("PLAN", "ADAM_M", "ADAM_V"):
+    a = e.read(name)
+    assert np.isfinite(a).all(), name
+assert np.all(np.abs(e.read("PLAN")) <= 1.0)
+# recovery as the header specifies: the handle stays usable; a reset (or set_state) re-pins it, and the next step is the oracle's
+o.optimizer_reset(d0); e.reset(d0)
+uo, ug = o.step(s, dr), e.step(s, dr)
+np.testing.assert_allclose(e.read("PLAN"), o.Q, rtol=2e-4, atol=2e-4)
+np.testing.assert_allclose(e.read("ADAM_M"), o.opt.m, rtol=2e-4, atol=2e-4)
+np.testing.assert_allclose(ug[0], uo, rtol=2e-4, atol=2e-4)
+e.close()
+print("HANDOFF-TIMEOUT-OK")
+'''
+
+
+@pytest.mark.timeout(300)
+def test_rpgd_jacobian_handoff_timeout_is_an_error_and_leaves_the_state_intact():
+    """VERDICT r3 weak 2 / ADVICE r3: a Jacobian worker whose poll runs out used to leave NaN records that Adam's clip turned into `lo`
+    with NaN moments behind a CTK_OK.  Forced here through the diagnostic switch (read once per process, hence the child process): the
+    step must raise CtkError (CTK_ERR_STATE), the plans and moments must stay finite, and after a reset the next step matches the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CTK_DIAG_RPGD_WITHHOLD_FLAG="3")
+    r = subprocess.run([sys.executable, "-c", HANDOFF_TIMEOUT_SCRIPT, root], capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0 and "HANDOFF-TIMEOUT-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

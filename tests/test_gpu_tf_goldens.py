@@ -18,7 +18,7 @@ from margins import record
 
 pytestmark = pytest.mark.gpu
 
-J_RTOL = 3e-5
+J_RTOL = 1e-5          # observed worst 1.3e-6 (profiles/r04_parity_margins.txt); SURVEY 8c proposes 1e-5
 Q_TOL = dict(rtol=1e-5, atol=2e-6)
 TRAJ_TOL = dict(rtol=1e-4, atol=4e-5)
 
@@ -126,18 +126,18 @@ def test_cem_naive_grad_matches_reference_golden(case):
     for t in range(int(d["steps"])):
         u = e.step(d[f"s_{t}"], d[f"noise_{t}"], u_prev=d[f"u_prev_{t}"])
         tag = f"cem_naive_grad_{case} step {t}"
-        # Q moved by lr * clipped gradient (|g| <= gradmax_clip = 10): an fp32 reverse sweep is good to ~1e-5 relative
-        record(tag, "Q", e.read("Q"), d[f"Q_{t}"], rtol=1e-4, atol=2e-4)
-        record(tag, "J", e.read("J"), d[f"J_{t}"], rtol=2e-4, atol=1e-2)
-        np.testing.assert_allclose(e.read("Q"), d[f"Q_{t}"], rtol=1e-4, atol=2e-4)
-        np.testing.assert_allclose(e.read("J"), d[f"J_{t}"], rtol=2e-4, atol=1e-2)
-        swapped = elite_sets_agree(d[f"J_{t}"], e.read("BEST_IDX"), K, 2e-4)
+        # Q moved by lr * clipped gradient (|g| <= gradmax_clip = 10); observed worst 6.6e-6 absolute on Q, 1.6e-6 on the mean
+        record(tag, "Q", e.read("Q"), d[f"Q_{t}"], rtol=2e-5, atol=2e-5)
+        record(tag, "J", e.read("J"), d[f"J_{t}"], rtol=J_RTOL)
+        np.testing.assert_allclose(e.read("Q"), d[f"Q_{t}"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(e.read("J"), d[f"J_{t}"], rtol=J_RTOL)
+        swapped = elite_sets_agree(d[f"J_{t}"], e.read("BEST_IDX"), K, J_RTOL)
         slack = swapped * span / K
-        record(tag, "dist_mue", e.read("U_NOM"), d[f"dist_mue_{t}"], rtol=1e-4, atol=1e-4 + slack)
-        record(tag, "stdev", e.read("STD"), d[f"stdev_{t}"], rtol=1e-3, atol=1e-4 + slack)
-        record(tag, "u", u, d[f"u_{t}"], rtol=1e-4, atol=1e-4 + slack)
-        np.testing.assert_allclose(e.read("U_NOM"), d[f"dist_mue_{t}"], rtol=1e-4, atol=1e-4 + slack)
-        np.testing.assert_allclose(e.read("STD"), d[f"stdev_{t}"], rtol=1e-3, atol=1e-4 + slack)
-        np.testing.assert_allclose(u, d[f"u_{t}"], rtol=1e-4, atol=1e-4 + slack)     # u = the refitted MEAN's first input (:103)
+        record(tag, "dist_mue", e.read("U_NOM"), d[f"dist_mue_{t}"], rtol=1e-5, atol=1e-5 + slack)
+        record(tag, "stdev", e.read("STD"), d[f"stdev_{t}"], rtol=1e-4, atol=1e-5 + slack)
+        record(tag, "u", u, d[f"u_{t}"], rtol=1e-5, atol=1e-5 + slack)
+        np.testing.assert_allclose(e.read("U_NOM"), d[f"dist_mue_{t}"], rtol=1e-5, atol=1e-5 + slack)
+        np.testing.assert_allclose(e.read("STD"), d[f"stdev_{t}"], rtol=1e-4, atol=1e-5 + slack)
+        np.testing.assert_allclose(u, d[f"u_{t}"], rtol=1e-5, atol=1e-5 + slack)     # u = the refitted MEAN's first input (:103)
         e.set_state(np.concatenate([d[f"dist_mue_{t}"].reshape(H * C), d[f"stdev_{t}"].reshape(H * C), d[f"u_{t}"].reshape(C), [t + 1]]).astype(np.float32))
     e.close()
