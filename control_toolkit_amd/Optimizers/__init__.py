@@ -343,7 +343,8 @@ class template_optimizer:
     def _logged(self, name: str):
         """the tensor `name` of the step just completed: a host array, or its handle in the device log"""
         if not self.logging_on_device:
-            return self.engine.read(name)
+            # RPGD logs its ages at optimizer_rpgd.py:432, BEFORE the step's keep-k gather and +1 (:456-458,:514)
+            return self.engine.read("AGES_LOGGED" if name == "AGES" else name)
         N, H = self.num_rollouts, self.mpc_horizon
         shape = {"Q": (N, H, self.num_control_inputs), "J": (N,), "TRAJ": (N, H + 1, self.num_states), "AGES": (N,)}[name]
         return DeviceLogEntry(self.engine, name, self.engine.log_count() - 1, shape)
@@ -356,7 +357,20 @@ class template_optimizer:
         self.logging_values["rollout_trajectories_logged"] = self.rollout_trajectories
         self.logging_values["u_logged"] = u
 
-    def _predict_optimal_trajectory(self, s, u_nom, u_prev):
+    def _predict_optimal_trajectory(self, s, u_nom, u_prev, want_summed_stage_cost: bool = False):
         # reference optimizer_mppi.py:199-202: single-trajectory rollout of the nominal plan
-        traj, _ = self.engine.rollout(s, np.asarray(u_nom, np.float32).reshape(1, self.mpc_horizon, self.num_control_inputs), u_prev=u_prev)
-        return traj
+        plan = np.asarray(u_nom, np.float32).reshape(1, self.mpc_horizon, self.num_control_inputs)
+        traj, _ = self.engine.rollout(s, plan, u_prev=u_prev)
+        if not want_summed_stage_cost:
+            return traj
+        # optimizer_rpgd.py:382-386: cost_function.get_summed_stage_cost(optimal_trajectory, u_nom, u) = the sum of the H stage costs
+        # WITHOUT the terminal cost (Cost_Functions/__init__.py:71-72).  The rollout kernels return J = (sum of stage costs + terminal)
+        # / (H + 1); every built environment's terminal cost is terminal_weight * (state terms), so the same plan rolled out once more
+        # with terminal_weight = 0 gives the sum of the stage costs alone — on the device, through the same kernel
+        tw = self.engine.get_param("terminal_weight")
+        self.engine.set_param("terminal_weight", 0.0)
+        try:
+            _, j0 = self.engine.rollout(s, plan, u_prev=u_prev, want_traj=False)
+        finally:
+            self.engine.set_param("terminal_weight", tw)
+        return traj, (j0 * np.float32(self.mpc_horizon + 1)).astype(np.float32)

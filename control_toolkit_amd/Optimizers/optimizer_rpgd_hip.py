@@ -87,13 +87,16 @@ class optimizer_rpgd_hip(template_optimizer):
         u = self.engine.step(s, draws, u_prev=u_prev)
         self._lazy.clear()                                           # u_nom (:426), optimal_control_sequence (:435): read on demand
         if self.optimizer_logging:                                   # :428-433
+            # get_action's rollout of the descended plans (:340-343,:424): the engine materialises it when logging (ctk_api.hip: rpgd_materialize)
+            self.rollout_trajectories = self._logged("TRAJ")
             self.logging_values["Q_logged"] = self._logged("Q")
             self.logging_values["J_logged"] = self._logged("J")
+            self.logging_values["rollout_trajectories_logged"] = self.rollout_trajectories
             self.logging_values["trajectory_ages_logged"] = self._logged("AGES")
             self.logging_values["u_logged"] = self.u
         self.count += 1
         if self.calculate_optimal_trajectory:                        # :518-521
-            self.optimal_trajectory = self._predict_optimal_trajectory(s, self.u_nom, u_prev)
+            self.optimal_trajectory, self.summed_stage_cost = self._predict_optimal_trajectory(s, self.u_nom, u_prev, want_summed_stage_cost=True)
         self.u = np.asarray(u, np.float32).reshape(-1).copy()        # :523
         return self.u
 

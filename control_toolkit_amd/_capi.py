@@ -23,7 +23,7 @@ MAX_STATES, MAX_INPUTS = 8, 4
 # CartPole's parameter names in id order (enum ctk_param); `environment_params(name)` asks the library for any environment's
 PARAMS = ("g", "m_cart", "m_pole", "L", "u_max", "M_fric", "J_fric", "target_position", "target_equilibrium",
           "dd_weight", "ep_weight", "ekp_weight", "cc_weight", "ccrc_weight", "R", "x_scale", "terminal_weight")
-BUFFERS = {"Q": 0, "J": 1, "TRAJ": 2, "U_NOM": 3, "STD": 4, "ADAM_M": 5, "ADAM_V": 6, "AGES": 7, "BEST_IDX": 8, "PLAN": 9}
+BUFFERS = {"Q": 0, "J": 1, "TRAJ": 2, "U_NOM": 3, "STD": 4, "ADAM_M": 5, "ADAM_V": 6, "AGES": 7, "BEST_IDX": 8, "PLAN": 9, "AGES_LOGGED": 10}
 LOC_NONE, LOC_HOST, LOC_DEVICE = 0, 1, 2
 MLP_NUM_WEIGHTS = 1380
 
@@ -147,7 +147,7 @@ def load_library():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.ctk_abi_version() != 5:
+    if lib.ctk_abi_version() != 6:
         raise CtkError("libctk_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -466,7 +466,7 @@ class CtkEngine:
         self._check(self._lib.ctk_read(self._h, BUFFERS[name], _ptr(buf), cap, C.byref(n)))
         out = buf[: n.value].copy()
         shapes = {"Q": (N, H, Cn), "J": (N,), "TRAJ": (N, H + 1, S), "U_NOM": (1, H, Cn), "STD": (1, H, Cn),
-                  "ADAM_M": (N, H, Cn), "ADAM_V": (N, H, Cn), "AGES": (N,), "PLAN": (N, H, Cn)}
+                  "ADAM_M": (N, H, Cn), "ADAM_V": (N, H, Cn), "AGES": (N,), "PLAN": (N, H, Cn), "AGES_LOGGED": (N,)}
         if name == "BEST_IDX":
             return out.astype(np.int64)
         return out.reshape(shapes[name])

@@ -48,6 +48,7 @@ struct ctk_handle {
     float* d_parts = nullptr;   size_t parts_cap = 0;
     float* d_parts2 = nullptr;
     float* d_parts3 = nullptr;
+    float* d_Jlog = nullptr;     // RPGD with materialised trajectories: cost output of the logging rollout (the step's own J stays in d_J)
     unsigned* d_counter = nullptr;   // ticket counter of the fused in-launch merge
     unsigned long long* d_ll = nullptr;   // {value, seq} record words of the low-latency in-launch hand-off
     unsigned long long* d_cem_ll = nullptr;   // hand-off words of the one-launch CEM step (ctk_cem_fused.hip); nullptr: not fusable
@@ -474,6 +475,8 @@ int locate_buffer(ctk_handle* h, int which, const float** src_out, size_t* n_out
             src = h->d_v[h->rcur]; n = N * H; break;
         case CTK_BUF_AGES: if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: AGES is an RPGD buffer");
             src = h->d_ages[h->rcur]; n = N; break;
+        case CTK_BUF_AGES_LOGGED: if (h->cfg.optimizer != CTK_OPT_RPGD) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_read: AGES_LOGGED is an RPGD buffer");
+            src = h->d_ages[h->rcur ^ 1]; n = N; break;    // the buffer the last step read its ages from (the warm start wrote the other one)
         case CTK_BUF_J: src = h->d_J; n = N; break;
         case CTK_BUF_TRAJ:
             if (!h->d_traj) return fail(h, CTK_ERR_STATE, "ctk_read: trajectories not materialised (cfg.materialize_trajectories == 0)");
@@ -507,7 +510,7 @@ size_t log_slot_floats(const ctk_handle* h, int i) {
 
 // append this step's tensors to the rings: one launch, behind the step on the stream (the result is out already)
 int log_step(ctk_handle* h) {
-    static const int which[4] = {CTK_BUF_Q, CTK_BUF_J, CTK_BUF_TRAJ, CTK_BUF_AGES};
+    static const int which[4] = {CTK_BUF_Q, CTK_BUF_J, CTK_BUF_TRAJ, CTK_BUF_AGES_LOGGED};
     const size_t slot = h->log_count % h->log_cap;
     CopyJob jobs[4];
     for (int i = 0; i < 4; ++i) {
@@ -1003,6 +1006,17 @@ int rpgd_descent(ctk_handle* h, const float* s, const float* u_prev, const RpgdF
     return CTK_OK;
 }
 
+// optimizer_rpgd.py:340-343,:424,:431: get_action's rollout of the DESCENDED plans is what the reference logs as
+// `rollout_trajectories`.  The descent kernels keep their states in LDS / tape scratch; with cfg.materialize_trajectories the same plans
+// go through the plain rollout kernel once more (limits as given: u = clip(0 + plan * 1) is the plan), its costs into a scratch vector
+// so that the keep-k selection still sees the descent's own J.  Logging mode only: one more launch per step.
+int rpgd_materialize(ctk_handle* h, const float* s, const float* u_prev, const float* d_plans) {
+    if (!h->cfg.materialize_trajectories || !h->d_traj || !h->d_Jlog) return CTK_OK;
+    RolloutArgs a = make_args(h, s, u_prev, h->N, h->H);
+    a.J = h->d_Jlog;                                       // (Q_out stays d_Q: the tuned kernels store u_run whenever they log; unused by RPGD)
+    return launch_affine(h, a, d_plans, 0, h->d_base, h->d_scale, true);
+}
+
 int rpgd_reset(ctk_handle* h, const float* draws, int loc) {
     const float* d_draws = nullptr;
     if (int rc = resolve_samples(h, draws, loc, (size_t)h->N * h->PC, &d_draws)) return rc;
@@ -1024,7 +1038,8 @@ RpgdFusedWarm rpgd_fused(ctk_handle* h, int K, int n_new, int gather, const floa
 }
 bool rpgd_can_fuse(const ctk_handle* h) {
     static const bool off = std::getenv("CTK_NO_RPGD_FUSED") != nullptr;   // A/B switch
-    return !off && !h->generic && h->N <= ctk_rpgd_fused_max_n(h->cfg.predictor, h->N);
+    // (materialised trajectories: the logging rollout goes between the descent and the warm start, which the single launch has no seam for)
+    return !off && !h->generic && !h->cfg.materialize_trajectories && h->N <= ctk_rpgd_fused_max_n(h->cfg.predictor, h->N);
 }
 
 int rpgd_step(ctk_handle* h, const float* s, const float* u_prev, const float* samples, int loc, float* u_out) {
@@ -1043,6 +1058,7 @@ int rpgd_step(ctk_handle* h, const float* s, const float* u_prev, const float* s
             if (int rc = rpgd_descent(h, s, u_prev, &fw)) return rc;
         } else {
             if (int rc = rpgd_descent(h, s, u_prev)) return rc;
+            if (int rc = rpgd_materialize(h, s, u_prev, h->d_pop[cur])) return rc;
             HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, 1, h->d_idx));
             RolloutArgs ag = make_args(h, s, u_prev, h->N, h->P);
             if (int rc = rpgd_warm(h, ag, 0, 0, 0, d_tail, cur, nxt, nullptr, nullptr, 0, 1)) return rc;
@@ -1060,6 +1076,7 @@ int rpgd_step(ctk_handle* h, const float* s, const float* u_prev, const float* s
         if (int rc = rpgd_descent(h, s, u_prev, &fw)) return rc;
     } else {
         if (int rc = rpgd_descent(h, s, u_prev)) return rc;
+        if (int rc = rpgd_materialize(h, s, u_prev, h->d_pop[cur])) return rc;
         HIP_TRY(h, ctk_launch_select_topk(h->stream, h->d_J, h->N, c.opt_keep_k, h->d_idx));   // :345-346
         RolloutArgs aw = make_args(h, s, u_prev, h->N, h->P);
         if (int rc = rpgd_warm(h, aw, resample ? h->N - c.opt_keep_k : 0, resample ? 1 : 0, 0, d_draws, cur, nxt)) return rc;
@@ -1252,6 +1269,14 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
             bc[2 * (tt - 1)] = (float)(1.0 - std::pow((double)cfg->adam_beta_1, (double)tt));
             bc[2 * (tt - 1) + 1] = (float)(1.0 - std::pow((double)cfg->adam_beta_2, (double)tt));
         }
+        if (cfg->materialize_trajectories) {   // the logging rollout of the descended plans (rpgd_materialize): u = 0 + plan * 1
+            TRY_CREATE(dev_alloc(h, &h->d_Jlog, N));
+            std::vector<float> zo(2 * HC, 0.0f);
+            for (size_t i = 0; i < HC; ++i) zo[HC + i] = 1.0f;
+            HIP_CREATE(hipMemcpyAsync(h->d_base, zo.data(), HC * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            HIP_CREATE(hipMemcpyAsync(h->d_scale, zo.data() + HC, HC * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            HIP_CREATE(hipStreamSynchronize(h->stream));
+        }
         TRY_CREATE(dev_alloc(h, &h->d_bc, bc.size()));
         HIP_CREATE(hipMemcpyAsync(h->d_bc, bc.data(), bc.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
         HIP_CREATE(hipStreamSynchronize(h->stream));
@@ -1291,7 +1316,7 @@ void ctk_destroy(ctk_handle* h) {
     for (auto& e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     void* bufs[] = {h->d_interp, h->d_samples, h->d_J, h->d_Q, h->d_traj, h->d_parts, h->d_parts2, h->d_parts3, h->d_unom[0], h->d_unom[1],
                     h->d_std, h->d_base, h->d_scale, h->d_idx, h->d_u, h->d_weights, h->d_wperm, h->d_counter, h->d_ll, h->d_cem_ll, h->d_rec,
-                    h->d_pop[0], h->d_pop[1], h->d_m[0], h->d_m[1], h->d_v[0], h->d_v[1], h->d_ages[0], h->d_ages[1], h->d_bc, h->d_scratch};
+                    h->d_pop[0], h->d_pop[1], h->d_m[0], h->d_m[1], h->d_v[0], h->d_v[1], h->d_ages[0], h->d_ages[1], h->d_bc, h->d_scratch, h->d_Jlog};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->d_shard_idx) hipFree(h->d_shard_idx);
     for (float* p : h->d_log) if (p) hipFree(p);
@@ -2071,7 +2096,7 @@ int ctk_log_read(ctk_handle* h, int which, size_t first_step, size_t n_steps, fl
     RES_Q(h);
     if (!h || !dst) return h ? fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_log_read: NULL destination") : CTK_ERR_INVALID_ARGUMENT;
     if (h->log_cap == 0) return fail(h, CTK_ERR_STATE, "ctk_log_read: logging is not enabled (ctk_log_enable)");
-    const int ring = which == CTK_BUF_Q ? 0 : which == CTK_BUF_J ? 1 : which == CTK_BUF_TRAJ ? 2 : which == CTK_BUF_AGES ? 3 : -1;
+    const int ring = which == CTK_BUF_Q ? 0 : which == CTK_BUF_J ? 1 : which == CTK_BUF_TRAJ ? 2 : (which == CTK_BUF_AGES || which == CTK_BUF_AGES_LOGGED) ? 3 : -1;
     if (ring < 0 || !h->d_log[ring]) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_log_read: this tensor is not logged for this handle");
     if (first_step + n_steps > h->log_count) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_log_read: steps not logged yet");
     if (h->log_count > h->log_cap && first_step < h->log_count - h->log_cap)

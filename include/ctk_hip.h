@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CTK_ABI_VERSION 5
+#define CTK_ABI_VERSION 6   /* v6: CTK_BUF_AGES_LOGGED; ctk_resident_enable on = 2 (read-ahead opt-in); the log's AGES ring holds the ages as logged */
 #define CTK_MAX_STATES 8   /* S <= 8 */
 #define CTK_MAX_INPUTS 4   /* C <= 4 */
 
@@ -136,6 +136,8 @@ typedef enum ctk_buffer {
     CTK_BUF_AGES = 7,   /* [N]       RPGD trajectory ages                                       */
     CTK_BUF_BEST_IDX = 8,/* [K] as fp32: indices of the best K rollouts, ascending cost         */
     CTK_BUF_PLAN = 9,   /* [N,H,C]   RPGD population after warm start (next step's Q_tf)        */
+    CTK_BUF_AGES_LOGGED = 10, /* [N] RPGD trajectory ages as the last step's get_action saw them, BEFORE its keep-k gather and
+                                 +1 (what optimizer_rpgd.py:432 logs; the device log's AGES ring holds these)   */
     CTK_BUF_COUNT
 } ctk_buffer;
 
@@ -372,7 +374,7 @@ int ctk_p2p_close(ctk_handle* h);
  * (optimizer_mppi.py:214-218, optimizer_cem_tf.py:104-108, optimizer_rpgd.py:428-433) + the per-step copies of
  * template_controller.update_logs (Controllers/__init__.py:170-178): after every completed step ONE copy
  * kernel appends Q [N,H,C], J [N], the rollout trajectories [N,H+1,S] (if materialised) and, for RPGD, the
- * trajectory ages [N] to a ring in HBM (what ctk_read would return for CTK_BUF_Q / J / TRAJ / AGES at that
+ * trajectory ages [N] to a ring in HBM (what ctk_read would return for CTK_BUF_Q / J / TRAJ / AGES_LOGGED at that
  * moment); the host fetches any run of steps in one transfer when it wants them
  * (template_controller.get_outputs, Controllers/__init__.py:159-168).
  * capacity_steps > 0 allocates the ring (capacity * (N*H + 2N + N*(H+1)*S) floats) and starts logging;
@@ -380,7 +382,7 @@ int ctk_p2p_close(ctk_handle* h);
  * ----------------------------------------------------------------------------------------- */
 int ctk_log_enable(ctk_handle* h, size_t capacity_steps);
 size_t ctk_log_count(const ctk_handle* h); /* steps logged since ctk_log_enable */
-/* which: CTK_BUF_Q | CTK_BUF_J | CTK_BUF_TRAJ | CTK_BUF_AGES; steps [first_step, first_step + n_steps)   */
+/* which: CTK_BUF_Q | CTK_BUF_J | CTK_BUF_TRAJ | CTK_BUF_AGES (= CTK_BUF_AGES_LOGGED: the ages as logged); steps [first_step, first_step + n_steps)   */
 int ctk_log_read(ctk_handle* h, int which, size_t first_step, size_t n_steps, float* dst, size_t cap, size_t* n_out);
 
 /* -------------------------------------------------------------------------------------------

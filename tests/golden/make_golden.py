@@ -136,6 +136,43 @@ def set_computation_library(name):
         yaml.safe_dump(cfg, f)
 
 
+def set_controller_key(key, value):
+    """one key of the work directory's config_controllers.yml (read by template_controller.__init__ at every construction)"""
+    import yaml
+    path = os.path.join("Control_Toolkit_ASF", "config_controllers.yml")
+    with open(path) as f:
+        cfg = yaml.safe_load(f)
+    cfg["mpc"][key] = value
+    with open(path, "w") as f:
+        yaml.safe_dump(cfg, f)
+
+
+def record_rpgd_logged_outputs(d, build_controller, steps):
+    """Second pass over an RPGD case with `controller_logging` and `calculate_optimal_trajectory` on (same seed => same draws): what
+    optimizer_rpgd.py:428-433 puts into logging_values — the DESCENDED population, its costs and get_action's rollout_trajectories
+    (:424), the ages as logged (before the step's update, :432) — and :518-521's optimal_trajectory / summed_stage_cost."""
+    set_controller_key("calculate_optimal_trajectory", True)
+    try:
+        ctrl = build_controller()
+    finally:
+        set_controller_key("calculate_optimal_trajectory", False)
+    # optimizer_logging only: with controller_logging the reference's update_logs (Controllers/__init__.py:176-178) calls .copy() on
+    # `u_logged`, which RPGD fills with self.u BEFORE updating it (:433 vs :523) — the float 0.0 of Optimizers/__init__.py:34 on step 0
+    opt = ctrl.optimizer
+    opt.optimizer_logging = True
+    assert opt.calculate_optimal_trajectory and not ctrl.controller_logging
+    for t in range(steps):
+        u = ctrl.step(d[f"s_{t}"].copy())
+        assert np.array_equal(np.asarray(u, np.float32).reshape(-1), d[f"u_{t}"])
+        lv = opt.logging_values
+        d[f"Q_logged_{t}"] = np.asarray(lv["Q_logged"]).copy()
+        d[f"J_logged_{t}"] = np.asarray(lv["J_logged"]).copy()
+        d[f"traj_logged_{t}"] = np.asarray(lv["rollout_trajectories_logged"]).copy()
+        d[f"ages_logged_{t}"] = np.asarray(lv["trajectory_ages_logged"]).copy()
+        d[f"optimal_trajectory_{t}"] = np.asarray(opt.optimal_trajectory).copy()
+        d[f"summed_stage_cost_{t}"] = np.asarray(opt.summed_stage_cost, np.float32).reshape(-1).copy()
+
+
 def record_tf_only_optimizers(out_dir, cm, envs, dt):
     """optimizer_cem_tf / optimizer_random_action_tf / optimizer_cem_naive_grad_tf, UNMODIFIED, driven through the reference's own
     controller_mpc with `computation_library: tensorflow`.  Their `import tensorflow as tf` resolves to the torch-backed stand-in
@@ -452,6 +489,7 @@ def main():
             d[f"ages_{t}"] = opt.trajectory_ages.numpy().copy()
             s = plant_step(plant, s, u)
         d["steps"] = np.int32(c["steps"])
+        record_rpgd_logged_outputs(d, lambda: make_controller("rpgd", cfg, c["pred"]), c["steps"])
         np.savez_compressed(os.path.join(out_dir, f"rpgd_{name}.npz"), **d)
 
     # ---- second environment, C = 2: the SAME unmodified reference optimizers on the planar quadrotor ---------------
@@ -537,6 +575,7 @@ def main():
             d[f"ages_{t}"] = opt.trajectory_ages.numpy().copy()
             s = plant_step(plant, s, u)
         d["steps"] = np.int32(c["steps"])
+        record_rpgd_logged_outputs(d, lambda: make_controller("rpgd", cfg, "ODE", "Quad2D", (qlow, qhigh)), c["steps"])
         np.savez_compressed(os.path.join(out_dir, f"rpgd_{name}.npz"), **d)
     # ---- third environment, S + C = 10 (> 8 network inputs), C = 3: the SAME unmodified reference optimizers on the hovercraft ----------
     # ODE and the 10-32-32-7 MLP predictor: pins the C = 3 shapes and, for the MLP, gives the device network a reference-driven fixture
@@ -619,6 +658,7 @@ def main():
             d[f"ages_{t}"] = opt.trajectory_ages.numpy().copy()
             s = plant_step(plant, s, u)
         d["steps"] = np.int32(c["steps"])
+        record_rpgd_logged_outputs(d, lambda: make_controller("rpgd", cfg, c["pred"], "Hover", (hlow, hhigh)), c["steps"])
         np.savez_compressed(os.path.join(out_dir, f"rpgd_{name}.npz"), **d)
     pw.ENVIRONMENT = "CartPole"
 

@@ -79,7 +79,7 @@ def test_resident_refilled_buffer_is_read_at_the_request():
     s = S0.copy()
     for t in range(10):
         buf.normal_(generator=g)                                   # same pointer, new contents
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()                  # (torch's stream only: a device-wide synchronize would wait for the resident kernel's idle time-out)
         ua, ub = a.step(s, buf.data_ptr()), b.step(s, buf.data_ptr())
         np.testing.assert_array_equal(ub, ua)
         s = s + np.array([0.01, 0.0, -0.02, 0.01], np.float32)

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libctk_hip.so does not export {n}"
     assert set(names) == set(SYMBOLS), "ctypes binding and header disagree"
-    assert lib.ctk_abi_version() == 5
+    assert lib.ctk_abi_version() == 6
     assert os.path.dirname(library_path()).endswith("control_toolkit_amd")   # in-tree, not site-packages
 
 

@@ -130,6 +130,15 @@ def test_rpgd_matches_reference(case):
         np.testing.assert_allclose(o.opt.m, d[f"m_{t}"], rtol=tol["rtol"], atol=tol["atol"])
         np.testing.assert_allclose(o.opt.v, d[f"v_{t}"], rtol=tol["rtol"], atol=tol["atol"])
         np.testing.assert_array_equal(o.trajectory_ages, d[f"ages_{t}"])
+        # what the reference logs (optimizer_rpgd.py:428-433): the descended population, get_action's costs and trajectories
+        np.testing.assert_allclose(o.Q_before_warmstart, d[f"Q_logged_{t}"], **tol)
+        np.testing.assert_allclose(o.J, d[f"J_logged_{t}"], rtol=1e-3 if many_its else 2e-5)
+        np.testing.assert_allclose(o.rollout_trajectories, d[f"traj_logged_{t}"], rtol=2e-3 if many_its else 1e-4, atol=1e-2 if many_its else 1e-5)   # (20 Adam iterations: plans to 2e-3, integrated over the horizon)
+        # :382-386: summed stage cost of the best plan = get_summed_stage_cost (no terminal term, Cost_Functions/__init__.py:71-72)
+        tr = o.predictor.predict_core(d[f"s_{t}"].reshape(1, -1), d[f"u_nom_{t}"])
+        np.testing.assert_allclose(tr, d[f"optimal_trajectory_{t}"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(o.cost.get_summed_stage_cost(tr, d[f"u_nom_{t}"], np.asarray(d[f"u_prev_{t}"], np.float32).reshape(-1)),
+                                   d[f"summed_stage_cost_{t}"], rtol=2e-5)
         assert o.opt.step_count == int(d[f"adam_step_{t}"])
         np.testing.assert_allclose(u, d[f"u_{t}"][0], **tol)
         # continue from the reference's own state so steps are pinned one at a time
@@ -310,7 +319,8 @@ def test_rpgd_two_inputs_matches_reference(case):
     o = rpgd_oracle_from(d)
     o.optimizer_reset(d["reset_draws"])
     np.testing.assert_allclose(o.Q, d["Q_init"], rtol=1e-6, atol=1e-7)
-    tol = dict(rtol=1e-3, atol=2e-3) if int(d["outer_its"]) >= 20 else dict(rtol=1e-4, atol=1e-4)
+    many_its = int(d["outer_its"]) >= 20
+    tol = dict(rtol=1e-3, atol=2e-3) if many_its else dict(rtol=1e-4, atol=1e-4)
     for t in range(int(d["steps"])):
         key = f"resample_draws_{t}"
         u = o.step(d[f"s_{t}"], d[key] if key in d.files else None)
@@ -319,6 +329,15 @@ def test_rpgd_two_inputs_matches_reference(case):
         np.testing.assert_allclose(o.opt.m, d[f"m_{t}"], **tol)
         np.testing.assert_allclose(o.opt.v, d[f"v_{t}"], **tol)
         np.testing.assert_array_equal(o.trajectory_ages, d[f"ages_{t}"])
+        # what the reference logs (optimizer_rpgd.py:428-433): the descended population, get_action's costs and trajectories
+        np.testing.assert_allclose(o.Q_before_warmstart, d[f"Q_logged_{t}"], **tol)
+        np.testing.assert_allclose(o.J, d[f"J_logged_{t}"], rtol=1e-3 if many_its else 2e-5)
+        np.testing.assert_allclose(o.rollout_trajectories, d[f"traj_logged_{t}"], rtol=2e-3 if many_its else 1e-4, atol=1e-2 if many_its else 1e-5)   # (20 Adam iterations: plans to 2e-3, integrated over the horizon)
+        # :382-386: summed stage cost of the best plan = get_summed_stage_cost (no terminal term, Cost_Functions/__init__.py:71-72)
+        tr = o.predictor.predict_core(d[f"s_{t}"].reshape(1, -1), d[f"u_nom_{t}"])
+        np.testing.assert_allclose(tr, d[f"optimal_trajectory_{t}"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(o.cost.get_summed_stage_cost(tr, d[f"u_nom_{t}"], np.asarray(d[f"u_prev_{t}"], np.float32).reshape(-1)),
+                                   d[f"summed_stage_cost_{t}"], rtol=2e-5)
         assert o.opt.step_count == int(d[f"adam_step_{t}"])
         np.testing.assert_allclose(u, d[f"u_{t}"], **tol)
         o.Q = d[f"Q_{t}"].copy(); o.opt.m = d[f"m_{t}"].copy(); o.opt.v = d[f"v_{t}"].copy(); o.u = d[f"u_{t}"].copy()
