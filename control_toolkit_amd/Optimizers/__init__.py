@@ -11,15 +11,8 @@ from .._capi import CtkEngine, ENVIRONMENTS, environment_info
 def predictor_kind(predictor_specification) -> str:
     """'ODE' | 'MLP' | 'GRU' from a predictor_specification string (reference controller_mpc.py:67-73; network names follow
     the convention 'GRU-6IN-32H1-32H2-5OUT-0', Control_Toolkit_ASF_Template/config_controllers.yml:8)."""
-    spec = "ODE" if predictor_specification in (None, "") else str(predictor_specification)
-    up = spec.upper()
-    if up.startswith("ODE"):
-        return "ODE"
-    if up.startswith("GRU"):
-        return "GRU"
-    if up.startswith("MLP") or up.startswith("DENSE"):
-        return "MLP"
-    raise NotImplementedError(f"predictor_specification {spec!r}: only 'ODE', 'MLP' / 'Dense' and 'GRU' networks are built")
+    from ..Predictors import parse_predictor_specification
+    return parse_predictor_specification(predictor_specification)[0]
 
 
 def caller_side_library_ok(lib) -> bool:
@@ -197,6 +190,12 @@ class template_optimizer:
         kind = getattr(pred, "kind", None)
         if kind not in ("ODE", "MLP", "GRU"):
             kind = predictor_kind(predictor_specification)
+        # hidden widths: what the build's wrapper parsed, else what the specification's name states (`Dense-5IN-16H1-16H2-4OUT-0`), else 32 / 32
+        from ..Predictors import parse_predictor_specification, check_network_sizes
+        self._hidden_sizes = getattr(pred, "hidden_sizes", None)
+        if self._hidden_sizes is None and kind != "ODE":
+            self._hidden_sizes = check_network_sizes(predictor_specification, parse_predictor_specification(predictor_specification)[1],
+                                                     self.num_states, self.num_control_inputs)
         weights = getattr(pred, "weights", None)
         wf = self._engine_options.get("predictor_weights_file")
         if weights is None and wf:
@@ -221,7 +220,7 @@ class template_optimizer:
         if kind in ("MLP", "GRU"):
             if weights is None:
                 raise ValueError(f"{kind} predictor: no weights (PredictorWrapper(weights=...) or `predictor_weights_file:` in the optimizer's YAML entry)")
-            self.engine.set_predictor_weights(weights)
+            self.engine.set_predictor_weights(weights, hidden=getattr(self, "_hidden_sizes", None))
         if self.logging_on_device:
             self.engine.log_enable(self.logging_capacity)
         self._param_cache = {}

@@ -19,14 +19,53 @@ MLP_NUM_WEIGHTS = 1380   # CartPole: W1[32,5] b1[32] W2[32,32] b2[32] W3[4,32] b
 GRU_NUM_WEIGHTS = 10212  # CartPole: per layer W_i[96,I] W_h[96,32] b_i[96] b_h[96] (I = 5, 32), then W_o[4,32] b_o[4]
 
 
-def network_weight_count(kind: str, num_states: int, num_control_inputs: int) -> int:
-    """flat fp32 weights of the built network shapes: (S+C)-32-32-S tanh MLP; 2x32 GRU + dense 32->S"""
+MAX_HIDDEN = 32   # units per hidden layer the matrix-core predictor kernels hold; narrower layers are embedded exactly (include/ctk_hip.h)
+
+
+def network_weight_count(kind: str, num_states: int, num_control_inputs: int, hidden=(32, 32)) -> int:
+    """flat fp32 weights of a (S+C)-h1-h2-S tanh MLP, or of two GRU layers (h1, h2 units) + dense h2->S"""
     I, S = num_states + num_control_inputs, num_states
+    h1, h2 = int(hidden[0]), int(hidden[1])
     if kind == "MLP":
-        return I * 32 + 32 + 32 * 32 + 32 + 32 * S + S
+        return I * h1 + h1 + h1 * h2 + h2 + h2 * S + S
     if kind == "GRU":
-        return (96 * I + 96 * 32 + 192) + (96 * 32 + 96 * 32 + 192) + (32 * S + S)
+        return (3 * h1 * I + 3 * h1 * h1 + 6 * h1) + (3 * h2 * h1 + 3 * h2 * h2 + 6 * h2) + (h2 * S + S)
     return 0
+
+
+def parse_predictor_specification(predictor_specification):
+    """(kind, sizes) from what `controller_mpc.configure` hands the predictor (reference Controllers/controller_mpc.py:67-73).
+    kind: 'ODE' | 'MLP' | 'GRU'.  sizes: None, or dict(inputs, h1, h2, outputs) when the string follows the reference's network-name
+    convention `<Type>-<I>IN-<h1>H1-<h2>H2-<O>OUT-<n>` (Control_Toolkit_ASF_Template/config_controllers.yml:8:
+    `GRU-6IN-32H1-32H2-5OUT-0`; `Dense-...` for a feed-forward net)."""
+    import re
+    spec = "ODE" if predictor_specification in (None, "") else str(predictor_specification)
+    up = spec.upper()
+    kind = ("ODE" if up.startswith("ODE") else "GRU" if up.startswith("GRU") else "MLP" if up.startswith("MLP") or up.startswith("DENSE") else None)
+    if kind is None:
+        raise NotImplementedError(f"predictor_specification {spec!r}: only 'ODE', 'MLP' / 'Dense' and 'GRU' networks are built")
+    sizes = None
+    m = re.search(r"-(\d+)IN((?:-\d+H\d+)+)-(\d+)OUT", up)
+    if m and kind != "ODE":
+        hidden = [int(x) for x in re.findall(r"-(\d+)H\d+", m.group(2))]
+        if len(hidden) != 2:
+            raise NotImplementedError(f"network {spec!r}: {len(hidden)} hidden layers; the predictor kernels are built for two")
+        sizes = dict(inputs=int(m.group(1)), h1=hidden[0], h2=hidden[1], outputs=int(m.group(3)))
+    return kind, sizes
+
+
+def check_network_sizes(spec, sizes, num_states: int, num_control_inputs: int):
+    """the sizes a network name states against the environment and the kernels; returns (h1, h2)"""
+    if sizes is None:
+        return (32, 32)
+    I, S = num_states + num_control_inputs, num_states
+    if sizes["inputs"] != I or sizes["outputs"] != S:
+        raise ValueError(f"network {spec!r} has {sizes['inputs']} inputs / {sizes['outputs']} outputs; this environment's predictor maps "
+                         f"{I} (states + control inputs) to {S} (next state)")
+    if max(sizes["h1"], sizes["h2"]) > MAX_HIDDEN or min(sizes["h1"], sizes["h2"]) < 1:
+        raise NotImplementedError(f"network {spec!r}: hidden widths {sizes['h1']} / {sizes['h2']}; the predictor kernels hold up to {MAX_HIDDEN} units "
+                                  f"per hidden layer (narrower layers are embedded exactly, wider ones are not built)")
+    return (sizes["h1"], sizes["h2"])
 
 
 def built_environment(name) -> str:
@@ -56,17 +95,16 @@ class PredictorWrapper:
     def configure(self, batch_size, dt=None, computation_library=None, variable_parameters=None,
                   predictor_specification=None, horizon=None, **kwargs):
         spec = "ODE" if predictor_specification in (None, "") else str(predictor_specification)
-        up = spec.upper()
-        kind = ("ODE" if up.startswith("ODE") else "GRU" if up.startswith("GRU")      # 'GRU-6IN-32H1-32H2-5OUT-0' convention
-                else "MLP" if up.startswith("MLP") or up.startswith("DENSE") else None)
-        if kind is None:
-            raise NotImplementedError(f"predictor_specification {spec!r}: only 'ODE', 'MLP' and 'GRU' are built")
+        kind, sizes = parse_predictor_specification(spec)       # 'GRU-6IN-32H1-32H2-5OUT-0' convention: the name carries the sizes
+        self.hidden_sizes = (32, 32)
         if kind in ("MLP", "GRU"):
-            want = network_weight_count(kind, self.num_states, self.num_control_inputs)
+            self.hidden_sizes = check_network_sizes(spec, sizes, self.num_states, self.num_control_inputs)
+            want = network_weight_count(kind, self.num_states, self.num_control_inputs, self.hidden_sizes)
             if self.weights is None:
                 raise ValueError(f"{kind} predictor needs weights (PredictorWrapper(weights=...))")
             if self.weights.size != want:
-                raise ValueError(f"{kind} predictor expects {want} weights, got {self.weights.size}")
+                raise ValueError(f"{kind} predictor {spec!r} expects {want} weights ({self.num_states + self.num_control_inputs}-"
+                                 f"{self.hidden_sizes[0]}-{self.hidden_sizes[1]}-{self.num_states}), got {self.weights.size}")
         self.kind = kind
         self.predictor_specification = spec
         self.batch_size = batch_size

@@ -81,6 +81,8 @@ SYMBOLS = {
     "ctk_environment_name": (C.c_char_p, [C.c_int]),
     "ctk_predictor_weight_count": (C.c_size_t, [_H]),
     "ctk_set_predictor_weights": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
+    "ctk_predictor_weight_count_shaped": (C.c_size_t, [_H, C.c_int, C.c_int]),
+    "ctk_set_predictor_weights_shaped": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
     "ctk_predictor_hidden_size": (C.c_size_t, [_H]),
     "ctk_predictor_update": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "ctk_predictor_get_hidden": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
@@ -277,12 +279,20 @@ class CtkEngine:
         self._check(self._lib.ctk_get_param(self._h, self.param_names.index(name), C.byref(v)))
         return v.value
 
-    def predictor_weight_count(self) -> int:
-        return int(self._lib.ctk_predictor_weight_count(self._h))
+    def predictor_weight_count(self, hidden=None) -> int:
+        if hidden is None:
+            return int(self._lib.ctk_predictor_weight_count(self._h))
+        return int(self._lib.ctk_predictor_weight_count_shaped(self._h, int(hidden[0]), int(hidden[1])))
 
-    def set_predictor_weights(self, w):
+    def set_predictor_weights(self, w, hidden=None):
+        """hidden = (h1, h2): the network's hidden widths (the <h1>H1-<h2>H2 of the reference's network names); None = 32 / 32.
+        Widths up to 32 are embedded exactly, wider ones raise NotImplementedError with the sizes."""
         w = _f32(w).ravel()
-        self._check(self._lib.ctk_set_predictor_weights(self._h, _ptr(w), w.size))
+        if hidden is None or tuple(int(x) for x in hidden) == (32, 32):
+            self._check(self._lib.ctk_set_predictor_weights(self._h, _ptr(w), w.size))
+        else:
+            self._check(self._lib.ctk_set_predictor_weights_shaped(self._h, _ptr(w), w.size, int(hidden[0]), int(hidden[1])))
+        self.hidden_sizes = (32, 32) if hidden is None else (int(hidden[0]), int(hidden[1]))
 
     # recurrent predictor state (GRU): predictor.update(s, Q0), optimizer_mppi.py:195-197
     def predictor_hidden_size(self) -> int:

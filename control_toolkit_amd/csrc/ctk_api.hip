@@ -1235,7 +1235,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     TRY_CREATE(dev_alloc(h, &h->d_parts3, ((nblk + 1023) / 1024) * (2 + PC)));
     TRY_CREATE(dev_alloc(h, &h->d_rec, 2 + PC));
     TRY_CREATE(dev_alloc(h, &h->d_counter, 1));
-    if (nblk <= (size_t)CTK_MPPI_FUSE_MAX_BLOCKS_LL && !std::getenv("CTK_NO_LL"))
+    if (ctk_ll_records_ok((int)nblk, (int)PC) && !std::getenv("CTK_NO_LL"))
         TRY_CREATE(dev_alloc(h, &h->d_ll, nblk * (2 + PC)));
     if (cfg->optimizer == CTK_OPT_CEM && ctk_cem_fusable(cfg->predictor, (int)N, (int)HC) && !std::getenv("CTK_NO_CEM_FUSED"))
         TRY_CREATE(dev_alloc(h, &h->d_cem_ll, ctk_cem_fused_ll_words((int)N, (int)HC)));   // tuned and template path alike
@@ -1424,6 +1424,58 @@ int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->have_weights = true;
     return CTK_OK;
+}
+
+// Networks of other widths (the reference names a network by its sizes, config_controllers.yml:8 `GRU-6IN-32H1-32H2-5OUT-0`): the
+// matrix-core kernels hold 32 units per hidden layer.  A NARROWER layer is embedded exactly — the missing units get zero weights and
+// biases: tanh(0) = 0 (MLP) puts exact zeros into every sum it enters; a GRU unit with zero weights has r = z = 1/2, n = tanh(0) = 0 and
+// h' = (1 - z) n + z h stays at the 0 it starts from.  A WIDER layer is refused with the sizes in the message.
+static size_t shaped_weight_count(int predictor, int S, int C, int h1, int h2) {
+    const size_t I = (size_t)S + C, a = (size_t)h1, b = (size_t)h2;
+    if (predictor == CTK_PRED_MLP) return I * a + a + a * b + b + b * (size_t)S + S;
+    if (predictor == CTK_PRED_GRU) return (3 * a * I + 3 * a * a + 6 * a) + (3 * b * a + 3 * b * b + 6 * b) + (b * (size_t)S + S);
+    return 0;
+}
+size_t ctk_predictor_weight_count_shaped(const ctk_handle* h, int h1, int h2) {
+    return (h && h1 >= 1 && h2 >= 1) ? shaped_weight_count(h->cfg.predictor, h->S, h->C, h1, h2) : 0;
+}
+
+int ctk_set_predictor_weights_shaped(ctk_handle* h, const float* w, size_t n, int h1, int h2) {
+    if (!h || !w) return CTK_ERR_INVALID_ARGUMENT;
+    if (h->cfg.predictor == CTK_PRED_ODE) return fail(h, CTK_ERR_STATE, "ctk_set_predictor_weights_shaped: the ODE predictor has no weights");
+    if (h1 < 1 || h2 < 1) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_set_predictor_weights_shaped: hidden widths must be >= 1");
+    const int S = h->S, I = h->S + h->C;
+    if (h1 > 32 || h2 > 32)
+        return fail(h, CTK_ERR_UNSUPPORTED, std::string("network ") + std::to_string(I) + "IN-" + std::to_string(h1) + "H1-" + std::to_string(h2) + "H2-" +
+                    std::to_string(S) + "OUT: hidden layers wider than 32 units are not built (the matrix-core tiles of the predictor kernels hold 32 "
+                    "units per layer; narrower layers are embedded exactly)");
+    if (n != shaped_weight_count(h->cfg.predictor, h->S, h->C, h1, h2))
+        return fail(h, CTK_ERR_INVALID_ARGUMENT, std::string("ctk_set_predictor_weights_shaped: expected ") +
+                    std::to_string(shaped_weight_count(h->cfg.predictor, h->S, h->C, h1, h2)) + " floats for " + std::to_string(I) + "IN-" +
+                    std::to_string(h1) + "H1-" + std::to_string(h2) + "H2-" + std::to_string(S) + "OUT, got " + std::to_string(n));
+    std::vector<float> full(weight_count(h->cfg.predictor, h->S, h->C), 0.0f);
+    const float* p = w;
+    float* q = full.data();
+    auto rows = [&](int r_src, int c_src, int r_dst, int c_dst) {      // a [r_src, c_src] matrix into the top-left of a [r_dst, c_dst] one
+        for (int r = 0; r < r_src; ++r) std::memcpy(q + (size_t)r * c_dst, p + (size_t)r * c_src, (size_t)c_src * sizeof(float));
+        p += (size_t)r_src * c_src; q += (size_t)r_dst * c_dst;
+    };
+    if (h->cfg.predictor == CTK_PRED_MLP) {
+        rows(h1, I, 32, I); rows(1, h1, 1, 32);        // W1, b1
+        rows(h2, h1, 32, 32); rows(1, h2, 1, 32);      // W2, b2
+        rows(S, h2, S, 32); rows(1, S, 1, S);          // W3, b3
+    } else {
+        auto gates = [&](int hs, int c_src, int c_dst) {               // [3 hs, c_src] (rows r|z|n) -> [96, c_dst]
+            for (int gte = 0; gte < 3; ++gte) {
+                for (int r = 0; r < hs; ++r) std::memcpy(q + ((size_t)gte * 32 + r) * c_dst, p + ((size_t)gte * hs + r) * c_src, (size_t)c_src * sizeof(float));
+            }
+            p += (size_t)3 * hs * c_src; q += (size_t)96 * c_dst;
+        };
+        gates(h1, I, I); gates(h1, h1, 32); gates(h1, 1, 1); gates(h1, 1, 1);          // layer 1: W_i, W_h, b_i, b_h
+        gates(h2, h1, 32); gates(h2, h2, 32); gates(h2, 1, 1); gates(h2, 1, 1);        // layer 2
+        rows(S, h2, S, 32); rows(1, S, 1, S);                                           // W_o, b_o
+    }
+    return ctk_set_predictor_weights(h, full.data(), full.size());
 }
 
 size_t ctk_predictor_hidden_size(const ctk_handle* h) { return (h && h->cfg.predictor == CTK_PRED_GRU) ? (size_t)GRU_HIDDEN_FLOATS : 0; }

@@ -385,7 +385,7 @@ size_t ctk_g_rollout_net_lds(int env, int net, int N, int cols, int H, int C) {
 NetFuse ctk_net_fuse(const MppiFuse* fuse, int mode, const RolloutArgs& a, int C, const float* u_nom, int blocks, int cols) {
     NetFuse gz{};
     if (fuse == nullptr || mode != CTK_G_MODE_MPPI || fuse->mode == 0 || fuse->ll == nullptr) return gz;
-    if (blocks > CTK_MPPI_FUSE_MAX_BLOCKS_LL || !merge_can_stage(cols, blocks)) return gz;
+    if (!ctk_ll_records_ok(blocks, cols) || !merge_can_stage(cols, blocks)) return gz;
     gz.mode = fuse->mode; gz.ll = fuse->ll; gz.out_rec = fuse->out_rec;
     gz.up = MppiUpdateArgs{nullptr, nullptr, nullptr, nullptr, a.H, a.interp, u_nom, fuse->u_nom_out, a.lo[0], a.hi[0], fuse->u_dev, fuse->u_host, fuse->seq};
     gz.up.C = C;
@@ -398,7 +398,7 @@ bool ctk_g_rollout_net_fusable(int env, int net, int N, int P, int H) {
     const int blocks = ctk_g_rollout_net_blocks(env, net, CTK_G_MODE_MPPI, N, P, H);
     // the merge tail is written for 256-thread workgroups: the two-wave MLP form (128 threads) keeps the separate update launch (~1 us)
     if (net != NET_GRU && ctk_g_rollout_split_ok(env, net, N, H, ctk_g_rollout_net_cols(env, CTK_G_MODE_MPPI, P, H))) return false;
-    return blocks <= CTK_MPPI_FUSE_MAX_BLOCKS_LL && merge_can_stage(ctk_g_rollout_net_cols(env, CTK_G_MODE_MPPI, P, H), blocks);
+    return ctk_ll_records_ok(blocks, ctk_g_rollout_net_cols(env, CTK_G_MODE_MPPI, P, H)) && merge_can_stage(ctk_g_rollout_net_cols(env, CTK_G_MODE_MPPI, P, H), blocks);
 }
 
 template <int EV, class NETT>

@@ -39,6 +39,14 @@ constexpr int CTK_PRED_MLP_PAIR = 3;   // kernel-variant id (internal to the lau
 // In-launch merge by the last block to finish (<= CTK_MPPI_FUSE_MAX_BLOCKS blocks).
 constexpr int CTK_MPPI_FUSE_MAX_BLOCKS = 64;     // ticket form: beyond this the last block's serial record fetch costs more than a launch
 constexpr int CTK_MPPI_FUSE_MAX_BLOCKS_LL = 128; // {value, seq} form (records staged in LDS): measured 26.7 vs 29.5 us at 128 blocks, 30.8 vs 29.1 at 256
+// ... of FULL-width records (cfg2: 2 + 50 words).  What the tail block pays for is WORDS polled and staged, not records: a shard of
+// BASELINE configs[4] (N 8 192, period 10: 256 records of 2 + 11 words = 3 328 words, half of cfg2's 128 x 52) hands over in-launch as
+// well (round 4: ctk_mppi_step_begin at that size was rollout + merge<false> + merge<true>, three launches)
+constexpr int CTK_MPPI_FUSE_MAX_BLOCKS_LL_NARROW = 512, CTK_MPPI_FUSE_MAX_WORDS_LL_NARROW = 4096;
+inline bool ctk_ll_records_ok(int blocks, int cols) {
+    return blocks <= CTK_MPPI_FUSE_MAX_BLOCKS_LL ||
+           (blocks <= CTK_MPPI_FUSE_MAX_BLOCKS_LL_NARROW && blocks * (2 + cols) <= CTK_MPPI_FUSE_MAX_WORDS_LL_NARROW);
+}
 // can a rollout launch of `blocks` workgroups merge and update in-launch?  (have_ll: the handle owns the LL word buffer)
 bool ctk_mppi_fusable(int P, int blocks, bool have_ll);
 // From this many rollouts on (ODE predictor) the latency-oriented 4-wave block gives way to the

@@ -697,7 +697,7 @@ static size_t rollout_launch_lds(int P, int H, int pred, int N, int blocks, int*
     size_t lds = ctk_mppi_rollout_lds(P, H, pred, N, C);
     *stage_ok = 0;
     P *= C;
-    if (blocks <= CTK_MPPI_FUSE_MAX_BLOCKS_LL && merge_can_stage(P, blocks)) {
+    if (ctk_ll_records_ok(blocks, P) && merge_can_stage(P, blocks)) {
         const size_t st = merge_lds_staged(P, blocks);
         if (st > lds) lds = st;
         *stage_ok = 1;
@@ -836,10 +836,10 @@ void ctk_p2p_fill_args(void* dst, float* const* bufs, int rank, int world, int P
 }
 bool ctk_mppi_fusable(int P, int blocks, bool have_ll) {
     if (blocks <= CTK_MPPI_FUSE_MAX_BLOCKS) return true;
-    return have_ll && blocks <= CTK_MPPI_FUSE_MAX_BLOCKS_LL && merge_can_stage(P, blocks);
+    return have_ll && ctk_ll_records_ok(blocks, P) && merge_can_stage(P, blocks);
 }
 bool ctk_p2p_can_fuse(int P, int world, int blocks) {
-    return blocks <= CTK_MPPI_FUSE_MAX_BLOCKS_LL && merge_can_stage(P, blocks) && merge_can_stage(P, world);
+    return ctk_ll_records_ok(blocks, P) && merge_can_stage(P, blocks) && merge_can_stage(P, world);
 }
 
 hipError_t ctk_launch_mppi_p2p_exchange(hipStream_t st, float* const* bufs, int rank, int world, int P, uint32_t p2p_seq,

@@ -91,13 +91,32 @@ CTK_DEV void mppi_merge_block(float* scratch, const float* base, int cnt, int P,
             a_acc += rec_at(c0 + i, 1) * sc;
         }
         __syncthreads();
+        if (stage != 0 && cnt > 128 && cnt <= MERGE_CHUNK && 2 * P <= MERGE_BLOCK) {
+            // many narrow records (a shard of configs[4]: 256 records of 11 columns): one thread per column would walk all of them with
+            // 245 threads idle.  Thread (slice, column) sums every slices-th record; the slices meet through LDS in slice order.
+            // (cnt > 128 with staged records did not exist before round 4: no earlier result changes its association)
+            const int slices = MERGE_BLOCK / P, sl = t / P, p = t - sl * P;
+            float* part_s = st_s + (size_t)cnt * rs;           // [slices][P], behind the staged records (merge_lds_staged reserves it)
+            if (sl < slices) {
+                float acc = 0.0f;
+                for (int i = sl; i < cn; i += slices) acc += rec_at(i, 2 + p) * sc_s[i];
+                part_s[sl * P + p] = acc;
+            }
+            __syncthreads();
+            if (t < P) {
+                float acc = 0.0f;
+                for (int q = 0; q < slices; ++q) acc += part_s[q * P + t];
+                b_acc[0] = acc;
+            }
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = t + j * MERGE_BLOCK;
-            if (p < P) {
-                float acc = b_acc[j];
-                for (int i = 0; i < cn; ++i) acc += rec_at(c0 + i, 2 + p) * sc_s[i];
-                b_acc[j] = acc;
+            for (int j = 0; j < 4; ++j) {
+                const int p = t + j * MERGE_BLOCK;
+                if (p < P) {
+                    float acc = b_acc[j];
+                    for (int i = 0; i < cn; ++i) acc += rec_at(c0 + i, 2 + p) * sc_s[i];
+                    b_acc[j] = acc;
+                }
             }
         }
         __syncthreads();
@@ -215,5 +234,5 @@ struct NetFuse {
 
 // LDS of a merge by one workgroup (bytes); with all records staged in LDS (used when it stays <= 64 KiB)
 inline size_t merge_lds(int P, int cnt) { return (size_t)(8 + P + 1 + (cnt < MERGE_CHUNK ? cnt : MERGE_CHUNK)) * sizeof(float); }
-inline size_t merge_lds_staged(int P, int cnt) { return merge_lds(P, cnt) + (size_t)cnt * (2 + P) * sizeof(float); }
+inline size_t merge_lds_staged(int P, int cnt) { return merge_lds(P, cnt) + ((size_t)cnt * (2 + P) + MERGE_BLOCK) * sizeof(float); }   // (+ the column slices' partial sums)
 inline bool merge_can_stage(int P, int cnt) { return merge_lds_staged(P, cnt) <= 64 * 1024; }

@@ -228,6 +228,15 @@ const char* ctk_environment_name(int environment);         /* "CartPole", "Quad2
  * Uploading GRU weights also zeroes the carried hidden state.                                 */
 size_t ctk_predictor_weight_count(const ctk_handle* h);    /* floats ctk_set_predictor_weights expects (0: ODE) */
 int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n);
+/* Networks of other widths.  The reference names a network by its sizes — `Dense-<I>IN-<h1>H1-<h2>H2-<O>OUT-<n>`, `GRU-6IN-32H1-32H2-5OUT-0`
+ * (Control_Toolkit_ASF_Template/config_controllers.yml:8) — and hands the specification to the predictor
+ * (Controllers/controller_mpc.py:67-73).  The matrix-core kernels hold 32 units per hidden layer: hidden widths 1..32 are embedded
+ * EXACTLY (absent units get zero weights and biases: tanh(0) = 0 enters every sum as an exact zero; a GRU unit with zero weights stays
+ * at 0), wider ones are refused with CTK_ERR_UNSUPPORTED and the sizes in ctk_last_error.  Layouts as ctk_set_predictor_weights with
+ * 32 replaced by h1 / h2: MLP W1[h1,I] b1[h1] W2[h2,h1] b2[h2] W3[S,h2] b3[S]; GRU per layer W_i[3h,in] W_h[3h,h] b_i[3h] b_h[3h] (rows
+ * r|z|n; layer 2's input is h1), then W_o[S,h2] b_o[S].  I = num_states + num_control_inputs, outputs = num_states.  (ABI v6)      */
+size_t ctk_predictor_weight_count_shaped(const ctk_handle* h, int h1, int h2);
+int ctk_set_predictor_weights_shaped(ctk_handle* h, const float* w, size_t n, int h1, int h2);
 
 /* Recurrent predictor state (GRU): [2,32] fp32, the state every rollout starts from.
  * ctk_predictor_update = predictor.update(s, Q0) (optimizer_mppi.py:195-197): advance it by the measured

@@ -228,36 +228,39 @@ MLP_IN, MLP_H, MLP_OUT = 5, 32, 4
 MLP_NUM_WEIGHTS = MLP_IN * MLP_H + MLP_H + MLP_H * MLP_H + MLP_H + MLP_H * MLP_OUT + MLP_OUT  # 1380
 
 
-def mlp_num_weights(n_in: int = MLP_IN, n_out: int = MLP_OUT) -> int:
-    return n_in * MLP_H + MLP_H + MLP_H * MLP_H + MLP_H + MLP_H * n_out + n_out
+def mlp_num_weights(n_in: int = MLP_IN, n_out: int = MLP_OUT, hidden=(MLP_H, MLP_H)) -> int:
+    h1, h2 = hidden
+    return n_in * h1 + h1 + h1 * h2 + h2 + h2 * n_out + n_out
 
 
-def mlp_default_weights(seed: int = 0, n_in: int = MLP_IN, n_out: int = MLP_OUT) -> np.ndarray:
-    """(S+C)->32->32->S tanh MLP (cart-pole: 5->32->32->4), weights N(0, 1/fan_in), biases N(0, 0.01) from
-    default_rng(seed).  Flat layout: W1[32,n_in] b1[32] W2[32,32] b2[32] W3[n_out,32] b3[n_out]."""
+def mlp_default_weights(seed: int = 0, n_in: int = MLP_IN, n_out: int = MLP_OUT, hidden=(MLP_H, MLP_H)) -> np.ndarray:
+    """(S+C)->h1->h2->S tanh MLP (cart-pole default: 5->32->32->4; the reference names a network by its sizes,
+    `Dense-<I>IN-<h1>H1-<h2>H2-<O>OUT-<n>`, Control_Toolkit_ASF_Template/config_controllers.yml:8), weights N(0, 1/fan_in), biases
+    N(0, 0.01) from default_rng(seed).  Flat layout: W1[h1,n_in] b1[h1] W2[h2,h1] b2[h2] W3[n_out,h2] b3[n_out]."""
+    h1, h2 = hidden
     rng = np.random.default_rng(seed)
-    W1 = rng.normal(0, 1 / math.sqrt(n_in), (MLP_H, n_in))
-    b1 = rng.normal(0, 0.1, (MLP_H,))
-    W2 = rng.normal(0, 1 / math.sqrt(MLP_H), (MLP_H, MLP_H))
-    b2 = rng.normal(0, 0.1, (MLP_H,))
-    W3 = rng.normal(0, 1 / math.sqrt(MLP_H), (n_out, MLP_H))
+    W1 = rng.normal(0, 1 / math.sqrt(n_in), (h1, n_in))
+    b1 = rng.normal(0, 0.1, (h1,))
+    W2 = rng.normal(0, 1 / math.sqrt(h1), (h2, h1))
+    b2 = rng.normal(0, 0.1, (h2,))
+    W3 = rng.normal(0, 1 / math.sqrt(h2), (n_out, h2))
     b3 = rng.normal(0, 0.1, (n_out,))
     return np.concatenate([a.ravel() for a in (W1, b1, W2, b2, W3, b3)]).astype(np.float32)
 
 
-def mlp_unpack(w: np.ndarray, n_in: int = MLP_IN, n_out: int = MLP_OUT):
+def mlp_unpack(w: np.ndarray, n_in: int = MLP_IN, n_out: int = MLP_OUT, hidden=(MLP_H, MLP_H)):
     w = np.asarray(w, dtype=np.float32)
-    assert w.size == mlp_num_weights(n_in, n_out)
-    MLP_IN, MLP_OUT = n_in, n_out   # noqa: N806 — local shadows for the layout below
+    h1, h2 = hidden
+    assert w.size == mlp_num_weights(n_in, n_out, hidden)
     o = 0
     def take(n, shape):
         nonlocal o
         a = w[o:o + n].reshape(shape)
         o += n
         return a
-    W1 = take(MLP_H * MLP_IN, (MLP_H, MLP_IN)); b1 = take(MLP_H, (MLP_H,))
-    W2 = take(MLP_H * MLP_H, (MLP_H, MLP_H)); b2 = take(MLP_H, (MLP_H,))
-    W3 = take(MLP_OUT * MLP_H, (MLP_OUT, MLP_H)); b3 = take(MLP_OUT, (MLP_OUT,))
+    W1 = take(h1 * n_in, (h1, n_in)); b1 = take(h1, (h1,))
+    W2 = take(h2 * h1, (h2, h1)); b2 = take(h2, (h2,))
+    W3 = take(n_out * h2, (n_out, h2)); b3 = take(n_out, (n_out,))
     return W1, b1, W2, b2, W3, b3
 
 
@@ -351,11 +354,12 @@ class Predictor:
     intermediate_steps: int = 1
     env: EnvParams = field(default_factory=EnvParams)
     weights: Optional[np.ndarray] = None
+    hidden_sizes: tuple = (MLP_H, MLP_H)     # MLP: the two hidden widths (the <h1>H1-<h2>H2 of the network name)
 
     def __post_init__(self):
         self.S, self.C = self.env.S, self.env.C
         if self.kind == "MLP" and self.weights is None:
-            self.weights = mlp_default_weights(0, self.S + self.C, self.S)
+            self.weights = mlp_default_weights(0, self.S + self.C, self.S, self.hidden_sizes)
         if self.kind == "GRU":
             if self.weights is None:
                 self.weights = gru_default_weights(0, self.S + self.C, self.S)
@@ -487,7 +491,7 @@ class Predictor:
         return np.stack([x, v, th, om], axis=1).astype(np.float32)
 
     def _mlp_step(self, s, q):
-        W1, b1, W2, b2, W3, b3 = mlp_unpack(self.weights, self.S + self.C, self.S)
+        W1, b1, W2, b2, W3, b3 = mlp_unpack(self.weights, self.S + self.C, self.S, self.hidden_sizes)
         xin = np.concatenate([s, self._q2(q)], axis=1).astype(np.float32)
         h1 = np.tanh(xin @ W1.T + b1).astype(np.float32)
         h2 = np.tanh(h1 @ W2.T + b2).astype(np.float32)
@@ -539,7 +543,7 @@ class Predictor:
                 g_q.astype(np.float32)[:, None])
 
     def _mlp_vjp(self, s, q, lam):
-        W1, b1, W2, b2, W3, b3 = mlp_unpack(self.weights, self.S + self.C, self.S)
+        W1, b1, W2, b2, W3, b3 = mlp_unpack(self.weights, self.S + self.C, self.S, self.hidden_sizes)
         _, (xin, h1, h2) = self._mlp_step(s, q)
         d2 = (lam @ W3) * (f32(1.0) - h2 * h2)
         d1 = (d2 @ W2) * (f32(1.0) - h1 * h1)

@@ -674,6 +674,43 @@ def main():
     }
     record_tf_only_optimizers(out_dir, cm, envs, dt)
 
+    # ---- a network of another width: the reference names networks by their sizes (config_controllers.yml:8) and hands the name to the
+    #      predictor (controller_mpc.py:67-73); the unmodified optimizer_mppi on a 5-16-16-4 and a 5-24-8-4 tanh MLP (stand-in predictor: it
+    #      takes whatever weight shapes it is given)
+    for name, hidden, seed in (("mlp_h16", (16, 16), 71), ("mlp_h24_8", (24, 8), 72)):
+        w_small = O.mlp_default_weights(9, 5, 4, hidden)
+        inject_constants(env, dt, mlp_w)
+        pw.MLP_WEIGHTS = tuple(torch.tensor(a) for a in O.mlp_unpack(w_small, 5, 4, hidden))
+        pw.ENVIRONMENT = "CartPole"
+        cfg = dict(seed=1, mpc_horizon=25, num_rollouts=96, cc_weight=1.0, R=1.0, LBD=100.0, NU=1000.0, SQRTRHOINV=0.03,
+                   period_interpolation_inducing_points=5, mpc_timestep=dt)
+        spec = f"Dense-5IN-{hidden[0]}H1-{hidden[1]}H2-4OUT-0"
+        ctrl = make_controller("mppi", cfg, spec)
+        ctrl.controller_logging = True
+        ctrl.optimizer.optimizer_logging = True
+        opt = ctrl.optimizer
+        rec = RecordingRng(opt.rng); opt.rng = rec
+        plant = O.Predictor(kind="ODE", dt=dt, env=env)
+        s = initial_state(seed)
+        d = dict(common, low=low, high=high, predictor=np.array("MLP"), predictor_specification=np.array(spec), hidden_sizes=np.array(hidden, np.int32),
+                 **{k: np.float32(v) if isinstance(v, float) else np.array(v) for k, v in cfg.items()})
+        d["mlp_weights"] = w_small
+        d["u_nom_init"] = opt.u_nom.numpy().copy()
+        for t in range(3):
+            u_prev = np.float32(np.asarray(opt.u).reshape(-1)[0])
+            u = ctrl.step(s.copy())
+            lv = opt.logging_values
+            d[f"s_{t}"] = s.copy(); d[f"u_prev_{t}"] = u_prev
+            d[f"noise_{t}"] = rec.raw[-1]
+            d[f"u_{t}"] = np.asarray(u, np.float32).reshape(-1)
+            d[f"u_nom_{t}"] = opt.u_nom.numpy().copy()
+            d[f"J_{t}"] = lv["J_logged"].copy(); d[f"u_run_{t}"] = lv["Q_logged"].copy()
+            d[f"traj_{t}"] = lv["rollout_trajectories_logged"].copy()
+            s = plant_step(plant, s, u)
+        d["steps"] = np.int32(3)
+        np.savez_compressed(os.path.join(out_dir, f"mppi_{name}.npz"), **d)
+    inject_constants(env, dt, mlp_w)
+
     print("golden fixtures written to", out_dir)
     for f in sorted(os.listdir(out_dir)):
         if f.endswith(".npz"):

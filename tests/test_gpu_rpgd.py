@@ -398,7 +398,7 @@ dr = rng.random((N - o.k, o.P, 1), dtype=np.float32)
 s = np.array([0.05, 0.0, 2.9, 0.3], np.float32)
 e.reset(d0)
 try:
-    e.step(s, dr)                 # CTK_DIAG_RPGD_WITHHOLD_FLAG: the first phase launch never raises step 3's flags
+    e.step(s, dr, u_prev=[0.0])   # CTK_DIAG_RPGD_WITHHOLD_FLAG: the first phase launch never raises step 3's flags
     print("NO-ERROR")
     raise SystemExit(3)
 except CtkError as ex:
@@ -410,11 +410,20 @@ for name in ("PLAN", "ADAM_M", "ADAM_V"):
 assert np.all(np.abs(e.read("PLAN")) <= 1.0)
 # recovery as the header specifies: the handle stays usable; a reset (or set_state) re-pins it, and the next step is the oracle's
 o.optimizer_reset(d0); e.reset(d0)
-uo, ug = o.step(s, dr), e.step(s, dr)
-np.testing.assert_allclose(e.read("PLAN"), o.Q, rtol=2e-4, atol=2e-4)
-np.testing.assert_allclose(e.read("ADAM_M"), o.opt.m, rtol=2e-4, atol=2e-4)
+uo, ug = o.step(s, dr), e.step(s, dr, u_prev=[0.0])      # (the failed step's output is still the handle's own "last u": pass the previous input)
 np.testing.assert_allclose(ug[0], uo, rtol=2e-4, atol=2e-4)
-e.close()
+bad = np.abs(e.read("PLAN") - o.Q) > 2e-4 + 2e-4 * np.abs(o.Q)       # (single elements may flip with a ~0 gradient under Adam: see test_rpgd_mlp_matches_oracle)
+assert bad.sum() <= 4, int(bad.sum())
+# ... and bit for bit the step of a handle that never saw the failure (the one-shot switch is spent)
+e2 = CtkEngine("rpgd", "MLP", generic_kernels=True, num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p, outer_its=its,
+               resamp_per=10, shift_previous=1, opt_keep_k=o.k, sampling_distribution=0, sample_min=-1.0, sample_max=1.0, learning_rate=0.05, gradmax_clip=5.0)
+apply_env(e2, env); e2.set_predictor_weights(w)
+e2.reset(d0)
+u2 = e2.step(s, dr, u_prev=[0.0])
+np.testing.assert_array_equal(u2, ug)
+for name in ("PLAN", "ADAM_M", "ADAM_V", "AGES", "J"):
+    np.testing.assert_array_equal(e2.read(name), e.read(name), err_msg=name)
+e.close(); e2.close()
 print("HANDOFF-TIMEOUT-OK")
 '''
 
@@ -430,4 +439,6 @@ def test_rpgd_jacobian_handoff_timeout_is_an_error_and_leaves_the_state_intact()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, CTK_DIAG_RPGD_WITHHOLD_FLAG="3")
     r = subprocess.run([sys.executable, "-c", HANDOFF_TIMEOUT_SCRIPT, root], capture_output=True, text=True, timeout=280, env=env)
-    assert r.returncode == 0 and "HANDOFF-TIMEOUT-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    if r.returncode != 0:
+        print(r.stdout[-4000:]); print(r.stderr[-6000:])
+    assert r.returncode == 0 and "HANDOFF-TIMEOUT-OK" in r.stdout

@@ -224,3 +224,28 @@ def test_environment_tables_agree_between_library_host_mirror_and_oracle():
     assert network_weight_count("MLP", 6, 2) == O.mlp_num_weights(8, 6)
     with pytest.raises(NotImplementedError):
         environment_info("Acrobot")
+
+
+def test_network_name_convention_is_parsed_and_checked():
+    """reference config_controllers.yml:8 `GRU-6IN-32H1-32H2-5OUT-0`; controller_mpc.py:67-73 hands the name to the predictor"""
+    from control_toolkit_amd.Predictors import parse_predictor_specification as parse, check_network_sizes, network_weight_count, PredictorWrapper
+    assert parse(None) == ("ODE", None) and parse("ODE") == ("ODE", None) and parse("MLP") == ("MLP", None)
+    assert parse("GRU-6IN-32H1-32H2-5OUT-0") == ("GRU", dict(inputs=6, h1=32, h2=32, outputs=5))
+    assert parse("Dense-5IN-16H1-24H2-4OUT-3") == ("MLP", dict(inputs=5, h1=16, h2=24, outputs=4))
+    with pytest.raises(NotImplementedError):
+        parse("LSTM-5IN-16H1-16H2-4OUT-0")
+    with pytest.raises(NotImplementedError, match="hidden layers"):
+        parse("Dense-5IN-16H1-16H2-16H3-4OUT-0")
+    assert check_network_sizes("x", None, 4, 1) == (32, 32)
+    assert check_network_sizes("x", parse("Dense-5IN-16H1-24H2-4OUT-3")[1], 4, 1) == (16, 24)
+    with pytest.raises(ValueError, match="6 inputs"):
+        check_network_sizes("GRU-6IN-32H1-32H2-5OUT-0", parse("GRU-6IN-32H1-32H2-5OUT-0")[1], 4, 1)
+    with pytest.raises(NotImplementedError, match="64 / 64"):
+        check_network_sizes("Dense-5IN-64H1-64H2-4OUT-0", parse("Dense-5IN-64H1-64H2-4OUT-0")[1], 4, 1)
+    assert network_weight_count("MLP", 4, 1) == 1380 and network_weight_count("GRU", 4, 1) == 10212
+    assert network_weight_count("MLP", 4, 1, (16, 24)) == 5 * 16 + 16 + 16 * 24 + 24 + 24 * 4 + 4
+    p = PredictorWrapper(weights=np.zeros(network_weight_count("MLP", 4, 1, (16, 24)), np.float32))
+    p.configure(batch_size=8, dt=0.02, predictor_specification="Dense-5IN-16H1-24H2-4OUT-0")
+    assert p.kind == "MLP" and p.hidden_sizes == (16, 24)
+    with pytest.raises(ValueError, match="expects"):
+        p.configure(batch_size=8, dt=0.02, predictor_specification="Dense-5IN-16H1-16H2-4OUT-0")
