@@ -195,7 +195,7 @@ class template_optimizer:
         self._hidden_sizes = getattr(pred, "hidden_sizes", None)
         if self._hidden_sizes is None and kind != "ODE":
             self._hidden_sizes = check_network_sizes(predictor_specification, parse_predictor_specification(predictor_specification)[1],
-                                                     self.num_states, self.num_control_inputs)
+                                                     self.num_states, self.num_control_inputs, kind)
         weights = getattr(pred, "weights", None)
         wf = self._engine_options.get("predictor_weights_file")
         if weights is None and wf:
@@ -216,7 +216,8 @@ class template_optimizer:
             self.engine_name, kind, num_rollouts=self.num_rollouts, mpc_horizon=self.mpc_horizon,
             dt=dt, action_low=lo, action_high=hi, seed=self.seed, device=self.device, intermediate_steps=isteps,
             materialize_trajectories=bool(self.optimizer_logging), environment=env,
-            generic_kernels=bool(self._engine_options.get("generic_kernels", False)), **engine_kwargs)
+            generic_kernels=bool(self._engine_options.get("generic_kernels", False)),
+            predictor_hidden=getattr(self, "_hidden_sizes", None) if kind != "ODE" else None, **engine_kwargs)
         if kind in ("MLP", "GRU"):
             if weights is None:
                 raise ValueError(f"{kind} predictor: no weights (PredictorWrapper(weights=...) or `predictor_weights_file:` in the optimizer's YAML entry)")

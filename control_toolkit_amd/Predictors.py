@@ -19,7 +19,7 @@ MLP_NUM_WEIGHTS = 1380   # CartPole: W1[32,5] b1[32] W2[32,32] b2[32] W3[4,32] b
 GRU_NUM_WEIGHTS = 10212  # CartPole: per layer W_i[96,I] W_h[96,32] b_i[96] b_h[96] (I = 5, 32), then W_o[4,32] b_o[4]
 
 
-MAX_HIDDEN = 32   # units per hidden layer the matrix-core predictor kernels hold; narrower layers are embedded exactly (include/ctk_hip.h)
+MAX_HIDDEN = {"MLP": 64, "GRU": 32}   # widest hidden layer built per network type (include/ctk_hip.h: cfg.predictor_hidden1/2); narrower layers are embedded exactly
 
 
 def network_weight_count(kind: str, num_states: int, num_control_inputs: int, hidden=(32, 32)) -> int:
@@ -54,16 +54,19 @@ def parse_predictor_specification(predictor_specification):
     return kind, sizes
 
 
-def check_network_sizes(spec, sizes, num_states: int, num_control_inputs: int):
+def check_network_sizes(spec, sizes, num_states: int, num_control_inputs: int, kind: str = None):
     """the sizes a network name states against the environment and the kernels; returns (h1, h2)"""
     if sizes is None:
         return (32, 32)
+    if kind is None:
+        kind = parse_predictor_specification(spec)[0]
+    widest = MAX_HIDDEN.get(kind, 32)
     I, S = num_states + num_control_inputs, num_states
     if sizes["inputs"] != I or sizes["outputs"] != S:
         raise ValueError(f"network {spec!r} has {sizes['inputs']} inputs / {sizes['outputs']} outputs; this environment's predictor maps "
                          f"{I} (states + control inputs) to {S} (next state)")
-    if max(sizes["h1"], sizes["h2"]) > MAX_HIDDEN or min(sizes["h1"], sizes["h2"]) < 1:
-        raise NotImplementedError(f"network {spec!r}: hidden widths {sizes['h1']} / {sizes['h2']}; the predictor kernels hold up to {MAX_HIDDEN} units "
+    if max(sizes["h1"], sizes["h2"]) > widest or min(sizes["h1"], sizes["h2"]) < 1:
+        raise NotImplementedError(f"network {spec!r}: hidden widths {sizes['h1']} / {sizes['h2']}; the {kind} predictor kernels hold up to {widest} units "
                                   f"per hidden layer (narrower layers are embedded exactly, wider ones are not built)")
     return (sizes["h1"], sizes["h2"])
 
@@ -98,7 +101,7 @@ class PredictorWrapper:
         kind, sizes = parse_predictor_specification(spec)       # 'GRU-6IN-32H1-32H2-5OUT-0' convention: the name carries the sizes
         self.hidden_sizes = (32, 32)
         if kind in ("MLP", "GRU"):
-            self.hidden_sizes = check_network_sizes(spec, sizes, self.num_states, self.num_control_inputs)
+            self.hidden_sizes = check_network_sizes(spec, sizes, self.num_states, self.num_control_inputs, kind)
             want = network_weight_count(kind, self.num_states, self.num_control_inputs, self.hidden_sizes)
             if self.weights is None:
                 raise ValueError(f"{kind} predictor needs weights (PredictorWrapper(weights=...))")

@@ -49,6 +49,7 @@ class CtkConfig(C.Structure):
         ("sample_stdev", C.c_float), ("sample_mean", C.c_float), ("sample_min", C.c_float), ("sample_max", C.c_float),
         ("learning_rate", C.c_float), ("gradmax_clip", C.c_float), ("adam_beta_1", C.c_float),
         ("adam_beta_2", C.c_float), ("adam_epsilon", C.c_float), ("adam_rule", C.c_int32),
+        ("predictor_hidden1", C.c_int32), ("predictor_hidden2", C.c_int32),
     ]
 
 
@@ -184,7 +185,7 @@ class CtkEngine:
                  action_low: float = -1.0, action_high: float = 1.0, period_interpolation_inducing_points: int = 1,
                  seed: int = 0, device: int = 0, intermediate_steps: int = 1, materialize_trajectories: bool = False,
                  global_rollout_offset: int = 0, num_states: int = None, num_control_inputs: int = None,
-                 environment: str = "CartPole", generic_kernels: bool = False, **kw):
+                 environment: str = "CartPole", generic_kernels: bool = False, predictor_hidden=None, **kw):
         """action_low / action_high: scalars (every input) or one value per control input.  environment: the plant +
         cost the kernels implement ("CartPole", "Quad2D", "Hover"); num_states / num_control_inputs default to its dimensions and
         are checked against them.  generic_kernels: run the environment-agnostic template kernels even where a hand-tuned
@@ -210,6 +211,10 @@ class CtkEngine:
         cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         cfg.dt = float(dt)
         cfg.environment, cfg.generic_kernels = ENVIRONMENTS[environment], int(bool(generic_kernels))
+        # hidden widths of a network predictor (the <h1>H1-<h2>H2 of the reference's network names): widths above 32 (MLP, up to 64) build
+        # the handle on the 64-unit kernels; narrower networks are embedded exactly when their weights are set
+        self.predictor_hidden = None if predictor_hidden is None else (int(predictor_hidden[0]), int(predictor_hidden[1]))
+        self.native_hidden = (64, 64) if (self.predictor_hidden and max(self.predictor_hidden) > 32) else (32, 32)
         lo = np.broadcast_to(np.asarray(action_low, np.float32).reshape(-1), (Cn,)) if np.size(action_low) in (1, Cn) else None
         hi = np.broadcast_to(np.asarray(action_high, np.float32).reshape(-1), (Cn,)) if np.size(action_high) in (1, Cn) else None
         if lo is None or hi is None:
@@ -221,11 +226,13 @@ class CtkEngine:
                         warmup=0, warmup_iterations=0, cem_initial_action_stdev=0.5, cem_stdev_min=0.01,
                         outer_its=1, resamp_per=1, shift_previous=1, opt_keep_k=1, sampling_distribution=0,
                         sample_whole_control_space=0, sample_stdev=0.5, sample_mean=0.0, sample_min=-1.0, sample_max=1.0, learning_rate=0.05,
-                        gradmax_clip=5.0, adam_beta_1=0.9, adam_beta_2=0.999, adam_epsilon=1e-8, adam_rule=0)
+                        gradmax_clip=5.0, adam_beta_1=0.9, adam_beta_2=0.999, adam_epsilon=1e-8, adam_rule=0, predictor_hidden1=0, predictor_hidden2=0)
         unknown = set(kw) - set(defaults)
         if unknown:
             raise TypeError(f"unknown engine arguments: {sorted(unknown)}")
         defaults.update(kw)
+        if self.predictor_hidden is not None:
+            defaults.update(predictor_hidden1=self.predictor_hidden[0], predictor_hidden2=self.predictor_hidden[1])
         for k, v in defaults.items():
             setattr(cfg, k, type(getattr(cfg, k))(v))
         self._lib, self.cfg = lib, cfg
@@ -285,14 +292,18 @@ class CtkEngine:
         return int(self._lib.ctk_predictor_weight_count_shaped(self._h, int(hidden[0]), int(hidden[1])))
 
     def set_predictor_weights(self, w, hidden=None):
-        """hidden = (h1, h2): the network's hidden widths (the <h1>H1-<h2>H2 of the reference's network names); None = 32 / 32.
-        Widths up to 32 are embedded exactly, wider ones raise NotImplementedError with the sizes."""
+        """hidden = (h1, h2): the network's hidden widths (the <h1>H1-<h2>H2 of the reference's network names); None = what the engine was
+        created for (predictor_hidden, default 32 / 32).  Widths below the handle's own (32, or 64 for an engine created with
+        predictor_hidden above 32) are embedded exactly; wider ones raise NotImplementedError with the sizes."""
         w = _f32(w).ravel()
-        if hidden is None or tuple(int(x) for x in hidden) == (32, 32):
+        if hidden is None:
+            hidden = self.predictor_hidden or self.native_hidden
+        hidden = (int(hidden[0]), int(hidden[1]))
+        if hidden == self.native_hidden:
             self._check(self._lib.ctk_set_predictor_weights(self._h, _ptr(w), w.size))
         else:
-            self._check(self._lib.ctk_set_predictor_weights_shaped(self._h, _ptr(w), w.size, int(hidden[0]), int(hidden[1])))
-        self.hidden_sizes = (32, 32) if hidden is None else (int(hidden[0]), int(hidden[1]))
+            self._check(self._lib.ctk_set_predictor_weights_shaped(self._h, _ptr(w), w.size, hidden[0], hidden[1]))
+        self.hidden_sizes = hidden
 
     # recurrent predictor state (GRU): predictor.update(s, Q0), optimizer_mppi.py:195-197
     def predictor_hidden_size(self) -> int:

@@ -34,6 +34,8 @@ struct ctk_handle {
     int env = CTK_ENV_CARTPOLE, S = CTK_S, C = CTK_C;   // the environment and its dimensions
     int HC = 0, PC = 0;         // floats per row of a [.,H,C] / [.,P,C] tensor
     bool generic = false;       // run the template kernels of ctk_generic.hip (always for environments without tuned kernels)
+    int net = 0;                // what the template NETWORK kernels are told to run: cfg.predictor, or NET_MLP64 (hidden widths 33..64)
+    int hid = 32;               // units per hidden layer the handle's predictor kernels hold (32; 64 for net == NET_MLP64)
     float params[CTK_MAX_PARAMS]{};
     EnvK k{};
     MppiK mk{};
@@ -242,6 +244,42 @@ std::vector<float> permute_mlp_weights(const float* raw, int S = CTK_S, int C = 
     return out;
 }
 
+// The 64-unit MLP of ctk_mlp_wide.h (NetMlpWideT): the same placement rules with four 16-row tiles per hidden layer.
+// raw: W1[64,I] b1[64] W2[64,64] b2[64] W3[S,64] b3[S].  Per lane: forward w1[T][3] | w2[T][KH] | w3[KH] | b1[T][4] | b2[T][4] | b3[4];
+// reverse (behind the 64 forward rows) w3t[T][2] | w2t[T][KH] | w1t[KH].
+std::vector<float> permute_mlp_weights_wide(const float* raw, int S, int C) {
+    constexpr int T = MLPW_T, HID = MLPW_HID, KH = MLPW_KH;
+    const int I = S + C;
+    const float* W1 = raw;                 const float* b1 = W1 + HID * I;
+    const float* W2 = b1 + HID;            const float* b2 = W2 + HID * HID;
+    const float* W3 = b2 + HID;            const float* b3 = W3 + S * HID;
+    std::vector<float> out((size_t)64 * (MLPW_FWD_PER_LANE + MLPW_BWD_PER_LANE), 0.0f);
+    auto io_of_row = [](int row) { return 4 * (row % 4) + row / 4; };
+    for (int l = 0; l < 64; ++l) {
+        const int i = l & 15, g = l >> 4;
+        float* f = out.data() + (size_t)l * MLPW_FWD_PER_LANE;
+        int o = 0;
+        for (int m = 0; m < T; ++m)
+            for (int ks = 0; ks < 3; ++ks) { const int kk = 4 * ks + g; f[o++] = kk < I ? W1[(16 * m + i) * I + kk] : 0.0f; }
+        for (int m = 0; m < T; ++m)
+            for (int j = 0; j < KH; ++j) f[o++] = W2[(16 * m + i) * HID + mlp_hid(j, g)];
+        const int out_i = (i % 4 < 2 && io_of_row(i) < S) ? io_of_row(i) : -1;     // rows r = 0, 1 of every lane group carry outputs
+        for (int j = 0; j < KH; ++j) f[o++] = out_i >= 0 ? W3[out_i * HID + mlp_hid(j, g)] : 0.0f;
+        for (int m = 0; m < T; ++m) for (int r = 0; r < 4; ++r) f[o++] = b1[16 * m + 4 * g + r];
+        for (int m = 0; m < T; ++m) for (int r = 0; r < 4; ++r) f[o++] = b2[16 * m + 4 * g + r];
+        for (int r = 0; r < 4; ++r) f[o++] = (r < 2 && 4 * r + g < S) ? b3[4 * r + g] : 0.0f;
+        float* b = out.data() + (size_t)64 * MLPW_FWD_PER_LANE + (size_t)l * MLPW_BWD_PER_LANE;
+        o = 0;
+        for (int m = 0; m < T; ++m)
+            for (int ks = 0; ks < 2; ++ks) b[o++] = (4 * ks + g < S) ? W3[(4 * ks + g) * HID + 16 * m + i] : 0.0f;    // rows: hidden, k: output component 4ks+g
+        for (int m = 0; m < T; ++m)
+            for (int j = 0; j < KH; ++j) b[o++] = W2[mlp_hid(j, g) * HID + 16 * m + i];                                // rows: hidden_in, k: hidden_out
+        const int inp = (i % 4 < 3 && io_of_row(i) < I) ? io_of_row(i) : -1;                                           // rows: network inputs
+        for (int j = 0; j < KH; ++j) b[o++] = inp >= 0 ? W1[mlp_hid(j, g) * I + inp] : 0.0f;
+    }
+    return out;
+}
+
 // Per-lane MFMA operands of the GRU weights for the four waves of a workgroup (ctk_gru.h header comment and
 // struct GruW): out[wave][lane][72].  Wave (m, q) = wave index 2m + q owns hidden-unit tile m; its A rows are the
 // r (q = 0) or z (q = 1) rows, its B rows the n rows (input products for q = 0, recurrent products for q = 1).
@@ -369,9 +407,9 @@ void default_params(int env, float* p) {
     for (int i = 0; i < e->n_params; ++i) p[i] = e->param_defaults[i];
 }
 
-size_t weight_count(int predictor, int S, int C) {   // include/ctk_hip.h: ctk_set_predictor_weights
-    const size_t I = (size_t)S + C;
-    if (predictor == CTK_PRED_MLP) return I * 32 + 32 + 32 * 32 + 32 + 32 * (size_t)S + S;
+size_t weight_count(int predictor, int S, int C, int hid = 32) {   // include/ctk_hip.h: ctk_set_predictor_weights
+    const size_t I = (size_t)S + C, W = (size_t)hid;
+    if (predictor == CTK_PRED_MLP) return I * W + W + W * W + W + W * (size_t)S + S;
     if (predictor == CTK_PRED_GRU) return (96 * I + 96 * 32 + 192) + (96 * 32 + 96 * 32 + 192) + (32 * (size_t)S + S);
     return 0;
 }
@@ -688,7 +726,7 @@ int check_predictor(ctk_handle* h) {
 
 // ---- MPPI ------------------------------------------------------------------------------------
 int mppi_block_parts(const ctk_handle* h) {
-    if (h->generic && h->cfg.predictor != CTK_PRED_ODE) return ctk_g_rollout_net_blocks(h->env, h->cfg.predictor, CTK_G_MODE_MPPI, h->N, h->P, h->H);
+    if (h->generic && h->cfg.predictor != CTK_PRED_ODE) return ctk_g_rollout_net_blocks(h->env, h->net, CTK_G_MODE_MPPI, h->N, h->P, h->H);
     return h->generic ? ctk_g_rollout_blocks(h->N) : ctk_mppi_num_blocks(h->N, h->cfg.predictor);
 }
 // template path: the analytic predictor of ANY environment runs the 4-wave kernel of ctk_mppi.hip (in-launch hand-off included)
@@ -699,7 +737,7 @@ bool mppi_env_kernel(const ctk_handle* h) {
 }
 bool mppi_can_fuse(const ctk_handle* h) {
     if (h->generic && h->cfg.predictor != CTK_PRED_ODE)     // network template kernels: the {value, seq} hand-off only
-        return h->d_ll != nullptr && ctk_g_rollout_net_fusable(h->env, h->cfg.predictor, h->N, h->P, h->H);
+        return h->d_ll != nullptr && ctk_g_rollout_net_fusable(h->env, h->net, h->N, h->P, h->H);
     if (h->generic) return mppi_env_kernel(h) && ctk_mppi_fusable(h->PC, mppi_block_parts(h), h->d_ll != nullptr);
     return !ctk_mppi_uses_throughput_kernel(h->cfg.predictor, h->N) && ctk_mppi_fusable(h->P, mppi_block_parts(h), h->d_ll != nullptr);
 }
@@ -728,7 +766,7 @@ int mppi_rollout(ctk_handle* h, const float* s, const float* u_prev, const float
             MppiFuse fz;
             fz.mode = fuse_mode; fz.out_rec = partial_dev; fz.ll = h->d_ll;
             fz.u_nom_out = h->d_unom[h->cur ^ 1]; fz.u_dev = h->d_u; fz.u_host = h->h_u_dev; fz.seq = h->seq;
-            HIP_TRY(h, ctk_launch_g_rollout_net(h->stream, h->env, h->cfg.predictor, CTK_G_MODE_MPPI, a, h->params, h->cfg.dt, h->cfg.intermediate_steps,
+            HIP_TRY(h, ctk_launch_g_rollout_net(h->stream, h->env, h->net, CTK_G_MODE_MPPI, a, h->params, h->cfg.dt, h->cfg.intermediate_steps,
                                                 h->mk, d_s, h->d_unom[h->cur], nullptr, 0, h->d_wperm, h->d_parts, log, ps.a, ps.b, &fz));
         } else
             HIP_TRY(h, ctk_launch_g_rollout(h->stream, h->env, CTK_G_MODE_MPPI, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s,
@@ -824,7 +862,7 @@ int launch_affine(ctk_handle* h, const RolloutArgs& a, const float* d_s, int rng
         HIP_TRY(h, ctk_launch_affine_rollout_env(h->stream, h->env, h->params, h->cfg.dt, h->cfg.intermediate_steps, a, d_s, rng_kind, base, scale,
                                                  log, ps.a, ps.b, bst));
     else if (h->generic && h->cfg.predictor != CTK_PRED_ODE)
-        HIP_TRY(h, ctk_launch_g_rollout_net(h->stream, h->env, h->cfg.predictor, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps,
+        HIP_TRY(h, ctk_launch_g_rollout_net(h->stream, h->env, h->net, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps,
                                             h->mk, d_s, base, scale, rng_kind, h->d_wperm, nullptr, log, ps.a, ps.b));
     else if (h->generic)
         HIP_TRY(h, ctk_launch_g_rollout(h->stream, h->env, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s, base,
@@ -840,7 +878,7 @@ int launch_descent(ctk_handle* h, const RolloutArgs& a, float lr, float b1, floa
     const ctk_config& c = h->cfg;
     ProfSlot ps(h);
     if (h->generic && c.predictor != CTK_PRED_ODE)
-        HIP_TRY(h, ctk_launch_g_rpgd_descent_net(h->stream, h->env, c.predictor, a, h->params, c.dt, c.intermediate_steps, lr, b1, b2, eps,
+        HIP_TRY(h, ctk_launch_g_rpgd_descent_net(h->stream, h->env, h->net, a, h->params, c.dt, c.intermediate_steps, lr, b1, b2, eps,
                                                  c.gradmax_clip, Q, m, v, bc, bc_len, t0, iters, h->d_wperm, h->d_scratch, ps.a, ps.b, rule,
                                                  reinterpret_cast<uint32_t*>(h->h_u_dev) + 2));     // (the error word behind {u, seq})
     else if (h->generic)
@@ -1162,7 +1200,15 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     // template kernels: every environment but CartPole; CartPole on request; and the gradient-based optimizers with the
     // recurrent predictor (reverse mode through the GRU = NetGru::Bwd of ctk_net.h; CartPole's 4-wave GRU kernels are forward only)
     const bool grad_family = cfg->optimizer == CTK_OPT_RPGD || variant != cfg->optimizer;
-    const bool generic = cfg->environment != CTK_ENV_CARTPOLE || cfg->generic_kernels != 0 || (cfg->predictor == CTK_PRED_GRU && grad_family);
+    // hidden widths of a network predictor (the <h1>H1-<h2>H2 of the reference's network names): 0 = 32; up to 32 the 32-unit kernels;
+    // 33..64 (MLP) the 64-unit form of the one-wave template kernels (ctk_mlp_wide.h)
+    const int hw1 = cfg->predictor_hidden1 ? cfg->predictor_hidden1 : 32, hw2 = cfg->predictor_hidden2 ? cfg->predictor_hidden2 : 32;
+    if (hw1 < 1 || hw2 < 1) return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: predictor_hidden1 / predictor_hidden2 must be >= 1 (0 = 32)");
+    const bool wide_net = cfg->predictor != CTK_PRED_ODE && std::max(hw1, hw2) > 32;
+    if (wide_net && (cfg->predictor != CTK_PRED_MLP || std::max(hw1, hw2) > MLPW_HID))
+        return fail(nullptr, CTK_ERR_UNSUPPORTED, std::string("ctk_create: network ") + std::to_string(einfo->S + einfo->C) + "IN-" + std::to_string(hw1) + "H1-" +
+                    std::to_string(hw2) + "H2-" + std::to_string(einfo->S) + "OUT: built are MLPs with hidden layers of up to 64 units and GRUs of up to 32");
+    const bool generic = cfg->environment != CTK_ENV_CARTPOLE || cfg->generic_kernels != 0 || (cfg->predictor == CTK_PRED_GRU && grad_family) || wide_net;
     if (cfg->optimizer == CTK_OPT_CEM && (cfg->cem_best_k < 1 || cfg->cem_best_k > cfg->num_rollouts || cfg->cem_outer_it < 1))
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: need 1 <= cem_best_k <= num_rollouts and cem_outer_it >= 1");
     if (cfg->optimizer == CTK_OPT_RPGD) {
@@ -1192,6 +1238,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     h->variant = variant;
     h->N = cfg->num_rollouts; h->H = cfg->mpc_horizon;
     h->env = cfg->environment; h->S = einfo->S; h->C = einfo->C; h->generic = generic;
+    h->net = wide_net ? NET_MLP64 : cfg->predictor; h->hid = wide_net ? MLPW_HID : 32;
     const bool interp = (cfg->optimizer == CTK_OPT_MPPI || cfg->optimizer == CTK_OPT_RPGD);
     h->P = interp ? num_inducing_points(h->H, cfg->period_interpolation_inducing_points) : h->H;
     h->HC = h->H * h->C; h->PC = h->P * h->C;
@@ -1213,7 +1260,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
         size_t lds;
         const int cols = (int)(cfg->optimizer == CTK_OPT_MPPI ? PC : HC);
         if (generic && cfg->predictor != CTK_PRED_ODE)
-            lds = descends ? ctk_g_rpgd_descent_net_lds(h->env, cfg->predictor, (int)N, (int)H) : ctk_g_rollout_net_lds(h->env, cfg->predictor, (int)N, cols, (int)H, h->C);
+            lds = descends ? ctk_g_rpgd_descent_net_lds(h->env, h->net, (int)N, (int)H) : ctk_g_rollout_net_lds(h->env, h->net, (int)N, cols, (int)H, h->C);
         else if (generic) lds = descends ? ctk_g_rpgd_descent_lds(h->env, (int)H, nullptr) : ctk_g_rollout_lds(cols, (int)H, h->C);
         else lds = cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_lds((int)P, (int)H, cfg->predictor, (int)N)
                  : descends ? ctk_rpgd_descent_lds(cfg->predictor, (int)H, nullptr) : ctk_affine_rollout_lds((int)H, cfg->predictor);
@@ -1246,8 +1293,8 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     TRY_CREATE(dev_alloc(h, &h->d_scale, HC));
     TRY_CREATE(dev_alloc(h, &h->d_idx, N));
     TRY_CREATE(dev_alloc(h, &h->d_u, CTK_MAX_INPUTS));
-    TRY_CREATE(dev_alloc(h, &h->d_weights, std::max<size_t>(1, weight_count(cfg->predictor, h->S, h->C))));
-    TRY_CREATE(dev_alloc(h, &h->d_wperm, generic ? ctk_g_net_table_floats(cfg->predictor == CTK_PRED_GRU ? CTK_PRED_GRU : CTK_PRED_MLP) + GRU_HIDDEN_FLOATS
+    TRY_CREATE(dev_alloc(h, &h->d_weights, std::max<size_t>(1, weight_count(cfg->predictor, h->S, h->C, h->hid))));
+    TRY_CREATE(dev_alloc(h, &h->d_wperm, generic ? ctk_g_net_table_floats(wide_net ? NET_MLP64 : cfg->predictor == CTK_PRED_GRU ? CTK_PRED_GRU : CTK_PRED_MLP) + GRU_HIDDEN_FLOATS
                                          : cfg->predictor == CTK_PRED_GRU ? (size_t)GRU_TABLE_FLOATS + GRU_HIDDEN_FLOATS
                                                                           : (size_t)64 * (MLP_FWD_PER_LANE + MLP_BWD_PER_LANE)));
     HIP_CREATE(hipHostMalloc((void**)&h->h_u, 64, hipHostMallocMapped | hipHostMallocCoherent));
@@ -1281,15 +1328,15 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
         HIP_CREATE(hipMemcpyAsync(h->d_bc, bc.data(), bc.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
         HIP_CREATE(hipStreamSynchronize(h->stream));
         TRY_CREATE(dev_alloc(h, &h->d_scratch, !generic ? ctk_rpgd_scratch_floats(cfg->predictor, (int)N, (int)H)
-                                               : cfg->predictor != CTK_PRED_ODE ? ctk_g_rpgd_scratch_floats_net(cfg->predictor, (int)N, (int)H)
+                                               : cfg->predictor != CTK_PRED_ODE ? ctk_g_rpgd_scratch_floats_net(h->net, (int)N, (int)H)
                                                                                 : ctk_g_rpgd_scratch_floats(h->env, (int)N, (int)H)));
     }
     const bool mat = cfg->materialize_trajectories != 0;
     const bool gnet = generic && cfg->predictor != CTK_PRED_ODE;
-    if (descends) h->dominant = gnet ? ctk_g_rpgd_descent_net_name(h->env, cfg->predictor, (int)N, (int)H) : generic ? ctk_g_rpgd_descent_name(h->env) : ctk_rpgd_descent_name(cfg->predictor, (int)N);
+    if (descends) h->dominant = gnet ? ctk_g_rpgd_descent_net_name(h->env, h->net, (int)N, (int)H) : generic ? ctk_g_rpgd_descent_name(h->env) : ctk_rpgd_descent_name(cfg->predictor, (int)N);
     else {
         const int mode = cfg->optimizer == CTK_OPT_MPPI ? CTK_G_MODE_MPPI : CTK_G_MODE_AFFINE;
-        h->dominant = gnet ? ctk_g_rollout_net_name(h->env, cfg->predictor, mode, mat, (int)N, (int)P, (int)H) : generic ? ctk_g_rollout_name(h->env, mode, mat)
+        h->dominant = gnet ? ctk_g_rollout_net_name(h->env, h->net, mode, mat, (int)N, (int)P, (int)H) : generic ? ctk_g_rollout_name(h->env, mode, mat)
                     : cfg->optimizer == CTK_OPT_MPPI ? ctk_mppi_rollout_name(cfg->predictor, mat, cfg->num_rollouts, cfg->period_interpolation_inducing_points == 1 && h->P == (int)H, false)
                                                      : ctk_affine_rollout_name(cfg->predictor, mat);
     }
@@ -1399,20 +1446,21 @@ const char* ctk_environment_name(int environment) {
     return e ? e->name : nullptr;
 }
 
-size_t ctk_predictor_weight_count(const ctk_handle* h) { return h ? weight_count(h->cfg.predictor, h->S, h->C) : 0; }
+size_t ctk_predictor_weight_count(const ctk_handle* h) { return h ? weight_count(h->cfg.predictor, h->S, h->C, h->hid) : 0; }
 
 int ctk_set_predictor_weights(ctk_handle* h, const float* w, size_t n) {
     RES_Q(h);
     if (!h || !w) return CTK_ERR_INVALID_ARGUMENT;
     if (h->cfg.predictor == CTK_PRED_ODE) return fail(h, CTK_ERR_STATE, "ctk_set_predictor_weights: the ODE predictor has no weights");
     const bool gru = h->cfg.predictor == CTK_PRED_GRU;
-    if (n != weight_count(h->cfg.predictor, h->S, h->C))
+    if (n != weight_count(h->cfg.predictor, h->S, h->C, h->hid))
         return fail(h, CTK_ERR_INVALID_ARGUMENT, std::string("ctk_set_predictor_weights: expected ") +
-                    std::to_string(weight_count(h->cfg.predictor, h->S, h->C)) + " floats for this predictor and environment (ctk_predictor_weight_count)");
+                    std::to_string(weight_count(h->cfg.predictor, h->S, h->C, h->hid)) + " floats for this predictor and environment (ctk_predictor_weight_count)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipMemcpyAsync(h->d_weights, w, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
     if (gru) HIP_TRY(h, hipMemsetAsync(gru_hidden(h), 0, GRU_HIDDEN_FLOATS * sizeof(float), h->stream));
-    const std::vector<float> perm = !gru ? permute_mlp_weights(w, h->S, h->C)
+    const std::vector<float> perm = h->net == NET_MLP64 ? permute_mlp_weights_wide(w, h->S, h->C)
+                                  : !gru ? permute_mlp_weights(w, h->S, h->C)
                                   : h->generic ? permute_gru_weights_g(w, h->S, h->C) : permute_gru_weights(w);
     if (gru && !h->generic) {   // |h2| <= 1 (convex mix of tanh values and the previous state, which starts at 0 or at what the caller set)
         const float* Wo = w + GRU_NW_RAW - 4 * 32 - 4; const float* bo = Wo + 4 * 32;
@@ -1444,16 +1492,16 @@ int ctk_set_predictor_weights_shaped(ctk_handle* h, const float* w, size_t n, in
     if (!h || !w) return CTK_ERR_INVALID_ARGUMENT;
     if (h->cfg.predictor == CTK_PRED_ODE) return fail(h, CTK_ERR_STATE, "ctk_set_predictor_weights_shaped: the ODE predictor has no weights");
     if (h1 < 1 || h2 < 1) return fail(h, CTK_ERR_INVALID_ARGUMENT, "ctk_set_predictor_weights_shaped: hidden widths must be >= 1");
-    const int S = h->S, I = h->S + h->C;
-    if (h1 > 32 || h2 > 32)
+    const int S = h->S, I = h->S + h->C, W = h->hid;
+    if (h1 > W || h2 > W)
         return fail(h, CTK_ERR_UNSUPPORTED, std::string("network ") + std::to_string(I) + "IN-" + std::to_string(h1) + "H1-" + std::to_string(h2) + "H2-" +
-                    std::to_string(S) + "OUT: hidden layers wider than 32 units are not built (the matrix-core tiles of the predictor kernels hold 32 "
-                    "units per layer; narrower layers are embedded exactly)");
+                    std::to_string(S) + "OUT: this handle's predictor kernels hold " + std::to_string(W) + " units per hidden layer (narrower layers are "
+                    "embedded exactly; create the handle with cfg.predictor_hidden1/2 = the widths: MLPs up to 64 / 64 are built, GRUs up to 32 / 32)");
     if (n != shaped_weight_count(h->cfg.predictor, h->S, h->C, h1, h2))
         return fail(h, CTK_ERR_INVALID_ARGUMENT, std::string("ctk_set_predictor_weights_shaped: expected ") +
                     std::to_string(shaped_weight_count(h->cfg.predictor, h->S, h->C, h1, h2)) + " floats for " + std::to_string(I) + "IN-" +
                     std::to_string(h1) + "H1-" + std::to_string(h2) + "H2-" + std::to_string(S) + "OUT, got " + std::to_string(n));
-    std::vector<float> full(weight_count(h->cfg.predictor, h->S, h->C), 0.0f);
+    std::vector<float> full(weight_count(h->cfg.predictor, h->S, h->C, W), 0.0f);
     const float* p = w;
     float* q = full.data();
     auto rows = [&](int r_src, int c_src, int r_dst, int c_dst) {      // a [r_src, c_src] matrix into the top-left of a [r_dst, c_dst] one
@@ -1461,9 +1509,9 @@ int ctk_set_predictor_weights_shaped(ctk_handle* h, const float* w, size_t n, in
         p += (size_t)r_src * c_src; q += (size_t)r_dst * c_dst;
     };
     if (h->cfg.predictor == CTK_PRED_MLP) {
-        rows(h1, I, 32, I); rows(1, h1, 1, 32);        // W1, b1
-        rows(h2, h1, 32, 32); rows(1, h2, 1, 32);      // W2, b2
-        rows(S, h2, S, 32); rows(1, S, 1, S);          // W3, b3
+        rows(h1, I, W, I); rows(1, h1, 1, W);          // W1, b1
+        rows(h2, h1, W, W); rows(1, h2, 1, W);         // W2, b2
+        rows(S, h2, S, W); rows(1, S, 1, S);           // W3, b3
     } else {
         auto gates = [&](int hs, int c_src, int c_dst) {               // [3 hs, c_src] (rows r|z|n) -> [96, c_dst]
             for (int gte = 0; gte < 3; ++gte) {
@@ -1776,7 +1824,7 @@ int ctk_rollout(ctk_handle* h, const float* s, const float* u_prev, const float*
     for (int c = 0; c < h->C; ++c) { a.lo[c] = -INFINITY; a.hi[c] = INFINITY; }
     a.traj_out = traj_out ? d_traj : nullptr;
     hipError_t e = (h->generic && h->cfg.predictor != CTK_PRED_ODE)
-        ? ctk_launch_g_rollout_net(h->stream, h->env, h->cfg.predictor, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk,
+        ? ctk_launch_g_rollout_net(h->stream, h->env, h->net, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk,
                                    d_s, d_zero, d_one, 0, h->d_wperm, nullptr, traj_out != nullptr)
         : h->generic
         ? ctk_launch_g_rollout(h->stream, h->env, CTK_G_MODE_AFFINE, a, h->params, h->cfg.dt, h->cfg.intermediate_steps, h->mk, d_s, d_zero, d_one,

@@ -8,10 +8,8 @@
 //   1. rollout    Q = clip(mu + eps * std) (:64-66), costs J of its 64 rows (anatomy of ctk_affine_rollout<ODE>; the NEXT
 //                 iteration's sample tile is fetched by waves 1..3 while wave 0 runs the recurrence — it does not depend on mu/std);
 //   2. hop 1      publishes its 64 costs as words {sortable key, tag}; polls all N words into LDS;
-//   3. selection  which of ITS rows are elite (:73-75): ONE histogram pass over all N keys (256 bins across [min, max]) finds the bin the
-//                 K-th key falls into; own rows in lower bins are elite, rows in that bin get their exact rank under (key, index) — the
-//                 total order of ctk_select_topk / tf.argsort — by one pass of the workgroup over the keys (round 4; rounds 2-3 found
-//                 the K-th key itself: up to 4 histogram passes + a tie pass);
+//   3. selection  finds the K-th smallest (key, index) of all N REDUNDANTLY (4-pass radix select on an LDS histogram; ties
+//                 broken by index, the total order of ctk_select_topk / tf.argsort) -> which of ITS rows are elite (:73-75);
 //   4. hop 2      publishes {n_b, m_b[H], M2_b[H]} of its elite rows: m_b = mean of d = q - mu (mu: the mean the samples were drawn around),
 //                 M2_b = centred sum of squares — formed in one pass in double, published as floats; polls every workgroup's record;
 //   5. refit      ONE pass over the records in a fixed order, in double: A = sum n_b m_b, B = sum (M2_b + n_b m_b^2) -> mean = mu + A/K,
@@ -75,13 +73,12 @@ __host__ __device__ inline CemCarve cem_carve(int N, int H, int nblk) {
     c.cin = o; o += CF_BLOCK;
     c.mu = o; o += H;
     c.sd = o; o += H;
-    o = (o + 3) & ~3;                       // (16-byte reads of the keys)
     c.keys = o; o += (N + CF_BLOCK * CF_CHUNK - 1) / (CF_BLOCK * CF_CHUNK) * (CF_BLOCK * CF_CHUNK);   // padded: the counting loop reads whole chunks
     c.recs = o; o += nblk * rs;
     o = (o + 1) & ~1;
     c.part = o; o += 4 * CF_BLOCK;          // [SEG][H] {S1, S2} doubles of the segmented refit (SEG * H <= CF_BLOCK)
     c.hist = o; o += 256;
-    c.misc = o; o += 80 + 2 * CF_WAVES + 64;   // [0..7] scalars | [8] n_b | [16..79] elite rows | [80..) two per-wave reduction rows | eflag[64]
+    c.misc = o; o += 80 + 2 * CF_WAVES;   // [0..7] selection scalars | [8] n_b | [16..79] elite rows | [80..) two per-wave reduction rows
     c.total = (o + 3) & ~3;
     return c;
 }
@@ -211,10 +208,13 @@ __global__ __launch_bounds__(CF_BLOCK) void ctk_cem_fused(const float* __restric
     int* nb_s = reinterpret_cast<int*>(lds + cv.misc) + 8;
     int* erow = reinterpret_cast<int*>(lds + cv.misc) + 16;       // [64] this workgroup's elite rows, ascending
     uint32_t* red = reinterpret_cast<uint32_t*>(lds + cv.misc) + 80;   // [2][CF_WAVES]
-    int* eflag = reinterpret_cast<int*>(lds + cv.misc) + 80 + 2 * CF_WAVES;   // [64] elite flag per row of the workgroup
     auto red_min = [&](int row) { uint32_t v = 0xFFFFFFFFu;
 #pragma unroll
         for (int w = 0; w < CF_WAVES; ++w) v = min(v, red[row * CF_WAVES + w]);
+        return v; };
+    auto red_sum = [&](int row) { uint32_t v = 0u;
+#pragma unroll
+        for (int w = 0; w < CF_WAVES; ++w) v += red[row * CF_WAVES + w];
         return v; };
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int row0 = blockIdx.x * CF_TRAJ;
@@ -226,7 +226,6 @@ __global__ __launch_bounds__(CF_BLOCK) void ctk_cem_fused(const float* __restric
     bool expired = false;
 
     for (int h = t; h < H; h += CF_BLOCK) { mu_s[h] = cf.mu[h]; sd_s[h] = cf.sd[h]; }
-    for (int i = N + t; i < ((N + 3) & ~3); i += CF_BLOCK) keys[i] = 0xFFFFFFFFu;     // the 16-byte reads of the exact-rank pass may reach behind N
     a.stream_id = 0;
     cem_fetch_tile(tiles[0], samples, a, row0, t, CF_BLOCK);
     __syncthreads();
@@ -334,93 +333,86 @@ __global__ __launch_bounds__(CF_BLOCK) void ctk_cem_fused(const float* __restric
         __syncthreads();
         const uint32_t kbase = red_min(0);
         const uint32_t krange = ~red_min(1) - kbase;
+        if (t == 0) { sel[0] = 0; sel[1] = cf.K; }
 
-        // ---- 3. which of THIS workgroup's rows are elite (:73-75).  Round 4: one histogram pass + an exact rank for the few rows it leaves
-        //      undecided, instead of finding the K-th key of all N (rounds 2-3: MSB-first radix select, up to 4 histogram passes + a tie
-        //      pass — 3.6 us per iteration at cfg3; a workgroup only ever needs the verdict on its own 64 rows):
-        //      (a) all N keys into 256 bins that split [min, max] linearly (the raw top bits of a float are nearly constant over a
-        //          population's costs: every key in one bin serialises the LDS atomics); a scan finds the bin the K-th key falls into;
-        //      (b) own rows in lower bins are elite, in higher bins not; own rows IN that bin (on average 64 / 256 of a row's worth of
-        //          the bin's keys: usually none) get their exact rank = number of (key, index) pairs in front of them among all N — the
-        //          total order of ctk_select_topk / tf.argsort — by a pass over the keys in LDS, one WAVE per such row (eight at a
-        //          time); elite iff rank < K.  Many equal costs put many rows into that bin: more passes, same answer.
+        // ---- 3. K-th smallest key: MSB-first radix select over d = key - kbase, 8 bits per pass.  Only the bits the range
+        //      needs are walked, and the first digit buckets the costs LINEARLY over [min, max] (the raw top bits of a float are
+        //      nearly constant over a population's costs: every key in one bin serialises the LDS atomics).  (Compacting the first
+        //      pass's bucket and ranking its keys by brute force instead of the later passes was measured: slower, 4.0 vs 3.0 us.)
         const int nbits = 32 - __builtin_clz(krange | 1u);
-        const int lo = max(nbits - 8, 0);                         // digit = the top 8 bits of d = key - min
-        if (t < 256) hist[t] = 0;
-        __syncthreads();
-        for (int j0 = t; j0 < N; j0 += CF_BLOCK * CF_CHUNK) {     // unconditional LDS reads in flight (keys[] is padded), then the counting
-            uint32_t dj[CF_CHUNK];
+        const int passes = (nbits + 7) >> 3;
+        for (int pass = 0; pass < passes; ++pass) {
+            const int hi = nbits - 8 * pass, lo = max(hi - 8, 0);   // this pass's digit = bits [lo, hi) of d: the first one is full
+            const uint32_t dmask = (1u << (hi - lo)) - 1u;
+            if (t < 256) hist[t] = 0;
+            __syncthreads();
+            const uint32_t prefix = (uint32_t)sel[0];
+            const int want = sel[1];
+            for (int j0 = t; j0 < N; j0 += CF_BLOCK * CF_CHUNK) { // unconditional LDS reads in flight (keys[] is padded), then the counting
+                uint32_t dj[CF_CHUNK];
 #pragma unroll
-            for (int u = 0; u < CF_CHUNK; ++u) dj[u] = keys[j0 + u * CF_BLOCK] - kbase;
+                for (int u = 0; u < CF_CHUNK; ++u) dj[u] = keys[j0 + u * CF_BLOCK] - kbase;
 #pragma unroll
-            for (int u = 0; u < CF_CHUNK; ++u)
-                if (j0 + u * CF_BLOCK < N) atomicAdd(&hist[(dj[u] >> lo) & 255u], 1);
-        }
-        __syncthreads();
-        CSTAMP(9);
-        if (wave == 0) {
-            const int b0 = hist[4 * lane], b1 = hist[4 * lane + 1], b2 = hist[4 * lane + 2], b3 = hist[4 * lane + 3];
-            const int c = b0 + b1 + b2 + b3;
-            // inclusive prefix over the 64 lanes: DPP row shifts inside each row of 16, then the three row totals
-            int inc = c;
-            inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true);   // row_shr:1, zero fill
-            inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true);   // row_shr:2
-            inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true);   // row_shr:4
-            inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true);   // row_shr:8
-            const int r0 = __builtin_amdgcn_readlane(inc, 15), r1 = __builtin_amdgcn_readlane(inc, 31), r2 = __builtin_amdgcn_readlane(inc, 47);
-            inc += lane >= 48 ? r0 + r1 + r2 : (lane >= 32 ? r0 + r1 : (lane >= 16 ? r0 : 0));
-            const unsigned long long hit = __builtin_amdgcn_ballot_w64(inc >= cf.K);
-            const int first = hit ? __builtin_ctzll(hit) : 63;    // hit != 0: the histogram holds N >= K keys
-            const int below4 = __builtin_amdgcn_readlane(inc - c, first);
-            const int q0 = __builtin_amdgcn_readlane(b0, first), q1 = __builtin_amdgcn_readlane(b1, first), q2 = __builtin_amdgcn_readlane(b2, first);
-            const int cut = 4 * first + (below4 + q0 >= cf.K ? 0 : below4 + q0 + q1 >= cf.K ? 1 : below4 + q0 + q1 + q2 >= cf.K ? 2 : 3);   // the K-th key's bin
-            // own rows: decided by their bin, or candidates for the exact rank
-            const uint32_t ki = valid ? keys[n] : 0xFFFFFFFFu;
-            const int dig = (int)(((ki - kbase) >> lo) & 255u);
-            const unsigned long long cand = __builtin_amdgcn_ballot_w64(valid && dig == cut);
-            eflag[lane] = (valid && dig < cut) ? 1 : 0;
-            if (lane == 0) { sel[0] = (int)(uint32_t)cand; sel[1] = (int)(uint32_t)(cand >> 32); }
-        }
-        __syncthreads();
-        CSTAMP(10);
-        {
-            // one WAVE per undecided row (up to CF_WAVES per round): its 64 lanes split the N keys, 4 per LDS read; no cross-wave reduction
-            unsigned long long cand = ((unsigned long long)(uint32_t)sel[1] << 32) | (uint32_t)sel[0];      // workgroup-uniform
-            while (cand) {
-                int row = -1;
-#pragma unroll
-                for (int q = 0; q < CF_WAVES; ++q) {
-                    const int r = cand ? __builtin_ctzll(cand) : -1;
-                    if (cand) cand &= cand - 1;
-                    row = q == wave ? r : row;
+                for (int u = 0; u < CF_CHUNK; ++u) {
+                    const bool act = (j0 + u * CF_BLOCK < N) & (pass == 0 || (dj[u] >> hi) == prefix);
+                    if (act) atomicAdd(&hist[(dj[u] >> lo) & dmask], 1);
                 }
-                if (row >= 0) {
-                    const uint32_t ck = keys[row0 + row];
-                    const int cidx = row0 + row;
-                    int cnt = 0;
-                    const uint4* k4p = reinterpret_cast<const uint4*>(keys);
-                    for (int j4 = lane; 4 * j4 < N; j4 += 64) {   // (the pad behind N holds the largest key: never in front of a valid row)
-                        const uint4 k4 = k4p[j4];
-                        const int j = 4 * j4;
-                        cnt += (int)((k4.x < ck) | ((k4.x == ck) & (j < cidx)));
-                        cnt += (int)((k4.y < ck) | ((k4.y == ck) & (j + 1 < cidx)));
-                        cnt += (int)((k4.z < ck) | ((k4.z == ck) & (j + 2 < cidx)));
-                        cnt += (int)((k4.w < ck) | ((k4.w == ck) & (j + 3 < cidx)));
-                    }
-                    cnt = (int)wave_sum((float)cnt);               // exact: < 2^24
-                    if (lane == 0) eflag[row] = cnt < cf.K ? 1 : 0;
-                }
-                __syncthreads();
             }
+            __syncthreads();
+            if (pass == 0) CSTAMP(9);
+            if (wave == 0) {
+                const int b0 = hist[4 * lane], b1 = hist[4 * lane + 1], b2 = hist[4 * lane + 2], b3 = hist[4 * lane + 3];
+                const int c = b0 + b1 + b2 + b3;
+                // inclusive prefix over the 64 lanes: DPP row shifts inside each row of 16, then the three row totals
+                int inc = c;
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true);   // row_shr:1, zero fill
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true);   // row_shr:2
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true);   // row_shr:4
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true);   // row_shr:8
+                const int r0 = __builtin_amdgcn_readlane(inc, 15), r1 = __builtin_amdgcn_readlane(inc, 31), r2 = __builtin_amdgcn_readlane(inc, 47);
+                inc += lane >= 48 ? r0 + r1 + r2 : (lane >= 32 ? r0 + r1 : (lane >= 16 ? r0 : 0));
+                const unsigned long long hit = __builtin_amdgcn_ballot_w64(inc >= want);
+                const int first = hit ? __builtin_ctzll(hit) : 64;   // hit != 0: the histogram holds >= want keys
+                if (lane == first) {
+                    int below = inc - c, dgt = 4 * lane, bsel = b0;
+                    if (below + b0 >= want) { dgt += 0; }
+                    else if (below + b0 + b1 >= want) { below += b0; dgt += 1; bsel = b1; }
+                    else if (below + b0 + b1 + b2 >= want) { below += b0 + b1; dgt += 2; bsel = b2; }
+                    else { below += b0 + b1 + b2; dgt += 3; bsel = b3; }
+                    sel[0] = (int)((prefix << (hi - lo)) | (uint32_t)dgt);
+                    sel[1] = want - below;
+                    sel[2] = bsel;                                // keys in the chosen bin (last pass: keys == the K-th smallest)
+                }
+            }
+            __syncthreads();
+            if (pass == 0) CSTAMP(10);
+            if (pass == 1) CSTAMP(11);
         }
+        CSTAMP(4);
+        const uint32_t T32 = kbase + (uint32_t)sel[0];            // the K-th smallest key
+        const int r_ties = sel[1];                                // of the keys == T32, the first r_ties in index order are elite
+        // ties in front of this workgroup's rows — only when the cut falls INSIDE a group of equal keys (workgroup-uniform)
+        const bool cut_in_tie = sel[2] != r_ties;
+        __syncthreads();                                          // red[] (the range) and sel[] have been read by everyone
+        if (cut_in_tie) {
+            int tb = 0;
+            for (int j = t; j < min(row0, N); j += CF_BLOCK) tb += keys[j] == T32;
+            tb = (int)wave_sum((float)tb);                        // exact: < 2^24
+            if (lane == 0) red[wave] = (uint32_t)tb;
+        } else if (lane == 0) red[wave] = 0u;
+        __syncthreads();
+        const int ties_before = (int)red_sum(0);
         if (wave == 0) {
-            const bool elite = valid && eflag[lane] != 0;
+            const uint32_t ki = valid ? keys[n] : 0xFFFFFFFFu;
+            const bool tie = valid && ki == T32;
+            const unsigned long long tm = __builtin_amdgcn_ballot_w64(tie);
+            const int my_tie_rank = ties_before + __builtin_popcountll(tm & ((1ull << lane) - 1ull));
+            const bool elite = valid && (ki < T32 || (tie && my_tie_rank < r_ties));
             const unsigned long long em = __builtin_amdgcn_ballot_w64(elite);
             if (elite) erow[__builtin_popcountll(em & ((1ull << lane) - 1ull))] = lane;
             if (lane == 0) nb_s[0] = __builtin_popcountll(em);
         }
         __syncthreads();
-        CSTAMP(4);
 
         CSTAMP(5);
         // ---- 4. local moments of the elite rows, hop 2 --------------------------------------------------------------

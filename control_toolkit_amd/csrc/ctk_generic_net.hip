@@ -352,7 +352,10 @@ __global__ __launch_bounds__(64) void ctk_g_gru_advance(RolloutArgs a, const flo
 // ---------------------------------------------------------------------------------------------------------------
 static uint32_t magic_of(int d) { return d >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d) : 0u; }
 
-size_t ctk_g_net_table_floats(int net) { return net == NET_GRU ? (size_t)(GRUG_FWD + GRUG_BWD) * 64 : (size_t)64 * (MLP_FWD_PER_LANE + MLP_BWD_PER_LANE); }
+size_t ctk_g_net_table_floats(int net) {
+    if (net == NET_MLP64) return (size_t)64 * (MLPW_FWD_PER_LANE + MLPW_BWD_PER_LANE);
+    return net == NET_GRU ? (size_t)(GRUG_FWD + GRUG_BWD) * 64 : (size_t)64 * (MLP_FWD_PER_LANE + MLP_BWD_PER_LANE);
+}
 size_t ctk_g_net_hidden_floats(int net) { return net == NET_GRU ? NetGru::HIDDEN : 0; }
 static const float* bwd_table(int net, const float* wperm) { return net == NET_GRU ? wperm + (size_t)GRUG_FWD * 64 : wperm; }
 static size_t net_lds_fwd(int net) { return net == NET_GRU ? NetGru::LDS_FWD : 0; }
@@ -373,7 +376,9 @@ const char* ctk_g_rollout_net_name(int env, int net, int mode, bool log, int N, 
     if (ctk_g_rollout_split_ok(env, net, N, H, ctk_g_rollout_net_cols(env, mode, P, H))) return ctk_g_rollout_split_name(env, net, mode, log, N, H, ctk_g_rollout_net_cols(env, mode, P, H));
     int io = 0;
     CTK_FOR_ENV(env, EV, { io = Env<EV>::S + Env<EV>::C; });
-    return ctk_kernel_name("ctk_g_rollout_net<%d, %4$s, %d, %5$s>", env, mode, 0, net == NET_GRU ? "NetGru" : (io > 8 ? "NetMlpT<true>" : "NetMlp"), log ? "true" : "false");
+    return ctk_kernel_name("ctk_g_rollout_net<%d, %4$s, %d, %5$s>", env, mode, 0,
+                           net == NET_MLP64 ? (io > 8 ? "NetMlpWideT<true>" : "NetMlpWideT<false>") : net == NET_GRU ? "NetGru" : (io > 8 ? "NetMlpT<true>" : "NetMlp"),
+                           log ? "true" : "false");
 }
 
 size_t ctk_g_rollout_net_lds(int env, int net, int N, int cols, int H, int C) {
@@ -433,6 +438,8 @@ hipError_t ctk_launch_g_rollout_net(hipStream_t st, int env, int net, int mode, 
     CTK_FOR_ENV(env, EV, {
         using MLP = NetMlpT<(Env<EV>::S + Env<EV>::C > 8)>;      // a third layer-1 k-step where the environment has more than 8 network inputs
         if (net == NET_GRU) launch_rollout_net<EV, NetGru>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
+        else if (net == NET_MLP64)
+            launch_rollout_net<EV, NetMlpWideT<(Env<EV>::S + Env<EV>::C > 8)>>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
         else launch_rollout_net<EV, MLP>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
     });
     return hipGetLastError();
@@ -446,6 +453,7 @@ size_t ctk_g_rpgd_descent_net_lds(int env, int net, int N, int H) {
 }
 
 size_t ctk_g_rpgd_scratch_floats_net(int net, int N, int H) {
+    if (net == NET_MLP64) return (size_t)((N + GN_TRAJ - 1) / GN_TRAJ) * 4 * H * 64 * NetMlpWideT<false>::TAPE;
     const size_t one_wave = (size_t)((N + GN_TRAJ - 1) / GN_TRAJ) * 4 * H * 64 * (net == NET_GRU ? NetGru::TAPE : NetMlp::TAPE);
     return std::max(std::max(one_wave, ctk_g_rpgd_scratch_floats_split(net, N, H)), net == NET_MLP ? ctk_g_rpgd_scratch_floats_wide(N, H) : (size_t)0);
 }
@@ -455,7 +463,8 @@ const char* ctk_g_rpgd_descent_net_name(int env, int net, int N, int H) {
     if (ctk_g_rpgd_split_ok(env, net, N, H)) return ctk_g_rpgd_descent_split_name(env, net);
     int io = 0;
     CTK_FOR_ENV(env, EV, { io = Env<EV>::S + Env<EV>::C; });
-    return ctk_kernel_name("ctk_g_rpgd_descent_net<%d, %4$s>", env, 0, 0, net == NET_GRU ? "NetGru" : (io > 8 ? "NetMlpT<true>" : "NetMlp"));
+    return ctk_kernel_name("ctk_g_rpgd_descent_net<%d, %4$s>", env, 0, 0,
+                           net == NET_MLP64 ? (io > 8 ? "NetMlpWideT<true>" : "NetMlpWideT<false>") : net == NET_GRU ? "NetGru" : (io > 8 ? "NetMlpT<true>" : "NetMlp"));
 }
 
 hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const RolloutArgs& a_in, const float* params, float dt, int isteps,
@@ -478,6 +487,8 @@ hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const
         const size_t lds = ctk_g_rpgd_descent_net_lds(env, net, 1 << 30, a.H);   // this (one-wave) form
         if (net == NET_GRU)
             CTK_LAUNCH((ctk_g_rpgd_descent_net<EV, NetGru>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wb, hidden, scratch);
+        else if (net == NET_MLP64)
+            CTK_LAUNCH((ctk_g_rpgd_descent_net<EV, NetMlpWideT<(E::S + E::C > 8)>>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wb, hidden, scratch);
         else
             CTK_LAUNCH((ctk_g_rpgd_descent_net<EV, NetMlpT<(E::S + E::C > 8)>>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wb, hidden, scratch);
     });

@@ -13,6 +13,7 @@
 #include "ctk_mlp.h"
 
 constexpr int NET_MLP = 1, NET_GRU = 2;     // == CTK_PRED_MLP, CTK_PRED_GRU
+constexpr int NET_MLP64 = 4;                // kernel-variant id (handles created with hidden widths 33..64): the 64-unit MLP of ctk_mlp_wide.h, one-wave kernels only
 
 CTK_DEV f32x4 ld4(const float4* p) { const float4 v = *p; return f32x4{v.x, v.y, v.z, v.w}; }
 CTK_DEV float4 st4(f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
@@ -240,3 +241,5 @@ struct NetGru {
         }
     };
 };
+
+#include "ctk_mlp_wide.h"

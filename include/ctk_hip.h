@@ -188,6 +188,12 @@ typedef struct ctk_config {
                             arithmetic, published rule: lr_t = lr sqrt(1-b2^t)/(1-b1^t), epsilon not bias-corrected.  Parity of rule 1 is
                             pinned only against the oracle's restatement of that rule (no reference recording: it needs
                             TensorFlow itself).  Any other value: CTK_ERR_INVALID_ARGUMENT at ctk_create.                     */
+    int32_t predictor_hidden1, predictor_hidden2;   /* (ABI v6, appended) hidden widths of the MLP / GRU predictor, the <h1>H1-<h2>H2 of the
+                            reference's network names (config_controllers.yml:8).  0 = 32.  1..32: the 32-unit kernels (narrower layers
+                            embedded exactly by ctk_set_predictor_weights_shaped).  33..64 (MLP only): the handle is built on the
+                            64-unit form of the template kernels (ctk_mlp_wide.h; one wave per 16-trajectory tile, ~3x the matrix
+                            work per step), ctk_set_predictor_weights then expects the 64 / 64 layout.  > 64, or a GRU wider
+                            than 32: CTK_ERR_UNSUPPORTED with the sizes in ctk_last_error.                                      */
 } ctk_config;
 
 /* -------------------------------------------------------------------------------------------

@@ -675,9 +675,9 @@ def main():
     record_tf_only_optimizers(out_dir, cm, envs, dt)
 
     # ---- a network of another width: the reference names networks by their sizes (config_controllers.yml:8) and hands the name to the
-    #      predictor (controller_mpc.py:67-73); the unmodified optimizer_mppi on a 5-16-16-4 and a 5-24-8-4 tanh MLP (stand-in predictor: it
+    #      predictor (controller_mpc.py:67-73); the unmodified optimizer_mppi on 5-16-16-4, 5-24-8-4 and 5-64-64-4 tanh MLPs (stand-in predictor: it
     #      takes whatever weight shapes it is given)
-    for name, hidden, seed in (("mlp_h16", (16, 16), 71), ("mlp_h24_8", (24, 8), 72)):
+    for name, hidden, seed in (("mlp_h16", (16, 16), 71), ("mlp_h24_8", (24, 8), 72), ("mlp_h64", (64, 64), 73)):
         w_small = O.mlp_default_weights(9, 5, 4, hidden)
         inject_constants(env, dt, mlp_w)
         pw.MLP_WEIGHTS = tuple(torch.tensor(a) for a in O.mlp_unpack(w_small, 5, 4, hidden))

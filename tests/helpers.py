@@ -90,7 +90,7 @@ def cut_is_separated(J, K, rel=1e-4):
     return K >= len(srt) or (srt[K] - srt[K - 1]) > rel * abs(srt[K - 1])
 
 
-MPPI_CASES = ["tiny_ode", "interp_ode", "cfg2_ode", "quirk_ode", "mlp", "mlp_h16", "mlp_h24_8"]   # (the last two: 5-16-16-4 and 5-24-8-4 networks)
+MPPI_CASES = ["tiny_ode", "interp_ode", "cfg2_ode", "quirk_ode", "mlp", "mlp_h16", "mlp_h24_8", "mlp_h64"]   # (the last three: 5-16-16-4, 5-24-8-4 and 5-64-64-4 networks)
 RPGD_CASES = ["ode_small", "ode_its20", "mlp_cfg4", "ode_normal"]
 # recorded from the same unmodified reference optimizers on the second environment (6 states, 2 control inputs)
 MPPI_QUAD_CASES = ["quad2d", "quad2d_p1"]

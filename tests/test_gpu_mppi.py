@@ -23,7 +23,7 @@ U_TOL = dict(rtol=1e-4, atol=2e-5)
 J_RTOL = 1e-5
 GOLDEN_U_TOL = dict(rtol=1e-5, atol=1e-5)
 
-ODE_CASES = [c for c in MPPI_CASES if c != "mlp"]
+ODE_CASES = [c for c in MPPI_CASES if c.endswith("_ode")]
 
 
 # materialize=False is the instantiation bench.py times (ctk_mppi_rollout<PRED, false>: no u_run / trajectory stores);

@@ -7,7 +7,10 @@ are embedded exactly (include/ctk_hip.h: ctk_set_predictor_weights_shaped), wide
  * MPPI + RPGD at (16, 16), (24, 8), (1, 32) on CartPole (tuned and template kernels) and Hover against the oracle, whose MLP takes
    (I, h1, h2, O);
  * the GRU at (16, 24) against the oracle run on the same weights embedded into 32 / 32 by the TEST (checks the library's embedding);
- * the name convention through controller_mpc; 64 / 64 refused."""
+ * hidden widths 33..64 (MLP): engines created with predictor_hidden run the 64-unit form of the one-wave template kernels
+   (csrc/ctk_mlp_wide.h) — MPPI / CEM / RPGD / plain rollouts on CartPole and Hover against the oracle, MPPI against a fixture recorded from the
+   unmodified optimizer_mppi on a 5-64-64-4 network (mppi_mlp_h64.npz);
+ * the name convention through controller_mpc; widths beyond 64 (MLP) / 32 (GRU) refused with the sizes."""
 import numpy as np
 import pytest
 
@@ -25,18 +28,21 @@ SHAPES = [(16, 16), (24, 8), (1, 32)]
 
 
 @pytest.mark.parametrize("materialize", [True, False])
-@pytest.mark.parametrize("case", ["mlp_h16", "mlp_h24_8"])
+@pytest.mark.parametrize("case", ["mlp_h16", "mlp_h24_8", "mlp_h64"])
 def test_mppi_narrow_mlp_matches_reference_golden(case, materialize):
     d = load(f"mppi_{case}.npz")
     hidden = tuple(int(x) for x in d["hidden_sizes"])
+    wide = max(hidden) > 32                                            # 33..64: an engine created for that width (64-unit kernels)
     e = CtkEngine("mppi", "MLP", num_rollouts=int(d["num_rollouts"]), mpc_horizon=int(d["mpc_horizon"]), dt=float(d["dt"]),
                   period_interpolation_inducing_points=int(d["period_interpolation_inducing_points"]), materialize_trajectories=materialize,
-                  cc_weight=float(d["cc_weight"]), R=float(d["R"]), LBD=float(d["LBD"]), NU=float(d["NU"]), SQRTRHOINV=float(d["SQRTRHOINV"]))
+                  cc_weight=float(d["cc_weight"]), R=float(d["R"]), LBD=float(d["LBD"]), NU=float(d["NU"]), SQRTRHOINV=float(d["SQRTRHOINV"]),
+                  predictor_hidden=hidden if wide else None)
     from helpers import env_from
     apply_env(e, env_from(d))
     assert e.predictor_weight_count(hidden) == d["mlp_weights"].size == O.mlp_num_weights(5, 4, hidden)
-    with pytest.raises(ValueError, match="expected"):
-        e.set_predictor_weights(d["mlp_weights"])                    # the 32 / 32 entry point counts its floats
+    if not wide:
+        with pytest.raises(ValueError, match="expected"):
+            e.set_predictor_weights(d["mlp_weights"], hidden=(32, 32))   # the 32 / 32 entry point counts its floats
     e.set_predictor_weights(d["mlp_weights"], hidden=hidden)
     H = int(d["mpc_horizon"])
     for t in range(int(d["steps"])):
@@ -155,12 +161,13 @@ def test_narrow_gru_is_embedded_exactly(generic):
     w = (rng.standard_normal(n) * 0.2).astype(np.float32)
     env = O.EnvParams(terminal_weight=0.25)
     N, H = 64, 12
-    e = CtkEngine("mppi", "GRU", generic_kernels=generic, num_rollouts=N, mpc_horizon=H, dt=0.02, materialize_trajectories=True)
+    e = CtkEngine("mppi", "GRU", generic_kernels=generic, num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=1,
+                  materialize_trajectories=True)
     apply_env(e, env)
     assert e.predictor_weight_count((h1, h2)) == n
     e.set_predictor_weights(w, hidden=(h1, h2))
     pred = O.Predictor("GRU", dt=0.02, env=env, weights=_embed_gru(w, I, S, h1, h2))
-    o = O.MPPI(pred, O.Cost(env), num_rollouts=N, mpc_horizon=H)
+    o = O.MPPI(pred, O.Cost(env), num_rollouts=N, mpc_horizon=H, period_interpolation_inducing_points=1)
     s = np.array([0.1, -0.2, 2.5, 0.7], np.float32)
     for t in range(2):
         noise = rng.standard_normal((N, o.P, 1)).astype(np.float32)
@@ -174,13 +181,114 @@ def test_narrow_gru_is_embedded_exactly(generic):
     e.close()
 
 
-def test_wider_networks_are_refused_with_their_sizes():
-    e = CtkEngine("mppi", "MLP", num_rollouts=8, mpc_horizon=5, dt=0.02)
-    with pytest.raises(NotImplementedError, match=r"5IN-64H1-64H2-4OUT"):
+def test_widths_beyond_the_built_ones_are_refused_with_their_sizes():
+    e = CtkEngine("mppi", "MLP", num_rollouts=8, mpc_horizon=5, dt=0.02)           # a 32-unit handle
+    with pytest.raises(NotImplementedError, match=r"5IN-64H1-64H2-4OUT.*hold 32 units"):
         e.set_predictor_weights(np.zeros(O.mlp_num_weights(5, 4, (64, 64)), np.float32), hidden=(64, 64))
     with pytest.raises(ValueError, match="expected"):
         e.set_predictor_weights(np.zeros(7, np.float32), hidden=(16, 16))
     e.close()
+    with pytest.raises(NotImplementedError, match=r"5IN-128H1-64H2-4OUT"):
+        CtkEngine("mppi", "MLP", num_rollouts=8, mpc_horizon=5, dt=0.02, predictor_hidden=(128, 64))
+    with pytest.raises(NotImplementedError, match=r"GRUs of up to 32"):
+        CtkEngine("mppi", "GRU", num_rollouts=8, mpc_horizon=5, dt=0.02, predictor_hidden=(64, 64))
+
+
+WIDE_SHAPES = [(64, 64), (48, 64), (33, 20)]
+
+
+@pytest.mark.parametrize("hidden", WIDE_SHAPES)
+def test_cartpole_mppi_and_rpgd_on_64_unit_mlp_match_oracle(hidden):
+    """hidden widths 33..64: the handle is built on the 64-unit form of the one-wave template kernels (csrc/ctk_mlp_wide.h)"""
+    env = O.EnvParams(terminal_weight=0.3)
+    w = O.mlp_default_weights(6, 5, 4, hidden)
+    pred = O.Predictor("MLP", dt=0.02, env=env, weights=w, hidden_sizes=hidden)
+    N, H, p = 200, 20, 5
+    o = O.MPPI(pred, O.Cost(env), num_rollouts=N, mpc_horizon=H, period_interpolation_inducing_points=p)
+    e = CtkEngine("mppi", "MLP", num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p, materialize_trajectories=True,
+                  predictor_hidden=hidden)
+    assert "NetMlpWideT<false>" in e.dominant_kernel(), e.dominant_kernel()
+    assert e.predictor_weight_count() == O.mlp_num_weights(5, 4, (64, 64)) and e.predictor_weight_count(hidden) == w.size
+    apply_env(e, env); e.set_predictor_weights(w)                   # hidden = what the engine was created for
+    rng = np.random.default_rng(sum(hidden))
+    s = np.array([0.05, 0.0, 2.9, 0.3], np.float32)
+    for t in range(2):
+        noise = rng.standard_normal((N, o.P, 1)).astype(np.float32)
+        uo, ug = o.step(s, noise), e.step(s, noise)
+        np.testing.assert_allclose(e.read("TRAJ"), o.rollout_trajectories, rtol=1e-4, atol=3e-5)
+        np.testing.assert_allclose(e.read("J"), o.J, rtol=5e-5, atol=1e-3)
+        np.testing.assert_allclose(e.read("U_NOM"), o.u_nom, **U_TOL)
+        np.testing.assert_allclose(ug[0], uo, **U_TOL)
+    Q = rng.uniform(-1, 1, (9, H, 1)).astype(np.float32)            # plain rollouts through the same network
+    traj, J = e.rollout(s, Q, u_prev=0.2)
+    np.testing.assert_allclose(traj, pred.predict_core(np.tile(s, (9, 1)), Q), rtol=1e-4, atol=3e-5)
+    e.close()
+    its = 3
+    orp = O.RPGD(pred, O.Cost(env), num_rollouts=48, mpc_horizon=12, outer_its=its, resamp_per=10, period_interpolation_inducing_points=4,
+                 SAMPLING_DISTRIBUTION="uniform", shift_previous=1, learning_rate=0.05, opt_keep_k_ratio=0.25, gradmax_clip=5.0)
+    er = CtkEngine("rpgd", "MLP", num_rollouts=48, mpc_horizon=12, dt=0.02, period_interpolation_inducing_points=4, outer_its=its, resamp_per=10,
+                   shift_previous=1, opt_keep_k=orp.k, sampling_distribution=0, sample_min=-1.0, sample_max=1.0, learning_rate=0.05, gradmax_clip=5.0,
+                   predictor_hidden=hidden)
+    assert "NetMlpWideT<false>" in er.dominant_kernel(), er.dominant_kernel()
+    apply_env(er, env); er.set_predictor_weights(w)
+    d0 = rng.random((48, orp.P, 1), dtype=np.float32)
+    dr = rng.random((48 - orp.k, orp.P, 1), dtype=np.float32)
+    orp.optimizer_reset(d0); er.reset(d0)
+    uo, ug = orp.step(s, dr), er.step(s, dr)
+    assert_close_mostly(er.read("PLAN"), orp.Q, max_outliers=4, rtol=2e-4, atol=2e-4)
+    assert_close_mostly(er.read("ADAM_M"), orp.opt.m, max_outliers=4, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(ug[0], uo, rtol=1e-3, atol=1e-3)
+    er.close()
+
+
+def test_hover_mppi_cem_and_rpgd_on_64_unit_mlp_match_oracle():
+    hidden = (64, 64)
+    env = O.HoverParams(target_x=0.2)
+    w = O.mlp_default_weights(8, 10, 7, hidden)
+    pred = O.Predictor("MLP", dt=0.02, env=env, weights=w, hidden_sizes=hidden)
+    lo, hi = np.array([-1.0, -0.7, -0.5], np.float32), np.array([0.9, 1.0, 0.5], np.float32)
+    N, H, p = 96, 16, 4
+    o = O.MPPI(pred, O.Cost(env), lo, hi, num_rollouts=N, mpc_horizon=H, period_interpolation_inducing_points=p)
+    e = CtkEngine("mppi", "MLP", environment="Hover", num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p, action_low=lo,
+                  action_high=hi, materialize_trajectories=True, predictor_hidden=hidden)
+    assert "NetMlpWideT<true>" in e.dominant_kernel(), e.dominant_kernel()     # ten network inputs: three layer-1 k-steps
+    for n in env.param_names():
+        e.set_param(n, float(getattr(env, n)))
+    e.set_predictor_weights(w)
+    rng = np.random.default_rng(17)
+    s = np.array([0.2, -0.1, -0.3, 0.15, 0.4, -0.2, 0.5], np.float32)
+    noise = rng.standard_normal((N, o.P, 3)).astype(np.float32)
+    uo, ug = o.step(s, noise), e.step(s, noise)
+    np.testing.assert_allclose(e.read("TRAJ"), o.rollout_trajectories, rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(e.read("J"), o.J, rtol=5e-5, atol=1e-3)
+    np.testing.assert_allclose(ug, np.asarray(uo).reshape(-1), **U_TOL)
+    e.close()
+    oc = O.CEM(pred, O.Cost(env), lo, hi, num_rollouts=128, mpc_horizon=10, cem_outer_it=2, cem_best_k=16)
+    ec = CtkEngine("cem", "MLP", environment="Hover", num_rollouts=128, mpc_horizon=10, dt=0.02, action_low=lo, action_high=hi, cem_outer_it=2, cem_best_k=16,
+                   predictor_hidden=hidden)
+    for n in env.param_names():
+        ec.set_param(n, float(getattr(env, n)))
+    ec.set_predictor_weights(w)
+    nz = rng.standard_normal((2, 128, 10, 3)).astype(np.float32)
+    uo, ug = oc.step(s, nz), ec.step(s, nz)
+    np.testing.assert_allclose(ec.read("J"), oc.J, rtol=5e-5, atol=1e-3)
+    np.testing.assert_allclose(ug, np.asarray(uo).reshape(-1), rtol=1e-5, atol=2e-6)
+    ec.close()
+    orp = O.RPGD(pred, O.Cost(env), lo, hi, num_rollouts=32, mpc_horizon=10, outer_its=3, resamp_per=10, period_interpolation_inducing_points=5,
+                 SAMPLING_DISTRIBUTION="uniform", shift_previous=1, learning_rate=0.05, opt_keep_k_ratio=0.25, gradmax_clip=5.0)
+    er = CtkEngine("rpgd", "MLP", environment="Hover", num_rollouts=32, mpc_horizon=10, dt=0.02, period_interpolation_inducing_points=5, action_low=lo,
+                   action_high=hi, outer_its=3, resamp_per=10, shift_previous=1, opt_keep_k=orp.k, sampling_distribution=0, sample_whole_control_space=1,
+                   learning_rate=0.05, gradmax_clip=5.0, predictor_hidden=hidden)
+    for n in env.param_names():
+        er.set_param(n, float(getattr(env, n)))
+    er.set_predictor_weights(w)
+    d0 = rng.random((32, orp.P, 3), dtype=np.float32)
+    dr = rng.random((32 - orp.k, orp.P, 3), dtype=np.float32)
+    orp.optimizer_reset(d0); er.reset(d0)
+    uo, ug = orp.step(s, dr), er.step(s, dr)
+    assert_close_mostly(er.read("PLAN"), orp.Q, max_outliers=4, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(ug, np.asarray(uo).reshape(-1), rtol=1e-3, atol=1e-3)
+    er.close()
 
 
 def test_network_name_reaches_the_kernels_through_controller_mpc():
@@ -201,5 +309,12 @@ def test_network_name_reaches_the_kernels_through_controller_mpc():
     # a name whose sizes do not fit the environment, or too wide, is refused where the reference would configure the predictor
     with pytest.raises(ValueError, match="inputs"):
         PredictorWrapper(weights=d["mlp_weights"]).configure(batch_size=4, dt=0.02, predictor_specification="Dense-6IN-16H1-16H2-5OUT-0")
-    with pytest.raises(NotImplementedError, match="64"):
-        PredictorWrapper(weights=d["mlp_weights"]).configure(batch_size=4, dt=0.02, predictor_specification="Dense-5IN-64H1-64H2-4OUT-0")
+    with pytest.raises(NotImplementedError, match="128"):
+        PredictorWrapper(weights=d["mlp_weights"]).configure(batch_size=4, dt=0.02, predictor_specification="Dense-5IN-128H1-128H2-4OUT-0")
+    # ... and a 64-unit name builds the 64-unit engine
+    d64 = load("mppi_mlp_h64.npz")
+    c64 = build(d64, "mppi-hip", cfg, predictor=str(d64["predictor_specification"]))
+    assert c64.optimizer.engine.native_hidden == (64, 64) and "NetMlpWideT" in c64.optimizer.engine.dominant_kernel()
+    c64.optimizer.rng = ReplayRng([d64[f"noise_{t}"] for t in range(steps)])
+    for t in range(steps):
+        np.testing.assert_allclose(c64.step(d64[f"s_{t}"]), d64[f"u_{t}"][0], rtol=1e-4, atol=2e-5)

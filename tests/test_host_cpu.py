@@ -122,9 +122,9 @@ def test_hip_library_gate_and_optimizer_discovery():
     with pytest.raises(NotImplementedError):
         PredictorWrapper().configure(batch_size=1, dt=0.02, predictor_specification="LSTM-6IN-32H1-32H2-5OUT-0")
     with pytest.raises(ValueError):
-        PredictorWrapper().configure(batch_size=1, dt=0.02, predictor_specification="GRU-6IN-32H1-32H2-5OUT-0")   # no weights
+        PredictorWrapper().configure(batch_size=1, dt=0.02, predictor_specification="GRU-5IN-32H1-32H2-4OUT-0")   # no weights
     g = PredictorWrapper(weights=np.zeros(10212, np.float32))
-    g.configure(batch_size=1, dt=0.02, predictor_specification="GRU-6IN-32H1-32H2-5OUT-0")
+    g.configure(batch_size=1, dt=0.02, predictor_specification="GRU-5IN-32H1-32H2-4OUT-0")
     assert g.kind == "GRU"
     with pytest.raises(ValueError):
         PredictorWrapper().configure(batch_size=1, dt=0.02, predictor_specification="MLP")   # no weights
@@ -237,11 +237,14 @@ def test_network_name_convention_is_parsed_and_checked():
     with pytest.raises(NotImplementedError, match="hidden layers"):
         parse("Dense-5IN-16H1-16H2-16H3-4OUT-0")
     assert check_network_sizes("x", None, 4, 1) == (32, 32)
-    assert check_network_sizes("x", parse("Dense-5IN-16H1-24H2-4OUT-3")[1], 4, 1) == (16, 24)
+    assert check_network_sizes("Dense-5IN-16H1-24H2-4OUT-3", parse("Dense-5IN-16H1-24H2-4OUT-3")[1], 4, 1) == (16, 24)
     with pytest.raises(ValueError, match="6 inputs"):
         check_network_sizes("GRU-6IN-32H1-32H2-5OUT-0", parse("GRU-6IN-32H1-32H2-5OUT-0")[1], 4, 1)
-    with pytest.raises(NotImplementedError, match="64 / 64"):
-        check_network_sizes("Dense-5IN-64H1-64H2-4OUT-0", parse("Dense-5IN-64H1-64H2-4OUT-0")[1], 4, 1)
+    assert check_network_sizes("Dense-5IN-64H1-48H2-4OUT-0", parse("Dense-5IN-64H1-48H2-4OUT-0")[1], 4, 1) == (64, 48)    # MLPs up to 64 / 64
+    with pytest.raises(NotImplementedError, match="128 / 64"):
+        check_network_sizes("Dense-5IN-128H1-64H2-4OUT-0", parse("Dense-5IN-128H1-64H2-4OUT-0")[1], 4, 1)
+    with pytest.raises(NotImplementedError, match="GRU predictor kernels hold up to 32"):
+        check_network_sizes("GRU-5IN-64H1-64H2-4OUT-0", parse("GRU-5IN-64H1-64H2-4OUT-0")[1], 4, 1)
     assert network_weight_count("MLP", 4, 1) == 1380 and network_weight_count("GRU", 4, 1) == 10212
     assert network_weight_count("MLP", 4, 1, (16, 24)) == 5 * 16 + 16 + 16 * 24 + 24 + 24 * 4 + 4
     p = PredictorWrapper(weights=np.zeros(network_weight_count("MLP", 4, 1, (16, 24)), np.float32))

@@ -38,8 +38,8 @@ int main(int argc, char** argv) {
     std::vector<unsigned long long> st((size_t)nb * 8 * 16);
     CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
     printf("N=%d H=%d K=%d blocks=%d its=%d: event time %.2f us (stamped build); err word %u\n", N, H, K, nb, its, ms * 1e3, reinterpret_cast<unsigned*>(h_u)[2]);
-    const char* names[8] = {"prepare first 16 steps (+barrier)", "recurrence -> J (thread 0 = wave 0)", "publish J + gather all N costs", "histogram + scan + exact rank of undecided rows",
-                            "(barrier)", "local moments + publish", "gather all records", "refit from the records     "};
+    const char* names[8] = {"prepare first 16 steps (+barrier)", "recurrence -> J (thread 0 = wave 0)", "publish J + gather all N costs", "range reduce + radix select",
+                            "ties + elite flags", "local moments + publish", "gather all records", "refit from the records     "};
     for (int it = 0; it < its; ++it) {
         printf(" iteration %d (ns, median over workgroups | max)\n", it);
         for (int ph = 0; ph < 8; ++ph) {
@@ -48,10 +48,10 @@ int main(int argc, char** argv) {
             std::sort(d.begin(), d.end());
             printf("   %-40s %8.0f | %8.0f\n", names[ph], d[d.size() / 2], d.back());
         }
-        {   // inside the selection: 3 -> 9 (range reduce + histogram) -> 10 (scan, own rows' bins) -> 4 (exact rank of the undecided own rows, flags)
-            const int seq[4] = {3, 9, 10, 4};
-            const char* nm[3] = {"range reduce + histogram", "scan + own rows' bins", "exact rank of undecided rows + flags"};
-            for (int i = 0; i < 3; ++i) {
+        {   // inside the selection: 3 -> 9 (range reduce + first histogram) -> 10 (first scan) -> 11 (second pass) -> 4 (rest)
+            const int seq[5] = {3, 9, 10, 11, 4};
+            const char* nm[4] = {"range reduce + histogram of pass 0", "scan of pass 0", "pass 1", "remaining passes"};
+            for (int i = 0; i < 4; ++i) {
                 std::vector<double> d;
                 for (int b = 0; b < nb; ++b) d.push_back(10.0 * (double)(long long)(st[((size_t)b * 8 + it) * 16 + seq[i + 1]] - st[((size_t)b * 8 + it) * 16 + seq[i]]));
                 std::sort(d.begin(), d.end());

@@ -1,20 +1,22 @@
 #!/bin/bash
-# round-3 profile pass (ONE gpurun call): HBM traffic of the headline kernel, bench lines of every workload, two-rank rehearsals of the
+# profile pass (ONE gpurun call; round 4: R=04, outputs under gpurun_out/p4): HBM traffic of the headline kernel, bench lines of every workload, two-rank rehearsals of the
 # sharded bench, rocprofv3 kernel traces, MFMA counters, the co-execution microbenchmark, the environment table, the CEM phase stamps.
 # Everything is CONDENSED ON THE BOX (tools/condense_profiles.py --out $O/condensed) before any size-based delete, and the condenser
 # refuses inputs older than this run's start stamp: a summary under profiles/ can only come from the run that produced its CSVs
 # (round 2 committed counters of an older kernel because a >1 MB CSV was deleted on the box and an older local copy was condensed).
-# usage: gpurun -- bash tools/gpu_run_profiles.sh <commit>;  then copy gpurun_out/p3/condensed/* to profiles/
+# usage: gpurun -- bash tools/gpu_run_profiles.sh <commit>;  then copy gpurun_out/p4/condensed/* to profiles/
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-R=03
-O=gpurun_out/p3
+R=04
+O=gpurun_out/p4
 rm -rf $O; mkdir -p $O
 date +%s > $O/run_started
 echo "commit $1" > $O/summary.txt
 say() { echo "$1 rc=$2" | tee -a $O/summary.txt; }
 B="--no-cpu-baseline --no-large-n --no-modes"
+# 0. parity margins of the reference-golden tests (tests/margins.py writes gpurun_out/parity_margins.txt)
+timeout -k 10 600 python -m pytest tests -m gpu -q -k "golden or replays_reference" > $O/golden_tests.log 2>&1; say "golden tests" $?
 # 1. HBM traffic of the headline kernel first: bench.py reports it from profiles/ (only while the kernel sources match its digest)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -o p -- python3 bench.py --steps 50 --warmup 5 $B > /dev/null 2> $O/pmc_f.err; say "pmc fetch" $?
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o p -- python3 bench.py --steps 50 --warmup 5 $B > /dev/null 2> $O/pmc_w.err; say "pmc write" $?
@@ -33,6 +35,10 @@ for wl in mppi_cfg5 cem_cfg3 rpgd_cfg4; do
   CTK_BENCH_SINGLE_DEVICE=1 CTK_BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29871 bench.py --gpus 2 --workload $wl --steps 50 --warmup 5 > $O/bench_g2_$wl.json 2> $O/bench_g2_$wl.err; say "bench g2 $wl" $?
 done
 CTK_BENCH_FORCE_PG=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29872 bench.py --gpus 1 --workload mppi_cfg5 --steps 50 --warmup 5 > $O/bench_rccl1_cfg5.json 2> $O/bench_rccl1_cfg5.err; say "bench rccl1" $?
+# one rank's share of configs[4] at G = 8 (N 8 192) with the RCCL collective actually issued: begin | exchange | end of the step the curve will be made of
+CTK_BENCH_FORCE_PG=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29873 bench.py --gpus 1 --workload mppi_cfg5_shard --steps 100 --warmup 10 > $O/bench_rccl1_cfg5_shard.json 2> $O/bench_rccl1_cfg5_shard.err; say "bench rccl1 shard" $?
+# `python bench.py --gpus 2` as a bare command (starts its own ranks): the shape of the driver's multi-GPU command, rehearsed on one GPU over gloo
+CTK_BENCH_SINGLE_DEVICE=1 CTK_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_bare_gpus2.json 2> $O/bench_bare_gpus2.err; say "bench bare --gpus 2" $?
 # 4. kernel traces
 for wl in mppi_cfg2 rpgd_cfg4 mppi_cfg5_shard cem_cfg3 mppi_gru; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o p -- python3 bench.py --workload $wl --steps 100 --warmup 10 $B > $O/prof_$wl.json 2> $O/prof_$wl.err; say "prof $wl" $?
@@ -51,9 +57,10 @@ python tools/sweep_n.py > $O/sweep_n.txt 2> $O/sweep_n.err; say "sweep_n" $?
 python tools/bench_resident.py > $O/resident.txt 2> $O/resident.err; say "bench_resident" $?
 ./tools/diag_mailbox_vram >> $O/resident.txt 2>&1; say "mailbox diag" $?
 ./tools/diag_wave_placement > $O/placement.txt 2>&1; say "wave placement" $?
-python3 tools/soak_handoff.py 1000 > $O/soak_handoff.txt 2>&1; say "soak hand-off" $?
-python tools/soak.py 1500 > $O/soak.txt 2>&1; say "soak" $?
+python3 tools/soak_handoff.py 300 > $O/soak_handoff.txt 2>&1; say "soak hand-off" $?
+python tools/soak.py 500 > $O/soak.txt 2>&1; say "soak" $?
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_largen -o p -- python3 tools/large_n_once.py > /dev/null 2> $O/pmc_largen.err; say "pmc large-N insts" $?
 # 7. condense HERE, then drop the big CSVs
-python3 tools/condense_profiles.py --src $O --round 3 --out $O/condensed; say "condense" $?
+cp gpurun_out/parity_margins.txt $O/parity_margins.txt 2>/dev/null
+python3 tools/condense_profiles.py --src $O --round 4 --out $O/condensed; say "condense" $?
 find $O -name "*.csv" -size +1M -delete
