@@ -28,6 +28,10 @@ ROWS = [
     ("rpgd  ODE", "rpgd", "ODE", 256, 50, 10, dict(outer_its=10, resamp_per=10, opt_keep_k=64, sampling_distribution=0)),
     ("rpgd  MLP", "rpgd", "MLP", 256, 50, 10, dict(outer_its=10, resamp_per=10, opt_keep_k=64, sampling_distribution=0)),
     ("rpgd  GRU", "rpgd", "GRU", 256, 50, 10, dict(outer_its=10, resamp_per=10, opt_keep_k=64, sampling_distribution=0)),
+    # hidden widths 33..64: the 64-unit form of the one-wave template kernels (csrc/ctk_mlp_wide.h) for every environment, CartPole included
+    ("mppi  MLP h64", "mppi", "MLP", 1024, 50, 1, dict(predictor_hidden=(64, 64))),
+    ("mppi  MLP h64 shard", "mppi", "MLP", 8192, 100, 10, dict(predictor_hidden=(64, 64))),
+    ("rpgd  MLP h64", "rpgd", "MLP", 256, 50, 10, dict(outer_its=10, resamp_per=10, opt_keep_k=64, sampling_distribution=0, predictor_hidden=(64, 64))),
 ]
 
 

@@ -109,8 +109,9 @@ def main():
     copy_text("resident.txt", f"{tag}_resident.txt", "# tools/bench_resident.py (CtkEngine.step, launched form against the resident form), then tools/diag_mailbox_vram (round trip of one word:\n"
               "# mailbox in pinned host memory against mailbox in host-written device memory)\n")
     copy_text("placement.txt", f"{tag}_wave_placement.txt", "# tools/diag_wave_placement: where a CU puts the waves of small workgroups (every wave: a dependent chain of 14 fp32 MFMAs per step; XCC / SE / CU / SIMD from s_getreg)\n")
-    copy_text("soak_handoff.txt", f"{tag}_soak_handoff.txt", "# tools/soak_handoff.py 1000: the in-launch hand-off of the template wide RPGD descent while a second process keeps the GPU busy\n")
-    copy_text("soak.txt", f"{tag}_soak.txt", "# tools/soak.py 1500: closed-loop soak of 21 engines (every optimizer, predictor, environment, the one-launch CEM, the split network kernels)\n")
+    copy_text("parity_margins.txt", f"{tag}_parity_margins.txt", "# tests/margins.py: written by the reference-golden -m gpu tests of this pass (tools/gpu_run_profiles.sh step 0)\n")
+    copy_text("soak_handoff.txt", f"{tag}_soak_handoff.txt", "# tools/soak_handoff.py: the in-launch hand-off of the template wide RPGD descent while a second process keeps the GPU busy\n")
+    copy_text("soak.txt", f"{tag}_soak.txt", "# tools/soak.py: closed-loop soak of 21 engines (every optimizer, predictor, environment, the one-launch CEM, the split network kernels)\n")
     p = pmc("pmc_largen")
     if fresh(p):
         import collections
@@ -147,7 +148,7 @@ def main():
         rows.append((name, d["ms_per_step"] * 1e3, d.get("step_ms_median", float("nan")) * 1e3, d["value"], r.get("kernel", ""), r.get("kernel_us", float("nan")),
                      r.get("achieved") or float("nan"), r.get("unit", ""), r.get("frac") or float("nan"), (d.get("config") or {}).get("parallelism", ""),
                      dec.get("begin_kernels"), dec.get("exchange"), dec.get("end_kernels")))
-        if name.startswith("g2_") or name.startswith("rccl1"):
+        if name.startswith("g2_") or name.startswith("rccl1") or name.startswith("bare_"):
             shutil.copy(f, os.path.join(out, f"{tag}_bench_{name}.json")); wrote.append(f"{tag}_bench_{name}.json")
     if rows:
         buf = io.StringIO()
