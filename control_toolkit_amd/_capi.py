@@ -75,6 +75,7 @@ SYMBOLS = {
     "ctk_reset": (C.c_int, [_H, C.c_void_p, C.c_int]),
     "ctk_last_error": (C.c_char_p, [_H]),
     "ctk_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "ctk_get_stream": (C.c_void_p, [_H]),
     "ctk_set_param": (C.c_int, [_H, C.c_int, C.c_float]),
     "ctk_get_param": (C.c_int, [_H, C.c_int, _FP]),
     "ctk_env_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -274,6 +275,10 @@ class CtkEngine:
             loc = LOC_HOST
         d = _f32(draws) if (draws is not None and loc == LOC_HOST) else None
         self._check(self._lib.ctk_reset(self._h, _ptr(d) if d is not None else (draws if loc == LOC_DEVICE else None), loc))
+
+    def get_stream(self) -> int:
+        """the HIP stream the handle issues on right now (after resident_enable: a high-priority stream of its own)"""
+        return int(self._lib.ctk_get_stream(self._h) or 0)
 
     def set_stream(self, stream_ptr: int):
         self._check(self._lib.ctk_set_stream(self._h, C.c_void_p(stream_ptr)))

@@ -1376,12 +1376,29 @@ void ctk_destroy(ctk_handle* h) {
 int ctk_set_stream(ctk_handle* h, void* hip_stream) {
     RES_Q(h);
     if (!h) return CTK_ERR_INVALID_ARGUMENT;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (h->own_stream && h->stream) HIP_TRY(h, hipStreamDestroy(h->stream));
-    h->stream = (hipStream_t)hip_stream;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t ns = (hipStream_t)hip_stream;
+    if (ns == h->stream) return CTK_OK;
+    // Order the handle's earlier work before whatever is issued on the new stream WITHOUT stopping the host (a caller that
+    // alternates streams paid a full hipStreamSynchronize per step): an event on the old stream, a wait on the new one.  Only the
+    // handle's own stream is synchronised, because it is destroyed right after.
+    if (h->own_stream && h->stream) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipStreamDestroy(h->stream));
+    } else {
+        hipEvent_t ev = nullptr;
+        HIP_TRY(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev, h->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ns, ev, 0);
+        (void)hipEventDestroy(ev);                            // (released when the recorded work has completed)
+        HIP_TRY(h, e);
+    }
+    h->stream = ns;
     h->own_stream = false;
     return CTK_OK;
 }
+
+void* ctk_get_stream(const ctk_handle* h) { return h ? (void*)h->stream : nullptr; }
 
 int ctk_reset(ctk_handle* h, const float* draws, int draws_loc) {
     RES_Q(h);

@@ -214,8 +214,12 @@ int ctk_reset(ctk_handle* h, const float* draws, int draws_loc);
 
 const char* ctk_last_error(const ctk_handle* h); /* h may be NULL: last create() error       */
 
-/* Use an existing HIP stream (e.g. torch's current stream) for all work of this handle.     */
+/* Use an existing HIP stream (e.g. torch's current stream) for all work of this handle.  The handle's earlier work is ordered before
+ * what follows on the new stream by an event (no host synchronisation; the handle's OWN stream, if it is being replaced, is drained and
+ * destroyed).  ctk_get_stream: the stream the handle issues on right now — after ctk_resident_enable that is a high-priority stream of
+ * its own (see there), which a caller who queues dependent work elsewhere must order against.                                      */
 int ctk_set_stream(ctk_handle* h, void* hip_stream);
+void* ctk_get_stream(const ctk_handle* h);
 
 /* -------------------------------------------------------------------------------------------
  * parameters

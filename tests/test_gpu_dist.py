@@ -128,3 +128,31 @@ def test_p2p_single_rank_and_error_paths():
     for t in range(3):
         np.testing.assert_allclose(e.p2p_step(s), f.step(s), rtol=1e-5, atol=1e-6)
     e.close(); f.close()
+
+
+def test_set_stream_orders_by_event_and_get_stream_reports_it():
+    """ctk_set_stream used to synchronise the host on every rebind; now the handle's earlier work is ordered before the new
+    stream by an event.  A handle hopping between two torch streams every step computes what a handle on its own stream computes."""
+    import numpy as np
+    import torch
+    from control_toolkit_amd import CtkEngine
+    kw = dict(num_rollouts=512, mpc_horizon=30, dt=0.02, period_interpolation_inducing_points=5, seed=9)
+    a, b = CtkEngine("mppi", "ODE", **kw), CtkEngine("mppi", "ODE", **kw)
+    own = b.get_stream()
+    assert own != 0
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    s = np.array([0.05, -0.1, 2.8, 0.4], np.float32)
+    for t in range(8):
+        st = streams[t & 1]
+        b.set_stream(st.cuda_stream)
+        assert b.get_stream() == st.cuda_stream
+        b.set_stream(st.cuda_stream)                                  # rebinding to the same stream is a no-op
+        np.testing.assert_array_equal(b.step(s), a.step(s))
+        s = s + np.array([0.01, 0.0, -0.02, 0.01], np.float32)
+    np.testing.assert_array_equal(b.read("U_NOM"), a.read("U_NOM"))
+    b.resident_enable(True, 200.0)                                    # a handle on a caller's stream keeps it (include/ctk_hip.h)
+    assert b.get_stream() == streams[1].cuda_stream
+    a.resident_enable(True, 200.0)                                    # ... a handle on its own stream moves to a high-priority one
+    np.testing.assert_array_equal(b.step(s), a.step(s))
+    assert a.get_stream() != 0
+    a.close(); b.close()
