@@ -171,10 +171,12 @@ class template_optimizer:
         name = (self._engine_options.get("environment_name") or getattr(self.cost_function, "environment_name", None)
                 or getattr(self.predictor, "environment_name", None) or "CartPole")
         stem = str(name).replace("-", "").replace("_", "").lower()
-        for built in ENVIRONMENTS:
-            if stem.startswith(built.lower()):
+        from .._capi import USER_ENVIRONMENTS
+        for built in list(ENVIRONMENTS) + list(USER_ENVIRONMENTS):
+            if stem.startswith(built.replace("_", "").lower()):
                 return built
-        raise NotImplementedError(f"environment {name!r} is not built into libctk_hip.so (have: {sorted(ENVIRONMENTS)})")
+        raise NotImplementedError(f"environment {name!r} is not built into libctk_hip.so (have: {sorted(ENVIRONMENTS)}) nor registered as a user "
+                                  f"environment ({sorted(USER_ENVIRONMENTS)}; control_toolkit_amd.build_env.register_environment)")
 
     def _resolve_predictor(self, dt, predictor_specification):
         """(kind, intermediate_steps, weights) from whatever predictor object the controller passed in.  The build's own

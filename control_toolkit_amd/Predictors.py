@@ -73,8 +73,8 @@ def check_network_sizes(spec, sizes, num_states: int, num_control_inputs: int, k
 
 def built_environment(name) -> str:
     stem = str(name or "CartPole").replace("-", "").replace("_", "").lower()
-    for built in ENVIRONMENT_DIMS:
-        if stem.startswith(built.lower()):
+    for built in ENVIRONMENT_DIMS:                  # (user environments are added here by build_env.register_environment)
+        if stem.startswith(built.replace("_", "").lower()):
             return built
     raise NotImplementedError(f"environment {name!r} is not built (have: {sorted(ENVIRONMENT_DIMS)})")
 

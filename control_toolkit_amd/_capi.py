@@ -81,6 +81,7 @@ SYMBOLS = {
     "ctk_env_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ctk_param_name": (C.c_char_p, [C.c_int, C.c_int]),
     "ctk_environment_name": (C.c_char_p, [C.c_int]),
+    "ctk_param_default": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "ctk_predictor_weight_count": (C.c_size_t, [_H]),
     "ctk_set_predictor_weights": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
     "ctk_predictor_weight_count_shaped": (C.c_size_t, [_H, C.c_int, C.c_int]),
@@ -126,10 +127,22 @@ SYMBOLS = {
 }
 
 
-def load_library():
+# user environments (include/ctk_user_env.h): name -> path of the library that was compiled with that model (control_toolkit_amd/build_env.py:
+# register_environment); their environment id inside that library is CTK_ENV_USER
+USER_ENVIRONMENTS = {}
+ENV_USER = 3
+_user_libs = {}
+
+
+def load_library(path: str = None):
     """Load libctk_hip.so (built in-tree by control_toolkit_amd/csrc/Makefile).  Raises CtkError
-    if it is missing — there is deliberately no other implementation to fall back to."""
+    if it is missing — there is deliberately no other implementation to fall back to.
+    path: a library compiled with a user environment (build_env.py); every such library carries the whole engine."""
     global _lib
+    if path is not None:
+        if path not in _user_libs:
+            _user_libs[path] = _bind_library(path)
+        return _user_libs[path]
     if _lib is not None:
         return _lib
     # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one
@@ -140,7 +153,15 @@ def load_library():
         import torch  # noqa: F401
     except ImportError:
         pass
-    path = library_path()
+    _lib = _bind_library(library_path())
+    return _lib
+
+
+def _bind_library(path: str):
+    try:
+        import torch  # noqa: F401  (see load_library: one HIP runtime per process)
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise CtkError(f"{path} not found: build it with `make -C control_toolkit_amd/csrc` "
                        f"(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
@@ -152,20 +173,40 @@ def load_library():
         fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
     if lib.ctk_abi_version() != 6:
-        raise CtkError("libctk_hip.so ABI version mismatch")
-    _lib = lib
+        raise CtkError(f"{path}: ABI version mismatch")
     return lib
+
+
+def environment_library(name: str):
+    """(library, environment id) that implement environment `name`: the product library for the built ones, the library compiled
+    with the model for a registered user environment"""
+    if name in ENVIRONMENTS:
+        return load_library(), ENVIRONMENTS[name]
+    if name in USER_ENVIRONMENTS:
+        return load_library(USER_ENVIRONMENTS[name]), ENV_USER
+    raise NotImplementedError(f"environment {name!r} is not built (have: {sorted(ENVIRONMENTS)} + registered user environments "
+                              f"{sorted(USER_ENVIRONMENTS)}; control_toolkit_amd.build_env.register_environment compiles a model header)")
 
 
 def environment_info(name: str):
     """(S, C, parameter names in id order) of an environment, as the library defines them (ctk_env_info / ctk_param_name)."""
-    if name not in ENVIRONMENTS:
-        raise NotImplementedError(f"environment {name!r} is not built (have: {sorted(ENVIRONMENTS)})")
-    lib, eid = load_library(), ENVIRONMENTS[name]
+    lib, eid = environment_library(name)
     S, Cn, n = C.c_int(), C.c_int(), C.c_int()
     if lib.ctk_env_info(eid, C.byref(S), C.byref(Cn), C.byref(n)) != 0:
         raise CtkError(f"ctk_env_info({name}) failed")
     return S.value, Cn.value, tuple(lib.ctk_param_name(eid, i).decode() for i in range(n.value))
+
+
+def environment_defaults(name: str) -> dict:
+    """parameter name -> the value a new handle starts with (ctk_param_default)"""
+    lib, eid = environment_library(name)
+    _, _, names = environment_info(name)
+    out, v = {}, C.c_float()
+    for i, n in enumerate(names):
+        if lib.ctk_param_default(eid, i, C.byref(v)) != 0:
+            raise CtkError(f"ctk_param_default({name}, {i}) failed")
+        out[n] = float(v.value)
+    return out
 
 
 def _ptr(a: Optional[np.ndarray]):
@@ -191,7 +232,7 @@ class CtkEngine:
         cost the kernels implement ("CartPole", "Quad2D", "Hover"); num_states / num_control_inputs default to its dimensions and
         are checked against them.  generic_kernels: run the environment-agnostic template kernels even where a hand-tuned
         one exists."""
-        lib = load_library()
+        lib, env_id = environment_library(environment)
         S, Cn, self.param_names = environment_info(environment)
         self.environment, self.S, self.C = environment, S, Cn
         num_states = S if num_states is None else num_states
@@ -211,7 +252,7 @@ class CtkEngine:
         cfg.global_rollout_offset = int(global_rollout_offset)
         cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         cfg.dt = float(dt)
-        cfg.environment, cfg.generic_kernels = ENVIRONMENTS[environment], int(bool(generic_kernels))
+        cfg.environment, cfg.generic_kernels = env_id, int(bool(generic_kernels))
         # hidden widths of a network predictor (the <h1>H1-<h2>H2 of the reference's network names): widths above 32 (MLP, up to 64) build
         # the handle on the 64-unit kernels; narrower networks are embedded exactly when their weights are set
         self.predictor_hidden = None if predictor_hidden is None else (int(predictor_hidden[0]), int(predictor_hidden[1]))

@@ -338,8 +338,13 @@ const EnvInfo kEnvs[CTK_ENV_COUNT] = {
     {"CartPole", Env<CTK_ENV_CARTPOLE>::S, Env<CTK_ENV_CARTPOLE>::C, CTK_P_COUNT, kCartPoleNames, kCartPoleDefaults},
     {"Quad2D", Env<CTK_ENV_QUAD2D>::S, Env<CTK_ENV_QUAD2D>::C, CTK_Q_COUNT, kQuadNames, kQuadDefaults},
     {"Hover", Env<CTK_ENV_HOVER>::S, Env<CTK_ENV_HOVER>::C, CTK_V_COUNT, kHoverNames, kHoverDefaults},
+#ifdef CTK_USER_ENV_HEADER
+    {CtkUserEnv::NAME, CtkUserEnv::S, CtkUserEnv::C, CtkUserEnv::NP, CtkUserEnv::PARAM_NAMES, CtkUserEnv::PARAM_DEFAULTS},    // CTK_ENV_USER
+#else
+    {nullptr, 0, 0, 0, nullptr, nullptr},              // CTK_ENV_USER: only in a library built with a user model (build_env.py)
+#endif
 };
-const EnvInfo* env_info(int env) { return (env >= 0 && env < CTK_ENV_COUNT) ? &kEnvs[env] : nullptr; }
+const EnvInfo* env_info(int env) { return (env >= 0 && env < CTK_ENV_COUNT && kEnvs[env].name != nullptr) ? &kEnvs[env] : nullptr; }
 
 // Per-lane operand tables of the GRU under the template kernels (ctk_net.h: NetGru — one wave per 16-trajectory tile, operands
 // staged in LDS): forward [232][64] then reverse [172][64], for a network with I = S + C <= 8 inputs and S <= 8 outputs.
@@ -1158,7 +1163,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     if (cfg->struct_size != sizeof(ctk_config))
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: ctk_config size mismatch (ABI)");
     const EnvInfo* einfo = env_info(cfg->environment);
-    if (!einfo) return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: unknown environment (built: CartPole, Quad2D, Hover)");
+    if (!einfo) return fail(nullptr, CTK_ERR_UNSUPPORTED, "ctk_create: unknown environment (built: CartPole, Quad2D, Hover; CTK_ENV_USER only in a library compiled with a user model, control_toolkit_amd/build_env.py)");
     if (cfg->num_states != einfo->S || cfg->num_control_inputs != einfo->C)
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, std::string("ctk_create: environment ") + einfo->name + " has num_states == " +
                     std::to_string(einfo->S) + ", num_control_inputs == " + std::to_string(einfo->C));
@@ -1456,6 +1461,13 @@ int ctk_env_info(int environment, int* num_states, int* num_control_inputs, int*
 const char* ctk_param_name(int environment, int id) {
     const EnvInfo* e = env_info(environment);
     return (e && id >= 0 && id < e->n_params) ? e->param_names[id] : nullptr;
+}
+
+int ctk_param_default(int environment, int id, float* value) {
+    const EnvInfo* e = env_info(environment);
+    if (!e || !value || id < 0 || id >= e->n_params) return CTK_ERR_INVALID_ARGUMENT;
+    *value = e->param_defaults[id];
+    return CTK_OK;
 }
 
 const char* ctk_environment_name(int environment) {

@@ -545,10 +545,76 @@ CTK_DEV void recur_env_range(const typename Env<ENV>::K& k, float* traj, bool va
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// A USER environment, compiled in at configure time (include/ctk_user_env.h says what the header must define; the reference imports its
+// concrete cost class and plant model at run time, cost_function_wrapper.py:59-66 / controller_mpc.py:43,67-73 — here the model is C++
+// that control_toolkit_amd/build_env.py compiles, with every optimizer kernel instantiated for it, into a library of its own).
+// EnvFromModel turns the mathematical minimum — step, state / input / terminal cost, and for the gradient optimizers the step's
+// vector-Jacobian product and the cost gradients — into the full hook set of the template kernels.
+// ---------------------------------------------------------------------------------------------------------------
+template <class M>
+struct EnvFromModel {
+    static constexpr int S = M::S, C = M::C;
+    using K = typename M::K;
+    static K derive(const float* p, float dt, int isteps) { return M::derive(p, dt, isteps); }
+    CTK_DEV static void step(const K& k, float (&s)[S], const float (&u)[C]) { M::step(k, s, u); }
+    CTK_DEV static float stage_cost(const K& k, const float (&s)[S], const float (&u)[C], const float (&up)[C]) {
+        return M::state_cost(k, s) + M::input_cost(k, u, up);
+    }
+    CTK_DEV static float terminal_cost(const K& k, const float (&s)[S]) { return M::terminal_cost(k, s); }
+    // hooks of the 4-wave rollout kernels: the stage cost is state part + input-only part by construction of the model interface; no
+    // range-limited fast path (the checked sin / cos always), inputs consumed as they are
+    static constexpr bool SEPARABLE = true;
+    CTK_DEV static float input_cost(const K& k, const float (&u)[C], const float (&up)[C]) { return M::input_cost(k, u, up); }
+    CTK_DEV static float prep_input(const K&, float u, int) { return u; }
+    CTK_DEV static bool fast_ok(const K&) { return false; }
+    CTK_DEV static bool out_of_range(float) { return false; }
+    template <bool FAST>
+    CTK_DEV static void cost_step(const K& k, float (&s)[S], const float (&u)[C], float& csum, float&) {
+        csum += M::state_cost(k, s);
+        M::step(k, s, u);
+    }
+    // hooks of the descent kernels: the tape is the state itself
+    static constexpr int NT = S;
+    CTK_DEV static void fwd_tape(const K& k, float (&s)[S], const float (&u)[C], float (&tp)[NT]) {
+#pragma unroll
+        for (int i = 0; i < S; ++i) tp[i] = s[i];
+        M::step(k, s, u);
+    }
+    CTK_DEV static void bwd_tape(const K& k, const float (&tp)[NT], const float (&u)[C], float (&lam)[S], float (&du)[C], float inv) {
+        float s[S], ds[S], gs[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) s[i] = tp[i];
+        M::step_vjp(k, s, u, lam, ds, du);
+        M::stage_grad_state(k, s, gs);
+#pragma unroll
+        for (int i = 0; i < S; ++i) lam[i] = gs[i] * inv + ds[i];
+    }
+    CTK_DEV static void step_vjp(const K& k, const float (&s)[S], const float (&u)[C], const float (&lam)[S], float (&ds)[S], float (&du)[C]) {
+        M::step_vjp(k, s, u, lam, ds, du);
+    }
+    CTK_DEV static void stage_grad_state(const K& k, const float (&s)[S], float (&g)[S]) { M::stage_grad_state(k, s, g); }
+    CTK_DEV static void terminal_grad(const K& k, const float (&s)[S], float (&g)[S]) { M::terminal_grad(k, s, g); }
+    CTK_DEV static void input_grad(const K& k, const float (&u)[C], const float (&up)[C], float (&gu)[C], float (&gp)[C]) { M::input_grad(k, u, up, gu, gp); }
+};
+
+#ifdef CTK_USER_ENV_HEADER
+#include CTK_USER_ENV_HEADER                      // struct CtkUserEnv
+static_assert(CtkUserEnv::S >= 1 && CtkUserEnv::S <= CTK_MAX_STATES && CtkUserEnv::C >= 1 && CtkUserEnv::C <= CTK_MAX_INPUTS,
+              "user environment: 1 <= S <= 8 states, 1 <= C <= 4 control inputs");
+static_assert(CtkUserEnv::NP >= 1 && CtkUserEnv::NP <= CTK_MAX_PARAMS, "user environment: 1 <= NP <= 32 parameters");
+template <>
+struct Env<CTK_ENV_USER> : EnvFromModel<CtkUserEnv> {};
+#define CTK_FOR_ENV_USER_BRANCH(id, ENVV, ...) else if ((id) == CTK_ENV_USER) { constexpr int ENVV = CTK_ENV_USER; __VA_ARGS__; }
+#else
+#define CTK_FOR_ENV_USER_BRANCH(id, ENVV, ...)
+#endif
+
 // dispatch on the runtime environment id: CTK_FOR_ENV(id, ENVV, stmt) runs `stmt` with the constant ENVV
 #define CTK_FOR_ENV(id, ENVV, ...)                                              \
     do {                                                                        \
         if ((id) == CTK_ENV_CARTPOLE) { constexpr int ENVV = CTK_ENV_CARTPOLE; __VA_ARGS__; } \
         else if ((id) == CTK_ENV_QUAD2D) { constexpr int ENVV = CTK_ENV_QUAD2D; __VA_ARGS__; } \
+        CTK_FOR_ENV_USER_BRANCH(id, ENVV, __VA_ARGS__)                          \
         else { constexpr int ENVV = CTK_ENV_HOVER; __VA_ARGS__; }             \
     } while (0)

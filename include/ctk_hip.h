@@ -75,6 +75,11 @@ typedef enum ctk_environment {
     CTK_ENV_HOVER = 2,    /* planar hovercraft with a reaction wheel: S 7 (x, vx, y, vy, theta, omega, wheel speed), C 3 (main
                              thruster, lateral thruster, wheel torque); S + C = 10 network inputs: the environment that
                              exercises a third layer-1 k-step of the network predictors; parameters: enum ctk_param_hover */
+    CTK_ENV_USER = 3,     /* an environment supplied by the USER as a C++ model header (include/ctk_user_env.h) and compiled into a
+                             library of its own at configure time (control_toolkit_amd/build_env.py) — the reference imports the concrete
+                             cost class and the plant model at run time (cost_function_wrapper.py:59-66, controller_mpc.py:43,67-73), and
+                             its own precedent for compile-at-configure is Controllers/controller_C.py:140-248.  Present only in a
+                             library built with such a header (ctk_env_info reports it); parameters: the header's own list        */
     CTK_ENV_COUNT
 } ctk_environment;
 
@@ -230,7 +235,8 @@ int ctk_get_param(const ctk_handle* h, int id, float* value);
  * the dynamics section).  Any output pointer may be NULL.                                                      */
 int ctk_env_info(int environment, int* num_states, int* num_control_inputs, int* n_params);
 const char* ctk_param_name(int environment, int id);       /* NULL if out of range */
-const char* ctk_environment_name(int environment);         /* "CartPole", "Quad2D"; NULL if unknown */
+const char* ctk_environment_name(int environment);         /* "CartPole", "Quad2D", ...; the model's NAME for CTK_ENV_USER; NULL if unknown */
+int ctk_param_default(int environment, int id, float* value);  /* the value a new handle starts with (ABI v6)                         */
 /* Network weights, flat fp32, I = S + C inputs, S outputs (CartPole: I 5, S 4):
  *   MLP: W1[32,I] b1[32] W2[32,32] b2[32] W3[S,32] b3[S]                       (CartPole 1380 floats)
  *   GRU: per layer W_i[96,I'] W_h[96,32] b_i[96] b_h[96] (rows r|z|n, I' = I then 32), then

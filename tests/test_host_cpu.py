@@ -252,3 +252,35 @@ def test_network_name_convention_is_parsed_and_checked():
     assert p.kind == "MLP" and p.hidden_sizes == (16, 24)
     with pytest.raises(ValueError, match="expects"):
         p.configure(batch_size=8, dt=0.02, predictor_specification="Dense-5IN-16H1-16H2-4OUT-0")
+
+
+def test_user_environment_library_builds_and_describes_itself():
+    """a plant + cost that is not in csrc/: tests/envs/pendulum_env.h compiled by control_toolkit_amd/build_env.py into a library of its own
+    (hipcc cross-compiles without a GPU; cached by content, so only the first run pays the ~1 minute).  No compute calls here."""
+    import os
+    from control_toolkit_amd import _capi
+    from control_toolkit_amd.build_env import build_environment, environment_name_of, register_environment
+    header = os.path.join(os.path.dirname(os.path.abspath(__file__)), "envs", "pendulum_env.h")
+    assert environment_name_of(header) == "Pendulum"
+    name, lib = build_environment(header)
+    assert name == "Pendulum" and os.path.exists(lib) and "_env_builds" in lib
+    assert build_environment(header)[1] == lib                         # cache hit: same content, same library
+    assert register_environment(header) == "Pendulum"
+    S, C, names = _capi.environment_info("Pendulum")
+    assert (S, C) == (2, 1) and names[0] == "g" and names[-1] == "terminal_weight" and len(names) == 11
+    assert _capi.environment_defaults("Pendulum")["torque_gain"] == 12.0
+    ulib, eid = _capi.environment_library("Pendulum")
+    assert eid == 3 and ulib.ctk_abi_version() == _capi.load_library().ctk_abi_version()
+    for sym in _capi.SYMBOLS:                                          # the user library is the whole engine: every declared symbol
+        assert hasattr(ulib, sym), sym
+    assert _capi.load_library().ctk_environment_name(3) is None        # the product library has no fourth environment
+    with pytest.raises(NotImplementedError, match="register_environment"):
+        _capi.environment_info("Acrobot")
+    # the host-side wrappers resolve the registered name
+    from control_toolkit_amd.Predictors import PredictorWrapper
+    from control_toolkit_amd.Cost_Functions import CostFunctionWrapper
+    assert PredictorWrapper(environment_name="Pendulum").num_states == 2
+    cw = CostFunctionWrapper({"ang_weight": 70.0}, watch=False, environment_name="Pendulum")
+    assert cw.parameters["ang_weight"] == 70.0 and cw.parameters["damping"] == pytest.approx(0.1)
+    with pytest.raises(ValueError, match="unknown cost parameters"):
+        CostFunctionWrapper({"dd_weight": 1.0}, watch=False, environment_name="Pendulum")
