@@ -53,6 +53,8 @@ WORKLOADS = {
     # BASELINE configs[4]: the sharded configuration (strong scaling: N is split over the ranks)
     "mppi_cfg5": dict(opt="mppi", pred="MLP", N=65536, H=100, p=10, kw={}),
     "mppi_cfg5_shard": dict(opt="mppi", pred="MLP", N=8192, H=100, p=10, kw={}),   # one rank's share at G = 8
+    "mppi_cfg5_shard_g4": dict(opt="mppi", pred="MLP", N=16384, H=100, p=10, kw={}),   # ... at G = 4 (rehearsal of the curve's points on one GPU)
+    "mppi_cfg5_shard_g2": dict(opt="mppi", pred="MLP", N=32768, H=100, p=10, kw={}),   # ... at G = 2
     # recurrent predictor (2x32 GRU) at the headline MPPI size
     "mppi_gru": dict(opt="mppi", pred="GRU", N=1024, H=50, p=1, kw={}),
     "mppi_mlp": dict(opt="mppi", pred="MLP", N=1024, H=50, p=1, kw={}),

@@ -52,19 +52,25 @@ def build_environment(header_path: str, jobs: int = 8, verbose: bool = False):
     out_dir = os.path.join(_OUT, f"{name}_{_digest(open(header_path, 'rb').read())}")
     lib = os.path.join(out_dir, f"libctk_hip_{name}.so")
     if not os.path.exists(lib):
+        import fcntl
         os.makedirs(out_dir, exist_ok=True)
-        # the build reads a COPY of the header next to the objects: the library stays valid when the original moves
-        copy = os.path.join(out_dir, "user_env.h")
-        with open(copy, "wb") as f:
-            f.write(open(header_path, "rb").read())
-        cmd = ["make", "-C", _CSRC, f"-j{jobs}", f"BUILD={os.path.join(out_dir, 'obj')}", f"LIB={lib}",
-               f"EXTRA=-DCTK_USER_ENV_HEADER='\"{copy}\"'", f"USER_ENV_DEP={copy}"]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0 or not os.path.exists(lib):
-            tail = "\n".join((r.stdout + "\n" + r.stderr).splitlines()[-40:])
-            raise RuntimeError(f"building the environment {name!r} from {header_path} failed (hipcc):\n{tail}")
-        if verbose:
-            print(r.stdout[-2000:])
+        with open(os.path.join(out_dir, ".lock"), "w") as lock:          # two processes asking for the same model: one builds, the other waits
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if not os.path.exists(lib):
+                if any(ch in out_dir for ch in " '\""):
+                    raise ValueError(f"{out_dir}: the build path is handed to make / the shell unquoted; no spaces or quotes in it, please")
+                # the build reads a COPY of the header next to the objects: the library stays valid when the original moves
+                copy = os.path.join(out_dir, "user_env.h")
+                with open(copy, "wb") as f:
+                    f.write(open(header_path, "rb").read())
+                cmd = ["make", "-C", _CSRC, f"-j{max(1, min(jobs, os.cpu_count() or 1))}", f"BUILD={os.path.join(out_dir, 'obj')}", f"LIB={lib}",
+                       f"EXTRA=-DCTK_USER_ENV_HEADER='\"{copy}\"'", f"USER_ENV_DEP={copy}"]
+                r = subprocess.run(cmd, capture_output=True, text=True)
+                if r.returncode != 0 or not os.path.exists(lib):
+                    tail = "\n".join((r.stdout + "\n" + r.stderr).splitlines()[-40:])
+                    raise RuntimeError(f"building the environment {name!r} from {header_path} failed (hipcc):\n{tail}")
+                if verbose:
+                    print(r.stdout[-2000:])
     return name, lib
 
 
