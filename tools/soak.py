@@ -32,8 +32,25 @@ others = {
  "hover_mppi_mlp": CtkEngine("mppi", "MLP", environment="Hover", num_rollouts=256, mpc_horizon=20, dt=0.02, seed=16, period_interpolation_inducing_points=4),
  "hover_rpgd": CtkEngine("rpgd", "ODE", environment="Hover", num_rollouts=48, mpc_horizon=16, dt=0.02, seed=17, outer_its=2, resamp_per=4, opt_keep_k=12, sampling_distribution=0, period_interpolation_inducing_points=4),
 }
+# round 4: the in-launch merge of 256 narrow records (one rank's share of configs[4]), the 64-unit MLP on the one-wave template kernels, a 16 / 24
+# network embedded into the 32-unit kernels, RPGD with materialised trajectories (the logging rollout), a USER environment (tests/envs/pendulum_env.h)
+engs.update({
+ "mppi_cfg5_shard": CtkEngine("mppi", "MLP", num_rollouts=8192, mpc_horizon=100, dt=0.02, seed=23, period_interpolation_inducing_points=10),
+ "mppi_mlp_h64": CtkEngine("mppi", "MLP", num_rollouts=512, mpc_horizon=30, dt=0.02, seed=24, period_interpolation_inducing_points=5, predictor_hidden=(64, 48)),
+ "rpgd_mlp_h64": CtkEngine("rpgd", "MLP", num_rollouts=48, mpc_horizon=16, dt=0.02, seed=25, outer_its=2, resamp_per=5, opt_keep_k=12, sampling_distribution=0, period_interpolation_inducing_points=4, predictor_hidden=(64, 64)),
+ "mppi_mlp_h16": CtkEngine("mppi", "MLP", num_rollouts=512, mpc_horizon=30, dt=0.02, seed=26, period_interpolation_inducing_points=5, predictor_hidden=(16, 24)),
+ "rpgd_log": CtkEngine("rpgd", "ODE", num_rollouts=96, mpc_horizon=20, dt=0.02, seed=27, outer_its=2, resamp_per=3, opt_keep_k=24, sampling_distribution=0, period_interpolation_inducing_points=5, materialize_trajectories=True),
+})
+assert engs["mppi_cfg5_shard"].dominant_kernel().startswith("ctk_mppi_rollout<0, 3")
+from control_toolkit_amd.build_env import register_environment
+register_environment(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "envs", "pendulum_env.h"))
+others_user = {
+ "pend_mppi": CtkEngine("mppi", "ODE", environment="Pendulum", num_rollouts=1024, mpc_horizon=40, dt=0.02, seed=28),
+ "pend_cem": CtkEngine("cem", "ODE", environment="Pendulum", num_rollouts=512, mpc_horizon=25, dt=0.02, seed=29, cem_outer_it=3, cem_best_k=50),
+ "pend_rpgd": CtkEngine("rpgd", "ODE", environment="Pendulum", num_rollouts=64, mpc_horizon=20, dt=0.02, seed=30, outer_its=3, resamp_per=4, opt_keep_k=16, sampling_distribution=0, period_interpolation_inducing_points=5),
+}
 for k, e in list(engs.items()) + list(others.items()):
-    n = e.predictor_weight_count()
+    n = e.predictor_weight_count(getattr(e, "predictor_hidden", None))
     if n and k not in ("mppi_mlp", "rpgd_mlp"):
         e.set_predictor_weights((np.random.default_rng(20).standard_normal(n) * 0.15).astype(np.float32))
 # the resident form under two regimes: idle time shorter than the gap between its steps here (it leaves and is launched again every step) and longer
@@ -41,12 +58,14 @@ engs["mppi_res_short"] = CtkEngine("mppi", "ODE", num_rollouts=1024, mpc_horizon
 engs["mppi_res_long"] = CtkEngine("mppi", "ODE", num_rollouts=512, mpc_horizon=30, dt=0.02, seed=22, period_interpolation_inducing_points=5)
 engs["mppi_res_short"].resident_enable(True, 50.0)
 engs["mppi_res_long"].resident_enable(True, 50000.0)
-for k in ("rpgd_gru_t", "rpgd_mlp_t"):
+for k in ("rpgd_gru_t", "rpgd_mlp_t", "rpgd_mlp_h64", "rpgd_log"):
     engs[k].reset()
 others["hover_rpgd"].reset()
+others_user["pend_rpgd"].reset()
+others.update(others_user)
 ostate = {k: np.zeros(e.S, np.float32) for k, e in others.items()}
 for v in ostate.values():
-    v[:3] = [0.1, 0.0, 0.2]
+    v[:min(3, v.size)] = [0.1, 0.0, 0.2][:min(3, v.size)]
 _w = (np.random.default_rng(11).standard_normal(engs["mppi_mlp"].predictor_weight_count()) * 0.15).astype(np.float32)
 engs["mppi_mlp"].set_predictor_weights(_w); engs["rpgd_mlp"].set_predictor_weights(_w)
 engs["rpgd"].reset(); engs["rpgd_mlp"].reset()
@@ -69,7 +88,9 @@ for i in range(STEPS):
         u = e.step(ostate[k])
         slow[k] = max(slow.get(k, 0.0), time.perf_counter() - _t0) if i > 5 else 0.0
         assert np.isfinite(u).all() and (np.abs(u) <= 1.0 + 1e-6).all(), (k, i, u)
-        ostate[k][0] = 0.1 + 0.05 * np.sin(0.01 * i); ostate[k][2] = 0.2 + 0.05 * np.cos(0.013 * i)
+        ostate[k][0] = 0.1 + 0.05 * np.sin(0.01 * i)
+        if e.S > 2:
+            ostate[k][2] = 0.2 + 0.05 * np.cos(0.013 * i)
     if i % 97 == 0:
         engs["mppi"].set_param("target_position", float(rng.uniform(-0.2, 0.2)))
         st = engs["cem"].get_state(); engs["cem"].set_state(st)
@@ -77,6 +98,7 @@ for i in range(STEPS):
         engs["mppi"].reset(); engs["rand"].reset()
         a = engs["mppi_log"].log_read("J", max(0, engs["mppi_log"].log_count() - 10), min(10, engs["mppi_log"].log_count()))
         assert np.isfinite(a).all()
+        assert np.isfinite(engs["rpgd_log"].read("TRAJ")).all() and engs["rpgd_log"].read("AGES_LOGGED").min() >= 0
 print("slowest step per engine (ms):", {k: round(v * 1e3, 2) for k, v in slow.items()})
 print("resident:", {k: engs[k].resident_stats() for k in ("mppi_res_short", "mppi_res_long")})
 print("soak ok", time.time() - t0, "s;", {k: [round(float(x), 3) for x in v] for k, v in states.items()})
