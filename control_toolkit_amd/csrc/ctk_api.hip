@@ -597,13 +597,26 @@ int finish_step(ctk_handle* h, float* u_out) {
     // arrived / non-finite gradient, ctk_net_split.hip: rpgd_jac_worker + the update's tile_bad) — the published
     // result is NaN or built from a stale record, never silently wrong
     volatile uint32_t* errw = reinterpret_cast<volatile uint32_t*>(h->h_u) + 2;
-    if (const uint32_t dev_err = *errw) {
-        *errw = 0;
+    const uint32_t dev_err = errw[0], bad_tile = errw[1];              // (word 3: a tile of the RPGD update saw a non-finite gradient norm)
+    if (dev_err || bad_tile) {
+        errw[0] = 0; errw[1] = 0;
+        if (dev_err == 3) {
+            char msg[512];
+            const uint32_t where = errw[6], seen = errw[7], want = errw[8], us = errw[9];
+            std::snprintf(msg, sizeof msg, "RPGD: an in-launch Jacobian hand-off timed out (flag %u of step %u, tile %u: held %u, awaited %u, for %u us); "
+                          "that iteration's update was skipped for the tile (its plans and Adam moments are as before it) — the returned control "
+                          "comes from a population that missed an update", where >> 20, (where >> 10) & 1023u, where & 1023u, seen, want, us);
+            return fail(h, CTK_ERR_STATE, msg);
+        }
+        if (dev_err == 0) {
+            char msg[384];
+            std::snprintf(msg, sizeof msg, "RPGD: the gradient of a plan of tile %u was not finite (a rollout that diverged); that iteration's update "
+                          "was skipped for the tile (its plans and Adam moments are as before it) — the returned control comes from a population "
+                          "that missed an update", bad_tile - 1);
+            return fail(h, CTK_ERR_STATE, msg);
+        }
         return fail(h, CTK_ERR_STATE, dev_err == 1 ? "timed out waiting for a peer's record (a rank is gone or out of step)"
-                                      : dev_err == 3 ? "RPGD: an in-launch Jacobian hand-off timed out or a plan's gradient was not finite; that iteration's "
-                                                       "update was skipped for the tile (its plans and Adam moments are as before it) — the returned "
-                                                       "control comes from a population that missed an update"
-                                                     : "in-launch record hand-off timed out (a workgroup's record never arrived)");
+                                                   : "in-launch record hand-off timed out (a workgroup's record never arrived)");
     }
     return h->log_cap ? log_step(h) : CTK_OK;
 }

@@ -327,12 +327,10 @@ CTK_DEV float4 ld4_through(const float4* p) {
     return make_float4(__builtin_bit_cast(float, (uint32_t)a), __builtin_bit_cast(float, (uint32_t)(a >> 32)), __builtin_bit_cast(float, (uint32_t)b),
                        __builtin_bit_cast(float, (uint32_t)(b >> 32)));
 }
-// flag i == seq?  nap: poll seldom (the producer is steps away).  false: gave up (1 << 17 polls)
-CTK_DEV bool await_flag(const uint32_t* flag, uint32_t seq, bool nap) {
-    uint32_t v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int spin = 0; v != seq && spin < (1 << 17); ++spin) {
-        if (nap) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(2);
-        v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return v == seq;
+// One flag word polled by a whole wave.  Every lane asks for the same word, but the memory pipeline serves a wave's lanes in groups: a store
+// that lands between two groups shows some lanes the old value and others the new one (seen under a loaded GPU, about once in 10^4
+// launches: tools/soak_handoff.py) — and the compiler, which takes a load from a wave-uniform address to be wave-uniform, leaves the poll
+// loop as soon as ANY lane is satisfied.  The wave goes by lane 0's answer, as a scalar.
+CTK_DEV uint32_t load_flag_wave(const uint32_t* flag) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }

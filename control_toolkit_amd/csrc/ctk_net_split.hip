@@ -708,12 +708,26 @@ CTK_DEV void rpgd_jac_worker(const RolloutArgs& a, const typename Env<ENV>::K& k
     const MlpFwdW w = mlp_load_fwd(wperm);
     float* base = scratch + (size_t)tile * gw_tile_floats(H, C);
     const uint32_t* flags = reinterpret_cast<const uint32_t*>(base + gw_flag_off(H, C));
+    // the error word's neighbours take what a poll that ran out saw (h_u words 8..11: which flag of which (step, tile), the value it last
+    // held, the sequence number awaited, and the wait in microseconds) — the message of the failed step quotes them
+    auto gave_up = [&](int i, uint32_t v, unsigned long long t_begin) {
+        if (err_word == nullptr || (threadIdx.x & 63) != 0) return;
+        const unsigned long long us = (wall_clock64() - t_begin) / 100u;                       // (the 100 MHz constant clock)
+        __hip_atomic_store(err_word + 6, ((uint32_t)i << 20) | ((uint32_t)h << 10) | (uint32_t)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(err_word + 7, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(err_word + 8, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(err_word + 9, (uint32_t)(us > 0xffffffffull ? 0xffffffffull : us), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(err_word, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
     auto await = [&](int i, int nap) {                                 // flag i; false: gave up
-        uint32_t v = __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t v = load_flag_wave(flags + i);                        // (wave-uniform by construction: ctk_device.h)
+        if (v == seq) return true;
+        const unsigned long long t_begin = wall_clock64();
         for (int spin = 0; v != seq && spin < (1 << 17); ++spin) {
             if (nap) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(2);
-            v = __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = load_flag_wave(flags + i);
         }
+        if (v != seq) gave_up(i, v, t_begin);
         return v == seq;
     };
     bool ok = true;
@@ -724,8 +738,6 @@ CTK_DEV void rpgd_jac_worker(const RolloutArgs& a, const typename Env<ENV>::K& k
     // (flag_through: counted wait, then the store), and nothing below may be satisfied from before the flag was seen.  The cost is on this
     // worker, not on the recurrence.
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (!__all(ok) && err_word != nullptr && threadIdx.x == 0)
-        __hip_atomic_store(err_word, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long* act = reinterpret_cast<const unsigned long long*>(base) + ((size_t)h * (2 * 2 * 64) + lane) * 2;   // [wave m][h1 | h2][64] float4
     f32x4 d1[2], d2[2];
     {
@@ -754,10 +766,7 @@ CTK_DEV void rpgd_jac_worker(const RolloutArgs& a, const typename Env<ENV>::K& k
     const int hh = wave == 0 ? h : H;
     if (wave == 0 || h == H - 1) {
         const bool got = hh < H ? __all(ok) : await(H * 2, 0);
-        if (hh == H) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (!got && err_word != nullptr && lane == 0) __hip_atomic_store(err_word, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        if (hh == H) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (g == 0) {
             const uint32_t* xs_u = reinterpret_cast<const uint32_t*>(base + gw_xs_off(H));
             float sx[S], gs[S];
@@ -965,7 +974,7 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
         // a plan whose gradient norm is not finite (a Jacobian record that never arrived is NaN; so is a rollout that diverged): the
         // whole tile keeps its plans and moments, and the step reports CTK_ERR_STATE
         const int tile_bad = __syncthreads_or(!(n2 <= 3.0e38f));
-        if (tile_bad && t == 0 && err_word != nullptr) __hip_atomic_store(err_word, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tile_bad && t == 0 && err_word != nullptr) __hip_atomic_store(err_word + 1, 1u + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (h_u word 3)
         const float scl = ad.clip / fmaxf(sqrtf(n2), ad.clip);
         if (wave == 0 && g == 0) red_s[64 + c] = scl;
         __syncthreads();

@@ -57,8 +57,8 @@ python tools/sweep_n.py > $O/sweep_n.txt 2> $O/sweep_n.err; say "sweep_n" $?
 python tools/bench_resident.py > $O/resident.txt 2> $O/resident.err; say "bench_resident" $?
 ./tools/diag_mailbox_vram >> $O/resident.txt 2>&1; say "mailbox diag" $?
 ./tools/diag_wave_placement > $O/placement.txt 2>&1; say "wave placement" $?
-python3 tools/soak_handoff.py 300 > $O/soak_handoff.txt 2>&1; say "soak hand-off" $?
-python tools/soak.py 500 > $O/soak.txt 2>&1; say "soak" $?
+python3 tools/soak_handoff.py 3000 > $O/soak_handoff.txt 2>&1; say "soak hand-off" $?
+python tools/soak.py 1500 > $O/soak.txt 2>&1; say "soak" $?
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_largen -o p -- python3 tools/large_n_once.py > /dev/null 2> $O/pmc_largen.err; say "pmc large-N insts" $?
 # 7. condense HERE, then drop the big CSVs
 cp gpurun_out/parity_margins.txt $O/parity_margins.txt 2>/dev/null
