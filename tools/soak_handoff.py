@@ -52,18 +52,60 @@ def run(steps):
     return out
 
 
+def run_records(steps):
+    """The other in-launch hand-offs — block records {value, seq} merged by the launch that produced them: MPPI (records of 8-byte words;
+    one rank's share of configs[4] with its 256 narrow records), the one-launch CEM, the template's MPPI — same comparison."""
+    from control_toolkit_amd import CtkEngine
+    out = {}
+    mk = {
+        "mppi_cfg3": lambda: CtkEngine("mppi", "ODE", num_rollouts=4096, mpc_horizon=50, dt=0.02, seed=41),
+        "mppi_shard": lambda: CtkEngine("mppi", "MLP", num_rollouts=8192, mpc_horizon=100, dt=0.02, seed=42, period_interpolation_inducing_points=10),
+        "cem_cfg3": lambda: CtkEngine("cem", "ODE", num_rollouts=4096, mpc_horizon=30, dt=0.02, seed=43, cem_outer_it=3, cem_best_k=409),
+        "quad_mppi": lambda: CtkEngine("mppi", "ODE", environment="Quad2D", num_rollouts=2048, mpc_horizon=30, dt=0.02, seed=44, period_interpolation_inducing_points=5),
+    }
+    def resident():
+        e = CtkEngine("mppi", "ODE", num_rollouts=1024, mpc_horizon=50, dt=0.02, seed=45)
+        e.resident_enable(True, 50000.0)                 # the mailbox kernel stays on the GPU between steps, beside the other process
+        return e
+    mk["mppi_resident"] = resident
+    for name, make in mk.items():
+        e = make()
+        n = e.predictor_weight_count()
+        if n: e.set_predictor_weights((np.random.default_rng(0).standard_normal(n) * 0.15).astype(np.float32))
+        s = (0.05 * np.arange(1, e.S + 1)).astype(np.float32)
+        us = []
+        for t in range(steps):
+            try:
+                u = np.asarray(e.step(s)).reshape(-1).copy()
+            except Exception as ex:
+                print(f"{name} step {t}: {ex}", flush=True)
+                ERRORS.append((name, t))
+                u = np.zeros(e.C, np.float32)
+            us.append(u)
+            s = (0.97 * s + 0.02 * np.resize(u, e.S) + 0.01 * np.sin(0.1 * t + np.arange(e.S))).astype(np.float32)
+        e.close()
+        out[name] = np.stack(us)
+    return out
+
+
 if __name__ == "__main__":
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     t0 = time.time()
     idle = run(steps)
     t_idle = time.time() - t0
-    load = subprocess.Popen([sys.executable, "-c", LOAD, str(3 * t_idle + 20)], stdout=subprocess.PIPE, text=True)
+    load = subprocess.Popen([sys.executable, "-c", LOAD, str(8 * t_idle + 40)], stdout=subprocess.PIPE, text=True)
     time.sleep(8)                                # the load process has created its engine and is stepping
     t0 = time.time()
     busy = run(steps)
     t_busy = time.time() - t0
+    busy_rec = run_records(steps)
     load.terminate(); load.wait()
+    idle_rec = run_records(steps)
     ok = True
+    for name in idle_rec:
+        same = np.array_equal(idle_rec[name], busy_rec[name]) and np.isfinite(busy_rec[name]).all()
+        ok &= same
+        print(f"{name:10s} {steps} steps, block records merged in the launch: idle GPU vs loaded GPU {'identical' if same else 'DIFFERENT'}; last u {busy_rec[name][-1]}")
     for env in idle:
         same = np.array_equal(idle[env], busy[env]) and np.isfinite(busy[env]).all()
         ok &= same
