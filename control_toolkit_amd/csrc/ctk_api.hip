@@ -63,6 +63,7 @@ struct ctk_handle {
     float* d_scale = nullptr;
     int* d_idx = nullptr;       // best indices [N]
     float* d_u = nullptr;       // optimizer's last output (device)
+    RpgdPersist rp_pers{64u, 0u, nullptr};   // the one-launch RPGD descent's hand-off numbers (ctk_rpgd.hip: ctk_rpgd_mlp_persistent)
     float* h_u = nullptr;       // pinned, coherent, device-visible host slot: {u, sequence number} written by ONE 8-B store
     float* h_u_dev = nullptr;   // device pointer aliasing h_u
     uint32_t seq = 1;           // sequence number the NEXT publishing kernel will write (the slot starts at 0)
@@ -904,7 +905,7 @@ int launch_descent(ctk_handle* h, const RolloutArgs& a, float lr, float b1, floa
                                              bc, bc_len, t0, iters, h->d_scratch, ps.a, ps.b, rule));
     else
         HIP_TRY(h, ctk_launch_rpgd_descent(h->stream, c.predictor, a, h->k, lr, b1, b2, eps, c.gradmax_clip, Q, m, v, bc, bc_len, t0, iters,
-                                           h->d_wperm, h->d_scratch, ps.a, ps.b, rule, fused));
+                                           h->d_wperm, h->d_scratch, ps.a, ps.b, rule, fused, &h->rp_pers));
     return CTK_OK;
 }
 
@@ -1318,6 +1319,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     HIP_CREATE(hipHostMalloc((void**)&h->h_u, 64, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(h->h_u, 0, 64);
     HIP_CREATE(hipHostGetDevicePointer((void**)&h->h_u_dev, h->h_u, 0));
+    h->rp_pers.err_word = reinterpret_cast<uint32_t*>(h->h_u_dev) + 2;
 
     if (descends) {
         for (int b = 0; b < 2; ++b) {
@@ -1351,7 +1353,7 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     }
     const bool mat = cfg->materialize_trajectories != 0;
     const bool gnet = generic && cfg->predictor != CTK_PRED_ODE;
-    if (descends) h->dominant = gnet ? ctk_g_rpgd_descent_net_name(h->env, h->net, (int)N, (int)H) : generic ? ctk_g_rpgd_descent_name(h->env) : ctk_rpgd_descent_name(cfg->predictor, (int)N);
+    if (descends) h->dominant = gnet ? ctk_g_rpgd_descent_net_name(h->env, h->net, (int)N, (int)H) : generic ? ctk_g_rpgd_descent_name(h->env) : ctk_rpgd_descent_name(cfg->predictor, (int)N, (int)H);
     else {
         const int mode = cfg->optimizer == CTK_OPT_MPPI ? CTK_G_MODE_MPPI : CTK_G_MODE_AFFINE;
         h->dominant = gnet ? ctk_g_rollout_net_name(h->env, h->net, mode, mat, (int)N, (int)P, (int)H) : generic ? ctk_g_rollout_name(h->env, mode, mat)

@@ -191,7 +191,11 @@ hipError_t ctk_launch_cem_fused(hipStream_t st, int env, const float* params, fl
                                 const CemFusedLaunch& c, bool log, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // ---- ctk_rpgd.hip ---------------------------------------------------------------------------
-const char* ctk_rpgd_descent_name(int pred, int N);
+const char* ctk_rpgd_descent_name(int pred, int N, int H = 0);
+bool ctk_rpgd_uses_persistent(int pred, int N, int H);   // the whole descent as one launch: producers + resident Jacobian workers
+// host-side state of the persistent form, per handle (the launcher advances both): sequence numbers of the in-launch hand-off
+// (64 per launch) and the base of the workers' ticket counter, which lives in the handle's scratch and only ever counts up
+struct RpgdPersist { uint32_t seq0, ticket_base; uint32_t* err_word; };
 constexpr int CTK_RPGD_WIDE_MAX_N = 4096;
 bool ctk_rpgd_uses_wide(int pred, int N);
 int ctk_rpgd_fused_max_n(int pred, int N);   // one-launch step (keep-k / warm start as the descent's tail) up to this population   // MLP, small populations: phase launches + grid-wide step Jacobians (ctk_rpgd.hip)
@@ -213,7 +217,8 @@ constexpr int CTK_RPGD_FUSED_MAX_N = 64;
 hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, float lr, float b1, float b2,
                                    float eps, float clip, float* Q, float* m, float* v, const float* bc_table, int bc_len,
                                    int t0, int iters, const float* wperm, float* scratch, hipEvent_t ev_start = nullptr,
-                                   hipEvent_t ev_stop = nullptr, int rule = 0, const RpgdFusedWarm* fused = nullptr);
+                                   hipEvent_t ev_stop = nullptr, int rule = 0, const RpgdFusedWarm* fused = nullptr,
+                                   RpgdPersist* pers = nullptr);
 // a.C control inputs, a.lo / a.hi the per-input limits; whole_space: uniform samples span [lo[c], hi[c]] (sample_whole_control_space)
 hipError_t ctk_launch_rpgd_warmstart(hipStream_t st, const RolloutArgs& a, int N, int H, int P, int n_new, int gather, int shift_previous,
                                      int sampling_distribution, int reset, int whole_space, float sample_stdev,

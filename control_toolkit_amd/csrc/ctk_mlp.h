@@ -174,6 +174,29 @@ CTK_DEV float mlp_step(const MlpFwdT& w, float sv, float u, int /*g*/, MlpAct* k
     return swap_sum16(s02, s13) + w.b3g;
 }
 
+// The hidden activations of one step exactly as mlp_step_pair forms them (its wave 1 sums layer 2's k-steps 4..7 before 0..3), on ONE wave
+// and without layer 3: a Jacobian worker of the one-launch RPGD descent (ctk_rpgd.hip) linearises the step at the very activations the
+// forward pass had, from the state and input alone.
+CTK_DEV void mlp_acts_as_pair(const MlpFwdT& w, float sv, float u, MlpAct* act) {
+    f32x4 a0 = w.w1u[0] * u + w.b1[0], a1 = w.w1u[1] * u + w.b1[1];
+    a0 = CTK_MFMA(w.w1s[0], sv, a0);
+    a1 = CTK_MFMA(w.w1s[1], sv, a1);
+    const f32x4 h10 = ctk_tanhf4(a0), h11 = ctk_tanhf4(a1);
+    f32x4 c0 = w.b2[0], c1 = w.b2[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                      // each pair wave: its OWN hidden units' k-steps first ...
+        c0 = CTK_MFMA(w.w2[0][j], h10[j], c0);
+        c1 = CTK_MFMA(w.w2[1][4 + j], h11[j], c1);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                      // ... then the other wave's
+        c0 = CTK_MFMA(w.w2[0][4 + j], h11[j], c0);
+        c1 = CTK_MFMA(w.w2[1][j], h10[j], c1);
+    }
+    act->h1[0] = h10; act->h1[1] = h11;
+    act->h2[0] = ctk_tanhf4(c0); act->h2[1] = ctk_tanhf4(c1);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The step SHARED BY TWO WAVES (where a launch leaves SIMDs idle: a wave's matrix and vector time add up —
 // profiles/r02_mlp_step_microbench.txt — so halving both per wave shortens the recurrence).  Wave m of the pair owns hidden

@@ -13,6 +13,8 @@
 //   ctk_rpgd_warmstart       keep the best k (sorted), shift plans by shift_previous and moments by
 //        one, resample the rest at the inducing points, age bookkeeping, u = best plan's first
 //        input (:426,:449-516,:523).
+#include <atomic>
+#include <algorithm>
 #include "ctk_rollout.h"
 #include "ctk_mlp.h"
 #include "ctk_adam.h"
@@ -220,6 +222,48 @@ CTK_DEV float rpgd_backward_mlp(const RolloutArgs& a, const EnvK& k, const MlpBw
 // ---------------------------------------------------------------------------------------------
 constexpr int RP_JAC = 8;
 
+// Tangent j of one step through the network (forward mode on the matrix cores): input basis vector e_j (j < 4: state component j, j == 4: the
+// input) -> the lane's row of column j of the step Jacobian, J[g][j] of plan c.  D..: tanh' of the step's activations (1 - h^2).
+CTK_DEV float rpgd_mlp_tangent(const MlpFwdT& w, const f32x4& D10, const f32x4& D11, const f32x4& D20, const f32x4& D21, int j, int g) {
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    // tangent of layer 1's pre-activation for input basis vector e_j: column j of W1 at this lane's accumulator rows
+    f32x4 a0, a1;
+    if (j < 4) {
+        const float ind = g == j ? 1.0f : 0.0f;
+        a0 = CTK_MFMA(w.w1s[0], ind, z); a1 = CTK_MFMA(w.w1s[1], ind, z);
+    } else { a0 = w.w1u[0]; a1 = w.w1u[1]; }
+    f32x4 d1[2];
+    d1[0] = a0 * D10; d1[1] = a1 * D11;
+    f32x4 c0 = z, c1 = z;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const float b = d1[jj >> 2][jj & 3];
+        c0 = CTK_MFMA(w.w2[0][jj], b, c0);
+        c1 = CTK_MFMA(w.w2[1][jj], b, c1);
+    }
+    f32x4 d2[2];
+    d2[0] = c0 * D20; d2[1] = c1 * D21;
+    f32x4 p0 = z, p1 = z;
+#pragma unroll
+    for (int jj = 0; jj < 8; jj += 2) {
+        p0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[jj], d2[jj >> 2][jj & 3], p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[jj + 1], d2[(jj + 1) >> 2][(jj + 1) & 3], p1, 0, 0, 0);
+    }
+    const f32x4 pp = p0 + p1;
+    return swap_sum16(swap_sum32(pp[0], pp[2]), swap_sum32(pp[1], pp[3]));
+}
+
+// stage-cost adjoint share of lane group g at s_h (the `share` of rpgd_backward_mlp), branch-free
+CTK_DEV float rpgd_mlp_stage_share(const RolloutArgs& a, const EnvK& k, int g, float sv) {
+    float sn, cs;
+    ctk_sincosf(sv, &sn, &cs);
+    const float two_dd = 2.0f * k.dd_weight * k.inv_xs * k.inv_xs;
+    const float A2 = g == 0 ? two_dd : (g == 3 ? 2.0f * k.ekp_weight : 0.0f);
+    const float B = g == 0 ? k.target_position : 0.0f;
+    const float E2 = g == 2 ? 2.0f * k.ep_c : 0.0f;
+    return (A2 * (sv - B) + E2 * (1.0f - cs) * sn) * a.inv_Hp1;
+}
+
 CTK_DEV void rpgd_mlp_jacobian_record(const RolloutArgs& a, const EnvK& k, const MlpFwdT& w, const float* __restrict__ tape_row,
                                       float* __restrict__ jac_step, int c, int g) {
     const float4* tp = reinterpret_cast<const float4*>(tape_row);
@@ -228,45 +272,10 @@ CTK_DEV void rpgd_mlp_jacobian_record(const RolloutArgs& a, const EnvK& k, const
     const f32x4 h10 = f32x4{r1.x, r1.y, r1.z, r1.w}, h11 = f32x4{r2.x, r2.y, r2.z, r2.w};
     const f32x4 h20 = f32x4{r3.x, r3.y, r3.z, r3.w}, h21 = f32x4{r4.x, r4.y, r4.z, r4.w};
     const f32x4 D10 = one - h10 * h10, D11 = one - h11 * h11, D20 = one - h20 * h20, D21 = one - h21 * h21;   // tanh'
-    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
     float Jrow[5];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        // tangent of layer 1's pre-activation for input basis vector e_j: column j of W1 at this lane's accumulator rows
-        f32x4 a0, a1;
-        if (j < 4) {
-            const float ind = g == j ? 1.0f : 0.0f;
-            a0 = CTK_MFMA(w.w1s[0], ind, z); a1 = CTK_MFMA(w.w1s[1], ind, z);
-        } else { a0 = w.w1u[0]; a1 = w.w1u[1]; }
-        f32x4 d1[2];
-        d1[0] = a0 * D10; d1[1] = a1 * D11;
-        f32x4 c0 = z, c1 = z;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const float b = d1[jj >> 2][jj & 3];
-            c0 = CTK_MFMA(w.w2[0][jj], b, c0);
-            c1 = CTK_MFMA(w.w2[1][jj], b, c1);
-        }
-        f32x4 d2[2];
-        d2[0] = c0 * D20; d2[1] = c1 * D21;
-        f32x4 p0 = z, p1 = z;
-#pragma unroll
-        for (int jj = 0; jj < 8; jj += 2) {
-            p0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[jj], d2[jj >> 2][jj & 3], p0, 0, 0, 0);
-            p1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w3n[jj + 1], d2[(jj + 1) >> 2][(jj + 1) & 3], p1, 0, 0, 0);
-        }
-        const f32x4 pp = p0 + p1;
-        Jrow[j] = swap_sum16(swap_sum32(pp[0], pp[2]), swap_sum32(pp[1], pp[3]));
-    }
-    // stage-cost adjoint share of lane group g at s_h (the `share` of rpgd_backward_mlp), branch-free
-    const float sv = r0.x;
-    float sn, cs;
-    ctk_sincosf(sv, &sn, &cs);
-    const float two_dd = 2.0f * k.dd_weight * k.inv_xs * k.inv_xs;
-    const float A2 = g == 0 ? two_dd : (g == 3 ? 2.0f * k.ekp_weight : 0.0f);
-    const float B = g == 0 ? k.target_position : 0.0f;
-    const float E2 = g == 2 ? 2.0f * k.ep_c : 0.0f;
-    const float share = (A2 * (sv - B) + E2 * (1.0f - cs) * sn) * a.inv_Hp1;
+    for (int j = 0; j < 5; ++j) Jrow[j] = rpgd_mlp_tangent(w, D10, D11, D20, D21, j, g);
+    const float share = rpgd_mlp_stage_share(a, k, g, r0.x);
     // jac_step: the 64 x RP_JAC floats of this (tile, step); this lane is row g of plan c
     float* slot = jac_step + (size_t)(4 * c) * RP_JAC;
 #pragma unroll
@@ -279,13 +288,18 @@ CTK_DEV void rpgd_mlp_jacobian_record(const RolloutArgs& a, const EnvK& k, const
 // component j of plan b (QUAD layout):  lam_h[j] = c_h[j] + sum_i lam_{h+1}[i] J_h[i][j]  is four FMAs whose lam operand is a
 // quad-local DPP broadcast, and  dJ/du_h = sum_i lam_{h+1}[i] J_h[i][4]  a two-step DPP sum over the quad, + the input-cost
 // terms.  Lanes j == 0 write g_s[h][plan] and return sum_h g^2 (as rpgd_backward_mlp); lamH comes in quad layout.
-struct RpgdChainMlp {
+template <bool THROUGH, bool CHECK = false>
+struct RpgdChainMlpT {
     // a step is ~20 instructions; the records were written by waves all over the chip (other XCDs' L2s), a round trip to them
     // costs >10 steps' worth: two register chunks of RP_CH steps, one being consumed while the other is in flight
     static constexpr int RP_CH = 8;
     float4 bufA[RP_CH][2], bufB[RP_CH][2];
     const float* jac;
     float lamH;
+    // CHECK (the one-launch form, where the records are written during the launch that reads them): every record carries the sequence number
+    // of its iteration in a spare word of its second half — same 32-byte sector as everything the chain reads of it — and a copy a cache
+    // kept from an earlier iteration shows the earlier number
+    uint32_t want = 0, stale = 0;
 
     CTK_DEV void fetch(float4 (&dst)[RP_CH][2], int top) const {     // steps top, top-1, ..., top-RP_CH+1 (those >= 0)
         const int lane = threadIdx.x & 63;
@@ -293,7 +307,8 @@ struct RpgdChainMlp {
         for (int i = 0; i < RP_CH; ++i) {
             const int h = max(top - i, 0);                   // unconditional (clamped): straight-line loads keep the wait counts exact
             const float4* jq = reinterpret_cast<const float4*>(jac + ((size_t)h * 64 + lane) * RP_JAC);
-            dst[i][0] = jq[0]; dst[i][1] = jq[1];
+            if constexpr (THROUGH) { dst[i][0] = ld4_through(jq); dst[i][1] = ld4_through(jq + 1); }   // (records stored by workers on other XCDs
+            else { dst[i][0] = jq[0]; dst[i][1] = jq[1]; }                                               //  in THIS launch: past this XCD's L2)
         }
     }
     // issue the first loads (the launch does this before anything waits on memory)
@@ -302,15 +317,21 @@ struct RpgdChainMlp {
         lamH = term[threadIdx.x & 63];
         fetch(bufA, H - 1);
     }
+    CTK_DEV void begin(const float* jac_tile, float lam_terminal, int H) {
+        jac = jac_tile;
+        lamH = lam_terminal;
+        fetch(bufA, H - 1);
+    }
     // Writes du_h = sum_i lam_{h+1}[i] J_h[i][4] to g_s[h][plan] (lanes j == 0, a chunk at a time); the input-cost terms, which do not
     // depend on lam, are added afterwards by rpgd_finish_gradient with the whole workgroup.
     template <bool PARTIAL>
-    CTK_DEV void consume(const float4 (&src)[RP_CH][2], int top, float& lam, float* g_col, int ld) const {
+    CTK_DEV void consume(const float4 (&src)[RP_CH][2], int top, float& lam, float* g_col, int ld) {
         float du[RP_CH];
 #pragma unroll
         for (int i = 0; i < RP_CH; ++i) {
             if (PARTIAL && top - i < 0) break;
             const float4 c0 = src[i][0], c1 = src[i][1];
+            if constexpr (CHECK) stale |= __builtin_bit_cast(uint32_t, c1.z) ^ want;
             float pu = lam * c1.x;
             pu += dpp_mov<DPP_QUAD_XOR1>(pu);
             du[i] = pu + dpp_mov<DPP_QUAD_XOR2>(pu);
@@ -346,6 +367,7 @@ struct RpgdChainMlp {
         }
     }
 };
+using RpgdChainMlp = RpgdChainMlpT<false, false>;
 
 // ---------------------------------------------------------------------------------------------
 // warm start / resampling / reset.  One thread per (row, h) of the NEW population.
@@ -766,6 +788,313 @@ __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_mlp_wide(RolloutArgs a, Env
     }
 }
 
+// ---- MLP, wide form as ONE launch per MPC step (round 4) ---------------------------------------------------------------------------
+// The phase launches above pay, per Adam iteration, a launch boundary, 2.2 us of reloads, the moments' round trip through memory and a
+// separate Jacobian launch (6 us for 1.8 us of matrix work).  Here the first `PB` workgroups are the producers of ctk_rpgd_mlp_wide —
+// two 16-plan tiles each, plans / moments / weights resident for all `iters` iterations — and the rest are Jacobian WORKERS that stay
+// for the whole step too:
+//   forward pass  : each step's {state component, seq} (wave 0 of the pair) and {input, seq} (wave 1) go through to memory as one 8-byte
+//                   word per lane — value and sequence number in one store, so a reader that sees the number has the value (no flag, no
+//                   wait on the recurrence; fewer stores than the tape this replaces);
+//   worker        : takes the next (iteration, step, tile) ticket (one counter, step-major: any number of resident workers drains the
+//                   queue in the order the forward passes produce), polls that step's words, RECOMPUTES the step's activations (0.45 us;
+//                   the chip is idle) and forms one tangent per wave (5 waves: 4 state components + the input), stores the record
+//                   through, raises the step's flag = seq;
+//   update        : the chain wave of a tile polls its H flags (lane h <- flag h), reads the records past its L2, then gradient finish
+//                   and Adam on registers / LDS as before.
+// Tiles never depend on each other (optimizer_rpgd.py:325); producers never wait for a worker that holds no ticket; every poll is
+// bounded (200 ms; then the error word, NaN records and a skipped update, as in ctk_net_split.hip).  seq = seq0 + iteration is unique per
+// launch and iteration (the host advances seq0 by 64 per launch, iters <= 63).
+constexpr int RP_PBLOCK = 320;                     // 5 waves: a worker's 5 tangents; a producer's fifth wave leaves at once
+constexpr unsigned long long RP_POLL_TICKS = 20000000ull;   // 200 ms of the 100 MHz clock
+
+struct RpgdPersistK {
+    uint32_t seq0, ticket_base;
+    uint32_t* err_word;      // behind {u, seq} (nullable)
+    int producers, live_tiles, withhold;   // withhold: diagnostic (the step whose words iteration 0 never publishes; -1: none)
+};
+
+CTK_DEV size_t rp_pers_flags_off(int tiles, int H) { return rp_wide_term_off(tiles, H); }            // [tiles][64] uint32
+CTK_DEV size_t rp_pers_ticket_off(int tiles, int H) { return rp_wide_term_off(tiles, H) + (size_t)tiles * 64; }
+
+CTK_DEV void rp_pers_gave_up(uint32_t* err_word, int what, int h, int tile, uint32_t seen, uint32_t want, unsigned long long t_begin) {
+    if (err_word == nullptr) return;
+    const unsigned long long us = (wall_clock64() - t_begin) / 100u;
+    __hip_atomic_store(err_word + 6, ((uint32_t)what << 20) | ((uint32_t)h << 10) | (uint32_t)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(err_word + 7, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(err_word + 8, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(err_word + 9, (uint32_t)(us > 0xffffffffull ? 0xffffffffull : us), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(err_word, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// the forward pass of a pair with its steps published (every wave of the workgroup's first four takes every step: barriers inside)
+CTK_DEV float rpgd_forward_mlp_publish_pair(const RolloutArgs& a, const MlpFwdHalf& w, const float* q_s, int ld, unsigned long long* pub_tile,
+                                            int col, int g, int m, float* ex, uint32_t seq, bool publish, int withhold) {
+    const int lane = threadIdx.x & 63;
+    float sv = lane_state4(a, g);
+    const int H = a.H;
+    float u_next = q_s[col];
+    const unsigned long long hi = (unsigned long long)seq << 32;
+    // The lane's word index, pinned to a register HERE: a value the register allocator reloads from scratch just before the loop carries
+    // that reload's `s_waitcnt vmcnt(0)` to its first use — inside the loop, where the same wait then also waits for the previous step's
+    // store (0.43 us per step: seen in this loop, 1156 against 720 us per MPC step; ctk_common.h: lane_state4 tells the same story).
+    uint32_t word = (uint32_t)(lane * 2 + m);                            // + h * 128
+    asm volatile("" : "+v"(word));
+    for (int h = 0; h < H; ++h) {
+        const float u = u_next;
+        if (h + 1 < H) u_next = q_s[(h + 1) * ld + col];
+        if (publish && h != withhold)
+            __hip_atomic_store(pub_tile + (uint32_t)(h * 128) + word, hi | (unsigned long long)__builtin_bit_cast(uint32_t, m == 0 ? sv : u),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sv = mlp_step_pair(w, sv, u, m, ex);
+    }
+    return sv;
+}
+
+__global__ __launch_bounds__(RP_PBLOCK) void ctk_rpgd_mlp_persistent(RolloutArgs a, EnvK k, AdamK ad, float* __restrict__ Q, float* __restrict__ m,
+                                                                    float* __restrict__ v, const float* __restrict__ bc_table, int bc_len,
+                                                                    int t0, int iters, const float* __restrict__ wperm,
+                                                                    float* __restrict__ scratch, int tiles, RpgdPersistK pk) {
+    extern __shared__ float lds[];
+    const int H = a.H;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, c = lane & 15;
+    unsigned long long* pub = reinterpret_cast<unsigned long long*>(scratch);                       // [tiles][H][64][2] words
+    float* jac = scratch + rp_wide_jac_off(tiles, H);
+    uint32_t* flags = reinterpret_cast<uint32_t*>(scratch + rp_pers_flags_off(tiles, H));
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(scratch + rp_pers_ticket_off(tiles, H));
+    if ((int)blockIdx.x >= pk.producers) {
+        // ------------------------------------------------------------------------------------------ a Jacobian worker
+        const MlpFwdT w = mlp_load_fwd_thin(wperm);
+        uint32_t* slot_s = reinterpret_cast<uint32_t*>(lds);                                         // [2] ticket hand-down
+        const int per_it = pk.live_tiles * H;
+        const uint32_t total = (uint32_t)per_it * (uint32_t)iters;
+        uint32_t pending = 0;
+        if (t == 0) pending = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int n = 0;; ++n) {
+            if (t == 0) slot_s[n & 1] = pending - pk.ticket_base;
+            __syncthreads();
+            const uint32_t job = slot_s[n & 1];
+            if (job >= total) break;                                                                 // (one ticket past the end per workgroup)
+            if (t == 0) pending = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next one, in this job's shadow
+            const int it = (int)(job / (uint32_t)per_it), r = (int)job - it * per_it, h = r / pk.live_tiles, tile = r - h * pk.live_tiles;
+            const uint32_t seq = pk.seq0 + (uint32_t)it;
+            const unsigned long long* p = pub + ((size_t)(tile * H + h) * 64 + lane) * 2;
+            unsigned long long w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long w1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool got = (uint32_t)(w0 >> 32) == seq && (uint32_t)(w1 >> 32) == seq;
+            if (!__all(got)) {
+                const unsigned long long t_begin = wall_clock64();
+                while (!__all(got)) {
+                    if (wall_clock64() - t_begin > RP_POLL_TICKS) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    got = (uint32_t)(w0 >> 32) == seq && (uint32_t)(w1 >> 32) == seq;
+                }
+                if (!__all(got) && wave == 0 && lane == 0) rp_pers_gave_up(pk.err_word, 1, h, tile, (uint32_t)(w0 >> 32), seq, t_begin);
+            }
+            const bool ok = __all(got);
+#if defined(CTK_DIAG_PERS_STAMPS)
+            const unsigned long long ws0 = wall_clock64();
+#endif
+            const float sv = __builtin_bit_cast(float, (uint32_t)w0), u = __builtin_bit_cast(float, (uint32_t)w1);
+            MlpAct act;
+            mlp_acts_as_pair(w, sv, u, &act);                                                        // bit for bit the forward pass's activations
+            const f32x4 one = f32x4{1.f, 1.f, 1.f, 1.f};
+            const f32x4 D10 = one - act.h1[0] * act.h1[0], D11 = one - act.h1[1] * act.h1[1];
+            const f32x4 D20 = one - act.h2[0] * act.h2[0], D21 = one - act.h2[1] * act.h2[1];
+            float Jr = rpgd_mlp_tangent(w, D10, D11, D20, D21, wave, g);                             // wave j: column j of the step Jacobian
+            if (!ok) Jr = __builtin_nanf("");
+            // the record of (tile, step): slot 4c + j = {J[0..3][j]}, {J[j][4], share, seq, -} (rpgd_mlp_jacobian_record + the number the chain
+            // checks).  The five waves' pieces meet in LDS, and wave 0 stores each slot as two 16-byte stores through to memory (scattered 4-byte
+            // stores of that kind cost ~6 x as much per byte), waits for them, and raises the step's flag itself.
+            float* rec_s = lds + 16;                                                                 // [64 slots][RP_JAC]
+            if (wave < 4) {
+                rec_s[(4 * c + wave) * RP_JAC + g] = Jr;
+            } else {
+                const float share = ok ? rpgd_mlp_stage_share(a, k, g, sv) : __builtin_nanf("");
+                float4* half2 = reinterpret_cast<float4*>(rec_s + (4 * c + g) * RP_JAC + 4);
+                *half2 = make_float4(Jr, share, __builtin_bit_cast(float, seq), 0.0f);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const float4* src = reinterpret_cast<const float4*>(rec_s + lane * RP_JAC);
+                float4* dst = reinterpret_cast<float4*>(jac + ((size_t)(tile * H + h) * 64 + lane) * RP_JAC);
+                const float4 c0 = src[0], c1 = src[1];
+                st4_through(dst, c0);
+                st4_through(dst + 1, c1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     // the record has reached memory
+                if (lane == 0) __hip_atomic_store(flags + tile * 64 + h, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#if defined(CTK_DIAG_PERS_STAMPS)
+            if (it == 7 && tile == 0 && t == 0 && (h == H - 1 || h == H - 2 || h == H / 2 || h == 0))
+                printf("pers worker (it 7, tile 0, step %d, job %u of this workgroup %d): words seen abs %llu, flag stored +%llu\n", h, job, n, ws0, wall_clock64() - ws0);
+#endif
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------------------------------- a producer (two tiles)
+    if (wave >= RP_WAVES) return;                          // (a finished wave no longer counts at the workgroup's barriers)
+    float* q_s = lds;                                   // [H][33]
+    float* g_s = q_s + H * RP_WLD;                      // [H][33]
+    float* sc_s = g_s + max(H * RP_WLD, 128);           // [32]
+    float* ex_s = sc_s + RP_WTRAJ;                      // [2 pairs][RP_PAIR_EX]
+    float* term_s = ex_s + 2 * RP_PAIR_EX;              // [2 pairs][64]
+    float* m_s = term_s + 128;                          // [H][33] Adam moments, resident for the step (registers would spill around the chain)
+    float* v_s = m_s + H * RP_WLD;                      // [H][33]
+    const int pair = wave >> 1, half = wave & 1;
+    const int row0 = blockIdx.x * RP_WTRAJ;
+    const int rows = min(RP_WTRAJ, a.N - row0);
+    const int total = rows * H;
+    const size_t gbase = (size_t)row0 * H;
+    const int tile = blockIdx.x * RP_WTILES + pair;
+    const bool live = row0 + pair * CTK_MLP_TRAJ_PER_WAVE < a.N;     // wave-uniform: the tile holds at least one plan
+    const int col = pair * CTK_MLP_TRAJ_PER_WAVE + c;
+    const float uprev0 = uniform_u_prev0(a);
+    constexpr int AB = 8;                               // elements per thread (H <= 64: all of them in one batch)
+    {
+        float q0[AB], mm0[AB], vv0[AB];
+#pragma unroll
+        for (int j = 0; j < AB; ++j) {
+            const int i = t + j * RP_BLOCK;
+            q0[j] = i < total ? Q[gbase + i] : 0.0f;
+            mm0[j] = 0.0f; vv0[j] = 0.0f;
+            if (i < total && ad.rule != 2) { mm0[j] = m[gbase + i]; vv0[j] = v[gbase + i]; }
+        }
+#pragma unroll
+        for (int j = 0; j < AB; ++j) {
+            const int i = t + j * RP_BLOCK;
+            if (i < RP_WTRAJ * H) {
+                const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;
+                q_s[h * RP_WLD + r] = q0[j]; m_s[h * RP_WLD + r] = mm0[j]; v_s[h * RP_WLD + r] = vv0[j];
+            }
+        }
+    }
+    MlpFwdHalf wh;
+    { const MlpFwdT wf = mlp_load_fwd_thin(wperm); wh = mlp_half_of(wf, half); }
+    __syncthreads();
+    const bool chains = live && half == 0;
+#if defined(CTK_DIAG_PERS_STAMPS)      // tools/rpgd_stamps.sh: where one iteration's time goes (block 0, thread 0; a worker's side below)
+    unsigned long long ps_[8]; int pn_ = 0;
+#define PSTAMP() do { if (it == 7 && pn_ < 8) ps_[pn_++] = wall_clock64(); } while (0)
+#else
+#define PSTAMP() do {} while (0)
+#endif
+    for (int it = 0; it < iters; ++it) {
+        const uint32_t seq = pk.seq0 + (uint32_t)it;
+        PSTAMP();
+        const int ti = t0 + it + 1;                                   // state['step'] += 1 (:59); the two scalars arrive in the forward pass's shadow
+        float bc1 = 1.0f, bc2 = 1.0f;
+        if (ti <= bc_len) { bc1 = bc_table[2 * (ti - 1)]; bc2 = bc_table[2 * (ti - 1) + 1]; }
+        const float svH = rpgd_forward_mlp_publish_pair(a, wh, q_s, RP_WLD, pub + (size_t)tile * H * 128, col, g, half, ex_s + pair * RP_PAIR_EX, seq,
+                                                        live, it == 0 ? pk.withhold : -1);
+        // ---- the update of this iteration: flags of the tile's H records, chain, gradient finish, Adam
+        PSTAMP();
+        if (chains) {
+            term_s[pair * 64 + 4 * c + g] = rpgd_mlp_terminal_adjoint(a, k, g, svH);                 // quad layout for the chain (same wave reads it)
+            const uint32_t* fl = flags + tile * 64;
+            uint32_t f = lane < H ? __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seq;
+            if (!__all(f == seq)) {
+                const unsigned long long t_begin = wall_clock64();
+                while (!__all(f == seq)) {
+                    if (wall_clock64() - t_begin > RP_POLL_TICKS) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    f = lane < H ? __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seq;
+                }
+                if (!__all(f == seq)) {
+                    const unsigned long long missing = __builtin_amdgcn_ballot_w64(f != seq);
+                    if (lane == (int)__builtin_ctzll(missing)) rp_pers_gave_up(pk.err_word, 2, lane, tile, f, seq, t_begin);
+                }
+            }
+            PSTAMP();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                       // flags, then the records they publish
+            // The guide's consumer form: one poll, one agent-scope acquire, then PLAIN loads by the acquiring wave (the workers stored every
+            // byte through, each wave waited for its stores, a barrier, then the flag).  Loads that bypass the L2 instead cost 2 us per
+            // dependent chunk here (15 us per chain against 2.8).  Belt and braces: each record's own sequence number is checked as it is
+            // consumed, and a chain that met an older copy is run again past the caches.
+            const float* jt = jac + (size_t)tile * H * 64 * RP_JAC;
+            RpgdChainMlpT<false, true> chain;
+            chain.want = seq;
+            chain.begin(jt, term_s[pair * 64 + lane], H);
+            chain.run(a, g_s + pair * CTK_MLP_TRAJ_PER_WAVE, RP_WLD);
+            if (__any(chain.stale != 0)) {
+                RpgdChainMlpT<true, true> again;
+                again.want = seq;
+                again.begin(jt, term_s[pair * 64 + lane], H);
+                again.run(a, g_s + pair * CTK_MLP_TRAJ_PER_WAVE, RP_WLD);
+                const bool still = __any(again.stale != 0);
+                if (lane == 0) {
+                    __hip_atomic_fetch_add(ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // (how often: word 1 behind the ticket counter)
+                    if (still) rp_pers_gave_up(pk.err_word, 3, 0, tile, 0u, seq, wall_clock64());
+#if defined(CTK_DIAG_PERS_STAMPS)
+                    printf("pers chain of tile %d, iteration %d: a record older than its flag, chain run again past the caches (still stale: %d)\n", tile, it, (int)still);
+#endif
+                }
+            }
+            PSTAMP();
+        } else if (half == 0) {
+            for (int h = lane >> 4; h < H; h += 4) g_s[h * RP_WLD + pair * CTK_MLP_TRAJ_PER_WAVE + c] = 0.0f;   // plans beyond N
+        }
+        __syncthreads();
+        rpgd_finish_gradient_w(a, k, ad, q_s, g_s, sc_s, uprev0);
+        __syncthreads();
+        PSTAMP();
+        float gg[AB];
+        int bad = 0;
+#pragma unroll
+        for (int j = 0; j < AB; ++j) {
+            const int i = t + j * RP_BLOCK;
+            gg[j] = 0.0f;
+            if (i < total) {
+                const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;
+                gg[j] = g_s[h * RP_WLD + r] * sc_s[r];
+                bad |= !(fabsf(gg[j]) <= 3.0e38f);
+            }
+        }
+        // a gradient that is not finite (a record that never arrived is NaN; so is a rollout that diverged): the workgroup keeps its plans
+        // and moments for this iteration, and the step reports CTK_ERR_STATE (h_u word 3: the tile)
+        bad = __syncthreads_or(bad);
+        if (bad && t == 0 && pk.err_word != nullptr) __hip_atomic_store(pk.err_word + 1, 1u + (uint32_t)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!bad) {
+#pragma unroll
+            for (int j = 0; j < AB; ++j) {
+                const int i = t + j * RP_BLOCK;
+                if (i < total) {
+                    const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;
+                    float mm = m_s[h * RP_WLD + r], vv = v_s[h * RP_WLD + r];
+                    q_s[h * RP_WLD + r] = adam_update(ad, q_s[h * RP_WLD + r], gg[j], mm, vv, bc1, bc2, a.lo[0], a.hi[0]);
+                    m_s[h * RP_WLD + r] = mm; v_s[h * RP_WLD + r] = vv;
+                }
+            }
+        }
+        __syncthreads();
+        PSTAMP();
+#if defined(CTK_DIAG_PERS_STAMPS)
+        if (it == 7 && blockIdx.x == 0 && t == 0) {
+            printf("pers producer stamps (10 ns ticks since the iteration's start): forward end %u, flags seen %u, chain end %u, finish end %u, Adam end %u (n = %d)\n",
+                   (unsigned)(ps_[1] - ps_[0]), (unsigned)(ps_[2] - ps_[0]), (unsigned)(ps_[3] - ps_[0]), (unsigned)(ps_[4] - ps_[0]),
+                   (unsigned)(ps_[5] - ps_[0]), pn_);
+        }
+#endif
+    }
+    // get_action's cost pass (:342), then the plans and moments back to memory
+    if (half == 0) {   // (one wave per tile, as the phase launches' cost pass: the two forms agree bit for bit; the pair form measured no faster here)
+        const MlpFwdT wf = mlp_load_fwd_thin(wperm);
+        const float J = rollout_mlp<false, false>(a, k, wf, row0 + pair * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return q_s[h * RP_WLD + col]; });
+        if (lane < 16 && row0 + col < a.N) a.J[row0 + col] = J;
+    }
+#pragma unroll
+    for (int j = 0; j < AB; ++j) {
+        const int i = t + j * RP_BLOCK;
+        if (i < total) {
+            const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;
+            Q[gbase + i] = q_s[h * RP_WLD + r];
+            if (ad.rule != 2) { m[gbase + i] = m_s[h * RP_WLD + r]; v[gbase + i] = v_s[h * RP_WLD + r]; }
+        }
+    }
+}
+
+
 __global__ __launch_bounds__(256) void ctk_rpgd_pack_keepers(const float* __restrict__ J, const float* __restrict__ Q,
                                                              const float* __restrict__ m, const float* __restrict__ v,
                                                              const float* __restrict__ ages, const int* __restrict__ idx, int K,
@@ -800,7 +1129,14 @@ bool ctk_rpgd_uses_wide(int pred, int N) {
     return pred == CTK_PRED_MLP && N <= CTK_RPGD_WIDE_MAX_N && !narrow;
 }
 
-const char* ctk_rpgd_descent_name(int pred, int N) {
+// ... and of those, more than one workgroup's worth of plans with H <= 64 runs the whole descent as ONE launch (ctk_rpgd_mlp_persistent)
+bool ctk_rpgd_uses_persistent(int pred, int N, int H) {
+    static const bool off = getenv("CTK_RPGD_NO_PERSISTENT") != nullptr;   // diagnostic switch: A/B the two forms
+    return ctk_rpgd_uses_wide(pred, N) && N > RP_WTRAJ && H <= 64 && !off;
+}
+
+const char* ctk_rpgd_descent_name(int pred, int N, int H) {
+    if (H > 0 && ctk_rpgd_uses_persistent(pred, N, H)) return "ctk_rpgd_mlp_persistent";
     if (ctk_rpgd_uses_wide(pred, N)) return "ctk_rpgd_mlp_wide + ctk_rpgd_mlp_jacobians";
     return pred == CTK_PRED_ODE ? "ctk_rpgd_descent<0>" : "ctk_rpgd_descent<1>";
 }
@@ -820,7 +1156,7 @@ size_t ctk_rpgd_scratch_floats(int pred, int N, int H) {
     if (pred == CTK_PRED_ODE) return blocks * H * RP_NS * 64;
     // single-launch form: tape per 16-plan tile; wide form: tape | Jacobian records | terminal adjoints per tile
     const size_t tiles = std::max(blocks * RP_WAVES, (size_t)wide_blocks(N) * RP_WTILES);
-    return tiles * (size_t)H * 64 * (RP_MLP_TAPE + RP_JAC) + tiles * 64;
+    return tiles * (size_t)H * 64 * (RP_MLP_TAPE + RP_JAC) + tiles * 64 + 16;   // (+ the persistent form's ticket counter)
 }
 
 // largest population whose step runs as ONE launch with the keep-k / warm-start tail (one workgroup holds it)
@@ -837,7 +1173,7 @@ static void launch_timed(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_
 hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& a, const EnvK& k, float lr, float b1, float b2,
                                    float eps, float clip, float* Q, float* m, float* v, const float* bc_table, int bc_len,
                                    int t0, int iters, const float* wperm, float* scratch, hipEvent_t e0, hipEvent_t e1, int rule,
-                                   const RpgdFusedWarm* fused) {
+                                   const RpgdFusedWarm* fused, RpgdPersist* pers) {
     AdamK ad{lr, b1, b2, (float)(1.0 - (double)b1), (float)(1.0 - (double)b2), eps, clip, rule};
     bool tape_in_lds = false;
     const size_t lds = ctk_rpgd_descent_lds(pred, a.H, &tape_in_lds);
@@ -853,6 +1189,22 @@ hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& 
     };
     FusedWarm fw{};
     if (fused && grid.x == 1) fw = fw_of(fused);
+    if (pers != nullptr && iters >= 1 && iters <= 63 && ctk_rpgd_uses_persistent(pred, a.N, a.H)) {
+        // ONE launch: producers (two tiles each) + Jacobian workers that stay for all iterations (ctk_rpgd_mlp_persistent)
+        static const int diag_step = getenv("CTK_DIAG_RPGD_WITHHOLD_FLAG") ? atoi(getenv("CTK_DIAG_RPGD_WITHHOLD_FLAG")) : -1;
+        static std::atomic<int> diag_armed{diag_step >= 0 ? 1 : 0};
+        const int PB = wide_blocks(a.N), tiles = PB * RP_WTILES, live = (a.N + CTK_MLP_TRAJ_PER_WAVE - 1) / CTK_MLP_TRAJ_PER_WAVE;
+        const int per_it = live * a.H, W = std::min(240, per_it);
+        if (pers->seq0 < 64u || pers->seq0 > 0xffffff00u) pers->seq0 = 64u;
+        RpgdPersistK pk{pers->seq0, pers->ticket_base, pers->err_word, PB, live, diag_armed.exchange(0) ? diag_step : -1};
+        pers->seq0 += 64u;
+        pers->ticket_base += (uint32_t)per_it * (uint32_t)iters + (uint32_t)W;       // every job + one ticket past the end per worker workgroup
+        // more than half a CU's LDS: one workgroup per CU — no worker on a producer's SIMDs
+        const size_t lds = std::max(wide_lds(a.H) + (128 + 2 * a.H * RP_WLD) * sizeof(float), (size_t)84 * 1024);
+        launch_timed(ctk_rpgd_mlp_persistent, dim3(PB + W), dim3(RP_PBLOCK), lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm,
+                     scratch, tiles, pk);
+        return hipGetLastError();
+    }
     if (ctk_rpgd_uses_wide(pred, a.N)) {
         // phase launches: [tape] J [update+tape] J ... [update+final]; the event pair brackets the whole sequence
         const dim3 wgrid(wide_blocks(a.N));

@@ -442,3 +442,55 @@ def test_rpgd_jacobian_handoff_timeout_is_an_error_and_leaves_the_state_intact()
     if r.returncode != 0:
         print(r.stdout[-4000:]); print(r.stderr[-6000:])
     assert r.returncode == 0 and "HANDOFF-TIMEOUT-OK" in r.stdout
+
+
+# ---- the one-launch form of the MLP descent (csrc/ctk_rpgd.hip: ctk_rpgd_mlp_persistent) against the phase launches it replaces ----------------
+ONE_LAUNCH_SCRIPT = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle.ctk_oracle as O
+from control_toolkit_amd import CtkEngine
+from gpu_helpers import apply_env
+N, H, p, its, K, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+env = O.EnvParams(terminal_weight=0.3)
+e = CtkEngine("rpgd", "MLP", num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p, outer_its=its, resamp_per=2,
+              shift_previous=1, opt_keep_k=K, sampling_distribution=0, sample_min=-1.0, sample_max=1.0, learning_rate=0.05, gradmax_clip=5.0)
+apply_env(e, env); e.set_predictor_weights(O.mlp_default_weights(0))
+P = -(-H // p) + 1
+rng = np.random.default_rng(N + H)
+e.reset(rng.random((N, P, 1), dtype=np.float32))
+s = np.array([0.05, 0.0, 2.9, 0.3], np.float32)
+res = {"kernel": np.array(e.dominant_kernel())}
+for t in range(4):
+    dr = rng.random((N - K, P, 1), dtype=np.float32) if t %% 2 == 0 else None
+    res["u%%d" %% t] = np.asarray(e.step(s, dr), np.float32).reshape(-1)
+    for b in ("PLAN", "ADAM_M", "ADAM_V", "J", "AGES"):
+        res[b + str(t)] = e.read(b).copy()
+    s = (s + np.array([0.01, 0.02, -0.03, 0.01], np.float32)).astype(np.float32)
+np.savez(out, **res)
+'''
+
+
+@pytest.mark.parametrize("N,H,p,its,K", [(256, 50, 10, 20, 64), (72, 20, 5, 3, 18), (40, 64, 8, 2, 10), (1000, 12, 4, 2, 250)])
+def test_rpgd_one_launch_descent_equals_the_phase_launches_bit_for_bit(tmp_path, N, H, p, its, K):
+    """Producers + resident Jacobian workers in ONE launch (words {value, seq} forward -> workers, records + flags back) must give what the
+    launch-per-phase form gives — plans, both moments, costs and inputs, bit for bit, over resampling and kept steps: a worker linearises
+    each step at the forward pass's own activations (ctk_mlp.h: mlp_acts_as_pair), the chain and Adam are the same code.  (256, 50, 10, 20)
+    is BASELINE configs[3]; (40, 64) a tile with plans beyond N and the longest horizon the form takes; 1000 plans = 63 tiles."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = ONE_LAUNCH_SCRIPT % (root, os.path.join(root, "tests"))
+    outs = {}
+    for form, extra in (("one_launch", {}), ("phases", {"CTK_RPGD_NO_PERSISTENT": "1"})):
+        out = str(tmp_path / f"{form}.npz")
+        env = {k: v for k, v in os.environ.items() if k != "CTK_RPGD_NO_PERSISTENT"}
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", script, str(N), str(H), str(p), str(its), str(K), out], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[form] = np.load(out)
+    assert str(outs["one_launch"]["kernel"]) == "ctk_rpgd_mlp_persistent", outs["one_launch"]["kernel"]
+    assert "ctk_rpgd_mlp_wide" in str(outs["phases"]["kernel"]), outs["phases"]["kernel"]
+    for key in outs["phases"].files:
+        if key != "kernel":
+            assert np.array_equal(outs["one_launch"][key], outs["phases"][key]), key
+            assert np.isfinite(outs["one_launch"][key]).all(), key
