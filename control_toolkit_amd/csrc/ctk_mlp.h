@@ -231,6 +231,16 @@ CTK_DEV MlpFwdHalf mlp_half_of(const MlpFwdT& w, int m) {
     return x;
 }
 
+// Pins every operand to a register HERE.  In front of a loop that stores to memory without waiting: a value whose load (or reload from
+// scratch) the compiler has not yet waited for carries that `s_waitcnt vmcnt(0)` to its first use, and inside the loop the same wait then
+// also waits for the loop's own stores — once per step.
+CTK_DEV void mlp_pin(MlpFwdHalf& w) {
+    asm volatile("" : "+v"(w.w1s), "+v"(w.b3g));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(w.w2o[j]), "+v"(w.w2x[j]), "+v"(w.w3n[j]));
+    asm volatile("" : "+v"(w.b1), "+v"(w.w1u), "+v"(w.b2));
+}
+
 struct MlpHalfAct {
     f32x4 h1m, h2m;         // this wave's halves of the activations
 };

@@ -798,14 +798,14 @@ __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_mlp_wide(RolloutArgs a, Env
 //                   wait on the recurrence; fewer stores than the tape this replaces);
 //   worker        : takes the next (iteration, step, tile) ticket (one counter, step-major: any number of resident workers drains the
 //                   queue in the order the forward passes produce), polls that step's words, RECOMPUTES the step's activations (0.45 us;
-//                   the chip is idle) and forms one tangent per wave (5 waves: 4 state components + the input), stores the record
+//                   the chip is idle) and forms one tangent per wave (4 state components; wave 3 the input's too), stores the record
 //                   through, raises the step's flag = seq;
 //   update        : the chain wave of a tile polls its H flags (lane h <- flag h), reads the records past its L2, then gradient finish
 //                   and Adam on registers / LDS as before.
 // Tiles never depend on each other (optimizer_rpgd.py:325); producers never wait for a worker that holds no ticket; every poll is
 // bounded (200 ms; then the error word, NaN records and a skipped update, as in ctk_net_split.hip).  seq = seq0 + iteration is unique per
 // launch and iteration (the host advances seq0 by 64 per launch, iters <= 63).
-constexpr int RP_PBLOCK = 320;                     // 5 waves: a worker's 5 tangents; a producer's fifth wave leaves at once
+constexpr int RP_PBLOCK = RP_BLOCK;                // 4 waves, one per SIMD (five — a wave per tangent — put two on one SIMD: 1.4 us per job against 0.96)
 constexpr unsigned long long RP_POLL_TICKS = 20000000ull;   // 200 ms of the 100 MHz clock
 
 struct RpgdPersistK {
@@ -828,9 +828,11 @@ CTK_DEV void rp_pers_gave_up(uint32_t* err_word, int what, int h, int tile, uint
 }
 
 // the forward pass of a pair with its steps published (every wave of the workgroup's first four takes every step: barriers inside)
-CTK_DEV float rpgd_forward_mlp_publish_pair(const RolloutArgs& a, const MlpFwdHalf& w, const float* q_s, int ld, unsigned long long* pub_tile,
+CTK_DEV float rpgd_forward_mlp_publish_pair(const RolloutArgs& a, const MlpFwdHalf& w_in, const float* q_s, int ld, unsigned long long* pub_tile,
                                             int col, int g, int m, float* ex, uint32_t seq, bool publish, int withhold) {
     const int lane = threadIdx.x & 63;
+    MlpFwdHalf w = w_in;
+    mlp_pin(w);                                                          // (as `word` below)
     float sv = lane_state4(a, g);
     const int H = a.H;
     float u_next = q_s[col];
@@ -840,10 +842,11 @@ CTK_DEV float rpgd_forward_mlp_publish_pair(const RolloutArgs& a, const MlpFwdHa
     // store (0.43 us per step: seen in this loop, 1156 against 720 us per MPC step; ctk_common.h: lane_state4 tells the same story).
     uint32_t word = (uint32_t)(lane * 2 + m);                            // + h * 128
     asm volatile("" : "+v"(word));
+    const bool pub = __builtin_amdgcn_readfirstlane((int)publish) != 0;  // wave-uniform, as a scalar: a branch, not an exec mask, per step
     for (int h = 0; h < H; ++h) {
         const float u = u_next;
         if (h + 1 < H) u_next = q_s[(h + 1) * ld + col];
-        if (publish && h != withhold)
+        if (pub && h != withhold)
             __hip_atomic_store(pub_tile + (uint32_t)(h * 128) + word, hi | (unsigned long long)__builtin_bit_cast(uint32_t, m == 0 ? sv : u),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sv = mlp_step_pair(w, sv, u, m, ex);
@@ -904,17 +907,17 @@ __global__ __launch_bounds__(RP_PBLOCK) void ctk_rpgd_mlp_persistent(RolloutArgs
             const f32x4 D10 = one - act.h1[0] * act.h1[0], D11 = one - act.h1[1] * act.h1[1];
             const f32x4 D20 = one - act.h2[0] * act.h2[0], D21 = one - act.h2[1] * act.h2[1];
             float Jr = rpgd_mlp_tangent(w, D10, D11, D20, D21, wave, g);                             // wave j: column j of the step Jacobian
-            if (!ok) Jr = __builtin_nanf("");
+            float Ju = wave == 3 ? rpgd_mlp_tangent(w, D10, D11, D20, D21, 4, g) : 0.0f;             // ... and wave 3 the input's (the short one)
+            if (!ok) { Jr = __builtin_nanf(""); Ju = Jr; }
             // the record of (tile, step): slot 4c + j = {J[0..3][j]}, {J[j][4], share, seq, -} (rpgd_mlp_jacobian_record + the number the chain
             // checks).  The five waves' pieces meet in LDS, and wave 0 stores each slot as two 16-byte stores through to memory (scattered 4-byte
             // stores of that kind cost ~6 x as much per byte), waits for them, and raises the step's flag itself.
             float* rec_s = lds + 16;                                                                 // [64 slots][RP_JAC]
-            if (wave < 4) {
-                rec_s[(4 * c + wave) * RP_JAC + g] = Jr;
-            } else {
+            rec_s[(4 * c + wave) * RP_JAC + g] = Jr;
+            if (wave == 3) {
                 const float share = ok ? rpgd_mlp_stage_share(a, k, g, sv) : __builtin_nanf("");
                 float4* half2 = reinterpret_cast<float4*>(rec_s + (4 * c + g) * RP_JAC + 4);
-                *half2 = make_float4(Jr, share, __builtin_bit_cast(float, seq), 0.0f);
+                *half2 = make_float4(Ju, share, __builtin_bit_cast(float, seq), 0.0f);
             }
             __syncthreads();
             if (wave == 0) {
@@ -934,7 +937,6 @@ __global__ __launch_bounds__(RP_PBLOCK) void ctk_rpgd_mlp_persistent(RolloutArgs
         return;
     }
     // ---------------------------------------------------------------------------------------------- a producer (two tiles)
-    if (wave >= RP_WAVES) return;                          // (a finished wave no longer counts at the workgroup's barriers)
     float* q_s = lds;                                   // [H][33]
     float* g_s = q_s + H * RP_WLD;                      // [H][33]
     float* sc_s = g_s + max(H * RP_WLD, 128);           // [32]
@@ -997,7 +999,7 @@ __global__ __launch_bounds__(RP_PBLOCK) void ctk_rpgd_mlp_persistent(RolloutArgs
             if (!__all(f == seq)) {
                 const unsigned long long t_begin = wall_clock64();
                 while (!__all(f == seq)) {
-                    if (wall_clock64() - t_begin > RP_POLL_TICKS) break;
+                    if (wall_clock64() - t_begin > 2 * RP_POLL_TICKS) break;            // (a worker that gave up still raises its flag: twice its budget)
                     __builtin_amdgcn_s_sleep(1);
                     f = lane < H ? __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seq;
                 }
@@ -1036,34 +1038,44 @@ __global__ __launch_bounds__(RP_PBLOCK) void ctk_rpgd_mlp_persistent(RolloutArgs
             for (int h = lane >> 4; h < H; h += 4) g_s[h * RP_WLD + pair * CTK_MLP_TRAJ_PER_WAVE + c] = 0.0f;   // plans beyond N
         }
         __syncthreads();
-        rpgd_finish_gradient_w(a, k, ad, q_s, g_s, sc_s, uprev0);
-        __syncthreads();
-        PSTAMP();
-        float gg[AB];
-        int bad = 0;
-#pragma unroll
-        for (int j = 0; j < AB; ++j) {
-            const int i = t + j * RP_BLOCK;
-            gg[j] = 0.0f;
-            if (i < total) {
-                const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;
-                gg[j] = g_s[h * RP_WLD + r] * sc_s[r];
-                bad |= !(fabsf(gg[j]) <= 3.0e38f);
-            }
-        }
-        // a gradient that is not finite (a record that never arrived is NaN; so is a rollout that diverged): the workgroup keeps its plans
-        // and moments for this iteration, and the step reports CTK_ERR_STATE (h_u word 3: the tile)
-        bad = __syncthreads_or(bad);
-        if (bad && t == 0 && pk.err_word != nullptr) __hip_atomic_store(pk.err_word + 1, 1u + (uint32_t)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (!bad) {
+        // gradient finish (rpgd_finish_gradient_w: the input-cost terms, the per-plan norm over 8 lanes by DPP) and Adam, fused: thread
+        // (plan r, eighth `part`) owns steps part, part + 8, ... of its plan in BOTH — the gradients stay in registers, the clip scale needs no
+        // LDS, and one barrier (the vote below: every neighbour's plan value has been read before any is rewritten) replaces three.
+        {
+            const int r = t >> 3, part = t & 7;
+            const float inv = a.inv_Hp1;
+            float gq[AB];
+            float nrm2 = 0.0f;
 #pragma unroll
             for (int j = 0; j < AB; ++j) {
-                const int i = t + j * RP_BLOCK;
-                if (i < total) {
-                    const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;
-                    float mm = m_s[h * RP_WLD + r], vv = v_s[h * RP_WLD + r];
-                    q_s[h * RP_WLD + r] = adam_update(ad, q_s[h * RP_WLD + r], gg[j], mm, vv, bc1, bc2, a.lo[0], a.hi[0]);
-                    m_s[h * RP_WLD + r] = mm; v_s[h * RP_WLD + r] = vv;
+                const int h = part + 8 * j;
+                gq[j] = 0.0f;
+                if (h < H) {
+                    const float u_h = q_s[h * RP_WLD + r], u_hm1 = h > 0 ? q_s[(h - 1) * RP_WLD + r] : uprev0;
+                    float gu = 2.0f * k.ccR * u_h + 2.0f * k.ccrc_weight * (u_h - u_hm1);
+                    if (h + 1 < H) gu -= 2.0f * k.ccrc_weight * (q_s[(h + 1) * RP_WLD + r] - u_h);
+                    gq[j] = gu * inv + g_s[h * RP_WLD + r];
+                    nrm2 += gq[j] * gq[j];
+                }
+            }
+            nrm2 += dpp_mov<DPP_QUAD_XOR1>(nrm2);
+            nrm2 += dpp_mov<DPP_QUAD_XOR2>(nrm2);
+            nrm2 += dpp_mov<DPP_ROW_HALF_MIRROR>(nrm2);           // every lane of the plan's 8 holds the total
+            const float scl = ad.clip / fmaxf(sqrtf(nrm2), ad.clip);   // lib.clip_by_norm(g, clip, [1,2]) (:315,:334)
+            PSTAMP();
+            // a gradient that is not finite (a record that never arrived is NaN; so is a rollout that diverged): the workgroup keeps its plans
+            // and moments for this iteration, and the step reports CTK_ERR_STATE (h_u word 3: the tile)
+            const int bad = __syncthreads_or(!(nrm2 <= 3.0e38f));
+            if (bad && t == 0 && pk.err_word != nullptr) __hip_atomic_store(pk.err_word + 1, 1u + (uint32_t)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (!bad && r < rows) {
+#pragma unroll
+                for (int j = 0; j < AB; ++j) {
+                    const int h = part + 8 * j;
+                    if (h < H) {
+                        float mm = m_s[h * RP_WLD + r], vv = v_s[h * RP_WLD + r];
+                        q_s[h * RP_WLD + r] = adam_update(ad, q_s[h * RP_WLD + r], gq[j] * scl, mm, vv, bc1, bc2, a.lo[0], a.hi[0]);
+                        m_s[h * RP_WLD + r] = mm; v_s[h * RP_WLD + r] = vv;
+                    }
                 }
             }
         }
@@ -1132,7 +1144,9 @@ bool ctk_rpgd_uses_wide(int pred, int N) {
 // ... and of those, more than one workgroup's worth of plans with H <= 64 runs the whole descent as ONE launch (ctk_rpgd_mlp_persistent)
 bool ctk_rpgd_uses_persistent(int pred, int N, int H) {
     static const bool off = getenv("CTK_RPGD_NO_PERSISTENT") != nullptr;   // diagnostic switch: A/B the two forms
-    return ctk_rpgd_uses_wide(pred, N) && N > RP_WTRAJ && H <= 64 && !off;
+    // up to 32 tiles: beyond that the (at most 240) resident workers no longer keep up with the forward passes — a job is ~1.8 us of a
+    // workgroup, the tiles produce one each per 0.47 us — and the grid-wide Jacobian launches of the phase form win
+    return ctk_rpgd_uses_wide(pred, N) && N > RP_WTRAJ && N <= 512 && H <= 64 && !off;
 }
 
 const char* ctk_rpgd_descent_name(int pred, int N, int H) {

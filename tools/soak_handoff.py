@@ -29,26 +29,30 @@ ERRORS = []
 def run(steps):
     from control_toolkit_amd import CtkEngine
     out = {}
-    for env, kw in (("CartPole", dict(generic_kernels=True)), ("Quad2D", {}), ("Hover", {})):
+    for name, env, kw, kernel in (("CartPole", "CartPole", dict(generic_kernels=True), "wide_split"), ("Quad2D", "Quad2D", {}, "wide_split"),
+                                  ("Hover", "Hover", {}, "wide_split"),
+                                  # CartPole's own kernels: the whole descent in one launch, resident workers, words / records / flags both ways
+                                  ("CartPole-1L", "CartPole", {}, "ctk_rpgd_mlp_persistent")):
         e = CtkEngine("rpgd", "MLP", environment=env, num_rollouts=256, mpc_horizon=50, dt=0.02, period_interpolation_inducing_points=10,
                       outer_its=10, resamp_per=10, opt_keep_k=64, seed=5, **kw)
-        assert "wide_split" in e.dominant_kernel(), e.dominant_kernel()
+        assert kernel in e.dominant_kernel(), e.dominant_kernel()
         e.set_predictor_weights((np.random.default_rng(0).standard_normal(e.predictor_weight_count()) * 0.15).astype(np.float32))
         e.reset()
-        S = {"CartPole": 4, "Quad2D": 6, "Hover": 7}[env]
+        S = e.S
         s = (0.05 * np.arange(1, S + 1)).astype(np.float32)
         us = []
         for t in range(steps):
             try:
                 u = np.asarray(e.step(s)).reshape(-1).copy()
             except Exception as ex:                      # a hand-off that timed out: the step says so, the engine stays usable
-                print(f"{env} step {t}: {ex}", flush=True)
-                ERRORS.append((env, t))
+                print(f"{name} step {t}: {ex}", flush=True)
+                ERRORS.append((name, t))
                 u = np.zeros(e.C, np.float32)           # (the loop goes on from a defined input)
             us.append(u)
             s = (0.97 * s + 0.02 * np.resize(u, S) + 0.01 * np.sin(0.1 * t + np.arange(S))).astype(np.float32)
+        plans = e.read("PLAN").reshape(-1).copy()        # (the inputs saturate in this loop: the final population is the sharper witness)
         e.close()
-        out[env] = np.stack(us)
+        out[name] = np.concatenate([np.stack(us).reshape(-1), plans])
     return out
 
 
@@ -109,7 +113,7 @@ if __name__ == "__main__":
     for env in idle:
         same = np.array_equal(idle[env], busy[env]) and np.isfinite(busy[env]).all()
         ok &= same
-        print(f"{env:9s} {steps} steps x 10 hand-off launches: idle GPU vs loaded GPU {'identical' if same else 'DIFFERENT'}; last u {busy[env][-1]}")
+        print(f"{env:11s} {steps} steps x 10 iterations handed off in-launch: idle GPU vs loaded GPU {'identical' if same else 'DIFFERENT'} (inputs of every step + the final population, bit for bit)")
     print(f"wall: idle {t_idle:.1f} s, under load {t_busy:.1f} s")
     ok &= not ERRORS
     print(f"steps that reported an error: {len(ERRORS)}")
