@@ -110,7 +110,9 @@ def main():
               "# mailbox in pinned host memory against mailbox in host-written device memory)\n")
     copy_text("placement.txt", f"{tag}_wave_placement.txt", "# tools/diag_wave_placement: where a CU puts the waves of small workgroups (every wave: a dependent chain of 14 fp32 MFMAs per step; XCC / SE / CU / SIMD from s_getreg)\n")
     copy_text("parity_margins.txt", f"{tag}_parity_margins.txt", "# tests/margins.py: written by the reference-golden -m gpu tests of this pass (tools/gpu_run_profiles.sh step 0)\n")
-    copy_text("soak_handoff.txt", f"{tag}_soak_handoff.txt", "# tools/soak_handoff.py: the in-launch hand-off of the template wide RPGD descent while a second process keeps the GPU busy (3000 steps per environment)\n")
+    copy_text("rpgd_forms.txt", f"{tag}_rpgd_forms.txt", "# tools/rpgd_forms.py: RPGD + MLP on CartPole's own kernels per MPC step (host clock, 60 steps) — the one-launch form against the phase launches it replaces\n")
+    copy_text("rpgd_pers_stamps.txt", f"{tag}_rpgd_pers_stamps.txt", "# tools/rpgd_stamps.sh: wall-clock stamps inside ctk_rpgd_mlp_persistent (variant build; the printf calls perturb what they time: read the lines that agree)\n")
+    copy_text("soak_handoff.txt", f"{tag}_soak_handoff.txt", "# tools/soak_handoff.py: the in-launch hand-offs (template wide RPGD descent, the one-launch descent of CartPole's own kernels, block records of MPPI / CEM, the resident kernel) while a second process keeps the GPU busy (3000 steps per environment)\n")
     copy_text("soak.txt", f"{tag}_soak.txt", "# tools/soak.py: closed-loop soak of 26 engines (every optimizer, predictor, environment, the one-launch CEM, the split network kernels, the narrow-record merge, 64-unit and embedded networks, a user environment)\n")
     p = pmc("pmc_largen")
     if fresh(p):

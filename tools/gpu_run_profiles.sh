@@ -57,6 +57,9 @@ python tools/sweep_n.py > $O/sweep_n.txt 2> $O/sweep_n.err; say "sweep_n" $?
 python tools/bench_resident.py > $O/resident.txt 2> $O/resident.err; say "bench_resident" $?
 ./tools/diag_mailbox_vram >> $O/resident.txt 2>&1; say "mailbox diag" $?
 ./tools/diag_wave_placement > $O/placement.txt 2>&1; say "wave placement" $?
+# the two forms of the RPGD + MLP descent over sizes (the switch is read once per process), and where one iteration of the one-launch form goes
+{ echo "== one launch per MPC step"; python tools/rpgd_forms.py 2>&1 | grep "us per"; echo "== phase launches (CTK_RPGD_NO_PERSISTENT=1)"; CTK_RPGD_NO_PERSISTENT=1 python tools/rpgd_forms.py 2>&1 | grep "us per"; } > $O/rpgd_forms.txt; say "rpgd forms" $?
+bash tools/rpgd_stamps.sh > /dev/null 2>&1; cp gpurun_out/split/stamps.txt $O/rpgd_pers_stamps.txt 2>/dev/null; say "rpgd stamps" $?
 python3 tools/soak_handoff.py 3000 > $O/soak_handoff.txt 2>&1; say "soak hand-off" $?
 python tools/soak.py 1500 > $O/soak.txt 2>&1; say "soak" $?
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_largen -o p -- python3 tools/large_n_once.py > /dev/null 2> $O/pmc_largen.err; say "pmc large-N insts" $?
