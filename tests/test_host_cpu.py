@@ -284,3 +284,39 @@ def test_user_environment_library_builds_and_describes_itself():
     assert cw.parameters["ang_weight"] == 70.0 and cw.parameters["damping"] == pytest.approx(0.1)
     with pytest.raises(ValueError, match="unknown cost parameters"):
         CostFunctionWrapper({"dd_weight": 1.0}, watch=False, environment_name="Pendulum")
+
+
+def test_rpgd_one_launch_forward_loop_never_waits_for_its_own_stores(tmp_path):
+    """A code-generation guard (no GPU needed: the built library is disassembled).  The forward pass of ctk_rpgd_mlp_persistent publishes one
+    8-byte word per lane and step and must never wait for those stores.  Twice while the kernel was written the compiler put an
+    `s_waitcnt vmcnt(0)` inside that loop — for a pointer reloaded from scratch, then for a weight whose load it had not yet waited for —
+    and each step then waited for the previous step's store: 1 156 us per MPC step instead of 720, with no spill in the loop and nothing
+    in a profile to point at it.  The operands are pinned in front of the loop (`mlp_pin`); this test keeps it that way."""
+    import shutil
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    lib = os.path.join(ROOT, "control_toolkit_amd", "libctk_hip.so")
+    if not os.path.exists(objdump) or not os.path.exists(lib):
+        pytest.skip("llvm-objdump or the built library is not here")
+    work = str(tmp_path / "libctk_hip.so")
+    shutil.copy(lib, work)
+    subprocess.run([objdump, "--offloading", "libctk_hip.so"], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)   # bundles land beside the file
+    listing = None
+    for name in sorted(os.listdir(str(tmp_path))):
+        if name.endswith("gfx950"):
+            text = subprocess.run([objdump, "-d", name], cwd=str(tmp_path), capture_output=True, text=True, timeout=300).stdout
+            if "<_Z23ctk_rpgd_mlp_persistent" in text:
+                listing = text.splitlines()
+    assert listing is not None, "ctk_rpgd_mlp_persistent is not in the library"
+    start = next(i for i, l in enumerate(listing) if re.match(r"^[0-9a-f]+ <_Z23ctk_rpgd_mlp_persistent.*>:", l))
+    end = next((i for i in range(start + 1, len(listing)) if re.match(r"^[0-9a-f]+ <.*>:", listing[i])), len(listing))
+    body = listing[start:end]
+    stores = [i for i, l in enumerate(body) if "global_store_dwordx2" in l and " sc1" in l and "sc0" not in l]
+    assert len(stores) == 1, f"expected ONE publish store (agent-scope 8-byte word) in the kernel, found {len(stores)}"
+    s = stores[0]
+    back = next(i for i in range(s, len(body)) if "s_cbranch_scc1" in body[i] or "s_cbranch_scc0" in body[i])     # the step loop's back edge
+    loop = body[max(0, s - 12):back + 1]
+    assert sum("v_mfma_f32_16x16x4" in l for l in loop) >= 9, "this is not the forward loop (a step is 9 wide + 4 narrow matrix products)"
+    waits = [l.strip() for l in loop if "s_waitcnt" in l and "vmcnt" in l]
+    spills = [l.strip() for l in loop if "scratch_" in l]
+    assert not waits, f"the forward loop waits for memory (and so for its own stores): {waits}"
+    assert not spills, f"the forward loop spills: {spills}"
