@@ -1044,19 +1044,18 @@ __global__ __launch_bounds__(RP_PBLOCK) void ctk_rpgd_mlp_persistent(RolloutArgs
         {
             const int r = t >> 3, part = t & 7;
             const float inv = a.inv_Hp1;
-            float gq[AB], q_own[AB], m_own[AB], v_own[AB];      // (the moments too, here: read in one batch, off the update's dependent path)
+            float gq[AB];
             float nrm2 = 0.0f;
 #pragma unroll
             for (int j = 0; j < AB; ++j) {
                 const int h = part + 8 * j;
-                gq[j] = 0.0f; q_own[j] = 0.0f; m_own[j] = 0.0f; v_own[j] = 0.0f;
+                gq[j] = 0.0f;
                 if (h < H) {
                     const float u_h = q_s[h * RP_WLD + r], u_hm1 = h > 0 ? q_s[(h - 1) * RP_WLD + r] : uprev0;
                     float gu = 2.0f * k.ccR * u_h + 2.0f * k.ccrc_weight * (u_h - u_hm1);
                     if (h + 1 < H) gu -= 2.0f * k.ccrc_weight * (q_s[(h + 1) * RP_WLD + r] - u_h);
                     gq[j] = gu * inv + g_s[h * RP_WLD + r];
                     nrm2 += gq[j] * gq[j];
-                    q_own[j] = u_h; m_own[j] = m_s[h * RP_WLD + r]; v_own[j] = v_s[h * RP_WLD + r];
                 }
             }
             nrm2 += dpp_mov<DPP_QUAD_XOR1>(nrm2);
@@ -1072,9 +1071,10 @@ __global__ __launch_bounds__(RP_PBLOCK) void ctk_rpgd_mlp_persistent(RolloutArgs
 #pragma unroll
                 for (int j = 0; j < AB; ++j) {
                     const int h = part + 8 * j;
-                    if (h < H) {
-                        q_s[h * RP_WLD + r] = adam_update(ad, q_own[j], gq[j] * scl, m_own[j], v_own[j], bc1, bc2, a.lo[0], a.hi[0]);
-                        m_s[h * RP_WLD + r] = m_own[j]; v_s[h * RP_WLD + r] = v_own[j];
+                    if (h < H) {   // (reading the moments in one batch ahead of the vote was 1 % faster and no longer bit-identical to the phase launches)
+                        float mm = m_s[h * RP_WLD + r], vv = v_s[h * RP_WLD + r];
+                        q_s[h * RP_WLD + r] = adam_update(ad, q_s[h * RP_WLD + r], gq[j] * scl, mm, vv, bc1, bc2, a.lo[0], a.hi[0]);
+                        m_s[h * RP_WLD + r] = mm; v_s[h * RP_WLD + r] = vv;
                     }
                 }
             }
@@ -1090,25 +1090,11 @@ __global__ __launch_bounds__(RP_PBLOCK) void ctk_rpgd_mlp_persistent(RolloutArgs
 #endif
     }
     // get_action's cost pass (:342), then the plans and moments back to memory
-#if defined(CTK_DIAG_PERS_PAIR_FINAL)   // experiment: the cost pass shared by the tile's two waves (other rounding of J than the phase launches')
-    {
-        float amax;
-        float* ex = ex_s + pair * RP_PAIR_EX;
-        const int traj0 = row0 + pair * CTK_MLP_TRAJ_PER_WAVE;
-        MlpFwdHalf wp = wh;
-        mlp_pin(wp);
-        float J = rollout_mlp_pair_impl<false, false, true, false>(a, k, wp, traj0, half, ex, [&](int h) { return q_s[h * RP_WLD + col]; }, &amax);
-        if (__builtin_expect(__syncthreads_or(!(amax <= CTK_SINCOS_FAST_LIMIT)), 0))
-            J = rollout_mlp_pair_impl<false, false, true, true>(a, k, wp, traj0, half, ex, [&](int h) { return q_s[h * RP_WLD + col]; }, &amax);
-        if (half == 0 && lane < 16 && row0 + col < a.N) a.J[row0 + col] = J;
-    }
-#else
-    if (half == 0) {   // (one wave per tile, as the phase launches' cost pass: the two forms agree bit for bit)
+    if (half == 0) {   // (one wave per tile, as the phase launches' cost pass: the two forms agree bit for bit; the pair form measured no faster, twice)
         const MlpFwdT wf = mlp_load_fwd_thin(wperm);
         const float J = rollout_mlp<false, false>(a, k, wf, row0 + pair * CTK_MLP_TRAJ_PER_WAVE, [&](int h) { return q_s[h * RP_WLD + col]; });
         if (lane < 16 && row0 + col < a.N) a.J[row0 + col] = J;
     }
-#endif
 #pragma unroll
     for (int j = 0; j < AB; ++j) {
         const int i = t + j * RP_BLOCK;
