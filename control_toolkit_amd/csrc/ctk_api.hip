@@ -352,9 +352,10 @@ const EnvInfo* env_info(int env) { return (env >= 0 && env < CTK_ENV_COUNT && kE
 // raw: per layer W_i[96,I'] W_h[96,32] b_i[96] b_h[96] (rows r|z|n, I' = I then 32), then W_o[S,32] b_o[S].
 std::vector<float> permute_gru_weights_g(const float* raw, int S, int C) {
     const int I = S + C;
-    std::vector<float> out((size_t)(GRUG_FWD + GRUG_BWD) * 64, 0.0f);
+    std::vector<float> out((size_t)GRUG_TABLE * 64, 0.0f);
     float* F = out.data();
     float* B = F + (size_t)GRUG_FWD * 64;
+    float* X = B + (size_t)GRUG_BWD * 64;              // layer 1's third k-step, [gate][tile] (S + C > 8; zeros otherwise)
     const float *Wi[2], *Wh[2], *bi[2], *bh[2];
     const float* p = raw;
     for (int L = 0; L < 2; ++L) {
@@ -376,6 +377,7 @@ std::vector<float> permute_gru_weights_g(const float* raw, int S, int C) {
                         F[(size_t)(base + (G * 2 + m) * KS + ks) * 64 + l] = (L == 0 && kk >= I) ? 0.0f : Wi[L][row * In + kk];
                     }
                     for (int j = 0; j < 8; ++j) F[(size_t)(base + 6 * KS + (G * 2 + m) * 8 + j) * 64 + l] = Wh[L][row * 32 + mlp_hid(j, g)];
+                    if (L == 0) X[(size_t)(G * 2 + m) * 64 + l] = 8 + g < I ? Wi[0][row * I + 8 + g] : 0.0f;
                 }
             const int bb = base + 6 * KS + 48;
             for (int m = 0; m < 2; ++m)
@@ -394,7 +396,7 @@ std::vector<float> permute_gru_weights_g(const float* raw, int S, int C) {
         // reverse: A operands of the transposed products; k-step (G, m, r) has k-slot g = gate neuron G*32 + 16m + 4g + r
         for (int m = 0; m < 2; ++m)
             for (int ks = 0; ks < 2; ++ks) B[(size_t)(m * 2 + ks) * 64 + l] = (4 * ks + g < S) ? Wo[(4 * ks + g) * 32 + 16 * m + i] : 0.0f;
-        const int inp = (i % 4 < 2 && io_of_row(i) < I) ? io_of_row(i) : -1;
+        const int inp = (i % 4 < 3 && io_of_row(i) < I) ? io_of_row(i) : -1;      // rows 4g + 0 / 1 / 2: network inputs g, 4 + g, 8 + g
         for (int G = 0; G < 3; ++G)
             for (int m = 0; m < 2; ++m)
                 for (int r = 0; r < 4; ++r) {
@@ -1193,9 +1195,9 @@ int ctk_create(const ctk_config* cfg, ctk_handle** out) {
     if (cfg->optimizer < CTK_OPT_MPPI || cfg->optimizer > CTK_OPT_CEM_GRAD_BHARADHWAJ)
         return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: unknown optimizer");
     if (cfg->predictor < CTK_PRED_ODE || cfg->predictor > CTK_PRED_GRU) return fail(nullptr, CTK_ERR_INVALID_ARGUMENT, "ctk_create: unknown predictor");
-    if (cfg->predictor == CTK_PRED_GRU && einfo->S + einfo->C > 8)
-        return fail(nullptr, CTK_ERR_UNSUPPORTED, std::string("ctk_create: the GRU predictor takes at most 8 network inputs (num_states + num_control_inputs); ") +
-                    einfo->name + " has " + std::to_string(einfo->S + einfo->C) + " — use the MLP (three layer-1 k-steps) or the analytic predictor");
+    if (cfg->predictor != CTK_PRED_ODE && einfo->S + einfo->C > 12)
+        return fail(nullptr, CTK_ERR_UNSUPPORTED, std::string("ctk_create: the network predictors take at most 12 network inputs (num_states + num_control_inputs: three "
+                    "layer-1 k-steps of four); ") + einfo->name + " has " + std::to_string(einfo->S + einfo->C));
     // variants run on an engine family: gradient = RPGD machinery without resampling (Keras Adam, fresh tail);
     // cem-naive-grad = CEM machinery with one SGD step on the samples
     ctk_config mapped = *cfg;

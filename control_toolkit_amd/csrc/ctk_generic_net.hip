@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64) void ctk_g_gru_advance(RolloutArgs a, const flo
     constexpr int S = E::S, C = E::C;
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    NetGru::Fwd net;
+    typename NetGruT<(S + C > 8)>::Fwd net;
     net.load(wperm, lds);
     __syncthreads();
     net.begin(hidden);
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64) void ctk_g_gru_advance(RolloutArgs a, const flo
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) u[cc] = u_dev ? u_dev[cc] : a.u_prev[cc];
     const float sv0 = g < S ? lane_state4(a, g) : 0.0f, sv1 = 4 + g < S ? lane_state4(a, g, 4) : 0.0f;
-    (void)net.step(first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g), 0.0f, nullptr);
+    (void)net.step(first_operand<S, C>(sv0, u, g), second_operand<S, C>(sv1, u, g), third_operand<S, C>(u, g), nullptr);
     __syncthreads();                       // every lane has read `hidden` (begin) before column 0 overwrites it
     if (c == 0) {
 #pragma unroll
@@ -354,11 +354,11 @@ static uint32_t magic_of(int d) { return d >= 2 ? (uint32_t)((0x100000000ull + (
 
 size_t ctk_g_net_table_floats(int net) {
     if (net == NET_MLP64) return (size_t)64 * (MLPW_FWD_PER_LANE + MLPW_BWD_PER_LANE);
-    return net == NET_GRU ? (size_t)(GRUG_FWD + GRUG_BWD) * 64 : (size_t)64 * (MLP_FWD_PER_LANE + MLP_BWD_PER_LANE);
+    return net == NET_GRU ? (size_t)GRUG_TABLE * 64 : (size_t)64 * (MLP_FWD_PER_LANE + MLP_BWD_PER_LANE);
 }
 size_t ctk_g_net_hidden_floats(int net) { return net == NET_GRU ? NetGru::HIDDEN : 0; }
 static const float* bwd_table(int net, const float* wperm) { return net == NET_GRU ? wperm + (size_t)GRUG_FWD * 64 : wperm; }
-static size_t net_lds_fwd(int net) { return net == NET_GRU ? NetGru::LDS_FWD : 0; }
+static size_t net_lds_fwd(int net) { return net == NET_GRU ? NetGruT<true>::LDS_FWD : 0; }     // (the larger of the two forms: six entries)
 static size_t net_lds_bwd(int net) { return net == NET_GRU ? NetGru::LDS_BWD : 0; }
 
 int ctk_g_rollout_net_cols(int env, int mode, int P, int H) {
@@ -377,7 +377,7 @@ const char* ctk_g_rollout_net_name(int env, int net, int mode, bool log, int N, 
     int io = 0;
     CTK_FOR_ENV(env, EV, { io = Env<EV>::S + Env<EV>::C; });
     return ctk_kernel_name("ctk_g_rollout_net<%d, %4$s, %d, %5$s>", env, mode, 0,
-                           net == NET_MLP64 ? (io > 8 ? "NetMlpWideT<true>" : "NetMlpWideT<false>") : net == NET_GRU ? "NetGru" : (io > 8 ? "NetMlpT<true>" : "NetMlp"),
+                           net == NET_MLP64 ? (io > 8 ? "NetMlpWideT<true>" : "NetMlpWideT<false>") : net == NET_GRU ? (io > 8 ? "NetGruT<true>" : "NetGru") : (io > 8 ? "NetMlpT<true>" : "NetMlp"),
                            log ? "true" : "false");
 }
 
@@ -437,7 +437,7 @@ hipError_t ctk_launch_g_rollout_net(hipStream_t st, int env, int net, int mode, 
         return ctk_launch_g_rollout_split(st, env, net, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
     CTK_FOR_ENV(env, EV, {
         using MLP = NetMlpT<(Env<EV>::S + Env<EV>::C > 8)>;      // a third layer-1 k-step where the environment has more than 8 network inputs
-        if (net == NET_GRU) launch_rollout_net<EV, NetGru>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
+        if (net == NET_GRU) launch_rollout_net<EV, NetGruT<(Env<EV>::S + Env<EV>::C > 8)>>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
         else if (net == NET_MLP64)
             launch_rollout_net<EV, NetMlpWideT<(Env<EV>::S + Env<EV>::C > 8)>>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
         else launch_rollout_net<EV, MLP>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
@@ -464,7 +464,7 @@ const char* ctk_g_rpgd_descent_net_name(int env, int net, int N, int H) {
     int io = 0;
     CTK_FOR_ENV(env, EV, { io = Env<EV>::S + Env<EV>::C; });
     return ctk_kernel_name("ctk_g_rpgd_descent_net<%d, %4$s>", env, 0, 0,
-                           net == NET_MLP64 ? (io > 8 ? "NetMlpWideT<true>" : "NetMlpWideT<false>") : net == NET_GRU ? "NetGru" : (io > 8 ? "NetMlpT<true>" : "NetMlp"));
+                           net == NET_MLP64 ? (io > 8 ? "NetMlpWideT<true>" : "NetMlpWideT<false>") : net == NET_GRU ? (io > 8 ? "NetGruT<true>" : "NetGru") : (io > 8 ? "NetMlpT<true>" : "NetMlp"));
 }
 
 hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const RolloutArgs& a_in, const float* params, float dt, int isteps,
@@ -486,7 +486,7 @@ hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const
         const dim3 grid((a.N + GN_TRAJ - 1) / GN_TRAJ), block(GN_BLOCK);
         const size_t lds = ctk_g_rpgd_descent_net_lds(env, net, 1 << 30, a.H);   // this (one-wave) form
         if (net == NET_GRU)
-            CTK_LAUNCH((ctk_g_rpgd_descent_net<EV, NetGru>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wb, hidden, scratch);
+            CTK_LAUNCH((ctk_g_rpgd_descent_net<EV, NetGruT<(E::S + E::C > 8)>>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wb, hidden, scratch);
         else if (net == NET_MLP64)
             CTK_LAUNCH((ctk_g_rpgd_descent_net<EV, NetMlpWideT<(E::S + E::C > 8)>>), grid, block, lds, st, e0, e1, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wb, hidden, scratch);
         else
@@ -498,9 +498,11 @@ hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const
 hipError_t ctk_launch_g_gru_advance(hipStream_t st, int env, const RolloutArgs& a, const float* u_dev, float* wperm) {
     float* hidden = wperm + ctk_g_net_table_floats(NET_GRU);
     static const bool one_wave = getenv("CTK_NET_ONE_WAVE") != nullptr;
-    if (!one_wave) return ctk_launch_g_gru_advance4(st, env, a, u_dev, wperm, hidden);      // ctk_net_split.hip: the four-wave step
+    int io = 0;
+    CTK_FOR_ENV(env, EV, { io = Env<EV>::S + Env<EV>::C; });
+    if (!one_wave && io <= 8) return ctk_launch_g_gru_advance4(st, env, a, u_dev, wperm, hidden);      // ctk_net_split.hip: the four-wave step (S + C <= 8)
     CTK_FOR_ENV(env, EV, {
-        hipLaunchKernelGGL((ctk_g_gru_advance<EV>), dim3(1), dim3(64), NetGru::LDS_FWD * sizeof(float), st, a, u_dev, wperm, hidden);
+        hipLaunchKernelGGL((ctk_g_gru_advance<EV>), dim3(1), dim3(64), NetGruT<true>::LDS_FWD * sizeof(float), st, a, u_dev, wperm, hidden);
     });
     return hipGetLastError();
 }

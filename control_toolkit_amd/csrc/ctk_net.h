@@ -64,6 +64,11 @@ using NetMlp3 = NetMlpT<true>;
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int GRUG_L1 = 92, GRUG_L2 = 128, GRUG_FWD = GRUG_L1 + GRUG_L2 + 12;      // 232
 constexpr int GRUG_BWD = 4 + 96 + 72;                                                // 172
+// environments with more than 8 network inputs (K3): layer 1's THIRD k-step, Wi3 [gate][tile] (k-slot g = input 8 + g), kept BEHIND the
+// reverse table so that every offset above holds for both; the reverse table needs nothing more (inputs 8 + g are rows 4g + 2 of the one
+// input tile it already has).  The table of every GRU handle has the six entries (zeros where S + C <= 8).
+constexpr int GRUG_X3 = 6;
+constexpr int GRUG_TABLE = GRUG_FWD + GRUG_BWD + GRUG_X3;                            // 410
 
 struct GruLayerTape {       // D layout, per hidden tile
     f32x4 r[2], z[2], n[2], ghn[2], hp[2];
@@ -71,12 +76,14 @@ struct GruLayerTape {       // D layout, per hidden tile
 
 CTK_DEV float gru_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
 
-struct NetGru {
-    static constexpr int TAPE = 84, LDS_FWD = GRUG_FWD * 64, LDS_BWD = GRUG_BWD * 64, HIDDEN = 64;
-    static constexpr bool THREE_KSTEPS = false;      // S + C <= 8 only (ctk_create refuses the GRU for larger environments)
+template <bool K3>
+struct NetGruT {
+    static constexpr int TAPE = 84, LDS_FWD = (GRUG_FWD + (K3 ? GRUG_X3 : 0)) * 64, LDS_BWD = GRUG_BWD * 64, HIDDEN = 64;
+    static constexpr bool THREE_KSTEPS = K3;         // K3: a third layer-1 k-step (network inputs 8 + g), as NetMlpT<true>
 
-    template <int KS, class XFn>
-    CTK_DEV static void layer_fwd(const float* tab, int lane, XFn&& xb, f32x4 (&h)[2], GruLayerTape* tp) {
+    // wi3 / x3: the third k-step of layer 1 (X3 only)
+    template <int KS, bool X3 = false, class XFn>
+    CTK_DEV static void layer_fwd(const float* tab, int lane, XFn&& xb, f32x4 (&h)[2], GruLayerTape* tp, const float* wi3 = nullptr, float x3 = 0.0f) {
         const float* wi = tab;
         const float* wh = tab + 6 * KS * 64;
         const float* bb = wh + 48 * 64;
@@ -96,6 +103,14 @@ struct NetGru {
                 ar[m] = CTK_MFMA(wi[((0 * 2 + m) * KS + ks) * 64 + lane], x, ar[m]);
                 az[m] = CTK_MFMA(wi[((1 * 2 + m) * KS + ks) * 64 + lane], x, az[m]);
                 ani[m] = CTK_MFMA(wi[((2 * 2 + m) * KS + ks) * 64 + lane], x, ani[m]);
+            }
+        }
+        if constexpr (X3) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ar[m] = CTK_MFMA(wi3[(0 * 2 + m) * 64 + lane], x3, ar[m]);
+                az[m] = CTK_MFMA(wi3[(1 * 2 + m) * 64 + lane], x3, az[m]);
+                ani[m] = CTK_MFMA(wi3[(2 * 2 + m) * 64 + lane], x3, ani[m]);
             }
         }
 #pragma unroll
@@ -128,7 +143,9 @@ struct NetGru {
         f32x4 h1[2], h2[2];
         int lane;
         CTK_DEV void load(const float* __restrict__ table, float* lds) {   // all threads of the workgroup stage the table; caller syncs
-            for (int i = threadIdx.x; i < LDS_FWD; i += blockDim.x) lds[i] = table[i];
+            for (int i = threadIdx.x; i < GRUG_FWD * 64; i += blockDim.x) lds[i] = table[i];
+            if constexpr (K3)
+                for (int i = threadIdx.x; i < GRUG_X3 * 64; i += blockDim.x) lds[GRUG_FWD * 64 + i] = table[(GRUG_FWD + GRUG_BWD) * 64 + i];
             tab = lds; lane = threadIdx.x & 63;
         }
         CTK_DEV void begin(const float* __restrict__ hidden) {             // every rollout starts from the carried hidden state
@@ -138,9 +155,9 @@ struct NetGru {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { h1[m][r] = hidden[16 * m + 4 * g + r]; h2[m][r] = hidden[32 + 16 * m + 4 * g + r]; }
         }
-        CTK_DEV MlpPair step(float x0, float x1, float /*x2*/, float4* tape) {
+        CTK_DEV MlpPair step(float x0, float x1, float x2, float4* tape) {
             GruLayerTape t1, t2;
-            layer_fwd<2>(tab, lane, [&](int ks) { return ks == 0 ? x0 : x1; }, h1, tape ? &t1 : nullptr);
+            layer_fwd<2, K3>(tab, lane, [&](int ks) { return ks == 0 ? x0 : x1; }, h1, tape ? &t1 : nullptr, tab + GRUG_FWD * 64, x2);
             const f32x4 a = h1[0], b = h1[1];
             layer_fwd<8>(tab + GRUG_L1 * 64, lane, [&](int j) { return (j >> 2) ? b[j & 3] : a[j & 3]; }, h2, tape ? &t2 : nullptr);
             const float* wo = tab + (GRUG_L1 + GRUG_L2) * 64;
@@ -153,7 +170,7 @@ struct NetGru {
                 o1 = CTK_MFMA(wo[(j + 1) * 64 + lane], h2[(j + 1) >> 2][(j + 1) & 3], o1);
             }
             if (tape) {
-                tape[0] = make_float4(x0, x1, 0.f, 0.f);
+                tape[0] = make_float4(x0, x1, x2, 0.f);
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     tape[1 + m] = st4(t1.r[m]); tape[3 + m] = st4(t1.z[m]); tape[5 + m] = st4(t1.n[m]); tape[7 + m] = st4(t1.ghn[m]); tape[9 + m] = st4(t1.hp[m]);
@@ -237,9 +254,10 @@ struct NetGru {
             f32x4 din[2] = {zero, zero};
             layer_products<1>(tab + (4 + 96) * 64, tab + (4 + 96 + 24) * 64, dar, daz, dan, dghn, din, dhp);
             dh1[0] = dhp[0]; dh1[1] = dhp[1];
-            return MlpPair{din[0][0], din[0][1]};
+            return MlpPair{din[0][0], din[0][1], din[0][2]};      // network inputs g, 4 + g, 8 + g (rows 4g + 0 / 1 / 2 of the input tile)
         }
     };
 };
+using NetGru = NetGruT<false>;
 
 #include "ctk_mlp_wide.h"

@@ -4,8 +4,10 @@
    optimizer_mppi.py / optimizer_rpgd.py driven through controller_mpc with a 7-state, 3-input plant);
  * plain rollouts, CEM, random-action and the single-gradient check against the oracle (parity pinned only through the oracle's own
    fixtures above: the reference has no CEM fixture on this plant);
- * what the third environment does NOT have (the GRU predictor: its input tile is 8 wide) fails at create.
-Tolerances as in test_gpu_env.py."""
+ * the GRU predictor with ten network inputs (ctk_net.h: NetGruT<true>, a third layer-1 k-step; round 4 — until then refused at create):
+   the same tests against the oracle, the hidden state carried over closed-loop steps, back-propagation through time with the
+   adjoints of network inputs 8 and 9.
+Tolerances as in test_gpu_env.py; the GRU's as in test_gpu_gru_grad.py (sigmoid / tanh through v_exp_f32 / v_rcp_f32)."""
 import numpy as np
 import pytest
 
@@ -22,6 +24,19 @@ pytestmark = pytest.mark.gpu
 
 HLO, HHI = np.array([-1.0, -0.7, -0.5], np.float32), np.array([0.9, 1.0, 0.5], np.float32)
 S0 = np.array([0.2, -0.1, -0.3, 0.15, 0.4, -0.2, 0.5], np.float32)
+KINDS = ["ODE", "MLP", "GRU"]
+
+
+def hover_weights(kind, seed):
+    return O.mlp_default_weights(seed, 10, 7) if kind == "MLP" else O.gru_default_weights(seed, 10, 7) if kind == "GRU" else None
+
+
+def j_tol(kind):
+    return dict(rtol=1e-4, atol=2e-3) if kind == "GRU" else dict(rtol=5e-5, atol=1e-3) if kind == "MLP" else dict(rtol=3e-5)
+
+
+def traj_tol(kind, H=25):
+    return dict(rtol=2e-4, atol=5e-5 * max(1, H // 25)) if kind == "GRU" else dict(rtol=1e-4, atol=3e-5 * max(1, H // 25))
 
 
 def hover_env(**kw):
@@ -53,16 +68,17 @@ def test_hover_env_info_and_errors():
     with pytest.raises(ValueError, match="expected"):
         em.set_predictor_weights(np.zeros(O.mlp_num_weights(8, 6), np.float32))
     em.close()
-    with pytest.raises(NotImplementedError):       # the GRU's input tile holds 8 columns; 7 + 3 does not fit (ctk_api.hip: create)
-        CtkEngine("mppi", "GRU", environment="Hover", num_rollouts=8, mpc_horizon=5, dt=0.02)
+    eg = CtkEngine("mppi", "GRU", environment="Hover", num_rollouts=8, mpc_horizon=5, dt=0.02)     # ten network inputs: the one-wave GRU with a third k-step
+    assert eg.predictor_weight_count() == O.gru_num_weights(10, 7) and "NetGruT<true>" in eg.dominant_kernel(), eg.dominant_kernel()
+    eg.close()
     with pytest.raises(ValueError):
         CtkEngine("mppi", "ODE", environment="Hover", num_rollouts=8, mpc_horizon=5, dt=0.02, action_low=[-1, -1])
 
 
-@pytest.mark.parametrize("kind", ["ODE", "MLP"])
+@pytest.mark.parametrize("kind", KINDS)
 def test_hover_plain_rollout_matches_oracle(kind):
     env = hover_env(target_x=0.3, target_y=-0.2)
-    w = O.mlp_default_weights(11, 10, 7) if kind == "MLP" else None
+    w = hover_weights(kind, 11)
     pred, cost = O.Predictor(kind, env=env, weights=w), O.Cost(env)
     e = CtkEngine("mppi", kind, environment="Hover", num_rollouts=64, mpc_horizon=30, dt=0.02, action_low=HLO, action_high=HHI)
     apply_params(e, env)
@@ -70,10 +86,13 @@ def test_hover_plain_rollout_matches_oracle(kind):
         e.set_predictor_weights(w)
     Q = np.random.default_rng(0).uniform(-1, 1, (37, 30, 3)).astype(np.float32)
     up = np.array([0.2, -0.3, 0.1], np.float32)
+    if kind == "GRU":
+        pred.hidden = (0.2 * np.random.default_rng(5).standard_normal((2, 32))).astype(np.float32)
+        e.predictor_set_hidden(pred.hidden)
     traj, J = e.rollout(S0, Q, u_prev=up)
     to = pred.predict_core(np.tile(S0, (37, 1)), Q)
-    np.testing.assert_allclose(traj, to, rtol=1e-4, atol=3e-5)
-    np.testing.assert_allclose(J, cost.get_trajectory_cost(to, Q, up), rtol=5e-5, atol=1e-3 if kind == "MLP" else 0)
+    np.testing.assert_allclose(traj, to, **traj_tol(kind))
+    np.testing.assert_allclose(J, cost.get_trajectory_cost(to, Q, up), **(j_tol(kind) if kind != "ODE" else dict(rtol=5e-5)))
     e.close()
 
 
@@ -128,11 +147,11 @@ def test_hover_rpgd_matches_reference_golden(case):
     e.close()
 
 
-@pytest.mark.parametrize("kind", ["ODE", "MLP"])
+@pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("N,H,p", [(1024, 40, 1), (300, 35, 10), (70, 7, 3), (1, 1, 1)])
 def test_hover_mppi_matches_oracle(kind, N, H, p):
     env = hover_env(target_x=0.3)
-    w = O.mlp_default_weights(12, 10, 7) if kind == "MLP" else None
+    w = hover_weights(kind, 12)
     pred = O.Predictor(kind, env=env, weights=w)
     o = O.MPPI(pred, O.Cost(env), HLO, HHI, num_rollouts=N, mpc_horizon=H, period_interpolation_inducing_points=p)
     e = CtkEngine("mppi", kind, environment="Hover", num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p,
@@ -143,16 +162,20 @@ def test_hover_mppi_matches_oracle(kind, N, H, p):
     assert e.inducing_points() == o.P and e.samples_needed() == N * o.P * 3
     rng = np.random.default_rng(N + H)
     s = S0.copy()
-    jt = dict(rtol=5e-5, atol=1e-3) if kind == "MLP" else dict(rtol=3e-5)
+    jt = j_tol(kind)
     for t in range(3):
         noise = rng.standard_normal((N, o.P, 3)).astype(np.float32)
         uo, ug = o.step(s, noise), e.step(s, noise)
         np.testing.assert_allclose(e.read("Q"), o.u_run, rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(e.read("J"), o.J, **jt)
-        np.testing.assert_allclose(e.read("TRAJ"), o.rollout_trajectories, rtol=1e-4, atol=3e-5 * max(1, H // 25))
+        np.testing.assert_allclose(e.read("TRAJ"), o.rollout_trajectories, **traj_tol(kind, H))
         np.testing.assert_allclose(e.read("U_NOM"), o.u_nom, **U_TOL)
         np.testing.assert_allclose(ug, np.asarray(uo).reshape(-1), **U_TOL)
-        s = pred.step(s.reshape(1, 7), np.asarray(uo, np.float32).reshape(1, 3))[0]
+        if kind == "GRU":       # predictor.update(s, u) after every step (optimizer_mppi.py:195-197): the hidden state the next rollouts start from
+            np.testing.assert_allclose(e.predictor_get_hidden(), pred.hidden, rtol=1e-5, atol=2e-6)
+            s = (s + np.array([0.01, 0.0, -0.02, 0.01, 0.0, 0.02, -0.01], np.float32)).astype(np.float32)
+        else:
+            s = pred.step(s.reshape(1, 7), np.asarray(uo, np.float32).reshape(1, 3))[0]
     e.close()
 
 
@@ -171,13 +194,13 @@ def test_hover_mppi_device_draws():
     e.close()
 
 
-@pytest.mark.parametrize("kind", ["ODE", "MLP"])
+@pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("N,H,K", [(512, 30, 51), (100, 9, 10)])
 def test_hover_cem_and_random_match_oracle(kind, N, H, K):
     env = hover_env(target_y=0.25)
-    w = O.mlp_default_weights(13, 10, 7) if kind == "MLP" else None
+    w = hover_weights(kind, 13)
     pred = O.Predictor(kind, env=env, weights=w)
-    jt = dict(rtol=5e-5, atol=1e-3) if kind == "MLP" else dict(rtol=3e-5)
+    jt = j_tol(kind)
     o = O.CEM(pred, O.Cost(env), HLO, HHI, num_rollouts=N, mpc_horizon=H, cem_outer_it=3, cem_best_k=K)
     e = CtkEngine("cem", kind, environment="Hover", num_rollouts=N, mpc_horizon=H, dt=0.02, cem_outer_it=3, cem_best_k=K,
                   action_low=HLO, action_high=HHI)
@@ -206,12 +229,12 @@ def test_hover_cem_and_random_match_oracle(kind, N, H, K):
     e.close()
 
 
-@pytest.mark.parametrize("kind", ["ODE", "MLP"])
+@pytest.mark.parametrize("kind", KINDS)
 def test_hover_single_gradient_matches_oracle_adjoint(kind):
     """one Adam iteration from zero moments: m = (1 - beta1) * dJ/dQ — isolates the reverse sweep (E::bwd_tape / mlp_step_vjp2 with the third
     k-step's input adjoints) for S = 7, C = 3"""
     env = hover_env(target_x=0.2, target_y=-0.3)
-    w = O.mlp_default_weights(14, 10, 7) if kind == "MLP" else None
+    w = hover_weights(kind, 14)
     pred, cost = O.Predictor(kind, env=env, weights=w), O.Cost(env)
     N, H = 64, 20
     e = CtkEngine("rpgd", kind, environment="Hover", num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=1,
@@ -220,13 +243,43 @@ def test_hover_single_gradient_matches_oracle_adjoint(kind):
     apply_params(e, env)
     if w is not None:
         e.set_predictor_weights(w)
+    if kind == "GRU":           # back-propagation through time from a non-zero hidden state (NetGruT<true>::Bwd: inputs 8, 9 are rows 4g + 2 of the input tile)
+        pred.hidden = (0.2 * np.random.default_rng(1).standard_normal((2, 32))).astype(np.float32)
+        e.predictor_set_hidden(pred.hidden)
     e.reset(np.random.default_rng(3).random((N, H, 3), dtype=np.float32))
     Q0 = e.read("PLAN")
     up = np.array([0.05, -0.02, 0.1], np.float32)
     e.set_state(np.concatenate([Q0.ravel(), np.zeros(2 * N * H * 3 + N, np.float32), up, [0], [1]]).astype(np.float32))
     e.step(S0, None, u_prev=up)
     _, _, g = O.rollout_cost_and_grad(pred, cost, np.tile(S0, (N, 1)), Q0, up)
-    np.testing.assert_allclose(e.read("ADAM_M")[:, :-1, :], 0.1 * g[:, 1:, :], rtol=2e-3, atol=2e-4 * np.abs(g).max())
+    np.testing.assert_allclose(e.read("ADAM_M")[:, :-1, :], 0.1 * g[:, 1:, :], rtol=3e-3 if kind == "GRU" else 2e-3, atol=(3e-4 if kind == "GRU" else 2e-4) * np.abs(g).max())
+    e.close()
+
+
+def test_hover_rpgd_with_gru_matches_oracle():
+    """closed-loop RPGD through the ten-input GRU (forward with the third k-step, BPTT, Adam, keep-k, resampling) against the oracle"""
+    env = hover_env(target_x=0.25)
+    w = hover_weights("GRU", 15)
+    pred = O.Predictor("GRU", env=env, weights=w)
+    N, H, p, its = 32, 20, 5, 3
+    o = O.RPGD(pred, O.Cost(env), HLO, HHI, num_rollouts=N, mpc_horizon=H, outer_its=its, resamp_per=2, period_interpolation_inducing_points=p,
+               SAMPLING_DISTRIBUTION="uniform", opt_keep_k_ratio=0.25)
+    e = CtkEngine("rpgd", "GRU", environment="Hover", num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p, outer_its=its,
+                  resamp_per=2, opt_keep_k=o.k, sampling_distribution=0, sample_whole_control_space=1, action_low=HLO, action_high=HHI)
+    apply_params(e, env)
+    e.set_predictor_weights(w)
+    rng = np.random.default_rng(8)
+    d0 = rng.random((N, o.P, 3), dtype=np.float32)
+    o.optimizer_reset(d0); e.reset(d0)
+    tol = dict(rtol=5e-4, atol=5e-4)
+    s = S0.copy()
+    for t in range(3):
+        dr = rng.random((N - o.k, o.P, 3), dtype=np.float32) if t % 2 == 0 else None
+        uo, ug = o.step(s, dr), e.step(s, dr)
+        assert_close_mostly(e.read("PLAN"), o.Q, max_outliers=max(4, o.Q.size // 400), **tol)
+        assert_close_mostly(e.read("ADAM_M"), o.opt.m, max_outliers=max(4, o.Q.size // 400), **tol)
+        np.testing.assert_allclose(ug, np.asarray(uo).reshape(-1), **tol)
+        s = (s + np.array([0.01, 0.0, -0.02, 0.01, 0.0, 0.02, -0.01], np.float32)).astype(np.float32)
     e.close()
 
 

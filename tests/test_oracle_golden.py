@@ -344,7 +344,7 @@ def test_rpgd_two_inputs_matches_reference(case):
 
 
 # ---- the oracle's hand-written reverse modes against torch autograd in fp64 (build container and GPU box: torch-CPU) ------------
-@pytest.mark.parametrize("kind,envname", [("GRU", "CartPole"), ("GRU", "Quad2D"), ("MLP", "Quad2D"), ("ODE", "Quad2D"), ("ODE", "Hover"), ("MLP", "Hover")])
+@pytest.mark.parametrize("kind,envname", [("GRU", "CartPole"), ("GRU", "Quad2D"), ("MLP", "Quad2D"), ("ODE", "Quad2D"), ("ODE", "Hover"), ("MLP", "Hover"), ("GRU", "Hover")])
 def test_oracle_adjoints_match_torch_autograd_fp64(kind, envname):
     """d(sum_n J_n)/dQ from rollout_cost_and_grad (what the HIP reverse sweeps are tested against) == autograd through a
     float64 torch restatement of the same rollout and cost (what the reference does at optimizer_rpgd.py:329-333)."""
