@@ -901,7 +901,7 @@ int launch_descent(ctk_handle* h, const RolloutArgs& a, float lr, float b1, floa
     if (h->generic && c.predictor != CTK_PRED_ODE)
         HIP_TRY(h, ctk_launch_g_rpgd_descent_net(h->stream, h->env, h->net, a, h->params, c.dt, c.intermediate_steps, lr, b1, b2, eps,
                                                  c.gradmax_clip, Q, m, v, bc, bc_len, t0, iters, h->d_wperm, h->d_scratch, ps.a, ps.b, rule,
-                                                 reinterpret_cast<uint32_t*>(h->h_u_dev) + 2));     // (the error word behind {u, seq})
+                                                 reinterpret_cast<uint32_t*>(h->h_u_dev) + 2, &h->rp_pers));     // (the error word behind {u, seq})
     else if (h->generic)
         HIP_TRY(h, ctk_launch_g_rpgd_descent(h->stream, h->env, a, h->params, c.dt, c.intermediate_steps, lr, b1, b2, eps, c.gradmax_clip, Q, m, v,
                                              bc, bc_len, t0, iters, h->d_scratch, ps.a, ps.b, rule));

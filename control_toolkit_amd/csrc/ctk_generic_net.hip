@@ -459,7 +459,7 @@ size_t ctk_g_rpgd_scratch_floats_net(int net, int N, int H) {
 }
 
 const char* ctk_g_rpgd_descent_net_name(int env, int net, int N, int H) {
-    if (ctk_g_rpgd_wide_ok(env, net, N, H)) return ctk_g_rpgd_wide_name(env);
+    if (ctk_g_rpgd_wide_ok(env, net, N, H)) return ctk_g_rpgd_wide_name(env, N, H);
     if (ctk_g_rpgd_split_ok(env, net, N, H)) return ctk_g_rpgd_descent_split_name(env, net);
     int io = 0;
     CTK_FOR_ENV(env, EV, { io = Env<EV>::S + Env<EV>::C; });
@@ -470,12 +470,12 @@ const char* ctk_g_rpgd_descent_net_name(int env, int net, int N, int H) {
 hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const RolloutArgs& a_in, const float* params, float dt, int isteps,
                                          float lr, float b1, float b2, float eps, float clip, float* Q, float* m, float* v,
                                          const float* bc_table, int bc_len, int t0, int iters, const float* wperm, float* scratch,
-                                         hipEvent_t e0, hipEvent_t e1, int rule, uint32_t* err_word) {
+                                         hipEvent_t e0, hipEvent_t e1, int rule, uint32_t* err_word, RpgdPersist* pers) {
     AdamK ad{lr, b1, b2, (float)(1.0 - (double)b1), (float)(1.0 - (double)b2), eps, clip, rule};
     const float* hidden = wperm + ctk_g_net_table_floats(net);
     const float* wb = bwd_table(net, wperm);
     if (ctk_g_rpgd_wide_ok(env, net, a_in.N, a_in.H))       // MLP, N <= 4 096: phase + grid-wide Jacobian launches (ctk_net_split.hip)
-        return ctk_launch_g_rpgd_wide_split(st, env, a_in, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, scratch, e0, e1, err_word);
+        return ctk_launch_g_rpgd_wide_split(st, env, a_in, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, scratch, e0, e1, err_word, pers);
     if (ctk_g_rpgd_split_ok(env, net, a_in.N, a_in.H))      // one tile over several waves while the population leaves SIMDs idle (ctk_net_split.hip)
         return ctk_launch_g_rpgd_descent_split(st, env, net, a_in, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wb, hidden, scratch, e0, e1);
     CTK_FOR_ENV(env, EV, {

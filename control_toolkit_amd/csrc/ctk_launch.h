@@ -285,10 +285,11 @@ hipError_t ctk_launch_g_rpgd_descent_split(hipStream_t st, int env, int net, con
                                            hipEvent_t e0, hipEvent_t e1);
 bool ctk_g_rpgd_wide_ok(int env, int net, int N, int H);          // the MLP descent as phase + Jacobian launches (N <= 4 096)
 size_t ctk_g_rpgd_scratch_floats_wide(int N, int H);
-const char* ctk_g_rpgd_wide_name(int env);
+const char* ctk_g_rpgd_wide_name(int env, int N = 0, int H = 0);
 hipError_t ctk_launch_g_rpgd_wide_split(hipStream_t st, int env, const RolloutArgs& a, const float* params, float dt, int isteps, const AdamK& ad,
                                         float* Q, float* m, float* v, const float* bc_table, int bc_len, int t0, int iters, const float* wperm,
-                                        float* scratch, hipEvent_t e0, hipEvent_t e1, uint32_t* err_word);
+                                        float* scratch, hipEvent_t e0, hipEvent_t e1, uint32_t* err_word, RpgdPersist* pers = nullptr);
+bool ctk_g_rpgd_persist_ok(int env, int net, int N, int H);   // the wide form as one launch per MPC step (ctk_g_rpgd_persist)
 bool ctk_g_rollout_split_ok(int env, int net, int N, int H, int cols);
 size_t ctk_g_rollout_split_lds(int net, int cols, int H, int C);
 int ctk_g_rollout_split_blocks(int N);
@@ -309,6 +310,7 @@ hipError_t ctk_launch_g_rpgd_descent_gru4(hipStream_t st, int env, const Rollout
 hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const RolloutArgs& a, const float* params, float dt, int isteps,
                                          float lr, float b1, float b2, float eps, float clip, float* Q, float* m, float* v,
                                          const float* bc_table, int bc_len, int t0, int iters, const float* wperm, float* scratch,
-                                         hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int rule = 0, uint32_t* err_word = nullptr);
+                                         hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int rule = 0, uint32_t* err_word = nullptr,
+                                         RpgdPersist* pers = nullptr);
 // predictor.update(s, Q0) for the GRU under the template kernels: a.s0 = measured state, a.u_prev = applied input (u_dev overrides)
 hipError_t ctk_launch_g_gru_advance(hipStream_t st, int env, const RolloutArgs& a, const float* u_dev, float* wperm);

@@ -601,7 +601,7 @@ CTK_DEV void jac_tangents(const MlpFwdW& w, const f32x4 (&d1)[2], const f32x4 (&
     const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < IO; ++j) {
-        if (jstep != 1 && (j % 2) != j0) continue;                      // (wave-uniform)
+        if (jstep != 1 && (j % jstep) != j0) continue;                  // (wave-uniform)
         const float ind = (g == (j & 3)) ? 1.0f : 0.0f;                 // B = e_j: input j lives in k-step j / 4, k-slot j % 4
         f32x4 t1[2];
 #pragma unroll
@@ -1085,6 +1085,415 @@ __global__ __launch_bounds__(128) void ctk_g_rpgd_wide_split(RolloutArgs a, type
     }
 }
 
+// ---- RPGD + MLP, the wide form as ONE launch per MPC step (round 4; the template counterpart of ctk_rpgd.hip: ctk_rpgd_mlp_persistent) ----------
+// The first `tiles` workgroups are the producers of ctk_g_rpgd_wide_split (one 16-plan tile each, two waves; plans, Adam moments and
+// weights resident for all `iters` iterations), the rest Jacobian WORKERS that stay for the whole step:
+//   forward pass : every step's network inputs leave as 8-byte {value, seq} words — {state g}, {state 4 + g}, {input g} per lane (value and
+//                  number in one store: who sees the number has the value; nothing waits on the recurrence, no activation tape);
+//   worker       : next (iteration, step, tile) ticket, polls the step's words, recomputes the step's activations bit for bit as
+//                  SplitMlp::Fwd::step forms them (the folded layer-1 bias, wave 1's k-step order), S + C tangents over its four waves into an
+//                  LDS image of the record, the cost's state gradient, everything stored through to memory, each wave waits, the step's flag;
+//   update       : both producer waves poll the tile's H flags, acquire, copy the cost-gradient terms in (LDS-DMA) and walk the chain on
+//                  plain loads of the records — then clip_by_norm and Adam on LDS-resident moments.
+// Same arithmetic as the phase launches, statement for statement: tests/test_gpu_env.py holds the two bit for bit.  Every poll is bounded
+// (ctk_rpgd.hip: RP_POLL_TICKS' 200 ms); seq = seq0 + iteration.  H <= 64, iters <= 63, up to 32 tiles.
+constexpr unsigned long long GP_POLL_TICKS = 20000000ull;
+struct GPersistK {
+    uint32_t seq0, ticket_base;
+    uint32_t* err_word;
+    int tiles, withhold;
+};
+__host__ __device__ inline size_t gp_ticket_off(int tiles, int H, int C) { return (size_t)tiles * gw_tile_floats(H, C); }
+
+CTK_DEV void gp_gave_up(uint32_t* err_word, int what, int h, int tile, uint32_t seen, uint32_t want, unsigned long long t_begin) {
+    if (err_word == nullptr) return;
+    const unsigned long long us = (wall_clock64() - t_begin) / 100u;
+    __hip_atomic_store(err_word + 6, ((uint32_t)what << 20) | ((uint32_t)h << 10) | (uint32_t)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(err_word + 7, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(err_word + 8, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(err_word + 9, (uint32_t)(us > 0xffffffffull ? 0xffffffffull : us), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(err_word, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <int ENV, bool K3>
+__global__ __launch_bounds__(256) void ctk_g_rpgd_persist(RolloutArgs a, typename Env<ENV>::K k, AdamK ad, float* __restrict__ Q, float* __restrict__ mom,
+                                                         float* __restrict__ var, const float* __restrict__ bc_table, int bc_len, int t0, int iters,
+                                                         const float* __restrict__ wperm, float* __restrict__ scratch, GPersistK pk) {
+    using E = Env<ENV>;
+    using SP = SplitMlp<K3>;
+    constexpr int S = E::S, C = E::C, IO = S + C, BLOCK = 128, NPARTS = BLOCK / G4_TRAJ;
+    constexpr int KS = K3 ? 3 : 2, NF = SP::Fwd::template fold_n<S, C>(), CC0 = 4 * (KS - 1) - S;
+    constexpr bool FOLD = NF > 0;
+    extern __shared__ float lds[];
+    const int H = a.H, HC = H * C;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 15, g = lane >> 4;
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(scratch + gp_ticket_off(pk.tiles, H, C));
+    if ((int)blockIdx.x >= pk.tiles) {
+        // ------------------------------------------------------------------------------------------ a Jacobian worker (four waves)
+        const MlpFwdW w = mlp_load_fwd(wperm);
+        f32x4 w1u[2][NF > 0 ? NF : 1];                                   // the folded layer-1 columns at this lane's accumulator rows (SplitMlp::fold_load)
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w1u[m][f][r] = __shfl(w.w1[m][KS - 1], 4 * g + r + 16 * f, 64);
+        }
+        uint32_t* slot_s = reinterpret_cast<uint32_t*>(lds);             // [2] ticket hand-down
+        float* rec_s = lds + 16;                                         // [16 plans][16 columns][8 rows]: the record's image
+        const int per_it = pk.tiles * H;
+        const uint32_t total = (uint32_t)per_it * (uint32_t)iters;
+        uint32_t pending = 0;
+        if (t == 0) pending = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int n = 0;; ++n) {
+            if (t == 0) slot_s[n & 1] = pending - pk.ticket_base;
+            __syncthreads();
+            const uint32_t job = slot_s[n & 1];
+            if (job >= total) break;
+            if (t == 0) pending = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int it = (int)(job / (uint32_t)per_it), r0 = (int)job - it * per_it, h = r0 / pk.tiles, tile = r0 - h * pk.tiles;
+            const uint32_t seq = pk.seq0 + (uint32_t)it;
+            float* base = scratch + (size_t)tile * gw_tile_floats(H, C);
+            const unsigned long long* pw = reinterpret_cast<const unsigned long long*>(base) + (size_t)h * 192 + lane;      // [3][64] words of step h
+            // wave 1 of the last step's job also takes the terminal state (the words of "step" H: states only)
+            const bool term = wave == 1 && h == H - 1;
+            unsigned long long v0, v1, v2, z0 = 0, z1 = 0;
+            bool got;
+            const unsigned long long t_begin = wall_clock64();
+            for (;;) {
+                v0 = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v1 = __hip_atomic_load(pw + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v2 = __hip_atomic_load(pw + 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                got = (uint32_t)(v0 >> 32) == seq && (uint32_t)(v1 >> 32) == seq && (uint32_t)(v2 >> 32) == seq;
+                if (term) {
+                    z0 = __hip_atomic_load(pw + 192, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    z1 = __hip_atomic_load(pw + 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    got = got && (uint32_t)(z0 >> 32) == seq && (uint32_t)(z1 >> 32) == seq;
+                }
+                if (__all(got) || wall_clock64() - t_begin > GP_POLL_TICKS) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            const bool ok = __all(got);
+            if (!ok && lane == 0) gp_gave_up(pk.err_word, 1, h, tile, (uint32_t)(v0 >> 32), seq, t_begin);
+            const float sv0 = __builtin_bit_cast(float, (uint32_t)v0), sv1 = __builtin_bit_cast(float, (uint32_t)v1), ug = __builtin_bit_cast(float, (uint32_t)v2);
+            float u[C];
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) u[cc] = __shfl(ug, c + 16 * cc, 64);
+            float x0, x1, x2;
+            split_operands<S, C>(sv0, sv1, u, g, x0, x1, x2);
+            // the step's activations, both row tiles on this one wave, as the pair of SplitMlp::Fwd::step forms them
+            f32x4 h1[2], h2[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                f32x4 b = w.b1[m];
+                if constexpr (FOLD) {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) b += w1u[m][f] * u[CC0 + f];
+                }
+                f32x4 acc = CTK_MFMA(w.w1[m][0], x0, b);
+                if constexpr (!(FOLD && !K3)) acc = CTK_MFMA(w.w1[m][1], x1, acc);
+                if constexpr (K3 && !FOLD) acc = CTK_MFMA(w.w1[m][2], x2, acc);
+                h1[m] = ctk_tanhf4(acc);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                f32x4 cc2 = w.b2[m];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cc2 = CTK_MFMA(w.w2[m][m ? 4 + j : j], h1[m][j], cc2);              // own half first ...
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cc2 = CTK_MFMA(w.w2[m][m ? j : 4 + j], h1[m ^ 1][j], cc2);          // ... then the other wave's
+                h2[m] = ctk_tanhf4(cc2);
+            }
+            f32x4 d1[2], d2[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) { d1[m] = 1.0f - h1[m] * h1[m]; d2[m] = 1.0f - h2[m] * h2[m]; }
+            if (!ok) {
+                const float nan = __builtin_nanf("");
+#pragma unroll
+                for (int m = 0; m < 2; ++m) { d1[m] = f32x4{nan, nan, nan, nan}; d2[m] = d1[m]; }
+            }
+            jac_tangents<IO>(w, d1, d2, rec_s + c * 128, g, wave, 4);
+            // the cost's state gradient of this step (wave 0) and, with the last step, of the terminal state (wave 1): plan c = lanes g == 0
+            if (wave == 0 || term) {
+                const float a0 = term ? __builtin_bit_cast(float, (uint32_t)z0) : sv0, a1 = term ? __builtin_bit_cast(float, (uint32_t)z1) : sv1;
+                float sx[S], gs[S];
+#pragma unroll
+                for (int j = 0; j < S; ++j) sx[j] = __shfl(j < 4 ? a0 : a1, c + 16 * (j & 3), 64);
+                const int hh = term ? H : h;
+                if (g == 0) {
+                    if (hh < H) E::stage_grad_state(k, sx, gs); else E::terminal_grad(k, sx, gs);
+                    uint32_t* gs_g = reinterpret_cast<uint32_t*>(base + gw_gs_off(H));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float val = !ok ? __builtin_nanf("") : j < S ? gs[j < S ? j : 0] * a.inv_Hp1 : 0.0f;
+                        __hip_atomic_store(gs_g + (hh * 64 + (j & 3) * 16 + c) * 2 + (j >> 2), __builtin_bit_cast(uint32_t, val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            __syncthreads();                                             // the record's image is complete
+            {
+                const float4* src = reinterpret_cast<const float4*>(rec_s);
+                float4* dst = reinterpret_cast<float4*>(base + gw_rec_off(H) + (size_t)h * GW_REC);
+                st4_through(dst + t, src[t]);
+                st4_through(dst + 256 + t, src[256 + t]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's stores have reached memory
+            __syncthreads();                                             // ... and the other waves' (and the image may be rewritten)
+            if (t == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(base + gw_flag_off(H, C)) + h, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------------------------------- a producer (one tile, two waves)
+    if (wave >= 2) return;                                               // (a finished wave no longer counts at the workgroup's barriers)
+    float* ex = lds;
+    float* red_s = ex + SP::EX_FWD;
+    float* xs_s = red_s + G4_RED;
+    float* gs_s = xs_s + (H + 1) * 128;
+    float* g_s = gs_s + (H + 1) * 128;                                  // (16-byte aligned like gs: LDS-DMA destinations)
+    float* q_s = g_s + gw_gd_floats(H, C);
+    float* m_s = q_s + HC * G4_LD;                                      // Adam moments, resident for the step
+    float* v_s = m_s + HC * G4_LD;
+    const int row0 = blockIdx.x * G4_TRAJ;
+    const int rows = min(G4_TRAJ, a.N - row0);
+    const int total = rows * HC;
+    const size_t gbase = (size_t)row0 * HC;
+    float* tbase = scratch + (size_t)blockIdx.x * gw_tile_floats(H, C);
+    unsigned long long* pub = reinterpret_cast<unsigned long long*>(tbase);                          // [H + 1][3][64] words
+    const float* rec_g = tbase + gw_rec_off(H);
+    const uint32_t* flags = reinterpret_cast<const uint32_t*>(tbase + gw_flag_off(H, C));
+    constexpr int RW = S > 4 ? 2 : 1, W4 = RW * (IO > 8 ? 2 : 1), RING = W4 == 1 ? 25 : W4 == 2 ? 17 : 10;
+    const int cp = t >> 3, ci = t & 7;
+    auto rec_fetch = [&](int h, float4 (&dst)[W4]) {
+        const float4* r4 = reinterpret_cast<const float4*>(rec_g + (size_t)h * GW_REC + cp * 128);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            dst[r] = r4[ci * 2 + r];
+            if constexpr (IO > 8) dst[RW + r] = r4[(8 + ci) * 2 + r];
+        }
+    };
+    auto rec_dot = [&](const float4 (&v)[W4], int o, const float (&l)[8]) {
+        float d = (v[o].x * l[0] + v[o].y * l[1]) + (v[o].z * l[2] + v[o].w * l[3]);
+        if constexpr (RW == 2) d += (v[o + 1].x * l[4] + v[o + 1].y * l[5]) + (v[o + 1].z * l[6] + v[o + 1].w * l[7]);
+        return d;
+    };
+    for (int i = t; i < G4_TRAJ * HC; i += BLOCK) {
+        const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, hc = i - r * HC;
+        const bool in = i < total;
+        q_s[hc * G4_LD + r] = in ? Q[gbase + i] : 0.0f;
+        m_s[hc * G4_LD + r] = in && ad.rule != 2 ? mom[gbase + i] : 0.0f;
+        v_s[hc * G4_LD + r] = in && ad.rule != 2 ? var[gbase + i] : 0.0f;
+    }
+    typename SP::Fwd nf;
+    nf.load(wperm, wave, lane);
+    nf.template fold_load<S, C>(lane);
+    float up0[C];
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) up0[cc] = a.u_prev_dev ? a.u_prev_dev[cc] : a.u_prev[cc];
+    const float inv = a.inv_Hp1;
+    const float s00 = g < S ? lane_state4(a, g) : 0.0f, s01 = 4 + g < S ? lane_state4(a, g, 4) : 0.0f;
+    const int pc = t & 15, part = t >> 4;
+    __syncthreads();
+    auto state_of = [&](int h, int p, float (&s)[S]) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) s[j] = xs_s[(h * 64 + (j & 3) * 16 + p) * 2 + (j >> 2)];
+    };
+    auto sum_parts = [&](float v) {
+        v = sum_over_groups(v);
+        if (g == 0) red_s[wave * 16 + c] = v;
+        __syncthreads();
+        const float r = red_s[c] + red_s[16 + c];
+        __syncthreads();
+        return r;
+    };
+    // the forward pass; PUBLISH: the step's network inputs leave as {value, seq} words (pass `it`); otherwise the states stay in LDS for the cost pass
+    auto forward = [&](bool publish, uint32_t seq, int withhold) {
+        const unsigned long long hi = (unsigned long long)seq << 32;
+        uint32_t word = (uint32_t)lane;
+        asm volatile("" : "+v"(word));                                   // (pinned: ctk_rpgd.hip, rpgd_forward_mlp_publish_pair)
+        nf.begin(nullptr, g);
+        float sv0 = s00, sv1 = s01;
+        for (int h = 0; h < H; ++h) {
+            float u[C];
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) u[cc] = q_s[(h * C + cc) * G4_LD + c];
+            if (publish) {
+                if (h != withhold) {
+                    unsigned long long* p = pub + (uint32_t)(h * 192) + word;
+                    if (wave == 0) {
+                        float ug = 0.0f;
+#pragma unroll
+                        for (int cc = 0; cc < C; ++cc) ug = g == cc ? u[cc] : ug;
+                        __hip_atomic_store(p, hi | (unsigned long long)__builtin_bit_cast(uint32_t, sv0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(p + 128, hi | (unsigned long long)__builtin_bit_cast(uint32_t, ug), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        __hip_atomic_store(p + 64, hi | (unsigned long long)__builtin_bit_cast(uint32_t, sv1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            } else if (wave == (h & 1)) {
+                reinterpret_cast<float2*>(xs_s)[h * 64 + lane] = make_float2(sv0, sv1);
+            }
+            float x0, x1, x2;
+            split_operands<S, C>(sv0, sv1, u, g, x0, x1, x2);
+            nf.template fold_inputs<S, C>(u);
+            const MlpPair o = nf.template step<0, S, C>(x0, x1, x2, ex, wave, lane, nullptr);
+            sv0 = o.lo; sv1 = o.hi;
+        }
+        if (publish) {                                                   // the terminal state: words of "step" H
+            unsigned long long* p = pub + (uint32_t)(H * 192) + word;
+            if (wave == 0) __hip_atomic_store(p, hi | (unsigned long long)__builtin_bit_cast(uint32_t, sv0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_store(p + 64, hi | (unsigned long long)__builtin_bit_cast(uint32_t, sv1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (wave == 0) {
+            reinterpret_cast<float2*>(xs_s)[H * 64 + lane] = make_float2(sv0, sv1);
+        }
+        __syncthreads();
+    };
+    for (int it = 0; it < iters; ++it) {
+        const uint32_t seq = pk.seq0 + (uint32_t)it;
+        const int ti = t0 + it + 1;
+        float bc1 = 1.0f, bc2 = 1.0f;
+        if (ti <= bc_len) { bc1 = bc_table[2 * (ti - 1)]; bc2 = bc_table[2 * (ti - 1) + 1]; }
+        forward(true, seq, it == 0 ? pk.withhold : -1);
+        // the input-only gradient terms of these plans, straight into the chain's LDS words (the phase launches pass them through memory)
+        for (int idx = t; idx < H * G4_TRAJ; idx += BLOCK) {
+            const int h = idx >> 4, p = idx & 15;
+            float u[C], upv[C], un[C], gu[C], gp[C], gu2[C], gpn[C];
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) {
+                u[cc] = q_s[(h * C + cc) * G4_LD + p];
+                upv[cc] = h > 0 ? q_s[((h - 1) * C + cc) * G4_LD + p] : up0[cc];
+                un[cc] = h + 1 < H ? q_s[((h + 1) * C + cc) * G4_LD + p] : 0.0f;
+                gpn[cc] = 0.0f;
+            }
+            E::input_grad(k, u, upv, gu, gp);
+            if (h + 1 < H) E::input_grad(k, un, u, gu2, gpn);
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) g_s[(h * C + cc) * G4_LD + p] = (gu[cc] + gpn[cc]) * inv;
+        }
+        // ---- the tile's H records: both waves poll the flags (lane h <- flag h) and acquire — each then reads with plain loads of its own
+        {
+            uint32_t f = lane < H ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seq;
+            if (!__all(f == seq)) {
+                const unsigned long long t_begin = wall_clock64();
+                while (!__all(f == seq)) {
+                    if (wall_clock64() - t_begin > 2 * GP_POLL_TICKS) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    f = lane < H ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seq;
+                }
+                if (!__all(f == seq) && wave == 0) {
+                    const unsigned long long missing = __builtin_amdgcn_ballot_w64(f != seq);
+                    if (lane == (int)__builtin_ctzll(missing)) gp_gave_up(pk.err_word, 2, lane, (int)blockIdx.x, f, seq, t_begin);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        float4 ring[RING][W4];
+#pragma unroll
+        for (int d = 0; d < RING; ++d) rec_fetch(max(H - 1 - d, 0), ring[d]);
+        {   // the cost-gradient terms the workers left: LDS-DMA, 1 KiB per wave-instruction; the barrier below waits for it
+            const int n4 = (H + 1) * 32;
+            const float4* src = reinterpret_cast<const float4*>(tbase + gw_gs_off(H));
+            float4* dst = reinterpret_cast<float4*>(gs_s);
+            for (int b = wave * 64; b < n4; b += BLOCK)
+                if (b + lane < n4)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + b + lane),
+                                                     (__attribute__((address_space(3))) void*)(dst + b), 16, 0, 0);
+        }
+        __syncthreads();
+        // ---- the adjoint chain (ctk_g_rpgd_wide_split: plan p = t / 8, lane i owns column i and, beyond 8 inputs, column 8 + i)
+        {
+            const int p = cp, i = ci;
+            const bool is_state = i < S, is_input = i >= S && i < IO;
+            const int w0 = is_state ? (int)(gs_s - lds) + ((i & 3) * 16 + p) * 2 + (i >> 2) : is_input ? (int)(g_s - lds) + (i - S) * G4_LD + p : (int)(gs_s - lds);
+            const int wstep = is_state ? 128 : is_input ? C * G4_LD : 0;
+            float lam = is_state ? lds[w0 + H * 128] : 0.0f;
+            const int nblk = (H + RING - 1) / RING;
+            float o0 = lds[w0 + (H - 1) * wstep], o1 = lds[w0 + max(H - 2, 0) * wstep];
+            for (int blk = 0, htop = H - 1; blk < nblk; ++blk, htop -= RING) {
+#pragma unroll
+                for (int d = 0; d < RING; ++d) {
+                    const int hr = htop - d, h = max(hr, 0);
+                    const int wd = w0 + h * wstep;
+                    const float own = o0;
+                    o0 = o1;
+                    o1 = lds[w0 + max(hr - 2, 0) * wstep];
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int lami = __builtin_bit_cast(int, lam);
+                    const float lamA = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(lami, lami, 0x114, 0xF, 0xA, false));
+                    float lamB = 0.0f;
+                    if constexpr (S > 4) lamB = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(lami, lami, 0x104, 0xF, 0x5, false));
+                    float l[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) l[r] = 0.0f;
+                    l[0] = dpp_mov<0x00>(lamA);
+                    if constexpr (S > 1) l[1] = dpp_mov<0x55>(lamA);
+                    if constexpr (S > 2) l[2] = dpp_mov<0xAA>(lamA);
+                    if constexpr (S > 3) l[3] = dpp_mov<0xFF>(lamA);
+                    if constexpr (S > 4) l[4] = dpp_mov<0x00>(lamB);
+                    if constexpr (S > 5) l[5] = dpp_mov<0x55>(lamB);
+                    if constexpr (S > 6) l[6] = dpp_mov<0xAA>(lamB);
+                    if constexpr (S > 7) l[7] = dpp_mov<0xFF>(lamB);
+                    const float dA = rec_dot(ring[d], 0, l);
+                    float dB = 0.0f;
+                    if constexpr (IO > 8) dB = rec_dot(ring[d], RW, l);
+                    rec_fetch(max(hr - RING, 0), ring[d]);
+                    const float v = own + dA;
+                    if (is_input && hr >= 0) lds[wd] = v;
+                    lam = is_state ? v : 0.0f;
+                    if constexpr (IO > 8) {
+                        if (8 + i < IO && hr >= 0) g_s[(h * C + (8 + i - S)) * G4_LD + p] += dB;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- per-plan clip_by_norm, Adam, clip
+        float n2 = 0.0f;
+        for (int hc = part; hc < HC; hc += NPARTS) { const float x = g_s[hc * G4_LD + pc]; n2 += x * x; }
+        n2 = sum_parts(n2);
+        const int tile_bad = __syncthreads_or(!(n2 <= 3.0e38f));
+        if (tile_bad && t == 0 && pk.err_word != nullptr) __hip_atomic_store(pk.err_word + 1, 1u + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const float scl = ad.clip / fmaxf(sqrtf(n2), ad.clip);
+        if (wave == 0 && g == 0) red_s[64 + c] = scl;
+        __syncthreads();
+        for (int i = t; !tile_bad && i < total; i += BLOCK) {
+            const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, hc = i - r * HC, cc = hc % C;
+            const float gg = g_s[hc * G4_LD + r] * red_s[64 + r];
+            float mm = m_s[hc * G4_LD + r], vv = v_s[hc * G4_LD + r];
+            q_s[hc * G4_LD + r] = adam_update(ad, q_s[hc * G4_LD + r], gg, mm, vv, bc1, bc2, a.lo[cc], a.hi[cc]);
+            m_s[hc * G4_LD + r] = mm; v_s[hc * G4_LD + r] = vv;
+        }
+        __syncthreads();
+    }
+    // ---- get_action's cost pass (optimizer_rpgd.py:342), then the plans and moments back to memory
+    forward(false, 0u, -1);
+    {
+        float cs = 0.0f;
+        for (int h = part; h < H; h += NPARTS) {
+            float s[S], u[C], upv[C];
+            state_of(h, pc, s);
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) {
+                u[cc] = q_s[(h * C + cc) * G4_LD + pc];
+                upv[cc] = h > 0 ? q_s[((h - 1) * C + cc) * G4_LD + pc] : up0[cc];
+            }
+            cs += E::stage_cost(k, s, u, upv);
+        }
+        if (part == 0) {
+            float s[S];
+            state_of(H, pc, s);
+            cs += E::terminal_cost(k, s);
+        }
+        cs = sum_parts(cs);
+        if (wave == 0 && g == 0 && row0 + c < a.N) a.J[row0 + c] = cs * inv;
+    }
+    for (int i = t; i < total; i += BLOCK) {
+        const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, hc = i - r * HC;
+        Q[gbase + i] = q_s[hc * G4_LD + r];
+        if (ad.rule != 2) { mom[gbase + i] = m_s[hc * G4_LD + r]; var[gbase + i] = v_s[hc * G4_LD + r]; }
+    }
+}
+
 // floats of one tile's LDS carve in ctk_g_rollout_split (a multiple of 4: the second tile of a workgroup starts 16-byte aligned)
 __host__ __device__ inline size_t split_tile_floats(int ex_fwd, int cols, int H, int C) {
     const size_t n = (size_t)ex_fwd + G4_RED + (size_t)(H + 1) * 128 + (size_t)H * C * G4_LD + (size_t)G4_TRAJ * tile_stride(cols) + G4_TRAJ + 2 * (size_t)H * C + 3 * (size_t)H;
@@ -1367,17 +1776,23 @@ bool ctk_g_rpgd_wide_ok(int env, int net, int N, int H) {
     // ring, the DPP chain and the in-launch Jacobian workgroups: 760 vs 742 us; now 637)
     return !narrow && net == NET_MLP && S + C <= 12 && N <= 4096 && ctk_g_rpgd_split_ok(env, net, N, H);
 }
-size_t ctk_g_rpgd_scratch_floats_wide(int N, int H) { return (size_t)((N + G4_TRAJ - 1) / G4_TRAJ) * gw_tile_floats(H, 4); }   // (C <= 4)
-const char* ctk_g_rpgd_wide_name(int env) {
+size_t ctk_g_rpgd_scratch_floats_wide(int N, int H) { return (size_t)((N + G4_TRAJ - 1) / G4_TRAJ) * gw_tile_floats(H, 4) + 16; }   // (C <= 4; + the one-launch form's ticket counter)
+// up to 32 tiles and H <= 64 the whole descent is ONE launch (ctk_g_rpgd_persist: producers + resident Jacobian workers)
+bool ctk_g_rpgd_persist_ok(int env, int net, int N, int H) {
+    static const bool off = getenv("CTK_RPGD_NO_PERSISTENT") != nullptr;   // diagnostic switch: A/B the two forms (shared with ctk_rpgd.hip)
+    return !off && ctk_g_rpgd_wide_ok(env, net, N, H) && N <= 32 * G4_TRAJ && H <= 64;
+}
+const char* ctk_g_rpgd_wide_name(int env, int N, int H) {
     int S = 0, C = 0;
     env_dims(env, &S, &C);
+    if (H > 0 && ctk_g_rpgd_persist_ok(env, NET_MLP, N, H)) return ctk_kernel_name("ctk_g_rpgd_persist<%d, %4$s>", env, 0, 0, S + C > 8 ? "true" : "false");
     return ctk_kernel_name("ctk_g_rpgd_wide_split<%d, %4$s> + ctk_g_rpgd_jac_split", env, 0, 0, S + C > 8 ? "true" : "false");
 }
 
 template <int EV>
 static void launch_wide_split(hipStream_t st, const RolloutArgs& a_in, const float* params, float dt, int isteps, const AdamK& ad, float* Q, float* m,
                               float* v, const float* bc_table, int bc_len, int t0, int iters, const float* wperm, float* scratch, hipEvent_t e0,
-                              hipEvent_t e1, uint32_t* err_word) {
+                              hipEvent_t e1, uint32_t* err_word, RpgdPersist* pers) {
     using E = Env<EV>;
     constexpr bool K3 = E::S + E::C > 8;
     // diagnostic switch, read once per process (tests/test_gpu_rpgd.py: the time-out path): CTK_DIAG_RPGD_WITHHOLD_FLAG=<step> makes the
@@ -1389,6 +1804,22 @@ static void launch_wide_split(hipStream_t st, const RolloutArgs& a_in, const flo
     const typename E::K k = E::derive(params, dt, isteps);
     const int tiles = (a.N + G4_TRAJ - 1) / G4_TRAJ;
     size_t lds = (size_t)(SplitMlp<K3>::EX_FWD + G4_RED + 2 * (a.H + 1) * 128 + gw_gd_floats(a.H, E::C) + a.H * E::C * G4_LD) * sizeof(float);
+    if (pers != nullptr && iters >= 1 && iters <= 63 && ctk_g_rpgd_persist_ok(EV, NET_MLP, a.N, a.H)) {
+        // ONE launch: producers (a tile each) + Jacobian workers that stay for all iterations; more than half a CU's LDS per workgroup, so
+        // that no worker sits on a producer's SIMDs
+        const int per_it = tiles * a.H, W = std::min(240, per_it);
+        if (pers->seq0 < 64u || pers->seq0 > 0xffffff00u) pers->seq0 = 64u;
+        GPersistK pk{pers->seq0, pers->ticket_base, err_word, tiles, diag_armed.exchange(0) ? diag_step : -1};
+        pers->seq0 += 64u;
+        pers->ticket_base += (uint32_t)per_it * (uint32_t)iters + (uint32_t)W;      // every job + one ticket past the end per worker workgroup
+        const size_t plds = std::max(lds + (size_t)2 * a.H * E::C * G4_LD * sizeof(float), (size_t)84 * 1024);
+        if (e0 || e1)
+            hipExtLaunchKernelGGL((ctk_g_rpgd_persist<EV, K3>), dim3(tiles + W), dim3(256), plds, st, e0, e1, 0, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm,
+                                  scratch, pk);
+        else
+            hipLaunchKernelGGL((ctk_g_rpgd_persist<EV, K3>), dim3(tiles + W), dim3(256), plds, st, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, scratch, pk);
+        return;
+    }
     // the Jacobian work rides inside the phase launch (rpgd_jac_worker); CTK_RPGD_NO_OVERLAP: its own launch after each phase launch
     static const bool no_overlap = getenv("CTK_RPGD_NO_OVERLAP") != nullptr;
     static std::atomic<uint32_t> launch_seq{0};
@@ -1413,8 +1844,8 @@ static void launch_wide_split(hipStream_t st, const RolloutArgs& a_in, const flo
 
 hipError_t ctk_launch_g_rpgd_wide_split(hipStream_t st, int env, const RolloutArgs& a, const float* params, float dt, int isteps, const AdamK& ad,
                                         float* Q, float* m, float* v, const float* bc_table, int bc_len, int t0, int iters, const float* wperm,
-                                        float* scratch, hipEvent_t e0, hipEvent_t e1, uint32_t* err_word) {
-    CTK_FOR_ENV(env, EV, { launch_wide_split<EV>(st, a, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, scratch, e0, e1, err_word); });
+                                        float* scratch, hipEvent_t e0, hipEvent_t e1, uint32_t* err_word, RpgdPersist* pers) {
+    CTK_FOR_ENV(env, EV, { launch_wide_split<EV>(st, a, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, scratch, e0, e1, err_word, pers); });
     return hipGetLastError();
 }
 

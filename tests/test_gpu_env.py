@@ -383,7 +383,7 @@ def test_cartpole_generic_mlp_kernels_match_tuned_mlp_kernels(opt):
         kw.update(outer_its=3, resamp_per=2, opt_keep_k=40, sample_whole_control_space=1)
     w = O.mlp_default_weights(2)
     a, b = CtkEngine(opt, "MLP", **kw), CtkEngine(opt, "MLP", generic_kernels=True, **kw)
-    assert "ctk_g_" in b.dominant_kernel() and ("Mlp" in b.dominant_kernel() or "wide_split" in b.dominant_kernel())   # SplitMlp<.> / the wide RPGD form
+    assert "ctk_g_" in b.dominant_kernel() and ("Mlp" in b.dominant_kernel() or "wide_split" in b.dominant_kernel() or "rpgd_persist" in b.dominant_kernel())   # SplitMlp<.> / the wide RPGD forms
     a.set_predictor_weights(w); b.set_predictor_weights(w)
     if opt == "rpgd":
         a.reset(); b.reset()
@@ -526,7 +526,8 @@ def test_quad2d_mlp_gradient_and_rpgd_match_oracle():
 def test_quad2d_mlp_wide_rpgd_edge_shapes_match_oracle(N, H):
     """The wide RPGD descent of the template (Jacobian workgroups inside the phase launch: flags lag the forward pass by four steps; the
     adjoint chain walks whole blocks of its ring depth) at horizons shorter than the lag and the ring, ragged populations, and more tiles
-    (N = 1100: 69) than the in-launch form takes (64: there the Jacobians keep their own launch)."""
+    (N = 1100: 69) than the in-launch form takes (64: there the Jacobians keep their own launch).  Up to 32 tiles these shapes now run the
+    one-launch form (ctk_g_rpgd_persist); test_template_rpgd_phase_launches_keep_their_edge_shapes runs them on the phase launches."""
     env, w, pred = quad_mlp()
     cost = O.Cost(env)
     p = 1 if H < 4 else 3
@@ -534,7 +535,9 @@ def test_quad2d_mlp_wide_rpgd_edge_shapes_match_oracle(N, H):
                SAMPLING_DISTRIBUTION="uniform", opt_keep_k_ratio=0.25)
     e = CtkEngine("rpgd", "MLP", environment="Quad2D", num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p,
                   outer_its=3, resamp_per=2, opt_keep_k=o.k, sampling_distribution=0, sample_whole_control_space=1, action_low=QLO, action_high=QHI)
-    assert "wide_split" in e.dominant_kernel(), e.dominant_kernel()
+    import os
+    want = "wide_split" if (N > 512 or os.environ.get("CTK_RPGD_NO_PERSISTENT")) else "rpgd_persist"      # up to 32 tiles: the one-launch form (round 4)
+    assert want in e.dominant_kernel(), e.dominant_kernel()
     apply_params(e, env); e.set_predictor_weights(w)
     rng = np.random.default_rng(N + H)
     d0 = rng.random((N, o.P, 2), dtype=np.float32)
@@ -631,3 +634,15 @@ def two_shards_equal_one_handle(opt, envname, env, lo, hi, s0, kind="ODE", weigh
         s = pred.step(s.reshape(1, S), u_full.reshape(1, C))[0]
     for e in sh + [full]:
         e.close()
+
+
+def test_template_rpgd_phase_launches_keep_their_edge_shapes():
+    """the phase-launch form of the template's wide RPGD descent (what populations beyond 32 tiles and horizons beyond 64 run) on the edge shapes
+    above, in a child process: CTK_RPGD_NO_PERSISTENT is read once per process"""
+    import os, subprocess, sys
+    env = dict(os.environ, CTK_RPGD_NO_PERSISTENT="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(here, "test_gpu_env.py"),
+                        "-k", "edge_shapes and not phase_launches"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

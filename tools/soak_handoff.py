@@ -29,8 +29,8 @@ ERRORS = []
 def run(steps):
     from control_toolkit_amd import CtkEngine
     out = {}
-    for name, env, kw, kernel in (("CartPole", "CartPole", dict(generic_kernels=True), "wide_split"), ("Quad2D", "Quad2D", {}, "wide_split"),
-                                  ("Hover", "Hover", {}, "wide_split"),
+    for name, env, kw, kernel in (("CartPole", "CartPole", dict(generic_kernels=True), "rpgd_"), ("Quad2D", "Quad2D", {}, "rpgd_"),
+                                  ("Hover", "Hover", {}, "rpgd_"),       # (the template's one-launch form; CTK_RPGD_NO_PERSISTENT=1: its phase launches)
                                   # CartPole's own kernels: the whole descent in one launch, resident workers, words / records / flags both ways
                                   ("CartPole-1L", "CartPole", {}, "ctk_rpgd_mlp_persistent")):
         e = CtkEngine("rpgd", "MLP", environment=env, num_rollouts=256, mpc_horizon=50, dt=0.02, period_interpolation_inducing_points=10,
