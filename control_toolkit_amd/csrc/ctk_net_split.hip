@@ -1311,6 +1311,7 @@ __global__ __launch_bounds__(256) void ctk_g_rpgd_persist(RolloutArgs a, typenam
         const unsigned long long hi = (unsigned long long)seq << 32;
         uint32_t word = (uint32_t)lane;
         asm volatile("" : "+v"(word));                                   // (pinned: ctk_rpgd.hip, rpgd_forward_mlp_publish_pair)
+        const int wv = __builtin_amdgcn_readfirstlane(wave);             // (a scalar: the per-step choice below is a branch, not an exec mask)
         nf.begin(nullptr, g);
         float sv0 = s00, sv1 = s01;
         for (int h = 0; h < H; ++h) {
@@ -1320,7 +1321,7 @@ __global__ __launch_bounds__(256) void ctk_g_rpgd_persist(RolloutArgs a, typenam
             if (publish) {
                 if (h != withhold) {
                     unsigned long long* p = pub + (uint32_t)(h * 192) + word;
-                    if (wave == 0) {
+                    if (wv == 0) {
                         float ug = 0.0f;
 #pragma unroll
                         for (int cc = 0; cc < C; ++cc) ug = g == cc ? u[cc] : ug;
@@ -1341,7 +1342,7 @@ __global__ __launch_bounds__(256) void ctk_g_rpgd_persist(RolloutArgs a, typenam
         }
         if (publish) {                                                   // the terminal state: words of "step" H
             unsigned long long* p = pub + (uint32_t)(H * 192) + word;
-            if (wave == 0) __hip_atomic_store(p, hi | (unsigned long long)__builtin_bit_cast(uint32_t, sv0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wv == 0) __hip_atomic_store(p, hi | (unsigned long long)__builtin_bit_cast(uint32_t, sv0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else __hip_atomic_store(p + 64, hi | (unsigned long long)__builtin_bit_cast(uint32_t, sv1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (wave == 0) {
             reinterpret_cast<float2*>(xs_s)[H * 64 + lane] = make_float2(sv0, sv1);
