@@ -113,7 +113,7 @@ def main():
     copy_text("rpgd_forms.txt", f"{tag}_rpgd_forms.txt", "# tools/rpgd_forms.py: RPGD + MLP on CartPole's own kernels per MPC step (host clock, 60 steps) — the one-launch form against the phase launches it replaces\n")
     copy_text("rpgd_pers_stamps.txt", f"{tag}_rpgd_pers_stamps.txt", "# tools/rpgd_stamps.sh: wall-clock stamps inside ctk_rpgd_mlp_persistent (variant build; the printf calls perturb what they time: read the lines that agree)\n")
     copy_text("soak_handoff.txt", f"{tag}_soak_handoff.txt", "# tools/soak_handoff.py: the in-launch hand-offs (template wide RPGD descent, the one-launch descent of CartPole's own kernels, block records of MPPI / CEM, the resident kernel) while a second process keeps the GPU busy (3000 steps per environment)\n")
-    copy_text("soak.txt", f"{tag}_soak.txt", "# tools/soak.py: closed-loop soak of 26 engines (every optimizer, predictor, environment, the one-launch CEM, the split network kernels, the narrow-record merge, 64-unit and embedded networks, a user environment)\n")
+    copy_text("soak.txt", f"{tag}_soak.txt", "# tools/soak.py: closed-loop soak of 29 engines (every optimizer, predictor, environment, the one-launch CEM, the split network kernels, the narrow-record merge, 64-unit and embedded networks, a user environment, the one-launch RPGD forms, the ten-input GRU)\n")
     p = pmc("pmc_largen")
     if fresh(p):
         import collections

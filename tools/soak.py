@@ -44,6 +44,13 @@ engs.update({
 assert engs["mppi_cfg5_shard"].dominant_kernel().startswith("ctk_mppi_rollout<0, 3")
 from control_toolkit_amd.build_env import register_environment
 register_environment(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "envs", "pendulum_env.h"))
+# round 4, later: the template's one-launch RPGD descent (Quad2D, Hover: resident Jacobian workers), the ten-input GRU (Hover)
+others.update({
+ "quad_rpgd_mlp": CtkEngine("rpgd", "MLP", environment="Quad2D", num_rollouts=64, mpc_horizon=20, dt=0.02, seed=31, outer_its=3, resamp_per=4, opt_keep_k=16, sampling_distribution=0, period_interpolation_inducing_points=5),
+ "hover_rpgd_mlp": CtkEngine("rpgd", "MLP", environment="Hover", num_rollouts=48, mpc_horizon=16, dt=0.02, seed=32, outer_its=2, resamp_per=4, opt_keep_k=12, sampling_distribution=0, period_interpolation_inducing_points=4),
+ "hover_mppi_gru": CtkEngine("mppi", "GRU", environment="Hover", num_rollouts=128, mpc_horizon=15, dt=0.02, seed=33, period_interpolation_inducing_points=5),
+})
+assert "rpgd_persist" in others["quad_rpgd_mlp"].dominant_kernel() and "NetGruT<true>" in others["hover_mppi_gru"].dominant_kernel()
 others_user = {
  "pend_mppi": CtkEngine("mppi", "ODE", environment="Pendulum", num_rollouts=1024, mpc_horizon=40, dt=0.02, seed=28),
  "pend_cem": CtkEngine("cem", "ODE", environment="Pendulum", num_rollouts=512, mpc_horizon=25, dt=0.02, seed=29, cem_outer_it=3, cem_best_k=50),
@@ -60,7 +67,7 @@ engs["mppi_res_short"].resident_enable(True, 50.0)
 engs["mppi_res_long"].resident_enable(True, 50000.0)
 for k in ("rpgd_gru_t", "rpgd_mlp_t", "rpgd_mlp_h64", "rpgd_log"):
     engs[k].reset()
-others["hover_rpgd"].reset()
+others["hover_rpgd"].reset(); others["quad_rpgd_mlp"].reset(); others["hover_rpgd_mlp"].reset()
 others_user["pend_rpgd"].reset()
 others.update(others_user)
 ostate = {k: np.zeros(e.S, np.float32) for k, e in others.items()}
