@@ -498,9 +498,7 @@ hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const
 hipError_t ctk_launch_g_gru_advance(hipStream_t st, int env, const RolloutArgs& a, const float* u_dev, float* wperm) {
     float* hidden = wperm + ctk_g_net_table_floats(NET_GRU);
     static const bool one_wave = getenv("CTK_NET_ONE_WAVE") != nullptr;
-    int io = 0;
-    CTK_FOR_ENV(env, EV, { io = Env<EV>::S + Env<EV>::C; });
-    if (!one_wave && io <= 8) return ctk_launch_g_gru_advance4(st, env, a, u_dev, wperm, hidden);      // ctk_net_split.hip: the four-wave step (S + C <= 8)
+    if (!one_wave) return ctk_launch_g_gru_advance4(st, env, a, u_dev, wperm, hidden);      // ctk_net_split.hip: the four-wave step
     CTK_FOR_ENV(env, EV, {
         hipLaunchKernelGGL((ctk_g_gru_advance<EV>), dim3(1), dim3(64), NetGruT<true>::LDS_FWD * sizeof(float), st, a, u_dev, wperm, hidden);
     });

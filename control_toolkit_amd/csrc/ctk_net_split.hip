@@ -2,7 +2,7 @@
 // of a workgroup, forward AND reverse, for small populations: the chip has 1 024 SIMDs, an MPC population of 1 024 rollouts is 64
 // tiles, and on gfx950 a wave's fp32 MFMA and VALU time add up — so the step's matrix AND vector work is divided.
 //
-//   SplitGru   2 x 32 GRU + dense over FOUR waves (S + C <= 8).  One wave per tile (ctk_net.h: NetGru) is 164 dependent-ish MFMAs + 48
+//   SplitGru   2 x 32 GRU + dense over FOUR waves (network inputs beyond 8 — control inputs — folded into the layer-1 biases).  One wave per tile (ctk_net.h: NetGru) is 164 dependent-ish MFMAs + 48
 //              gate nonlinearities per lane forward, 172 MFMAs + the gate adjoints reverse, every A operand re-read from LDS: 6.3 ms for
 //              RPGD at N 256 / H 50 x 10 Adam iterations (optimizer_rpgd.py:306-338 differentiates through whatever predictor it gets).
 //     forward  ctk_gru.h: gru_layer.  Wave (m, q) owns hidden tile m; q = 0: r rows + the input half of the n rows, q = 1: z rows + the
@@ -204,16 +204,17 @@ CTK_DEV MlpPair gru4_vjp(const Gru4BwdW& w, Gru4Adj& ad, const float4 (&tp)[G4_T
     float4* B4 = reinterpret_cast<float4*>(exB);
     B4[(wave * 3 + 0) * 64 + lane] = st4(din); B4[(wave * 3 + 1) * 64 + lane] = st4(dh[0]); B4[(wave * 3 + 2) * 64 + lane] = st4(dh[1]);
     __syncthreads();
-    float lo = 0.0f, hi = 0.0f;
+    float lo = 0.0f, hi = 0.0f, exi = 0.0f;
     float c1[2] = {direct[0], direct[1]};
     const float2* B2 = reinterpret_cast<const float2*>(exB);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const float2 x = B2[((s * 3 + 0) * 64 + lane) * 2], y = B2[((s * 3 + 1 + m) * 64 + lane) * 2 + q];
         lo += x.x; hi += x.y; c1[0] += y.x; c1[1] += y.y;
+        exi += B2[((s * 3 + 0) * 64 + lane) * 2 + 1].x;                // row 4g + 2 of the input tile: network input 8 + g (zero rows where S + C <= 8)
     }
     ad.dh1[0] = c1[0]; ad.dh1[1] = c1[1];
-    return MlpPair{lo, hi};
+    return MlpPair{lo, hi, exi};
 }
 
 // network operands of a step (inputs g, 4+g, 8+g) from the (component g, component 4+g) state layout and the step's inputs
@@ -236,11 +237,45 @@ struct SplitGru {
     struct Fwd {
         GruW w;
         GruState st;
-        CTK_DEV void load(const float* __restrict__ tab, int wave, int lane) { w = gru4_load_fwd(tab, wave >> 1, wave & 1, lane); }
+        const float* tab3;                  // layer 1's third k-step, Wi3[gate][tile] (ctk_net.h: behind the reverse table)
+        int wv;
+        // More than 8 network inputs (round 4): inputs 8 + f are control inputs (S <= 8), known before the step — their columns enter
+        // layer 1 as a rank-NF update of the accumulators' initial values (this wave's r or z rows; the n rows' input half on q = 0), on
+        // the VALU, like SplitMlp's folded columns: no third k-step on the recurrence.
+        f32x4 xA[4], xB[4], bA0, bB0;
+        CTK_DEV void load(const float* __restrict__ tab, int wave, int lane) {
+            w = gru4_load_fwd(tab, wave >> 1, wave & 1, lane);
+            tab3 = tab + (size_t)(GRUG_FWD + GRUG_BWD) * 64; wv = wave;
+        }
         CTK_DEV void begin(const float* __restrict__ hidden, int g) { st = gru_load_state(hidden, g); }
+        template <int S, int C> static constexpr int fold_n() { return S + C > 8 ? S + C - 8 : 0; }
+        template <int S, int C>
+        CTK_DEV void fold_load(int lane) {
+            constexpr int NF = fold_n<S, C>();
+            if constexpr (NF > 0) {
+                const int m = wv >> 1, q = wv & 1, g = lane >> 4;
+                const float a3 = tab3[(q * 2 + m) * 64 + lane], b3 = tab3[(2 * 2 + m) * 64 + lane];      // A operands: lane (i, k) holds W_i[row i][8 + k]
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        xA[f][r] = __shfl(a3, 4 * g + r + 16 * f, 64);
+                        xB[f][r] = q == 0 ? __shfl(b3, 4 * g + r + 16 * f, 64) : 0.0f;
+                    }
+                bA0 = w.bA1; bB0 = w.bB1;
+            }
+        }
+        template <int S, int C>
+        CTK_DEV void fold_inputs(const float (&u)[C]) {
+            constexpr int NF = fold_n<S, C>();
+            if constexpr (NF > 0) {
+                f32x4 a = bA0, b = bB0;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) { a += xA[f] * u[8 - S + f]; b += xB[f] * u[8 - S + f]; }
+                w.bA1 = a; w.bB1 = b;
+            }
+        }
         // tq: this wave's tape of the step (+ i * 64 per float4), used when TAPE
-        template <int S, int C> CTK_DEV void fold_load(int) {}                       // (SplitMlp: layer-1 input columns as a bias update)
-        template <int S, int C> CTK_DEV void fold_inputs(const float (&)[C]) {}
         template <bool TAPE, int = 0, int = 0>
         CTK_DEV MlpPair step(float x0, float x1, float, float* ex, int wave, int lane, float4* tq) {
             GruPairTape t1, t2;
@@ -1610,6 +1645,7 @@ __global__ __launch_bounds__(64 * SP::WAVES * TILES) void ctk_g_rollout_split(Ro
             if (wave == (h & (WAVES - 1))) reinterpret_cast<float2*>(xs_s)[h * 64 + lane] = make_float2(sv0, sv1);
             float x0, x1, x2;
             split_operands<S, C>(sv0, sv1, u, g, x0, x1, x2);
+            if constexpr (SP::NET == NET_GRU) nf.template fold_inputs<S, C>(u);     // (the GRU's inputs beyond 8: it has no third k-step to take them)
             const MlpPair o = nf.template step<false>(x0, x1, x2, ex, wave, lane, nullptr);
             sv0 = o.lo; sv1 = o.hi;
         }
@@ -1685,23 +1721,25 @@ __global__ __launch_bounds__(256) void ctk_g_gru_advance4(RolloutArgs a, const f
                                                               float* __restrict__ hidden) {
     using E = Env<ENV>;
     constexpr int S = E::S, C = E::C;
-    static_assert(S + C <= 8, "the GRU's input tile holds 8 columns");
     __shared__ float ex[G4_EX_FWD];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 15, g = lane >> 4;
-    const GruW wf = gru4_load_fwd(wperm, wave >> 1, wave & 1, lane);
-    GruState st = gru_load_state(hidden, g);
+    SplitGru::Fwd nf;
+    nf.load(wperm, wave, lane);
+    nf.template fold_load<S, C>(lane);
+    nf.begin(hidden, g);
     float u[C];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) u[cc] = u_dev ? u_dev[cc] : a.u_prev[cc];
     const float sv0 = g < S ? lane_state4(a, g) : 0.0f, sv1 = 4 + g < S ? lane_state4(a, g, 4) : 0.0f;
     float x0, x1, x2;
     split_operands<S, C>(sv0, sv1, u, g, x0, x1, x2);
-    (void)gru4_step(wf, st, x0, x1, ex, wave, lane, nullptr, nullptr);      // its barriers order every lane's read of `hidden` before the write below
+    nf.template fold_inputs<S, C>(u);
+    (void)nf.template step<false>(x0, x1, x2, ex, wave, lane, nullptr);     // its barriers order every lane's read of `hidden` before the write below
     if (wave == 0 && c == 0) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { hidden[16 * m + 4 * g + r] = st.h1[m][r]; hidden[32 + 16 * m + 4 * g + r] = st.h2[m][r]; }
+            for (int r = 0; r < 4; ++r) { hidden[16 * m + 4 * g + r] = nf.st.h1[m][r]; hidden[32 + 16 * m + 4 * g + r] = nf.st.h2[m][r]; }
     }
 }
 
@@ -1722,7 +1760,7 @@ static const char* split_policy_name(int env, int net) {
 static bool split_env_ok(int env, int net) {
     int S = 0, C = 0;
     env_dims(env, &S, &C);
-    return net == NET_MLP || (net == NET_GRU && S + C <= 8);
+    return net == NET_MLP || (net == NET_GRU && S + C <= 12);      // (beyond 8 inputs the GRU's extra ones are folded into its layer-1 biases: SplitGru::Fwd)
 }
 
 size_t ctk_g_rpgd_descent_split_lds(int net, int H, int C) {
@@ -1759,8 +1797,7 @@ hipError_t ctk_launch_g_rpgd_descent_split(hipStream_t st, int env, int net, con
     CTK_FOR_ENV(env, EV, {
         using E = Env<EV>;
         if (net == NET_GRU) {
-            if constexpr (E::S + E::C <= 8) launch_descent_split<EV, SplitGru>(st, a, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wperm_bwd, hidden, scratch, e0, e1);
-            else return hipErrorInvalidValue;
+            launch_descent_split<EV, SplitGru>(st, a, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wperm_bwd, hidden, scratch, e0, e1);
         } else {
             launch_descent_split<EV, SplitMlp<(E::S + E::C > 8)>>(st, a, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, wperm_bwd, hidden, scratch, e0, e1);
         }
@@ -1908,8 +1945,7 @@ hipError_t ctk_launch_g_rollout_split(hipStream_t st, int env, int net, int mode
     CTK_FOR_ENV(env, EV, {
         using E = Env<EV>;
         if (net == NET_GRU) {
-            if constexpr (E::S + E::C <= 8) launch_rollout_split<EV, SplitGru>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
-            else return hipErrorInvalidValue;
+            launch_rollout_split<EV, SplitGru>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
         } else {
             launch_rollout_split<EV, SplitMlp<(E::S + E::C > 8)>>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
         }
@@ -1919,8 +1955,7 @@ hipError_t ctk_launch_g_rollout_split(hipStream_t st, int env, int net, int mode
 
 hipError_t ctk_launch_g_gru_advance4(hipStream_t st, int env, const RolloutArgs& a, const float* u_dev, const float* wperm, float* hidden) {
     CTK_FOR_ENV(env, EV, {
-        if constexpr (Env<EV>::S + Env<EV>::C <= 8) hipLaunchKernelGGL((ctk_g_gru_advance4<EV>), dim3(1), dim3(256), 0, st, a, u_dev, wperm, hidden);
-        else return hipErrorInvalidValue;
+        hipLaunchKernelGGL((ctk_g_gru_advance4<EV>), dim3(1), dim3(256), 0, st, a, u_dev, wperm, hidden);
     });
     return hipGetLastError();
 }

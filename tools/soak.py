@@ -50,7 +50,7 @@ others.update({
  "hover_rpgd_mlp": CtkEngine("rpgd", "MLP", environment="Hover", num_rollouts=48, mpc_horizon=16, dt=0.02, seed=32, outer_its=2, resamp_per=4, opt_keep_k=12, sampling_distribution=0, period_interpolation_inducing_points=4),
  "hover_mppi_gru": CtkEngine("mppi", "GRU", environment="Hover", num_rollouts=128, mpc_horizon=15, dt=0.02, seed=33, period_interpolation_inducing_points=5),
 })
-assert "rpgd_persist" in others["quad_rpgd_mlp"].dominant_kernel() and "NetGruT<true>" in others["hover_mppi_gru"].dominant_kernel()
+assert "rpgd_persist" in others["quad_rpgd_mlp"].dominant_kernel() and "SplitGru" in others["hover_mppi_gru"].dominant_kernel()
 others_user = {
  "pend_mppi": CtkEngine("mppi", "ODE", environment="Pendulum", num_rollouts=1024, mpc_horizon=40, dt=0.02, seed=28),
  "pend_cem": CtkEngine("cem", "ODE", environment="Pendulum", num_rollouts=512, mpc_horizon=25, dt=0.02, seed=29, cem_outer_it=3, cem_best_k=50),
