@@ -301,6 +301,73 @@ struct SplitGru {
     };
 };
 
+// ---- the 64-unit MLP (ctk_mlp_wide.h: hidden widths 33..64) over FOUR waves, forward only (round 4) ---------------------------------------
+// One wave per tile runs 12 + 64 + 16 matrix products per step (2.2 us: MPPI N 1 024 / H 50 = 116 us against 45 for the 32-unit network).
+// Here wave m owns hidden row tile m of both layers: layer 1 is its own KS products, the four waves exchange their h1 tiles (LDS, one
+// barrier), layer 2 is 16 products (its own tile's k-steps first, the others' as they arrive), layer 3 the four k-steps of its own h2
+// units, and the four partial outputs meet through LDS (second barrier) — 2..3 + 16 + 4 products per wave and step, two exchanges like
+// SplitMlp.  Same operand table as NetMlpWideT (ctk_mlp_wide.h); every wave ends with the same next state (one association).
+// The reverse mode (RPGD) keeps the one-wave kernels for this width.
+constexpr int M4_EX_FWD = 4 * 64 * 4 + 4 * 64 * 2;
+template <bool K3>
+struct SplitMlp64 {
+    static constexpr int WAVES = 4, TAPE_F4 = 2, EX_FWD = M4_EX_FWD, EX_BWD = 0, NET = NET_MLP64;
+    struct Fwd {
+        float w1[3], w2[MLPW_KH], w3[4];
+        f32x4 b1, b2;
+        float b3lo, b3hi;
+        CTK_DEV void load(const float* __restrict__ tab, int m, int lane) {
+            const float* p = tab + (size_t)lane * MLPW_FWD_PER_LANE;
+            // per lane: w1[T][3] | w2[T][KH] | w3[KH] | b1[T][4] | b2[T][4] | b3[4]
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) w1[ks] = p[m * 3 + ks];
+#pragma unroll
+            for (int o = 0; o < 4; ++o)                                    // in the order of use: the own tile's k-steps, then tiles m + 1, m + 2, m + 3
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) w2[o * 4 + jj] = p[MLPW_T * 3 + m * MLPW_KH + ((m + o) & 3) * 4 + jj];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w3[j] = p[MLPW_T * 3 + MLPW_T * MLPW_KH + 4 * m + j];
+            const int ob = MLPW_T * 3 + MLPW_T * MLPW_KH + MLPW_KH;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { b1[r] = p[ob + m * 4 + r]; b2[r] = p[ob + 4 * MLPW_T + m * 4 + r]; }
+            b3lo = p[ob + 8 * MLPW_T]; b3hi = p[ob + 8 * MLPW_T + 1];
+        }
+        CTK_DEV void begin(const float*, int) {}
+        template <int S, int C> CTK_DEV void fold_load(int) {}
+        template <int S, int C> CTK_DEV void fold_inputs(const float (&)[C]) {}
+        template <int TAPE, int = 0, int = 0>
+        CTK_DEV MlpPair step(float x0, float x1, float x2, float* ex, int m, int lane, float4*) {
+            static_assert(TAPE == 0, "forward only");
+            float4* ex_h = reinterpret_cast<float4*>(ex);                  // [4][64]
+            float2* ex_o = reinterpret_cast<float2*>(ex + 4 * 64 * 4);     // [4][64]
+            f32x4 a = CTK_MFMA(w1[0], x0, b1);
+            a = CTK_MFMA(w1[1], x1, a);
+            if constexpr (K3) a = CTK_MFMA(w1[2], x2, a);
+            const f32x4 h1m = ctk_tanhf4(a);
+            ex_h[m * 64 + lane] = st4(h1m);
+            __syncthreads();
+            f32x4 c = b2;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {                                  // own tile first: the others are still arriving
+                const int mm = (m + o) & 3;
+                const f32x4 hx = o == 0 ? h1m : ld4(ex_h + mm * 64 + lane);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) c = CTK_MFMA(w2[o * 4 + jj], hx[jj], c);
+            }
+            const f32x4 h2m = ctk_tanhf4(c);
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 p0 = CTK_MFMA(w3[0], h2m[0], z), p1 = CTK_MFMA(w3[1], h2m[1], z);
+            p0 = CTK_MFMA(w3[2], h2m[2], p0);
+            p1 = CTK_MFMA(w3[3], h2m[3], p1);
+            ex_o[m * 64 + lane] = make_float2(p0[0] + p1[0], p0[1] + p1[1]);
+            __syncthreads();
+            const float2 q0 = ex_o[lane], q1 = ex_o[64 + lane], q2 = ex_o[128 + lane], q3 = ex_o[192 + lane];
+            return MlpPair{((q0.x + q1.x) + (q2.x + q3.x)) + b3lo, ((q0.y + q1.y) + (q2.y + q3.y)) + b3hi};   // the same association in every wave
+        }
+    };
+    struct Bwd {};      // (not built: RPGD with this width runs ctk_generic_net.hip's one-wave kernels)
+};
+
 template <bool K3>
 struct SplitMlp {
     static constexpr int WAVES = 2, TAPE_F4 = 2, EX_FWD = M2_EX_FWD, EX_BWD = M2_EX_BWD, NET = NET_MLP;
@@ -1745,14 +1812,15 @@ __global__ __launch_bounds__(256) void ctk_g_gru_advance4(RolloutArgs a, const f
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
 static uint32_t g4_magic_of(int d) { return d >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d) : 0u; }
-static int split_waves(int net) { return net == NET_GRU ? SplitGru::WAVES : SplitMlp<false>::WAVES; }
-static int split_ex_fwd(int net) { return net == NET_GRU ? SplitGru::EX_FWD : SplitMlp<false>::EX_FWD; }
+static int split_waves(int net) { return net == NET_GRU ? SplitGru::WAVES : net == NET_MLP64 ? SplitMlp64<false>::WAVES : SplitMlp<false>::WAVES; }
+static int split_ex_fwd(int net) { return net == NET_GRU ? SplitGru::EX_FWD : net == NET_MLP64 ? SplitMlp64<false>::EX_FWD : SplitMlp<false>::EX_FWD; }
 static int split_ex_bwd(int net) { return net == NET_GRU ? SplitGru::EX_BWD : SplitMlp<false>::EX_BWD; }
 static int split_tape_f4(int net) { return net == NET_GRU ? SplitGru::TAPE_F4 : SplitMlp<false>::TAPE_F4; }
 static void env_dims(int env, int* S, int* C) { CTK_FOR_ENV(env, EV, { *S = Env<EV>::S; *C = Env<EV>::C; }); }
 static const char* split_policy_name(int env, int net) {
     int S = 0, C = 0;
     env_dims(env, &S, &C);
+    if (net == NET_MLP64) return S + C > 8 ? "SplitMlp64<true>" : "SplitMlp64<false>";
     return net == NET_GRU ? "SplitGru" : (S + C > 8 ? "SplitMlp<true>" : "SplitMlp<false>");
 }
 // the split forms serve the populations that leave SIMDs idle with one wave per tile (N <= 8 192: 512 tiles on 1 024 SIMDs); larger
@@ -1890,7 +1958,7 @@ hipError_t ctk_launch_g_rpgd_wide_split(hipStream_t st, int env, const RolloutAr
 // two tiles per workgroup (kernel comment): the two-wave policies, more than one tile per CU, every tile full
 static bool rollout_split_two_tiles(int net, int N, int H, int cols, int C) {
     const int tiles = (N + G4_TRAJ - 1) / G4_TRAJ;
-    return net != NET_GRU && tiles > 256 && tiles % 2 == 0 && N % G4_TRAJ == 0 &&
+    return net == NET_MLP && tiles > 256 && tiles % 2 == 0 && N % G4_TRAJ == 0 &&
            2 * split_tile_floats(split_ex_fwd(net), cols, H, C) * sizeof(float) <= 160 * 1024 && getenv("CTK_SPLIT_ONE_TILE") == nullptr;
 }
 size_t ctk_g_rollout_split_lds(int net, int cols, int H, int C) { return split_tile_floats(split_ex_fwd(net), cols, H, C) * sizeof(float); }
@@ -1898,7 +1966,9 @@ bool ctk_g_rollout_split_ok(int env, int net, int N, int H, int cols) {
     static const bool off = getenv("CTK_NET_ONE_WAVE") != nullptr;
     int S = 0, C = 0;
     env_dims(env, &S, &C);
-    return !off && split_env_ok(env, net) && N <= 8192 && ctk_g_rollout_split_lds(net, cols, H, C) <= 160 * 1024;
+    // (the 64-unit MLP: forward only, so the rollout kernels take it and the RPGD descent does not)
+    // (... up to 256 tiles: its four waves per tile fill the chip's 1 024 SIMDs there; beyond, one wave per tile is faster — 233 against 333 us at 512)
+    return !off && (split_env_ok(env, net) || net == NET_MLP64) && N <= (net == NET_MLP64 ? 4096 : 8192) && ctk_g_rollout_split_lds(net, cols, H, C) <= 160 * 1024;
 }
 int ctk_g_rollout_split_blocks(int N) { return (N + G4_TRAJ - 1) / G4_TRAJ; }
 const char* ctk_g_rollout_split_name(int env, int net, int mode, bool log, int N, int H, int cols) {
@@ -1946,6 +2016,8 @@ hipError_t ctk_launch_g_rollout_split(hipStream_t st, int env, int net, int mode
         using E = Env<EV>;
         if (net == NET_GRU) {
             launch_rollout_split<EV, SplitGru>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
+        } else if (net == NET_MLP64) {
+            launch_rollout_split<EV, SplitMlp64<(E::S + E::C > 8)>>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
         } else {
             launch_rollout_split<EV, SplitMlp<(E::S + E::C > 8)>>(st, mode, a, params, dt, isteps, mk, samples, base, scale, rng_kind, wperm, hidden, parts, log, e0, e1, fuse);
         }

@@ -199,7 +199,8 @@ WIDE_SHAPES = [(64, 64), (48, 64), (33, 20)]
 
 @pytest.mark.parametrize("hidden", WIDE_SHAPES)
 def test_cartpole_mppi_and_rpgd_on_64_unit_mlp_match_oracle(hidden):
-    """hidden widths 33..64: the handle is built on the 64-unit form of the one-wave template kernels (csrc/ctk_mlp_wide.h)"""
+    """hidden widths 33..64: the handle is built on the 64-unit forms (csrc/ctk_mlp_wide.h: one wave per tile, forward and reverse;
+    csrc/ctk_net_split.hip: SplitMlp64, four waves per tile for the rollouts)"""
     env = O.EnvParams(terminal_weight=0.3)
     w = O.mlp_default_weights(6, 5, 4, hidden)
     pred = O.Predictor("MLP", dt=0.02, env=env, weights=w, hidden_sizes=hidden)
@@ -207,7 +208,9 @@ def test_cartpole_mppi_and_rpgd_on_64_unit_mlp_match_oracle(hidden):
     o = O.MPPI(pred, O.Cost(env), num_rollouts=N, mpc_horizon=H, period_interpolation_inducing_points=p)
     e = CtkEngine("mppi", "MLP", num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p, materialize_trajectories=True,
                   predictor_hidden=hidden)
-    assert "NetMlpWideT<false>" in e.dominant_kernel(), e.dominant_kernel()
+    import os
+    one_wave = bool(os.environ.get("CTK_NET_ONE_WAVE"))        # rollouts: four waves per tile (SplitMlp64, forward only) unless the diagnostic switch is set
+    assert ("NetMlpWideT<false>" if one_wave else "SplitMlp64<false>") in e.dominant_kernel(), e.dominant_kernel()
     assert e.predictor_weight_count() == O.mlp_num_weights(5, 4, (64, 64)) and e.predictor_weight_count(hidden) == w.size
     apply_env(e, env); e.set_predictor_weights(w)                   # hidden = what the engine was created for
     rng = np.random.default_rng(sum(hidden))
@@ -251,7 +254,8 @@ def test_hover_mppi_cem_and_rpgd_on_64_unit_mlp_match_oracle():
     o = O.MPPI(pred, O.Cost(env), lo, hi, num_rollouts=N, mpc_horizon=H, period_interpolation_inducing_points=p)
     e = CtkEngine("mppi", "MLP", environment="Hover", num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p, action_low=lo,
                   action_high=hi, materialize_trajectories=True, predictor_hidden=hidden)
-    assert "NetMlpWideT<true>" in e.dominant_kernel(), e.dominant_kernel()     # ten network inputs: three layer-1 k-steps
+    import os
+    assert ("NetMlpWideT<true>" if os.environ.get("CTK_NET_ONE_WAVE") else "SplitMlp64<true>") in e.dominant_kernel(), e.dominant_kernel()     # ten network inputs: three layer-1 k-steps
     for n in env.param_names():
         e.set_param(n, float(getattr(env, n)))
     e.set_predictor_weights(w)
@@ -314,7 +318,7 @@ def test_network_name_reaches_the_kernels_through_controller_mpc():
     # ... and a 64-unit name builds the 64-unit engine
     d64 = load("mppi_mlp_h64.npz")
     c64 = build(d64, "mppi-hip", cfg, predictor=str(d64["predictor_specification"]))
-    assert c64.optimizer.engine.native_hidden == (64, 64) and "NetMlpWideT" in c64.optimizer.engine.dominant_kernel()
+    assert c64.optimizer.engine.native_hidden == (64, 64) and ("NetMlpWideT" in c64.optimizer.engine.dominant_kernel() or "SplitMlp64" in c64.optimizer.engine.dominant_kernel())
     c64.optimizer.rng = ReplayRng([d64[f"noise_{t}"] for t in range(steps)])
     for t in range(steps):
         np.testing.assert_allclose(c64.step(d64[f"s_{t}"]), d64[f"u_{t}"][0], rtol=1e-4, atol=2e-5)
