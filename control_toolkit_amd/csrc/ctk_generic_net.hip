@@ -453,12 +453,13 @@ size_t ctk_g_rpgd_descent_net_lds(int env, int net, int N, int H) {
 }
 
 size_t ctk_g_rpgd_scratch_floats_net(int net, int N, int H) {
-    if (net == NET_MLP64) return (size_t)((N + GN_TRAJ - 1) / GN_TRAJ) * 4 * H * 64 * NetMlpWideT<false>::TAPE;
+    if (net == NET_MLP64) return std::max((size_t)((N + GN_TRAJ - 1) / GN_TRAJ) * 4 * H * 64 * NetMlpWideT<false>::TAPE, ctk_g_rpgd_scratch_floats_wide(N, H));
     const size_t one_wave = (size_t)((N + GN_TRAJ - 1) / GN_TRAJ) * 4 * H * 64 * (net == NET_GRU ? NetGru::TAPE : NetMlp::TAPE);
     return std::max(std::max(one_wave, ctk_g_rpgd_scratch_floats_split(net, N, H)), net == NET_MLP ? ctk_g_rpgd_scratch_floats_wide(N, H) : (size_t)0);
 }
 
 const char* ctk_g_rpgd_descent_net_name(int env, int net, int N, int H) {
+    if (net == NET_MLP64 && ctk_g_rpgd_persist64_ok(env, N, H)) return ctk_g_rpgd_persist64_name(env);
     if (ctk_g_rpgd_wide_ok(env, net, N, H)) return ctk_g_rpgd_wide_name(env, N, H);
     if (ctk_g_rpgd_split_ok(env, net, N, H)) return ctk_g_rpgd_descent_split_name(env, net);
     int io = 0;
@@ -474,6 +475,8 @@ hipError_t ctk_launch_g_rpgd_descent_net(hipStream_t st, int env, int net, const
     AdamK ad{lr, b1, b2, (float)(1.0 - (double)b1), (float)(1.0 - (double)b2), eps, clip, rule};
     const float* hidden = wperm + ctk_g_net_table_floats(net);
     const float* wb = bwd_table(net, wperm);
+    if (net == NET_MLP64 && pers != nullptr && iters >= 1 && iters <= 63 && ctk_g_rpgd_persist64_ok(env, a_in.N, a_in.H))   // the 64-unit network: one launch (ctk_net_split.hip)
+        return ctk_launch_g_rpgd_persist64(st, env, a_in, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, scratch, e0, e1, err_word, pers);
     if (ctk_g_rpgd_wide_ok(env, net, a_in.N, a_in.H))       // MLP, N <= 4 096: phase + grid-wide Jacobian launches (ctk_net_split.hip)
         return ctk_launch_g_rpgd_wide_split(st, env, a_in, params, dt, isteps, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, scratch, e0, e1, err_word, pers);
     if (ctk_g_rpgd_split_ok(env, net, a_in.N, a_in.H))      // one tile over several waves while the population leaves SIMDs idle (ctk_net_split.hip)

@@ -289,6 +289,11 @@ const char* ctk_g_rpgd_wide_name(int env, int N = 0, int H = 0);
 hipError_t ctk_launch_g_rpgd_wide_split(hipStream_t st, int env, const RolloutArgs& a, const float* params, float dt, int isteps, const AdamK& ad,
                                         float* Q, float* m, float* v, const float* bc_table, int bc_len, int t0, int iters, const float* wperm,
                                         float* scratch, hipEvent_t e0, hipEvent_t e1, uint32_t* err_word, RpgdPersist* pers = nullptr);
+bool ctk_g_rpgd_persist64_ok(int env, int N, int H);          // ... and of the 64-unit network's (no phase-launch form exists for that width)
+const char* ctk_g_rpgd_persist64_name(int env);
+hipError_t ctk_launch_g_rpgd_persist64(hipStream_t st, int env, const RolloutArgs& a, const float* params, float dt, int isteps, const AdamK& ad,
+                                       float* Q, float* m, float* v, const float* bc_table, int bc_len, int t0, int iters, const float* wperm,
+                                       float* scratch, hipEvent_t e0, hipEvent_t e1, uint32_t* err_word, RpgdPersist* pers);
 bool ctk_g_rpgd_persist_ok(int env, int net, int N, int H);   // the wide form as one launch per MPC step (ctk_g_rpgd_persist)
 bool ctk_g_rollout_split_ok(int env, int net, int N, int H, int cols);
 size_t ctk_g_rollout_split_lds(int net, int cols, int H, int C);

@@ -1217,14 +1217,44 @@ CTK_DEV void gp_gave_up(uint32_t* err_word, int what, int h, int tile, uint32_t 
     __hip_atomic_store(err_word, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <int ENV, bool K3>
+// S + C tangents through the 64-unit network (the worker of the WIDE instantiation below; ctk_mlp_wide.h's operand table)
+template <int IO, bool K3>
+CTK_DEV void jac_tangents64(const typename NetMlpWideT<K3>::Fwd& w, const f32x4 (&d1)[MLPW_T], const f32x4 (&d2)[MLPW_T], float* rec, int g, int j0, int jstep) {
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < IO; ++j) {
+        if (jstep != 1 && (j % jstep) != j0) continue;                  // (wave-uniform)
+        const float ind = (g == (j & 3)) ? 1.0f : 0.0f;
+        f32x4 t1[MLPW_T], zz[MLPW_T];
+#pragma unroll
+        for (int m = 0; m < MLPW_T; ++m) { t1[m] = CTK_MFMA(w.w1[m][j >> 2], ind, z) * d1[m]; zz[m] = z; }
+#pragma unroll
+        for (int q = 0; q < MLPW_KH; ++q) {
+            const float bq = t1[q >> 2][q & 3];
+#pragma unroll
+            for (int m = 0; m < MLPW_T; ++m) zz[m] = CTK_MFMA(w.w2[m][q], bq, zz[m]);
+        }
+        f32x4 o0 = z, o1 = z;
+#pragma unroll
+        for (int q = 0; q < MLPW_KH; q += 2) {
+            o0 = CTK_MFMA(w.w3[q], zz[q >> 2][q & 3] * d2[q >> 2][q & 3], o0);
+            o1 = CTK_MFMA(w.w3[q + 1], zz[(q + 1) >> 2][(q + 1) & 3] * d2[(q + 1) >> 2][(q + 1) & 3], o1);
+        }
+        rec[j * 8 + g] = o0[0] + o1[0];
+        rec[j * 8 + 4 + g] = o0[1] + o1[1];
+    }
+}
+
+// WIDE: the 64-unit network (SplitMlp64 forward over four producer waves; no phase-launch counterpart exists for it — it is held to the
+// oracle and to the one-wave kernels, tests/test_gpu_net_shapes.py)
+template <int ENV, bool K3, bool WIDE>
 __global__ __launch_bounds__(256) void ctk_g_rpgd_persist(RolloutArgs a, typename Env<ENV>::K k, AdamK ad, float* __restrict__ Q, float* __restrict__ mom,
                                                          float* __restrict__ var, const float* __restrict__ bc_table, int bc_len, int t0, int iters,
                                                          const float* __restrict__ wperm, float* __restrict__ scratch, GPersistK pk) {
     using E = Env<ENV>;
-    using SP = SplitMlp<K3>;
-    constexpr int S = E::S, C = E::C, IO = S + C, BLOCK = 128, NPARTS = BLOCK / G4_TRAJ;
-    constexpr int KS = K3 ? 3 : 2, NF = SP::Fwd::template fold_n<S, C>(), CC0 = 4 * (KS - 1) - S;
+    using SP = std::conditional_t<WIDE, SplitMlp64<K3>, SplitMlp<K3>>;
+    constexpr int S = E::S, C = E::C, IO = S + C, PW = SP::WAVES, BLOCK = 64 * PW, NPARTS = BLOCK / G4_TRAJ;
+    constexpr int KS = K3 ? 3 : 2, NF = WIDE ? 0 : SplitMlp<K3>::Fwd::template fold_n<S, C>(), CC0 = 4 * (KS - 1) - S;
     constexpr bool FOLD = NF > 0;
     extern __shared__ float lds[];
     const int H = a.H, HC = H * C;
@@ -1232,7 +1262,9 @@ __global__ __launch_bounds__(256) void ctk_g_rpgd_persist(RolloutArgs a, typenam
     uint32_t* ticket = reinterpret_cast<uint32_t*>(scratch + gp_ticket_off(pk.tiles, H, C));
     if ((int)blockIdx.x >= pk.tiles) {
         // ------------------------------------------------------------------------------------------ a Jacobian worker (four waves)
-        const MlpFwdW w = mlp_load_fwd(wperm);
+        using WT = std::conditional_t<WIDE, typename NetMlpWideT<K3>::Fwd, MlpFwdW>;
+        WT w;
+        if constexpr (WIDE) w.load(wperm, nullptr); else w = mlp_load_fwd(wperm);
         f32x4 w1u[2][NF > 0 ? NF : 1];                                   // the folded layer-1 columns at this lane's accumulator rows (SplitMlp::fold_load)
         if constexpr (FOLD) {
 #pragma unroll
@@ -1284,38 +1316,65 @@ __global__ __launch_bounds__(256) void ctk_g_rpgd_persist(RolloutArgs a, typenam
             for (int cc = 0; cc < C; ++cc) u[cc] = __shfl(ug, c + 16 * cc, 64);
             float x0, x1, x2;
             split_operands<S, C>(sv0, sv1, u, g, x0, x1, x2);
-            // the step's activations, both row tiles on this one wave, as the pair of SplitMlp::Fwd::step forms them
-            f32x4 h1[2], h2[2];
+            // the step's activations, every row tile on this one wave, as the waves of the forward pass form them
+            if constexpr (WIDE) {
+                f32x4 h1[MLPW_T], d1[MLPW_T], d2[MLPW_T];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                f32x4 b = w.b1[m];
-                if constexpr (FOLD) {
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) b += w1u[m][f] * u[CC0 + f];
+                for (int m = 0; m < MLPW_T; ++m) {
+                    f32x4 acc = CTK_MFMA(w.w1[m][0], x0, w.b1[m]);
+                    acc = CTK_MFMA(w.w1[m][1], x1, acc);
+                    if constexpr (K3) acc = CTK_MFMA(w.w1[m][2], x2, acc);
+                    h1[m] = ctk_tanhf4(acc);
                 }
-                f32x4 acc = CTK_MFMA(w.w1[m][0], x0, b);
-                if constexpr (!(FOLD && !K3)) acc = CTK_MFMA(w.w1[m][1], x1, acc);
-                if constexpr (K3 && !FOLD) acc = CTK_MFMA(w.w1[m][2], x2, acc);
-                h1[m] = ctk_tanhf4(acc);
+#pragma unroll
+                for (int m = 0; m < MLPW_T; ++m) {
+                    f32x4 cc2 = w.b2[m];
+#pragma unroll
+                    for (int o = 0; o < 4; ++o)                            // SplitMlp64::Fwd::step: tile m's own k-steps, then tiles m + 1, m + 2, m + 3
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) cc2 = CTK_MFMA(w.w2[m][((m + o) & 3) * 4 + jj], h1[(m + o) & 3][jj], cc2);
+                    const f32x4 h2 = ctk_tanhf4(cc2);
+                    d1[m] = 1.0f - h1[m] * h1[m]; d2[m] = 1.0f - h2 * h2;
+                }
+                if (!ok) {
+                    const float nan = __builtin_nanf("");
+#pragma unroll
+                    for (int m = 0; m < MLPW_T; ++m) { d1[m] = f32x4{nan, nan, nan, nan}; d2[m] = d1[m]; }
+                }
+                jac_tangents64<IO, K3>(w, d1, d2, rec_s + c * 128, g, wave, 4);
+            } else {
+                f32x4 h1[2], h2[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    f32x4 b = w.b1[m];
+                    if constexpr (FOLD) {
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) b += w1u[m][f] * u[CC0 + f];
+                    }
+                    f32x4 acc = CTK_MFMA(w.w1[m][0], x0, b);
+                    if constexpr (!(FOLD && !K3)) acc = CTK_MFMA(w.w1[m][1], x1, acc);
+                    if constexpr (K3 && !FOLD) acc = CTK_MFMA(w.w1[m][2], x2, acc);
+                    h1[m] = ctk_tanhf4(acc);
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    f32x4 cc2 = w.b2[m];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cc2 = CTK_MFMA(w.w2[m][m ? 4 + j : j], h1[m][j], cc2);              // own half first ...
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cc2 = CTK_MFMA(w.w2[m][m ? j : 4 + j], h1[m ^ 1][j], cc2);          // ... then the other wave's
+                    h2[m] = ctk_tanhf4(cc2);
+                }
+                f32x4 d1[2], d2[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) { d1[m] = 1.0f - h1[m] * h1[m]; d2[m] = 1.0f - h2[m] * h2[m]; }
+                if (!ok) {
+                    const float nan = __builtin_nanf("");
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) { d1[m] = f32x4{nan, nan, nan, nan}; d2[m] = d1[m]; }
+                }
+                jac_tangents<IO>(w, d1, d2, rec_s + c * 128, g, wave, 4);
             }
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                f32x4 cc2 = w.b2[m];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) cc2 = CTK_MFMA(w.w2[m][m ? 4 + j : j], h1[m][j], cc2);              // own half first ...
-#pragma unroll
-                for (int j = 0; j < 4; ++j) cc2 = CTK_MFMA(w.w2[m][m ? j : 4 + j], h1[m ^ 1][j], cc2);          // ... then the other wave's
-                h2[m] = ctk_tanhf4(cc2);
-            }
-            f32x4 d1[2], d2[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) { d1[m] = 1.0f - h1[m] * h1[m]; d2[m] = 1.0f - h2[m] * h2[m]; }
-            if (!ok) {
-                const float nan = __builtin_nanf("");
-#pragma unroll
-                for (int m = 0; m < 2; ++m) { d1[m] = f32x4{nan, nan, nan, nan}; d2[m] = d1[m]; }
-            }
-            jac_tangents<IO>(w, d1, d2, rec_s + c * 128, g, wave, 4);
             // the cost's state gradient of this step (wave 0) and, with the last step, of the terminal state (wave 1): plan c = lanes g == 0
             if (wave == 0 || term) {
                 const float a0 = term ? __builtin_bit_cast(float, (uint32_t)z0) : sv0, a1 = term ? __builtin_bit_cast(float, (uint32_t)z1) : sv1;
@@ -1346,8 +1405,8 @@ __global__ __launch_bounds__(256) void ctk_g_rpgd_persist(RolloutArgs a, typenam
         }
         return;
     }
-    // ---------------------------------------------------------------------------------------------- a producer (one tile, two waves)
-    if (wave >= 2) return;                                               // (a finished wave no longer counts at the workgroup's barriers)
+    // ---------------------------------------------------------------------------------------------- a producer (one tile; two waves, four for the 64-unit network)
+    if (wave >= PW) return;                                              // (a finished wave no longer counts at the workgroup's barriers)
     float* ex = lds;
     float* red_s = ex + SP::EX_FWD;
     float* xs_s = red_s + G4_RED;
@@ -1404,7 +1463,8 @@ __global__ __launch_bounds__(256) void ctk_g_rpgd_persist(RolloutArgs a, typenam
         v = sum_over_groups(v);
         if (g == 0) red_s[wave * 16 + c] = v;
         __syncthreads();
-        const float r = red_s[c] + red_s[16 + c];
+        float r = red_s[c] + red_s[16 + c];
+        if constexpr (PW == 4) r += red_s[32 + c] + red_s[48 + c];
         __syncthreads();
         return r;
     };
@@ -1423,7 +1483,8 @@ __global__ __launch_bounds__(256) void ctk_g_rpgd_persist(RolloutArgs a, typenam
             if (publish) {
                 if (h != withhold) {
                     unsigned long long* p = pub + (uint32_t)(h * 192) + word;
-                    if (wv == 0) {
+                    if (wv >= 2) {
+                    } else if (wv == 0) {
                         float ug = 0.0f;
 #pragma unroll
                         for (int cc = 0; cc < C; ++cc) ug = g == cc ? u[cc] : ug;
@@ -1433,7 +1494,7 @@ __global__ __launch_bounds__(256) void ctk_g_rpgd_persist(RolloutArgs a, typenam
                         __hip_atomic_store(p + 64, hi | (unsigned long long)__builtin_bit_cast(uint32_t, sv1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-            } else if (wave == (h & 1)) {
+            } else if (wave == (h & (PW - 1))) {
                 reinterpret_cast<float2*>(xs_s)[h * 64 + lane] = make_float2(sv0, sv1);
             }
             float x0, x1, x2;
@@ -1445,7 +1506,7 @@ __global__ __launch_bounds__(256) void ctk_g_rpgd_persist(RolloutArgs a, typenam
         if (publish) {                                                   // the terminal state: words of "step" H
             unsigned long long* p = pub + (uint32_t)(H * 192) + word;
             if (wv == 0) __hip_atomic_store(p, hi | (unsigned long long)__builtin_bit_cast(uint32_t, sv0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else __hip_atomic_store(p + 64, hi | (unsigned long long)__builtin_bit_cast(uint32_t, sv1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (wv == 1) __hip_atomic_store(p + 64, hi | (unsigned long long)__builtin_bit_cast(uint32_t, sv1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (wave == 0) {
             reinterpret_cast<float2*>(xs_s)[H * 64 + lane] = make_float2(sv0, sv1);
         }
@@ -1491,8 +1552,10 @@ __global__ __launch_bounds__(256) void ctk_g_rpgd_persist(RolloutArgs a, typenam
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         float4 ring[RING][W4];
+        if (t < 128) {
 #pragma unroll
-        for (int d = 0; d < RING; ++d) rec_fetch(max(H - 1 - d, 0), ring[d]);
+            for (int d = 0; d < RING; ++d) rec_fetch(max(H - 1 - d, 0), ring[d]);
+        }
         {   // the cost-gradient terms the workers left: LDS-DMA, 1 KiB per wave-instruction; the barrier below waits for it
             const int n4 = (H + 1) * 32;
             const float4* src = reinterpret_cast<const float4*>(tbase + gw_gs_off(H));
@@ -1504,7 +1567,7 @@ __global__ __launch_bounds__(256) void ctk_g_rpgd_persist(RolloutArgs a, typenam
         }
         __syncthreads();
         // ---- the adjoint chain (ctk_g_rpgd_wide_split: plan p = t / 8, lane i owns column i and, beyond 8 inputs, column 8 + i)
-        {
+        if (t < 128) {
             const int p = cp, i = ci;
             const bool is_state = i < S, is_input = i >= S && i < IO;
             const int w0 = is_state ? (int)(gs_s - lds) + ((i & 3) * 16 + p) * 2 + (i >> 2) : is_input ? (int)(g_s - lds) + (i - S) * G4_LD + p : (int)(gs_s - lds);
@@ -1557,7 +1620,7 @@ __global__ __launch_bounds__(256) void ctk_g_rpgd_persist(RolloutArgs a, typenam
         const int tile_bad = __syncthreads_or(!(n2 <= 3.0e38f));
         if (tile_bad && t == 0 && pk.err_word != nullptr) __hip_atomic_store(pk.err_word + 1, 1u + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const float scl = ad.clip / fmaxf(sqrtf(n2), ad.clip);
-        if (wave == 0 && g == 0) red_s[64 + c] = scl;
+        if (wave == 0 && g == 0) red_s[64 + c] = scl;                    // (G4_RED = 80 floats: [4 waves][16] + [16])
         __syncthreads();
         for (int i = t; !tile_bad && i < total; i += BLOCK) {
             const int r = HC >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, hc = i - r * HC, cc = hc % C;
@@ -1920,10 +1983,10 @@ static void launch_wide_split(hipStream_t st, const RolloutArgs& a_in, const flo
         pers->ticket_base += (uint32_t)per_it * (uint32_t)iters + (uint32_t)W;      // every job + one ticket past the end per worker workgroup
         const size_t plds = std::max(lds + (size_t)2 * a.H * E::C * G4_LD * sizeof(float), (size_t)84 * 1024);
         if (e0 || e1)
-            hipExtLaunchKernelGGL((ctk_g_rpgd_persist<EV, K3>), dim3(tiles + W), dim3(256), plds, st, e0, e1, 0, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm,
+            hipExtLaunchKernelGGL((ctk_g_rpgd_persist<EV, K3, false>), dim3(tiles + W), dim3(256), plds, st, e0, e1, 0, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm,
                                   scratch, pk);
         else
-            hipLaunchKernelGGL((ctk_g_rpgd_persist<EV, K3>), dim3(tiles + W), dim3(256), plds, st, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, scratch, pk);
+            hipLaunchKernelGGL((ctk_g_rpgd_persist<EV, K3, false>), dim3(tiles + W), dim3(256), plds, st, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, scratch, pk);
         return;
     }
     // the Jacobian work rides inside the phase launch (rpgd_jac_worker); CTK_RPGD_NO_OVERLAP: its own launch after each phase launch
@@ -1946,6 +2009,43 @@ static void launch_wide_split(hipStream_t st, const RolloutArgs& a_in, const flo
                                it > 0 ? 1 : 0, last ? 1 : 0, seq, err_word, withhold);
         if (!last && !ovl) hipLaunchKernelGGL((ctk_g_rpgd_jac_split<EV, K3>), dim3(tiles * a.H), dim3(64), 0, st, a, k, Q, wperm, scratch);
     }
+}
+
+// the 64-unit network's descent as one launch (ctk_g_rpgd_persist<., ., true>): up to 32 tiles, H <= 64, 1..63 iterations
+bool ctk_g_rpgd_persist64_ok(int env, int N, int H) {
+    static const bool off = getenv("CTK_RPGD_NO_PERSISTENT") != nullptr || getenv("CTK_RPGD_NET_ONE_WAVE") != nullptr;
+    int S = 0, C = 0;
+    env_dims(env, &S, &C);
+    const size_t lds = (size_t)(M4_EX_FWD + G4_RED + 2 * (H + 1) * 128 + gw_gd_floats(H, C) + 3 * H * C * G4_LD) * sizeof(float);
+    return !off && S + C <= 12 && N <= 32 * G4_TRAJ && H <= 64 && lds <= 160 * 1024;
+}
+const char* ctk_g_rpgd_persist64_name(int env) {
+    int S = 0, C = 0;
+    env_dims(env, &S, &C);
+    return ctk_kernel_name("ctk_g_rpgd_persist<%d, %4$s, true>", env, 0, 0, S + C > 8 ? "true" : "false");
+}
+hipError_t ctk_launch_g_rpgd_persist64(hipStream_t st, int env, const RolloutArgs& a_in, const float* params, float dt, int isteps, const AdamK& ad,
+                                       float* Q, float* m, float* v, const float* bc_table, int bc_len, int t0, int iters, const float* wperm,
+                                       float* scratch, hipEvent_t e0, hipEvent_t e1, uint32_t* err_word, RpgdPersist* pers) {
+    CTK_FOR_ENV(env, EV, {
+        using E = Env<EV>;
+        constexpr bool K3 = E::S + E::C > 8;
+        RolloutArgs a = a_in;
+        a.C = E::C; a.p_magic = g4_magic_of(a.H * E::C);
+        const typename E::K k = E::derive(params, dt, isteps);
+        const int tiles = (a.N + G4_TRAJ - 1) / G4_TRAJ, per_it = tiles * a.H, W = std::min(240, per_it);
+        if (pers->seq0 < 64u || pers->seq0 > 0xffffff00u) pers->seq0 = 64u;
+        GPersistK pk{pers->seq0, pers->ticket_base, err_word, tiles, -1};
+        pers->seq0 += 64u;
+        pers->ticket_base += (uint32_t)per_it * (uint32_t)iters + (uint32_t)W;
+        const size_t lds = std::max((size_t)(M4_EX_FWD + G4_RED + 2 * (a.H + 1) * 128 + gw_gd_floats(a.H, E::C) + 3 * a.H * E::C * G4_LD) * sizeof(float), (size_t)84 * 1024);
+        if (e0 || e1)
+            hipExtLaunchKernelGGL((ctk_g_rpgd_persist<EV, K3, true>), dim3(tiles + W), dim3(256), lds, st, e0, e1, 0, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm,
+                                  scratch, pk);
+        else
+            hipLaunchKernelGGL((ctk_g_rpgd_persist<EV, K3, true>), dim3(tiles + W), dim3(256), lds, st, a, k, ad, Q, m, v, bc_table, bc_len, t0, iters, wperm, scratch, pk);
+    });
+    return hipGetLastError();
 }
 
 hipError_t ctk_launch_g_rpgd_wide_split(hipStream_t st, int env, const RolloutArgs& a, const float* params, float dt, int isteps, const AdamK& ad,

@@ -232,7 +232,8 @@ def test_cartpole_mppi_and_rpgd_on_64_unit_mlp_match_oracle(hidden):
     er = CtkEngine("rpgd", "MLP", num_rollouts=48, mpc_horizon=12, dt=0.02, period_interpolation_inducing_points=4, outer_its=its, resamp_per=10,
                    shift_previous=1, opt_keep_k=orp.k, sampling_distribution=0, sample_min=-1.0, sample_max=1.0, learning_rate=0.05, gradmax_clip=5.0,
                    predictor_hidden=hidden)
-    assert "NetMlpWideT<false>" in er.dominant_kernel(), er.dominant_kernel()
+    rpgd_one_wave = os.environ.get("CTK_RPGD_NET_ONE_WAVE") or os.environ.get("CTK_RPGD_NO_PERSISTENT")      # (read once per process by the library)
+    assert ("NetMlpWideT<false>" if rpgd_one_wave else "ctk_g_rpgd_persist<0, false, true>") in er.dominant_kernel(), er.dominant_kernel()
     apply_env(er, env); er.set_predictor_weights(w)
     d0 = rng.random((48, orp.P, 1), dtype=np.float32)
     dr = rng.random((48 - orp.k, orp.P, 1), dtype=np.float32)
@@ -322,3 +323,58 @@ def test_network_name_reaches_the_kernels_through_controller_mpc():
     c64.optimizer.rng = ReplayRng([d64[f"noise_{t}"] for t in range(steps)])
     for t in range(steps):
         np.testing.assert_allclose(c64.step(d64[f"s_{t}"]), d64[f"u_{t}"][0], rtol=1e-4, atol=2e-5)
+
+
+# ---- the 64-unit network's RPGD descent as one launch (ctk_net_split.hip: ctk_g_rpgd_persist<., ., true>) against the one-wave kernels ----------
+WIDE_RPGD_SCRIPT = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle.ctk_oracle as O
+from control_toolkit_amd import CtkEngine
+N, H, p, its, K, out, ENVNAME = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], sys.argv[7]
+e = CtkEngine("rpgd", "MLP", environment=ENVNAME, num_rollouts=N, mpc_horizon=H, dt=0.02, period_interpolation_inducing_points=p, outer_its=its, resamp_per=2,
+              shift_previous=1, opt_keep_k=K, sampling_distribution=0, sample_whole_control_space=1, learning_rate=0.05, gradmax_clip=5.0, predictor_hidden=(64, 48))
+S, C = e.S, e.C
+e.set_predictor_weights(O.mlp_default_weights(3, S + C, S, (64, 48)), hidden=(64, 48))
+P = -(-H // p) + 1
+rng = np.random.default_rng(N + H)
+e.reset(rng.random((N, P, C), dtype=np.float32))
+s = np.resize(np.array([0.05, 0.0, 2.9, 0.3, -0.1, 0.2, 0.15], np.float32), S).astype(np.float32)
+res = {"kernel": np.array(e.dominant_kernel())}
+for t in range(2):
+    dr = rng.random((N - K, P, C), dtype=np.float32) if t %% 2 == 0 else None
+    res["u%%d" %% t] = np.asarray(e.step(s, dr), np.float32).reshape(-1)
+    for b in ("PLAN", "ADAM_M", "ADAM_V", "J"):
+        res[b + str(t)] = e.read(b).copy()
+    # the next step starts from THIS form's state in both processes only if the forms agree; to compare step by step, re-pin from the file of the one-wave run
+    s = (s + np.resize(np.array([0.01, 0.02, -0.03, 0.01], np.float32), S)).astype(np.float32)
+np.savez(out, **res)
+'''
+
+
+@pytest.mark.parametrize("N,H,p,its,K,envname", [(256, 50, 10, 5, 64, "CartPole"), (40, 64, 8, 2, 10, "Hover"), (500, 12, 4, 2, 125, "Quad2D"), (72, 20, 5, 3, 18, "Hover")])
+def test_64_unit_rpgd_one_launch_form_agrees_with_the_one_wave_kernels(tmp_path, N, H, p, its, K, envname):
+    """The 64-unit network has no phase-launch form to be held to bit for bit: its one-launch descent (producers on SplitMlp64, workers that
+    recompute the activations in the producers' association, 64-unit tangents) is compared with the one-wave reverse mode of
+    ctk_generic_net.hip (NetMlpWideT::Bwd, a different association of every sum) at the tolerance the oracle tests use, first step of a
+    descent from the same plans; ragged tiles, H = 64, 32 tiles, all three environments."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = WIDE_RPGD_SCRIPT % (root, os.path.join(root, "tests"))
+    outs = {}
+    for form, extra in (("one_launch", {}), ("one_wave", {"CTK_RPGD_NET_ONE_WAVE": "1"})):
+        out = str(tmp_path / f"{form}.npz")
+        env = {k: v for k, v in os.environ.items() if k not in ("CTK_RPGD_NET_ONE_WAVE", "CTK_RPGD_NO_PERSISTENT")}
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", script, str(N), str(H), str(p), str(its), str(K), out, envname], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[form] = np.load(out)
+    assert "ctk_g_rpgd_persist<" in str(outs["one_launch"]["kernel"]) and "true>" in str(outs["one_launch"]["kernel"]), outs["one_launch"]["kernel"]
+    assert "NetMlpWideT" in str(outs["one_wave"]["kernel"]), outs["one_wave"]["kernel"]
+    a, b = outs["one_launch"], outs["one_wave"]
+    tol = dict(rtol=2e-4, atol=2e-4)
+    assert_close_mostly(a["PLAN0"], b["PLAN0"], max_outliers=max(4, a["PLAN0"].size // 400), **tol)
+    assert_close_mostly(a["ADAM_M0"], b["ADAM_M0"], max_outliers=max(4, a["PLAN0"].size // 400), **tol)
+    assert_close_mostly(a["ADAM_V0"], b["ADAM_V0"], max_outliers=max(4, a["PLAN0"].size // 400), rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(a["J0"], b["J0"], rtol=1e-3, atol=2e-3)
+    assert np.isfinite(a["PLAN1"]).all() and np.isfinite(a["J1"]).all()
