@@ -71,6 +71,13 @@ def build_environment(header_path: str, jobs: int = 8, verbose: bool = False):
                     raise RuntimeError(f"building the environment {name!r} from {header_path} failed (hipcc):\n{tail}")
                 if verbose:
                     print(r.stdout[-2000:])
+                # the objects are not needed again (another digest = another directory), and builds of this model against OLDER kernel
+                # sources can never be loaded again: drop both (best effort — another process may hold one of them open)
+                import shutil
+                shutil.rmtree(os.path.join(out_dir, "obj"), ignore_errors=True)
+                for other in os.listdir(_OUT):
+                    if other.startswith(name + "_") and os.path.join(_OUT, other) != out_dir:
+                        shutil.rmtree(os.path.join(_OUT, other), ignore_errors=True)
     return name, lib
 
 
