@@ -10,6 +10,10 @@
 //        get_action sorts (:342).  ODE: one thread per plan (wave 0 of the block), adjoint state in
 //        LDS.  MLP: 16 plans per wave on the fp32 matrix cores both ways, activations in an
 //        L2-resident global scratch.
+//   ctk_rpgd_mlp_wide + ctk_rpgd_mlp_jacobians   MLP predictor, small populations: the reverse sweep's sequential part shrunk to a
+//        4 x 5 product per step by forming all step Jacobians at once on the idle chip (a launch per phase);
+//   ctk_rpgd_mlp_persistent  the same work as ONE launch per MPC step (up to 512 plans, H <= 64): producers keep plans, Adam moments and
+//        weights for all iterations, resident Jacobian workers take (iteration, step, tile) tickets; DESIGN.md 2.5b.
 //   ctk_rpgd_warmstart       keep the best k (sorted), shift plans by shift_previous and moments by
 //        one, resample the rest at the inducing points, age bookkeeping, u = best plan's first
 //        input (:426,:449-516,:523).
