@@ -513,3 +513,38 @@ def test_rpgd_one_launch_descent_equals_the_phase_launches_bit_for_bit(tmp_path,
         if key != "kernel":
             assert np.array_equal(outs["one_launch"][key], outs["phases"][key]), key
             assert np.isfinite(outs["one_launch"][key]).all(), key
+
+
+def test_two_one_launch_descents_on_one_gpu_at_the_same_time():
+    """Two handles whose steps overlap on the GPU (two host threads, each handle its own stream): each one-launch descent asks for every CU's
+    LDS, so neither gets all its workers resident while the other runs — the ticket queue must drain with whatever is resident, nobody may
+    time out, and the results must be those of the same steps run one after the other."""
+    import threading
+    from control_toolkit_amd import CtkEngine
+    def make(seed):
+        e = CtkEngine("rpgd", "MLP", num_rollouts=256, mpc_horizon=50, dt=0.02, period_interpolation_inducing_points=10, outer_its=10, resamp_per=3,
+                      opt_keep_k=64, sampling_distribution=0, seed=seed)
+        e.set_predictor_weights((np.random.default_rng(seed).standard_normal(e.predictor_weight_count()) * 0.15).astype(np.float32))
+        e.reset()
+        return e
+    def run(e, steps, out):
+        s = np.array([0.05, 0.0, 2.9, 0.3], np.float32)
+        us = []
+        for t in range(steps):
+            us.append(np.asarray(e.step(s), np.float32).reshape(-1).copy())
+            s = (s + np.array([0.01, 0.02, -0.03, 0.01], np.float32)).astype(np.float32)
+        out.append((np.stack(us), e.read("PLAN").copy(), e.read("ADAM_M").copy()))
+    steps = 40
+    want = []
+    for seed in (1, 2):                                   # one after the other
+        e = make(seed); assert "ctk_rpgd_mlp_persistent" in e.dominant_kernel()
+        run(e, steps, want); e.close()
+    a, b = make(1), make(2)
+    got_a, got_b = [], []
+    ta, tb = threading.Thread(target=run, args=(a, steps, got_a)), threading.Thread(target=run, args=(b, steps, got_b))
+    ta.start(); tb.start(); ta.join(); tb.join()          # a CtkError in a thread leaves its list empty
+    a.close(); b.close()
+    assert got_a and got_b, "a step raised (hand-off time-out?) while the two descents shared the GPU"
+    for got, ref in ((got_a[0], want[0]), (got_b[0], want[1])):
+        for x, y in zip(got, ref):
+            np.testing.assert_array_equal(x, y)
