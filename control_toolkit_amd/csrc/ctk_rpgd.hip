@@ -795,7 +795,7 @@ __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_mlp_wide(RolloutArgs a, Env
 // ---- MLP, wide form as ONE launch per MPC step (round 4) ---------------------------------------------------------------------------
 // The phase launches above pay, per Adam iteration, a launch boundary, 2.2 us of reloads, the moments' round trip through memory and a
 // separate Jacobian launch (6 us for 1.8 us of matrix work).  Here the first `PB` workgroups are the producers of ctk_rpgd_mlp_wide —
-// two 16-plan tiles each, plans / moments / weights resident for all `iters` iterations — and the rest are Jacobian WORKERS that stay
+// one 16-plan tile each (RP_PT), plans / moments / weights resident for all `iters` iterations — and the rest are Jacobian WORKERS that stay
 // for the whole step too:
 //   forward pass  : each step's {state component, seq} (wave 0 of the pair) and {input, seq} (wave 1) go through to memory as one 8-byte
 //                   word per lane — value and sequence number in one store, so a reader that sees the number has the value (no flag, no
@@ -809,6 +809,8 @@ __global__ __launch_bounds__(RP_BLOCK) void ctk_rpgd_mlp_wide(RolloutArgs a, Env
 // Tiles never depend on each other (optimizer_rpgd.py:325); producers never wait for a worker that holds no ticket; every poll is
 // bounded (200 ms; then the error word, NaN records and a skipped update, as in ctk_net_split.hip).  seq = seq0 + iteration is unique per
 // launch and iteration (the host advances seq0 by 64 per launch, iters <= 63).
+constexpr int RP_PT = 1;                            // tiles per producer workgroup.  The phase launches hold two (four waves); one — two waves, whose
+                                                    // per-step barriers then couple nothing else — measured 693 against 706 us per MPC step at cfg4
 constexpr int RP_PBLOCK = RP_BLOCK;                // 4 waves, one per SIMD (five — a wave per tangent — put two on one SIMD: 1.4 us per job against 0.96)
 constexpr unsigned long long RP_POLL_TICKS = 20000000ull;   // 200 ms of the 100 MHz clock
 
@@ -940,7 +942,8 @@ __global__ __launch_bounds__(RP_PBLOCK) void ctk_rpgd_mlp_persistent(RolloutArgs
         }
         return;
     }
-    // ---------------------------------------------------------------------------------------------- a producer (two tiles)
+    // ---------------------------------------------------------------------------------------------- a producer (RP_PT tiles)
+    if (wave >= 2 * RP_PT) return;
     float* q_s = lds;                                   // [H][33]
     float* g_s = q_s + H * RP_WLD;                      // [H][33]
     float* sc_s = g_s + max(H * RP_WLD, 128);           // [32]
@@ -949,11 +952,11 @@ __global__ __launch_bounds__(RP_PBLOCK) void ctk_rpgd_mlp_persistent(RolloutArgs
     float* m_s = term_s + 128;                          // [H][33] Adam moments, resident for the step (registers would spill around the chain)
     float* v_s = m_s + H * RP_WLD;                      // [H][33]
     const int pair = wave >> 1, half = wave & 1;
-    const int row0 = blockIdx.x * RP_WTRAJ;
-    const int rows = min(RP_WTRAJ, a.N - row0);
+    const int row0 = blockIdx.x * (16 * RP_PT);
+    const int rows = min(16 * RP_PT, a.N - row0);
     const int total = rows * H;
     const size_t gbase = (size_t)row0 * H;
-    const int tile = blockIdx.x * RP_WTILES + pair;
+    const int tile = blockIdx.x * RP_PT + pair;
     const bool live = row0 + pair * CTK_MLP_TRAJ_PER_WAVE < a.N;     // wave-uniform: the tile holds at least one plan
     const int col = pair * CTK_MLP_TRAJ_PER_WAVE + c;
     const float uprev0 = uniform_u_prev0(a);
@@ -962,15 +965,15 @@ __global__ __launch_bounds__(RP_PBLOCK) void ctk_rpgd_mlp_persistent(RolloutArgs
         float q0[AB], mm0[AB], vv0[AB];
 #pragma unroll
         for (int j = 0; j < AB; ++j) {
-            const int i = t + j * RP_BLOCK;
+            const int i = t + j * (128 * RP_PT);
             q0[j] = i < total ? Q[gbase + i] : 0.0f;
             mm0[j] = 0.0f; vv0[j] = 0.0f;
             if (i < total && ad.rule != 2) { mm0[j] = m[gbase + i]; vv0[j] = v[gbase + i]; }
         }
 #pragma unroll
         for (int j = 0; j < AB; ++j) {
-            const int i = t + j * RP_BLOCK;
-            if (i < RP_WTRAJ * H) {
+            const int i = t + j * (128 * RP_PT);
+            if (i < 16 * RP_PT * H) {
                 const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;
                 q_s[h * RP_WLD + r] = q0[j]; m_s[h * RP_WLD + r] = mm0[j]; v_s[h * RP_WLD + r] = vv0[j];
             }
@@ -1101,7 +1104,7 @@ __global__ __launch_bounds__(RP_PBLOCK) void ctk_rpgd_mlp_persistent(RolloutArgs
     }
 #pragma unroll
     for (int j = 0; j < AB; ++j) {
-        const int i = t + j * RP_BLOCK;
+        const int i = t + j * (128 * RP_PT);
         if (i < total) {
             const int r = H >= 2 ? (int)__umulhi((uint32_t)i, a.p_magic) : i, h = i - r * H;
             Q[gbase + i] = q_s[h * RP_WLD + r];
@@ -1211,7 +1214,7 @@ hipError_t ctk_launch_rpgd_descent(hipStream_t st, int pred, const RolloutArgs& 
         // ONE launch: producers (two tiles each) + Jacobian workers that stay for all iterations (ctk_rpgd_mlp_persistent)
         static const int diag_step = getenv("CTK_DIAG_RPGD_WITHHOLD_FLAG") ? atoi(getenv("CTK_DIAG_RPGD_WITHHOLD_FLAG")) : -1;
         static std::atomic<int> diag_armed{diag_step >= 0 ? 1 : 0};
-        const int PB = wide_blocks(a.N), tiles = PB * RP_WTILES, live = (a.N + CTK_MLP_TRAJ_PER_WAVE - 1) / CTK_MLP_TRAJ_PER_WAVE;
+        const int PB = (a.N + 16 * RP_PT - 1) / (16 * RP_PT), tiles = PB * RP_PT, live = (a.N + CTK_MLP_TRAJ_PER_WAVE - 1) / CTK_MLP_TRAJ_PER_WAVE;
         const int per_it = live * a.H, W = std::min(240, per_it);
         if (pers->seq0 < 64u || pers->seq0 > 0xffffff00u) pers->seq0 = 64u;
         RpgdPersistK pk{pers->seq0, pers->ticket_base, pers->err_word, PB, live, diag_armed.exchange(0) ? diag_step : -1};
